@@ -1,0 +1,252 @@
+"""Generate the golden fixtures by running the UNMODIFIED reference functions
+(read-only import from /root/reference, see tests/ref_shim.py).  Build container only:
+
+    python tests/golden/make_golden.py
+
+Writes tests/golden/{kernel_vectors.npz,kernel_vectors.json,loop_traces.json,
+eos_pad.json,noise.npz,calibration.json}.  Only inputs/outputs are stored — no
+reference source.  Versions used are recorded in kernel_vectors.json.
+"""
+from __future__ import annotations
+
+import hashlib
+import json
+import os
+import sys
+
+import numpy as np
+import torch
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, os.path.dirname(HERE))            # tests/
+sys.path.insert(0, os.path.dirname(os.path.dirname(HERE)))  # repo root
+from golden.gen_inputs import DTYPES, logit_rows, to_bits  # noqa: E402
+from ref_shim import load_reference, run_reference  # noqa: E402
+from toy_lm import BankModel, ToyVLM, pope_like_ids  # noqa: E402
+
+ARGMAX_MN = lambda probs, num_samples=1, **kw: probs.argmax(-1, keepdim=True)  # noqa: E731
+MODE_KW = {1: {}, 2: {"use_dd_unk": True}, 3: {"use_dd": True, "use_dd_unk": True}}
+
+
+def kernel_cases():
+    cases = []
+
+    def add(**kw):
+        kw.setdefault("kind", "normal"); kw.setdefault("steps", 1); kw.setdefault("B", 3)
+        kw.setdefault("warp", {}); kw.setdefault("alpha", 1.0); kw.setdefault("beta", 0.1)
+        kw["seed"] = 1000 + len(cases)
+        cases.append(kw)
+
+    warps = [{}, {"temperature": 0.05}, {"temperature": 0.2}, {"top_k": 1}, {"top_k": 2}, {"top_k": 50},
+             {"top_p": 0.05}, {"top_p": 0.6}, {"top_p": 0.9}, {"top_p": 0.0},
+             {"temperature": 0.7, "top_k": 50, "top_p": 0.9}, {"temperature": 0.2, "top_k": 1}]
+    # small-V full grid (V=97 and an odd, non-multiple-of-8 V=1003)
+    for V in (97, 1003):
+        for dt in ("fp32", "fp16", "bf16"):
+            for n_in in (1, 2, 3):
+                for wi, w in enumerate(warps):
+                    for (a, b) in ((1.0, 0.1), (0.5, 0.2)):
+                        if n_in == 1 and (a, b) != (1.0, 0.1):
+                            continue
+                        if V == 1003 and (wi % 3 != (0 if n_in == 2 else 1) or (a, b) != (1.0, 0.1)):
+                            continue
+                        add(V=V, dtype=dt, n_in=n_in, warp=w, alpha=a, beta=b, steps=2)
+            for b in (1.0, 1e-6, 0.5):
+                add(V=V, dtype=dt, n_in=2, beta=b, warp={"temperature": 0.2})
+            for kind in ("flat", "vc_equal", "big", "one_left", "max_tie"):
+                add(V=V, dtype=dt, n_in=2, kind=kind, warp={"temperature": 0.2})
+                add(V=V, dtype=dt, n_in=3, kind=kind, warp={"top_p": 0.9}, alpha=0.5)
+                add(V=V, dtype=dt, n_in=2, kind=kind, warp={"top_k": 2})
+            add(V=V, dtype=dt, n_in=2, alpha=0.3, beta=0.37, warp={"temperature": 0.33})  # inexact scalars
+    # real vocab sizes (inputs regenerated from the seed; outputs stored sparsely)
+    for dt in ("fp16", "bf16"):
+        add(V=32000, dtype=dt, n_in=2, B=2, warp={"temperature": 0.2})                 # POPE config
+        add(V=32000, dtype=dt, n_in=3, B=2, warp={"top_p": 0.9})                       # LLaVA-Bench config
+        add(V=32000, dtype=dt, n_in=2, B=2, warp={"top_k": 1})
+        add(V=32000, dtype=dt, n_in=2, B=2, kind="flat", beta=0.2, warp={"temperature": 0.2, "top_k": 50})
+        add(V=32000, dtype=dt, n_in=1, B=2, warp={"temperature": 0.7, "top_k": 50})    # plain path
+        add(V=151936, dtype=dt, n_in=2, B=1, alpha=0.5, warp={"temperature": 0.2})     # Qwen vocab
+    add(V=32000, dtype="fp32", n_in=2, B=2, warp={"temperature": 0.2})
+    add(V=151936, dtype="bf16", n_in=3, B=1, kind="vc_equal", warp={"top_p": 0.6})
+    return cases
+
+
+def sparse_pack(t: torch.Tensor):
+    """finite entries as (flat index, bit pattern); everything else must be -inf."""
+    flat = t.reshape(-1)
+    fin = torch.isfinite(flat)
+    idx = torch.nonzero(fin).reshape(-1)
+    return idx.numpy().astype(np.int64), to_bits(flat[idx]), int((flat == -float("inf")).sum()), \
+        int(torch.isnan(flat).sum()), int((flat == float("inf")).sum())
+
+
+def gen_kernel_vectors():
+    arrays, manifest = {}, []
+    for ci, case in enumerate(kernel_cases()):
+        dt = DTYPES[case["dtype"]]
+        rows = logit_rows(case["seed"], case["B"], case["V"], dt, case["n_in"], case["kind"], case["steps"])
+        bank = [r for step in rows for r in step]
+        model = BankModel(bank)
+        ids = torch.ones(case["B"], 4, dtype=torch.long)
+        ids[:, 2] = -200
+        kw = dict(attention_mask=torch.ones_like(ids), cd_alpha=case["alpha"], cd_beta=case["beta"],
+                  **MODE_KW[case["n_in"]])
+        out = run_reference(model, ids, max_length=4 + case["steps"], warp=case["warp"], multinomial=ARGMAX_MN, **kw)
+        entry = dict(case)
+        entry["id"] = ci
+        entry["tokens"] = out.sequences[:, 4:].tolist()
+        dense = case["V"] <= 1003
+        entry["dense"] = dense
+        # inputs are never stored: tests regenerate them with gen_inputs.logit_rows(seed, ...)
+        for s, sc in enumerate(out.scores):
+            assert sc.dtype == dt
+            if dense:
+                arrays[f"c{ci}_s{s}_scores"] = to_bits(sc)
+            else:
+                idx, bits, n_neg, n_nan, n_pos = sparse_pack(sc)
+                if len(idx) > 4096:   # dense-finite rows: keep a strided sample
+                    keep = np.arange(0, len(idx), 61)
+                    entry.setdefault("strided", {})[str(s)] = 61
+                    idx, bits = idx[keep], bits[keep]
+                arrays[f"c{ci}_s{s}_idx"] = idx
+                arrays[f"c{ci}_s{s}_val"] = bits
+                entry.setdefault("counts", {})[str(s)] = [n_neg, n_nan, n_pos]
+            entry.setdefault("sha256", {})[str(s)] = hashlib.sha256(to_bits(sc).tobytes()).hexdigest()
+        manifest.append(entry)
+    # error behaviour: beta > 1 masks every token -> softmax NaN -> multinomial raises (vcd_sample.py:191-202)
+    rows = logit_rows(77, 1, 97, torch.float16, 2)[0]
+    ids = torch.ones(1, 4, dtype=torch.long)
+    try:
+        run_reference(BankModel(rows), ids, max_length=5, warp={}, attention_mask=torch.ones_like(ids),
+                      use_dd_unk=True, cd_alpha=1.0, cd_beta=2.0)
+        raised = None
+    except RuntimeError as e:
+        raised = type(e).__name__
+    import transformers
+    meta = {"torch": torch.__version__, "transformers": transformers.__version__, "numpy": np.__version__,
+            "all_masked_row_raises": raised, "cases": manifest}
+    np.savez_compressed(os.path.join(HERE, "kernel_vectors.npz"), **arrays)
+    with open(os.path.join(HERE, "kernel_vectors.json"), "w") as f:
+        json.dump(meta, f, indent=0)
+    print("kernel vectors:", len(manifest), "cases")
+
+
+def loop_kwargs(mode, ids, img, img_cd):
+    kw = dict(images=img, attention_mask=torch.ones_like(ids), use_cache=True, cd_alpha=1.0, cd_beta=0.1)
+    kw.update({"plain": {}, "cd": {"images_cd": img_cd}, "dd": {"use_dd": True}, "dd_unk": {"use_dd_unk": True},
+               "both": {"use_dd": True, "use_dd_unk": True}}[mode])
+    return kw
+
+
+def gen_loop_traces():
+    """32 POPE-like prompts, toy LM, TopK(1), 8 new tokens; 5 modes."""
+    traces = []
+    g = torch.Generator().manual_seed(7)
+    for dt in ("fp32", "fp16", "bf16"):
+        for mode in ("plain", "cd", "dd", "dd_unk", "both"):
+            rng = np.random.default_rng(1234)
+            n_q = 32 if (mode == "dd" and dt == "fp16") else 4
+            for q in range(n_q):
+                ids = pope_like_ids(rng, vocab=97)
+                img = torch.randn(1, 3, 2, 2, generator=g)
+                img_cd = img * 0.5 + torch.randn(1, 3, 2, 2, generator=g)
+                model = ToyVLM(logit_dtype=DTYPES[dt])
+                out = run_reference(model, ids.clone(), max_length=ids.shape[1] + 8, warp={"top_k": 1},
+                                    multinomial=ARGMAX_MN, **loop_kwargs(mode, ids, img, img_cd))
+                traces.append({"dtype": dt, "mode": mode, "q": q, "ids": ids.tolist(), "img": img.tolist(),
+                               "img_cd": img_cd.tolist(), "tokens": out.sequences[:, ids.shape[1]:].tolist(),
+                               "schedule": [list(map(lambda x: list(x) if isinstance(x, tuple) else x, c)) for c in model.calls],
+                               "score_sha256": [hashlib.sha256(to_bits(s).tobytes()).hexdigest() for s in out.scores]})
+    with open(os.path.join(HERE, "loop_traces.json"), "w") as f:
+        json.dump(traces, f)
+    print("loop traces:", len(traces))
+
+
+def gen_eos_pad():
+    """vcd_sample.py:257-299: pad after EOS, multi-EOS product, stop when all rows finished."""
+    cases = []
+    V = 50
+    for eos, plan in (([2], [[7, 2, 9, 9, 9], [7, 8, 9, 2, 9], [7, 8, 9, 10, 11]]),
+                      ([2, 5], [[5, 9, 9, 9, 9], [7, 2, 9, 9, 9], [7, 8, 2, 9, 9]]),
+                      (2, [[7, 2, 9, 9, 9]])):
+        plan_t = torch.tensor(plan)
+        B, S = plan_t.shape
+        bank = []
+        for s in range(S):
+            for _branch in range(2):
+                row = torch.zeros(B, V, dtype=torch.float16)
+                row[torch.arange(B), plan_t[:, s]] = 9.0
+                bank.append(row)
+        ids = torch.ones(B, 4, dtype=torch.long)
+        out = run_reference(BankModel(bank), ids, max_length=4 + S, warp={"top_k": 1}, pad=0, eos=eos,
+                            multinomial=ARGMAX_MN, attention_mask=torch.ones_like(ids), use_dd_unk=True,
+                            cd_alpha=1.0, cd_beta=0.1)
+        cases.append({"eos": eos, "pad": 0, "plan": plan, "V": V, "sequences": out.sequences.tolist(),
+                      "n_scores": len(out.scores)})
+    # eos without pad -> ValueError (vcd_sample.py:258-259)
+    try:
+        run_reference(BankModel(bank, pad=None), ids, max_length=6, warp={"top_k": 1}, pad=None, eos=2,
+                      multinomial=ARGMAX_MN, attention_mask=torch.ones_like(ids), use_dd_unk=True)
+        err = None
+    except ValueError as e:
+        err = str(e)
+    with open(os.path.join(HERE, "eos_pad.json"), "w") as f:
+        json.dump({"cases": cases, "eos_without_pad_error": err}, f)
+    print("eos/pad:", len(cases))
+
+
+def gen_noise():
+    ref = load_reference()
+    arrays = {}
+    for t in (0, 1, 500, 999):
+        torch.manual_seed(100 + t)
+        x = torch.randn(3, 6, 5)
+        torch.manual_seed(200 + t)
+        y = ref.add_diffusion_noise(x, t)
+        arrays[f"x_{t}"] = x.numpy()
+        arrays[f"y_{t}"] = y.numpy()
+    np.savez(os.path.join(HERE, "noise.npz"), **arrays)
+    print("noise: ok")
+
+
+class FakeTok:
+    """token id -> string with case/space collisions, for metrics.calibrate_label_dict."""
+    TABLE = {0: "<unk>", 1: "Yes", 2: " yes", 3: "No", 4: "no ", 5: "YES", 6: "maybe"}
+
+    def decode(self, i):
+        return self.TABLE.get(int(i), f"t{int(i)}")
+
+
+def gen_calibration():
+    ref = load_reference()
+    out = {"label_dict": [], "affine": []}
+    rng = np.random.default_rng(5)
+    for dt in ("fp16", "bf16", "fp32"):
+        for trial in range(3):
+            row = torch.from_numpy(rng.standard_normal((1, 40), dtype=np.float32) * 3).to(DTYPES[dt])
+            row[0, rng.integers(0, 7)] += 6
+            d = ref.metrics.calibrate_label_dict(row, FakeTok())
+            p = ref.metrics.get_prob_from_logits(d)
+            out["label_dict"].append({"dtype": dt, "row_bits": to_bits(row).tolist(), "dict": d, "p": p})
+    for mode in ("diagonal_W", "identity_W"):
+        probs = rng.random((6, 2))
+        p_cf = rng.random(2) * 0.5 + 0.1
+        labels = rng.integers(0, 2, size=6)
+        acc, cal = ref.metrics.eval_accuracy(probs, labels, mode=mode, p_cf=p_cf)
+        out["affine"].append({"mode": mode, "probs": probs.tolist(), "p_cf": p_cf.tolist(), "labels": labels.tolist(),
+                              "acc": float(acc), "calibrated": [c.reshape(-1).tolist() for c in cal]})
+    acc, cal = ref.metrics.eval_accuracy(probs, labels)
+    out["affine"].append({"mode": None, "probs": probs.tolist(), "p_cf": None, "labels": labels.tolist(),
+                          "acc": float(acc), "calibrated": [c.reshape(-1).tolist() for c in cal]})
+    with open(os.path.join(HERE, "calibration.json"), "w") as f:
+        json.dump(out, f)
+    print("calibration: ok")
+
+
+if __name__ == "__main__":
+    torch.set_num_threads(8)
+    gen_kernel_vectors()
+    gen_loop_traces()
+    gen_eos_pad()
+    gen_noise()
+    gen_calibration()
