@@ -1,0 +1,121 @@
+/*
+ * vdd_hip.h — C ABI of the MI355X-native visual-contrastive-decoding core (libvdd_hip.so).
+ *
+ * Drop-in boundary for the hot path of yfzhang114/LLaVA-Align (reference paths are
+ * relative to that repo).  The reference is pure Python with no FFI, so these entry
+ * points are what a maintainer would bind (ctypes stub: INTEGRATION.md) to replace:
+ *
+ *   vdd_add_diffusion_noise  vcd_utils/vcd_add_noise.py:18-22 (q(x_t | x_0) of the noisy-image branch)
+ *   vdd_contrast_sample      vcd_utils/vcd_sample.py:185-207,257-260,285-288
+ *                            (both-branch average, contrast, adaptive-plausibility
+ *                             mask, HF temperature/top-k/top-p warpers, softmax,
+ *                             multinomial, pad-after-EOS, unfinished update) and
+ *                            experiments/utils/metrics.py:102-104 (softmax -> top-k
+ *                             probabilities of the step-0 scores row).
+ *
+ * Conventions: plain pointers and sizes only (no torch types); every pointer is a
+ * DEVICE pointer owned by the caller unless stated otherwise; the library never
+ * allocates, frees or synchronises; all work is enqueued on the given hipStream_t
+ * (passed as void*); functions return 0 on success or a negative vdd_status code and
+ * never throw or exit.  Re-entrant; no global mutable state.
+ */
+#ifndef VDD_HIP_H
+#define VDD_HIP_H
+
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define VDD_ABI_VERSION 1
+
+typedef enum vdd_status {
+    VDD_OK = 0,
+    VDD_ERR_INVALID_ARG = -1,   /* null/negative/misaligned argument, see vdd_last_error() */
+    VDD_ERR_UNSUPPORTED = -2,   /* reserved */
+    VDD_ERR_LAUNCH = -3         /* hipLaunchKernel failed */
+} vdd_status;
+
+typedef enum vdd_dtype { VDD_F32 = 0, VDD_F16 = 1, VDD_BF16 = 2 } vdd_dtype;
+
+/* flags */
+#define VDD_PICK_ARGMAX        (1u << 0) /* token = first index of the row maximum of the final scores
+                                            (deterministic stand-in for multinomial when one survivor) */
+#define VDD_CUTOFF_F32_SCALAR  (1u << 1) /* cutoff = fl(max + log_beta) with log_beta kept in fp32 (torch-GPU
+                                            CPU-scalar path); default demotes log_beta to dtype first
+                                            (torch-CPU, what the golden vectors pin) */
+#define VDD_TEMP_RECIPROCAL    (1u << 2) /* scores * (1/T) (torch-GPU div-by-scalar) instead of scores / T */
+#define VDD_NO_SAMPLE          (1u << 3) /* only produce scores_out (used when a Python logits_processor
+                                            must run between contrast and warp) */
+
+/* row_status values */
+#define VDD_ROW_OK 0
+#define VDD_ROW_EMPTY 1   /* no finite score left or NaN present: the reference's torch.multinomial raises */
+
+typedef struct vdd_sample_params {
+    uint32_t abi_version;        /* = VDD_ABI_VERSION */
+    uint32_t flags;
+    /* ---- inputs: last-position logits of each branch, row-major [B, V] ---- */
+    const void* logit_v;         /* main (image) branch                       vcd_sample.py:119 */
+    const void* logit_cd;        /* <unk> / noisy-image branch, NULL = plain path      :169    */
+    const void* logit_dd;        /* image-token-dropped branch, NULL unless both modes :184    */
+    int64_t stride_v, stride_cd, stride_dd;   /* row strides in ELEMENTS */
+    int32_t B, V;
+    int32_t dtype;               /* vdd_dtype: the model dtype; all arithmetic is rounded in it */
+    int32_t min_keep;            /* HF min_tokens_to_keep (>=1) */
+    double alpha;                /* cd_alpha                                           :188    */
+    double log_beta;             /* fp32 value of log(cd_beta) as torch.log(torch.tensor(beta)) :191 */
+    double temperature;          /* <=0 or ==1: no temperature warper */
+    double top_p;                /* >=1 or <0: no top-p warper */
+    int32_t top_k;               /* <=0: no top-k warper */
+    int32_t n_eos;
+    /* ---- sampling ---- */
+    uint64_t philox_seed, philox_offset;   /* u_row = philox4x32-10(seed; offset, row) */
+    const float* uniforms;       /* optional [B]: explicit u in [0,1) overriding philox */
+    /* ---- EOS / pad bookkeeping (vcd_sample.py:257-260,285-288) ---- */
+    const int64_t* eos_ids;      /* [n_eos] or NULL */
+    int64_t pad_id;              /* used iff unfinished != NULL && n_eos > 0 */
+    int64_t* unfinished;         /* optional in/out [B] (1 = still generating) */
+    /* ---- outputs ---- */
+    int64_t* next_tokens;        /* [B] (may be NULL iff VDD_NO_SAMPLE); row r at next_tokens[r*stride_tokens] */
+    int64_t stride_tokens;       /* >=1; lets the caller point at column `cur_len` of its [B, max_len] id buffer */
+    void* scores_out;            /* optional [B, V] dtype: post-warp scores (what output_scores returns) */
+    int64_t stride_scores;
+    float* top_prob;             /* optional [B, n_top] softmax(scores) top-n, descending */
+    int64_t* top_tok;            /* optional [B, n_top] */
+    int32_t n_top;               /* <= 16 */
+    int32_t _pad0;
+    int32_t* row_status;         /* optional [B] */
+    /* ---- scratch ---- */
+    void* workspace;             /* optional [B, V] dtype: working row for V > vdd_lds_row_capacity(dtype)
+                                    when scores_out is NULL (rows that fit LDS never touch it) */
+    int64_t stride_workspace;
+} vdd_sample_params;
+
+/* Fused per-step contrastive sampling tail; one launch for all B rows. */
+int vdd_contrast_sample(const vdd_sample_params* p, void* hip_stream);
+
+/* VCD branch input: x_t = sqrt(abar_t) x_0 + sqrt(1-abar_t) eps   (vcd_utils/vcd_add_noise.py:18-22).
+ * x, y: n elements of `dtype` (may alias).  eps: optional explicit fp32 noise [n]; NULL draws
+ * N(0,1) from philox4x32-10(seed; offset + i/4) + Box-Muller.  The two scalars are row t of the
+ * reference's sigmoid schedule (:7-16), tabulated by the host. */
+int vdd_add_diffusion_noise(const void* x, void* y, int64_t n, int dtype, float sqrt_abar,
+                            float sqrt_one_minus_abar, const float* eps, uint64_t seed,
+                            uint64_t offset, void* hip_stream);
+
+/* Largest V whose working row stays in LDS; larger V need scores_out or workspace. */
+int vdd_lds_row_capacity(int dtype);
+
+/* Name of the dominant kernel symbol launched for (dtype, V) — for matching rocprof rows. */
+const char* vdd_kernel_name(int dtype, int V);
+
+int vdd_abi_version(void);
+
+/* Thread-local description of the last non-zero status returned on this thread. */
+const char* vdd_last_error(void);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* VDD_HIP_H */

@@ -1,0 +1,735 @@
+// Fused visual-contrastive-decoding sampling tail for gfx950 (MI355X, wave64).
+//
+// One launch replaces the ~15 eager kernels + 2 host syncs of the reference per decode
+// step (vcd_utils/vcd_sample.py:185-207,257-260,285-288):
+//
+//   c   = fl(fl(c+d)/2)                         both-branch average            (:185)
+//   cut = fl(max_j v_j + log beta)              adaptive-plausibility cutoff   (:191)
+//   x   = fl(fl((1+a) v) - fl(a c)) ; x[v<cut] = -inf                          (:193-194)
+//   x   = fl(x / T) ; top-k ; top-p             HF warpers                     (:198)
+//   tok ~ softmax(x)                            multinomial                    (:201-202)
+//   tok = tok*unfinished + pad*(1-unfinished) ; unfinished *= (tok not in eos) (:260,:286)
+//
+// fl() = round-to-nearest-even into the MODEL dtype after every torch op, exactly as
+// eager torch does, so the scores row is bit-identical to the reference's.
+//
+// Mapping: one 1024-thread workgroup (16 waves) per row; the row is cut into 16-byte
+// chunks and chunk ch belongs to thread ch % 1024 in EVERY pass, so a wave reads 1 KiB
+// contiguous per load and no pass ever reads another thread's chunk (no data barriers,
+// only the 16-entry reduction exchanges).  The working row lives in LDS (V=32000 bf16 =
+// 62.5 KiB -> two workgroups per CU, 2048 threads); v is read from HBM once, c/d once,
+// scores written once: HBM traffic = the algorithmic (n_in + n_out) * V * sizeof(dtype)
+// bytes per row.  Rows too large for LDS (Qwen, V=151936) keep the working row in the
+// caller's scores/workspace buffer instead (re-reads served by L2 / Infinity Cache).
+// Every later pass (softmax statistics, radix threshold selection for top-k / top-p,
+// inverse-CDF sampling, top-n extraction) runs over the LDS row.
+//
+// Roofline: HBM-bound; nothing here is a contraction, so no MFMA.
+
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+#include <string.h>
+#include <stdio.h>
+
+#include "vdd_hip.h"
+
+namespace {
+
+constexpr int BLOCK = 1024;
+constexpr int NWAVE = BLOCK / 64;
+constexpr int UNR = 4;                   // chunks in flight per thread per batch
+constexpr int LDS_ROW_BYTES_MAX = 150 * 1024;
+
+// ------------------------------------------------------------------ dtype traits
+template <int DT> struct Tr;
+template <> struct Tr<VDD_F16> {
+    using bits_t = uint16_t;
+    static constexpr int KEYBITS = 16, EPC = 8;
+    static __device__ __forceinline__ float to_f(uint32_t b) { return (float)__builtin_bit_cast(_Float16, (uint16_t)b); }
+    static __device__ __forceinline__ uint32_t from_f(float f) { return __builtin_bit_cast(uint16_t, (_Float16)f); }
+    static constexpr uint32_t NEG_INF = 0xFC00u;
+};
+template <> struct Tr<VDD_BF16> {
+    using bits_t = uint16_t;
+    static constexpr int KEYBITS = 16, EPC = 8;
+    static __device__ __forceinline__ float to_f(uint32_t b) { return __builtin_bit_cast(float, b << 16); }
+    static __device__ __forceinline__ uint32_t from_f(float f) {
+        uint32_t u = __builtin_bit_cast(uint32_t, f);
+        if ((u & 0x7fffffffu) > 0x7f800000u) return (u >> 16) | 0x40u;   // quiet NaN
+        return (u + 0x7fffu + ((u >> 16) & 1u)) >> 16;                    // RNE
+    }
+    static constexpr uint32_t NEG_INF = 0xFF80u;
+};
+template <> struct Tr<VDD_F32> {
+    using bits_t = uint32_t;
+    static constexpr int KEYBITS = 32, EPC = 4;
+    static __device__ __forceinline__ float to_f(uint32_t b) { return __builtin_bit_cast(float, b); }
+    static __device__ __forceinline__ uint32_t from_f(float f) { return __builtin_bit_cast(uint32_t, f); }
+    static constexpr uint32_t NEG_INF = 0xFF800000u;
+};
+
+template <int DT> __device__ __forceinline__ float rnd(float f) { return Tr<DT>::to_f(Tr<DT>::from_f(f)); }
+
+// order-preserving key: larger float <=> larger unsigned key
+template <int DT> __device__ __forceinline__ uint32_t okey(uint32_t b) {
+    if constexpr (Tr<DT>::KEYBITS == 16) return (b & 0x8000u) ? (~b & 0xFFFFu) : (b | 0x8000u);
+    else return (b & 0x80000000u) ? ~b : (b | 0x80000000u);
+}
+
+template <int DT> __device__ __forceinline__ uint32_t getb(const uint32_t* w, int j) {
+    if constexpr (Tr<DT>::KEYBITS == 16) return (w[j >> 1] >> ((j & 1) * 16)) & 0xFFFFu;
+    else return w[j];
+}
+template <int DT> __device__ __forceinline__ void setb(uint32_t* w, int j, uint32_t b) {
+    if constexpr (Tr<DT>::KEYBITS == 16) {
+        if (j & 1) w[j >> 1] = (w[j >> 1] & 0x0000FFFFu) | (b << 16);
+        else w[j >> 1] = (w[j >> 1] & 0xFFFF0000u) | (b & 0xFFFFu);
+    } else w[j] = b;
+}
+
+// ------------------------------------------------------------------ kernel params (by value)
+struct KP {
+    const void* v; const void* c; const void* d;
+    long long sv, sc, sd, ss, sw, st;
+    int B, V;
+    unsigned flags;
+    int min_keep, top_k, n_eos, n_top;
+    float s1, s2, log_beta, temp, inv_temp, one_minus_p;   // s1 = 1+alpha, s2 = alpha (fp32 scalars, as torch passes them)
+    int use_temp, use_topp;
+    unsigned long long seed, offset;
+    const float* uniforms;
+    const long long* eos;
+    long long pad;
+    long long* unfinished;
+    long long* next_tokens;
+    void* scores;      // optional output
+    void* work;        // global working row (== scores when given) — only used when the row does not fit LDS
+    float* top_prob; long long* top_tok;
+    int* status;
+    int vec_in, vec_out, vec_work;   // 16-B aligned fast paths usable
+};
+
+// ------------------------------------------------------------------ block collectives
+struct Smem {
+    float f[2][NWAVE];
+    int i[2][NWAVE];
+    unsigned hist[4][256];     // 4 copies (wave & 3) to thin same-address atomic contention
+    float histf[4][256];
+    unsigned sel[4];
+    float self[2];
+};
+
+__device__ __forceinline__ float wave_max(float v) {
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) v = fmaxf(v, __shfl_xor(v, o));
+    return v;
+}
+__device__ __forceinline__ float wave_sum(float v) {
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o);
+    return v;
+}
+__device__ __forceinline__ int wave_sumi(int v) {
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o);
+    return v;
+}
+
+// max and two integer sums in one exchange
+__device__ __forceinline__ void block_max_count2(float& m, int& c0, int& c1, Smem& sm, int lane, int wave) {
+    m = wave_max(m); c0 = wave_sumi(c0); c1 = wave_sumi(c1);
+    if (lane == 0) { sm.f[0][wave] = m; sm.i[0][wave] = c0; sm.i[1][wave] = c1; }
+    __syncthreads();
+    float mm = sm.f[0][0]; int a = sm.i[0][0], b = sm.i[1][0];
+#pragma unroll
+    for (int w = 1; w < NWAVE; ++w) { mm = fmaxf(mm, sm.f[0][w]); a += sm.i[0][w]; b += sm.i[1][w]; }
+    __syncthreads();
+    m = mm; c0 = a; c1 = b;
+}
+__device__ __forceinline__ float block_sum(float v, Smem& sm, int lane, int wave) {
+    v = wave_sum(v);
+    if (lane == 0) sm.f[1][wave] = v;
+    __syncthreads();
+    float s = sm.f[1][0];
+#pragma unroll
+    for (int w = 1; w < NWAVE; ++w) s += sm.f[1][w];
+    __syncthreads();
+    return s;
+}
+
+// philox4x32-10, returns a 24-bit uniform in [0,1)
+__device__ __forceinline__ float philox_uniform(unsigned long long seed, unsigned long long offset, unsigned row) {
+    uint32_t c0 = (uint32_t)offset, c1 = (uint32_t)(offset >> 32), c2 = row, c3 = 0;
+    uint32_t k0 = (uint32_t)seed, k1 = (uint32_t)(seed >> 32);
+#pragma unroll
+    for (int r = 0; r < 10; ++r) {
+        unsigned long long p0 = (unsigned long long)0xD2511F53u * c0;
+        unsigned long long p1 = (unsigned long long)0xCD9E8D57u * c2;
+        uint32_t n0 = (uint32_t)(p1 >> 32) ^ c1 ^ k0, n1 = (uint32_t)p1;
+        uint32_t n2 = (uint32_t)(p0 >> 32) ^ c3 ^ k1, n3 = (uint32_t)p0;
+        c0 = n0; c1 = n1; c2 = n2; c3 = n3;
+        k0 += 0x9E3779B9u; k1 += 0xBB67AE85u;
+    }
+    return (float)(c0 >> 8) * (1.0f / 16777216.0f);
+}
+
+// ------------------------------------------------------------------ chunk loads / stores (global)
+// A chunk is 16 bytes = EPC elements held as 4 packed words.
+template <int DT>
+__device__ __forceinline__ void gload(const void* base, long long row_off, int ch, int V, int vec, uint32_t* w) {
+    using B = typename Tr<DT>::bits_t;
+    constexpr int EPC = Tr<DT>::EPC;
+    const B* p = reinterpret_cast<const B*>(base) + row_off;
+    const int idx0 = ch * EPC;
+    if (vec && idx0 + EPC <= V) {
+        uint4 a = *reinterpret_cast<const uint4*>(p + idx0);
+        w[0] = a.x; w[1] = a.y; w[2] = a.z; w[3] = a.w;
+    } else {
+        w[0] = w[1] = w[2] = w[3] = 0;
+#pragma unroll
+        for (int j = 0; j < EPC; ++j) {
+            uint32_t b = (idx0 + j < V) ? (uint32_t)p[idx0 + j] : Tr<DT>::NEG_INF;
+            setb<DT>(w, j, b);
+        }
+    }
+}
+template <int DT>
+__device__ __forceinline__ void gstore(void* base, long long row_off, int ch, int V, int vec, const uint32_t* w) {
+    using B = typename Tr<DT>::bits_t;
+    constexpr int EPC = Tr<DT>::EPC;
+    B* p = reinterpret_cast<B*>(base) + row_off;
+    const int idx0 = ch * EPC;
+    if (vec && idx0 + EPC <= V) {
+        *reinterpret_cast<uint4*>(p + idx0) = make_uint4(w[0], w[1], w[2], w[3]);
+    } else {
+#pragma unroll
+        for (int j = 0; j < EPC; ++j) if (idx0 + j < V) p[idx0 + j] = (B)getb<DT>(w, j);
+    }
+}
+
+// The working row: LDS (one uint4 per chunk) or the caller's global buffer.
+template <int DT, bool LDSROW>
+struct Row {
+    uint4* lds; void* g; long long goff; int V; int vec;
+    __device__ __forceinline__ void get(int ch, uint32_t* w) const {
+        if constexpr (LDSROW) { uint4 a = lds[ch]; w[0] = a.x; w[1] = a.y; w[2] = a.z; w[3] = a.w; }
+        else gload<DT>(g, goff, ch, V, vec, w);
+    }
+    __device__ __forceinline__ void put(int ch, const uint32_t* w) const {
+        if constexpr (LDSROW) lds[ch] = make_uint4(w[0], w[1], w[2], w[3]);
+        else gstore<DT>(g, goff, ch, V, vec, w);
+    }
+};
+
+// ------------------------------------------------------------------ radix threshold selection
+// Count-based: ordered key of the k-th largest among finite entries (k <= #finite).
+template <int DT, bool L>
+__device__ __forceinline__ uint32_t select_kth_key(const Row<DT, L>& R, int nch, unsigned k, Smem& sm, int tid, int lane, int wave) {
+    constexpr int KB = Tr<DT>::KEYBITS, EPC = Tr<DT>::EPC;
+    uint32_t prefix = 0, pmask = 0;
+    unsigned rem = k;
+    for (int shift = KB - 8; shift >= 0; shift -= 8) {
+        sm.hist[tid >> 8][tid & 255] = 0;
+        __syncthreads();
+        unsigned* h = sm.hist[wave & 3];
+        for (int ch = tid; ch < nch; ch += BLOCK) {
+            uint32_t w[4]; R.get(ch, w);
+#pragma unroll
+            for (int j = 0; j < EPC; ++j) {
+                uint32_t b = getb<DT>(w, j);
+                if (b != Tr<DT>::NEG_INF) {
+                    uint32_t key = okey<DT>(b);
+                    if ((key & pmask) == prefix) atomicAdd(&h[(key >> shift) & 0xFFu], 1u);
+                }
+            }
+        }
+        __syncthreads();
+        if (wave == 0) {
+            unsigned c[4];
+#pragma unroll
+            for (int q = 0; q < 4; ++q) { int bin = 4 * lane + q; c[q] = sm.hist[0][bin] + sm.hist[1][bin] + sm.hist[2][bin] + sm.hist[3][bin]; }
+            unsigned loc = c[0] + c[1] + c[2] + c[3];
+            unsigned suf = loc;   // inclusive suffix sum over lanes >= lane
+#pragma unroll
+            for (int o = 1; o < 64; o <<= 1) { unsigned t = __shfl_down(suf, o); if (lane + o < 64) suf += t; }
+            unsigned above = suf - loc;
+            if (above < rem && rem <= suf) {
+                unsigned a = above; bool done = false;
+#pragma unroll
+                for (int q = 3; q >= 0; --q) {
+                    if (!done) {
+                        if (a + c[q] >= rem) { sm.sel[0] = 4 * lane + q; sm.sel[1] = rem - a; done = true; }
+                        else a += c[q];
+                    }
+                }
+            }
+        }
+        __syncthreads();
+        prefix |= sm.sel[0] << shift;
+        pmask |= 0xFFu << shift;
+        rem = sm.sel[1];
+        __syncthreads();
+    }
+    return prefix;
+}
+
+// Mass-based, ascending: smallest key K such that mass(key <= K) > thr.  Entries with
+// key < K are the ones HF's TopPLogitsWarper removes (cum <= 1-p).  Returns false if the
+// whole row's mass never exceeds thr (then only min_keep survive).
+template <int DT, bool L>
+__device__ __forceinline__ bool select_mass_key(const Row<DT, L>& R, int nch, float m, float thr, Smem& sm,
+                                                int tid, int lane, int wave, uint32_t& out_key) {
+    constexpr int KB = Tr<DT>::KEYBITS, EPC = Tr<DT>::EPC;
+    uint32_t prefix = 0, pmask = 0;
+    float below = 0.f;
+    bool ok = true;
+    for (int shift = KB - 8; shift >= 0; shift -= 8) {
+        sm.histf[tid >> 8][tid & 255] = 0.f;
+        __syncthreads();
+        float* h = sm.histf[wave & 3];
+        for (int ch = tid; ch < nch; ch += BLOCK) {
+            uint32_t w[4]; R.get(ch, w);
+#pragma unroll
+            for (int j = 0; j < EPC; ++j) {
+                uint32_t b = getb<DT>(w, j);
+                if (b != Tr<DT>::NEG_INF) {
+                    uint32_t key = okey<DT>(b);
+                    if ((key & pmask) == prefix) atomicAdd(&h[(key >> shift) & 0xFFu], __expf(Tr<DT>::to_f(b) - m));
+                }
+            }
+        }
+        __syncthreads();
+        if (wave == 0) {
+            float c[4];
+#pragma unroll
+            for (int q = 0; q < 4; ++q) { int bin = 4 * lane + q; c[q] = (sm.histf[0][bin] + sm.histf[1][bin]) + (sm.histf[2][bin] + sm.histf[3][bin]); }
+            float loc = (c[0] + c[1]) + (c[2] + c[3]);
+            float pre = loc;   // inclusive prefix over lanes <= lane
+#pragma unroll
+            for (int o = 1; o < 64; o <<= 1) { float t = __shfl_up(pre, o); if (lane >= o) pre += t; }
+            unsigned long long cross = __ballot(below + pre > thr);
+            unsigned long long nonempty = __ballot(loc > 0.f);
+            int hit_lane;
+            if (cross) hit_lane = __ffsll((long long)cross) - 1;
+            else if (shift == KB - 8) hit_lane = -1;                               // whole row below thr
+            else hit_lane = nonempty ? 63 - __clzll((long long)nonempty) : -1;     // association fuzz: top non-empty
+            if (hit_lane < 0) { if (lane == 0) sm.sel[2] = 0; }
+            else if (lane == hit_lane) {
+                float a = below + (pre - loc);
+                int bin = -1;
+#pragma unroll
+                for (int q = 0; q < 4; ++q) {
+                    if (bin < 0) { if (a + c[q] > thr) bin = q; else a += c[q]; }
+                }
+                if (bin < 0) {            // fuzz: take the highest non-empty bin of this lane
+                    a = below + (pre - loc);
+                    bin = 0;
+#pragma unroll
+                    for (int q = 0; q < 4; ++q) if (c[q] > 0.f) bin = q;
+#pragma unroll
+                    for (int q = 0; q < 4; ++q) if (q < bin) a += c[q];
+                }
+                sm.sel[0] = 4 * lane + bin; sm.self[0] = a; sm.sel[2] = 1;
+            }
+        }
+        __syncthreads();
+        ok = sm.sel[2] != 0;
+        uint32_t bin = sm.sel[0]; float nb = sm.self[0];
+        __syncthreads();
+        if (!ok) break;
+        prefix |= bin << shift;
+        pmask |= 0xFFu << shift;
+        below = nb;
+    }
+    out_key = prefix;
+    return ok;
+}
+
+template <int DT, bool L>
+__device__ __forceinline__ void mask_below_key(const Row<DT, L>& R, int nch, uint32_t thr_key, int tid) {
+    constexpr int EPC = Tr<DT>::EPC;
+    for (int ch = tid; ch < nch; ch += BLOCK) {
+        uint32_t w[4]; R.get(ch, w);
+        bool changed = false;
+#pragma unroll
+        for (int j = 0; j < EPC; ++j) {
+            uint32_t b = getb<DT>(w, j);
+            if (b != Tr<DT>::NEG_INF && okey<DT>(b) < thr_key) { setb<DT>(w, j, Tr<DT>::NEG_INF); changed = true; }
+        }
+        if (changed) R.put(ch, w);
+    }
+}
+
+// ------------------------------------------------------------------ the kernel
+template <int DT, bool LDSROW>
+__global__ void __launch_bounds__(BLOCK) vdd_contrast_sample_kernel(KP p) {
+    constexpr int EPC = Tr<DT>::EPC;
+    constexpr uint32_t NINF = Tr<DT>::NEG_INF;
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int row = blockIdx.x;
+    const int V = p.V;
+    const int nch = (V + EPC - 1) / EPC;
+    Smem& sm = *reinterpret_cast<Smem*>(smem_raw + (LDSROW ? (size_t)nch * 16 : 0));
+    Row<DT, LDSROW> R{reinterpret_cast<uint4*>(smem_raw), p.work, (long long)row * p.sw, V, p.vec_work};
+    const long long ov = (long long)row * p.sv, oc = (long long)row * p.sc, od = (long long)row * p.sd;
+
+    float m = -INFINITY; int nfin = 0; int t_nan = 0, t_pinf = 0;
+    const bool recip = (p.flags & VDD_TEMP_RECIPROCAL) != 0;
+
+    if (p.c != nullptr) {
+        // ---- pass A: v -> working row, row max (vcd_sample.py:191) --------------------
+        float vmax = -INFINITY; int vnan = 0, zero = 0;
+        for (int base = tid; base < nch; base += UNR * BLOCK) {
+            uint32_t q[UNR][4];
+#pragma unroll
+            for (int u = 0; u < UNR; ++u) { const int ch = base + u * BLOCK; if (ch < nch) gload<DT>(p.v, ov, ch, V, p.vec_in, q[u]); }
+#pragma unroll
+            for (int u = 0; u < UNR; ++u) {
+                const int ch = base + u * BLOCK;
+                if (ch < nch) {
+                    if constexpr (LDSROW) R.put(ch, q[u]);
+#pragma unroll
+                    for (int j = 0; j < EPC; ++j) { float f = Tr<DT>::to_f(getb<DT>(q[u], j)); vnan |= (f != f) ? 1 : 0; vmax = fmaxf(vmax, f); }
+                }
+            }
+        }
+        block_max_count2(vmax, vnan, zero, sm, lane, wave);
+        t_nan = vnan ? 1 : 0;
+        const float lb = (p.flags & VDD_CUTOFF_F32_SCALAR) ? p.log_beta : rnd<DT>(p.log_beta);
+        const float cutoff = rnd<DT>(__fadd_rn(vmax, lb));                                   // :191
+        const bool both = p.d != nullptr;
+        // ---- pass B: contrast + mask + temperature -> working row ----------------------
+        for (int base = tid; base < nch; base += UNR * BLOCK) {
+            uint32_t qc[UNR][4], qd[UNR][4], qv[UNR][4];
+#pragma unroll
+            for (int u = 0; u < UNR; ++u) {
+                const int ch = base + u * BLOCK;
+                if (ch < nch) {
+                    gload<DT>(p.c, oc, ch, V, p.vec_in, qc[u]);
+                    if (both) gload<DT>(p.d, od, ch, V, p.vec_in, qd[u]);
+                    if constexpr (!LDSROW) gload<DT>(p.v, ov, ch, V, p.vec_in, qv[u]);
+                }
+            }
+#pragma unroll
+            for (int u = 0; u < UNR; ++u) {
+                const int ch = base + u * BLOCK;
+                if (ch < nch) {
+                    if constexpr (LDSROW) R.get(ch, qv[u]);
+                    uint32_t x4[4] = {0, 0, 0, 0};
+#pragma unroll
+                    for (int j = 0; j < EPC; ++j) {
+                        const int idx = ch * EPC + j;
+                        float vf = Tr<DT>::to_f(getb<DT>(qv[u], j)), cf = Tr<DT>::to_f(getb<DT>(qc[u], j));
+                        if (both) {
+                            float df = Tr<DT>::to_f(getb<DT>(qd[u], j));
+                            cf = rnd<DT>(__fmul_rn(rnd<DT>(__fadd_rn(cf, df)), 0.5f));                 // :185
+                        }
+                        float a = rnd<DT>(__fmul_rn(vf, p.s1));
+                        float b = rnd<DT>(__fmul_rn(cf, p.s2));
+                        float x = rnd<DT>(__fsub_rn(a, b));                                           // :193
+                        if (p.use_temp) x = rnd<DT>(recip ? __fmul_rn(x, p.inv_temp) : __fdiv_rn(x, p.temp));   // HF temperature
+                        const bool masked = (vf < cutoff) || (idx >= V);                              // :194
+                        uint32_t xb = masked ? NINF : Tr<DT>::from_f(x);
+                        setb<DT>(x4, j, xb);
+                        if (xb != NINF) { nfin += 1; m = fmaxf(m, x); t_nan |= (x != x) ? 1 : 0; t_pinf |= (x == INFINITY) ? 1 : 0; }
+                    }
+                    R.put(ch, x4);
+                }
+            }
+        }
+    } else {
+        // ---- plain path (vcd_sample.py:204-205): x = warp(v) ---------------------------
+        for (int base = tid; base < nch; base += UNR * BLOCK) {
+            uint32_t q[UNR][4];
+#pragma unroll
+            for (int u = 0; u < UNR; ++u) { const int ch = base + u * BLOCK; if (ch < nch) gload<DT>(p.v, ov, ch, V, p.vec_in, q[u]); }
+#pragma unroll
+            for (int u = 0; u < UNR; ++u) {
+                const int ch = base + u * BLOCK;
+                if (ch < nch) {
+#pragma unroll
+                    for (int j = 0; j < EPC; ++j) {
+                        const int idx = ch * EPC + j;
+                        uint32_t b = getb<DT>(q[u], j);
+                        float x = Tr<DT>::to_f(b);
+                        if (p.use_temp) { x = rnd<DT>(recip ? __fmul_rn(x, p.inv_temp) : __fdiv_rn(x, p.temp)); b = Tr<DT>::from_f(x); }
+                        if (idx >= V) b = NINF;
+                        setb<DT>(q[u], j, b);
+                        if (b != NINF) { nfin += 1; m = fmaxf(m, x); t_nan |= (x != x) ? 1 : 0; t_pinf |= (x == INFINITY) ? 1 : 0; }
+                    }
+                    R.put(ch, q[u]);
+                }
+            }
+        }
+    }
+    int flags2 = t_nan + 2048 * t_pinf;                      // per-thread 0/1 flags: sums stay < 2^22
+    block_max_count2(m, nfin, flags2, sm, lane, wave);
+    const bool has_nan = (flags2 % 2048) != 0;
+    const bool has_pinf = (flags2 / 2048) != 0;
+    const bool row_bad = (nfin == 0) || has_nan || has_pinf;
+
+    // ---- top-k (HF TopKLogitsWarper: scores < kth -> -inf, ties kept) ------------
+    if (p.top_k > 0 && !has_nan && nfin > 0) {
+        int k = p.top_k < p.min_keep ? p.min_keep : p.top_k;
+        if (k < nfin) {
+            uint32_t kth = select_kth_key<DT, LDSROW>(R, nch, (unsigned)k, sm, tid, lane, wave);
+            mask_below_key<DT, LDSROW>(R, nch, kth, tid);
+        }
+    }
+
+    // ---- top-p (HF TopPLogitsWarper) ----------------------------------------------
+    if (p.use_topp && !row_bad) {
+        float z = 0.f;
+        for (int ch = tid; ch < nch; ch += BLOCK) {
+            uint32_t w[4]; R.get(ch, w);
+#pragma unroll
+            for (int j = 0; j < EPC; ++j) { uint32_t b = getb<DT>(w, j); if (b != NINF) z += __expf(Tr<DT>::to_f(b) - m); }
+        }
+        z = block_sum(z, sm, lane, wave);
+        const float thr = rnd<DT>(p.one_minus_p) * z;      // cum <= fl(1-p)  <=>  mass <= fl(1-p) * Z
+        uint32_t pkey = 0;
+        bool crossed = select_mass_key<DT, LDSROW>(R, nch, m, thr, sm, tid, lane, wave, pkey);
+        // never remove the top min_keep entries
+        uint32_t keep_key;
+        if (p.min_keep <= 1) keep_key = okey<DT>(Tr<DT>::from_f(m));
+        else keep_key = (p.min_keep < nfin) ? select_kth_key<DT, LDSROW>(R, nch, (unsigned)p.min_keep, sm, tid, lane, wave) : 0u;
+        uint32_t thr_key = crossed ? (pkey < keep_key ? pkey : keep_key) : keep_key;
+        mask_below_key<DT, LDSROW>(R, nch, thr_key, tid);
+    }
+
+    // ---- scores row out -----------------------------------------------------------
+    if (p.scores != nullptr) {
+        if constexpr (LDSROW) {
+            for (int ch = tid; ch < nch; ch += BLOCK) { uint32_t w[4]; R.get(ch, w); gstore<DT>(p.scores, (long long)row * p.ss, ch, V, p.vec_out, w); }
+        } else if (p.scores != p.work) {
+            for (int ch = tid; ch < nch; ch += BLOCK) { uint32_t w[4]; R.get(ch, w); gstore<DT>(p.scores, (long long)row * p.ss, ch, V, p.vec_out, w); }
+        }
+    }
+    if (row_bad) {
+        if (tid == 0) {
+            if (p.status) p.status[row] = VDD_ROW_EMPTY;
+            if (p.next_tokens && !(p.flags & VDD_NO_SAMPLE)) p.next_tokens[(long long)row * p.st] = -1;
+        }
+        if (p.top_prob && tid < p.n_top) { p.top_prob[(long long)row * p.n_top + tid] = 0.f; p.top_tok[(long long)row * p.n_top + tid] = -1; }
+        return;
+    }
+    if (tid == 0 && p.status) p.status[row] = VDD_ROW_OK;
+    const bool want_top = p.top_prob != nullptr && p.n_top > 0;
+    if ((p.flags & VDD_NO_SAMPLE) && !want_top) return;
+
+    // ---- per-thread mass, block scan (thread-major order) ---------------------------
+    float t = 0.f;
+    for (int ch = tid; ch < nch; ch += BLOCK) {
+        uint32_t w[4]; R.get(ch, w);
+#pragma unroll
+        for (int j = 0; j < EPC; ++j) { uint32_t b = getb<DT>(w, j); if (b != NINF) t += __expf(Tr<DT>::to_f(b) - m); }
+    }
+    float incl = t;
+#pragma unroll
+    for (int o = 1; o < 64; o <<= 1) { float n = __shfl_up(incl, o); if (lane >= o) incl += n; }
+    if (lane == 63) sm.f[0][wave] = incl;
+    __syncthreads();
+    float base = 0.f, Z = 0.f;
+#pragma unroll
+    for (int w = 0; w < NWAVE; ++w) { if (w == wave) base = Z; Z += sm.f[0][w]; }
+    incl += base;
+    float excl = __shfl_up(incl, 1);
+    if (lane == 0) excl = base;
+    __syncthreads();
+
+    // ---- top-n of softmax(scores) (metrics.py:103-104) -------------------------------
+    if (want_top) {
+        float pv = INFINITY; int pi = -1;     // previous pick (value desc, index asc)
+        for (int r = 0; r < p.n_top; ++r) {
+            float bv = -INFINITY; int bi = 0x7fffffff;
+            for (int ch = tid; ch < nch; ch += BLOCK) {
+                uint32_t w[4]; R.get(ch, w);
+#pragma unroll
+                for (int j = 0; j < EPC; ++j) {
+                    uint32_t b = getb<DT>(w, j);
+                    const int idx = ch * EPC + j;
+                    float f = Tr<DT>::to_f(b);
+                    bool after = (b != NINF) && (f < pv || (f == pv && idx > pi));
+                    if (after && (f > bv || (f == bv && idx < bi))) { bv = f; bi = idx; }
+                }
+            }
+#pragma unroll
+            for (int o = 32; o > 0; o >>= 1) {
+                float ov2 = __shfl_xor(bv, o); int oi = __shfl_xor(bi, o);
+                if (ov2 > bv || (ov2 == bv && oi < bi)) { bv = ov2; bi = oi; }
+            }
+            if (lane == 0) { sm.f[1][wave] = bv; sm.i[1][wave] = bi; }
+            __syncthreads();
+            bv = sm.f[1][0]; bi = sm.i[1][0];
+#pragma unroll
+            for (int w = 1; w < NWAVE; ++w) {
+                float ov2 = sm.f[1][w]; int oi = sm.i[1][w];
+                if (ov2 > bv || (ov2 == bv && oi < bi)) { bv = ov2; bi = oi; }
+            }
+            __syncthreads();
+            const bool have = bi != 0x7fffffff;
+            if (tid == 0) {
+                p.top_prob[(long long)row * p.n_top + r] = have ? rnd<DT>(__fdiv_rn(__expf(bv - m), Z)) : 0.f;
+                p.top_tok[(long long)row * p.n_top + r] = have ? bi : -1;
+            }
+            pv = have ? bv : -INFINITY; pi = bi;
+        }
+    }
+    if (p.flags & VDD_NO_SAMPLE) return;
+
+    // ---- token: argmax or inverse-CDF draw in thread-major order ---------------------
+    if (tid == 0) sm.sel[3] = 0xFFFFFFFFu;
+    __syncthreads();
+    if (p.flags & VDD_PICK_ARGMAX) {
+        float bv = -INFINITY; int bi = 0x7fffffff;
+        for (int ch = tid; ch < nch; ch += BLOCK) {
+            uint32_t w[4]; R.get(ch, w);
+#pragma unroll
+            for (int j = 0; j < EPC; ++j) {
+                uint32_t b = getb<DT>(w, j);
+                const int idx = ch * EPC + j;
+                float f = Tr<DT>::to_f(b);
+                if (b != NINF && (f > bv || (f == bv && idx < bi))) { bv = f; bi = idx; }
+            }
+        }
+        if (bv == m) atomicMin(&sm.sel[3], (unsigned)bi);
+    } else {
+        const float u = p.uniforms ? p.uniforms[row] : philox_uniform(p.seed, p.offset, (unsigned)row);
+        const float target = u * Z;
+        bool hit = (t > 0.f) && (target >= excl) && (target < incl);
+        // rounding fallback: target >= Z lands on the last thread holding mass
+        unsigned long long anyhit = __ballot(hit);
+        unsigned long long mass = __ballot(t > 0.f);
+        if (lane == 0) { sm.i[0][wave] = anyhit ? 1 : 0; sm.i[1][wave] = mass ? (wave * 64 + 63 - __clzll((long long)mass)) : -1; }
+        __syncthreads();
+        int any = 0, last = -1;
+#pragma unroll
+        for (int w = 0; w < NWAVE; ++w) { any |= sm.i[0][w]; last = sm.i[1][w] > last ? sm.i[1][w] : last; }
+        if (!any) hit = (tid == last);
+        if (hit) {
+            float acc = excl; int pick = -1, lastfin = -1;
+            for (int ch = tid; ch < nch; ch += BLOCK) {
+                uint32_t w[4]; R.get(ch, w);
+#pragma unroll
+                for (int j = 0; j < EPC; ++j) {
+                    uint32_t b = getb<DT>(w, j);
+                    const int idx = ch * EPC + j;
+                    if (b != NINF) {
+                        acc += __expf(Tr<DT>::to_f(b) - m);
+                        lastfin = idx;
+                        if (pick < 0 && target < acc) pick = idx;
+                    }
+                }
+            }
+            sm.sel[3] = (unsigned)(pick >= 0 ? pick : lastfin);
+        }
+    }
+    __syncthreads();
+    if (tid == 0) {
+        long long tok = (long long)sm.sel[3];
+        if (p.unfinished != nullptr && p.n_eos > 0) {
+            long long uf = p.unfinished[row];
+            tok = tok * uf + p.pad * (1 - uf);                                              // :260
+            long long keep = 1;
+            for (int e = 0; e < p.n_eos; ++e) keep *= (tok != p.eos[e]) ? 1 : 0;             // :286-288
+            p.unfinished[row] = uf * keep;
+        }
+        p.next_tokens[(long long)row * p.st] = tok;
+    }
+}
+
+// ------------------------------------------------------------------ host side
+thread_local char g_err[256] = "";
+
+int fail(int code, const char* msg) { snprintf(g_err, sizeof(g_err), "%s", msg); return code; }
+
+template <int DT, bool L>
+int launch_one(const KP& kp, size_t lds, hipStream_t st) {
+    static int attr_rc = (int)hipFuncSetAttribute(reinterpret_cast<const void*>(&vdd_contrast_sample_kernel<DT, L>),
+                                                  hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+    (void)attr_rc;
+    hipLaunchKernelGGL((vdd_contrast_sample_kernel<DT, L>), dim3(kp.B), dim3(BLOCK), lds, st, kp);
+    return hipGetLastError() == hipSuccess ? VDD_OK : VDD_ERR_LAUNCH;
+}
+
+template <int DT>
+int launch_dt(const KP& kp, bool ldsrow, size_t lds, hipStream_t st) {
+    return ldsrow ? launch_one<DT, true>(kp, lds, st) : launch_one<DT, false>(kp, lds, st);
+}
+
+size_t esize(int dtype) { return dtype == VDD_F32 ? 4 : 2; }
+
+}  // namespace
+
+extern "C" {
+
+int vdd_abi_version(void) { return VDD_ABI_VERSION; }
+const char* vdd_last_error(void) { return g_err; }
+int vdd_lds_row_capacity(int dtype) { return (int)(LDS_ROW_BYTES_MAX / esize(dtype)); }
+
+const char* vdd_kernel_name(int dtype, int V) {
+    (void)dtype; (void)V;
+    return "vdd_contrast_sample_kernel";
+}
+
+int vdd_contrast_sample(const vdd_sample_params* p, void* hip_stream) {
+    if (!p) return fail(VDD_ERR_INVALID_ARG, "params is NULL");
+    if (p->abi_version != VDD_ABI_VERSION) return fail(VDD_ERR_INVALID_ARG, "abi_version mismatch");
+    if (p->B < 0 || p->V <= 0) return fail(VDD_ERR_INVALID_ARG, "B < 0 or V <= 0");
+    if (p->B == 0) return VDD_OK;
+    if (!p->logit_v) return fail(VDD_ERR_INVALID_ARG, "logit_v is NULL");
+    if (p->logit_dd && !p->logit_cd) return fail(VDD_ERR_INVALID_ARG, "logit_dd given without logit_cd");
+    if (!(p->flags & VDD_NO_SAMPLE) && !p->next_tokens) return fail(VDD_ERR_INVALID_ARG, "next_tokens is NULL");
+    if ((p->flags & VDD_NO_SAMPLE) && !p->scores_out && !p->top_prob) return fail(VDD_ERR_INVALID_ARG, "VDD_NO_SAMPLE without any output");
+    if (p->dtype != VDD_F32 && p->dtype != VDD_F16 && p->dtype != VDD_BF16) return fail(VDD_ERR_INVALID_ARG, "bad dtype");
+    if (p->min_keep < 1) return fail(VDD_ERR_INVALID_ARG, "min_keep < 1");
+    if (p->n_top < 0 || p->n_top > 16) return fail(VDD_ERR_INVALID_ARG, "n_top out of [0,16]");
+    if ((p->top_prob == nullptr) != (p->top_tok == nullptr)) return fail(VDD_ERR_INVALID_ARG, "top_prob/top_tok must be given together");
+    if (p->n_eos < 0 || (p->n_eos > 0 && !p->eos_ids)) return fail(VDD_ERR_INVALID_ARG, "eos_ids missing");
+    if (p->temperature != p->temperature) return fail(VDD_ERR_INVALID_ARG, "temperature is NaN");
+
+    const size_t es = esize(p->dtype);
+    const int epc = (int)(16 / es);
+    const size_t row_bytes = (size_t)((p->V + epc - 1) / epc) * 16;
+    const bool ldsrow = row_bytes <= (size_t)LDS_ROW_BYTES_MAX;
+    auto al = [&](const void* ptr, long long stride) { return ptr == nullptr || ((((uintptr_t)ptr) & 15u) == 0 && ((stride * (long long)es) & 15) == 0); };
+    KP kp{};
+    kp.v = p->logit_v; kp.c = p->logit_cd; kp.d = p->logit_dd;
+    kp.sv = p->stride_v; kp.sc = p->stride_cd; kp.sd = p->stride_dd; kp.ss = p->stride_scores;
+    kp.B = p->B; kp.V = p->V; kp.flags = p->flags;
+    kp.min_keep = p->min_keep; kp.top_k = p->top_k > 0 ? p->top_k : 0; kp.n_eos = p->n_eos;
+    kp.n_top = p->top_prob ? p->n_top : 0;
+    kp.s1 = (float)(1.0 + p->alpha); kp.s2 = (float)p->alpha; kp.log_beta = (float)p->log_beta;
+    kp.use_temp = (p->temperature > 0.0 && p->temperature != 1.0) ? 1 : 0;
+    kp.temp = kp.use_temp ? (float)p->temperature : 1.0f;
+    kp.inv_temp = 1.0f / kp.temp;
+    kp.use_topp = (p->top_p >= 0.0 && p->top_p < 1.0) ? 1 : 0;
+    kp.one_minus_p = (float)(1.0 - p->top_p);
+    kp.seed = p->philox_seed; kp.offset = p->philox_offset; kp.uniforms = p->uniforms;
+    kp.eos = (const long long*)p->eos_ids; kp.pad = p->pad_id;
+    kp.unfinished = (long long*)p->unfinished; kp.next_tokens = (long long*)p->next_tokens;
+    kp.st = p->stride_tokens > 0 ? p->stride_tokens : 1;
+    kp.scores = p->scores_out; kp.top_prob = p->top_prob; kp.top_tok = (long long*)p->top_tok;
+    kp.status = p->row_status;
+    kp.vec_in = al(p->logit_v, p->stride_v) && al(p->logit_cd, p->stride_cd) && al(p->logit_dd, p->stride_dd);
+    kp.vec_out = al(p->scores_out, p->stride_scores);
+    if (!ldsrow) {
+        if (p->scores_out) { kp.work = p->scores_out; kp.sw = p->stride_scores; }
+        else if (p->workspace) { kp.work = p->workspace; kp.sw = p->stride_workspace; }
+        else return fail(VDD_ERR_INVALID_ARG, "V exceeds vdd_lds_row_capacity(dtype): pass scores_out or workspace [B,V]");
+        kp.vec_work = al(kp.work, kp.sw);
+    }
+    const size_t lds = sizeof(Smem) + (ldsrow ? row_bytes : 0);
+    hipStream_t st = (hipStream_t)hip_stream;
+    int rc;
+    switch (p->dtype) {
+        case VDD_F16: rc = launch_dt<VDD_F16>(kp, ldsrow, lds, st); break;
+        case VDD_BF16: rc = launch_dt<VDD_BF16>(kp, ldsrow, lds, st); break;
+        default: rc = launch_dt<VDD_F32>(kp, ldsrow, lds, st); break;
+    }
+    if (rc == VDD_ERR_LAUNCH) return fail(rc, "hipLaunchKernel failed");
+    return rc;
+}
+
+}  // extern "C"

@@ -1,0 +1,61 @@
+"""Drop-in for the reference's `vcd_utils/vcd_add_noise.py`: add_diffusion_noise(image, t).
+
+The 1000-step sigmoid schedule (vcd_add_noise.py:7-16) is tabulated once per process
+with the same fp32 torch ops the reference re-runs on every call; the noising itself
+(:18-22) is a HIP kernel (`vdd_add_diffusion_noise`) with an in-kernel Philox/Box-Muller
+normal generator seeded from torch's global seed.  A CPU image tensor (what the
+reference's LLaVA drivers pass, llava_calibrate.py:152) is moved to the GPU for the
+kernel and returned on its original device; without a GPU this raises — no CPU path.
+"""
+from __future__ import annotations
+
+import ctypes as C
+import itertools
+from typing import Optional
+
+import torch
+
+from . import _lib
+
+_schedule = None
+_calls = itertools.count()
+_DT = {torch.float32: _lib.VDD_F32, torch.float16: _lib.VDD_F16, torch.bfloat16: _lib.VDD_BF16}
+
+
+def schedule(num_steps: int = 1000):
+    """(sqrt(abar), sqrt(1-abar)) as python floats per step — vcd_add_noise.py:7-16."""
+    global _schedule
+    if _schedule is None or len(_schedule[0]) != num_steps:
+        betas = torch.sigmoid(torch.linspace(-6, 6, num_steps)) * (0.5e-2 - 1e-5) + 1e-5
+        abar = torch.cumprod(1 - betas, dim=0)
+        _schedule = (torch.sqrt(abar).tolist(), torch.sqrt(1 - abar).tolist())
+    return _schedule
+
+
+def add_diffusion_noise(image_tensor: torch.Tensor, noise_step: int, noise: Optional[torch.Tensor] = None,
+                        seed: Optional[int] = None) -> torch.Tensor:
+    lib = _lib.load_lib()
+    if not torch.cuda.is_available():
+        raise _lib.VddLibraryError("add_diffusion_noise needs a GPU: this package has no CPU path")
+    if image_tensor.dtype not in _DT:
+        raise ValueError(f"unsupported image dtype {image_tensor.dtype}")
+    a, b = schedule()
+    t = int(noise_step)
+    src_dev = image_tensor.device
+    x = image_tensor.to("cuda", non_blocking=True).contiguous()
+    y = torch.empty_like(x)
+    eps_ptr = None
+    if noise is not None:
+        eps = noise.to(device=x.device, dtype=torch.float32).contiguous()
+        if eps.numel() != x.numel():
+            raise ValueError("noise must have as many elements as the image")
+        eps_ptr = eps.data_ptr()
+    lib.vdd_add_diffusion_noise.argtypes = [C.c_void_p, C.c_void_p, C.c_int64, C.c_int, C.c_float, C.c_float,
+                                            C.c_void_p, C.c_uint64, C.c_uint64, C.c_void_p]
+    lib.vdd_add_diffusion_noise.restype = C.c_int
+    sd = (torch.initial_seed() if seed is None else int(seed)) & 0xFFFFFFFFFFFFFFFF
+    off = next(_calls) << 40      # disjoint counter ranges per call
+    with torch.cuda.device(x.device):
+        _lib.check(lib.vdd_add_diffusion_noise(x.data_ptr(), y.data_ptr(), x.numel(), _DT[x.dtype], a[t], b[t],
+                                               eps_ptr, sd, off, torch.cuda.current_stream(x.device).cuda_stream))
+    return y if src_dev.type == "cuda" else y.to(src_dev)

@@ -1,0 +1,116 @@
+"""Host-side logic of the drop-in (no GPU): warper absorption, criteria parsing, the
+install hook, and the guarantee that the product path has no CPU fallback."""
+import os
+import re
+
+import pytest
+import torch
+import transformers
+from transformers.generation.logits_process import (LogitsProcessorList, MinLengthLogitsProcessor,
+                                                    TemperatureLogitsWarper, TopKLogitsWarper, TopPLogitsWarper,
+                                                    TypicalLogitsWarper)
+
+import llava_align_amd as L
+from llava_align_amd import vcd_sample as VS
+from llava_align_amd.sampling import thread_major_order
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def test_warpers_are_absorbed_in_hf_order():
+    procs, spec, fused = VS._split_warpers(LogitsProcessorList(), LogitsProcessorList(
+        [TemperatureLogitsWarper(0.2), TopKLogitsWarper(50), TopPLogitsWarper(0.9)]))
+    assert fused and procs == [] and (spec.temperature, spec.top_k, spec.top_p) == (0.2, 50, 0.9)
+    # merged list (transformers >= 4.39 `_sample`)
+    procs, spec, fused = VS._split_warpers(LogitsProcessorList([TemperatureLogitsWarper(0.7), TopKLogitsWarper(3)]), None)
+    assert fused and (spec.temperature, spec.top_k, spec.top_p) == (0.7, 3, None)
+    # a real processor in front keeps the warpers fused but the step split in two launches
+    mlp = MinLengthLogitsProcessor(5, eos_token_id=2)
+    procs, spec, fused = VS._split_warpers(LogitsProcessorList([mlp]), LogitsProcessorList([TopKLogitsWarper(1)]))
+    assert not fused and procs == [mlp] and spec.top_k == 1
+    # unknown or re-ordered warpers run in Python as a whole
+    procs, spec, fused = VS._split_warpers(None, LogitsProcessorList([TopPLogitsWarper(0.9), TopKLogitsWarper(5)]))
+    assert not fused and len(procs) == 2 and spec.top_k is None
+    procs, spec, fused = VS._split_warpers(None, LogitsProcessorList([TypicalLogitsWarper(0.5)]))
+    assert not fused and len(procs) == 1
+    # non -inf filter value cannot be fused
+    procs, spec, fused = VS._split_warpers(None, LogitsProcessorList([TopKLogitsWarper(5, filter_value=-1e4)]))
+    assert not fused
+
+
+def test_warpspec_activation_rules():
+    w = L.WarpSpec(temperature=1.0, top_k=0, top_p=1.0)
+    assert (w.t, w.k, w.p) == (0.0, 0, 2.0)          # all three off, as HF skips them
+    w = L.WarpSpec(temperature=0.2, top_k=1, top_p=0.0)
+    assert (w.t, w.k, w.p) == (0.2, 1, 0.0)
+
+
+def test_criteria_parsing():
+    sc = transformers.StoppingCriteriaList([transformers.MaxLengthCriteria(max_length=77)])
+    rest, ml, eos = VS._parse_criteria(sc, None)
+    assert rest == [] and ml == 77 and eos is None
+    if hasattr(transformers, "EosTokenCriteria"):
+        sc.append(transformers.EosTokenCriteria(eos_token_id=[2, 5]))
+        rest, ml, eos = VS._parse_criteria(sc, 50)
+        assert ml == 50 and torch.as_tensor(eos).tolist() == [2, 5]
+
+
+def test_thread_major_order_is_a_permutation():
+    for V, dt in ((97, torch.float16), (1003, torch.float32), (20000, torch.bfloat16)):
+        o = thread_major_order(V, dt)
+        assert sorted(o) == list(range(V))
+    o = thread_major_order(20000, torch.float16)
+    assert o[:8] == list(range(8)) and o[8:16] == list(range(8192, 8200))   # thread 0: chunk 0 then chunk 1024
+
+
+def test_install_hook_is_idempotent():
+    mixin = transformers.generation.utils.GenerationMixin
+    saved = (mixin.__dict__.get("sample"), mixin.__dict__.get("_sample"))
+    try:
+        L.evolve_vcd_sampling()
+        L.evolve_vcd_sampling()
+        assert mixin.sample is VS.sample
+        if saved[1] is not None:
+            assert mixin._sample is VS._sample_v5
+    finally:
+        if saved[0] is None:
+            del mixin.sample
+        else:
+            mixin.sample = saved[0]
+        if saved[1] is not None:
+            mixin._sample = saved[1]
+
+
+def test_no_cpu_fallback():
+    v = torch.zeros(2, 97, dtype=torch.float16)
+    with pytest.raises(L.VddLibraryError):
+        L.contrast_sample(v, v)
+    if not torch.cuda.is_available():
+        with pytest.raises(L.VddLibraryError):
+            L.add_diffusion_noise(torch.zeros(3, 4, 4), 500)
+
+
+def test_missing_library_fails_loudly(monkeypatch, tmp_path):
+    from llava_align_amd import _lib
+    monkeypatch.setattr(_lib, "_lib", None)
+    monkeypatch.setenv("VDD_HIP_LIB", str(tmp_path / "nope.so"))
+    with pytest.raises(L.VddLibraryError, match="no CPU fallback"):
+        _lib.load_lib()
+
+
+def test_product_never_imports_the_oracle():
+    pkg = os.path.join(ROOT, "llava-align_amd")
+    for dp, _, files in os.walk(pkg):
+        for f in files:
+            if f.endswith((".py", ".hip", ".h", ".cpp")):
+                src = open(os.path.join(dp, f)).read()
+                assert not re.search(r"^\s*(from|import)\s+oracle\b", src, flags=re.M), f
+                assert "vdd_oracle" not in src, f
+
+
+def test_eos_without_pad_raises_like_the_reference():
+    class M:
+        generation_config = transformers.GenerationConfig()
+    ids = torch.ones(1, 4, dtype=torch.long)
+    with pytest.raises(ValueError, match="make sure that `pad_token_id` is defined"):
+        VS.sample(M(), ids, eos_token_id=2, pad_token_id=None)
