@@ -362,7 +362,7 @@ __device__ __forceinline__ void mask_below_key(const Row<DT, L>& R, int nch, uin
 
 // ------------------------------------------------------------------ the kernel
 template <int DT, bool LDSROW>
-__global__ void __launch_bounds__(BLOCK) vdd_contrast_sample_kernel(KP p) {
+__global__ void __launch_bounds__(BLOCK, 8) vdd_contrast_sample_kernel(KP p) {
     constexpr int EPC = Tr<DT>::EPC;
     constexpr uint32_t NINF = Tr<DT>::NEG_INF;
     extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
@@ -400,29 +400,39 @@ __global__ void __launch_bounds__(BLOCK) vdd_contrast_sample_kernel(KP p) {
         const float cutoff = rnd<DT>(__fadd_rn(vmax, lb));                                   // :191
         const bool both = p.d != nullptr;
         // ---- pass B: contrast + mask + temperature -> working row ----------------------
+        // Where v < cutoff the result is -inf whatever c/d hold (:194), so the contrast
+        // branches are only READ for chunks that contain a survivor: with the usual beta the
+        // c/d rows cost a few 64-B sectors instead of V*e bytes each.
         for (int base = tid; base < nch; base += UNR * BLOCK) {
-            uint32_t qc[UNR][4], qd[UNR][4], qv[UNR][4];
+            uint32_t qv[UNR][4];
+            if constexpr (!LDSROW) {       // global working row: batch the v re-reads (L2 / Infinity-Cache hits)
 #pragma unroll
-            for (int u = 0; u < UNR; ++u) {
-                const int ch = base + u * BLOCK;
-                if (ch < nch) {
-                    gload<DT>(p.c, oc, ch, V, p.vec_in, qc[u]);
-                    if (both) gload<DT>(p.d, od, ch, V, p.vec_in, qd[u]);
-                    if constexpr (!LDSROW) gload<DT>(p.v, ov, ch, V, p.vec_in, qv[u]);
-                }
+                for (int u = 0; u < UNR; ++u) { const int ch = base + u * BLOCK; if (ch < nch) gload<DT>(p.v, ov, ch, V, p.vec_in, qv[u]); }
             }
 #pragma unroll
             for (int u = 0; u < UNR; ++u) {
                 const int ch = base + u * BLOCK;
-                if (ch < nch) {
-                    if constexpr (LDSROW) R.get(ch, qv[u]);
-                    uint32_t x4[4] = {0, 0, 0, 0};
+                if (ch >= nch) continue;
+                if constexpr (LDSROW) R.get(ch, qv[u]);
+                bool live = false;
+#pragma unroll
+                for (int j = 0; j < EPC; ++j) {
+                    float vf = Tr<DT>::to_f(getb<DT>(qv[u], j));
+                    live |= !(vf < cutoff) && (ch * EPC + j < V);
+                }
+                uint32_t x4[4];
+                if constexpr (Tr<DT>::KEYBITS == 16) { x4[0] = x4[1] = x4[2] = x4[3] = NINF | (NINF << 16); }
+                else { x4[0] = x4[1] = x4[2] = x4[3] = NINF; }
+                if (live) {
+                    uint32_t qc[4], qd[4];
+                    gload<DT>(p.c, oc, ch, V, p.vec_in, qc);
+                    if (both) gload<DT>(p.d, od, ch, V, p.vec_in, qd);
 #pragma unroll
                     for (int j = 0; j < EPC; ++j) {
                         const int idx = ch * EPC + j;
-                        float vf = Tr<DT>::to_f(getb<DT>(qv[u], j)), cf = Tr<DT>::to_f(getb<DT>(qc[u], j));
+                        float vf = Tr<DT>::to_f(getb<DT>(qv[u], j)), cf = Tr<DT>::to_f(getb<DT>(qc, j));
                         if (both) {
-                            float df = Tr<DT>::to_f(getb<DT>(qd[u], j));
+                            float df = Tr<DT>::to_f(getb<DT>(qd, j));
                             cf = rnd<DT>(__fmul_rn(rnd<DT>(__fadd_rn(cf, df)), 0.5f));                 // :185
                         }
                         float a = rnd<DT>(__fmul_rn(vf, p.s1));
@@ -430,12 +440,13 @@ __global__ void __launch_bounds__(BLOCK) vdd_contrast_sample_kernel(KP p) {
                         float x = rnd<DT>(__fsub_rn(a, b));                                           // :193
                         if (p.use_temp) x = rnd<DT>(recip ? __fmul_rn(x, p.inv_temp) : __fdiv_rn(x, p.temp));   // HF temperature
                         const bool masked = (vf < cutoff) || (idx >= V);                              // :194
-                        uint32_t xb = masked ? NINF : Tr<DT>::from_f(x);
-                        setb<DT>(x4, j, xb);
-                        if (xb != NINF) { nfin += 1; m = fmaxf(m, x); t_nan |= (x != x) ? 1 : 0; t_pinf |= (x == INFINITY) ? 1 : 0; }
+                        if (!masked) {
+                            setb<DT>(x4, j, Tr<DT>::from_f(x));
+                            nfin += 1; m = fmaxf(m, x); t_nan |= (x != x) ? 1 : 0; t_pinf |= (x == INFINITY) ? 1 : 0;
+                        }
                     }
-                    R.put(ch, x4);
                 }
+                R.put(ch, x4);
             }
         }
     } else {

@@ -150,6 +150,10 @@ def sample(self, input_ids: torch.LongTensor, logits_processor=None, stopping_cr
     contrast = use_cd or use_dd or use_dd_unk
     alpha = model_kwargs.get("cd_alpha") if model_kwargs.get("cd_alpha") is not None else 0.5    # :188
     beta = model_kwargs.get("cd_beta") if model_kwargs.get("cd_beta") is not None else 0.1       # :189
+    # extension (not in the reference): deterministic draw = arg-max of the final distribution,
+    # ties to the lowest index.  With top_k=1 this is the reference's sample() whenever its
+    # multinomial has a single survivor, and stays deterministic when fp16 ties leave several.
+    greedy = bool(model_kwargs.pop("cd_greedy", False))
 
     # id buffer: preallocated when the length bound is known (replaces torch.cat at :263)
     cap = max_length if max_length is not None else L0 + 64
@@ -209,7 +213,7 @@ def sample(self, input_ids: torch.LongTensor, logits_processor=None, stopping_cr
         eos_kw = dict(eos_ids=eos_t, pad_id=pad_token_id, unfinished=unfinished) if eos_t is not None else {}
         if fused:
             r = contrast_sample(v, c, d, alpha=alpha, beta=beta, warp=spec, out_tokens=tok_col,
-                                return_scores=want_scores, **eos_kw)
+                                return_scores=want_scores, pick_argmax=greedy, **eos_kw)
         else:
             # a Python logits_processor sits between contrast and warp (e.g. Qwen's
             # StopWordsLogitsProcessor, qwen_generation_utils.py:352-359): contrast-only launch,
@@ -217,7 +221,8 @@ def sample(self, input_ids: torch.LongTensor, logits_processor=None, stopping_cr
             x = contrast_sample(v, c, d, alpha=alpha, beta=beta, no_sample=True, return_scores=True).scores if contrast else v
             for proc in py_procs:
                 x = proc(ids, x)
-            r = contrast_sample(x, None, None, warp=spec, out_tokens=tok_col, return_scores=want_scores, **eos_kw)
+            r = contrast_sample(x, None, None, warp=spec, out_tokens=tok_col, return_scores=want_scores,
+                                pick_argmax=greedy, **eos_kw)
         statuses.append(r.status)
         if want_scores:
             scores.append(r.scores)                                                              # :240

@@ -260,7 +260,10 @@ def test_add_diffusion_noise_matches_oracle_with_explicit_noise(golden_dir):
         torch.manual_seed(200 + t)
         eps = torch.randn_like(x)
         y = L.add_diffusion_noise(x, t, noise=eps)          # CPU tensor in -> CPU tensor out, computed by the HIP kernel
-        assert y.device.type == "cpu" and torch.equal(y, torch.from_numpy(z[f"y_{t}"]))
+        assert y.device.type == "cpu" and torch.equal(y, O.add_diffusion_noise(x, t, noise=eps))
+        # the schedule constants come out of vectorised CPU sigmoid/cumprod and differ in the last bit
+        # between host CPUs, so the fixture (made on the build container) is matched to 2 ulp
+        assert torch.allclose(y, torch.from_numpy(z[f"y_{t}"]), rtol=3e-7, atol=1e-7)
     big = torch.zeros(3, 336, 336, device=DEV)
     n = L.add_diffusion_noise(big, 999, seed=1)
     a, b = O.diffusion_schedule()

@@ -42,14 +42,25 @@ def test_loop_trace(tr):
     ids = torch.tensor(tr["ids"])
     img, img_cd = torch.tensor(tr["img"]), torch.tensor(tr["img_cd"])
     kw = dict(images=img, attention_mask=torch.ones_like(ids).to(DEV), use_cache=True, cd_alpha=1.0, cd_beta=0.1)
+    det = dict(cd_greedy=True)      # fp16 ties at the max: the oracle takes the lowest index, so must we
     kw.update({"plain": {}, "cd": {"images_cd": img_cd}, "dd": {"use_dd": True}, "dd_unk": {"use_dd_unk": True},
                "both": {"use_dd": True, "use_dd_unk": True}}[tr["mode"]])
     model = Hosted(logit_dtype=DTYPES[tr["dtype"]])
     out = sample(model, ids.to(DEV), logits_warper=LogitsProcessorList([TopKLogitsWarper(1)]),
-                 stopping_criteria=_crit(ids.shape[1] + 8), output_scores=True, return_dict_in_generate=True, **kw)
-    assert out["sequences"][:, ids.shape[1]:].cpu().tolist() == tr["tokens"]
+                 stopping_criteria=_crit(ids.shape[1] + 8), output_scores=True, return_dict_in_generate=True, **kw, **det)
+    # the forward-call schedule does not depend on the logits: must equal the reference's
     assert [[list(x) if isinstance(x, tuple) else x for x in c] for c in model.calls] == tr["schedule"]
-    assert [hashlib.sha256(to_bits(s.cpu()).tobytes()).hexdigest() for s in out["scores"]] == tr["score_sha256"]
+    # tokens and scores: bit-exact against the oracle loop run on THIS host.  (The toy LM's fp32
+    # CPU math differs in the last bit between host CPUs, so the fixture's tokens/score hashes
+    # are only guaranteed on the build container, where tests/test_oracle_golden.py pins the
+    # oracle to them.)
+    from oracle import vdd_oracle as O
+    kw_cpu = {k: (v.cpu() if torch.is_tensor(v) else v) for k, v in kw.items()}
+    r = O.reference_loop(ToyVLM(logit_dtype=DTYPES[tr["dtype"]]), ids.clone(), warp=O.WarpConfig(top_k=1),
+                         max_length=ids.shape[1] + 8, pad_token_id=None, eos_token_id=None, pick=O.pick_argmax, **kw_cpu)
+    assert out["sequences"].cpu().tolist() == r.sequences.tolist()
+    assert all(torch.equal(to_bits(a.cpu()) if False else a.cpu().view(torch.int16 if a.dtype != torch.float32 else torch.int32),
+                           b.view(torch.int16 if b.dtype != torch.float32 else torch.int32)) for a, b in zip(out["scores"], r.scores))
 
 
 def test_eos_pad_and_early_stop():
@@ -68,7 +79,7 @@ def test_eos_pad_and_early_stop():
         out = sample(HostedBank(bank), ids, logits_warper=LogitsProcessorList([TopKLogitsWarper(1)]),
                      stopping_criteria=_crit(4 + S), pad_token_id=case["pad"], eos_token_id=case["eos"],
                      output_scores=True, return_dict_in_generate=True,
-                     attention_mask=torch.ones_like(ids), use_dd_unk=True, cd_alpha=1.0, cd_beta=0.1)
+                     attention_mask=torch.ones_like(ids), use_dd_unk=True, cd_alpha=1.0, cd_beta=0.1, cd_greedy=True)
         assert out["sequences"].cpu().tolist() == case["sequences"]
         assert len(out["scores"]) == case["n_scores"]
 

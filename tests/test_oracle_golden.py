@@ -88,7 +88,9 @@ def test_noise_matches_reference(golden_dir):
         torch.manual_seed(200 + t)
         eps = torch.randn_like(x)
         y = O.add_diffusion_noise(x, t, noise=eps)
-        assert torch.equal(y, torch.from_numpy(z[f"y_{t}"]))
+        # bit-exact on the host that made the fixture; other CPUs' vectorised sigmoid/cumprod may
+        # differ in the last bit of the schedule constants
+        assert torch.allclose(y, torch.from_numpy(z[f"y_{t}"]), rtol=3e-7, atol=1e-7)
 
 
 class FakeTok:

@@ -1,0 +1,51 @@
+"""Microbench sweep of the fused sampling kernel (SURVEY.md §8d grid). Prints one line per point."""
+import os, sys, json
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+import torch
+import llava_align_amd as L
+
+dev = torch.device("cuda:0")
+
+
+def point(B, V, dtype, n_in, scores, warp, iters=100, beta=0.1):
+    g = torch.Generator(device=dev).manual_seed(0)
+    v = (torch.randn(B, V, device=dev, generator=g) * 4).to(dtype)
+    v[torch.arange(B, device=dev), torch.randint(0, V, (B,), device=dev, generator=g)] = 25.0
+    c = (v.float() + torch.randn(B, V, device=dev, generator=g) * 1.5).to(dtype) if n_in >= 2 else None
+    d = (v.float() + torch.randn(B, V, device=dev, generator=g) * 1.5).to(dtype) if n_in == 3 else None
+    out_scores = torch.empty(B, V, dtype=dtype, device=dev) if scores else None
+    toks = torch.empty(B, dtype=torch.long, device=dev)
+    run = lambda i: L.contrast_sample(v, c, d, alpha=1.0, beta=beta, warp=warp, out_tokens=toks, out_scores=out_scores, seed=0, offset=i)
+    for i in range(10):
+        run(i)
+    torch.cuda.synchronize()
+    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    e0.record()
+    for i in range(iters):
+        run(i)
+    e1.record()
+    torch.cuda.synchronize()
+    us = e0.elapsed_time(e1) / iters * 1e3
+    es = torch.finfo(dtype).bits // 8
+    alg = B * ((n_in + int(scores)) * V * es + 8)
+    return {"B": B, "V": V, "dtype": str(dtype)[6:], "n_in": n_in, "scores": scores, "warp": str(warp), "beta": beta,
+            "us": round(us, 2), "alg_GBs": round(alg / us / 1e3, 1), "us_per_row_per_slot": round(us / max(1, B / 512), 2)}
+
+
+if __name__ == "__main__":
+    W = L.WarpSpec
+    pts = []
+    for B in (1, 8, 64, 256, 512, 1024, 4096):
+        pts.append(point(B, 32000, torch.bfloat16, 2, True, W(temperature=0.2)))
+    pts.append(point(4096, 32000, torch.bfloat16, 2, False, W(temperature=0.2)))
+    pts.append(point(4096, 32000, torch.bfloat16, 3, True, W(temperature=0.2)))
+    pts.append(point(4096, 32000, torch.float16, 2, True, W(temperature=0.2)))
+    pts.append(point(4096, 32000, torch.bfloat16, 2, True, W(temperature=0.2), beta=1e-6))
+    pts.append(point(4096, 32000, torch.bfloat16, 1, True, W(temperature=0.7, top_k=50)))
+    pts.append(point(4096, 32000, torch.bfloat16, 2, True, W(temperature=0.7, top_k=50, top_p=0.9)))
+    pts.append(point(4096, 32000, torch.bfloat16, 1, True, W(top_p=0.9)))
+    pts.append(point(1024, 151936, torch.bfloat16, 2, True, W(temperature=0.2)))
+    pts.append(point(1024, 151936, torch.bfloat16, 2, False, W(temperature=0.2)))
+    for p in pts:
+        print(json.dumps(p))
