@@ -104,6 +104,52 @@ int vdd_add_diffusion_noise(const void* x, void* y, int64_t n, int dtype, float 
                             float sqrt_one_minus_abar, const float* eps, uint64_t seed,
                             uint64_t offset, void* hip_stream);
 
+/* ---------------------------------------------------------------------------------------------
+ * Branch-batched language-model step (all tensors bf16, device pointers, row-major).
+ * These replace what the reference runs per branch and per token through HF's eager LlamaModel
+ * (experiments/llava/model/language_model/llava_llama.py:88-103; vcd_sample.py:109,163,178):
+ * rows of one call = (question, branch) pairs, so weights stream from HBM once per step.
+ * ------------------------------------------------------------------------------------------- */
+
+/* h = x (+ delta); resid_out = h (optional); y = bf16(bf16(h * rsqrt(mean h^2 + eps)) * w).  d % 8 == 0, d <= 8192. */
+int vdd_rmsnorm(const void* x, const void* delta, const void* w, void* y, void* resid_out, int M, int d, float eps,
+                void* hip_stream);
+
+/* qkv [M, (Hq+2Hkv)*D] -> q_out [M, Hq, D] with rotary embedding at pos[row] (HF rotate_half pairing;
+ * cos_sin fp32 [max_pos, D/2, 2]); k (rotated) and v are written to cache[slot[row]][kv_head][pos[row]][D]
+ * (cache slot stride in elements; t_max tokens per slot). */
+int vdd_rope_kv_write(const void* qkv, const int* pos, const int* slot, const float* cos_sin, void* q_out, void* k_cache,
+                      void* v_cache, int M, int Hq, int Hkv, int D, int64_t slot_stride, int t_max, void* hip_stream);
+
+/* out[m, f] = silu(gate_up[m, f]) * gate_up[m, F + f]. */
+int vdd_silu_mul(const void* gate_up, void* out, int64_t M, int F, void* hip_stream);
+
+int vdd_embed(const int64_t* ids, const void* table, void* out, int M, int d, void* hip_stream);
+
+/* Y[M,N] = X[M,K] W[N,K]^T (+ R[M,N]); M <= 64, K % 128 == 0; W is read from HBM exactly once. */
+int vdd_skinny_gemm(const void* X, const void* W, const void* R, void* Y, int M, int N, int K, int64_t ldx, int64_t ldr,
+                    int64_t ldy, void* hip_stream);
+
+/* One query per (row, head) over that row's KV: rows[m] = {slot, len, prefix_slot, prefix_len} (int32 x4);
+ * tokens [0, prefix_len) are read from prefix_slot (shared prompt prefix), [prefix_len, len) from slot. D == 128. */
+int vdd_decode_attention(const void* q, const void* k_cache, const void* v_cache, const int32_t* rows, void* out, int M, int H,
+                         int Hkv, int D, int64_t slot_stride, int t_max, float scale, void* hip_stream);
+
+/* Prefill attention (MFMA, flash-style).  q/out [Ttot, H*D] packed by sequence; seqs[s] = {q_row0, Tq, pos0,
+ * slot, prefix_slot, prefix_len} (int32 x6): query i of sequence s sits at position pos0+i and attends keys
+ * [0, pos0+i] (causal) or [0, pos0+Tq) (non-causal) read from the cache (prefix slot below prefix_len, own
+ * slot above), whose K/V for the new tokens must already be written.  D in {64, 128}.
+ * Replaces the eager attention of LlamaModel / CLIPVisionModel at step 0 (llava_arch.py:82-204). */
+int vdd_flash_attention(const void* q, const void* k_cache, const void* v_cache, const int32_t* seqs, void* out, int n_seq,
+                        int max_tq, int H, int Hkv, int D, int64_t slot_stride, int t_max, float scale, int causal,
+                        void* hip_stream);
+
+/* CLIP ViT LayerNorm (with bias); d % 8 == 0, d <= 4096. */
+int vdd_layernorm(const void* x, const void* w, const void* b, void* y, int M, int d, float eps, void* hip_stream);
+
+/* y = act(x + bias): act 0 none, 1 quick_gelu (CLIP MLP), 2 gelu-erf (mlp2x_gelu projector, builder.py:33-46). */
+int vdd_bias_act(const void* x, const void* bias, void* y, int64_t M, int d, int act, void* hip_stream);
+
 /* Largest V whose working row stays in LDS; larger V need scores_out or workspace. */
 int vdd_lds_row_capacity(int dtype);
 

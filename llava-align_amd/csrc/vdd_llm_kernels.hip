@@ -1,0 +1,352 @@
+// Decode-step kernels of the branch-batched LLaVA language model for gfx950 (MI355X).
+//
+// They replace what the reference executes, per branch and per token, through HF's eager
+// LlamaModel (experiments/llava/model/language_model/llava_llama.py:88-103 -> transformers
+// LlamaDecoderLayer [ext]).  Rows of one step = (question, branch) pairs, so the weights are
+// streamed from HBM once per step for ALL branches (the reference streams them once per
+// branch: vcd_sample.py:109,163,178).  All tensors bf16, accumulation fp32.
+//
+//   vdd_rmsnorm            h = residual(+delta); y = h * rsqrt(mean h^2 + eps) * w      HBM-bound
+//   vdd_rope_kv_write      RoPE(q,k) at per-row positions; k,v -> per-row KV slot        HBM-bound
+//   vdd_silu_mul           silu(gate) * up                                               HBM-bound
+//   vdd_embed              token embedding gather                                        HBM-bound
+//   vdd_skinny_gemm        Y[M,N] = X[M,K] W[N,K]^T (+R), M <= 64: weight streaming      HBM-bound
+//                          (W read once; MFMA 16x16x32 does the k-reduction)
+//   vdd_decode_attention   one query per (row, head) over a ragged, prefix-shared KV      HBM-bound
+
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+#include "vdd_hip.h"
+
+namespace {
+
+typedef __attribute__((ext_vector_type(8))) short bf16x8_t;   // MFMA A/B fragment: 8 bf16
+typedef __attribute__((ext_vector_type(4))) float f32x4_t;    // MFMA C/D fragment
+
+__device__ __forceinline__ float bf2f(uint32_t b) { return __builtin_bit_cast(float, b << 16); }
+__device__ __forceinline__ uint32_t f2bf(float f) {
+    uint32_t u = __builtin_bit_cast(uint32_t, f);
+    if ((u & 0x7fffffffu) > 0x7f800000u) return (u >> 16) | 0x40u;
+    return (u + 0x7fffu + ((u >> 16) & 1u)) >> 16;
+}
+__device__ __forceinline__ float lo(uint32_t w) { return bf2f(w & 0xFFFFu); }
+__device__ __forceinline__ float hi(uint32_t w) { return __builtin_bit_cast(float, w & 0xFFFF0000u); }
+__device__ __forceinline__ uint32_t pack(float a, float b) { return f2bf(a) | (f2bf(b) << 16); }
+
+__device__ __forceinline__ float wave_sum(float v) {
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o);
+    return v;
+}
+
+// ------------------------------------------------------------------ RMSNorm (+ residual add)
+// One 256-thread block per row; the row stays in registers between the two passes.
+// HF rounding order: h = bf16(resid + delta); y = bf16( bf16(h * rstd) * w ).
+template <int VPT>   // uint4 (8 x bf16) per thread
+__global__ void __launch_bounds__(256) rmsnorm_kernel(const uint16_t* __restrict__ x, const uint16_t* __restrict__ delta,
+                                                      const uint16_t* __restrict__ w, uint16_t* __restrict__ y,
+                                                      uint16_t* __restrict__ resid_out, int d, float eps) {
+    __shared__ float red[4];
+    const int row = blockIdx.x, tid = threadIdx.x;
+    const size_t off = (size_t)row * d;
+    uint4 h[VPT];
+    float ss = 0.f;
+#pragma unroll
+    for (int i = 0; i < VPT; ++i) {
+        const int e = (i * 256 + tid) * 8;
+        if (e < d) {
+            uint4 a = *reinterpret_cast<const uint4*>(x + off + e);
+            if (delta != nullptr) {
+                uint4 b = *reinterpret_cast<const uint4*>(delta + off + e);
+                a.x = pack(lo(a.x) + lo(b.x), hi(a.x) + hi(b.x)); a.y = pack(lo(a.y) + lo(b.y), hi(a.y) + hi(b.y));
+                a.z = pack(lo(a.z) + lo(b.z), hi(a.z) + hi(b.z)); a.w = pack(lo(a.w) + lo(b.w), hi(a.w) + hi(b.w));
+            }
+            if (resid_out != nullptr) *reinterpret_cast<uint4*>(resid_out + off + e) = a;
+            h[i] = a;
+            float f;
+            f = lo(a.x); ss += f * f; f = hi(a.x); ss += f * f; f = lo(a.y); ss += f * f; f = hi(a.y); ss += f * f;
+            f = lo(a.z); ss += f * f; f = hi(a.z); ss += f * f; f = lo(a.w); ss += f * f; f = hi(a.w); ss += f * f;
+        }
+    }
+    ss = wave_sum(ss);
+    if ((tid & 63) == 0) red[tid >> 6] = ss;
+    __syncthreads();
+    const float rstd = rsqrtf((red[0] + red[1] + red[2] + red[3]) / (float)d + eps);
+#pragma unroll
+    for (int i = 0; i < VPT; ++i) {
+        const int e = (i * 256 + tid) * 8;
+        if (e < d) {
+            uint4 a = h[i], g = *reinterpret_cast<const uint4*>(w + e), o;
+            auto nrm = [&](uint32_t hv, uint32_t gv) {
+                float n0 = bf2f(f2bf(lo(hv) * rstd)), n1 = bf2f(f2bf(hi(hv) * rstd));
+                return pack(n0 * lo(gv), n1 * hi(gv));
+            };
+            o.x = nrm(a.x, g.x); o.y = nrm(a.y, g.y); o.z = nrm(a.z, g.z); o.w = nrm(a.w, g.w);
+            *reinterpret_cast<uint4*>(y + off + e) = o;
+        }
+    }
+}
+
+// ------------------------------------------------------------------ RoPE + KV-cache write
+// qkv: [M, (Hq + 2 Hkv) * D] (q | k | v).  One block per row, one 16-lane group per head
+// chunk.  rotate_half pairing (HF Llama): (i, i + D/2).  cos/sin table: fp32 [max_pos, D/2].
+// K/V go to cache[slot][kv_head][pos][D].
+__global__ void __launch_bounds__(256) rope_kv_kernel(const uint16_t* __restrict__ qkv, const int* __restrict__ pos,
+                                                      const int* __restrict__ slot, const float* __restrict__ cs_table,
+                                                      uint16_t* __restrict__ q_out, uint16_t* __restrict__ k_cache,
+                                                      uint16_t* __restrict__ v_cache, int Hq, int Hkv, int D,
+                                                      long long slot_stride, int t_max) {
+    const int row = blockIdx.x, tid = threadIdx.x;
+    const int p = pos[row], s = slot[row];
+    const int half = D / 2;
+    const int nq = Hq * half, nk = Hkv * half;
+    const uint16_t* src = qkv + (size_t)row * (size_t)((Hq + 2 * Hkv) * D);
+    for (int i = tid; i < nq + nk; i += 256) {          // one (head, pair) per iteration
+        const bool is_k = i >= nq;
+        const int j = is_k ? i - nq : i;
+        const int head = j / half, pi = j % half;
+        const uint16_t* hsrc = src + (is_k ? (size_t)Hq * D : 0) + (size_t)head * D;
+        const float c = cs_table[((size_t)p * half + pi) * 2], sn = cs_table[((size_t)p * half + pi) * 2 + 1];
+        const float a = bf2f(hsrc[pi]), b = bf2f(hsrc[pi + half]);
+        const uint16_t r0 = (uint16_t)f2bf(a * c - b * sn), r1 = (uint16_t)f2bf(b * c + a * sn);
+        uint16_t* dst = is_k ? k_cache + (size_t)s * slot_stride + ((size_t)head * t_max + p) * D
+                             : q_out + (size_t)row * Hq * D + (size_t)head * D;
+        dst[pi] = r0; dst[pi + half] = r1;
+    }
+    const uint16_t* vsrc = src + (size_t)(Hq + Hkv) * D;
+    for (int i = tid; i < Hkv * D / 8; i += 256) {
+        const int head = (i * 8) / D, dd = (i * 8) % D;
+        *reinterpret_cast<uint4*>(v_cache + (size_t)s * slot_stride + ((size_t)head * t_max + p) * D + dd) =
+            *reinterpret_cast<const uint4*>(vsrc + (size_t)i * 8);
+    }
+}
+
+// ------------------------------------------------------------------ SiLU(gate) * up
+__global__ void __launch_bounds__(256) silu_mul_kernel(const uint16_t* __restrict__ gu, uint16_t* __restrict__ out,
+                                                       long long M, int F) {
+    const long long n8 = M * (F / 8);
+    for (long long i = (long long)blockIdx.x * 256 + threadIdx.x; i < n8; i += (long long)gridDim.x * 256) {
+        const long long m = i / (F / 8); const int f = (int)(i % (F / 8)) * 8;
+        uint4 g = *reinterpret_cast<const uint4*>(gu + m * 2 * F + f);
+        uint4 u = *reinterpret_cast<const uint4*>(gu + m * 2 * F + F + f);
+        auto act = [](uint32_t gv, uint32_t uv) {
+            float g0 = lo(gv), g1 = hi(gv);
+            float s0 = bf2f(f2bf(g0 / (1.f + __expf(-g0)))), s1 = bf2f(f2bf(g1 / (1.f + __expf(-g1))));
+            return pack(s0 * lo(uv), s1 * hi(uv));
+        };
+        uint4 o; o.x = act(g.x, u.x); o.y = act(g.y, u.y); o.z = act(g.z, u.z); o.w = act(g.w, u.w);
+        *reinterpret_cast<uint4*>(out + m * F + f) = o;
+    }
+}
+
+// ------------------------------------------------------------------ embedding gather
+__global__ void __launch_bounds__(256) embed_kernel(const long long* __restrict__ ids, const uint16_t* __restrict__ table,
+                                                    uint16_t* __restrict__ out, int d) {
+    const int row = blockIdx.x;
+    const long long id = ids[row];
+    for (int e = threadIdx.x * 8; e < d; e += 256 * 8)
+        *reinterpret_cast<uint4*>(out + (size_t)row * d + e) = *reinterpret_cast<const uint4*>(table + (size_t)id * d + e);
+}
+
+// ------------------------------------------------------------------ skinny GEMM (weight streaming)
+// Y[M,N] = X[M,K] * W[N,K]^T (+ R[M,N]).  One 256-thread block owns 16 output columns; its 4
+// waves split K four ways and each streams its quarter of the 16 W rows straight into MFMA B
+// fragments (lane (n = l&15, g = l>>4) holds W[n0+n][k + 8g .. +7]: 16 B, k-contiguous), so W
+// is read from HBM exactly once and never staged.  X fragments (A operand, same lane map over
+// rows) are L2-resident re-reads.  MT = number of 16-row M tiles (M <= 16*MT); the four wave
+// partials are summed through LDS.
+template <int MT>
+__global__ void __launch_bounds__(256) skinny_gemm_kernel(const uint16_t* __restrict__ X, const uint16_t* __restrict__ W,
+                                                          const uint16_t* __restrict__ R, uint16_t* __restrict__ Y,
+                                                          int M, int N, int K, long long ldx, long long ldr, long long ldy) {
+    __shared__ float part[4][MT][64][4];
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int n0 = blockIdx.x * 16;
+    const int ln = lane & 15, g = lane >> 4;
+    const int kq = K / 4;
+    const int kbeg = wave * kq;
+    int nrow = n0 + ln; if (nrow >= N) nrow = N - 1;
+    const uint16_t* wp = W + (size_t)nrow * K + kbeg + g * 8;
+    const uint16_t* xp[MT];
+#pragma unroll
+    for (int t = 0; t < MT; ++t) { int r = t * 16 + ln; if (r >= M) r = M - 1; xp[t] = X + (size_t)r * ldx + kbeg + g * 8; }
+    f32x4_t acc[MT];
+#pragma unroll
+    for (int t = 0; t < MT; ++t) acc[t] = f32x4_t{0.f, 0.f, 0.f, 0.f};
+    constexpr int U = 4;
+    int k = 0;
+    for (; k + 32 * U <= kq; k += 32 * U) {
+        bf16x8_t b[U], a[U][MT];
+#pragma unroll
+        for (int u = 0; u < U; ++u) b[u] = *reinterpret_cast<const bf16x8_t*>(wp + k + 32 * u);
+#pragma unroll
+        for (int u = 0; u < U; ++u)
+#pragma unroll
+            for (int t = 0; t < MT; ++t) a[u][t] = *reinterpret_cast<const bf16x8_t*>(xp[t] + k + 32 * u);
+#pragma unroll
+        for (int u = 0; u < U; ++u)
+#pragma unroll
+            for (int t = 0; t < MT; ++t) acc[t] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a[u][t], b[u], acc[t], 0, 0, 0);
+    }
+    for (; k < kq; k += 32) {
+        bf16x8_t b = *reinterpret_cast<const bf16x8_t*>(wp + k);
+#pragma unroll
+        for (int t = 0; t < MT; ++t) {
+            bf16x8_t a = *reinterpret_cast<const bf16x8_t*>(xp[t] + k);
+            acc[t] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a, b, acc[t], 0, 0, 0);
+        }
+    }
+#pragma unroll
+    for (int t = 0; t < MT; ++t)
+#pragma unroll
+        for (int r = 0; r < 4; ++r) part[wave][t][lane][r] = acc[t][r];
+    __syncthreads();
+    // C/D map of 16x16x32: col = lane & 15, row = (lane >> 4) * 4 + r.  Wave w finishes tile(s) t = w, w+4, ...
+    for (int t = wave; t < MT; t += 4) {
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+            const int row = t * 16 + g * 4 + r, col = n0 + ln;
+            float s = (part[0][t][lane][r] + part[1][t][lane][r]) + (part[2][t][lane][r] + part[3][t][lane][r]);
+            if (row < M && col < N) {
+                float o = bf2f(f2bf(s));
+                if (R != nullptr) o = o + bf2f(R[(size_t)row * ldr + col]);
+                Y[(size_t)row * ldy + col] = (uint16_t)f2bf(o);
+            }
+        }
+    }
+}
+
+// ------------------------------------------------------------------ decode attention
+// One wave per (row, head).  Lane group g = lane>>4 takes keys t = 4i + g, lane j = lane&15 the
+// dims 8j..8j+7: per iteration a wave reads 4 consecutive K rows (1 KiB contiguous) and the 4
+// matching V rows.  Each group runs its own online softmax; the 4 partial states merge at the
+// end.  Context of a row = [prefix slot: tokens 0..plen) ++ [own slot: tokens plen..len): rows
+// that share a prompt prefix (same image + system prompt) point at ONE physical copy.
+struct AttnRow { int slot, len, pslot, plen; };
+
+template <int D>   // head dim 128
+__global__ void __launch_bounds__(256) decode_attn_kernel(const uint16_t* __restrict__ q, const uint16_t* __restrict__ kc,
+                                                          const uint16_t* __restrict__ vc, const AttnRow* __restrict__ rows,
+                                                          uint16_t* __restrict__ out, int H, int Hkv, long long slot_stride,
+                                                          int t_max, float scale) {
+    static_assert(D == 128, "lane map assumes 16 lanes x 8 dims");
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int head = blockIdx.x * 4 + wave, row = blockIdx.y;
+    if (head >= H) return;
+    const int g = lane >> 4, j = lane & 15;
+    const AttnRow ar = rows[row];
+    const int kvh = head / (H / Hkv);
+    uint4 qv = *reinterpret_cast<const uint4*>(q + ((size_t)row * H + head) * D + j * 8);
+    float qf[8] = {lo(qv.x) * scale, hi(qv.x) * scale, lo(qv.y) * scale, hi(qv.y) * scale,
+                   lo(qv.z) * scale, hi(qv.z) * scale, lo(qv.w) * scale, hi(qv.w) * scale};
+    float m = -INFINITY, l = 0.f, acc[8] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+    auto span = [&](int slot, int t0, int t1) {
+        const size_t base = (size_t)slot * slot_stride + (size_t)kvh * t_max * D;
+        for (int t = t0 + g; t < t1; t += 4) {     // trip counts differ per 16-lane group; shuffles stay inside a group
+            uint4 kv = *reinterpret_cast<const uint4*>(kc + base + (size_t)t * D + j * 8);
+            uint4 vv = *reinterpret_cast<const uint4*>(vc + base + (size_t)t * D + j * 8);
+            float s = qf[0] * lo(kv.x) + qf[1] * hi(kv.x) + qf[2] * lo(kv.y) + qf[3] * hi(kv.y)
+                    + qf[4] * lo(kv.z) + qf[5] * hi(kv.z) + qf[6] * lo(kv.w) + qf[7] * hi(kv.w);
+            s += __shfl_xor(s, 1); s += __shfl_xor(s, 2); s += __shfl_xor(s, 4); s += __shfl_xor(s, 8);
+            {
+                const float mn = fmaxf(m, s);
+                const float corr = __expf(m - mn), p = __expf(s - mn);
+                l = l * corr + p;
+                acc[0] = acc[0] * corr + p * lo(vv.x); acc[1] = acc[1] * corr + p * hi(vv.x);
+                acc[2] = acc[2] * corr + p * lo(vv.y); acc[3] = acc[3] * corr + p * hi(vv.y);
+                acc[4] = acc[4] * corr + p * lo(vv.z); acc[5] = acc[5] * corr + p * hi(vv.z);
+                acc[6] = acc[6] * corr + p * lo(vv.w); acc[7] = acc[7] * corr + p * hi(vv.w);
+                m = mn;
+            }
+        }
+    };
+    if (ar.plen > 0) span(ar.pslot, 0, ar.plen);
+    span(ar.slot, ar.plen, ar.len);
+    // merge the 4 lane groups (xor 16, 32)
+#pragma unroll
+    for (int o = 16; o <= 32; o <<= 1) {
+        const float mo = __shfl_xor(m, o), lo_ = __shfl_xor(l, o);
+        const float mn = fmaxf(m, mo);
+        const float c0 = (m == -INFINITY) ? 0.f : __expf(m - mn), c1 = (mo == -INFINITY) ? 0.f : __expf(mo - mn);
+        l = l * c0 + lo_ * c1;
+#pragma unroll
+        for (int e = 0; e < 8; ++e) { const float ao = __shfl_xor(acc[e], o); acc[e] = acc[e] * c0 + ao * c1; }
+        m = mn;
+    }
+    if (g == 0) {
+        const float inv = 1.f / l;
+        uint4 o;
+        o.x = pack(acc[0] * inv, acc[1] * inv); o.y = pack(acc[2] * inv, acc[3] * inv);
+        o.z = pack(acc[4] * inv, acc[5] * inv); o.w = pack(acc[6] * inv, acc[7] * inv);
+        *reinterpret_cast<uint4*>(out + ((size_t)row * H + head) * D + j * 8) = o;
+    }
+}
+
+inline int ok(hipError_t) { return hipGetLastError() == hipSuccess ? VDD_OK : VDD_ERR_LAUNCH; }
+
+}  // namespace
+
+extern "C" {
+
+int vdd_rmsnorm(const void* x, const void* delta, const void* w, void* y, void* resid_out, int M, int d, float eps, void* stream) {
+    if (M <= 0) return VDD_OK;
+    if (!x || !w || !y || d % 8 != 0 || d > 8192) return VDD_ERR_INVALID_ARG;
+    hipStream_t st = (hipStream_t)stream;
+    auto X = (const uint16_t*)x; auto Dl = (const uint16_t*)delta; auto Wt = (const uint16_t*)w; auto Y = (uint16_t*)y; auto Ro = (uint16_t*)resid_out;
+    const int vpt = (d / 8 + 255) / 256;
+    if (vpt <= 1) hipLaunchKernelGGL(rmsnorm_kernel<1>, dim3(M), dim3(256), 0, st, X, Dl, Wt, Y, Ro, d, eps);
+    else if (vpt <= 2) hipLaunchKernelGGL(rmsnorm_kernel<2>, dim3(M), dim3(256), 0, st, X, Dl, Wt, Y, Ro, d, eps);
+    else hipLaunchKernelGGL(rmsnorm_kernel<4>, dim3(M), dim3(256), 0, st, X, Dl, Wt, Y, Ro, d, eps);
+    return ok(hipSuccess);
+}
+
+int vdd_rope_kv_write(const void* qkv, const int* pos, const int* slot, const float* cos_sin, void* q_out, void* k_cache,
+                      void* v_cache, int M, int Hq, int Hkv, int D, int64_t slot_stride, int t_max, void* stream) {
+    if (M <= 0) return VDD_OK;
+    if (!qkv || !pos || !slot || !cos_sin || !q_out || !k_cache || !v_cache || D % 8 != 0) return VDD_ERR_INVALID_ARG;
+    hipLaunchKernelGGL(rope_kv_kernel, dim3(M), dim3(256), 0, (hipStream_t)stream, (const uint16_t*)qkv, pos, slot, cos_sin,
+                       (uint16_t*)q_out, (uint16_t*)k_cache, (uint16_t*)v_cache, Hq, Hkv, D, (long long)slot_stride, t_max);
+    return ok(hipSuccess);
+}
+
+int vdd_silu_mul(const void* gate_up, void* out, int64_t M, int F, void* stream) {
+    if (M <= 0) return VDD_OK;
+    if (!gate_up || !out || F % 8 != 0) return VDD_ERR_INVALID_ARG;
+    long long n8 = (long long)M * (F / 8);
+    int blocks = (int)((n8 + 255) / 256); if (blocks > 4096) blocks = 4096;
+    hipLaunchKernelGGL(silu_mul_kernel, dim3(blocks), dim3(256), 0, (hipStream_t)stream, (const uint16_t*)gate_up, (uint16_t*)out, (long long)M, F);
+    return ok(hipSuccess);
+}
+
+int vdd_embed(const int64_t* ids, const void* table, void* out, int M, int d, void* stream) {
+    if (M <= 0) return VDD_OK;
+    if (!ids || !table || !out || d % 8 != 0) return VDD_ERR_INVALID_ARG;
+    hipLaunchKernelGGL(embed_kernel, dim3(M), dim3(256), 0, (hipStream_t)stream, (const long long*)ids, (const uint16_t*)table, (uint16_t*)out, d);
+    return ok(hipSuccess);
+}
+
+int vdd_skinny_gemm(const void* X, const void* W, const void* R, void* Y, int M, int N, int K, int64_t ldx, int64_t ldr,
+                    int64_t ldy, void* stream) {
+    if (M <= 0 || N <= 0) return VDD_OK;
+    if (!X || !W || !Y || K % 128 != 0 || M > 64 || (ldx % 8) != 0) return VDD_ERR_INVALID_ARG;
+    hipStream_t st = (hipStream_t)stream;
+    dim3 grid((N + 15) / 16), block(256);
+    auto x = (const uint16_t*)X; auto w = (const uint16_t*)W; auto r = (const uint16_t*)R; auto y = (uint16_t*)Y;
+    if (M <= 16) hipLaunchKernelGGL(skinny_gemm_kernel<1>, grid, block, 0, st, x, w, r, y, M, N, K, (long long)ldx, (long long)ldr, (long long)ldy);
+    else if (M <= 32) hipLaunchKernelGGL(skinny_gemm_kernel<2>, grid, block, 0, st, x, w, r, y, M, N, K, (long long)ldx, (long long)ldr, (long long)ldy);
+    else hipLaunchKernelGGL(skinny_gemm_kernel<4>, grid, block, 0, st, x, w, r, y, M, N, K, (long long)ldx, (long long)ldr, (long long)ldy);
+    return ok(hipSuccess);
+}
+
+int vdd_decode_attention(const void* q, const void* k_cache, const void* v_cache, const int32_t* rows, void* out, int M, int H,
+                         int Hkv, int D, int64_t slot_stride, int t_max, float scale, void* stream) {
+    if (M <= 0) return VDD_OK;
+    if (!q || !k_cache || !v_cache || !rows || !out || D != 128 || H % Hkv != 0) return VDD_ERR_INVALID_ARG;
+    hipLaunchKernelGGL(decode_attn_kernel<128>, dim3((H + 3) / 4, M), dim3(256), 0, (hipStream_t)stream, (const uint16_t*)q,
+                       (const uint16_t*)k_cache, (const uint16_t*)v_cache, (const AttnRow*)rows, (uint16_t*)out, H, Hkv,
+                       (long long)slot_stride, t_max, scale);
+    return ok(hipSuccess);
+}
+
+}  // extern "C"

@@ -1,0 +1,146 @@
+"""torch-tensor front-ends of the C-ABI model kernels (include/vdd_hip.h).  torch only
+provides device memory and the stream; every op here is a hand-written HIP kernel and
+raises if the library is missing (no eager fallback)."""
+from __future__ import annotations
+
+import ctypes as C
+from typing import Optional
+
+import torch
+
+from . import _lib
+
+_P, _I, _L, _F = C.c_void_p, C.c_int, C.c_int64, C.c_float
+_SIGS = {
+    "vdd_rmsnorm": [_P, _P, _P, _P, _P, _I, _I, _F, _P],
+    "vdd_rope_kv_write": [_P, _P, _P, _P, _P, _P, _P, _I, _I, _I, _I, _L, _I, _P],
+    "vdd_silu_mul": [_P, _P, _L, _I, _P],
+    "vdd_embed": [_P, _P, _P, _I, _I, _P],
+    "vdd_skinny_gemm": [_P, _P, _P, _P, _I, _I, _I, _L, _L, _L, _P],
+    "vdd_decode_attention": [_P, _P, _P, _P, _P, _I, _I, _I, _I, _L, _I, _F, _P],
+    "vdd_flash_attention": [_P, _P, _P, _P, _P, _I, _I, _I, _I, _I, _L, _I, _F, _I, _P],
+    "vdd_layernorm": [_P, _P, _P, _P, _I, _I, _F, _P],
+    "vdd_bias_act": [_P, _P, _P, _L, _I, _I, _P],
+}
+_bound = False
+
+
+def _lib_ready():
+    global _bound
+    lib = _lib.load_lib()
+    if not _bound:
+        for name, sig in _SIGS.items():
+            if hasattr(lib, name):
+                fn = getattr(lib, name)
+                fn.argtypes, fn.restype = sig, C.c_int
+        _bound = True
+    return lib
+
+
+def _st(t: torch.Tensor):
+    return torch.cuda.current_stream(t.device).cuda_stream
+
+
+def _bf16(*ts):
+    for t in ts:
+        if t is not None and (t.dtype != torch.bfloat16 or not t.is_cuda):
+            raise ValueError("model kernels take bf16 device tensors")
+
+
+def rmsnorm(x, w, eps, delta=None, resid_out=None, out=None):
+    """h = x (+ delta); resid_out <- h; returns h * rsqrt(mean h^2 + eps) * w.   x: [M, d]"""
+    _bf16(x, w, delta, resid_out)
+    M, d = x.shape
+    out = torch.empty_like(x) if out is None else out
+    _lib.check(_lib_ready().vdd_rmsnorm(x.data_ptr(), delta.data_ptr() if delta is not None else None, w.data_ptr(),
+                                        out.data_ptr(), resid_out.data_ptr() if resid_out is not None else None, M, d, eps, _st(x)))
+    return out
+
+
+def rope_kv_write(qkv, pos, slot, cos_sin, k_cache, v_cache, Hq, Hkv, D, q_out=None):
+    """qkv [M, (Hq+2Hkv)*D]; pos/slot int32 [M]; caches [n_slots, Hkv, t_max, D].  Returns rotated q [M, Hq*D]."""
+    _bf16(qkv, k_cache, v_cache)
+    M = qkv.shape[0]
+    q_out = torch.empty(M, Hq * D, dtype=qkv.dtype, device=qkv.device) if q_out is None else q_out
+    _lib.check(_lib_ready().vdd_rope_kv_write(qkv.data_ptr(), pos.data_ptr(), slot.data_ptr(), cos_sin.data_ptr(), q_out.data_ptr(),
+                                              k_cache.data_ptr(), v_cache.data_ptr(), M, Hq, Hkv, D, k_cache.stride(0),
+                                              k_cache.shape[2], _st(qkv)))
+    return q_out
+
+
+def silu_mul(gate_up, out=None):
+    _bf16(gate_up)
+    M, F2 = gate_up.shape
+    out = torch.empty(M, F2 // 2, dtype=gate_up.dtype, device=gate_up.device) if out is None else out
+    _lib.check(_lib_ready().vdd_silu_mul(gate_up.data_ptr(), out.data_ptr(), M, F2 // 2, _st(gate_up)))
+    return out
+
+
+def embed(ids, table, out=None):
+    _bf16(table)
+    M, d = ids.numel(), table.shape[1]
+    out = torch.empty(M, d, dtype=table.dtype, device=table.device) if out is None else out
+    _lib.check(_lib_ready().vdd_embed(ids.data_ptr(), table.data_ptr(), out.data_ptr(), M, d, _st(table)))
+    return out
+
+
+def skinny_gemm(x, w, resid=None, out=None):
+    """x [M<=64, K] @ w[N, K]^T (+ resid [M, N]) -> [M, N]; streams w from HBM exactly once."""
+    _bf16(x, w, resid)
+    M, K = x.shape
+    N = w.shape[0]
+    out = torch.empty(M, N, dtype=x.dtype, device=x.device) if out is None else out
+    _lib.check(_lib_ready().vdd_skinny_gemm(x.data_ptr(), w.data_ptr(), resid.data_ptr() if resid is not None else None,
+                                            out.data_ptr(), M, N, K, x.stride(0), resid.stride(0) if resid is not None else 0,
+                                            out.stride(0), _st(x)))
+    return out
+
+
+def linear(x, w, out=None):
+    """Row-batched projection: hand-written weight-streaming MFMA kernel up to 64 rows (the decode
+    regime), the vendor GEMM library (hipBLASLt via torch.matmul) for the large-M prefill GEMMs."""
+    if x.shape[0] <= 64 and x.shape[1] % 128 == 0:
+        return skinny_gemm(x, w, out=out)
+    return torch.matmul(x, w.t(), out=out) if out is not None else torch.matmul(x, w.t())
+
+
+def decode_attention(q, k_cache, v_cache, rows, H, Hkv, D, out=None):
+    """q [M, H*D]; rows int32 [M, 4] = (slot, len, prefix_slot, prefix_len)."""
+    _bf16(q, k_cache, v_cache)
+    M = q.shape[0]
+    out = torch.empty_like(q) if out is None else out
+    _lib.check(_lib_ready().vdd_decode_attention(q.data_ptr(), k_cache.data_ptr(), v_cache.data_ptr(), rows.data_ptr(), out.data_ptr(),
+                                                 M, H, Hkv, D, k_cache.stride(0), k_cache.shape[2], D ** -0.5, _st(q)))
+    return out
+
+
+def flash_attention(q, k_cache, v_cache, seqs, n_seq, max_tq, H, Hkv, D, causal=True, out=None):
+    """Prefill attention.  q [Ttot, H*D] packed by sequence; seqs int32 [n_seq, 6] =
+    (q_row0, Tq, pos0, slot, prefix_slot, prefix_len): query i of a sequence sits at position pos0+i and
+    attends keys [0, pos0+i] (causal) or [0, pos0+Tq) (non-causal) of its slot / prefix slot."""
+    _bf16(q, k_cache, v_cache)
+    out = torch.empty_like(q) if out is None else out
+    _lib.check(_lib_ready().vdd_flash_attention(q.data_ptr(), k_cache.data_ptr(), v_cache.data_ptr(), seqs.data_ptr(), out.data_ptr(),
+                                                n_seq, max_tq, H, Hkv, D, k_cache.stride(0), k_cache.shape[2], D ** -0.5,
+                                                1 if causal else 0, _st(q)))
+    return out
+
+
+def layernorm(x, w, b, eps, out=None):
+    _bf16(x, w, b)
+    M, d = x.shape
+    out = torch.empty_like(x) if out is None else out
+    _lib.check(_lib_ready().vdd_layernorm(x.data_ptr(), w.data_ptr(), b.data_ptr(), out.data_ptr(), M, d, eps, _st(x)))
+    return out
+
+
+ACT_NONE, ACT_QUICK_GELU, ACT_GELU = 0, 1, 2
+
+
+def bias_act(x, bias, act=ACT_NONE, out=None):
+    """out = act(x + bias) rowwise; bias may be None."""
+    _bf16(x, bias)
+    M, d = x.shape
+    out = torch.empty_like(x) if out is None else out
+    _lib.check(_lib_ready().vdd_bias_act(x.data_ptr(), bias.data_ptr() if bias is not None else None, out.data_ptr(), M, d, act, _st(x)))
+    return out

@@ -1,0 +1,160 @@
+"""Numerics of the hand-written model kernels vs plain PyTorch fp32 references of the same op
+(bf16 inputs, so tolerances are bf16-rounding sized and written next to each check)."""
+import math
+
+import pytest
+import torch
+
+pytestmark = pytest.mark.gpu
+DEV = "cuda:0"
+
+
+def ops():
+    from llava_align_amd import ops as O
+    return O
+
+
+def bf(*shape, scale=1.0, seed=0):
+    g = torch.Generator(device=DEV).manual_seed(seed)
+    return (torch.randn(*shape, device=DEV, generator=g) * scale).to(torch.bfloat16)
+
+
+@pytest.mark.parametrize("M,d", [(1, 4096), (7, 4096), (3, 5120), (5, 1024), (2, 256)])
+def test_rmsnorm(M, d):
+    O = ops()
+    x, dl, w = bf(M, d, seed=1), bf(M, d, seed=2), bf(d, seed=3) * 0.1 + 1
+    ro = torch.empty_like(x)
+    y = O.rmsnorm(x, w, 1e-5, delta=dl, resid_out=ro)
+    h = (x.float() + dl.float()).to(torch.bfloat16)
+    assert torch.equal(ro, h)
+    ref = (h.float() * torch.rsqrt(h.float().pow(2).mean(-1, keepdim=True) + 1e-5)).to(torch.bfloat16).float() * w.float()
+    assert torch.allclose(y.float(), ref, rtol=1.6e-2, atol=1e-3)       # 2 bf16 roundings
+    y2 = O.rmsnorm(x, w, 1e-5)
+    ref2 = (x.float() * torch.rsqrt(x.float().pow(2).mean(-1, keepdim=True) + 1e-5)).to(torch.bfloat16).float() * w.float()
+    assert torch.allclose(y2.float(), ref2, rtol=1.6e-2, atol=1e-3)
+
+
+def rope_table(max_pos, D, theta=10000.0):
+    inv = 1.0 / (theta ** (torch.arange(0, D, 2, dtype=torch.float32) / D))
+    ang = torch.arange(max_pos, dtype=torch.float32)[:, None] * inv[None, :]
+    return torch.stack([ang.cos(), ang.sin()], dim=-1).contiguous().to(DEV)      # [max_pos, D/2, 2]
+
+
+def test_rope_kv_write():
+    O = ops()
+    M, H, Hkv, D, T, S = 6, 8, 4, 128, 32, 5
+    qkv = bf(M, (H + 2 * Hkv) * D, seed=4)
+    pos = torch.tensor([0, 3, 31, 7, 7, 12], dtype=torch.int32, device=DEV)
+    slot = torch.tensor([0, 1, 2, 3, 4, 0], dtype=torch.int32, device=DEV)
+    kc = torch.zeros(S, Hkv, T, D, dtype=torch.bfloat16, device=DEV)
+    vc = torch.zeros_like(kc)
+    cs = rope_table(64, D)
+    q = O.rope_kv_write(qkv, pos, slot, cs, kc, vc, H, Hkv, D).view(M, H, D)
+
+    def rot(x, p):      # x [.., D]
+        c, s = cs[p.long(), :, 0], cs[p.long(), :, 1]
+        a, b = x[..., : D // 2].float(), x[..., D // 2:].float()
+        return torch.cat([a * c[:, None] - b * s[:, None], b * c[:, None] + a * s[:, None]], -1)
+    qr = rot(qkv[:, : H * D].view(M, H, D), pos)
+    kr = rot(qkv[:, H * D: (H + Hkv) * D].view(M, Hkv, D), pos)
+    assert torch.allclose(q.float(), qr, rtol=8e-3, atol=8e-3)
+    for m in range(M):
+        assert torch.allclose(kc[slot[m], :, pos[m]].float(), kr[m], rtol=8e-3, atol=8e-3)
+        assert torch.equal(vc[slot[m], :, pos[m]], qkv[m, (H + Hkv) * D:].view(Hkv, D))
+    assert int((kc != 0).any(-1).sum()) == M * Hkv      # nothing else touched
+
+
+def test_silu_mul_and_embed():
+    O = ops()
+    gu = bf(5, 2 * 11008, seed=5)
+    y = O.silu_mul(gu)
+    g, u = gu[:, :11008].float(), gu[:, 11008:].float()
+    ref = torch.nn.functional.silu(g).to(torch.bfloat16).float() * u
+    assert torch.allclose(y.float(), ref, rtol=1.6e-2, atol=1e-3)
+    table = bf(1000, 4096, seed=6)
+    ids = torch.tensor([0, 999, 5, 5, 17], device=DEV)
+    assert torch.equal(O.embed(ids, table), table[ids])
+
+
+@pytest.mark.parametrize("M,N,K", [(1, 4096, 4096), (2, 12288, 4096), (3, 4096, 11008), (16, 4096, 4096), (17, 32000, 4096),
+                                    (33, 22016, 4096), (64, 4096, 11008), (5, 1000, 256), (4, 40, 128)])
+def test_skinny_gemm(M, N, K):
+    O = ops()
+    x, w = bf(M, K, seed=7), bf(N, K, scale=0.02, seed=8)
+    r = bf(M, N, seed=9)
+    y = O.skinny_gemm(x, w)
+    ref = x.float() @ w.float().t()
+    tol = 2e-2 * ref.abs().max().item()
+    assert (y.float() - ref).abs().max().item() <= tol          # fp32 accumulate, one bf16 rounding (+ ordering)
+    y2 = O.skinny_gemm(x, w, resid=r)
+    ref2 = ref.to(torch.bfloat16).float() + r.float()
+    assert (y2.float() - ref2).abs().max().item() <= 2e-2 * ref2.abs().max().item()
+    # strided input view (rows of a bigger buffer)
+    big = bf(M, K + 128, seed=10)
+    y3 = O.skinny_gemm(big[:, :K], w)
+    assert (y3.float() - big[:, :K].float() @ w.float().t()).abs().max().item() <= tol
+
+
+def attn_ref(q, K, V):      # q [H, D], K/V [H, T, D] fp32
+    s = torch.einsum("hd,htd->ht", q, K) / math.sqrt(q.shape[-1])
+    return torch.einsum("ht,htd->hd", s.softmax(-1), V)
+
+
+def test_decode_attention_ragged_and_prefix_shared():
+    O = ops()
+    H, Hkv, D, T, S = 8, 4, 128, 700, 6
+    kc, vc = bf(S, Hkv, T, D, seed=11), bf(S, Hkv, T, D, seed=12)
+    rows = torch.tensor([[0, 1, 0, 0], [1, 4, 0, 0], [2, 37, 0, 0], [3, 700, 0, 0],      # own slot only
+                         [4, 650, 5, 611], [3, 620, 5, 611], [1, 5, 2, 4]], dtype=torch.int32, device=DEV)
+    M = rows.shape[0]
+    q = bf(M, H * D, seed=13)
+    out = O.decode_attention(q, kc, vc, rows, H, Hkv, D).view(M, H, D)
+    rep = H // Hkv
+    for m, (slot, ln, ps, pl) in enumerate(rows.tolist()):
+        K = torch.cat([kc[ps, :, :pl], kc[slot, :, pl:ln]], 1).float().repeat_interleave(rep, 0)
+        V = torch.cat([vc[ps, :, :pl], vc[slot, :, pl:ln]], 1).float().repeat_interleave(rep, 0)
+        ref = attn_ref(q[m].view(H, D).float(), K, V)
+        assert torch.allclose(out[m].float(), ref, rtol=2e-2, atol=2e-2), m
+
+
+@pytest.mark.parametrize("D,H,Hkv,causal", [(128, 4, 4, True), (128, 8, 2, True), (64, 4, 4, False)])
+def test_flash_attention_prefill(D, H, Hkv, causal):
+    """Packed sequences, ragged lengths, a sequence that continues a shared prefix held in another slot."""
+    O = ops()
+    T, S = 700, 4
+    kc, vc = bf(S, Hkv, T, D, seed=21), bf(S, Hkv, T, D, seed=22)
+    # (q_row0, Tq, pos0, slot, pslot, plen)
+    seqs = [(0, 100, 0, 0, 0, 0), (100, 1, 0, 1, 0, 0), (101, 65, 0, 2, 0, 0), (166, 30, 611, 3, 0, 611)] if causal else \
+           [(0, 577, 0, 0, 0, 0), (577, 33, 0, 1, 0, 0)]
+    Ttot = sum(s[1] for s in seqs)
+    q = bf(Ttot, H * D, seed=23)
+    sd = torch.tensor(seqs, dtype=torch.int32, device=DEV)
+    out = O.flash_attention(q, kc, vc, sd, len(seqs), max(s[1] for s in seqs), H, Hkv, D, causal=causal).view(Ttot, H, D)
+    rep = H // Hkv
+    for (r0, Tq, p0, slot, ps, pl) in seqs:
+        Tk = p0 + Tq
+        K = torch.cat([kc[ps, :, :pl], kc[slot, :, pl:Tk]], 1).float().repeat_interleave(rep, 0)     # [H, Tk, D]
+        V = torch.cat([vc[ps, :, :pl], vc[slot, :, pl:Tk]], 1).float().repeat_interleave(rep, 0)
+        Q = q[r0:r0 + Tq].view(Tq, H, D).float().transpose(0, 1)                                     # [H, Tq, D]
+        s = Q @ K.transpose(1, 2) / math.sqrt(D)
+        if causal:
+            mask = torch.arange(Tk, device=DEV)[None, :] > (p0 + torch.arange(Tq, device=DEV))[:, None]
+            s = s.masked_fill(mask[None], -float("inf"))
+        ref = (s.softmax(-1) @ V).transpose(0, 1)
+        got = out[r0:r0 + Tq].float()
+        assert torch.allclose(got, ref, rtol=2e-2, atol=2e-2), (r0, (got - ref).abs().max().item())
+
+
+def test_layernorm_and_bias_act():
+    O = ops()
+    x, w, b = bf(9, 1024, seed=31), bf(1024, seed=32) * 0.1 + 1, bf(1024, seed=33) * 0.1
+    y = O.layernorm(x, w, b, 1e-5)
+    ref = torch.nn.functional.layer_norm(x.float(), (1024,), w.float(), b.float(), 1e-5)
+    assert torch.allclose(y.float(), ref, rtol=1e-2, atol=1e-2)
+    z = bf(7, 4096, seed=34)
+    bias = bf(4096, seed=35)
+    zb = (z.float() + bias.float()).to(torch.bfloat16).float()
+    assert torch.allclose(O.bias_act(z, bias, O.ACT_QUICK_GELU).float(), zb * torch.sigmoid(1.702 * zb), rtol=1e-2, atol=1e-2)
+    assert torch.allclose(O.bias_act(z, bias, O.ACT_GELU).float(), torch.nn.functional.gelu(zb), rtol=1e-2, atol=1e-2)
+    assert torch.equal(O.bias_act(z, bias, O.ACT_NONE), zb.to(torch.bfloat16))
+    assert torch.equal(O.bias_act(z, None, O.ACT_NONE), z)
