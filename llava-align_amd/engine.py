@@ -1,0 +1,573 @@
+"""Branch-batched LLaVA-1.5 generation engine for MI355X.
+
+What the reference does per question (experiments/eval/calibrate/llava_calibrate.py:161-177 ->
+vcd_utils/vcd_sample.py:93-299): B=1, one full eager forward per branch per token (2 for
+use_dd_unk, 3 for both), every forward re-reading all weights, the CLIP tower re-run for every
+question although POPE asks 6 questions per image.
+
+What this engine does instead (same decoding semantics, same kwargs):
+  * many questions in flight; rows of a step = (question, branch) pairs, so the weights stream
+    from HBM once per token for ALL questions and branches;
+  * ViT + projector features cached per image;
+  * prompt-prefix KV sharing: questions with the same [system prompt + image] prefix (and all
+    image-free branches, whose prefix is [system prompt + <unk>]) prefill that prefix once; the
+    attention kernels read [prefix slot | own slot];
+  * lm_head only on last positions (the reference computes logits for all ~635, :103);
+  * the per-step tail is the fused vdd_contrast_sample kernel; token/position/length state
+    stays on the device and the decode step is replayed as a HIP graph.
+
+Reference-compat details: <unk> is ONE token (#3), so image-free branches are
+575 positions shorter; the VCD branch (images_cd) contributes its own logits at step 0 only and
+c == v afterwards (#1); use_dd alone or with use_dd_unk adds the image-token-dropped branch.
+
+Every compute op is a hand-written HIP kernel (ops.py) except the large-M prefill GEMMs, which
+go to hipBLASLt through torch.matmul (a plain library GEMM).  bf16 storage, fp32 accumulation.
+"""
+from __future__ import annotations
+
+import math
+from dataclasses import dataclass, field
+from typing import Dict, List, Optional, Sequence
+
+import torch
+
+from . import ops
+from .sampling import WarpSpec, contrast_sample
+
+IMAGE_TOKEN_INDEX = -200   # experiments/llava/constants.py:8
+
+
+# ------------------------------------------------------------------ configs
+@dataclass
+class LMConfig:
+    d: int = 4096
+    n_layers: int = 32
+    n_heads: int = 32
+    n_kv_heads: int = 32
+    head_dim: int = 128
+    ffn: int = 11008
+    vocab: int = 32000
+    rope_theta: float = 10000.0
+    eps: float = 1e-5
+    max_pos: int = 4096
+
+
+@dataclass
+class VisionConfig:
+    image: int = 336
+    patch: int = 14
+    width: int = 1024
+    layers: int = 24
+    select_layer: int = -2          # clip_encoder.py:29-37: hidden_states[-2], CLS dropped
+    heads: int = 16
+    mlp: int = 4096
+    eps: float = 1e-5
+
+    @property
+    def n_patches(self):
+        return (self.image // self.patch) ** 2
+
+    @property
+    def run_layers(self):           # hidden_states[-2] is the output of layer `layers - 1` (1-based), i.e. skip the last
+        return self.layers + 1 + self.select_layer
+
+
+@dataclass
+class LlavaConfig:
+    lm: LMConfig = field(default_factory=LMConfig)
+    vision: VisionConfig = field(default_factory=VisionConfig)
+    name: str = "llava-1.5-7b"
+
+
+def preset(name: str) -> LlavaConfig:
+    if name == "llava-1.5-7b":
+        return LlavaConfig(LMConfig(), VisionConfig(), name)
+    if name == "llava-1.5-13b":
+        return LlavaConfig(LMConfig(d=5120, n_layers=40, n_heads=40, n_kv_heads=40, ffn=13824), VisionConfig(), name)
+    if name == "tiny":          # test-sized: same structure, every kernel path exercised
+        return LlavaConfig(LMConfig(d=256, n_layers=2, n_heads=2, n_kv_heads=2, ffn=512, vocab=1000, max_pos=512),
+                           VisionConfig(image=56, patch=14, width=128, layers=3, heads=2, mlp=256), name)
+    raise KeyError(name)
+
+
+# ------------------------------------------------------------------ weights
+class LlavaWeights:
+    """Flat container of bf16 device tensors.  `random()` draws N(0, 0.02) (no
+    checkpoints exist on either box); `from_state_dict()` maps HF LLaVA-1.5 parameter names."""
+
+    def __init__(self, cfg: LlavaConfig, device):
+        self.cfg, self.device = cfg, torch.device(device)
+        self.t: Dict[str, torch.Tensor] = {}
+
+    @staticmethod
+    def random(cfg: LlavaConfig, device, seed: int = 0, std: float = 0.02) -> "LlavaWeights":
+        w = LlavaWeights(cfg, device)
+        g = torch.Generator(device=device).manual_seed(seed)
+
+        def rnd(*shape, s=std):
+            return (torch.randn(*shape, device=device, generator=g, dtype=torch.float32) * s).to(torch.bfloat16)
+
+        def ones(n):
+            return (1.0 + torch.randn(n, device=device, generator=g) * 0.02).to(torch.bfloat16)
+        lm, v = cfg.lm, cfg.vision
+        qkv_out = (lm.n_heads + 2 * lm.n_kv_heads) * lm.head_dim
+        w.t["embed"] = rnd(lm.vocab, lm.d)
+        for i in range(lm.n_layers):
+            p = f"l{i}."
+            w.t[p + "ln1"], w.t[p + "ln2"] = ones(lm.d), ones(lm.d)
+            w.t[p + "wqkv"] = rnd(qkv_out, lm.d)
+            w.t[p + "wo"] = rnd(lm.d, lm.n_heads * lm.head_dim)
+            w.t[p + "wgu"] = rnd(2 * lm.ffn, lm.d)
+            w.t[p + "wd"] = rnd(lm.d, lm.ffn)
+        w.t["norm"] = ones(lm.d)
+        w.t["lm_head"] = rnd(lm.vocab, lm.d)
+        pd = 3 * v.patch * v.patch
+        pd_pad = (pd + 7) // 8 * 8
+        pw = torch.zeros(v.width, pd_pad, dtype=torch.bfloat16, device=device)
+        pw[:, :pd] = rnd(v.width, pd)
+        w.t["v.patch"] = pw                                      # conv14x14/stride14 as a [width, 588(+pad)] GEMM
+        w.t["v.cls"], w.t["v.pos"] = rnd(v.width), rnd(v.n_patches + 1, v.width)
+        w.t["v.pre_ln.w"], w.t["v.pre_ln.b"] = ones(v.width), rnd(v.width)
+        for i in range(v.run_layers):
+            p = f"v{i}."
+            for ln in ("ln1", "ln2"):
+                w.t[p + ln + ".w"], w.t[p + ln + ".b"] = ones(v.width), rnd(v.width)
+            w.t[p + "wqkv"], w.t[p + "bqkv"] = rnd(3 * v.width, v.width), rnd(3 * v.width)
+            w.t[p + "wo"], w.t[p + "bo"] = rnd(v.width, v.width), rnd(v.width)
+            w.t[p + "fc1"], w.t[p + "b1"] = rnd(v.mlp, v.width), rnd(v.mlp)
+            w.t[p + "fc2"], w.t[p + "b2"] = rnd(v.width, v.mlp), rnd(v.width)
+        w.t["mm.w1"], w.t["mm.b1"] = rnd(lm.d, v.width), rnd(lm.d)        # mlp2x_gelu (builder.py:33-46)
+        w.t["mm.w2"], w.t["mm.b2"] = rnd(lm.d, lm.d), rnd(lm.d)
+        return w
+
+    def nbytes(self) -> int:
+        return sum(t.numel() * t.element_size() for t in self.t.values())
+
+    def lm_stream_bytes(self) -> int:
+        """Bytes a decode step must stream: every LM weight except the embedding table (gathered)."""
+        return sum(t.numel() * 2 for k, t in self.t.items()
+                   if (k.startswith("l") and k[1].isdigit()) or k in ("norm", "lm_head"))
+
+
+def rope_table(lm: LMConfig, device) -> torch.Tensor:
+    inv = 1.0 / (lm.rope_theta ** (torch.arange(0, lm.head_dim, 2, dtype=torch.float32) / lm.head_dim))
+    ang = torch.arange(lm.max_pos, dtype=torch.float32)[:, None] * inv[None, :]
+    return torch.stack([ang.cos(), ang.sin()], dim=-1).contiguous().to(device)
+
+
+# ------------------------------------------------------------------ vision tower + projector
+class VisionTower:
+    """CLIP ViT-L/14-336 forward up to hidden_states[select_layer], CLS dropped, then the
+    mlp2x_gelu projector (llava_arch.py:82-85, clip_encoder.py:39-51)."""
+
+    def __init__(self, w: LlavaWeights):
+        self.w, self.cfg = w, w.cfg.vision
+        v = self.cfg
+        self.T = v.n_patches + 1
+        dh = v.width // v.heads
+        assert dh == 64, "the ViT attention kernel is instantiated for head_dim 64"
+        self._kv = None
+
+    def _kv_cache(self, n_img):
+        v = self.cfg
+        if self._kv is None or self._kv[0].shape[0] < n_img:
+            mk = lambda: torch.empty(n_img, v.heads, self.T, v.width // v.heads, dtype=torch.bfloat16, device=self.w.device)
+            self._kv = (mk(), mk())
+        return self._kv
+
+    @torch.no_grad()
+    def __call__(self, images: torch.Tensor) -> torch.Tensor:
+        """images [n, 3, S, S] (any float dtype) -> projected patch features [n, n_patches, d_lm] bf16."""
+        v, t = self.cfg, self.w.t
+        n = images.shape[0]
+        dev = self.w.device
+        x = images.to(device=dev, dtype=torch.bfloat16)
+        P, G = v.patch, v.image // v.patch
+        patches = x.view(n, 3, G, P, G, P).permute(0, 2, 4, 1, 3, 5).reshape(n * G * G, 3 * P * P)   # im2col of the stride-14 conv
+        pd_pad = t["v.patch"].shape[1]
+        if pd_pad != patches.shape[1]:
+            patches = torch.nn.functional.pad(patches, (0, pd_pad - patches.shape[1]))
+        emb = torch.matmul(patches, t["v.patch"].t()).view(n, G * G, v.width)                       # patch-embed GEMM (hipBLASLt)
+        h = torch.cat([t["v.cls"].view(1, 1, -1).expand(n, 1, -1), emb], dim=1) + t["v.pos"][None]
+        T, H, D = self.T, v.heads, v.width // v.heads
+        h = ops.layernorm(h.reshape(n * T, v.width).contiguous(), t["v.pre_ln.w"], t["v.pre_ln.b"], v.eps)
+        kc, vc = self._kv_cache(n)
+        seqs = torch.tensor([[i * T, T, 0, i, 0, 0] for i in range(n)], dtype=torch.int32, device=dev)
+        for i in range(v.run_layers):
+            p = f"v{i}."
+            a = ops.layernorm(h, t[p + "ln1.w"], t[p + "ln1.b"], v.eps)
+            qkv = ops.bias_act(torch.matmul(a, t[p + "wqkv"].t()), t[p + "bqkv"]).view(n, T, 3, H, D)
+            kc[:n].copy_(qkv[:, :, 1].permute(0, 2, 1, 3))
+            vc[:n].copy_(qkv[:, :, 2].permute(0, 2, 1, 3))
+            q = qkv[:, :, 0].reshape(n * T, H * D)
+            att = ops.flash_attention(q.contiguous(), kc, vc, seqs, n, T, H, H, D, causal=False)
+            h = h + ops.bias_act(torch.matmul(att, t[p + "wo"].t()), t[p + "bo"])
+            a = ops.layernorm(h, t[p + "ln2.w"], t[p + "ln2.b"], v.eps)
+            f = ops.bias_act(torch.matmul(a, t[p + "fc1"].t()), t[p + "b1"], ops.ACT_QUICK_GELU)
+            h = h + ops.bias_act(torch.matmul(f, t[p + "fc2"].t()), t[p + "b2"])
+        feat = h.view(n, T, v.width)[:, 1:].reshape(n * (T - 1), v.width)                            # drop CLS ('patch')
+        z = ops.bias_act(torch.matmul(feat, t["mm.w1"].t()), t["mm.b1"], ops.ACT_GELU)
+        z = ops.bias_act(torch.matmul(z, t["mm.w2"].t()), t["mm.b2"])
+        return z.view(n, T - 1, -1)
+
+
+# ------------------------------------------------------------------ language model
+class KVCache:
+    def __init__(self, lm: LMConfig, n_slots: int, t_max: int, device):
+        self.n_slots, self.t_max = n_slots, t_max
+        shape = (n_slots, lm.n_kv_heads, t_max, lm.head_dim)
+        self.k = [torch.empty(shape, dtype=torch.bfloat16, device=device) for _ in range(lm.n_layers)]
+        self.v = [torch.empty(shape, dtype=torch.bfloat16, device=device) for _ in range(lm.n_layers)]
+
+    def nbytes(self):
+        return 2 * len(self.k) * self.k[0].numel() * 2
+
+
+class LanguageModel:
+    def __init__(self, w: LlavaWeights):
+        self.w, self.cfg = w, w.cfg.lm
+        self.cs = rope_table(self.cfg, w.device)
+
+    def _mlp_attn_out(self, i, h_resid, delta, x_norm_out=None):
+        raise NotImplementedError
+
+    @torch.no_grad()
+    def prefill(self, x: torch.Tensor, pos: torch.Tensor, slot: torch.Tensor, seqs: torch.Tensor, n_seq: int, max_tq: int,
+                kv: KVCache) -> torch.Tensor:
+        """x [T, d] packed embeddings; pos/slot int32 [T]; seqs [n_seq, 6] (ops.flash_attention).  Writes KV, returns
+        the final hidden states [T, d] (before the last norm)."""
+        c, t = self.cfg, self.w.t
+        H, Hkv, D = c.n_heads, c.n_kv_heads, c.head_dim
+        resid, delta = x, None
+        for i in range(c.n_layers):
+            p = f"l{i}."
+            new_resid = torch.empty_like(resid) if delta is not None else None
+            a = ops.rmsnorm(resid, t[p + "ln1"], c.eps, delta=delta, resid_out=new_resid)
+            resid = new_resid if new_resid is not None else resid
+            qkv = ops.linear(a, t[p + "wqkv"])
+            q = ops.rope_kv_write(qkv, pos, slot, self.cs, kv.k[i], kv.v[i], H, Hkv, D)
+            att = ops.flash_attention(q, kv.k[i], kv.v[i], seqs, n_seq, max_tq, H, Hkv, D, causal=True)
+            o = ops.linear(att, t[p + "wo"])
+            new_resid = torch.empty_like(resid)
+            a = ops.rmsnorm(resid, t[p + "ln2"], c.eps, delta=o, resid_out=new_resid)
+            resid = new_resid
+            gu = ops.linear(a, t[p + "wgu"])
+            delta = ops.linear(ops.silu_mul(gu), t[p + "wd"])
+        return resid, delta
+
+    @torch.no_grad()
+    def logits(self, resid, delta, rows: Optional[torch.Tensor] = None) -> torch.Tensor:
+        """final norm + lm_head on the selected rows only (the reference computes all positions, llava_llama.py:103)."""
+        c, t = self.cfg, self.w.t
+        if rows is not None:
+            resid, delta = resid[rows].contiguous(), delta[rows].contiguous()
+        a = ops.rmsnorm(resid, t["norm"], c.eps, delta=delta)
+        return ops.linear(a, t["lm_head"])
+
+    @torch.no_grad()
+    def decode_step(self, tokens: torch.Tensor, pos: torch.Tensor, slot: torch.Tensor, attn_rows: torch.Tensor, kv: KVCache,
+                    bufs: Optional[dict] = None) -> torch.Tensor:
+        """One token for each of M rows: tokens int64 [M], pos/slot int32 [M], attn_rows int32 [M,4] (slot, len, pslot, plen)
+        with len already counting the new token.  Returns logits [M, V]."""
+        c, t = self.cfg, self.w.t
+        H, Hkv, D = c.n_heads, c.n_kv_heads, c.head_dim
+        resid = ops.embed(tokens, t["embed"])
+        delta = None
+        for i in range(c.n_layers):
+            p = f"l{i}."
+            if delta is None:
+                a = ops.rmsnorm(resid, t[p + "ln1"], c.eps)
+            else:
+                a = ops.rmsnorm(resid, t[p + "ln1"], c.eps, delta=delta, resid_out=resid)
+            qkv = ops.linear(a, t[p + "wqkv"])
+            q = ops.rope_kv_write(qkv, pos, slot, self.cs, kv.k[i], kv.v[i], H, Hkv, D)
+            att = ops.decode_attention(q, kv.k[i], kv.v[i], attn_rows, H, Hkv, D)
+            o = ops.linear(att, t[p + "wo"])
+            a = ops.rmsnorm(resid, t[p + "ln2"], c.eps, delta=o, resid_out=resid)
+            gu = ops.linear(a, t[p + "wgu"])
+            delta = ops.linear(ops.silu_mul(gu), t[p + "wd"])
+        a = ops.rmsnorm(resid, t["norm"], c.eps, delta=delta)
+        return ops.linear(a, t["lm_head"])
+
+
+# ------------------------------------------------------------------ generation
+@dataclass
+class GenerateOutput:
+    sequences: List[torch.Tensor]            # per question: prompt ids (with -200) + generated ids
+    tokens: torch.Tensor                     # [Q, n_new] int64 generated ids (pad after EOS)
+    scores: Optional[List[torch.Tensor]]     # per step [Q, V] post-warp scores when output_scores
+    top_prob: Optional[torch.Tensor] = None  # step-0 top-10 softmax(scores) (metrics.py:102-104)
+    top_tok: Optional[torch.Tensor] = None
+    stats: dict = field(default_factory=dict)
+
+    def __getitem__(self, k):
+        return getattr(self, k)
+
+
+class VddLlavaEngine:
+    """model.generate()-compatible surface (llava_calibrate.py:161-177) over the native kernels."""
+
+    def __init__(self, cfg: LlavaConfig | str = "llava-1.5-7b", weights: Optional[LlavaWeights] = None, device="cuda:0",
+                 seed: int = 0, max_questions: int = 64, t_max: int = 768, use_graph: bool = True):
+        self.cfg = preset(cfg) if isinstance(cfg, str) else cfg
+        self.device = torch.device(device)
+        self.w = weights if weights is not None else LlavaWeights.random(self.cfg, self.device, seed)
+        self.vit = VisionTower(self.w)
+        self.lm = LanguageModel(self.w)
+        self.max_q, self.t_max, self.use_graph = max_questions, t_max, use_graph
+        self._kv: Optional[KVCache] = None
+        self._feat_cache: Dict[int, torch.Tensor] = {}
+        self._graphs: dict = {}
+
+    # -- plumbing ---------------------------------------------------------------------------
+    def kv(self, n_slots):
+        if self._kv is None or self._kv.n_slots < n_slots:
+            self._kv = None
+            self._graphs.clear()
+            self._kv = KVCache(self.cfg.lm, n_slots, self.t_max, self.device)
+        return self._kv
+
+    def image_features(self, images: Sequence[torch.Tensor], keys: Optional[Sequence[int]] = None) -> List[torch.Tensor]:
+        """ViT + projector per DISTINCT image (POPE: 6 questions share one image)."""
+        if keys is not None:                     # caller-supplied identities: cache persists across generate() calls
+            keys, cache = list(keys), self._feat_cache
+        else:                                    # same storage within this call = same image
+            keys, cache = [(im.data_ptr(), tuple(im.shape)) for im in images], {}
+        todo, seen = [], set()
+        for k, im in zip(keys, images):
+            if k not in cache and k not in seen:
+                todo.append((k, im)); seen.add(k)
+        for i in range(0, len(todo), 16):
+            chunk = todo[i:i + 16]
+            feats = self.vit(torch.stack([im.reshape(im.shape[-3:]) for _, im in chunk]))
+            for (k, _), f in zip(chunk, feats):
+                cache[k] = f
+        return [cache[k] for k in keys]
+
+    def clear_image_cache(self):
+        self._feat_cache.clear()
+
+    # -- generate -------------------------------------------------------------------------------
+    @torch.no_grad()
+    def generate(self, input_ids: Sequence[torch.Tensor] | torch.Tensor, images=None, images_cd=None, image_keys=None,
+                 cd_alpha: Optional[float] = None, cd_beta: Optional[float] = None, use_dd: bool = False,
+                 use_dd_unk: bool = False, do_sample: bool = True, temperature: Optional[float] = None,
+                 top_p: Optional[float] = None, top_k: Optional[int] = None, max_new_tokens: int = 64,
+                 eos_token_id=None, pad_token_id: Optional[int] = None, output_scores: bool = False,
+                 return_dict_in_generate: bool = True, cd_greedy: bool = False, n_top: int = 0, seed: Optional[int] = None,
+                 share_prefix: bool = True, sync_every: int = 8, **_ignored) -> GenerateOutput:
+        """Same kwargs as the reference's model.generate(...) call (llava_calibrate.py:161-177); `input_ids` is a
+        list of 1-D id tensors (one per question, each with one -200 image slot) or a [Q, L] tensor; `images` one
+        image per question (repeat the SAME tensor for questions about the same image to share its features and
+        prompt-prefix KV).  use_cache / output_attentions are accepted and ignored (attention maps are never
+        materialised: flash-style kernels; the reference only reads them for a commented-out plot, :180-183)."""
+        dev, lm = self.device, self.cfg.lm
+        ids_list = [r for r in input_ids] if torch.is_tensor(input_ids) else list(input_ids)
+        ids_list = [r.reshape(-1).tolist() for r in ids_list]
+        Q = len(ids_list)
+        alpha = cd_alpha if cd_alpha is not None else 0.5                                     # vcd_sample.py:188
+        beta = cd_beta if cd_beta is not None else 0.1                                        # :189
+        use_cd = images_cd is not None
+        if not do_sample:                  # reference: greedy_search is not patched -> no contrast (A.3 #5)
+            use_cd = use_dd = use_dd_unk = False
+            cd_greedy, temperature, top_p, top_k = True, None, None, None
+        contrast = use_cd or use_dd or use_dd_unk
+        if isinstance(eos_token_id, int):
+            eos_token_id = [eos_token_id]
+        if eos_token_id is not None and pad_token_id is None:
+            raise ValueError("If `eos_token_id` is defined, make sure that `pad_token_id` is defined.")   # :258-259
+        warp = WarpSpec(temperature=temperature, top_k=top_k, top_p=top_p)
+
+        # ---- branches: (name, per-question token lists with image slot handling) ------------
+        feats = None
+        if images is not None:
+            imgs = [images[i] for i in range(Q)] if torch.is_tensor(images) else list(images)
+            feats = self.image_features(imgs, image_keys)
+        feats_cd = None
+        if use_cd:
+            imgs_cd = [images_cd[i] for i in range(Q)] if torch.is_tensor(images_cd) else list(images_cd)
+            feats_cd = [self.vit(im.reshape(1, *im.shape[-3:]))[0] for im in imgs_cd]
+        branches = [("main", ids_list, feats)]
+        if use_cd:
+            branches.append(("cd", ids_list, feats_cd))                                       # :148-150, takes precedence
+        elif use_dd_unk:
+            branches.append(("unk", [[0 if t == IMAGE_TOKEN_INDEX else t for t in r] for r in ids_list], None))   # :154-155
+        elif use_dd:
+            branches.append(("none", [[t for t in r if t != IMAGE_TOKEN_INDEX] for r in ids_list], None))         # :157-160
+        if use_dd and use_dd_unk:
+            branches.append(("none", [[t for t in r if t != IMAGE_TOKEN_INDEX] for r in ids_list], None))         # :171-177
+        nb = len(branches)
+
+        # ---- plan prefill: split every (branch, question) sequence into shared prefix + own suffix -----
+        n_img_tok = self.cfg.vision.n_patches
+        plan = self._plan(branches, n_img_tok, share_prefix)
+        kv = self.kv(plan["n_slots"])
+        assert plan["max_len"] + max_new_tokens <= self.t_max, "raise t_max"
+        stats = {"n_rows": nb * Q, "prefill_tokens": plan["prefill_tokens"], "unshared_prefill_tokens": plan["unshared_tokens"]}
+
+        last_rows = None
+        for phase in ("prefix", "suffix"):
+            segs = plan[phase]
+            if not segs:
+                continue
+            x, pos, slot, seqs, max_tq = self._pack(segs)
+            resid, delta = self.lm.prefill(x, pos, slot, seqs, len(segs), max_tq, kv)
+            if phase == "suffix":
+                last = torch.tensor([s["q_row0"] + s["T"] - 1 for s in segs], device=dev)
+                logits0 = self.lm.logits(resid, delta, last)                                  # [nb*Q, V], rows ordered branch-major
+                self.debug_logits0 = logits0
+        V = lm.vocab
+
+        # ---- device-resident decode state --------------------------------------------------------------
+        R = nb * Q
+        seg = plan["suffix"]
+        d_pos = torch.tensor([s["pos0"] + s["T"] for s in seg], dtype=torch.int32, device=dev)          # next position per row
+        d_slot = torch.tensor([s["slot"] for s in seg], dtype=torch.int32, device=dev)
+        d_rows = torch.tensor([[s["slot"], s["pos0"] + s["T"] + 1, s["pslot"], s["plen"]] for s in seg], dtype=torch.int32, device=dev)
+        gen = torch.zeros(Q, max_new_tokens, dtype=torch.long, device=dev)
+        unfinished = torch.ones(Q, dtype=torch.long, device=dev)
+        eos_t = torch.tensor(eos_token_id, dtype=torch.long, device=dev) if eos_token_id is not None else None
+        eos_kw = dict(eos_ids=eos_t, pad_id=pad_token_id, unfinished=unfinished) if eos_t is not None else {}
+        statuses, scores = [], ([] if output_scores else None)
+        sd = torch.initial_seed() if seed is None else seed
+        is_vcd = use_cd
+
+        def tail(logits, step, tok_out):
+            v = logits[:Q]
+            c = d = None
+            if contrast:
+                if is_vcd and step > 0:
+                    c = v                                                                     # quirk #1: cd runs on the main cache -> c == v
+                    d = logits[Q:2 * Q] if (use_dd and use_dd_unk) else None
+                else:
+                    c = logits[Q:2 * Q]
+                    d = logits[2 * Q:3 * Q] if nb == 3 else None
+            r = contrast_sample(v, c, d, alpha=alpha, beta=beta, warp=warp, out_tokens=tok_out, return_scores=output_scores,
+                                pick_argmax=cd_greedy, seed=sd, offset=step, n_top=(n_top if step == 0 else 0), **eos_kw)
+            statuses.append(r.status)
+            if output_scores:
+                scores.append(r.scores)
+            return r
+
+        tok = torch.empty(Q, dtype=torch.long, device=dev)
+        r0 = tail(logits0, 0, tok)
+        gen[:, 0] = tok
+        top_prob, top_tok = r0.top_prob, r0.top_tok
+        n_new = 1
+        if is_vcd:                         # the cd branch has no state of its own after step 0: drop its rows
+            keep = [i for i, (name, _, _) in enumerate(branches) if name != "cd"]
+            sel = torch.cat([torch.arange(b * Q, (b + 1) * Q, device=dev) for b in keep])
+            d_pos, d_slot, d_rows = d_pos[sel].contiguous(), d_slot[sel].contiguous(), d_rows[sel].contiguous()
+            nb = len(keep)
+            R = nb * Q
+        tokens_rows = torch.empty(R, dtype=torch.long, device=dev)
+        while n_new < max_new_tokens:
+            tokens_rows.view(nb, Q).copy_(tok[None].expand(nb, Q))                             # same new token for every branch of a question
+            logits = self.lm.decode_step(tokens_rows, d_pos, d_slot, d_rows, kv)
+            tail(logits, n_new, tok)
+            gen[:, n_new] = tok
+            d_pos += 1
+            d_rows[:, 1] += 1
+            n_new += 1
+            if eos_t is not None and (n_new % sync_every == 0 or n_new == max_new_tokens):
+                if bool((unfinished.max() == 0).item()):                                      # :291, amortised over sync_every steps
+                    break
+        bad = torch.stack(statuses).ne(0).any()
+        if bool(bad.item()):
+            raise RuntimeError("probability tensor contains either `inf`, `nan` or element < 0")   # torch.multinomial, :202
+        gen = gen[:, :n_new]
+        if eos_t is not None:
+            gen = self._trim_after_all_finished(gen, eos_t, pad_token_id)
+            if scores is not None:
+                scores = scores[:gen.shape[1]]
+        seqs_out = [torch.cat([torch.tensor(ids_list[q], device=dev), gen[q]]) for q in range(Q)]
+        stats["steps"] = int(gen.shape[1])
+        return GenerateOutput(seqs_out, gen, scores, top_prob, top_tok, stats)
+
+    @staticmethod
+    def _trim_after_all_finished(gen, eos_t, pad):
+        """The reference stops at the first step after which every row has emitted EOS (:291); we check every
+        `sync_every` steps, so cut the surplus all-pad columns to return exactly what it returns."""
+        is_eos = (gen[:, :, None] == eos_t[None, None, :]).any(-1)
+        done_at = torch.where(is_eos.any(1), is_eos.float().argmax(1), torch.full((gen.shape[0],), gen.shape[1] - 1, device=gen.device))
+        return gen[:, : int(done_at.max().item()) + 1]
+
+    # -- prefill planning ---------------------------------------------------------------------------------
+    def _plan(self, branches, n_img_tok, share_prefix):
+        """Every (branch, question) sequence = [prefix | suffix].  Prefix = everything up to and including the
+        image slot (main/cd: system prompt + 576 patch embeddings; unk: system prompt + <unk>; none: system prompt);
+        identical prefixes (same tokens, same image features) are prefilled ONCE into a prefix slot."""
+        prefix_slots: Dict[tuple, dict] = {}
+        prefix, suffix = [], []
+        n_slots, max_len, unshared = 0, 0, 0
+        main_rows = branches[0][1]
+        for name, rows, feats in branches:
+            for qi, ids in enumerate(rows):
+                src = main_rows[qi]
+                s_img = src.index(IMAGE_TOKEN_INDEX) if IMAGE_TOKEN_INDEX in src else None
+                img = feats[qi] if (feats is not None and s_img is not None) else None
+                if img is not None:                          # main / cd: [tokens before the slot | 576 patch embeddings]
+                    pre_tok, suf_tok, plen = ids[:s_img], ids[s_img + 1:], s_img + n_img_tok
+                    key = (tuple(pre_tok), img.data_ptr())
+                else:
+                    if s_img is None:
+                        cut = self._common_split(name, ids)
+                    else:
+                        cut = s_img + 1 if name == "unk" else s_img     # unk keeps the one <unk> token in the prefix (quirk #3)
+                    pre_tok, suf_tok, plen = ids[:cut], ids[cut:], cut
+                    key = (tuple(pre_tok), None)
+                total = plen + len(suf_tok)
+                unshared += total
+                max_len = max(max_len, total)
+                if len(suf_tok) == 0:                      # keep at least the last token in the suffix: its logits are needed
+                    if img is None:
+                        pre_tok, suf_tok, plen = pre_tok[:-1], pre_tok[-1:], plen - 1
+                        key = (tuple(pre_tok), None)
+                    else:
+                        raise ValueError("prompt must not end with the image token")
+                if share_prefix and plen > 0:
+                    if key not in prefix_slots:
+                        prefix_slots[key] = dict(slot=n_slots, tokens=pre_tok, img=img, T=plen, pos0=0, pslot=0, plen=0)
+                        prefix.append(prefix_slots[key])
+                        n_slots += 1
+                    ps = prefix_slots[key]["slot"]
+                    suffix.append(dict(slot=n_slots, tokens=suf_tok, img=None, T=len(suf_tok), pos0=plen, pslot=ps, plen=plen))
+                else:
+                    suffix.append(dict(slot=n_slots, tokens=pre_tok + suf_tok if img is None else None, pre=pre_tok, img=img,
+                                       suf=suf_tok, T=total, pos0=0, pslot=0, plen=0))
+                n_slots += 1
+        tokens = sum(s["T"] for s in prefix) + sum(s["T"] for s in suffix)
+        return dict(prefix=prefix, suffix=suffix, n_slots=n_slots, max_len=max_len, prefill_tokens=tokens, unshared_tokens=unshared)
+
+    def _common_split(self, name, ids):
+        """Text-only prompts (no image slot): nothing marks a shareable prefix, so share nothing."""
+        return 0
+
+    def _pack(self, segs):
+        """Builds the packed embedding matrix and the per-token / per-sequence descriptors of a prefill pass."""
+        dev, t = self.device, self.w.t
+        tok_ids, spans = [], []
+        row = 0
+        for s in segs:
+            s["q_row0"] = row
+            row += s["T"]
+        x = torch.empty(row, self.cfg.lm.d, dtype=torch.bfloat16, device=dev)
+        flat_ids, flat_rows = [], []
+        for s in segs:
+            r = s["q_row0"]
+            if s.get("tokens") is not None and s["img"] is None:
+                flat_ids += s["tokens"]; flat_rows += list(range(r, r + s["T"]))
+            else:
+                pre = s["tokens"] if s.get("tokens") is not None else s["pre"]
+                suf = s.get("suf", [])
+                flat_ids += pre; flat_rows += list(range(r, r + len(pre)))
+                x[r + len(pre): r + len(pre) + s["img"].shape[0]] = s["img"]
+                r2 = r + len(pre) + s["img"].shape[0]
+                flat_ids += suf; flat_rows += list(range(r2, r2 + len(suf)))
+        if flat_ids:
+            emb = ops.embed(torch.tensor(flat_ids, dtype=torch.long, device=dev), t["embed"])
+            x[torch.tensor(flat_rows, dtype=torch.long, device=dev)] = emb
+        pos = torch.cat([torch.arange(s["pos0"], s["pos0"] + s["T"], dtype=torch.int32) for s in segs]).to(dev)
+        slot = torch.cat([torch.full((s["T"],), s["slot"], dtype=torch.int32) for s in segs]).to(dev)
+        seqs = torch.tensor([[s["q_row0"], s["T"], s["pos0"], s["slot"], s["pslot"], s["plen"]] for s in segs], dtype=torch.int32, device=dev)
+        return x, pos, slot, seqs, max(s["T"] for s in segs)

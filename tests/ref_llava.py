@@ -1,0 +1,106 @@
+"""Plain-PyTorch fp32 reference of the LLaVA-1.5 forward (CLIP ViT -> mlp2x_gelu projector ->
+multimodal splice -> Llama), written against the reference's model protocol
+(llava_llama.py:58-174, llava_arch.py:82-204) so that oracle.reference_loop can drive it exactly
+like the reference's sample() drives LlavaLlamaForCausalLM.  Test infrastructure only."""
+from __future__ import annotations
+
+import math
+from types import SimpleNamespace
+
+import torch
+import torch.nn.functional as F
+
+from toy_lm import IMAGE_TOKEN_INDEX, _Proto, _gen_cfg
+
+
+class RefLlava(_Proto):
+    def __init__(self, weights, device="cpu", logit_dtype=torch.bfloat16, pad=0, eos=None):
+        self.cfg = weights.cfg
+        self.w = {k: v.detach().to(device=device, dtype=torch.float32) for k, v in weights.t.items()}
+        self.device = torch.device(device)
+        self.logit_dtype = logit_dtype
+        self.generation_config = _gen_cfg(pad, eos)
+        lm = self.cfg.lm
+        inv = 1.0 / (lm.rope_theta ** (torch.arange(0, lm.head_dim, 2, dtype=torch.float32) / lm.head_dim))
+        ang = torch.arange(lm.max_pos, dtype=torch.float32)[:, None] * inv[None, :]
+        self.cos, self.sin = ang.cos().to(device), ang.sin().to(device)
+        self.calls = []
+
+    # ---- vision ----
+    def encode_images(self, images):
+        v, w = self.cfg.vision, self.w
+        x = images.to(self.device, torch.bfloat16).float()
+        n = x.shape[0]
+        P, G = v.patch, v.image // v.patch
+        patches = x.view(n, 3, G, P, G, P).permute(0, 2, 4, 1, 3, 5).reshape(n, G * G, 3 * P * P)
+        h = patches @ w["v.patch"][:, : 3 * P * P].t()
+        h = torch.cat([w["v.cls"].view(1, 1, -1).expand(n, 1, -1), h], 1) + w["v.pos"][None]
+        h = F.layer_norm(h, (v.width,), w["v.pre_ln.w"], w["v.pre_ln.b"], v.eps)
+        H, D = v.heads, v.width // v.heads
+        for i in range(v.run_layers):
+            p = f"v{i}."
+            a = F.layer_norm(h, (v.width,), w[p + "ln1.w"], w[p + "ln1.b"], v.eps)
+            qkv = (a @ w[p + "wqkv"].t() + w[p + "bqkv"]).view(n, -1, 3, H, D)
+            q, k, val = (qkv[:, :, j].transpose(1, 2) for j in range(3))
+            att = ((q @ k.transpose(-1, -2)) / math.sqrt(D)).softmax(-1) @ val
+            h = h + att.transpose(1, 2).reshape(n, -1, v.width) @ w[p + "wo"].t() + w[p + "bo"]
+            a = F.layer_norm(h, (v.width,), w[p + "ln2.w"], w[p + "ln2.b"], v.eps)
+            f = a @ w[p + "fc1"].t() + w[p + "b1"]
+            f = f * torch.sigmoid(1.702 * f)
+            h = h + f @ w[p + "fc2"].t() + w[p + "b2"]
+        z = F.gelu(h[:, 1:] @ w["mm.w1"].t() + w["mm.b1"])
+        return z @ w["mm.w2"].t() + w["mm.b2"]
+
+    # ---- language model ----
+    def _rope(self, x, pos):            # x [1, H, T, D]
+        D = x.shape[-1]
+        c, s = self.cos[pos][None, None], self.sin[pos][None, None]
+        a, b = x[..., : D // 2], x[..., D // 2:]
+        return torch.cat([a * c - b * s, b * c + a * s], -1)
+
+    def _lm(self, emb, past):
+        lm, w = self.cfg.lm, self.w
+        T = emb.shape[1]
+        p0 = past[0][0].shape[-2] if past else 0
+        pos = torch.arange(p0, p0 + T, device=self.device)
+        h = emb
+        new = []
+        rms = lambda x, g: x * torch.rsqrt(x.pow(2).mean(-1, keepdim=True) + lm.eps) * g
+        H, Hkv, D = lm.n_heads, lm.n_kv_heads, lm.head_dim
+        for i in range(lm.n_layers):
+            p = f"l{i}."
+            a = rms(h, w[p + "ln1"])
+            qkv = a @ w[p + "wqkv"].t()
+            q = qkv[..., : H * D].view(1, T, H, D).transpose(1, 2)
+            k = qkv[..., H * D: (H + Hkv) * D].view(1, T, Hkv, D).transpose(1, 2)
+            v = qkv[..., (H + Hkv) * D:].view(1, T, Hkv, D).transpose(1, 2)
+            q, k = self._rope(q, pos), self._rope(k, pos)
+            if past:
+                k, v = torch.cat([past[i][0], k], 2), torch.cat([past[i][1], v], 2)
+            new.append((k, v))
+            kk, vv = k.repeat_interleave(H // Hkv, 1), v.repeat_interleave(H // Hkv, 1)
+            s = (q @ kk.transpose(-1, -2)) / math.sqrt(D)
+            S = kk.shape[2]
+            mask = torch.ones(T, S, dtype=torch.bool, device=self.device).tril(diagonal=S - T)
+            att = s.masked_fill(~mask, -float("inf")).softmax(-1) @ vv
+            h = h + att.transpose(1, 2).reshape(1, T, H * D) @ w[p + "wo"].t()
+            a = rms(h, w[p + "ln2"])
+            gu = a @ w[p + "wgu"].t()
+            h = h + (F.silu(gu[..., : lm.ffn]) * gu[..., lm.ffn:]) @ w[p + "wd"].t()
+        return rms(h, w["norm"]) @ w["lm_head"].t(), tuple(new)
+
+    def __call__(self, input_ids=None, attention_mask=None, past_key_values=None, inputs_embeds=None, use_cache=None,
+                 images=None, image_sizes=None, return_dict=True, output_attentions=None, output_hidden_states=None, **_):
+        ids = input_ids.to(self.device)
+        past_len = int(past_key_values[0][0].shape[-2]) if past_key_values else 0
+        self.calls.append((tuple(ids.shape), images is not None, past_len))
+        if images is None or ids.shape[1] == 1:                 # llava_arch.py:91-94
+            emb = self.w["embed"][ids]
+        else:                                                   # llava_arch.py:122-163 (batch 1)
+            row = ids[0]
+            s = int(torch.where(row == IMAGE_TOKEN_INDEX)[0][0])
+            feat = self.encode_images(images)[0]
+            emb = torch.cat([self.w["embed"][row[:s]], feat, self.w["embed"][row[s + 1:]]], 0)[None]
+        emb = emb.to(torch.bfloat16).float()
+        logits, past = self._lm(emb, past_key_values)
+        return SimpleNamespace(logits=logits.to(self.logit_dtype).cpu(), past_key_values=past, attentions=None, hidden_states=None)
