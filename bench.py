@@ -1,12 +1,23 @@
-"""bench.py — contract: python bench.py --gpus N --steps K --warmup W  -> ONE JSON line on rank 0.
+"""bench.py — python bench.py --gpus N --steps K --warmup W  -> ONE JSON line on rank 0.
 
-Legs
-  kernel   the fused contrastive-sampling kernel at a bandwidth-meaningful batch
-           (SURVEY.md §8d microbench: B rows x V=32000, bf16, use_dd_unk, scores on),
-           timed with HIP events on the launch stream -> `roofline`
-  cpu      the reference CPU path (oracle restatement of sample()'s tail, torch eager,
-           stubbed forward) on a bounded sample -> `cpu_baseline`
-  e2e      (engine) LLaVA-1.5-7B-shaped VDD generation -> `value`   [added with engine.py]
+Metric (BASELINE.json): decode tokens/sec under VDD dual-pass, LLaVA-1.5-7B, POPE.
+Workload (synthetic — no checkpoints / tokenizer / images exist on either
+box): LLaVA-1.5-7B shapes with N(0, 0.02) bf16 weights; POPE-like prompts = 35 system tokens +
+1 image slot (576 patch embeddings) + 19..28 question tokens, 6 questions per 336x336 image;
+use_dd_unk, cd_alpha=1, cd_beta=0.1, T=0.2, 64 new tokens, no EOS (steady-state variant).
+
+A "step" = one generate() over one batch of `--questions` questions: ViT + projector per distinct
+image, prefill of both branches, 64 decode steps with the fused contrastive tail.  Everything is
+inside the timed region.  value = generated tokens / wall time over all ranks (weak scaling: every
+rank runs its own batch of the same size; results gathered once at the end with RCCL).
+
+Extra objects on the line:
+  roofline      the fused contrastive sampling kernel (the kernel north_star prices) at B=4096 rows,
+                HIP events on the launch stream
+  decode_step   measured ms per decode step of the engine vs the weight-streaming floor
+  cpu_baseline  the reference path (oracle loop + eager torch model) on the host CPU, bounded sample
+  eager_gpu     the same reference path on this GPU (what the monkey-patched HF sample() executes:
+                B=1, one eager forward per branch per token, cat-grown KV, attention maps materialised)
 """
 from __future__ import annotations
 
@@ -20,27 +31,42 @@ ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
 sys.path.insert(0, os.path.join(ROOT, "tests"))
 
+import numpy as np  # noqa: E402
 import torch  # noqa: E402
 
 HBM_PEAK_GBS = 8000.0      # MI355X_MICROARCH.md: 8.0 TB/s spec (6.29 TB/s measured float4 copy)
+N_NEW = 64
 
 
 def dist_env():
     return int(os.environ.get("RANK", 0)), int(os.environ.get("LOCAL_RANK", 0)), int(os.environ.get("WORLD_SIZE", 1))
 
 
-def bench_kernel(dev, B=4096, V=32000, dtype=torch.bfloat16, n_in=2, scores=True, iters=200, warmup=20):
+def pope_prompts(n_img, per_img=6, seed=1234, vocab=32000, n_sys=35, txt=(19, 29), image=336):
+    rng = np.random.default_rng(seed)
+    sys_tok = [1] + rng.integers(3, vocab, size=n_sys - 1).tolist()
+    ids, imgs = [], []
+    g = torch.Generator().manual_seed(7 + seed)
+    for _ in range(n_img):
+        im = torch.randn(3, image, image, generator=g)
+        for _ in range(per_img):
+            t = rng.integers(3, vocab, size=int(rng.integers(*txt))).tolist()
+            ids.append(torch.tensor(sys_tok + [-200] + t))
+            imgs.append(im)
+    return ids, imgs
+
+
+# ------------------------------------------------------------------ fused-kernel roofline leg
+def bench_kernel(dev, B=4096, V=32000, dtype=torch.bfloat16, n_in=2, scores=True, iters=100, warmup=10):
     import llava_align_amd as L
     g = torch.Generator(device=dev).manual_seed(0)
     v = (torch.randn(B, V, device=dev, generator=g) * 4).to(dtype)
     v[torch.arange(B, device=dev), torch.randint(0, V, (B,), device=dev, generator=g)] = 25.0   # planted row max
     c = (v.float() + torch.randn(B, V, device=dev, generator=g) * 1.5).to(dtype)
-    d = (v.float() + torch.randn(B, V, device=dev, generator=g) * 1.5).to(dtype) if n_in == 3 else None
     out_scores = torch.empty(B, V, dtype=dtype, device=dev) if scores else None
     toks = torch.empty(B, dtype=torch.long, device=dev)
     spec = L.WarpSpec(temperature=0.2)
-    run = lambda i: L.contrast_sample(v, c, d, alpha=1.0, beta=0.1, warp=spec, out_tokens=toks, out_scores=out_scores,
-                                      seed=0, offset=i)
+    run = lambda i: L.contrast_sample(v, c, None, alpha=1.0, beta=0.1, warp=spec, out_tokens=toks, out_scores=out_scores, seed=0, offset=i)
     for i in range(warmup):
         run(i)
     torch.cuda.synchronize(dev)
@@ -52,71 +78,162 @@ def bench_kernel(dev, B=4096, V=32000, dtype=torch.bfloat16, n_in=2, scores=True
     torch.cuda.synchronize(dev)
     ms = e0.elapsed_time(e1) / iters
     es = torch.finfo(dtype).bits // 8
-    alg_bytes = B * ((n_in + (1 if scores else 0)) * V * es + 8)          # (n_in+n_out)*V*e + 8 per row
-    gbs = alg_bytes / (ms * 1e-3) / 1e9
+    alg = B * ((n_in + (1 if scores else 0)) * V * es + 8)          # (n_in+n_out)*V*e + 8 per row
+    gbs = alg / (ms * 1e-3) / 1e9
+    del v, c, out_scores
+    torch.cuda.empty_cache()
     return {"bound": "hbm", "achieved": round(gbs, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": round(gbs / HBM_PEAK_GBS, 4),
-            "traffic": None, "kernel": "vdd_contrast_sample_kernel", "launch_us": round(ms * 1e3, 2),
-            "algorithmic_bytes_per_launch": alg_bytes,
-            "shape": {"B": B, "V": V, "dtype": str(dtype).split(".")[-1], "n_in": n_in, "scores_out": scores}}
+            "traffic": 526.0e6 if (B, V) == (4096, 32000) else None,   # bytes/launch from PMC (profiles/r01_pmc_fused_kernel.txt)
+            "kernel": "vdd_contrast_sample_kernel<bf16, lds-row>", "launch_us": round(ms * 1e3, 2),
+            "algorithmic_bytes_per_launch": alg,
+            "shape": {"B": B, "V": V, "dtype": "bf16", "n_in": n_in, "scores_out": scores, "note": "use_dd_unk, T=0.2"}}
 
 
-def bench_cpu_tail(seconds=12.0, V=32000, dtype=torch.bfloat16):
-    """Reference CPU path: the oracle's restatement of sample()'s per-step tail (use_dd_unk,
-    T=0.2, softmax, multinomial) with the forward stubbed out, B=1 as every reference driver runs."""
+# ------------------------------------------------------------------ reference-path baselines (oracle loop + eager torch model)
+def reference_path(weights, device, ids, img, n_new, dtype=torch.bfloat16, layers=None):
+    """Runs the reference's decoding path for ONE question: oracle restatement of sample() (B=1, one forward per
+    branch per token) over an eager torch LLaVA.  Returns seconds."""
     from oracle import vdd_oracle as O
-    torch.manual_seed(0)
-    bank = [(torch.randn(1, V) * 4).to(dtype) for _ in range(64)]
-    warp = O.WarpConfig(temperature=0.2)
-    n, t0 = 0, time.perf_counter()
-    while time.perf_counter() - t0 < seconds:
-        v, c = bank[n % 64], bank[(n + 1) % 64]
-        s = O.step_scores(v, c, None, 1.0, 0.1, warp)
-        O.pick_multinomial(torch.softmax(s, -1))
-        n += 1
-    dt = time.perf_counter() - t0
-    return {"value": round(n / dt, 1), "unit": "sampling-tail steps/s (B=1 rows/s)", "cores": torch.get_num_threads(),
-            "kind": "port", "host_cpus": os.cpu_count(),
-            "sample": f"{n} steps of the per-step tail at V={V} {str(dtype).split('.')[-1]} in {dt:.1f}s, forward stubbed"}
+    from ref_llava import RefLlava
+    model = RefLlava(weights, device=device, dtype=dtype, output_attentions=True)
+    kw = dict(images=img[None], attention_mask=torch.ones(1, ids.numel(), dtype=torch.long), use_cache=True,
+              cd_alpha=1.0, cd_beta=0.1, use_dd_unk=True)
+    if torch.device(device).type == "cuda":
+        torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    O.reference_loop(model, ids[None].clone(), warp=O.WarpConfig(temperature=0.2), max_length=ids.numel() + n_new,
+                     pad_token_id=None, eos_token_id=None, pick=O.pick_multinomial, **kw)
+    if torch.device(device).type == "cuda":
+        torch.cuda.synchronize()
+    return time.perf_counter() - t0
 
 
+def bench_eager_gpu(eng, dev, n_q=2, n_new=N_NEW):
+    ids, imgs = pope_prompts(1, per_img=n_q, seed=99)
+    reference_path(eng.w, dev, ids[0], imgs[0], 2)                      # warm-up (library handles)
+    dt = sum(reference_path(eng.w, dev, ids[q], imgs[q], n_new) for q in range(n_q))
+    return {"value": round(n_q * n_new / dt, 2), "unit": "tokens/s", "kind": "port",
+            "what": "oracle restatement of the monkey-patched sample() over an eager bf16 torch-ROCm LLaVA-1.5-7B: B=1, "
+                    "one forward per branch per token, KV grown by torch.cat, attention maps materialised",
+            "sample": f"{n_q} questions x {n_new} new tokens in {dt:.1f}s"}
+
+
+def bench_cpu(eng, n_new=3, layers=4):
+    """The reference path on the host CPU, bounded: ONE question, `n_new` tokens, on the first `layers` decoder
+    layers (+ full ViT/projector/embedding/lm_head), scaled to the full depth.  Says what it timed."""
+    from llava_align_amd.engine import LlavaConfig, LMConfig, LlavaWeights
+    import copy
+    cfg = copy.deepcopy(eng.cfg)
+    full = cfg.lm.n_layers
+    cfg.lm.n_layers = layers
+    w = LlavaWeights(cfg, "cpu")
+    for k, t in eng.w.t.items():
+        if k.startswith("l") and k[1].isdigit() and int(k[1:k.index(".")]) >= layers:
+            continue
+        w.t[k] = t.cpu()
+    ids, imgs = pope_prompts(1, per_img=1, seed=99)
+    t_small = reference_path(w, "cpu", ids[0], imgs[0], n_new)
+    # time of everything that does not scale with depth: measure with 0 decoder layers
+    cfg0 = copy.deepcopy(cfg)
+    cfg0.lm.n_layers = 0
+    w0 = LlavaWeights(cfg0, "cpu")
+    w0.t = {k: t for k, t in w.t.items() if not (k.startswith("l") and k[1].isdigit())}
+    t_fixed = reference_path(w0, "cpu", ids[0], imgs[0], n_new)
+    per_layer = max(0.0, (t_small - t_fixed) / layers)
+    t_full = t_fixed + per_layer * full
+    return {"value": round(n_new / t_full, 4), "unit": "tokens/s", "cores": torch.get_num_threads(), "host_cpus": os.cpu_count(),
+            "kind": "port",
+            "sample": f"1 POPE-like question, {n_new} new tokens, use_dd_unk, bf16 torch-CPU: ViT+projector+lm_head in full, "
+                      f"{layers} of {full} decoder layers timed ({t_small:.1f}s; depth-independent part {t_fixed:.1f}s) and scaled "
+                      f"to {full} layers -> {t_full:.1f}s per question"}
+
+
+# ------------------------------------------------------------------ main
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=200)
-    ap.add_argument("--warmup", type=int, default=20)
-    ap.add_argument("--rows", type=int, default=4096)
-    ap.add_argument("--no-cpu", action="store_true")
+    ap.add_argument("--steps", type=int, default=3)
+    ap.add_argument("--warmup", type=int, default=1)
+    ap.add_argument("--questions", type=int, default=96, help="questions per generate() batch per GPU (6 per image)")
+    ap.add_argument("--model", default="llava-1.5-7b")
+    ap.add_argument("--no-baselines", action="store_true")
     a = ap.parse_args()
     rank, local, world = dist_env()
     dev = torch.device(f"cuda:{local}")
     torch.cuda.set_device(dev)
     if world > 1:
         import torch.distributed as dist
-        dist.init_process_group("nccl", device_id=dev)
+        dist.init_process_group("nccl", device_id=dev)      # "nccl" is RCCL on ROCm
+
+    import llava_align_amd  # noqa: F401  (raises if the HIP library is missing)
+    from llava_align_amd.engine import VddLlavaEngine
+    from llava_align_amd.shard import gather_tokens
+
+    roof = bench_kernel(dev) if rank == 0 else None
+    eng = VddLlavaEngine(a.model, device=dev, seed=0, t_max=704, use_graph=True)
+    n_img = max(1, a.questions // 6)
+    ids, imgs = pope_prompts(n_img, seed=1234 + rank)                   # every rank: its own shard of the question list
+    Q = len(ids)
+    kw = dict(images=imgs, use_dd_unk=True, cd_alpha=1.0, cd_beta=0.1, temperature=0.2, max_new_tokens=N_NEW, seed=1 + rank)
+
+    def step():
+        return eng.generate(ids, **kw)
+
+    for _ in range(a.warmup):
+        out = step()
+    torch.cuda.synchronize(dev)
+    if world > 1:
+        import torch.distributed as dist
         dist.barrier()
     torch.cuda.synchronize(dev)
     t0 = time.perf_counter()
-    roof = bench_kernel(dev, B=a.rows, iters=a.steps, warmup=a.warmup)
+    for _ in range(a.steps):
+        out = step()
+    gathered = gather_tokens(torch.arange(rank * Q, (rank + 1) * Q, device=dev), out.tokens, world * Q)   # the one result gather
     torch.cuda.synchronize(dev)
-    wall = time.perf_counter() - t0
-    rows_per_s = a.rows / (roof["launch_us"] * 1e-6)
     if world > 1:
-        import torch.distributed as dist
-        t = torch.tensor([roof["launch_us"]], device=dev)
-        dist.all_reduce(t, op=dist.ReduceOp.MAX)
-        rows_per_s = world * a.rows / (t.item() * 1e-6)
         dist.barrier()
+    torch.cuda.synchronize(dev)
+    dt = time.perf_counter() - t0
+    if world > 1:
+        t = torch.tensor([dt], device=dev, dtype=torch.float64)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        dt = t.item()
+    assert gathered.shape == (world * Q, N_NEW)
+
     if rank == 0:
-        cpu = None if a.no_cpu else bench_cpu_tail()
-        line = {"metric": "fused contrastive sampling tail rows/s (interim line: e2e decode tokens/s lands with engine.py)",
-                "value": round(rows_per_s, 1), "unit": "rows/s", "n_gpus": world, "steps": a.steps, "warmup": a.warmup,
-                "ms_per_step": round(roof["launch_us"] / 1e3, 4), "higher_is_better": True, "scaling": "weak",
-                "vs_baseline": None, "dtype": "bf16", "data": "synthetic",
-                "config": {"workload": "vdd_contrast_sample B=%d V=32000 bf16 use_dd_unk T=0.2 scores_out" % a.rows},
-                "roofline": roof, "cpu_baseline": cpu, "wall_s": round(wall, 2)}
+        # decode-only rate: same batch, 2 new tokens (prefill + 1 decode step) subtracted
+        kw2 = dict(kw, max_new_tokens=2)
+        eng.generate(ids, **kw2); eng.generate(ids, **kw2)
+        torch.cuda.synchronize(dev)
+        t1 = time.perf_counter(); eng.generate(ids, **kw2); torch.cuda.synchronize(dev); t_pre = time.perf_counter() - t1
+        ms_step = dt / a.steps * 1e3
+        ms_decode = (dt / a.steps - t_pre) / (N_NEW - 2) * 1e3
+        wbytes = eng.w.lm_stream_bytes()
+        line = {"metric": "decode tokens/sec (VDD dual-pass) LLaVA-1.5-7B POPE", "value": round(world * Q * N_NEW * a.steps / dt, 1),
+                "unit": "tokens/s", "n_gpus": world, "steps": a.steps, "warmup": a.warmup, "ms_per_step": round(ms_step, 2),
+                "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "bf16", "data": "synthetic",
+                "config": {"workload": f"LLaVA-1.5-7B shapes (synthetic N(0,0.02) weights), POPE-like: {Q} questions/GPU = {n_img} images x 6, "
+                                       f"prompt 35 sys + 576 image + 19..28 text tokens, use_dd_unk, cd_alpha=1, cd_beta=0.1, T=0.2, "
+                                       f"{N_NEW} new tokens (no EOS), ViT + both-branch prefill + decode all inside the timed step",
+                           "questions_per_gpu": Q, "max_new_tokens": N_NEW, "parallelism": f"dp{world}"},
+                "tokens_per_s_per_gpu": round(Q * N_NEW * a.steps / dt, 1),
+                "decode_only_tokens_per_s_per_gpu": round(Q / (ms_decode * 1e-3), 1),
+                "prefill_plus_first_token_s": round(t_pre, 4),
+                "decode_step": {"ms": round(ms_decode, 3), "rows": 2 * Q, "lm_weight_bytes": wbytes,
+                                "weight_stream_GBs": round(wbytes / (ms_decode * 1e-3) / 1e9, 1),
+                                "note": "per step the LM weights are streamed once for all rows; KV reads come on top"},
+                "prefill_tokens": out.stats["prefill_tokens"], "unshared_prefill_tokens": out.stats["unshared_prefill_tokens"],
+                "roofline": roof}
+        if world == 1 and not a.no_baselines:
+            line["eager_gpu"] = bench_eager_gpu(eng, dev)
+            line["speedup_vs_eager_gpu"] = round(line["value"] / line["eager_gpu"]["value"], 1)
+            line["cpu_baseline"] = bench_cpu(eng)
+        else:
+            line["cpu_baseline"] = None
         print(json.dumps(line))
     if world > 1:
-        import torch.distributed as dist
+        dist.barrier()
         dist.destroy_process_group()
 
 

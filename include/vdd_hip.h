@@ -91,6 +91,8 @@ typedef struct vdd_sample_params {
     void* workspace;             /* optional [B, V] dtype: working row for V > vdd_lds_row_capacity(dtype)
                                     when scores_out is NULL (rows that fit LDS never touch it) */
     int64_t stride_workspace;
+    const uint64_t* philox_offset_ptr;   /* optional device counter ADDED to philox_offset at run time, so a launch
+                                            captured in a HIP graph draws fresh numbers on every replay */
 } vdd_sample_params;
 
 /* Fused per-step contrastive sampling tail; one launch for all B rows. */
@@ -131,9 +133,12 @@ int vdd_skinny_gemm(const void* X, const void* W, const void* R, void* Y, int M,
                     int64_t ldy, void* hip_stream);
 
 /* One query per (row, head) over that row's KV: rows[m] = {slot, len, prefix_slot, prefix_len} (int32 x4);
- * tokens [0, prefix_len) are read from prefix_slot (shared prompt prefix), [prefix_len, len) from slot. D == 128. */
-int vdd_decode_attention(const void* q, const void* k_cache, const void* v_cache, const int32_t* rows, void* out, int M, int H,
-                         int Hkv, int D, int64_t slot_stride, int t_max, float scale, void* hip_stream);
+ * tokens [0, prefix_len) are read from prefix_slot (shared prompt prefix), [prefix_len, len) from slot. D == 128.
+ * Split-KV: the key range is cut in 64-key chunks processed by independent waves (partials in `workspace`,
+ * vdd_decode_attention_workspace_bytes(M, H, D, max_len) bytes, max_len >= every rows[m].len) and merged. */
+int vdd_decode_attention(const void* q, const void* k_cache, const void* v_cache, const int32_t* rows, void* out, void* workspace,
+                         int M, int H, int Hkv, int D, int64_t slot_stride, int t_max, int max_len, float scale, void* hip_stream);
+int64_t vdd_decode_attention_workspace_bytes(int M, int H, int D, int max_len);
 
 /* Prefill attention (MFMA, flash-style).  q/out [Ttot, H*D] packed by sequence; seqs[s] = {q_row0, Tq, pos0,
  * slot, prefix_slot, prefix_len} (int32 x6): query i of sequence s sits at position pos0+i and attends keys

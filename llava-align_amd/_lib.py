@@ -34,6 +34,7 @@ class VddSampleParams(C.Structure):
         ("top_prob", C.c_void_p), ("top_tok", C.c_void_p), ("n_top", C.c_int32), ("_pad0", C.c_int32),
         ("row_status", C.c_void_p),
         ("workspace", C.c_void_p), ("stride_workspace", C.c_int64),
+        ("philox_offset_ptr", C.c_void_p),
     ]
 
 

@@ -98,6 +98,7 @@ struct KP {
     int use_temp, use_topp;
     unsigned long long seed, offset;
     const float* uniforms;
+    const unsigned long long* offset_ptr;
     const long long* eos;
     long long pad;
     long long* unfinished;
@@ -606,7 +607,7 @@ __global__ void __launch_bounds__(BLOCK, 8) vdd_contrast_sample_kernel(KP p) {
         }
         if (bv == m) atomicMin(&sm.sel[3], (unsigned)bi);
     } else {
-        const float u = p.uniforms ? p.uniforms[row] : philox_uniform(p.seed, p.offset, (unsigned)row);
+        const float u = p.uniforms ? p.uniforms[row] : philox_uniform(p.seed, p.offset + (p.offset_ptr ? *p.offset_ptr : 0ull), (unsigned)row);
         const float target = u * Z;
         bool hit = (t > 0.f) && (target >= excl) && (target < incl);
         // rounding fallback: target >= Z lands on the last thread holding mass
@@ -718,6 +719,7 @@ int vdd_contrast_sample(const vdd_sample_params* p, void* hip_stream) {
     kp.use_topp = (p->top_p >= 0.0 && p->top_p < 1.0) ? 1 : 0;
     kp.one_minus_p = (float)(1.0 - p->top_p);
     kp.seed = p->philox_seed; kp.offset = p->philox_offset; kp.uniforms = p->uniforms;
+    kp.offset_ptr = (const unsigned long long*)p->philox_offset_ptr;
     kp.eos = (const long long*)p->eos_ids; kp.pad = p->pad_id;
     kp.unfinished = (long long*)p->unfinished; kp.next_tokens = (long long*)p->next_tokens;
     kp.st = p->stride_tokens > 0 ? p->stride_tokens : 1;

@@ -225,44 +225,67 @@ __global__ void __launch_bounds__(256) skinny_gemm_kernel(const uint16_t* __rest
 // that share a prompt prefix (same image + system prompt) point at ONE physical copy.
 struct AttnRow { int slot, len, pslot, plen; };
 
+// Split-KV form: blockIdx.z = key chunk of CH keys; every (row, head, chunk) wave leaves an
+// un-normalised partial (acc[128], m, l) in `ws`, and decode_attn_combine merges the chunks.
+// The split turns one ~650-iteration latency chain per (row, head) into <= CH/4 iterations with
+// 8 x 16-B loads in flight per lane, and multiplies the number of independent waves by T/CH.
+constexpr int ATT_CH = 64;
+
 template <int D>   // head dim 128
 __global__ void __launch_bounds__(256) decode_attn_kernel(const uint16_t* __restrict__ q, const uint16_t* __restrict__ kc,
                                                           const uint16_t* __restrict__ vc, const AttnRow* __restrict__ rows,
-                                                          uint16_t* __restrict__ out, int H, int Hkv, long long slot_stride,
-                                                          int t_max, float scale) {
+                                                          float* __restrict__ ws, int H, int Hkv, long long slot_stride,
+                                                          int t_max, float scale, int nchunk) {
     static_assert(D == 128, "lane map assumes 16 lanes x 8 dims");
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-    const int head = blockIdx.x * 4 + wave, row = blockIdx.y;
+    const int head = blockIdx.x * 4 + wave, row = blockIdx.y, chunk = blockIdx.z;
     if (head >= H) return;
     const int g = lane >> 4, j = lane & 15;
     const AttnRow ar = rows[row];
+    float* wsp = ws + (((size_t)row * H + head) * nchunk + chunk) * (D + 2);
+    const int k0 = chunk * ATT_CH, k1 = min(ar.len, k0 + ATT_CH);
+    if (k0 >= ar.len) {                                   // empty chunk: neutral partial
+        if (lane == 0) { wsp[D] = -INFINITY; wsp[D + 1] = 0.f; }
+        return;
+    }
     const int kvh = head / (H / Hkv);
     uint4 qv = *reinterpret_cast<const uint4*>(q + ((size_t)row * H + head) * D + j * 8);
-    float qf[8] = {lo(qv.x) * scale, hi(qv.x) * scale, lo(qv.y) * scale, hi(qv.y) * scale,
-                   lo(qv.z) * scale, hi(qv.z) * scale, lo(qv.w) * scale, hi(qv.w) * scale};
+    const float qf[8] = {lo(qv.x) * scale, hi(qv.x) * scale, lo(qv.y) * scale, hi(qv.y) * scale,
+                         lo(qv.z) * scale, hi(qv.z) * scale, lo(qv.w) * scale, hi(qv.w) * scale};
+    const size_t hoff = (size_t)kvh * t_max * D + j * 8;
+    const uint16_t* k_own = kc + (size_t)ar.slot * slot_stride + hoff;
+    const uint16_t* k_pre = kc + (size_t)ar.pslot * slot_stride + hoff;
+    const uint16_t* v_own = vc + (size_t)ar.slot * slot_stride + hoff;
+    const uint16_t* v_pre = vc + (size_t)ar.pslot * slot_stride + hoff;
     float m = -INFINITY, l = 0.f, acc[8] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
-    auto span = [&](int slot, int t0, int t1) {
-        const size_t base = (size_t)slot * slot_stride + (size_t)kvh * t_max * D;
-        for (int t = t0 + g; t < t1; t += 4) {     // trip counts differ per 16-lane group; shuffles stay inside a group
-            uint4 kv = *reinterpret_cast<const uint4*>(kc + base + (size_t)t * D + j * 8);
-            uint4 vv = *reinterpret_cast<const uint4*>(vc + base + (size_t)t * D + j * 8);
-            float s = qf[0] * lo(kv.x) + qf[1] * hi(kv.x) + qf[2] * lo(kv.y) + qf[3] * hi(kv.y)
-                    + qf[4] * lo(kv.z) + qf[5] * hi(kv.z) + qf[6] * lo(kv.w) + qf[7] * hi(kv.w);
+    constexpr int U = 4;
+    for (int t0 = k0 + g; t0 < k1; t0 += 4 * U) {
+        uint4 kv[U], vv[U];
+#pragma unroll
+        for (int u = 0; u < U; ++u) {
+            const int t = t0 + 4 * u;
+            const int tt = t < k1 ? t : k1 - 1;
+            const bool pre = tt < ar.plen;
+            kv[u] = *reinterpret_cast<const uint4*>((pre ? k_pre : k_own) + (size_t)tt * D);
+            vv[u] = *reinterpret_cast<const uint4*>((pre ? v_pre : v_own) + (size_t)tt * D);
+        }
+#pragma unroll
+        for (int u = 0; u < U; ++u) {
+            float s = qf[0] * lo(kv[u].x) + qf[1] * hi(kv[u].x) + qf[2] * lo(kv[u].y) + qf[3] * hi(kv[u].y)
+                    + qf[4] * lo(kv[u].z) + qf[5] * hi(kv[u].z) + qf[6] * lo(kv[u].w) + qf[7] * hi(kv[u].w);
             s += __shfl_xor(s, 1); s += __shfl_xor(s, 2); s += __shfl_xor(s, 4); s += __shfl_xor(s, 8);
-            {
+            if (t0 + 4 * u < k1) {
                 const float mn = fmaxf(m, s);
                 const float corr = __expf(m - mn), p = __expf(s - mn);
                 l = l * corr + p;
-                acc[0] = acc[0] * corr + p * lo(vv.x); acc[1] = acc[1] * corr + p * hi(vv.x);
-                acc[2] = acc[2] * corr + p * lo(vv.y); acc[3] = acc[3] * corr + p * hi(vv.y);
-                acc[4] = acc[4] * corr + p * lo(vv.z); acc[5] = acc[5] * corr + p * hi(vv.z);
-                acc[6] = acc[6] * corr + p * lo(vv.w); acc[7] = acc[7] * corr + p * hi(vv.w);
+                acc[0] = acc[0] * corr + p * lo(vv[u].x); acc[1] = acc[1] * corr + p * hi(vv[u].x);
+                acc[2] = acc[2] * corr + p * lo(vv[u].y); acc[3] = acc[3] * corr + p * hi(vv[u].y);
+                acc[4] = acc[4] * corr + p * lo(vv[u].z); acc[5] = acc[5] * corr + p * hi(vv[u].z);
+                acc[6] = acc[6] * corr + p * lo(vv[u].w); acc[7] = acc[7] * corr + p * hi(vv[u].w);
                 m = mn;
             }
         }
-    };
-    if (ar.plen > 0) span(ar.pslot, 0, ar.plen);
-    span(ar.slot, ar.plen, ar.len);
+    }
     // merge the 4 lane groups (xor 16, 32)
 #pragma unroll
     for (int o = 16; o <= 32; o <<= 1) {
@@ -275,12 +298,33 @@ __global__ void __launch_bounds__(256) decode_attn_kernel(const uint16_t* __rest
         m = mn;
     }
     if (g == 0) {
-        const float inv = 1.f / l;
-        uint4 o;
-        o.x = pack(acc[0] * inv, acc[1] * inv); o.y = pack(acc[2] * inv, acc[3] * inv);
-        o.z = pack(acc[4] * inv, acc[5] * inv); o.w = pack(acc[6] * inv, acc[7] * inv);
-        *reinterpret_cast<uint4*>(out + ((size_t)row * H + head) * D + j * 8) = o;
+        *reinterpret_cast<float4*>(wsp + j * 8) = make_float4(acc[0], acc[1], acc[2], acc[3]);
+        *reinterpret_cast<float4*>(wsp + j * 8 + 4) = make_float4(acc[4], acc[5], acc[6], acc[7]);
+        if (j == 0) { wsp[D] = m; wsp[D + 1] = l; }
     }
+}
+
+// one wave per (row, head): lane owns dims 2*lane, 2*lane+1
+template <int D>
+__global__ void __launch_bounds__(256) decode_attn_combine_kernel(const float* __restrict__ ws, const AttnRow* __restrict__ rows,
+                                                                  uint16_t* __restrict__ out, int H, int nchunk) {
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int head = blockIdx.x * 4 + wave, row = blockIdx.y;
+    if (head >= H) return;
+    const int used = min(nchunk, (rows[row].len + ATT_CH - 1) / ATT_CH);
+    const float* base = ws + ((size_t)row * H + head) * nchunk * (D + 2);
+    float M = -INFINITY;
+    for (int c = 0; c < used; ++c) M = fmaxf(M, base[c * (D + 2) + D]);
+    float L = 0.f, a0 = 0.f, a1 = 0.f;
+    for (int c = 0; c < used; ++c) {
+        const float* p = base + c * (D + 2);
+        const float w = __expf(p[D] - M);
+        L += w * p[D + 1];
+        const float2 v = *reinterpret_cast<const float2*>(p + 2 * lane);
+        a0 += w * v.x; a1 += w * v.y;
+    }
+    const float inv = 1.f / L;
+    reinterpret_cast<uint32_t*>(out + ((size_t)row * H + head) * D)[lane] = pack(a0 * inv, a1 * inv);
 }
 
 inline int ok(hipError_t) { return hipGetLastError() == hipSuccess ? VDD_OK : VDD_ERR_LAUNCH; }
@@ -339,14 +383,22 @@ int vdd_skinny_gemm(const void* X, const void* W, const void* R, void* Y, int M,
     return ok(hipSuccess);
 }
 
-int vdd_decode_attention(const void* q, const void* k_cache, const void* v_cache, const int32_t* rows, void* out, int M, int H,
-                         int Hkv, int D, int64_t slot_stride, int t_max, float scale, void* stream) {
+int vdd_decode_attention(const void* q, const void* k_cache, const void* v_cache, const int32_t* rows, void* out, void* workspace,
+                         int M, int H, int Hkv, int D, int64_t slot_stride, int t_max, int max_len, float scale, void* stream) {
     if (M <= 0) return VDD_OK;
-    if (!q || !k_cache || !v_cache || !rows || !out || D != 128 || H % Hkv != 0) return VDD_ERR_INVALID_ARG;
-    hipLaunchKernelGGL(decode_attn_kernel<128>, dim3((H + 3) / 4, M), dim3(256), 0, (hipStream_t)stream, (const uint16_t*)q,
-                       (const uint16_t*)k_cache, (const uint16_t*)v_cache, (const AttnRow*)rows, (uint16_t*)out, H, Hkv,
-                       (long long)slot_stride, t_max, scale);
+    if (!q || !k_cache || !v_cache || !rows || !out || !workspace || D != 128 || H % Hkv != 0 || max_len <= 0) return VDD_ERR_INVALID_ARG;
+    const int nchunk = (max_len + ATT_CH - 1) / ATT_CH;
+    hipStream_t st = (hipStream_t)stream;
+    hipLaunchKernelGGL(decode_attn_kernel<128>, dim3((H + 3) / 4, M, nchunk), dim3(256), 0, st, (const uint16_t*)q,
+                       (const uint16_t*)k_cache, (const uint16_t*)v_cache, (const AttnRow*)rows, (float*)workspace, H, Hkv,
+                       (long long)slot_stride, t_max, scale, nchunk);
+    hipLaunchKernelGGL(decode_attn_combine_kernel<128>, dim3((H + 3) / 4, M), dim3(256), 0, st, (const float*)workspace,
+                       (const AttnRow*)rows, (uint16_t*)out, H, nchunk);
     return ok(hipSuccess);
+}
+
+int64_t vdd_decode_attention_workspace_bytes(int M, int H, int D, int max_len) {
+    return (int64_t)M * H * ((max_len + ATT_CH - 1) / ATT_CH) * (D + 2) * 4;
 }
 
 }  // extern "C"

@@ -304,6 +304,90 @@ class GenerateOutput:
         return getattr(self, k)
 
 
+class _DecodeRunner:
+    """One decode step over static device buffers, so that it can be captured once and replayed as a HIP graph:
+    token broadcast -> 32 x (rmsnorm, qkv, rope+KV write, attention, o-proj, rmsnorm, gate/up, silu*mul, down)
+    -> final norm -> lm_head -> fused contrastive sampling tail -> state update.  No host interaction."""
+
+    def __init__(self, eng, Q, nb, max_new, tail):
+        dev = eng.device
+        self.eng, self.Q, self.nb, self.tail = eng, Q, nb, tail
+        R = nb * Q
+        i32 = dict(dtype=torch.int32, device=dev)
+        self.tokens_rows = torch.zeros(R, dtype=torch.long, device=dev)
+        self.pos, self.slot, self.rows = torch.zeros(R, **i32), torch.zeros(R, **i32), torch.zeros(R, 4, **i32)
+        self.tok = torch.zeros(Q, dtype=torch.long, device=dev)
+        self.unfinished = torch.ones(Q, dtype=torch.long, device=dev)
+        self.gen = torch.zeros(Q, max_new + 1, dtype=torch.long, device=dev)     # +1: slack column, never returned
+        self.step_idx = torch.zeros(1, dtype=torch.long, device=dev)
+        self.ctr = torch.zeros(1, dtype=torch.long, device=dev)
+        self.status, self.status0, self._st = torch.zeros(Q, **i32), torch.zeros(Q, **i32), torch.zeros(Q, **i32)
+        self.scores_buf = torch.empty(Q, eng.cfg.lm.vocab, dtype=torch.bfloat16, device=dev) if tail["output_scores"] else None
+        self.graph = None
+        self._tried = False
+
+    def reset(self, ctr0):
+        self.unfinished.fill_(1)
+        self.status.zero_(); self.status0.zero_()
+        self.step_idx.fill_(0)
+        self.ctr.fill_(ctr0)
+
+    def load(self, pos, slot, rows):
+        dev = self.eng.device
+        self.pos.copy_(torch.tensor(pos, dtype=torch.int32)); self.slot.copy_(torch.tensor(slot, dtype=torch.int32))
+        self.rows.copy_(torch.tensor(rows, dtype=torch.int32))
+        self.gen[:, 0] = self.tok
+        self.step_idx.fill_(1)
+        self.ctr += 1
+
+    def body(self, kv):
+        t, Q, nb = self.tail, self.Q, self.nb
+        self.tokens_rows.view(nb, Q).copy_(self.tok[None].expand(nb, Q))        # same new token for every branch of a question
+        logits = self.eng.lm.decode_step(self.tokens_rows, self.pos, self.slot, self.rows, kv)
+        v, c, d = logits[:Q], None, None
+        if t["contrast"]:
+            if t["is_vcd"]:
+                c = v                                                           # quirk #1: the cd branch runs on the main cache -> c == v
+                d = logits[Q:2 * Q] if t["both"] else None
+            else:
+                c = logits[Q:2 * Q]
+                d = logits[2 * Q:3 * Q] if nb == 3 else None
+        eos_kw = dict(eos_ids=t["eos_t"], pad_id=t["pad"], unfinished=self.unfinished) if t["eos_t"] is not None else {}
+        contrast_sample(v, c, d, alpha=t["alpha"], beta=t["beta"], warp=t["warp"], out_tokens=self.tok, out_scores=self.scores_buf,
+                        pick_argmax=t["greedy"], seed=0, offset=0, offset_ptr=self.ctr, status_out=self._st, **eos_kw)
+        self.status |= self._st
+        self.gen.index_copy_(1, self.step_idx, self.tok[:, None])
+        self.pos += 1
+        self.rows[:, 1] += 1
+        self.step_idx += 1
+        self.ctr += 1
+
+    def _state(self):
+        return [self.tokens_rows, self.pos, self.slot, self.rows, self.tok, self.unfinished, self.gen, self.step_idx, self.ctr,
+                self.status, self._st]
+
+    def step(self, kv):
+        if self.graph is None and self.eng.use_graph and not self._tried:
+            self._tried = True
+            saved = [x.clone() for x in self._state()]
+            side = torch.cuda.Stream(device=self.eng.device)
+            side.wait_stream(torch.cuda.current_stream(self.eng.device))
+            with torch.cuda.stream(side):                       # warm-up: library handles, allocator pools, attention workspace
+                for _ in range(2):
+                    self.body(kv)
+                    for x, sv in zip(self._state(), saved):     # the warm-ups only scribble the KV row of the CURRENT position,
+                        x.copy_(sv)                             # which the real step rewrites before reading it
+            torch.cuda.current_stream(self.eng.device).wait_stream(side)
+            g = torch.cuda.CUDAGraph()
+            with torch.cuda.graph(g):
+                self.body(kv)
+            self.graph = g
+        if self.graph is not None:
+            self.graph.replay()
+        else:
+            self.body(kv)
+
+
 class VddLlavaEngine:
     """model.generate()-compatible surface (llava_calibrate.py:161-177) over the native kernels."""
 
@@ -418,71 +502,61 @@ class VddLlavaEngine:
                 self.debug_logits0 = logits0
         V = lm.vocab
 
-        # ---- device-resident decode state --------------------------------------------------------------
-        R = nb * Q
+        # ---- step 0: sample from the prefill logits (eager; also yields the top-n for calibration) -----------
         seg = plan["suffix"]
-        d_pos = torch.tensor([s["pos0"] + s["T"] for s in seg], dtype=torch.int32, device=dev)          # next position per row
-        d_slot = torch.tensor([s["slot"] for s in seg], dtype=torch.int32, device=dev)
-        d_rows = torch.tensor([[s["slot"], s["pos0"] + s["T"] + 1, s["pslot"], s["plen"]] for s in seg], dtype=torch.int32, device=dev)
-        gen = torch.zeros(Q, max_new_tokens, dtype=torch.long, device=dev)
-        unfinished = torch.ones(Q, dtype=torch.long, device=dev)
+        sd = (torch.initial_seed() if seed is None else int(seed)) & 0xFFFFFFFF
+        ctr0 = sd << 24                                       # device-side Philox counter = (seed, step): graphs are seed-agnostic
         eos_t = torch.tensor(eos_token_id, dtype=torch.long, device=dev) if eos_token_id is not None else None
-        eos_kw = dict(eos_ids=eos_t, pad_id=pad_token_id, unfinished=unfinished) if eos_t is not None else {}
-        statuses, scores = [], ([] if output_scores else None)
-        sd = torch.initial_seed() if seed is None else seed
-        is_vcd = use_cd
-
-        def tail(logits, step, tok_out):
-            v = logits[:Q]
-            c = d = None
-            if contrast:
-                if is_vcd and step > 0:
-                    c = v                                                                     # quirk #1: cd runs on the main cache -> c == v
-                    d = logits[Q:2 * Q] if (use_dd and use_dd_unk) else None
-                else:
-                    c = logits[Q:2 * Q]
-                    d = logits[2 * Q:3 * Q] if nb == 3 else None
-            r = contrast_sample(v, c, d, alpha=alpha, beta=beta, warp=warp, out_tokens=tok_out, return_scores=output_scores,
-                                pick_argmax=cd_greedy, seed=sd, offset=step, n_top=(n_top if step == 0 else 0), **eos_kw)
-            statuses.append(r.status)
-            if output_scores:
-                scores.append(r.scores)
-            return r
-
-        tok = torch.empty(Q, dtype=torch.long, device=dev)
-        r0 = tail(logits0, 0, tok)
-        gen[:, 0] = tok
+        cfgkey = (Q, nb, max_new_tokens, alpha, beta, warp.t, warp.k, warp.p, use_cd, use_dd, use_dd_unk, cd_greedy,
+                  tuple(eos_token_id) if eos_token_id is not None else None, pad_token_id, output_scores)
+        keep = [i for i, (name, _, _) in enumerate(branches) if not (use_cd and name == "cd")]
+        run = self._runner(cfgkey, Q, len(keep), max_new_tokens, dict(alpha=alpha, beta=beta, warp=warp, contrast=contrast,
+                           is_vcd=use_cd, both=(use_dd and use_dd_unk), greedy=cd_greedy, eos_t=eos_t, pad=pad_token_id,
+                           output_scores=output_scores))
+        run.reset(ctr0)
+        scores = [] if output_scores else None
+        v0 = logits0[:Q]
+        c0 = logits0[Q:2 * Q] if contrast else None
+        d0 = logits0[2 * Q:3 * Q] if (contrast and nb == 3) else None
+        eos_kw = dict(eos_ids=eos_t, pad_id=pad_token_id, unfinished=run.unfinished) if eos_t is not None else {}
+        r0 = contrast_sample(v0, c0, d0, alpha=alpha, beta=beta, warp=warp, out_tokens=run.tok, return_scores=output_scores,
+                             pick_argmax=cd_greedy, seed=0, offset=0, offset_ptr=run.ctr, n_top=n_top, status_out=run.status0, **eos_kw)
+        if output_scores:
+            scores.append(r0.scores)
         top_prob, top_tok = r0.top_prob, r0.top_tok
+        # the VCD branch has no state of its own after step 0 (quirk #1): only the other branches keep decoding
+        sel = [b * Q + q for b in keep for q in range(Q)]
+        run.load(pos=[seg[i]["pos0"] + seg[i]["T"] for i in sel], slot=[seg[i]["slot"] for i in sel],
+                 rows=[[seg[i]["slot"], seg[i]["pos0"] + seg[i]["T"] + 1, seg[i]["pslot"], seg[i]["plen"]] for i in sel])
         n_new = 1
-        if is_vcd:                         # the cd branch has no state of its own after step 0: drop its rows
-            keep = [i for i, (name, _, _) in enumerate(branches) if name != "cd"]
-            sel = torch.cat([torch.arange(b * Q, (b + 1) * Q, device=dev) for b in keep])
-            d_pos, d_slot, d_rows = d_pos[sel].contiguous(), d_slot[sel].contiguous(), d_rows[sel].contiguous()
-            nb = len(keep)
-            R = nb * Q
-        tokens_rows = torch.empty(R, dtype=torch.long, device=dev)
         while n_new < max_new_tokens:
-            tokens_rows.view(nb, Q).copy_(tok[None].expand(nb, Q))                             # same new token for every branch of a question
-            logits = self.lm.decode_step(tokens_rows, d_pos, d_slot, d_rows, kv)
-            tail(logits, n_new, tok)
-            gen[:, n_new] = tok
-            d_pos += 1
-            d_rows[:, 1] += 1
+            run.step(kv)
+            if output_scores:
+                scores.append(run.scores_buf.clone())
             n_new += 1
             if eos_t is not None and (n_new % sync_every == 0 or n_new == max_new_tokens):
-                if bool((unfinished.max() == 0).item()):                                      # :291, amortised over sync_every steps
+                if bool((run.unfinished.max() == 0).item()):                                  # :291, amortised over sync_every steps
                     break
-        bad = torch.stack(statuses).ne(0).any()
-        if bool(bad.item()):
+        if bool((run.status | run.status0).ne(0).any().item()):
             raise RuntimeError("probability tensor contains either `inf`, `nan` or element < 0")   # torch.multinomial, :202
-        gen = gen[:, :n_new]
+        gen = run.gen[:, :n_new].clone()
         if eos_t is not None:
             gen = self._trim_after_all_finished(gen, eos_t, pad_token_id)
             if scores is not None:
                 scores = scores[:gen.shape[1]]
         seqs_out = [torch.cat([torch.tensor(ids_list[q], device=dev), gen[q]]) for q in range(Q)]
         stats["steps"] = int(gen.shape[1])
+        stats["graph"] = run.graph is not None
         return GenerateOutput(seqs_out, gen, scores, top_prob, top_tok, stats)
+
+    def _runner(self, key, Q, nb, max_new, tail):
+        r = self._graphs.get(key)
+        if r is None:
+            if len(self._graphs) >= 4:
+                self._graphs.pop(next(iter(self._graphs)))
+            r = _DecodeRunner(self, Q, nb, max_new, tail)
+            self._graphs[key] = r
+        return r
 
     @staticmethod
     def _trim_after_all_finished(gen, eos_t, pad):

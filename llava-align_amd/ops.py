@@ -17,7 +17,7 @@ _SIGS = {
     "vdd_silu_mul": [_P, _P, _L, _I, _P],
     "vdd_embed": [_P, _P, _P, _I, _I, _P],
     "vdd_skinny_gemm": [_P, _P, _P, _P, _I, _I, _I, _L, _L, _L, _P],
-    "vdd_decode_attention": [_P, _P, _P, _P, _P, _I, _I, _I, _I, _L, _I, _F, _P],
+    "vdd_decode_attention": [_P, _P, _P, _P, _P, _P, _I, _I, _I, _I, _L, _I, _I, _F, _P],
     "vdd_flash_attention": [_P, _P, _P, _P, _P, _I, _I, _I, _I, _I, _L, _I, _F, _I, _P],
     "vdd_layernorm": [_P, _P, _P, _P, _I, _I, _F, _P],
     "vdd_bias_act": [_P, _P, _P, _L, _I, _I, _P],
@@ -96,21 +96,36 @@ def skinny_gemm(x, w, resid=None, out=None):
     return out
 
 
+SKINNY_MAX_M = 8      # measured on MI355X (tools/e2e_probe.py): 5.1-5.4 TB/s for M<=4 vs 4.0-5.0 for the library; slower past ~8 rows
+
+
 def linear(x, w, out=None):
     """Row-batched projection: hand-written weight-streaming MFMA kernel up to 64 rows (the decode
     regime), the vendor GEMM library (hipBLASLt via torch.matmul) for the large-M prefill GEMMs."""
-    if x.shape[0] <= 64 and x.shape[1] % 128 == 0:
+    if x.shape[0] <= SKINNY_MAX_M and x.shape[1] % 128 == 0:
         return skinny_gemm(x, w, out=out)
     return torch.matmul(x, w.t(), out=out) if out is not None else torch.matmul(x, w.t())
 
 
-def decode_attention(q, k_cache, v_cache, rows, H, Hkv, D, out=None):
-    """q [M, H*D]; rows int32 [M, 4] = (slot, len, prefix_slot, prefix_len)."""
+_attn_ws = {}
+
+
+def decode_attention(q, k_cache, v_cache, rows, H, Hkv, D, out=None, max_len=None):
+    """q [M, H*D]; rows int32 [M, 4] = (slot, len, prefix_slot, prefix_len); max_len bounds every len (default t_max)."""
     _bf16(q, k_cache, v_cache)
     M = q.shape[0]
+    lib = _lib_ready()
+    max_len = int(max_len) if max_len is not None else k_cache.shape[2]
+    lib.vdd_decode_attention_workspace_bytes.restype = C.c_int64
+    need = lib.vdd_decode_attention_workspace_bytes(M, H, D, max_len)
+    key = (q.device, )
+    ws = _attn_ws.get(key)
+    if ws is None or ws.numel() * 4 < need:
+        ws = torch.empty((need + 3) // 4, dtype=torch.float32, device=q.device)
+        _attn_ws[key] = ws
     out = torch.empty_like(q) if out is None else out
-    _lib.check(_lib_ready().vdd_decode_attention(q.data_ptr(), k_cache.data_ptr(), v_cache.data_ptr(), rows.data_ptr(), out.data_ptr(),
-                                                 M, H, Hkv, D, k_cache.stride(0), k_cache.shape[2], D ** -0.5, _st(q)))
+    _lib.check(lib.vdd_decode_attention(q.data_ptr(), k_cache.data_ptr(), v_cache.data_ptr(), rows.data_ptr(), out.data_ptr(),
+                                        ws.data_ptr(), M, H, Hkv, D, k_cache.stride(0), k_cache.shape[2], max_len, D ** -0.5, _st(q)))
     return out
 
 

@@ -82,7 +82,8 @@ def contrast_sample(logits_v: torch.Tensor, logits_cd: Optional[torch.Tensor] = 
                     out_tokens: Optional[torch.Tensor] = None, return_scores: bool = False,
                     out_scores: Optional[torch.Tensor] = None, n_top: int = 0, pick_argmax: bool = False,
                     no_sample: bool = False, cutoff_f32_scalar: bool = False, temp_reciprocal: bool = False,
-                    workspace: Optional[torch.Tensor] = None, stream: Optional[int] = None) -> SampleOutput:
+                    workspace: Optional[torch.Tensor] = None, stream: Optional[int] = None,
+                    offset_ptr: Optional[torch.Tensor] = None, status_out: Optional[torch.Tensor] = None) -> SampleOutput:
     """Fused contrastive sampling tail on [B, V] last-position logits (any row stride).
 
     logits_cd=None is the reference's plain path (:204-207); logits_dd selects the
@@ -123,6 +124,8 @@ def contrast_sample(logits_v: torch.Tensor, logits_cd: Optional[torch.Tensor] = 
     prm.temperature, prm.top_p, prm.top_k = warp.t, warp.p, warp.k
     prm.philox_seed = (torch.initial_seed() if seed is None else int(seed)) & 0xFFFFFFFFFFFFFFFF
     prm.philox_offset = next(_offset_counter) if offset is None else int(offset)
+    if offset_ptr is not None:                     # int64 device scalar added to the offset at run time (graph replay)
+        prm.philox_offset_ptr = offset_ptr.data_ptr()
     if uniforms is not None:
         if uniforms.dtype != torch.float32 or uniforms.numel() != B or not uniforms.is_contiguous():
             raise ValueError("uniforms must be contiguous fp32 [B]")
@@ -154,7 +157,7 @@ def contrast_sample(logits_v: torch.Tensor, logits_cd: Optional[torch.Tensor] = 
         top_prob = torch.empty(B, n_top, dtype=torch.float32, device=dev)
         top_tok = torch.empty(B, n_top, dtype=torch.long, device=dev)
         prm.top_prob, prm.top_tok, prm.n_top = top_prob.data_ptr(), top_tok.data_ptr(), n_top
-    status = torch.empty(B, dtype=torch.int32, device=dev)
+    status = status_out if status_out is not None else torch.empty(B, dtype=torch.int32, device=dev)
     prm.row_status = status.data_ptr()
     st = torch.cuda.current_stream(dev).cuda_stream if stream is None else stream
     with torch.cuda.device(dev):

@@ -14,9 +14,14 @@ from toy_lm import IMAGE_TOKEN_INDEX, _Proto, _gen_cfg
 
 
 class RefLlava(_Proto):
-    def __init__(self, weights, device="cpu", logit_dtype=torch.bfloat16, pad=0, eos=None):
+    def __init__(self, weights, device="cpu", logit_dtype=torch.bfloat16, pad=0, eos=None, dtype=torch.float32,
+                 output_attentions=False):
+        """dtype=float32: numerics reference.  dtype=bfloat16/float16: what the reference's eager HF stack executes
+        (weights and matmuls in the model dtype, fp32 softmax / norm statistics, KV cache grown by torch.cat)."""
         self.cfg = weights.cfg
-        self.w = {k: v.detach().to(device=device, dtype=torch.float32) for k, v in weights.t.items()}
+        self.dtype = dtype
+        self.materialize_attn = output_attentions            # llava_calibrate.py:175 asks for the [H, T, S] maps every step
+        self.w = {k: v.detach().to(device=device, dtype=dtype) for k, v in weights.t.items()}
         self.device = torch.device(device)
         self.logit_dtype = logit_dtype
         self.generation_config = _gen_cfg(pad, eos)
@@ -29,20 +34,21 @@ class RefLlava(_Proto):
     # ---- vision ----
     def encode_images(self, images):
         v, w = self.cfg.vision, self.w
-        x = images.to(self.device, torch.bfloat16).float()
+        x = images.to(self.device, torch.bfloat16).to(self.dtype)
         n = x.shape[0]
         P, G = v.patch, v.image // v.patch
         patches = x.view(n, 3, G, P, G, P).permute(0, 2, 4, 1, 3, 5).reshape(n, G * G, 3 * P * P)
         h = patches @ w["v.patch"][:, : 3 * P * P].t()
         h = torch.cat([w["v.cls"].view(1, 1, -1).expand(n, 1, -1), h], 1) + w["v.pos"][None]
         h = F.layer_norm(h, (v.width,), w["v.pre_ln.w"], w["v.pre_ln.b"], v.eps)
+        sm = lambda t: t.float().softmax(-1).to(self.dtype)
         H, D = v.heads, v.width // v.heads
         for i in range(v.run_layers):
             p = f"v{i}."
             a = F.layer_norm(h, (v.width,), w[p + "ln1.w"], w[p + "ln1.b"], v.eps)
             qkv = (a @ w[p + "wqkv"].t() + w[p + "bqkv"]).view(n, -1, 3, H, D)
             q, k, val = (qkv[:, :, j].transpose(1, 2) for j in range(3))
-            att = ((q @ k.transpose(-1, -2)) / math.sqrt(D)).softmax(-1) @ val
+            att = sm((q @ k.transpose(-1, -2)) / math.sqrt(D)) @ val
             h = h + att.transpose(1, 2).reshape(n, -1, v.width) @ w[p + "wo"].t() + w[p + "bo"]
             a = F.layer_norm(h, (v.width,), w[p + "ln2.w"], w[p + "ln2.b"], v.eps)
             f = a @ w[p + "fc1"].t() + w[p + "b1"]
@@ -54,7 +60,7 @@ class RefLlava(_Proto):
     # ---- language model ----
     def _rope(self, x, pos):            # x [1, H, T, D]
         D = x.shape[-1]
-        c, s = self.cos[pos][None, None], self.sin[pos][None, None]
+        c, s = self.cos[pos][None, None].to(x.dtype), self.sin[pos][None, None].to(x.dtype)
         a, b = x[..., : D // 2], x[..., D // 2:]
         return torch.cat([a * c - b * s, b * c + a * s], -1)
 
@@ -65,7 +71,7 @@ class RefLlava(_Proto):
         pos = torch.arange(p0, p0 + T, device=self.device)
         h = emb
         new = []
-        rms = lambda x, g: x * torch.rsqrt(x.pow(2).mean(-1, keepdim=True) + lm.eps) * g
+        rms = lambda x, g: (x.float() * torch.rsqrt(x.float().pow(2).mean(-1, keepdim=True) + lm.eps)).to(x.dtype) * g
         H, Hkv, D = lm.n_heads, lm.n_kv_heads, lm.head_dim
         for i in range(lm.n_layers):
             p = f"l{i}."
@@ -82,11 +88,15 @@ class RefLlava(_Proto):
             s = (q @ kk.transpose(-1, -2)) / math.sqrt(D)
             S = kk.shape[2]
             mask = torch.ones(T, S, dtype=torch.bool, device=self.device).tril(diagonal=S - T)
-            att = s.masked_fill(~mask, -float("inf")).softmax(-1) @ vv
+            pw = s.masked_fill(~mask, -float("inf")).float().softmax(-1).to(self.dtype)     # materialised [1, H, T, S]
+            att = pw @ vv
             h = h + att.transpose(1, 2).reshape(1, T, H * D) @ w[p + "wo"].t()
             a = rms(h, w[p + "ln2"])
             gu = a @ w[p + "wgu"].t()
             h = h + (F.silu(gu[..., : lm.ffn]) * gu[..., lm.ffn:]) @ w[p + "wd"].t()
+        if lm.n_layers == 0:                    # depth-0 model (bench.py's fixed-cost measurement): keep a length-carrying dummy cache
+            z = torch.zeros(1, 1, p0 + T, 1, device=self.device)
+            new = [(z, z)]
         return rms(h, w["norm"]) @ w["lm_head"].t(), tuple(new)
 
     def __call__(self, input_ids=None, attention_mask=None, past_key_values=None, inputs_embeds=None, use_cache=None,
@@ -101,6 +111,6 @@ class RefLlava(_Proto):
             s = int(torch.where(row == IMAGE_TOKEN_INDEX)[0][0])
             feat = self.encode_images(images)[0]
             emb = torch.cat([self.w["embed"][row[:s]], feat, self.w["embed"][row[s + 1:]]], 0)[None]
-        emb = emb.to(torch.bfloat16).float()
+        emb = emb.to(torch.bfloat16).to(self.dtype)
         logits, past = self._lm(emb, past_key_values)
         return SimpleNamespace(logits=logits.to(self.logit_dtype).cpu(), past_key_values=past, attentions=None, hidden_states=None)

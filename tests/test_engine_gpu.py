@@ -171,3 +171,18 @@ def test_sampled_mode_runs_and_is_seed_reproducible(eng):
     b = eng.generate(ids, seed=1, **kw)
     c = eng.generate(ids, seed=2, **kw)
     assert torch.equal(a.tokens, b.tokens) and not torch.equal(a.tokens, c.tokens)
+
+
+def test_hip_graph_replay_matches_eager(eng):
+    from llava_align_amd.engine import VddLlavaEngine
+    g = VddLlavaEngine(eng.cfg, weights=eng.w, device=DEV, t_max=256, use_graph=True)
+    ids, imgs = prompts(seed=13)
+    for kw in (dict(use_dd_unk=True, cd_greedy=True, temperature=0.5),
+               dict(use_dd=True, use_dd_unk=True, temperature=1.0, top_p=0.9, seed=5),
+               dict(use_dd_unk=True, temperature=1.0, seed=6, eos_token_id=[7, 11], pad_token_id=0)):
+        a = eng.generate(ids, images=imgs, cd_alpha=1.0, cd_beta=0.2, max_new_tokens=7, output_scores=True, **kw)
+        for rep in range(2):                               # second call replays the cached graph with fresh state
+            b = g.generate(ids, images=imgs, cd_alpha=1.0, cd_beta=0.2, max_new_tokens=7, output_scores=True, **kw)
+            assert b.stats["graph"] and not a.stats["graph"]
+            assert torch.equal(a.tokens, b.tokens)
+            assert all(torch.equal(x, y) for x, y in zip(a.scores, b.scores))
