@@ -118,10 +118,11 @@ int vdd_rmsnorm(const void* x, const void* delta, const void* w, void* y, void* 
                 void* hip_stream);
 
 /* qkv [M, (Hq+2Hkv)*D] -> q_out [M, Hq, D] with rotary embedding at pos[row] (HF rotate_half pairing;
- * cos_sin fp32 [max_pos, D/2, 2]); k (rotated) and v are written to cache[slot[row]][kv_head][pos[row]][D]
- * (cache slot stride in elements; t_max tokens per slot). */
-int vdd_rope_kv_write(const void* qkv, const int* pos, const int* slot, const float* cos_sin, void* q_out, void* k_cache,
-                      void* v_cache, int M, int Hq, int Hkv, int D, int64_t slot_stride, int t_max, void* hip_stream);
+ * cos_sin fp32 [max_pos, D/2, 2]); k (rotated) and v are written to cache[slot[row]][kv_head][cpos[row]][D]
+ * (cpos = index inside the slot: pos for a prefix slot, pos - prefix_len for a compact own slot;
+ * cache slot stride in elements; t_max tokens per slot). */
+int vdd_rope_kv_write(const void* qkv, const int* pos, const int* cpos, const int* slot, const float* cos_sin, void* q_out,
+                      void* k_cache, void* v_cache, int M, int Hq, int Hkv, int D, int64_t slot_stride, int t_max, void* hip_stream);
 
 /* out[m, f] = silu(gate_up[m, f]) * gate_up[m, F + f]. */
 int vdd_silu_mul(const void* gate_up, void* out, int64_t M, int F, void* hip_stream);
@@ -133,21 +134,25 @@ int vdd_skinny_gemm(const void* X, const void* W, const void* R, void* Y, int M,
                     int64_t ldy, void* hip_stream);
 
 /* One query per (row, head) over that row's KV: rows[m] = {slot, len, prefix_slot, prefix_len} (int32 x4);
- * tokens [0, prefix_len) are read from prefix_slot (shared prompt prefix), [prefix_len, len) from slot. D == 128.
+ * tokens [0, prefix_len) are read from the PREFIX pool (k_prefix/v_prefix, slot prefix_slot, index t: a shared
+ * prompt prefix), tokens [prefix_len, len) from the OWN pool (k_cache/v_cache, slot `slot`, index t - prefix_len).
+ * The two pools may be the same buffer. D == 128.
  * Split-KV: the key range is cut in 64-key chunks processed by independent waves (partials in `workspace`,
  * vdd_decode_attention_workspace_bytes(M, H, D, max_len) bytes, max_len >= every rows[m].len) and merged. */
-int vdd_decode_attention(const void* q, const void* k_cache, const void* v_cache, const int32_t* rows, void* out, void* workspace,
-                         int M, int H, int Hkv, int D, int64_t slot_stride, int t_max, int max_len, float scale, void* hip_stream);
+int vdd_decode_attention(const void* q, const void* k_cache, const void* v_cache, const void* k_prefix, const void* v_prefix,
+                         const int32_t* rows, void* out, void* workspace, int M, int H, int Hkv, int D, int64_t slot_stride, int t_max,
+                         int64_t prefix_stride, int prefix_tmax, int max_len, float scale, void* hip_stream);
 int64_t vdd_decode_attention_workspace_bytes(int M, int H, int D, int max_len);
 
 /* Prefill attention (MFMA, flash-style).  q/out [Ttot, H*D] packed by sequence; seqs[s] = {q_row0, Tq, pos0,
  * slot, prefix_slot, prefix_len} (int32 x6): query i of sequence s sits at position pos0+i and attends keys
- * [0, pos0+i] (causal) or [0, pos0+Tq) (non-causal) read from the cache (prefix slot below prefix_len, own
- * slot above), whose K/V for the new tokens must already be written.  D in {64, 128}.
+ * [0, pos0+i] (causal) or [0, pos0+Tq) (non-causal) read from the caches (prefix pool below prefix_len, own
+ * pool at index t - prefix_len above, as in vdd_decode_attention), whose K/V for the new tokens must already be
+ * written.  D in {64, 128}.
  * Replaces the eager attention of LlamaModel / CLIPVisionModel at step 0 (llava_arch.py:82-204). */
-int vdd_flash_attention(const void* q, const void* k_cache, const void* v_cache, const int32_t* seqs, void* out, int n_seq,
-                        int max_tq, int H, int Hkv, int D, int64_t slot_stride, int t_max, float scale, int causal,
-                        void* hip_stream);
+int vdd_flash_attention(const void* q, const void* k_cache, const void* v_cache, const void* k_prefix, const void* v_prefix,
+                        const int32_t* seqs, void* out, int n_seq, int max_tq, int H, int Hkv, int D, int64_t slot_stride, int t_max,
+                        int64_t prefix_stride, int prefix_tmax, float scale, int causal, void* hip_stream);
 
 /* CLIP ViT LayerNorm (with bias); d % 8 == 0, d <= 4096. */
 int vdd_layernorm(const void* x, const void* w, const void* b, void* y, int M, int d, float eps, void* hip_stream);

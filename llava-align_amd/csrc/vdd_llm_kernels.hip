@@ -93,12 +93,13 @@ __global__ void __launch_bounds__(256) rmsnorm_kernel(const uint16_t* __restrict
 // chunk.  rotate_half pairing (HF Llama): (i, i + D/2).  cos/sin table: fp32 [max_pos, D/2].
 // K/V go to cache[slot][kv_head][pos][D].
 __global__ void __launch_bounds__(256) rope_kv_kernel(const uint16_t* __restrict__ qkv, const int* __restrict__ pos,
-                                                      const int* __restrict__ slot, const float* __restrict__ cs_table,
+                                                      const int* __restrict__ cpos, const int* __restrict__ slot,
+                                                      const float* __restrict__ cs_table,
                                                       uint16_t* __restrict__ q_out, uint16_t* __restrict__ k_cache,
                                                       uint16_t* __restrict__ v_cache, int Hq, int Hkv, int D,
                                                       long long slot_stride, int t_max) {
     const int row = blockIdx.x, tid = threadIdx.x;
-    const int p = pos[row], s = slot[row];
+    const int p = pos[row], s = slot[row], cp = cpos[row];     // rotary position vs index inside the cache slot
     const int half = D / 2;
     const int nq = Hq * half, nk = Hkv * half;
     const uint16_t* src = qkv + (size_t)row * (size_t)((Hq + 2 * Hkv) * D);
@@ -110,14 +111,14 @@ __global__ void __launch_bounds__(256) rope_kv_kernel(const uint16_t* __restrict
         const float c = cs_table[((size_t)p * half + pi) * 2], sn = cs_table[((size_t)p * half + pi) * 2 + 1];
         const float a = bf2f(hsrc[pi]), b = bf2f(hsrc[pi + half]);
         const uint16_t r0 = (uint16_t)f2bf(a * c - b * sn), r1 = (uint16_t)f2bf(b * c + a * sn);
-        uint16_t* dst = is_k ? k_cache + (size_t)s * slot_stride + ((size_t)head * t_max + p) * D
+        uint16_t* dst = is_k ? k_cache + (size_t)s * slot_stride + ((size_t)head * t_max + cp) * D
                              : q_out + (size_t)row * Hq * D + (size_t)head * D;
         dst[pi] = r0; dst[pi + half] = r1;
     }
     const uint16_t* vsrc = src + (size_t)(Hq + Hkv) * D;
     for (int i = tid; i < Hkv * D / 8; i += 256) {
         const int head = (i * 8) / D, dd = (i * 8) % D;
-        *reinterpret_cast<uint4*>(v_cache + (size_t)s * slot_stride + ((size_t)head * t_max + p) * D + dd) =
+        *reinterpret_cast<uint4*>(v_cache + (size_t)s * slot_stride + ((size_t)head * t_max + cp) * D + dd) =
             *reinterpret_cast<const uint4*>(vsrc + (size_t)i * 8);
     }
 }
@@ -233,9 +234,10 @@ constexpr int ATT_CH = 64;
 
 template <int D>   // head dim 128
 __global__ void __launch_bounds__(256) decode_attn_kernel(const uint16_t* __restrict__ q, const uint16_t* __restrict__ kc,
-                                                          const uint16_t* __restrict__ vc, const AttnRow* __restrict__ rows,
+                                                          const uint16_t* __restrict__ vc, const uint16_t* __restrict__ kpre,
+                                                          const uint16_t* __restrict__ vpre, const AttnRow* __restrict__ rows,
                                                           float* __restrict__ ws, int H, int Hkv, long long slot_stride,
-                                                          int t_max, float scale, int nchunk) {
+                                                          int t_max, long long pre_stride, int pre_tmax, float scale, int nchunk) {
     static_assert(D == 128, "lane map assumes 16 lanes x 8 dims");
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     const int head = blockIdx.x * 4 + wave, row = blockIdx.y, chunk = blockIdx.z;
@@ -252,11 +254,12 @@ __global__ void __launch_bounds__(256) decode_attn_kernel(const uint16_t* __rest
     uint4 qv = *reinterpret_cast<const uint4*>(q + ((size_t)row * H + head) * D + j * 8);
     const float qf[8] = {lo(qv.x) * scale, hi(qv.x) * scale, lo(qv.y) * scale, hi(qv.y) * scale,
                          lo(qv.z) * scale, hi(qv.z) * scale, lo(qv.w) * scale, hi(qv.w) * scale};
-    const size_t hoff = (size_t)kvh * t_max * D + j * 8;
-    const uint16_t* k_own = kc + (size_t)ar.slot * slot_stride + hoff;
-    const uint16_t* k_pre = kc + (size_t)ar.pslot * slot_stride + hoff;
-    const uint16_t* v_own = vc + (size_t)ar.slot * slot_stride + hoff;
-    const uint16_t* v_pre = vc + (size_t)ar.pslot * slot_stride + hoff;
+    // own pool stores token t at index t - plen (compact slots); the prefix pool at index t
+    const size_t hoff = (size_t)kvh * t_max * D + j * 8, poff = (size_t)kvh * pre_tmax * D + j * 8;
+    const uint16_t* k_own = kc + (size_t)ar.slot * slot_stride + hoff - (size_t)ar.plen * D;
+    const uint16_t* v_own = vc + (size_t)ar.slot * slot_stride + hoff - (size_t)ar.plen * D;
+    const uint16_t* k_pre = kpre + (size_t)ar.pslot * pre_stride + poff;
+    const uint16_t* v_pre = vpre + (size_t)ar.pslot * pre_stride + poff;
     float m = -INFINITY, l = 0.f, acc[8] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
     constexpr int U = 4;
     for (int t0 = k0 + g; t0 < k1; t0 += 4 * U) {
@@ -345,11 +348,11 @@ int vdd_rmsnorm(const void* x, const void* delta, const void* w, void* y, void* 
     return ok(hipSuccess);
 }
 
-int vdd_rope_kv_write(const void* qkv, const int* pos, const int* slot, const float* cos_sin, void* q_out, void* k_cache,
+int vdd_rope_kv_write(const void* qkv, const int* pos, const int* cpos, const int* slot, const float* cos_sin, void* q_out, void* k_cache,
                       void* v_cache, int M, int Hq, int Hkv, int D, int64_t slot_stride, int t_max, void* stream) {
     if (M <= 0) return VDD_OK;
-    if (!qkv || !pos || !slot || !cos_sin || !q_out || !k_cache || !v_cache || D % 8 != 0) return VDD_ERR_INVALID_ARG;
-    hipLaunchKernelGGL(rope_kv_kernel, dim3(M), dim3(256), 0, (hipStream_t)stream, (const uint16_t*)qkv, pos, slot, cos_sin,
+    if (!qkv || !pos || !cpos || !slot || !cos_sin || !q_out || !k_cache || !v_cache || D % 8 != 0) return VDD_ERR_INVALID_ARG;
+    hipLaunchKernelGGL(rope_kv_kernel, dim3(M), dim3(256), 0, (hipStream_t)stream, (const uint16_t*)qkv, pos, cpos, slot, cos_sin,
                        (uint16_t*)q_out, (uint16_t*)k_cache, (uint16_t*)v_cache, Hq, Hkv, D, (long long)slot_stride, t_max);
     return ok(hipSuccess);
 }
@@ -383,15 +386,17 @@ int vdd_skinny_gemm(const void* X, const void* W, const void* R, void* Y, int M,
     return ok(hipSuccess);
 }
 
-int vdd_decode_attention(const void* q, const void* k_cache, const void* v_cache, const int32_t* rows, void* out, void* workspace,
-                         int M, int H, int Hkv, int D, int64_t slot_stride, int t_max, int max_len, float scale, void* stream) {
+int vdd_decode_attention(const void* q, const void* k_cache, const void* v_cache, const void* k_prefix, const void* v_prefix,
+                         const int32_t* rows, void* out, void* workspace, int M, int H, int Hkv, int D, int64_t slot_stride, int t_max,
+                         int64_t prefix_stride, int prefix_tmax, int max_len, float scale, void* stream) {
     if (M <= 0) return VDD_OK;
-    if (!q || !k_cache || !v_cache || !rows || !out || !workspace || D != 128 || H % Hkv != 0 || max_len <= 0) return VDD_ERR_INVALID_ARG;
+    if (!q || !k_cache || !v_cache || !k_prefix || !v_prefix || !rows || !out || !workspace || D != 128 || H % Hkv != 0 || max_len <= 0) return VDD_ERR_INVALID_ARG;
     const int nchunk = (max_len + ATT_CH - 1) / ATT_CH;
     hipStream_t st = (hipStream_t)stream;
     hipLaunchKernelGGL(decode_attn_kernel<128>, dim3((H + 3) / 4, M, nchunk), dim3(256), 0, st, (const uint16_t*)q,
-                       (const uint16_t*)k_cache, (const uint16_t*)v_cache, (const AttnRow*)rows, (float*)workspace, H, Hkv,
-                       (long long)slot_stride, t_max, scale, nchunk);
+                       (const uint16_t*)k_cache, (const uint16_t*)v_cache, (const uint16_t*)k_prefix, (const uint16_t*)v_prefix,
+                       (const AttnRow*)rows, (float*)workspace, H, Hkv, (long long)slot_stride, t_max, (long long)prefix_stride,
+                       prefix_tmax, scale, nchunk);
     hipLaunchKernelGGL(decode_attn_combine_kernel<128>, dim3((H + 3) / 4, M), dim3(256), 0, st, (const float*)workspace,
                        (const AttnRow*)rows, (uint16_t*)out, H, nchunk);
     return ok(hipSuccess);

@@ -39,9 +39,10 @@ constexpr float NEG_BIG = -1.0e30f;
 
 template <int D, bool CAUSAL>
 __global__ void __launch_bounds__(256) flash_attn_kernel(const uint16_t* __restrict__ q, const uint16_t* __restrict__ kc,
-                                                         const uint16_t* __restrict__ vc, const SeqDesc* __restrict__ seqs,
+                                                         const uint16_t* __restrict__ vc, const uint16_t* __restrict__ kpre,
+                                                         const uint16_t* __restrict__ vpre, const SeqDesc* __restrict__ seqs,
                                                          uint16_t* __restrict__ out, int H, int Hkv, long long slot_stride,
-                                                         int t_max, float scale) {
+                                                         int t_max, long long pre_stride, int pre_tmax, float scale) {
     constexpr int KS = D / 32;        // k-steps of the QK^T contraction
     constexpr int NT = D / 16;        // 16-wide output tiles over the head dim
     constexpr int VLD = D + 8;        // padded V row (elements)
@@ -68,11 +69,12 @@ __global__ void __launch_bounds__(256) flash_attn_kernel(const uint16_t* __restr
 #pragma unroll
         for (int ks = 0; ks < KS; ++ks) qf[ks] = *reinterpret_cast<const bf16x8_t*>(qp + ks * 32);
     }
-    const size_t head_off = (size_t)kvh * t_max * D;
-    const uint16_t* kbase_own = kc + (size_t)sd.slot * slot_stride + head_off;
-    const uint16_t* kbase_pre = kc + (size_t)sd.pslot * slot_stride + head_off;
-    const uint16_t* vbase_own = vc + (size_t)sd.slot * slot_stride + head_off;
-    const uint16_t* vbase_pre = vc + (size_t)sd.pslot * slot_stride + head_off;
+    // own pool: token t at index t - plen (compact slots); prefix pool: token t at index t
+    const size_t head_off = (size_t)kvh * t_max * D, pre_off = (size_t)kvh * pre_tmax * D;
+    const uint16_t* kbase_own = kc + (size_t)sd.slot * slot_stride + head_off - (size_t)sd.plen * D;
+    const uint16_t* vbase_own = vc + (size_t)sd.slot * slot_stride + head_off - (size_t)sd.plen * D;
+    const uint16_t* kbase_pre = kpre + (size_t)sd.pslot * pre_stride + pre_off;
+    const uint16_t* vbase_pre = vpre + (size_t)sd.pslot * pre_stride + pre_off;
 
     f32x4_t o[NT];
 #pragma unroll
@@ -227,20 +229,22 @@ inline int ok() { return hipGetLastError() == hipSuccess ? VDD_OK : VDD_ERR_LAUN
 
 extern "C" {
 
-int vdd_flash_attention(const void* q, const void* k_cache, const void* v_cache, const int32_t* seqs, void* out, int n_seq,
-                        int max_tq, int H, int Hkv, int D, int64_t slot_stride, int t_max, float scale, int causal, void* stream) {
+int vdd_flash_attention(const void* q, const void* k_cache, const void* v_cache, const void* k_prefix, const void* v_prefix,
+                        const int32_t* seqs, void* out, int n_seq, int max_tq, int H, int Hkv, int D, int64_t slot_stride, int t_max,
+                        int64_t prefix_stride, int prefix_tmax, float scale, int causal, void* stream) {
     if (n_seq <= 0 || max_tq <= 0) return VDD_OK;
-    if (!q || !k_cache || !v_cache || !seqs || !out || (D != 128 && D != 64) || H % Hkv != 0) return VDD_ERR_INVALID_ARG;
+    if (!q || !k_cache || !v_cache || !k_prefix || !v_prefix || !seqs || !out || (D != 128 && D != 64) || H % Hkv != 0) return VDD_ERR_INVALID_ARG;
     dim3 grid((max_tq + 63) / 64, H, n_seq), block(256);
     hipStream_t st = (hipStream_t)stream;
     auto Q = (const uint16_t*)q; auto K = (const uint16_t*)k_cache; auto V = (const uint16_t*)v_cache; auto O = (uint16_t*)out;
-    auto S = (const SeqDesc*)seqs;
+    auto S = (const SeqDesc*)seqs; auto KP = (const uint16_t*)k_prefix; auto VP = (const uint16_t*)v_prefix;
+    const long long ps = (long long)prefix_stride;
     if (D == 128) {
-        if (causal) hipLaunchKernelGGL((flash_attn_kernel<128, true>), grid, block, 0, st, Q, K, V, S, O, H, Hkv, (long long)slot_stride, t_max, scale);
-        else hipLaunchKernelGGL((flash_attn_kernel<128, false>), grid, block, 0, st, Q, K, V, S, O, H, Hkv, (long long)slot_stride, t_max, scale);
+        if (causal) hipLaunchKernelGGL((flash_attn_kernel<128, true>), grid, block, 0, st, Q, K, V, KP, VP, S, O, H, Hkv, (long long)slot_stride, t_max, ps, prefix_tmax, scale);
+        else hipLaunchKernelGGL((flash_attn_kernel<128, false>), grid, block, 0, st, Q, K, V, KP, VP, S, O, H, Hkv, (long long)slot_stride, t_max, ps, prefix_tmax, scale);
     } else {
-        if (causal) hipLaunchKernelGGL((flash_attn_kernel<64, true>), grid, block, 0, st, Q, K, V, S, O, H, Hkv, (long long)slot_stride, t_max, scale);
-        else hipLaunchKernelGGL((flash_attn_kernel<64, false>), grid, block, 0, st, Q, K, V, S, O, H, Hkv, (long long)slot_stride, t_max, scale);
+        if (causal) hipLaunchKernelGGL((flash_attn_kernel<64, true>), grid, block, 0, st, Q, K, V, KP, VP, S, O, H, Hkv, (long long)slot_stride, t_max, ps, prefix_tmax, scale);
+        else hipLaunchKernelGGL((flash_attn_kernel<64, false>), grid, block, 0, st, Q, K, V, KP, VP, S, O, H, Hkv, (long long)slot_stride, t_max, ps, prefix_tmax, scale);
     }
     return ok();
 }

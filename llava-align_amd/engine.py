@@ -213,14 +213,23 @@ class VisionTower:
 
 # ------------------------------------------------------------------ language model
 class KVCache:
-    def __init__(self, lm: LMConfig, n_slots: int, t_max: int, device):
-        self.n_slots, self.t_max = n_slots, t_max
-        shape = (n_slots, lm.n_kv_heads, t_max, lm.head_dim)
-        self.k = [torch.empty(shape, dtype=torch.bfloat16, device=device) for _ in range(lm.n_layers)]
-        self.v = [torch.empty(shape, dtype=torch.bfloat16, device=device) for _ in range(lm.n_layers)]
+    """Two pools per layer, both [n_slots, n_kv_heads, t_max, head_dim] bf16:
+    `pre`  shared prompt prefixes (system prompt + image patches / + <unk>), token t at index t;
+    `own`  one COMPACT slot per (question, branch): token t at index t - prefix_len, so a slot only holds the
+           question's own ~25 prompt tokens + the generated ones instead of a full-length context."""
+
+    def __init__(self, lm: LMConfig, n_pre: int, t_pre: int, n_own: int, t_own: int, device):
+        self.n_pre, self.t_pre, self.n_own, self.t_own = n_pre, t_pre, n_own, t_own
+        mk = lambda n, t: [torch.empty((max(n, 1), lm.n_kv_heads, t, lm.head_dim), dtype=torch.bfloat16, device=device)
+                           for _ in range(lm.n_layers)]
+        self.kp, self.vp = mk(n_pre, t_pre), mk(n_pre, t_pre)
+        self.ko, self.vo = mk(n_own, t_own), mk(n_own, t_own)
+
+    def fits(self, n_pre, t_pre, n_own, t_own):
+        return n_pre <= self.n_pre and t_pre <= self.t_pre and n_own <= self.n_own and t_own <= self.t_own
 
     def nbytes(self):
-        return 2 * len(self.k) * self.k[0].numel() * 2
+        return sum(t.numel() * 2 for pool in (self.kp, self.vp, self.ko, self.vo) for t in pool)
 
 
 class LanguageModel:
@@ -232,10 +241,11 @@ class LanguageModel:
         raise NotImplementedError
 
     @torch.no_grad()
-    def prefill(self, x: torch.Tensor, pos: torch.Tensor, slot: torch.Tensor, seqs: torch.Tensor, n_seq: int, max_tq: int,
-                kv: KVCache) -> torch.Tensor:
-        """x [T, d] packed embeddings; pos/slot int32 [T]; seqs [n_seq, 6] (ops.flash_attention).  Writes KV, returns
-        the final hidden states [T, d] (before the last norm)."""
+    def prefill(self, x: torch.Tensor, pos: torch.Tensor, cpos: torch.Tensor, slot: torch.Tensor, seqs: torch.Tensor, n_seq: int,
+                max_tq: int, kv: KVCache, to_prefix_pool: bool) -> torch.Tensor:
+        """x [T, d] packed embeddings; pos (rotary) / cpos (index inside the slot) / slot int32 [T]; seqs [n_seq, 6]
+        (ops.flash_attention).  Writes K/V into the prefix pool (prefix pass) or the own pool (suffix pass) and returns
+        (residual, delta): the final hidden state is their sum (added inside the last norm)."""
         c, t = self.cfg, self.w.t
         H, Hkv, D = c.n_heads, c.n_kv_heads, c.head_dim
         resid, delta = x, None
@@ -245,8 +255,9 @@ class LanguageModel:
             a = ops.rmsnorm(resid, t[p + "ln1"], c.eps, delta=delta, resid_out=new_resid)
             resid = new_resid if new_resid is not None else resid
             qkv = ops.linear(a, t[p + "wqkv"])
-            q = ops.rope_kv_write(qkv, pos, slot, self.cs, kv.k[i], kv.v[i], H, Hkv, D)
-            att = ops.flash_attention(q, kv.k[i], kv.v[i], seqs, n_seq, max_tq, H, Hkv, D, causal=True)
+            kw_, vw_ = (kv.kp[i], kv.vp[i]) if to_prefix_pool else (kv.ko[i], kv.vo[i])
+            q = ops.rope_kv_write(qkv, pos, slot, self.cs, kw_, vw_, H, Hkv, D, cpos=cpos)
+            att = ops.flash_attention(q, kw_, vw_, seqs, n_seq, max_tq, H, Hkv, D, causal=True, k_prefix=kv.kp[i], v_prefix=kv.vp[i])
             o = ops.linear(att, t[p + "wo"])
             new_resid = torch.empty_like(resid)
             a = ops.rmsnorm(resid, t[p + "ln2"], c.eps, delta=o, resid_out=new_resid)
@@ -265,8 +276,8 @@ class LanguageModel:
         return ops.linear(a, t["lm_head"])
 
     @torch.no_grad()
-    def decode_step(self, tokens: torch.Tensor, pos: torch.Tensor, slot: torch.Tensor, attn_rows: torch.Tensor, kv: KVCache,
-                    bufs: Optional[dict] = None) -> torch.Tensor:
+    def decode_step(self, tokens: torch.Tensor, pos: torch.Tensor, cpos: torch.Tensor, slot: torch.Tensor, attn_rows: torch.Tensor,
+                    kv: KVCache) -> torch.Tensor:
         """One token for each of M rows: tokens int64 [M], pos/slot int32 [M], attn_rows int32 [M,4] (slot, len, pslot, plen)
         with len already counting the new token.  Returns logits [M, V]."""
         c, t = self.cfg, self.w.t
@@ -280,8 +291,9 @@ class LanguageModel:
             else:
                 a = ops.rmsnorm(resid, t[p + "ln1"], c.eps, delta=delta, resid_out=resid)
             qkv = ops.linear(a, t[p + "wqkv"])
-            q = ops.rope_kv_write(qkv, pos, slot, self.cs, kv.k[i], kv.v[i], H, Hkv, D)
-            att = ops.decode_attention(q, kv.k[i], kv.v[i], attn_rows, H, Hkv, D)
+            q = ops.rope_kv_write(qkv, pos, slot, self.cs, kv.ko[i], kv.vo[i], H, Hkv, D, cpos=cpos)
+            att = ops.decode_attention(q, kv.ko[i], kv.vo[i], attn_rows, H, Hkv, D, k_prefix=kv.kp[i], v_prefix=kv.vp[i],
+                                       max_len=kv.t_pre + kv.t_own)
             o = ops.linear(att, t[p + "wo"])
             a = ops.rmsnorm(resid, t[p + "ln2"], c.eps, delta=o, resid_out=resid)
             gu = ops.linear(a, t[p + "wgu"])
@@ -315,7 +327,7 @@ class _DecodeRunner:
         R = nb * Q
         i32 = dict(dtype=torch.int32, device=dev)
         self.tokens_rows = torch.zeros(R, dtype=torch.long, device=dev)
-        self.pos, self.slot, self.rows = torch.zeros(R, **i32), torch.zeros(R, **i32), torch.zeros(R, 4, **i32)
+        self.pos, self.cpos, self.slot, self.rows = torch.zeros(R, **i32), torch.zeros(R, **i32), torch.zeros(R, **i32), torch.zeros(R, 4, **i32)
         self.tok = torch.zeros(Q, dtype=torch.long, device=dev)
         self.unfinished = torch.ones(Q, dtype=torch.long, device=dev)
         self.gen = torch.zeros(Q, max_new + 1, dtype=torch.long, device=dev)     # +1: slack column, never returned
@@ -332,9 +344,9 @@ class _DecodeRunner:
         self.step_idx.fill_(0)
         self.ctr.fill_(ctr0)
 
-    def load(self, pos, slot, rows):
-        dev = self.eng.device
+    def load(self, pos, cpos, slot, rows):
         self.pos.copy_(torch.tensor(pos, dtype=torch.int32)); self.slot.copy_(torch.tensor(slot, dtype=torch.int32))
+        self.cpos.copy_(torch.tensor(cpos, dtype=torch.int32))
         self.rows.copy_(torch.tensor(rows, dtype=torch.int32))
         self.gen[:, 0] = self.tok
         self.step_idx.fill_(1)
@@ -343,7 +355,7 @@ class _DecodeRunner:
     def body(self, kv):
         t, Q, nb = self.tail, self.Q, self.nb
         self.tokens_rows.view(nb, Q).copy_(self.tok[None].expand(nb, Q))        # same new token for every branch of a question
-        logits = self.eng.lm.decode_step(self.tokens_rows, self.pos, self.slot, self.rows, kv)
+        logits = self.eng.lm.decode_step(self.tokens_rows, self.pos, self.cpos, self.slot, self.rows, kv)
         v, c, d = logits[:Q], None, None
         if t["contrast"]:
             if t["is_vcd"]:
@@ -358,12 +370,13 @@ class _DecodeRunner:
         self.status |= self._st
         self.gen.index_copy_(1, self.step_idx, self.tok[:, None])
         self.pos += 1
+        self.cpos += 1
         self.rows[:, 1] += 1
         self.step_idx += 1
         self.ctr += 1
 
     def _state(self):
-        return [self.tokens_rows, self.pos, self.slot, self.rows, self.tok, self.unfinished, self.gen, self.step_idx, self.ctr,
+        return [self.tokens_rows, self.pos, self.cpos, self.slot, self.rows, self.tok, self.unfinished, self.gen, self.step_idx, self.ctr,
                 self.status, self._st]
 
     def step(self, kv):
@@ -392,7 +405,7 @@ class VddLlavaEngine:
     """model.generate()-compatible surface (llava_calibrate.py:161-177) over the native kernels."""
 
     def __init__(self, cfg: LlavaConfig | str = "llava-1.5-7b", weights: Optional[LlavaWeights] = None, device="cuda:0",
-                 seed: int = 0, max_questions: int = 64, t_max: int = 768, use_graph: bool = True):
+                 seed: int = 0, max_questions: int = 64, t_max: int = 0, use_graph: bool = True):
         self.cfg = preset(cfg) if isinstance(cfg, str) else cfg
         self.device = torch.device(device)
         self.w = weights if weights is not None else LlavaWeights.random(self.cfg, self.device, seed)
@@ -404,11 +417,18 @@ class VddLlavaEngine:
         self._graphs: dict = {}
 
     # -- plumbing ---------------------------------------------------------------------------
-    def kv(self, n_slots):
-        if self._kv is None or self._kv.n_slots < n_slots:
+    def kv(self, n_pre, t_pre, n_own, t_own):
+        r64 = lambda v: (v + 63) // 64 * 64
+        t_pre, t_own = r64(max(t_pre, 64)), r64(max(t_own, 64))
+        if self._kv is None or not self._kv.fits(n_pre, t_pre, n_own, t_own):
+            old = self._kv
             self._kv = None
             self._graphs.clear()
-            self._kv = KVCache(self.cfg.lm, n_slots, self.t_max, self.device)
+            grow = lambda a, b: max(a, b)
+            if old is not None:
+                n_pre, t_pre, n_own, t_own = grow(n_pre, old.n_pre), grow(t_pre, old.t_pre), grow(n_own, old.n_own), grow(t_own, old.t_own)
+            del old
+            self._kv = KVCache(self.cfg.lm, n_pre, t_pre, n_own, t_own, self.device)
         return self._kv
 
     def image_features(self, images: Sequence[torch.Tensor], keys: Optional[Sequence[int]] = None) -> List[torch.Tensor]:
@@ -485,8 +505,9 @@ class VddLlavaEngine:
         # ---- plan prefill: split every (branch, question) sequence into shared prefix + own suffix -----
         n_img_tok = self.cfg.vision.n_patches
         plan = self._plan(branches, n_img_tok, share_prefix)
-        kv = self.kv(plan["n_slots"])
-        assert plan["max_len"] + max_new_tokens <= self.t_max, "raise t_max"
+        kv = self.kv(len(plan["prefix"]), max([s_["T"] for s_ in plan["prefix"]] + [0]), len(plan["suffix"]),
+                     max(s_["T"] for s_ in plan["suffix"]) + max_new_tokens)
+        assert plan["max_len"] + max_new_tokens <= self.cfg.lm.max_pos, "prompt + new tokens exceed the rotary table"
         stats = {"n_rows": nb * Q, "prefill_tokens": plan["prefill_tokens"], "unshared_prefill_tokens": plan["unshared_tokens"]}
 
         last_rows = None
@@ -494,8 +515,8 @@ class VddLlavaEngine:
             segs = plan[phase]
             if not segs:
                 continue
-            x, pos, slot, seqs, max_tq = self._pack(segs)
-            resid, delta = self.lm.prefill(x, pos, slot, seqs, len(segs), max_tq, kv)
+            x, pos, cpos, slot, seqs, max_tq = self._pack(segs)
+            resid, delta = self.lm.prefill(x, pos, cpos, slot, seqs, len(segs), max_tq, kv, to_prefix_pool=(phase == "prefix"))
             if phase == "suffix":
                 last = torch.tensor([s["q_row0"] + s["T"] - 1 for s in segs], device=dev)
                 logits0 = self.lm.logits(resid, delta, last)                                  # [nb*Q, V], rows ordered branch-major
@@ -526,7 +547,7 @@ class VddLlavaEngine:
         top_prob, top_tok = r0.top_prob, r0.top_tok
         # the VCD branch has no state of its own after step 0 (quirk #1): only the other branches keep decoding
         sel = [b * Q + q for b in keep for q in range(Q)]
-        run.load(pos=[seg[i]["pos0"] + seg[i]["T"] for i in sel], slot=[seg[i]["slot"] for i in sel],
+        run.load(pos=[seg[i]["pos0"] + seg[i]["T"] for i in sel], cpos=[seg[i]["T"] for i in sel], slot=[seg[i]["slot"] for i in sel],
                  rows=[[seg[i]["slot"], seg[i]["pos0"] + seg[i]["T"] + 1, seg[i]["pslot"], seg[i]["plen"]] for i in sel])
         n_new = 1
         while n_new < max_new_tokens:
@@ -601,13 +622,12 @@ class VddLlavaEngine:
                         raise ValueError("prompt must not end with the image token")
                 if share_prefix and plen > 0:
                     if key not in prefix_slots:
-                        prefix_slots[key] = dict(slot=n_slots, tokens=pre_tok, img=img, T=plen, pos0=0, pslot=0, plen=0)
+                        prefix_slots[key] = dict(slot=len(prefix), tokens=pre_tok, img=img, T=plen, pos0=0, pslot=0, plen=0)
                         prefix.append(prefix_slots[key])
-                        n_slots += 1
                     ps = prefix_slots[key]["slot"]
-                    suffix.append(dict(slot=n_slots, tokens=suf_tok, img=None, T=len(suf_tok), pos0=plen, pslot=ps, plen=plen))
+                    suffix.append(dict(slot=len(suffix), tokens=suf_tok, img=None, T=len(suf_tok), pos0=plen, pslot=ps, plen=plen))
                 else:
-                    suffix.append(dict(slot=n_slots, tokens=pre_tok + suf_tok if img is None else None, pre=pre_tok, img=img,
+                    suffix.append(dict(slot=len(suffix), tokens=pre_tok + suf_tok if img is None else None, pre=pre_tok, img=img,
                                        suf=suf_tok, T=total, pos0=0, pslot=0, plen=0))
                 n_slots += 1
         tokens = sum(s["T"] for s in prefix) + sum(s["T"] for s in suffix)
@@ -642,6 +662,7 @@ class VddLlavaEngine:
             emb = ops.embed(torch.tensor(flat_ids, dtype=torch.long, device=dev), t["embed"])
             x[torch.tensor(flat_rows, dtype=torch.long, device=dev)] = emb
         pos = torch.cat([torch.arange(s["pos0"], s["pos0"] + s["T"], dtype=torch.int32) for s in segs]).to(dev)
+        cpos = torch.cat([torch.arange(0, s["T"], dtype=torch.int32) for s in segs]).to(dev)      # index inside the slot (= pos - plen)
         slot = torch.cat([torch.full((s["T"],), s["slot"], dtype=torch.int32) for s in segs]).to(dev)
         seqs = torch.tensor([[s["q_row0"], s["T"], s["pos0"], s["slot"], s["pslot"], s["plen"]] for s in segs], dtype=torch.int32, device=dev)
-        return x, pos, slot, seqs, max(s["T"] for s in segs)
+        return x, pos, cpos, slot, seqs, max(s["T"] for s in segs)

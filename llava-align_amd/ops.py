@@ -13,12 +13,12 @@ from . import _lib
 _P, _I, _L, _F = C.c_void_p, C.c_int, C.c_int64, C.c_float
 _SIGS = {
     "vdd_rmsnorm": [_P, _P, _P, _P, _P, _I, _I, _F, _P],
-    "vdd_rope_kv_write": [_P, _P, _P, _P, _P, _P, _P, _I, _I, _I, _I, _L, _I, _P],
+    "vdd_rope_kv_write": [_P, _P, _P, _P, _P, _P, _P, _P, _I, _I, _I, _I, _L, _I, _P],
     "vdd_silu_mul": [_P, _P, _L, _I, _P],
     "vdd_embed": [_P, _P, _P, _I, _I, _P],
     "vdd_skinny_gemm": [_P, _P, _P, _P, _I, _I, _I, _L, _L, _L, _P],
-    "vdd_decode_attention": [_P, _P, _P, _P, _P, _P, _I, _I, _I, _I, _L, _I, _I, _F, _P],
-    "vdd_flash_attention": [_P, _P, _P, _P, _P, _I, _I, _I, _I, _I, _L, _I, _F, _I, _P],
+    "vdd_decode_attention": [_P, _P, _P, _P, _P, _P, _P, _P, _I, _I, _I, _I, _L, _I, _L, _I, _I, _F, _P],
+    "vdd_flash_attention": [_P, _P, _P, _P, _P, _P, _P, _I, _I, _I, _I, _I, _L, _I, _L, _I, _F, _I, _P],
     "vdd_layernorm": [_P, _P, _P, _P, _I, _I, _F, _P],
     "vdd_bias_act": [_P, _P, _P, _L, _I, _I, _P],
 }
@@ -57,12 +57,14 @@ def rmsnorm(x, w, eps, delta=None, resid_out=None, out=None):
     return out
 
 
-def rope_kv_write(qkv, pos, slot, cos_sin, k_cache, v_cache, Hq, Hkv, D, q_out=None):
-    """qkv [M, (Hq+2Hkv)*D]; pos/slot int32 [M]; caches [n_slots, Hkv, t_max, D].  Returns rotated q [M, Hq*D]."""
+def rope_kv_write(qkv, pos, slot, cos_sin, k_cache, v_cache, Hq, Hkv, D, q_out=None, cpos=None):
+    """qkv [M, (Hq+2Hkv)*D]; pos/slot int32 [M]; caches [n_slots, Hkv, t_max, D]; cpos = index inside the slot
+    (default: pos).  Returns rotated q [M, Hq*D]."""
     _bf16(qkv, k_cache, v_cache)
     M = qkv.shape[0]
     q_out = torch.empty(M, Hq * D, dtype=qkv.dtype, device=qkv.device) if q_out is None else q_out
-    _lib.check(_lib_ready().vdd_rope_kv_write(qkv.data_ptr(), pos.data_ptr(), slot.data_ptr(), cos_sin.data_ptr(), q_out.data_ptr(),
+    cpos = pos if cpos is None else cpos
+    _lib.check(_lib_ready().vdd_rope_kv_write(qkv.data_ptr(), pos.data_ptr(), cpos.data_ptr(), slot.data_ptr(), cos_sin.data_ptr(), q_out.data_ptr(),
                                               k_cache.data_ptr(), v_cache.data_ptr(), M, Hq, Hkv, D, k_cache.stride(0),
                                               k_cache.shape[2], _st(qkv)))
     return q_out
@@ -110,12 +112,15 @@ def linear(x, w, out=None):
 _attn_ws = {}
 
 
-def decode_attention(q, k_cache, v_cache, rows, H, Hkv, D, out=None, max_len=None):
-    """q [M, H*D]; rows int32 [M, 4] = (slot, len, prefix_slot, prefix_len); max_len bounds every len (default t_max)."""
+def decode_attention(q, k_cache, v_cache, rows, H, Hkv, D, out=None, max_len=None, k_prefix=None, v_prefix=None):
+    """q [M, H*D]; rows int32 [M, 4] = (slot, len, prefix_slot, prefix_len); max_len bounds every len.
+    k_prefix/v_prefix: separate pool holding the shared prefixes (default: the same buffers, index t)."""
     _bf16(q, k_cache, v_cache)
     M = q.shape[0]
     lib = _lib_ready()
-    max_len = int(max_len) if max_len is not None else k_cache.shape[2]
+    k_prefix = k_cache if k_prefix is None else k_prefix
+    v_prefix = v_cache if v_prefix is None else v_prefix
+    max_len = int(max_len) if max_len is not None else k_cache.shape[2] + k_prefix.shape[2]
     lib.vdd_decode_attention_workspace_bytes.restype = C.c_int64
     need = lib.vdd_decode_attention_workspace_bytes(M, H, D, max_len)
     key = (q.device, )
@@ -124,19 +129,23 @@ def decode_attention(q, k_cache, v_cache, rows, H, Hkv, D, out=None, max_len=Non
         ws = torch.empty((need + 3) // 4, dtype=torch.float32, device=q.device)
         _attn_ws[key] = ws
     out = torch.empty_like(q) if out is None else out
-    _lib.check(lib.vdd_decode_attention(q.data_ptr(), k_cache.data_ptr(), v_cache.data_ptr(), rows.data_ptr(), out.data_ptr(),
-                                        ws.data_ptr(), M, H, Hkv, D, k_cache.stride(0), k_cache.shape[2], max_len, D ** -0.5, _st(q)))
+    _lib.check(lib.vdd_decode_attention(q.data_ptr(), k_cache.data_ptr(), v_cache.data_ptr(), k_prefix.data_ptr(), v_prefix.data_ptr(),
+                                        rows.data_ptr(), out.data_ptr(), ws.data_ptr(), M, H, Hkv, D, k_cache.stride(0), k_cache.shape[2],
+                                        k_prefix.stride(0), k_prefix.shape[2], max_len, D ** -0.5, _st(q)))
     return out
 
 
-def flash_attention(q, k_cache, v_cache, seqs, n_seq, max_tq, H, Hkv, D, causal=True, out=None):
+def flash_attention(q, k_cache, v_cache, seqs, n_seq, max_tq, H, Hkv, D, causal=True, out=None, k_prefix=None, v_prefix=None):
     """Prefill attention.  q [Ttot, H*D] packed by sequence; seqs int32 [n_seq, 6] =
     (q_row0, Tq, pos0, slot, prefix_slot, prefix_len): query i of a sequence sits at position pos0+i and
     attends keys [0, pos0+i] (causal) or [0, pos0+Tq) (non-causal) of its slot / prefix slot."""
     _bf16(q, k_cache, v_cache)
     out = torch.empty_like(q) if out is None else out
-    _lib.check(_lib_ready().vdd_flash_attention(q.data_ptr(), k_cache.data_ptr(), v_cache.data_ptr(), seqs.data_ptr(), out.data_ptr(),
-                                                n_seq, max_tq, H, Hkv, D, k_cache.stride(0), k_cache.shape[2], D ** -0.5,
+    k_prefix = k_cache if k_prefix is None else k_prefix
+    v_prefix = v_cache if v_prefix is None else v_prefix
+    _lib.check(_lib_ready().vdd_flash_attention(q.data_ptr(), k_cache.data_ptr(), v_cache.data_ptr(), k_prefix.data_ptr(), v_prefix.data_ptr(),
+                                                seqs.data_ptr(), out.data_ptr(), n_seq, max_tq, H, Hkv, D, k_cache.stride(0),
+                                                k_cache.shape[2], k_prefix.stride(0), k_prefix.shape[2], D ** -0.5,
                                                 1 if causal else 0, _st(q)))
     return out
 

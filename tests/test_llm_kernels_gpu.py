@@ -111,8 +111,8 @@ def test_decode_attention_ragged_and_prefix_shared():
     out = O.decode_attention(q, kc, vc, rows, H, Hkv, D).view(M, H, D)
     rep = H // Hkv
     for m, (slot, ln, ps, pl) in enumerate(rows.tolist()):
-        K = torch.cat([kc[ps, :, :pl], kc[slot, :, pl:ln]], 1).float().repeat_interleave(rep, 0)
-        V = torch.cat([vc[ps, :, :pl], vc[slot, :, pl:ln]], 1).float().repeat_interleave(rep, 0)
+        K = torch.cat([kc[ps, :, :pl], kc[slot, :, :ln - pl]], 1).float().repeat_interleave(rep, 0)     # own slot is compact: token t at t - plen
+        V = torch.cat([vc[ps, :, :pl], vc[slot, :, :ln - pl]], 1).float().repeat_interleave(rep, 0)
         ref = attn_ref(q[m].view(H, D).float(), K, V)
         assert torch.allclose(out[m].float(), ref, rtol=2e-2, atol=2e-2), m
 
@@ -133,8 +133,8 @@ def test_flash_attention_prefill(D, H, Hkv, causal):
     rep = H // Hkv
     for (r0, Tq, p0, slot, ps, pl) in seqs:
         Tk = p0 + Tq
-        K = torch.cat([kc[ps, :, :pl], kc[slot, :, pl:Tk]], 1).float().repeat_interleave(rep, 0)     # [H, Tk, D]
-        V = torch.cat([vc[ps, :, :pl], vc[slot, :, pl:Tk]], 1).float().repeat_interleave(rep, 0)
+        K = torch.cat([kc[ps, :, :pl], kc[slot, :, :Tk - pl]], 1).float().repeat_interleave(rep, 0)     # [H, Tk, D]; own slot compact
+        V = torch.cat([vc[ps, :, :pl], vc[slot, :, :Tk - pl]], 1).float().repeat_interleave(rep, 0)
         Q = q[r0:r0 + Tq].view(Tq, H, D).float().transpose(0, 1)                                     # [H, Tq, D]
         s = Q @ K.transpose(1, 2) / math.sqrt(D)
         if causal:
