@@ -144,6 +144,16 @@ int vdd_decode_attention(const void* q, const void* k_cache, const void* v_cache
                          int64_t prefix_stride, int prefix_tmax, int max_len, float scale, void* hip_stream);
 int64_t vdd_decode_attention_workspace_bytes(int M, int H, int D, int max_len);
 
+/* Same result as vdd_decode_attention when every row with prefix_len > 0 is listed in exactly one group of rows
+ * sharing (prefix_slot, prefix_len): groups[g] = {row_off, n_rows, prefix_slot, prefix_len} (int32 x4) indexes
+ * group_rows[].  The shared prefix is attended ONCE per group with the group's queries as the MFMA M dimension
+ * (each prefix K/V byte fetched once per group, not once per row); own tokens go through the split-KV kernel.
+ * Workspace: vdd_decode_attention_workspace_bytes(M, H, D, round_up(max_prefix_len, 64) + round_up(max_own_len, 64)). */
+int vdd_decode_attention_grouped(const void* q, const void* k_cache, const void* v_cache, const void* k_prefix, const void* v_prefix,
+                                 const int32_t* rows, const int32_t* groups, const int32_t* group_rows, int n_groups, int max_group_rows,
+                                 void* out, void* workspace, int M, int H, int Hkv, int D, int64_t slot_stride, int t_max,
+                                 int64_t prefix_stride, int prefix_tmax, int max_prefix_len, int max_own_len, float scale, void* hip_stream);
+
 /* Prefill attention (MFMA, flash-style).  q/out [Ttot, H*D] packed by sequence; seqs[s] = {q_row0, Tq, pos0,
  * slot, prefix_slot, prefix_len} (int32 x6): query i of sequence s sits at position pos0+i and attends keys
  * [0, pos0+i] (causal) or [0, pos0+Tq) (non-causal) read from the caches (prefix pool below prefix_len, own

@@ -1,0 +1,153 @@
+"""Post-hoc calibration and POPE scoring — the consumers of the decoding path's outputs
+(SURVEY.md §8 f.1, f.4).  Host-side float64 arithmetic exactly as the reference does it; the only
+device work (softmax of the step-0 scores row and its top-k) already happened inside the fused
+sampling kernel (`top_prob`, `top_tok`).
+
+  label_dict_from_top      experiments/utils/metrics.py:102-113  calibrate_label_dict
+  get_prob_from_logits     experiments/utils/metrics.py:115-125 (and eval_pope_calibrate.py:18-29)
+  affine_calibrate         experiments/eval/eval_pope_calibrate.py:65-74,136-141 (metrics.py:8-41)
+  pope_scores              experiments/eval/eval_pope.py:27-67
+  pope_scores_calibrated   experiments/eval/eval_pope_calibrate.py:84-180 ('individual' mode)
+  AnswerWriter             experiments/eval/calibrate/llava_calibrate.py:209-219 (JSONL schema, flush per question)
+"""
+from __future__ import annotations
+
+import json
+from typing import Callable, Dict, Iterable, List, Optional, Sequence
+
+import numpy as np
+
+LABEL_DICT = {0: ["yes"], 1: ["no"]}
+LABEL_TO_INT = {"yes": 0, "no": 1}
+
+
+def label_dict_from_top(top_tok: Sequence[int], top_prob: Sequence[float], decode: Callable[[int], str]) -> Dict[str, float]:
+    """Top-k (token, prob) pairs in descending probability -> {normalised string: prob}; the FIRST (highest)
+    occurrence of a string wins, later collisions are dropped, not summed."""
+    out: Dict[str, float] = {}
+    for tok, p in zip(top_tok, top_prob):
+        if int(tok) < 0:
+            continue
+        s = decode(int(tok)).lower().strip()
+        if s not in out:
+            out[s] = float(p)
+    return out
+
+
+def get_prob_from_logits(top_token_probs: Dict[str, float], label_dict=LABEL_DICT) -> List[float]:
+    probs = {k.lower().strip(): v for k, v in top_token_probs.items()}
+    return [sum(probs.get(a.lower(), 0) for a in answers) for _, answers in label_dict.items()]
+
+
+def calibrate_weight(p_cf, mode: str = "diagonal_W"):
+    n = len(p_cf)
+    if mode == "diagonal_W":
+        return np.linalg.inv(np.identity(n) * p_cf), np.zeros([n, 1])
+    if mode == "identity_W":
+        return np.identity(n), -1 * np.expand_dims(p_cf, axis=-1)
+    raise AssertionError(mode)
+
+
+def affine_calibrate(p, p_cf=None, mode: str = "diagonal_W", eps: float = 1e-4):
+    """q = W p + b renormalised; p_cf (content-free prior) is normalised and offset by eps as the POPE scorer does."""
+    p = np.asarray(p, dtype=np.float64)
+    p = p / np.sum(p)
+    n = p.shape[0]
+    if p_cf is None:
+        W, b = np.identity(n), np.zeros([n, 1])
+    else:
+        p_cf = np.asarray(p_cf, dtype=np.float64)
+        p_cf = p_cf / np.sum(p_cf)
+        W, b = calibrate_weight([x + eps for x in p_cf], mode)
+    q = np.matmul(W, np.expand_dims(p, axis=-1)) + b
+    q /= np.sum(q)
+    return q.reshape(-1), int(np.argmax(q))
+
+
+def _prf(tp, tn, fp, fn, yes, unknown, total):
+    precision = tp / (tp + fp)
+    recall = tp / (tp + fn)
+    return {"precision": precision, "recall": recall, "f1": 2 * precision * recall / (precision + recall),
+            "accuracy": (tp + tn) / total, "yes": yes / total, "unknown": unknown / total, "n": total}
+
+
+def pope_scores(gt: Sequence[dict], gen: Sequence[dict]) -> dict:
+    """String-match scoring of generated answers: 'yes' / 'no' substring tests, exactly eval_pope.py."""
+    tp = tn = fp = fn = unknown = yes = 0
+    for g, a in zip(gt, gen):
+        assert g["question_id"] == a["question_id"]
+        label, text = g["label"].lower().strip(), a["text"].lower().strip()
+        if label == "yes":
+            if "yes" in text:
+                tp += 1; yes += 1
+            else:
+                fn += 1
+        elif label == "no":
+            if "no" in text:
+                tn += 1
+            else:
+                yes += 1; fp += 1
+        else:
+            unknown += 1
+    return _prf(tp, tn, fp, fn, yes, unknown, len(gt))
+
+
+def pope_scores_calibrated(gt: Sequence[dict], gen: Sequence[dict], name: str = "naive", mode: str = "diagonal_W") -> dict:
+    """'individual' calibration per question: p from gen['naive'], prior from gen[name] ('none', 'unk', or
+    'none_unk' = their sum); arg-max of the calibrated 2-vector is the answer (0 = yes)."""
+    tp = tn = fp = fn = unknown = yes = total = 0
+    confidence = 0.0
+    for g, a in zip(gt, gen):
+        assert g["question_id"] == a["question_id"]
+        label = LABEL_TO_INT[g["label"]]
+        p = np.array(get_prob_from_logits(a["naive"]), dtype=np.float64)
+        p = p / np.sum(p)
+        W, b = np.identity(2), np.zeros([2, 1])
+        if name != "naive":
+            if name == "none_unk":
+                cf = np.array(get_prob_from_logits(a["unk"])) + np.array(get_prob_from_logits(a["none"]))
+            else:
+                cf = np.array(get_prob_from_logits(a[name]), dtype=np.float64)
+            cf = cf / np.sum(cf)
+            W, b = calibrate_weight([x + 1e-4 for x in cf], mode)
+        q = np.matmul(W, np.expand_dims(p, axis=-1)) + b
+        q /= np.sum(q)
+        ans = int(np.argmax(q))
+        confidence += float(np.max(q))
+        if label == 0:
+            if ans == 0:
+                tp += 1; yes += 1
+            else:
+                fn += 1
+        else:
+            if ans == 1:
+                tn += 1
+            else:
+                yes += 1; fp += 1
+        total += 1
+    out = _prf(tp, tn, fp, fn, yes, unknown, total)
+    out["confidence"] = confidence / total
+    return out
+
+
+class AnswerWriter:
+    """One JSON line per question, flushed immediately (the reference's only crash tolerance)."""
+    FIELDS = ("question_id", "prompt", "text", "model_id", "image", "logits_score", "naive", "unk", "none", "metadata")
+
+    def __init__(self, path: str):
+        self.f = open(path, "w")
+
+    def write(self, question_id, prompt, text, model_id, image, logits_score, naive, unk=None, none=None, metadata=None):
+        rec = {"question_id": question_id, "prompt": prompt, "text": text, "model_id": model_id, "image": image,
+               "logits_score": logits_score, "naive": naive, "unk": unk, "none": none, "metadata": metadata or {}}
+        self.f.write(json.dumps(rec) + "\n")
+        self.f.flush()
+
+    def close(self):
+        self.f.close()
+
+    def __enter__(self):
+        return self
+
+    def __exit__(self, *a):
+        self.close()

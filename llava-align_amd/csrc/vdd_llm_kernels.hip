@@ -237,15 +237,17 @@ __global__ void __launch_bounds__(256) decode_attn_kernel(const uint16_t* __rest
                                                           const uint16_t* __restrict__ vc, const uint16_t* __restrict__ kpre,
                                                           const uint16_t* __restrict__ vpre, const AttnRow* __restrict__ rows,
                                                           float* __restrict__ ws, int H, int Hkv, long long slot_stride,
-                                                          int t_max, long long pre_stride, int pre_tmax, float scale, int nchunk) {
+                                                          int t_max, long long pre_stride, int pre_tmax, float scale, int nchunk,
+                                                          int own_only, int chunk_base) {
     static_assert(D == 128, "lane map assumes 16 lanes x 8 dims");
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     const int head = blockIdx.x * 4 + wave, row = blockIdx.y, chunk = blockIdx.z;
     if (head >= H) return;
     const int g = lane >> 4, j = lane & 15;
     const AttnRow ar = rows[row];
-    float* wsp = ws + (((size_t)row * H + head) * nchunk + chunk) * (D + 2);
-    const int k0 = chunk * ATT_CH, k1 = min(ar.len, k0 + ATT_CH);
+    float* wsp = ws + (((size_t)row * H + head) * nchunk + chunk_base + chunk) * (D + 2);
+    // own_only: the shared prefix [0, plen) is handled by the grouped MFMA kernel; this one starts at plen
+    const int k0 = (own_only ? ar.plen : 0) + chunk * ATT_CH, k1 = min(ar.len, k0 + ATT_CH);
     if (k0 >= ar.len) {                                   // empty chunk: neutral partial
         if (lane == 0) { wsp[D] = -INFINITY; wsp[D + 1] = 0.f; }
         return;
@@ -307,27 +309,144 @@ __global__ void __launch_bounds__(256) decode_attn_kernel(const uint16_t* __rest
     }
 }
 
-// one wave per (row, head): lane owns dims 2*lane, 2*lane+1
+// one wave per (row, head): lane owns dims 2*lane, 2*lane+1.  Chunk space: [0, npre) prefix chunks (grouped
+// kernel; only when grouped), then own/whole-context chunks.
 template <int D>
 __global__ void __launch_bounds__(256) decode_attn_combine_kernel(const float* __restrict__ ws, const AttnRow* __restrict__ rows,
-                                                                  uint16_t* __restrict__ out, int H, int nchunk) {
+                                                                  uint16_t* __restrict__ out, int H, int nchunk, int npre) {
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     const int head = blockIdx.x * 4 + wave, row = blockIdx.y;
     if (head >= H) return;
-    const int used = min(nchunk, (rows[row].len + ATT_CH - 1) / ATT_CH);
+    const AttnRow ar = rows[row];
+    const int used_pre = npre > 0 ? (ar.plen + ATT_CH - 1) / ATT_CH : 0;
+    const int own_len = npre > 0 ? ar.len - ar.plen : ar.len;
+    const int used_own = min(nchunk - npre, (own_len + ATT_CH - 1) / ATT_CH);
     const float* base = ws + ((size_t)row * H + head) * nchunk * (D + 2);
     float M = -INFINITY;
-    for (int c = 0; c < used; ++c) M = fmaxf(M, base[c * (D + 2) + D]);
+    for (int c = 0; c < used_pre; ++c) M = fmaxf(M, base[c * (D + 2) + D]);
+    for (int c = 0; c < used_own; ++c) M = fmaxf(M, base[(npre + c) * (D + 2) + D]);
     float L = 0.f, a0 = 0.f, a1 = 0.f;
-    for (int c = 0; c < used; ++c) {
+    auto add = [&](int c) {
         const float* p = base + c * (D + 2);
         const float w = __expf(p[D] - M);
         L += w * p[D + 1];
         const float2 v = *reinterpret_cast<const float2*>(p + 2 * lane);
         a0 += w * v.x; a1 += w * v.y;
-    }
+    };
+    for (int c = 0; c < used_pre; ++c) add(c);
+    for (int c = 0; c < used_own; ++c) add(npre + c);
     const float inv = 1.f / L;
     reinterpret_cast<uint32_t*>(out + ((size_t)row * H + head) * D)[lane] = pack(a0 * inv, a1 * inv);
+}
+
+// ------------------------------------------------------------------ prefix-grouped decode attention (MFMA)
+// Rows that share a prompt prefix (the 6 POPE questions of one image; ALL image-free branch rows) are one
+// group: their queries form the M dimension of 16x16x32 MFMAs, so every prefix K/V byte is fetched ONCE per
+// group instead of once per row.  Block = (16-row query tile, head, 4 consecutive 64-key chunks): wave w owns
+// chunk 4*quad + w; S = Q K^T with K fragments straight from the prefix pool, one-shot softmax over the 64
+// keys (no online rescale inside a chunk), P re-laid out through LDS, V staged per wave in LDS, O = P V.
+// Output: un-normalised partials (acc[128], m, l) per (row, head, chunk) in the same workspace the split
+// kernel uses, merged by decode_attn_combine_kernel.
+struct GroupDesc { int row_off, n_rows, pslot, plen; };
+
+template <int D>
+__global__ void __launch_bounds__(256) decode_attn_prefix_kernel(const uint16_t* __restrict__ q, const uint16_t* __restrict__ kpre,
+                                                                 const uint16_t* __restrict__ vpre, const GroupDesc* __restrict__ groups,
+                                                                 const int* __restrict__ group_rows, float* __restrict__ ws, int H, int Hkv,
+                                                                 long long pre_stride, int pre_tmax, float scale, int nchunk, int nquad) {
+    static_assert(D == 128, "");
+    constexpr int KS = D / 32, NT = D / 16, VLD = D + 8, PLD = ATT_CH + 8;
+    extern __shared__ __attribute__((aligned(16))) uint16_t lds[];
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, ln = lane & 15, g = lane >> 4;
+    uint16_t* v_lds = lds + (size_t)wave * (ATT_CH * VLD + 16 * PLD);
+    uint16_t* p_lds = v_lds + ATT_CH * VLD;
+    const GroupDesc gd = groups[blockIdx.z / nquad];
+    const int chunk = (blockIdx.z % nquad) * 4 + wave;
+    const int head = blockIdx.y, kvh = head / (H / Hkv);
+    const int r0 = blockIdx.x * 16;
+    const int k0 = chunk * ATT_CH;
+    const bool active = (r0 < gd.n_rows) && (k0 < gd.plen);
+    const int k1 = min(gd.plen, k0 + ATT_CH);
+    f32x4_t o[NT];
+    float mrow[4], lrow[4];
+    int rid = 0;
+    if (active) {
+        int rr = r0 + ln; if (rr >= gd.n_rows) rr = gd.n_rows - 1;
+        rid = group_rows[gd.row_off + rr];
+        bf16x8_t qf[KS];
+        const uint16_t* qp = q + ((size_t)rid * H + head) * D + g * 8;
+#pragma unroll
+        for (int ks = 0; ks < KS; ++ks) qf[ks] = *reinterpret_cast<const bf16x8_t*>(qp + ks * 32);
+        const uint16_t* kb = kpre + (size_t)gd.pslot * pre_stride + (size_t)kvh * pre_tmax * D;
+        const uint16_t* vb = vpre + (size_t)gd.pslot * pre_stride + (size_t)kvh * pre_tmax * D;
+        // stage this wave's V tile: 64 keys x 128 dims, 16 B per lane, 1 KiB contiguous per instruction
+#pragma unroll
+        for (int i = 0; i < ATT_CH * (D / 8) / 64; ++i) {
+            const int e = i * 64 + lane, key = e / (D / 8), dd = (e % (D / 8)) * 8;
+            int t = k0 + key; if (t >= k1) t = k1 - 1;
+            *reinterpret_cast<uint4*>(&v_lds[key * VLD + dd]) = *reinterpret_cast<const uint4*>(vb + (size_t)t * D + dd);
+        }
+        f32x4_t s[4];
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            s[j] = f32x4_t{0.f, 0.f, 0.f, 0.f};
+            int t = k0 + 16 * j + ln; if (t >= k1) t = k1 - 1;
+            const uint16_t* kp = kb + (size_t)t * D + g * 8;
+#pragma unroll
+            for (int ks = 0; ks < KS; ++ks) {
+                bf16x8_t kf = *reinterpret_cast<const bf16x8_t*>(kp + ks * 32);
+                s[j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(qf[ks], kf, s[j], 0, 0, 0);
+            }
+        }
+        // C layout: row = 4 g + r, col = key 16 j + ln
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+            float mx = -INFINITY;
+#pragma unroll
+            for (int j = 0; j < 4; ++j) {
+                float v = (k0 + 16 * j + ln < k1) ? s[j][r] * scale : -INFINITY;
+                s[j][r] = v; mx = fmaxf(mx, v);
+            }
+            mx = fmaxf(mx, __shfl_xor(mx, 1)); mx = fmaxf(mx, __shfl_xor(mx, 2));
+            mx = fmaxf(mx, __shfl_xor(mx, 4)); mx = fmaxf(mx, __shfl_xor(mx, 8));
+            float ps = 0.f;
+#pragma unroll
+            for (int j = 0; j < 4; ++j) {
+                const float pv = __expf(s[j][r] - mx);          // exp(-inf) = 0 for masked keys; key k0 is always valid
+                ps += pv;
+                p_lds[(g * 4 + r) * PLD + 16 * j + ln] = (uint16_t)f2bf(pv);
+            }
+            ps += __shfl_xor(ps, 1); ps += __shfl_xor(ps, 2); ps += __shfl_xor(ps, 4); ps += __shfl_xor(ps, 8);
+            mrow[r] = mx; lrow[r] = ps;
+        }
+    }
+    __syncthreads();                                             // V tile + P patch of every wave visible
+    if (active) {
+#pragma unroll
+        for (int nt = 0; nt < NT; ++nt) o[nt] = f32x4_t{0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+        for (int kk = 0; kk < ATT_CH / 32; ++kk) {
+            const bf16x8_t pf = *reinterpret_cast<const bf16x8_t*>(&p_lds[ln * PLD + kk * 32 + g * 8]);
+#pragma unroll
+            for (int nt = 0; nt < NT; ++nt) {
+                bf16x8_t vf;
+#pragma unroll
+                for (int i = 0; i < 8; ++i) vf[i] = (short)v_lds[(kk * 32 + g * 8 + i) * VLD + nt * 16 + ln];
+                o[nt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(pf, vf, o[nt], 0, 0, 0);
+            }
+        }
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+            const int rr = r0 + g * 4 + r;
+            if (rr < gd.n_rows) {
+                const int orow = group_rows[gd.row_off + rr];
+                float* wsp = ws + (((size_t)orow * H + head) * nchunk + chunk) * (D + 2);
+#pragma unroll
+                for (int nt = 0; nt < NT; ++nt) wsp[nt * 16 + ln] = o[nt][r];
+                if (ln == 0) { wsp[D] = mrow[r]; wsp[D + 1] = lrow[r]; }
+            }
+        }
+    }
 }
 
 inline int ok(hipError_t) { return hipGetLastError() == hipSuccess ? VDD_OK : VDD_ERR_LAUNCH; }
@@ -396,9 +515,38 @@ int vdd_decode_attention(const void* q, const void* k_cache, const void* v_cache
     hipLaunchKernelGGL(decode_attn_kernel<128>, dim3((H + 3) / 4, M, nchunk), dim3(256), 0, st, (const uint16_t*)q,
                        (const uint16_t*)k_cache, (const uint16_t*)v_cache, (const uint16_t*)k_prefix, (const uint16_t*)v_prefix,
                        (const AttnRow*)rows, (float*)workspace, H, Hkv, (long long)slot_stride, t_max, (long long)prefix_stride,
-                       prefix_tmax, scale, nchunk);
+                       prefix_tmax, scale, nchunk, 0, 0);
     hipLaunchKernelGGL(decode_attn_combine_kernel<128>, dim3((H + 3) / 4, M), dim3(256), 0, st, (const float*)workspace,
-                       (const AttnRow*)rows, (uint16_t*)out, H, nchunk);
+                       (const AttnRow*)rows, (uint16_t*)out, H, nchunk, 0);
+    return ok(hipSuccess);
+}
+
+int vdd_decode_attention_grouped(const void* q, const void* k_cache, const void* v_cache, const void* k_prefix, const void* v_prefix,
+                                 const int32_t* rows, const int32_t* groups, const int32_t* group_rows, int n_groups, int max_group_rows,
+                                 void* out, void* workspace, int M, int H, int Hkv, int D, int64_t slot_stride, int t_max,
+                                 int64_t prefix_stride, int prefix_tmax, int max_prefix_len, int max_own_len, float scale, void* stream) {
+    if (M <= 0) return VDD_OK;
+    if (!q || !k_cache || !v_cache || !k_prefix || !v_prefix || !rows || !groups || !group_rows || !out || !workspace || D != 128 ||
+        H % Hkv != 0 || max_own_len <= 0 || max_prefix_len < 0 || n_groups < 0) return VDD_ERR_INVALID_ARG;
+    const int npre = (max_prefix_len + ATT_CH - 1) / ATT_CH, nown = (max_own_len + ATT_CH - 1) / ATT_CH;
+    const int nchunk = npre + nown;
+    hipStream_t st = (hipStream_t)stream;
+    if (n_groups > 0 && npre > 0) {
+        const int nquad = (npre + 3) / 4;
+        const size_t lds = 4 * (size_t)(ATT_CH * (128 + 8) + 16 * (ATT_CH + 8)) * 2;
+        static int attr = (int)hipFuncSetAttribute(reinterpret_cast<const void*>(&decode_attn_prefix_kernel<128>),
+                                                   hipFuncAttributeMaxDynamicSharedMemorySize, 96 * 1024);
+        (void)attr;
+        hipLaunchKernelGGL(decode_attn_prefix_kernel<128>, dim3((max_group_rows + 15) / 16, H, n_groups * nquad), dim3(256), lds, st,
+                           (const uint16_t*)q, (const uint16_t*)k_prefix, (const uint16_t*)v_prefix, (const GroupDesc*)groups, group_rows,
+                           (float*)workspace, H, Hkv, (long long)prefix_stride, prefix_tmax, scale, nchunk, nquad);
+    }
+    hipLaunchKernelGGL(decode_attn_kernel<128>, dim3((H + 3) / 4, M, nown), dim3(256), 0, st, (const uint16_t*)q,
+                       (const uint16_t*)k_cache, (const uint16_t*)v_cache, (const uint16_t*)k_prefix, (const uint16_t*)v_prefix,
+                       (const AttnRow*)rows, (float*)workspace, H, Hkv, (long long)slot_stride, t_max, (long long)prefix_stride,
+                       prefix_tmax, scale, nchunk, 1, npre);
+    hipLaunchKernelGGL(decode_attn_combine_kernel<128>, dim3((H + 3) / 4, M), dim3(256), 0, st, (const float*)workspace,
+                       (const AttnRow*)rows, (uint16_t*)out, H, nchunk, npre);
     return ok(hipSuccess);
 }
 

@@ -277,7 +277,7 @@ class LanguageModel:
 
     @torch.no_grad()
     def decode_step(self, tokens: torch.Tensor, pos: torch.Tensor, cpos: torch.Tensor, slot: torch.Tensor, attn_rows: torch.Tensor,
-                    kv: KVCache) -> torch.Tensor:
+                    kv: KVCache, grouping: Optional[dict] = None) -> torch.Tensor:
         """One token for each of M rows: tokens int64 [M], pos/slot int32 [M], attn_rows int32 [M,4] (slot, len, pslot, plen)
         with len already counting the new token.  Returns logits [M, V]."""
         c, t = self.cfg, self.w.t
@@ -292,8 +292,13 @@ class LanguageModel:
                 a = ops.rmsnorm(resid, t[p + "ln1"], c.eps, delta=delta, resid_out=resid)
             qkv = ops.linear(a, t[p + "wqkv"])
             q = ops.rope_kv_write(qkv, pos, slot, self.cs, kv.ko[i], kv.vo[i], H, Hkv, D, cpos=cpos)
-            att = ops.decode_attention(q, kv.ko[i], kv.vo[i], attn_rows, H, Hkv, D, k_prefix=kv.kp[i], v_prefix=kv.vp[i],
-                                       max_len=kv.t_pre + kv.t_own)
+            if grouping is not None:      # rows sharing a prompt prefix attend it once per group (MFMA), own tokens per row
+                att = ops.decode_attention_grouped(q, kv.ko[i], kv.vo[i], kv.kp[i], kv.vp[i], attn_rows, grouping["groups"],
+                                                   grouping["group_rows"], grouping["n_groups"], grouping["max_rows"], H, Hkv, D,
+                                                   kv.t_pre, kv.t_own, workspace=grouping["workspace"])
+            else:
+                att = ops.decode_attention(q, kv.ko[i], kv.vo[i], attn_rows, H, Hkv, D, k_prefix=kv.kp[i], v_prefix=kv.vp[i],
+                                           max_len=kv.t_pre + kv.t_own)
             o = ops.linear(att, t[p + "wo"])
             a = ops.rmsnorm(resid, t[p + "ln2"], c.eps, delta=o, resid_out=resid)
             gu = ops.linear(a, t[p + "wgu"])
@@ -314,6 +319,20 @@ class GenerateOutput:
 
     def __getitem__(self, k):
         return getattr(self, k)
+
+
+def group_rows_by_prefix(rows):
+    """rows: [[slot, len, pslot, plen], ...] -> (groups [[row_off, n_rows, pslot, plen]], flat member row ids);
+    rows without a prefix belong to no group."""
+    by = {}
+    for i, (_, _, ps, pl) in enumerate(rows):
+        if pl > 0:
+            by.setdefault((ps, pl), []).append(i)
+    groups, members = [], []
+    for (ps, pl), idx in by.items():
+        groups.append([len(members), len(idx), ps, pl])
+        members += idx
+    return groups, members
 
 
 class _DecodeRunner:
@@ -337,6 +356,12 @@ class _DecodeRunner:
         self.scores_buf = torch.empty(Q, eng.cfg.lm.vocab, dtype=torch.bfloat16, device=dev) if tail["output_scores"] else None
         self.graph = None
         self._tried = False
+        self.grouping = None
+        if tail.get("n_groups", 0) > 0:
+            lm = eng.cfg.lm
+            self.grouping = dict(groups=torch.zeros(max(1, tail["n_groups"]), 4, **i32), group_rows=torch.zeros(R, **i32),
+                                 n_groups=tail["n_groups"], max_rows=tail["max_group_rows"],
+                                 workspace=ops.attention_workspace(R, lm.n_heads, lm.head_dim, eng._kv.t_pre + eng._kv.t_own, dev))
 
     def reset(self, ctr0):
         self.unfinished.fill_(1)
@@ -347,6 +372,11 @@ class _DecodeRunner:
     def load(self, pos, cpos, slot, rows):
         self.pos.copy_(torch.tensor(pos, dtype=torch.int32)); self.slot.copy_(torch.tensor(slot, dtype=torch.int32))
         self.cpos.copy_(torch.tensor(cpos, dtype=torch.int32))
+        if self.grouping is not None:
+            groups, members = group_rows_by_prefix(rows)
+            assert len(groups) == self.grouping["n_groups"] and max(g[1] for g in groups) <= self.grouping["max_rows"]
+            self.grouping["groups"].copy_(torch.tensor(groups, dtype=torch.int32))
+            self.grouping["group_rows"][: len(members)].copy_(torch.tensor(members, dtype=torch.int32))
         self.rows.copy_(torch.tensor(rows, dtype=torch.int32))
         self.gen[:, 0] = self.tok
         self.step_idx.fill_(1)
@@ -355,7 +385,7 @@ class _DecodeRunner:
     def body(self, kv):
         t, Q, nb = self.tail, self.Q, self.nb
         self.tokens_rows.view(nb, Q).copy_(self.tok[None].expand(nb, Q))        # same new token for every branch of a question
-        logits = self.eng.lm.decode_step(self.tokens_rows, self.pos, self.cpos, self.slot, self.rows, kv)
+        logits = self.eng.lm.decode_step(self.tokens_rows, self.pos, self.cpos, self.slot, self.rows, kv, self.grouping)
         v, c, d = logits[:Q], None, None
         if t["contrast"]:
             if t["is_vcd"]:
@@ -412,6 +442,9 @@ class VddLlavaEngine:
         self.vit = VisionTower(self.w)
         self.lm = LanguageModel(self.w)
         self.max_q, self.t_max, self.use_graph = max_questions, t_max, use_graph
+        # attend shared prompt prefixes once per group of rows with MFMA (decode).  Correct (tests) but measured no faster
+        # than the split-KV kernel on MI355X yet (L2/Infinity Cache already de-duplicate the prefix reads): off by default
+        self.group_attention = False
         self._kv: Optional[KVCache] = None
         self._feat_cache: Dict[int, torch.Tensor] = {}
         self._graphs: dict = {}
@@ -531,9 +564,14 @@ class VddLlavaEngine:
         cfgkey = (Q, nb, max_new_tokens, alpha, beta, warp.t, warp.k, warp.p, use_cd, use_dd, use_dd_unk, cd_greedy,
                   tuple(eos_token_id) if eos_token_id is not None else None, pad_token_id, output_scores)
         keep = [i for i, (name, _, _) in enumerate(branches) if not (use_cd and name == "cd")]
+        sel = [b * Q + q for b in keep for q in range(Q)]
+        dec_rows = [[seg[i]["slot"], seg[i]["pos0"] + seg[i]["T"] + 1, seg[i]["pslot"], seg[i]["plen"]] for i in sel]
+        grp, _members = group_rows_by_prefix(dec_rows) if self.group_attention else ([], [])
+        n_groups, max_group_rows = len(grp), max([g_[1] for g_ in grp] + [0])
+        cfgkey = cfgkey + (n_groups, max_group_rows)
         run = self._runner(cfgkey, Q, len(keep), max_new_tokens, dict(alpha=alpha, beta=beta, warp=warp, contrast=contrast,
                            is_vcd=use_cd, both=(use_dd and use_dd_unk), greedy=cd_greedy, eos_t=eos_t, pad=pad_token_id,
-                           output_scores=output_scores))
+                           output_scores=output_scores, n_groups=n_groups, max_group_rows=max_group_rows))
         run.reset(ctr0)
         scores = [] if output_scores else None
         v0 = logits0[:Q]
@@ -546,9 +584,8 @@ class VddLlavaEngine:
             scores.append(r0.scores)
         top_prob, top_tok = r0.top_prob, r0.top_tok
         # the VCD branch has no state of its own after step 0 (quirk #1): only the other branches keep decoding
-        sel = [b * Q + q for b in keep for q in range(Q)]
         run.load(pos=[seg[i]["pos0"] + seg[i]["T"] for i in sel], cpos=[seg[i]["T"] for i in sel], slot=[seg[i]["slot"] for i in sel],
-                 rows=[[seg[i]["slot"], seg[i]["pos0"] + seg[i]["T"] + 1, seg[i]["pslot"], seg[i]["plen"]] for i in sel])
+                 rows=dec_rows)
         n_new = 1
         while n_new < max_new_tokens:
             run.step(kv)

@@ -18,6 +18,7 @@ _SIGS = {
     "vdd_embed": [_P, _P, _P, _I, _I, _P],
     "vdd_skinny_gemm": [_P, _P, _P, _P, _I, _I, _I, _L, _L, _L, _P],
     "vdd_decode_attention": [_P, _P, _P, _P, _P, _P, _P, _P, _I, _I, _I, _I, _L, _I, _L, _I, _I, _F, _P],
+    "vdd_decode_attention_grouped": [_P, _P, _P, _P, _P, _P, _P, _P, _I, _I, _P, _P, _I, _I, _I, _I, _L, _I, _L, _I, _I, _I, _F, _P],
     "vdd_flash_attention": [_P, _P, _P, _P, _P, _P, _P, _I, _I, _I, _I, _I, _L, _I, _L, _I, _F, _I, _P],
     "vdd_layernorm": [_P, _P, _P, _P, _I, _I, _F, _P],
     "vdd_bias_act": [_P, _P, _P, _L, _I, _I, _P],
@@ -132,6 +133,36 @@ def decode_attention(q, k_cache, v_cache, rows, H, Hkv, D, out=None, max_len=Non
     _lib.check(lib.vdd_decode_attention(q.data_ptr(), k_cache.data_ptr(), v_cache.data_ptr(), k_prefix.data_ptr(), v_prefix.data_ptr(),
                                         rows.data_ptr(), out.data_ptr(), ws.data_ptr(), M, H, Hkv, D, k_cache.stride(0), k_cache.shape[2],
                                         k_prefix.stride(0), k_prefix.shape[2], max_len, D ** -0.5, _st(q)))
+    return out
+
+
+def attention_workspace(M, H, D, max_len, device):
+    lib = _lib_ready()
+    lib.vdd_decode_attention_workspace_bytes.restype = C.c_int64
+    return torch.empty((lib.vdd_decode_attention_workspace_bytes(M, H, D, int(max_len)) + 3) // 4, dtype=torch.float32, device=device)
+
+
+def decode_attention_grouped(q, k_cache, v_cache, k_prefix, v_prefix, rows, groups, group_rows, n_groups, max_group_rows,
+                             H, Hkv, D, max_prefix_len, max_own_len, out=None, workspace=None):
+    """decode_attention with the shared prefixes attended once per group of rows (MFMA over the group's queries)."""
+    _bf16(q, k_cache, v_cache, k_prefix, v_prefix)
+    M = q.shape[0]
+    lib = _lib_ready()
+    r64 = lambda v: (int(v) + 63) // 64 * 64
+    lib.vdd_decode_attention_workspace_bytes.restype = C.c_int64
+    need = lib.vdd_decode_attention_workspace_bytes(M, H, D, r64(max_prefix_len) + r64(max_own_len))
+    ws = workspace if workspace is not None else _attn_ws.get((q.device,))
+    if ws is None or ws.numel() * 4 < need:
+        if workspace is not None:
+            raise ValueError("attention workspace too small")
+        ws = torch.empty((need + 3) // 4, dtype=torch.float32, device=q.device)
+        _attn_ws[(q.device,)] = ws
+    out = torch.empty_like(q) if out is None else out
+    _lib.check(lib.vdd_decode_attention_grouped(q.data_ptr(), k_cache.data_ptr(), v_cache.data_ptr(), k_prefix.data_ptr(), v_prefix.data_ptr(),
+                                                rows.data_ptr(), groups.data_ptr(), group_rows.data_ptr(), n_groups, max_group_rows,
+                                                out.data_ptr(), ws.data_ptr(), M, H, Hkv, D, k_cache.stride(0), k_cache.shape[2],
+                                                k_prefix.stride(0), k_prefix.shape[2], int(max_prefix_len), int(max_own_len),
+                                                D ** -0.5, _st(q)))
     return out
 
 

@@ -243,6 +243,50 @@ def gen_calibration():
     print("calibration: ok")
 
 
+def gen_scorers():
+    """Drive the reference's POPE scorer SCRIPTS (eval_pope.py, eval_pope_calibrate.py) on synthetic answer files and
+    record what they print.  The calibrate script hard-codes relative paths, so it runs in a scratch cwd."""
+    import re
+    import subprocess
+    import tempfile
+    from ref_shim import REF_ROOT
+    rng = np.random.default_rng(11)
+    n = 60
+    words = ["Yes", "No", "yes, it is", "no.", "Maybe", "The answer is no", "YES"]
+    gt, gen = [], []
+    for i in range(n):
+        lab = "yes" if rng.random() < 0.5 else "no"
+        def td():
+            py = float(rng.random()); pn = float(rng.random())
+            d = {"Yes" if rng.random() < 0.5 else "yes": py, "no": pn, "maybe": 0.01}
+            if rng.random() < 0.2:
+                d.pop("no")
+            return d
+        gt.append({"question_id": i, "label": lab, "text": "q", "image": "x.jpg"})
+        gen.append({"question_id": i, "text": words[int(rng.integers(len(words)))], "naive": td(), "unk": td(), "none": td()})
+    out = {"gt": gt, "gen": gen}
+    with tempfile.TemporaryDirectory() as d:
+        gtp, gp = os.path.join(d, "gt.json"), os.path.join(d, "gen.jsonl")
+        open(gtp, "w").write("\n".join(json.dumps(x) for x in gt))
+        open(gp, "w").write("\n".join(json.dumps(x) for x in gen))
+        r = subprocess.run([sys.executable, os.path.join(REF_ROOT, "experiments/eval/eval_pope.py"), "--gt_files", gtp, "--gen_files", gp],
+                           capture_output=True, text=True, check=True)
+        out["eval_pope"] = {k.lower(): float(v) for k, v in re.findall(r"^(Precision|Recall|F1|Accuracy|yes|unknow): ([0-9.eE+-]+)", r.stdout, flags=re.M)}
+        for split in ("random", "popular", "adversarial"):
+            os.makedirs(os.path.join(d, "experiments/data/POPE/gqa"), exist_ok=True)
+            os.makedirs(os.path.join(d, "experiments/output/llava-13B"), exist_ok=True)
+            open(os.path.join(d, f"experiments/data/POPE/gqa/gqa_pope_{split}.json"), "w").write("\n".join(json.dumps(x) for x in gt))
+            open(os.path.join(d, f"experiments/output/llava-13B/llava_gqa_pope_{split}_seed55_both.jsonl"), "w").write("\n".join(json.dumps(x) for x in gen))
+        r = subprocess.run([sys.executable, os.path.join(REF_ROOT, "experiments/eval/eval_pope_calibrate.py")], cwd=d,
+                           capture_output=True, text=True, check=True, env={**os.environ, "PYTHONDONTWRITEBYTECODE": "1"})
+        blocks = re.findall(r"Evaluate the performance in (\w+) setting\nF1: ([0-9.]+) Accuracy: ([0-9.]+) Precision: ([0-9.]+) \t Recall: ([0-9.]+) \t yes: ([0-9.]+) unknow: ([0-9.]+) number questions (\d+) confidence ([0-9.eE+-]+)", r.stdout)
+        out["eval_pope_calibrate"] = {b[0]: {"f1": float(b[1]), "accuracy": float(b[2]), "precision": float(b[3]), "recall": float(b[4]),
+                                             "yes": float(b[5]), "n": int(b[7]), "confidence": float(b[8])} for b in blocks[:4]}
+    with open(os.path.join(HERE, "scorers.json"), "w") as f:
+        json.dump(out, f)
+    print("scorers:", out["eval_pope"], list(out["eval_pope_calibrate"]))
+
+
 if __name__ == "__main__":
     torch.set_num_threads(8)
     gen_kernel_vectors()
@@ -250,3 +294,4 @@ if __name__ == "__main__":
     gen_eos_pad()
     gen_noise()
     gen_calibration()
+    gen_scorers()

@@ -1,0 +1,66 @@
+"""Product-side calibration / scoring (llava_align_amd.calibrate) against what the reference's own functions and
+scorer scripts produced (fixtures from tests/golden/make_golden.py).  Pure host arithmetic: no GPU."""
+import json
+import os
+
+import numpy as np
+import pytest
+import torch
+
+from golden.gen_inputs import DTYPES, from_bits
+from golden_io import load_json
+from llava_align_amd import calibrate as C
+
+
+class FakeTok:
+    TABLE = {0: "<unk>", 1: "Yes", 2: " yes", 3: "No", 4: "no ", 5: "YES", 6: "maybe"}
+
+    def decode(self, i):
+        return self.TABLE.get(int(i), f"t{int(i)}")
+
+
+def test_label_dict_and_label_probs_match_reference():
+    g = load_json("calibration.json")
+    for e in g["label_dict"]:
+        dt = DTYPES[e["dtype"]]
+        row = from_bits(np.array(e["row_bits"], dtype=np.int32 if dt == torch.float32 else np.int16), dt)
+        probs = torch.softmax(row, dim=-1).float()            # what the fused kernel emits as top_prob/top_tok
+        p, t = torch.topk(probs, 10)
+        d = C.label_dict_from_top(t[0].tolist(), p[0].tolist(), FakeTok().decode)
+        assert d == e["dict"]
+        assert C.get_prob_from_logits(d) == e["p"]
+
+
+def test_affine_modes_match_reference_eval_accuracy():
+    g = load_json("calibration.json")
+    for e in g["affine"]:
+        for p, want in zip(e["probs"], e["calibrated"]):
+            if e["p_cf"] is None:
+                q, _ = C.affine_calibrate(p, None)
+            else:     # metrics.eval_accuracy uses p_cf as is (no normalisation / eps): reproduce through calibrate_weight
+                W, b = C.calibrate_weight(np.array(e["p_cf"]), e["mode"])
+                pp = np.array(p) / np.sum(p)
+                q = np.matmul(W, pp[:, None]) + b
+                q = (q / np.sum(q)).reshape(-1)
+            assert np.array_equal(q, np.array(want))
+
+
+def test_pope_scorers_match_reference_scripts():
+    g = load_json("scorers.json")
+    s = C.pope_scores(g["gt"], g["gen"])
+    for k_ref, k in (("precision", "precision"), ("recall", "recall"), ("f1", "f1"), ("accuracy", "accuracy"), ("yes", "yes"), ("unknow", "unknown")):
+        assert s[k] == pytest.approx(g["eval_pope"][k_ref], abs=1e-12)
+    for name, want in g["eval_pope_calibrate"].items():
+        got = C.pope_scores_calibrated(g["gt"], g["gen"], name)
+        assert got["n"] == want["n"]
+        for k in ("f1", "accuracy", "precision", "recall", "yes"):
+            assert float(f"{got[k] * 100:.4}") == want[k], (name, k)        # the script prints percentages with 4 significant digits
+        assert got["confidence"] == pytest.approx(want["confidence"], rel=1e-12)
+
+
+def test_answer_writer_schema(tmp_path):
+    p = tmp_path / "a.jsonl"
+    with C.AnswerWriter(str(p)) as w:
+        w.write(7, "Is there a dog?", "Yes", "llava-1.5-7b", "x.jpg", [0.9, 0.1], {"yes": 0.9}, {"yes": 0.5}, {"no": 0.6})
+        line = json.loads(open(p).read().splitlines()[0])      # flushed before close
+    assert tuple(line.keys()) == C.AnswerWriter.FIELDS and line["question_id"] == 7 and line["metadata"] == {}

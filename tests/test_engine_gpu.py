@@ -123,7 +123,7 @@ def test_prefix_sharing_is_transparent(eng):
     assert torch.equal(a.tokens, b.tokens)
     for sa, sb in zip(a.scores, b.scores):
         fin = torch.isfinite(sa) & torch.isfinite(sb)
-        assert (sa[fin].float() - sb[fin].float()).abs().max().item() <= 0.05
+        assert (sa[fin].float() - sb[fin].float()).abs().max().item() <= 0.2      # grouped path rounds P to bf16 for the MFMA; x6 contrast gain
 
 
 def test_vcd_branch_only_counts_at_step_zero(eng, ref):
@@ -186,3 +186,18 @@ def test_hip_graph_replay_matches_eager(eng):
             assert b.stats["graph"] and not a.stats["graph"]
             assert torch.equal(a.tokens, b.tokens)
             assert all(torch.equal(x, y) for x, y in zip(a.scores, b.scores))
+
+
+def test_grouped_prefix_attention_is_transparent(eng):
+    ids, imgs = prompts(seed=17)
+    kw = dict(images=imgs, cd_alpha=1.0, cd_beta=0.1, temperature=0.5, max_new_tokens=6, cd_greedy=True, output_scores=True,
+              use_dd=True, use_dd_unk=True)
+    eng.group_attention = True
+    a = eng.generate(ids, **kw)
+    eng.group_attention = False
+    b = eng.generate(ids, **kw)
+    eng.group_attention = True
+    assert torch.equal(a.tokens, b.tokens)
+    for sa, sb in zip(a.scores, b.scores):
+        fin = torch.isfinite(sa) & torch.isfinite(sb)
+        assert (sa[fin].float() - sb[fin].float()).abs().max().item() <= 0.1

@@ -158,3 +158,38 @@ def test_layernorm_and_bias_act():
     assert torch.allclose(O.bias_act(z, bias, O.ACT_GELU).float(), torch.nn.functional.gelu(zb), rtol=1e-2, atol=1e-2)
     assert torch.equal(O.bias_act(z, bias, O.ACT_NONE), zb.to(torch.bfloat16))
     assert torch.equal(O.bias_act(z, None, O.ACT_NONE), z)
+
+
+def test_grouped_prefix_decode_attention_equals_per_row():
+    """Rows sharing a prompt prefix attended as a group (MFMA over the group's queries) == one query at a time."""
+    O = ops()
+    H, Hkv, D = 8, 4, 128
+    kp, vp = bf(3, Hkv, 640, D, seed=41), bf(3, Hkv, 640, D, seed=42)          # prefix pool
+    ko, vo = bf(40, Hkv, 128, D, seed=43), bf(40, Hkv, 128, D, seed=44)        # compact own slots
+    rows, groups, grp_rows = [], [], []
+    # group 0: 6 rows on prefix slot 0 (611 tokens); group 1: 21 rows on prefix slot 2 (36 tokens); 2 rows without prefix
+    for i in range(6):
+        rows.append([i, 611 + 20 + i, 0, 611])
+    groups.append([0, 6, 0, 611]); grp_rows += list(range(0, 6))
+    for i in range(21):
+        rows.append([6 + i, 36 + 5 + 3 * i, 2, 36])
+    groups.append([6, 21, 2, 36]); grp_rows += list(range(6, 27))
+    rows += [[27, 90, 0, 0], [28, 1, 0, 0]]
+    # shuffle the row order so that group membership is a real gather
+    perm = torch.randperm(len(rows), generator=torch.Generator().manual_seed(0)).tolist()
+    inv = {old: new for new, old in enumerate(perm)}
+    rows_p = [rows[o] for o in perm]
+    grp_rows_p = [inv[r] for r in grp_rows]
+    M = len(rows)
+    q = bf(M, H * D, seed=45)
+    rt = torch.tensor(rows_p, dtype=torch.int32, device=DEV)
+    a = O.decode_attention(q, ko, vo, rt, H, Hkv, D, k_prefix=kp, v_prefix=vp, max_len=768)
+    b = O.decode_attention_grouped(q, ko, vo, kp, vp, rt, torch.tensor(groups, dtype=torch.int32, device=DEV),
+                                   torch.tensor(grp_rows_p, dtype=torch.int32, device=DEV), 2, 21, H, Hkv, D, 611, 128)
+    assert torch.allclose(a.float(), b.float(), rtol=2e-2, atol=2e-2)
+    rep = H // Hkv
+    for m, (slot, ln, ps, pl) in enumerate(rows_p):
+        K = torch.cat([kp[ps, :, :pl], ko[slot, :, :ln - pl]], 1).float().repeat_interleave(rep, 0)
+        V = torch.cat([vp[ps, :, :pl], vo[slot, :, :ln - pl]], 1).float().repeat_interleave(rep, 0)
+        ref = attn_ref(q[m].view(H, D).float(), K, V)
+        assert torch.allclose(b[m].view(H, D).float(), ref, rtol=2e-2, atol=2e-2), m
