@@ -43,6 +43,7 @@ def dist_env():
 
 
 def pope_prompts(n_img, per_img=6, seed=1234, vocab=32000, n_sys=35, txt=(19, 29), image=336):
+    """[35 system tokens] + [-200] + [19..28 question tokens], 6 questions per synthetic image."""
     rng = np.random.default_rng(seed)
     sys_tok = [1] + rng.integers(3, vocab, size=n_sys - 1).tolist()
     ids, imgs = [], []
@@ -154,25 +155,29 @@ def main():
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=3)
     ap.add_argument("--warmup", type=int, default=1)
-    ap.add_argument("--questions", type=int, default=96, help="questions per generate() batch per GPU (6 per image)")
+    ap.add_argument("--questions", type=int, default=384, help="questions per generate() batch per GPU (6 per image)")
     ap.add_argument("--model", default="llava-1.5-7b")
     ap.add_argument("--no-baselines", action="store_true")
     a = ap.parse_args()
     rank, local, world = dist_env()
+    if os.environ.get("VDD_FORCE_DEVICE") is not None:      # dry-run aid: several ranks on one GPU (with VDD_DIST_BACKEND=gloo)
+        local = int(os.environ["VDD_FORCE_DEVICE"])
     dev = torch.device(f"cuda:{local}")
     torch.cuda.set_device(dev)
     if world > 1:
         import torch.distributed as dist
-        dist.init_process_group("nccl", device_id=dev)      # "nccl" is RCCL on ROCm
+        backend = os.environ.get("VDD_DIST_BACKEND", "nccl")            # "nccl" is RCCL on ROCm
+        dist.init_process_group(backend, **({"device_id": dev} if backend == "nccl" else {}))
 
     import llava_align_amd  # noqa: F401  (raises if the HIP library is missing)
     from llava_align_amd.engine import VddLlavaEngine
     from llava_align_amd.shard import gather_tokens
 
-    roof = bench_kernel(dev) if rank == 0 else None
-    eng = VddLlavaEngine(a.model, device=dev, seed=0, t_max=704, use_graph=True)
+    roof = bench_kernel(dev) if (rank == 0 and a.model != "tiny") else None
+    eng = VddLlavaEngine(a.model, device=dev, seed=0, use_graph=True)
     n_img = max(1, a.questions // 6)
-    ids, imgs = pope_prompts(n_img, seed=1234 + rank)                   # every rank: its own shard of the question list
+    # every rank: its own shard of the question list (weak scaling)
+    ids, imgs = pope_prompts(n_img, seed=1234 + rank, vocab=eng.cfg.lm.vocab, image=eng.cfg.vision.image)
     Q = len(ids)
     kw = dict(images=imgs, use_dd_unk=True, cd_alpha=1.0, cd_beta=0.1, temperature=0.2, max_new_tokens=N_NEW, seed=1 + rank)
 
@@ -204,6 +209,7 @@ def main():
     if rank == 0:
         # decode-only rate: same batch, 2 new tokens (prefill + 1 decode step) subtracted
         kw2 = dict(kw, max_new_tokens=2)
+        roof_ = roof
         eng.generate(ids, **kw2); eng.generate(ids, **kw2)
         torch.cuda.synchronize(dev)
         t1 = time.perf_counter(); eng.generate(ids, **kw2); torch.cuda.synchronize(dev); t_pre = time.perf_counter() - t1
@@ -225,9 +231,18 @@ def main():
                                 "note": "per step the LM weights are streamed once for all rows; KV reads come on top"},
                 "prefill_tokens": out.stats["prefill_tokens"], "unshared_prefill_tokens": out.stats["unshared_prefill_tokens"],
                 "roofline": roof}
-        if world == 1 and not a.no_baselines:
+        if world == 1 and not a.no_baselines and a.model != "tiny":
+            # single question in flight (the reference's own B=1 regime): latency-mode tokens/s of the engine
+            ids1, imgs1 = pope_prompts(1, per_img=1, seed=99)
+            kw1 = dict(images=imgs1, use_dd_unk=True, cd_alpha=1.0, cd_beta=0.1, temperature=0.2, max_new_tokens=N_NEW, seed=3)
+            eng.generate(ids1, **kw1); eng.generate(ids1, **kw1)
+            torch.cuda.synchronize(dev)
+            t2 = time.perf_counter(); eng.generate(ids1, **kw1); torch.cuda.synchronize(dev); t_b1 = time.perf_counter() - t2
+            line["single_question"] = {"tokens_per_s": round(N_NEW / t_b1, 1), "ms_per_token": round(t_b1 / N_NEW * 1e3, 2),
+                                       "note": "B=1 (2 rows: main + <unk> branch), prefill + 64 tokens, HIP-graph decode"}
             line["eager_gpu"] = bench_eager_gpu(eng, dev)
             line["speedup_vs_eager_gpu"] = round(line["value"] / line["eager_gpu"]["value"], 1)
+            line["speedup_vs_eager_gpu_single_question"] = round(line["single_question"]["tokens_per_s"] / line["eager_gpu"]["value"], 1)
             line["cpu_baseline"] = bench_cpu(eng)
         else:
             line["cpu_baseline"] = None

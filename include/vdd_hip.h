@@ -113,9 +113,11 @@ int vdd_add_diffusion_noise(const void* x, void* y, int64_t n, int dtype, float 
  * rows of one call = (question, branch) pairs, so weights stream from HBM once per step.
  * ------------------------------------------------------------------------------------------- */
 
-/* h = x (+ delta); resid_out = h (optional); y = bf16(bf16(h * rsqrt(mean h^2 + eps)) * w).  d % 8 == 0, d <= 8192. */
-int vdd_rmsnorm(const void* x, const void* delta, const void* w, void* y, void* resid_out, int M, int d, float eps,
-                void* hip_stream);
+/* h = x (+ delta); resid_out = h (optional); y = bf16(bf16(h * rsqrt(mean h^2 + eps)) * w).  d % 8 == 0, d <= 8192.
+ * delta is either bf16 [M, d] or, as delta_slabs, the n_slabs fp32 split-K partials [n_slabs][M][d] of vdd_mid_gemm
+ * (summed, rounded to bf16, then added - the same roundings as a bf16 GEMM output followed by the residual add). */
+int vdd_rmsnorm(const void* x, const void* delta, const float* delta_slabs, int n_slabs, const void* w, void* y, void* resid_out,
+                int M, int d, float eps, void* hip_stream);
 
 /* qkv [M, (Hq+2Hkv)*D] -> q_out [M, Hq, D] with rotary embedding at pos[row] (HF rotate_half pairing;
  * cos_sin fp32 [max_pos, D/2, 2]); k (rotated) and v are written to cache[slot[row]][kv_head][cpos[row]][D]
@@ -132,6 +134,12 @@ int vdd_embed(const int64_t* ids, const void* table, void* out, int M, int d, vo
 /* Y[M,N] = X[M,K] W[N,K]^T (+ R[M,N]); M <= 64, K % 128 == 0; W is read from HBM exactly once. */
 int vdd_skinny_gemm(const void* X, const void* W, const void* R, void* Y, int M, int N, int K, int64_t ldx, int64_t ldr,
                     int64_t ldy, void* hip_stream);
+
+/* Decode-regime GEMM, 9 <= M <= 256 rows: Y[M,N] = X[M,K] W[N,K]^T with W streamed from HBM exactly once and the X
+ * tile shared through LDS (csrc/vdd_mid_gemm.hip).  Either Y (bf16, n_split == 1) or Y_slabs (fp32 [n_split][M][N]:
+ * split-K partial sums, summed by vdd_rmsnorm's delta_slabs input); K % (64 * n_split) == 0. */
+int vdd_mid_gemm(const void* X, const void* W, void* Y, float* Y_slabs, int M, int N, int K, int64_t ldx, int64_t ldy,
+                 int n_split, void* hip_stream);
 
 /* One query per (row, head) over that row's KV: rows[m] = {slot, len, prefix_slot, prefix_len} (int32 x4);
  * tokens [0, prefix_len) are read from the PREFIX pool (k_prefix/v_prefix, slot prefix_slot, index t: a shared

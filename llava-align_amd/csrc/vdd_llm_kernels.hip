@@ -45,6 +45,7 @@ __device__ __forceinline__ float wave_sum(float v) {
 // HF rounding order: h = bf16(resid + delta); y = bf16( bf16(h * rstd) * w ).
 template <int VPT>   // uint4 (8 x bf16) per thread
 __global__ void __launch_bounds__(256) rmsnorm_kernel(const uint16_t* __restrict__ x, const uint16_t* __restrict__ delta,
+                                                      const float* __restrict__ slabs, int n_slabs, long long slab_stride,
                                                       const uint16_t* __restrict__ w, uint16_t* __restrict__ y,
                                                       uint16_t* __restrict__ resid_out, int d, float eps) {
     __shared__ float red[4];
@@ -61,6 +62,18 @@ __global__ void __launch_bounds__(256) rmsnorm_kernel(const uint16_t* __restrict
                 uint4 b = *reinterpret_cast<const uint4*>(delta + off + e);
                 a.x = pack(lo(a.x) + lo(b.x), hi(a.x) + hi(b.x)); a.y = pack(lo(a.y) + lo(b.y), hi(a.y) + hi(b.y));
                 a.z = pack(lo(a.z) + lo(b.z), hi(a.z) + hi(b.z)); a.w = pack(lo(a.w) + lo(b.w), hi(a.w) + hi(b.w));
+            }
+            if (slabs != nullptr) {      // delta = bf16(sum of the split-K fp32 partial slabs of the producing GEMM)
+                float dsum[8] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+                for (int sl = 0; sl < n_slabs; ++sl) {
+                    const float4 p0 = *reinterpret_cast<const float4*>(slabs + (size_t)sl * slab_stride + off + e);
+                    const float4 p1 = *reinterpret_cast<const float4*>(slabs + (size_t)sl * slab_stride + off + e + 4);
+                    dsum[0] += p0.x; dsum[1] += p0.y; dsum[2] += p0.z; dsum[3] += p0.w;
+                    dsum[4] += p1.x; dsum[5] += p1.y; dsum[6] += p1.z; dsum[7] += p1.w;
+                }
+                auto addr = [&](uint32_t hv, float d0, float d1) { return pack(lo(hv) + bf2f(f2bf(d0)), hi(hv) + bf2f(f2bf(d1))); };
+                a.x = addr(a.x, dsum[0], dsum[1]); a.y = addr(a.y, dsum[2], dsum[3]);
+                a.z = addr(a.z, dsum[4], dsum[5]); a.w = addr(a.w, dsum[6], dsum[7]);
             }
             if (resid_out != nullptr) *reinterpret_cast<uint4*>(resid_out + off + e) = a;
             h[i] = a;
@@ -455,15 +468,17 @@ inline int ok(hipError_t) { return hipGetLastError() == hipSuccess ? VDD_OK : VD
 
 extern "C" {
 
-int vdd_rmsnorm(const void* x, const void* delta, const void* w, void* y, void* resid_out, int M, int d, float eps, void* stream) {
+int vdd_rmsnorm(const void* x, const void* delta, const float* delta_slabs, int n_slabs, const void* w, void* y, void* resid_out,
+                int M, int d, float eps, void* stream) {
     if (M <= 0) return VDD_OK;
-    if (!x || !w || !y || d % 8 != 0 || d > 8192) return VDD_ERR_INVALID_ARG;
+    if (!x || !w || !y || d % 8 != 0 || d > 8192 || (delta && delta_slabs) || (delta_slabs && n_slabs < 1)) return VDD_ERR_INVALID_ARG;
+    const float* Sl = delta_slabs; const long long ss = (long long)M * d;
     hipStream_t st = (hipStream_t)stream;
     auto X = (const uint16_t*)x; auto Dl = (const uint16_t*)delta; auto Wt = (const uint16_t*)w; auto Y = (uint16_t*)y; auto Ro = (uint16_t*)resid_out;
     const int vpt = (d / 8 + 255) / 256;
-    if (vpt <= 1) hipLaunchKernelGGL(rmsnorm_kernel<1>, dim3(M), dim3(256), 0, st, X, Dl, Wt, Y, Ro, d, eps);
-    else if (vpt <= 2) hipLaunchKernelGGL(rmsnorm_kernel<2>, dim3(M), dim3(256), 0, st, X, Dl, Wt, Y, Ro, d, eps);
-    else hipLaunchKernelGGL(rmsnorm_kernel<4>, dim3(M), dim3(256), 0, st, X, Dl, Wt, Y, Ro, d, eps);
+    if (vpt <= 1) hipLaunchKernelGGL(rmsnorm_kernel<1>, dim3(M), dim3(256), 0, st, X, Dl, Sl, n_slabs, ss, Wt, Y, Ro, d, eps);
+    else if (vpt <= 2) hipLaunchKernelGGL(rmsnorm_kernel<2>, dim3(M), dim3(256), 0, st, X, Dl, Sl, n_slabs, ss, Wt, Y, Ro, d, eps);
+    else hipLaunchKernelGGL(rmsnorm_kernel<4>, dim3(M), dim3(256), 0, st, X, Dl, Sl, n_slabs, ss, Wt, Y, Ro, d, eps);
     return ok(hipSuccess);
 }
 

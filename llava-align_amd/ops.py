@@ -12,7 +12,8 @@ from . import _lib
 
 _P, _I, _L, _F = C.c_void_p, C.c_int, C.c_int64, C.c_float
 _SIGS = {
-    "vdd_rmsnorm": [_P, _P, _P, _P, _P, _I, _I, _F, _P],
+    "vdd_rmsnorm": [_P, _P, _P, _I, _P, _P, _P, _I, _I, _F, _P],
+    "vdd_mid_gemm": [_P, _P, _P, _P, _I, _I, _I, _L, _L, _I, _P],
     "vdd_rope_kv_write": [_P, _P, _P, _P, _P, _P, _P, _P, _I, _I, _I, _I, _L, _I, _P],
     "vdd_silu_mul": [_P, _P, _L, _I, _P],
     "vdd_embed": [_P, _P, _P, _I, _I, _P],
@@ -49,12 +50,38 @@ def _bf16(*ts):
 
 
 def rmsnorm(x, w, eps, delta=None, resid_out=None, out=None):
-    """h = x (+ delta); resid_out <- h; returns h * rsqrt(mean h^2 + eps) * w.   x: [M, d]"""
-    _bf16(x, w, delta, resid_out)
+    """h = x (+ delta); resid_out <- h; returns h * rsqrt(mean h^2 + eps) * w.   x: [M, d].
+    delta: bf16 [M, d], or fp32 [S, M, d] split-K slabs from mid_gemm(..., n_split=S)."""
+    _bf16(x, w, resid_out)
     M, d = x.shape
     out = torch.empty_like(x) if out is None else out
-    _lib.check(_lib_ready().vdd_rmsnorm(x.data_ptr(), delta.data_ptr() if delta is not None else None, w.data_ptr(),
-                                        out.data_ptr(), resid_out.data_ptr() if resid_out is not None else None, M, d, eps, _st(x)))
+    dptr = sptr = None
+    ns = 0
+    if delta is not None:
+        if delta.dtype == torch.float32:
+            if delta.dim() != 3 or delta.shape[1:] != x.shape or not delta.is_contiguous():
+                raise ValueError("fp32 delta must be contiguous [n_slabs, M, d]")
+            sptr, ns = delta.data_ptr(), delta.shape[0]
+        else:
+            _bf16(delta)
+            dptr = delta.data_ptr()
+    _lib.check(_lib_ready().vdd_rmsnorm(x.data_ptr(), dptr, sptr, ns, w.data_ptr(), out.data_ptr(),
+                                        resid_out.data_ptr() if resid_out is not None else None, M, d, eps, _st(x)))
+    return out
+
+
+def mid_gemm(x, w, n_split=1, slabs=False, out=None):
+    """x [9..256 rows, K] @ w[N, K]^T: weight-streaming MFMA kernel for the decode regime.  slabs=True returns the fp32
+    split-K partials [n_split, M, N] (feed them to rmsnorm as `delta`); otherwise bf16 [M, N]."""
+    _bf16(x, w)
+    M, K = x.shape
+    N = w.shape[0]
+    if slabs:
+        out = torch.empty(n_split, M, N, dtype=torch.float32, device=x.device) if out is None else out
+        _lib.check(_lib_ready().vdd_mid_gemm(x.data_ptr(), w.data_ptr(), None, out.data_ptr(), M, N, K, x.stride(0), N, n_split, _st(x)))
+    else:
+        out = torch.empty(M, N, dtype=x.dtype, device=x.device) if out is None else out
+        _lib.check(_lib_ready().vdd_mid_gemm(x.data_ptr(), w.data_ptr(), out.data_ptr(), None, M, N, K, x.stride(0), out.stride(0), 1, _st(x)))
     return out
 
 
@@ -102,11 +129,18 @@ def skinny_gemm(x, w, resid=None, out=None):
 SKINNY_MAX_M = 8      # measured on MI355X (tools/e2e_probe.py): 5.1-5.4 TB/s for M<=4 vs 4.0-5.0 for the library; slower past ~8 rows
 
 
+MID_MAX_M = 0         # csrc/vdd_mid_gemm.hip is correct (tests) but measured 2.5-4x SLOWER than hipBLASLt for M >= 48 on MI355X
+                      # (tools/gemm_probe2.py: X-tile latency exposed at 1 wave/SIMD); it only wins for split-K N=4096, M <= 32.
+                      # Not dispatched until it is pipelined properly.
+
+
 def linear(x, w, out=None):
     """Row-batched projection: hand-written weight-streaming MFMA kernel up to 64 rows (the decode
     regime), the vendor GEMM library (hipBLASLt via torch.matmul) for the large-M prefill GEMMs."""
     if x.shape[0] <= SKINNY_MAX_M and x.shape[1] % 128 == 0:
         return skinny_gemm(x, w, out=out)
+    if x.shape[0] <= MID_MAX_M and x.shape[1] % 64 == 0:
+        return mid_gemm(x, w, out=out)
     return torch.matmul(x, w.t(), out=out) if out is not None else torch.matmul(x, w.t())
 
 

@@ -193,3 +193,34 @@ def test_grouped_prefix_decode_attention_equals_per_row():
         V = torch.cat([vp[ps, :, :pl], vo[slot, :, :ln - pl]], 1).float().repeat_interleave(rep, 0)
         ref = attn_ref(q[m].view(H, D).float(), K, V)
         assert torch.allclose(b[m].view(H, D).float(), ref, rtol=2e-2, atol=2e-2), m
+
+
+@pytest.mark.parametrize("M,N,K", [(9, 4096, 4096), (33, 12288, 4096), (48, 22016, 4096), (96, 4096, 11008), (130, 32000, 4096),
+                                    (192, 12288, 4096), (256, 4096, 4096), (20, 1000, 256), (17, 200, 512)])
+def test_mid_gemm(M, N, K):
+    O = ops()
+    x, w = bf(M, K, seed=51), bf(N, K, scale=0.02, seed=52)
+    ref = x.float() @ w.float().t()
+    tol = 2e-2 * ref.abs().max().item()
+    y = O.mid_gemm(x, w)
+    assert (y.float() - ref).abs().max().item() <= tol
+    for ns in (1, 2, 4):
+        if K % (64 * ns):
+            continue
+        sl = O.mid_gemm(x, w, n_split=ns, slabs=True)
+        assert sl.shape == (ns, M, N) and (sl.sum(0) - ref).abs().max().item() <= 1e-3 * ref.abs().max().item() + 1e-3
+    big = bf(M, K + 64, seed=53)                      # strided rows
+    assert (O.mid_gemm(big[:, :K], w).float() - big[:, :K].float() @ w.float().t()).abs().max().item() <= tol
+
+
+def test_rmsnorm_sums_split_k_slabs():
+    O = ops()
+    M, d = 40, 4096
+    x, w = bf(M, d, seed=61), bf(d, seed=62) * 0.1 + 1
+    slabs = torch.randn(4, M, d, device=DEV) * 0.5
+    ro = torch.empty_like(x)
+    y = O.rmsnorm(x, w, 1e-5, delta=slabs, resid_out=ro)
+    h = (x.float() + slabs.sum(0).to(torch.bfloat16).float()).to(torch.bfloat16)
+    assert (ro.float() - h.float()).abs().max().item() <= 0.04          # fp32 summation order may move one bf16 ulp
+    ref = (h.float() * torch.rsqrt(h.float().pow(2).mean(-1, keepdim=True) + 1e-5)).to(torch.bfloat16).float() * w.float()
+    assert torch.allclose(y.float(), ref, rtol=3e-2, atol=2e-2)

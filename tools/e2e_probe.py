@@ -47,7 +47,7 @@ if __name__ == "__main__":
             ts = timeit(lambda: ops.skinny_gemm(x, w), 20) if M <= 64 else float("nan")
             print(f"gate_up M={M}: torch {tm*1e6:.1f} us ({w.numel()*2/tm/1e9:.0f} GB/s)  skinny {ts*1e6:.1f} us ({w.numel()*2/ts/1e9:.0f} GB/s)", flush=True)
     if what in ("all", "e2e"):
-        cfgs = ((1, 64), (4, 64), (8, 64), (16, 64), (32, 64)) if len(sys.argv) < 3 else ((int(sys.argv[2]), 64),)
+        cfgs = ((16, 64), (32, 64), (64, 64), (128, 64)) if len(sys.argv) < 3 else ((int(sys.argv[2]), 64),)
         for n_img, new in cfgs:
             ids, imgs = pope_prompts(n_img)
             kw = dict(images=imgs, use_dd_unk=True, cd_alpha=1.0, cd_beta=0.1, temperature=0.2)
