@@ -154,11 +154,13 @@ int64_t vdd_decode_attention_workspace_bytes(int M, int H, int D, int max_len);
 
 /* Same result as vdd_decode_attention when every row with prefix_len > 0 is listed in exactly one group of rows
  * sharing (prefix_slot, prefix_len): groups[g] = {row_off, n_rows, prefix_slot, prefix_len} (int32 x4) indexes
- * group_rows[].  The shared prefix is attended ONCE per group with the group's queries as the MFMA M dimension
- * (each prefix K/V byte fetched once per group, not once per row); own tokens go through the split-KV kernel.
+ * group_rows[]; items[i] = {group, first_row_of_16_row_slice, 64-key chunk, 0} (int32 x4) is the host-built work
+ * list of the prefix pass (one block per item and head).  Each 64-key prefix K/V tile is staged ONCE per group (per 16 rows of it) in LDS and every row of the
+ * group attends it from there (each prefix byte fetched once per group, not once per row); own tokens go through
+ * the split-KV kernel.
  * Workspace: vdd_decode_attention_workspace_bytes(M, H, D, round_up(max_prefix_len, 64) + round_up(max_own_len, 64)). */
 int vdd_decode_attention_grouped(const void* q, const void* k_cache, const void* v_cache, const void* k_prefix, const void* v_prefix,
-                                 const int32_t* rows, const int32_t* groups, const int32_t* group_rows, int n_groups, int max_group_rows,
+                                 const int32_t* rows, const int32_t* groups, const int32_t* group_rows, const int32_t* items, int n_items,
                                  void* out, void* workspace, int M, int H, int Hkv, int D, int64_t slot_stride, int t_max,
                                  int64_t prefix_stride, int prefix_tmax, int max_prefix_len, int max_own_len, float scale, void* hip_stream);
 

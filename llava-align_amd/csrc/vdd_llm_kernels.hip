@@ -34,6 +34,33 @@ __device__ __forceinline__ float lo(uint32_t w) { return bf2f(w & 0xFFFFu); }
 __device__ __forceinline__ float hi(uint32_t w) { return __builtin_bit_cast(float, w & 0xFFFF0000u); }
 __device__ __forceinline__ uint32_t pack(float a, float b) { return f2bf(a) | (f2bf(b) << 16); }
 
+typedef __attribute__((ext_vector_type(2))) __bf16 bf16x2_t;
+// q.k over 8 packed bf16 pairs with v_dot2c_f32_bf16 (fp32 accumulate; bf16 x bf16 products are exact in fp32)
+__device__ __forceinline__ float dot8(const uint4& a, const uint4& b) {
+    float s = __builtin_amdgcn_fdot2_f32_bf16(__builtin_bit_cast(bf16x2_t, a.x), __builtin_bit_cast(bf16x2_t, b.x), 0.f, false);
+    s = __builtin_amdgcn_fdot2_f32_bf16(__builtin_bit_cast(bf16x2_t, a.y), __builtin_bit_cast(bf16x2_t, b.y), s, false);
+    s = __builtin_amdgcn_fdot2_f32_bf16(__builtin_bit_cast(bf16x2_t, a.z), __builtin_bit_cast(bf16x2_t, b.z), s, false);
+    s = __builtin_amdgcn_fdot2_f32_bf16(__builtin_bit_cast(bf16x2_t, a.w), __builtin_bit_cast(bf16x2_t, b.w), s, false);
+    return s;
+}
+// One key of the online softmax for a 16-lane group: s is already reduced over the group.  The running maximum only
+// moves on a small fraction of the keys, so the rescale of (l, acc) is taken lazily behind a wave-uniform test and
+// the common path is 8 converts + 8 FMAs.
+#define ATT_ONLINE_STEP(s, vv, m, l, acc)                                                                      \
+    do {                                                                                                       \
+        if (__any((s) > (m))) {                                                                                \
+            const float mn_ = fmaxf((m), (s));                                                                 \
+            const float corr_ = __expf((m) - mn_);                                                             \
+            (l) *= corr_;                                                                                      \
+            _Pragma("unroll") for (int e_ = 0; e_ < 8; ++e_) (acc)[e_] *= corr_;                                \
+            (m) = mn_;                                                                                         \
+        }                                                                                                      \
+        const float p_ = __expf((s) - (m));                                                                    \
+        (l) += p_;                                                                                             \
+        (acc)[0] += p_ * lo((vv).x); (acc)[1] += p_ * hi((vv).x); (acc)[2] += p_ * lo((vv).y); (acc)[3] += p_ * hi((vv).y); \
+        (acc)[4] += p_ * lo((vv).z); (acc)[5] += p_ * hi((vv).z); (acc)[6] += p_ * lo((vv).w); (acc)[7] += p_ * hi((vv).w); \
+    } while (0)
+
 __device__ __forceinline__ float wave_sum(float v) {
 #pragma unroll
     for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o);
@@ -266,9 +293,7 @@ __global__ void __launch_bounds__(256) decode_attn_kernel(const uint16_t* __rest
         return;
     }
     const int kvh = head / (H / Hkv);
-    uint4 qv = *reinterpret_cast<const uint4*>(q + ((size_t)row * H + head) * D + j * 8);
-    const float qf[8] = {lo(qv.x) * scale, hi(qv.x) * scale, lo(qv.y) * scale, hi(qv.y) * scale,
-                         lo(qv.z) * scale, hi(qv.z) * scale, lo(qv.w) * scale, hi(qv.w) * scale};
+    const uint4 qv = *reinterpret_cast<const uint4*>(q + ((size_t)row * H + head) * D + j * 8);
     // own pool stores token t at index t - plen (compact slots); the prefix pool at index t
     const size_t hoff = (size_t)kvh * t_max * D + j * 8, poff = (size_t)kvh * pre_tmax * D + j * 8;
     const uint16_t* k_own = kc + (size_t)ar.slot * slot_stride + hoff - (size_t)ar.plen * D;
@@ -289,19 +314,10 @@ __global__ void __launch_bounds__(256) decode_attn_kernel(const uint16_t* __rest
         }
 #pragma unroll
         for (int u = 0; u < U; ++u) {
-            float s = qf[0] * lo(kv[u].x) + qf[1] * hi(kv[u].x) + qf[2] * lo(kv[u].y) + qf[3] * hi(kv[u].y)
-                    + qf[4] * lo(kv[u].z) + qf[5] * hi(kv[u].z) + qf[6] * lo(kv[u].w) + qf[7] * hi(kv[u].w);
+            float s = dot8(qv, kv[u]);
             s += __shfl_xor(s, 1); s += __shfl_xor(s, 2); s += __shfl_xor(s, 4); s += __shfl_xor(s, 8);
-            if (t0 + 4 * u < k1) {
-                const float mn = fmaxf(m, s);
-                const float corr = __expf(m - mn), p = __expf(s - mn);
-                l = l * corr + p;
-                acc[0] = acc[0] * corr + p * lo(vv[u].x); acc[1] = acc[1] * corr + p * hi(vv[u].x);
-                acc[2] = acc[2] * corr + p * lo(vv[u].y); acc[3] = acc[3] * corr + p * hi(vv[u].y);
-                acc[4] = acc[4] * corr + p * lo(vv[u].z); acc[5] = acc[5] * corr + p * hi(vv[u].z);
-                acc[6] = acc[6] * corr + p * lo(vv[u].w); acc[7] = acc[7] * corr + p * hi(vv[u].w);
-                m = mn;
-            }
+            s *= scale;
+            if (t0 + 4 * u < k1) ATT_ONLINE_STEP(s, vv[u], m, l, acc);
         }
     }
     // merge the 4 lane groups (xor 16, 32)
@@ -352,112 +368,74 @@ __global__ void __launch_bounds__(256) decode_attn_combine_kernel(const float* _
     reinterpret_cast<uint32_t*>(out + ((size_t)row * H + head) * D)[lane] = pack(a0 * inv, a1 * inv);
 }
 
-// ------------------------------------------------------------------ prefix-grouped decode attention (MFMA)
-// Rows that share a prompt prefix (the 6 POPE questions of one image; ALL image-free branch rows) are one
-// group: their queries form the M dimension of 16x16x32 MFMAs, so every prefix K/V byte is fetched ONCE per
-// group instead of once per row.  Block = (16-row query tile, head, 4 consecutive 64-key chunks): wave w owns
-// chunk 4*quad + w; S = Q K^T with K fragments straight from the prefix pool, one-shot softmax over the 64
-// keys (no online rescale inside a chunk), P re-laid out through LDS, V staged per wave in LDS, O = P V.
-// Output: un-normalised partials (acc[128], m, l) per (row, head, chunk) in the same workspace the split
-// kernel uses, merged by decode_attn_combine_kernel.
+// ------------------------------------------------------------------ prefix-grouped decode attention
+// Rows that share a prompt prefix (the 6 POPE questions of one image; ALL image-free branch rows) form a group.
+// A block = (16-row slice of a group, head, 64-key chunk of the prefix): it stages that K/V tile ONCE in LDS
+// (2 x 16 KiB, 16 B per lane, 1 KiB contiguous per wave instruction) and every row of the slice attends it from
+// LDS, so each prefix K/V byte leaves HBM/L2 once per group instead of once per row.  Per row the arithmetic is the
+// split-KV kernel's (16-lane group per key, online softmax per group, 4-way merge); partials go to the same
+// workspace and are merged by decode_attn_combine_kernel.
 struct GroupDesc { int row_off, n_rows, pslot, plen; };
 
 template <int D>
 __global__ void __launch_bounds__(256) decode_attn_prefix_kernel(const uint16_t* __restrict__ q, const uint16_t* __restrict__ kpre,
                                                                  const uint16_t* __restrict__ vpre, const GroupDesc* __restrict__ groups,
-                                                                 const int* __restrict__ group_rows, float* __restrict__ ws, int H, int Hkv,
-                                                                 long long pre_stride, int pre_tmax, float scale, int nchunk, int nquad) {
+                                                                 const int* __restrict__ group_rows, const int4* __restrict__ items,
+                                                                 float* __restrict__ ws, int H, int Hkv,
+                                                                 long long pre_stride, int pre_tmax, float scale, int nchunk) {
     static_assert(D == 128, "");
-    constexpr int KS = D / 32, NT = D / 16, VLD = D + 8, PLD = ATT_CH + 8;
-    extern __shared__ __attribute__((aligned(16))) uint16_t lds[];
-    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, ln = lane & 15, g = lane >> 4;
-    uint16_t* v_lds = lds + (size_t)wave * (ATT_CH * VLD + 16 * PLD);
-    uint16_t* p_lds = v_lds + ATT_CH * VLD;
-    const GroupDesc gd = groups[blockIdx.z / nquad];
-    const int chunk = (blockIdx.z % nquad) * 4 + wave;
+    __shared__ __attribute__((aligned(16))) uint16_t k_lds[ATT_CH * D];
+    __shared__ __attribute__((aligned(16))) uint16_t v_lds[ATT_CH * D];
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, g = lane >> 4, j = lane & 15;
+    const int4 item = items[blockIdx.x];                          // {group, first row of the slice, chunk, -}: host-built work list
+    const GroupDesc gd = groups[item.x];
+    const int chunk = item.z;
     const int head = blockIdx.y, kvh = head / (H / Hkv);
-    const int r0 = blockIdx.x * 16;
+    const int r0 = item.y;
     const int k0 = chunk * ATT_CH;
-    const bool active = (r0 < gd.n_rows) && (k0 < gd.plen);
-    const int k1 = min(gd.plen, k0 + ATT_CH);
-    f32x4_t o[NT];
-    float mrow[4], lrow[4];
-    int rid = 0;
-    if (active) {
-        int rr = r0 + ln; if (rr >= gd.n_rows) rr = gd.n_rows - 1;
-        rid = group_rows[gd.row_off + rr];
-        bf16x8_t qf[KS];
-        const uint16_t* qp = q + ((size_t)rid * H + head) * D + g * 8;
+    if (r0 >= gd.n_rows || k0 >= gd.plen) return;                 // block-uniform
+    const int k1 = min(gd.plen, k0 + ATT_CH), nk = k1 - k0;
+    {   // stage the tile: 64 keys x 256 B for K and V
+        const uint16_t* kb = kpre + (size_t)gd.pslot * pre_stride + ((size_t)kvh * pre_tmax + k0) * D;
+        const uint16_t* vb = vpre + (size_t)gd.pslot * pre_stride + ((size_t)kvh * pre_tmax + k0) * D;
 #pragma unroll
-        for (int ks = 0; ks < KS; ++ks) qf[ks] = *reinterpret_cast<const bf16x8_t*>(qp + ks * 32);
-        const uint16_t* kb = kpre + (size_t)gd.pslot * pre_stride + (size_t)kvh * pre_tmax * D;
-        const uint16_t* vb = vpre + (size_t)gd.pslot * pre_stride + (size_t)kvh * pre_tmax * D;
-        // stage this wave's V tile: 64 keys x 128 dims, 16 B per lane, 1 KiB contiguous per instruction
-#pragma unroll
-        for (int i = 0; i < ATT_CH * (D / 8) / 64; ++i) {
-            const int e = i * 64 + lane, key = e / (D / 8), dd = (e % (D / 8)) * 8;
-            int t = k0 + key; if (t >= k1) t = k1 - 1;
-            *reinterpret_cast<uint4*>(&v_lds[key * VLD + dd]) = *reinterpret_cast<const uint4*>(vb + (size_t)t * D + dd);
-        }
-        f32x4_t s[4];
-#pragma unroll
-        for (int j = 0; j < 4; ++j) {
-            s[j] = f32x4_t{0.f, 0.f, 0.f, 0.f};
-            int t = k0 + 16 * j + ln; if (t >= k1) t = k1 - 1;
-            const uint16_t* kp = kb + (size_t)t * D + g * 8;
-#pragma unroll
-            for (int ks = 0; ks < KS; ++ks) {
-                bf16x8_t kf = *reinterpret_cast<const bf16x8_t*>(kp + ks * 32);
-                s[j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(qf[ks], kf, s[j], 0, 0, 0);
+        for (int i = 0; i < ATT_CH * D / 8 / 256; ++i) {
+            const int e = (i * 256 + tid) * 8;
+            if (e < nk * D) {
+                *reinterpret_cast<uint4*>(&k_lds[e]) = *reinterpret_cast<const uint4*>(kb + e);
+                *reinterpret_cast<uint4*>(&v_lds[e]) = *reinterpret_cast<const uint4*>(vb + e);
             }
-        }
-        // C layout: row = 4 g + r, col = key 16 j + ln
-#pragma unroll
-        for (int r = 0; r < 4; ++r) {
-            float mx = -INFINITY;
-#pragma unroll
-            for (int j = 0; j < 4; ++j) {
-                float v = (k0 + 16 * j + ln < k1) ? s[j][r] * scale : -INFINITY;
-                s[j][r] = v; mx = fmaxf(mx, v);
-            }
-            mx = fmaxf(mx, __shfl_xor(mx, 1)); mx = fmaxf(mx, __shfl_xor(mx, 2));
-            mx = fmaxf(mx, __shfl_xor(mx, 4)); mx = fmaxf(mx, __shfl_xor(mx, 8));
-            float ps = 0.f;
-#pragma unroll
-            for (int j = 0; j < 4; ++j) {
-                const float pv = __expf(s[j][r] - mx);          // exp(-inf) = 0 for masked keys; key k0 is always valid
-                ps += pv;
-                p_lds[(g * 4 + r) * PLD + 16 * j + ln] = (uint16_t)f2bf(pv);
-            }
-            ps += __shfl_xor(ps, 1); ps += __shfl_xor(ps, 2); ps += __shfl_xor(ps, 4); ps += __shfl_xor(ps, 8);
-            mrow[r] = mx; lrow[r] = ps;
         }
     }
-    __syncthreads();                                             // V tile + P patch of every wave visible
-    if (active) {
-#pragma unroll
-        for (int nt = 0; nt < NT; ++nt) o[nt] = f32x4_t{0.f, 0.f, 0.f, 0.f};
-#pragma unroll
-        for (int kk = 0; kk < ATT_CH / 32; ++kk) {
-            const bf16x8_t pf = *reinterpret_cast<const bf16x8_t*>(&p_lds[ln * PLD + kk * 32 + g * 8]);
-#pragma unroll
-            for (int nt = 0; nt < NT; ++nt) {
-                bf16x8_t vf;
-#pragma unroll
-                for (int i = 0; i < 8; ++i) vf[i] = (short)v_lds[(kk * 32 + g * 8 + i) * VLD + nt * 16 + ln];
-                o[nt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(pf, vf, o[nt], 0, 0, 0);
-            }
+    __syncthreads();
+    const int nrows = min(16, gd.n_rows - r0);
+    for (int rr = wave; rr < nrows; rr += 4) {
+        const int row = group_rows[gd.row_off + r0 + rr];
+        const uint4 qv = *reinterpret_cast<const uint4*>(q + ((size_t)row * H + head) * D + j * 8);
+        float m = -INFINITY, l = 0.f, acc[8] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+        for (int t = g; t < nk; t += 4) {
+            const uint4 kv = *reinterpret_cast<const uint4*>(&k_lds[t * D + j * 8]);
+            const uint4 vv = *reinterpret_cast<const uint4*>(&v_lds[t * D + j * 8]);
+            float s = dot8(qv, kv);
+            s += __shfl_xor(s, 1); s += __shfl_xor(s, 2); s += __shfl_xor(s, 4); s += __shfl_xor(s, 8);
+            s *= scale;
+            ATT_ONLINE_STEP(s, vv, m, l, acc);
         }
 #pragma unroll
-        for (int r = 0; r < 4; ++r) {
-            const int rr = r0 + g * 4 + r;
-            if (rr < gd.n_rows) {
-                const int orow = group_rows[gd.row_off + rr];
-                float* wsp = ws + (((size_t)orow * H + head) * nchunk + chunk) * (D + 2);
+        for (int o = 16; o <= 32; o <<= 1) {
+            const float mo = __shfl_xor(m, o), lo_ = __shfl_xor(l, o);
+            const float mn = fmaxf(m, mo);
+            const float c0 = (m == -INFINITY) ? 0.f : __expf(m - mn), c1 = (mo == -INFINITY) ? 0.f : __expf(mo - mn);
+            l = l * c0 + lo_ * c1;
 #pragma unroll
-                for (int nt = 0; nt < NT; ++nt) wsp[nt * 16 + ln] = o[nt][r];
-                if (ln == 0) { wsp[D] = mrow[r]; wsp[D + 1] = lrow[r]; }
-            }
+            for (int e = 0; e < 8; ++e) { const float ao = __shfl_xor(acc[e], o); acc[e] = acc[e] * c0 + ao * c1; }
+            m = mn;
+        }
+        if (g == 0) {
+            float* wsp = ws + (((size_t)row * H + head) * nchunk + chunk) * (D + 2);
+            *reinterpret_cast<float4*>(wsp + j * 8) = make_float4(acc[0], acc[1], acc[2], acc[3]);
+            *reinterpret_cast<float4*>(wsp + j * 8 + 4) = make_float4(acc[4], acc[5], acc[6], acc[7]);
+            if (j == 0) { wsp[D] = m; wsp[D + 1] = l; }
         }
     }
 }
@@ -537,24 +515,19 @@ int vdd_decode_attention(const void* q, const void* k_cache, const void* v_cache
 }
 
 int vdd_decode_attention_grouped(const void* q, const void* k_cache, const void* v_cache, const void* k_prefix, const void* v_prefix,
-                                 const int32_t* rows, const int32_t* groups, const int32_t* group_rows, int n_groups, int max_group_rows,
+                                 const int32_t* rows, const int32_t* groups, const int32_t* group_rows, const int32_t* items, int n_items,
                                  void* out, void* workspace, int M, int H, int Hkv, int D, int64_t slot_stride, int t_max,
                                  int64_t prefix_stride, int prefix_tmax, int max_prefix_len, int max_own_len, float scale, void* stream) {
     if (M <= 0) return VDD_OK;
-    if (!q || !k_cache || !v_cache || !k_prefix || !v_prefix || !rows || !groups || !group_rows || !out || !workspace || D != 128 ||
-        H % Hkv != 0 || max_own_len <= 0 || max_prefix_len < 0 || n_groups < 0) return VDD_ERR_INVALID_ARG;
+    if (!q || !k_cache || !v_cache || !k_prefix || !v_prefix || !rows || !groups || !group_rows || !items || !out || !workspace || D != 128 ||
+        H % Hkv != 0 || max_own_len <= 0 || max_prefix_len < 0 || n_items < 0) return VDD_ERR_INVALID_ARG;
     const int npre = (max_prefix_len + ATT_CH - 1) / ATT_CH, nown = (max_own_len + ATT_CH - 1) / ATT_CH;
     const int nchunk = npre + nown;
     hipStream_t st = (hipStream_t)stream;
-    if (n_groups > 0 && npre > 0) {
-        const int nquad = (npre + 3) / 4;
-        const size_t lds = 4 * (size_t)(ATT_CH * (128 + 8) + 16 * (ATT_CH + 8)) * 2;
-        static int attr = (int)hipFuncSetAttribute(reinterpret_cast<const void*>(&decode_attn_prefix_kernel<128>),
-                                                   hipFuncAttributeMaxDynamicSharedMemorySize, 96 * 1024);
-        (void)attr;
-        hipLaunchKernelGGL(decode_attn_prefix_kernel<128>, dim3((max_group_rows + 15) / 16, H, n_groups * nquad), dim3(256), lds, st,
+    if (n_items > 0 && npre > 0) {
+        hipLaunchKernelGGL(decode_attn_prefix_kernel<128>, dim3(n_items, H), dim3(256), 0, st,
                            (const uint16_t*)q, (const uint16_t*)k_prefix, (const uint16_t*)v_prefix, (const GroupDesc*)groups, group_rows,
-                           (float*)workspace, H, Hkv, (long long)prefix_stride, prefix_tmax, scale, nchunk, nquad);
+                           (const int4*)items, (float*)workspace, H, Hkv, (long long)prefix_stride, prefix_tmax, scale, nchunk);
     }
     hipLaunchKernelGGL(decode_attn_kernel<128>, dim3((H + 3) / 4, M, nown), dim3(256), 0, st, (const uint16_t*)q,
                        (const uint16_t*)k_cache, (const uint16_t*)v_cache, (const uint16_t*)k_prefix, (const uint16_t*)v_prefix,

@@ -294,7 +294,7 @@ class LanguageModel:
             q = ops.rope_kv_write(qkv, pos, slot, self.cs, kv.ko[i], kv.vo[i], H, Hkv, D, cpos=cpos)
             if grouping is not None:      # rows sharing a prompt prefix attend it once per group (MFMA), own tokens per row
                 att = ops.decode_attention_grouped(q, kv.ko[i], kv.vo[i], kv.kp[i], kv.vp[i], attn_rows, grouping["groups"],
-                                                   grouping["group_rows"], grouping["n_groups"], grouping["max_rows"], H, Hkv, D,
+                                                   grouping["group_rows"], grouping["items"], grouping["n_items"], H, Hkv, D,
                                                    kv.t_pre, kv.t_own, workspace=grouping["workspace"])
             else:
                 att = ops.decode_attention(q, kv.ko[i], kv.vo[i], attn_rows, H, Hkv, D, k_prefix=kv.kp[i], v_prefix=kv.vp[i],
@@ -360,7 +360,7 @@ class _DecodeRunner:
         if tail.get("n_groups", 0) > 0:
             lm = eng.cfg.lm
             self.grouping = dict(groups=torch.zeros(max(1, tail["n_groups"]), 4, **i32), group_rows=torch.zeros(R, **i32),
-                                 n_groups=tail["n_groups"], max_rows=tail["max_group_rows"],
+                                 n_groups=tail["n_groups"], items=torch.zeros(max(1, tail["n_items"]), 4, **i32), n_items=tail["n_items"],
                                  workspace=ops.attention_workspace(R, lm.n_heads, lm.head_dim, eng._kv.t_pre + eng._kv.t_own, dev))
 
     def reset(self, ctr0):
@@ -374,8 +374,10 @@ class _DecodeRunner:
         self.cpos.copy_(torch.tensor(cpos, dtype=torch.int32))
         if self.grouping is not None:
             groups, members = group_rows_by_prefix(rows)
-            assert len(groups) == self.grouping["n_groups"] and max(g[1] for g in groups) <= self.grouping["max_rows"]
+            items = ops.prefix_work_items(groups)
+            assert len(groups) == self.grouping["n_groups"] and len(items) == self.grouping["n_items"]
             self.grouping["groups"].copy_(torch.tensor(groups, dtype=torch.int32))
+            self.grouping["items"].copy_(torch.tensor(items, dtype=torch.int32))
             self.grouping["group_rows"][: len(members)].copy_(torch.tensor(members, dtype=torch.int32))
         self.rows.copy_(torch.tensor(rows, dtype=torch.int32))
         self.gen[:, 0] = self.tok
@@ -442,9 +444,8 @@ class VddLlavaEngine:
         self.vit = VisionTower(self.w)
         self.lm = LanguageModel(self.w)
         self.max_q, self.t_max, self.use_graph = max_questions, t_max, use_graph
-        # attend shared prompt prefixes once per group of rows with MFMA (decode).  Correct (tests) but measured no faster
-        # than the split-KV kernel on MI355X yet (L2/Infinity Cache already de-duplicate the prefix reads): off by default
-        self.group_attention = False
+        # decode attention reads each shared prompt prefix once per GROUP of rows (K/V tiles staged in LDS)
+        self.group_attention = True
         self._kv: Optional[KVCache] = None
         self._feat_cache: Dict[int, torch.Tensor] = {}
         self._graphs: dict = {}
@@ -567,11 +568,11 @@ class VddLlavaEngine:
         sel = [b * Q + q for b in keep for q in range(Q)]
         dec_rows = [[seg[i]["slot"], seg[i]["pos0"] + seg[i]["T"] + 1, seg[i]["pslot"], seg[i]["plen"]] for i in sel]
         grp, _members = group_rows_by_prefix(dec_rows) if self.group_attention else ([], [])
-        n_groups, max_group_rows = len(grp), max([g_[1] for g_ in grp] + [0])
-        cfgkey = cfgkey + (n_groups, max_group_rows)
+        n_groups, n_items = len(grp), len(ops.prefix_work_items(grp))
+        cfgkey = cfgkey + (n_groups, n_items)
         run = self._runner(cfgkey, Q, len(keep), max_new_tokens, dict(alpha=alpha, beta=beta, warp=warp, contrast=contrast,
                            is_vcd=use_cd, both=(use_dd and use_dd_unk), greedy=cd_greedy, eos_t=eos_t, pad=pad_token_id,
-                           output_scores=output_scores, n_groups=n_groups, max_group_rows=max_group_rows))
+                           output_scores=output_scores, n_groups=n_groups, n_items=n_items))
         run.reset(ctr0)
         scores = [] if output_scores else None
         v0 = logits0[:Q]

@@ -19,7 +19,7 @@ _SIGS = {
     "vdd_embed": [_P, _P, _P, _I, _I, _P],
     "vdd_skinny_gemm": [_P, _P, _P, _P, _I, _I, _I, _L, _L, _L, _P],
     "vdd_decode_attention": [_P, _P, _P, _P, _P, _P, _P, _P, _I, _I, _I, _I, _L, _I, _L, _I, _I, _F, _P],
-    "vdd_decode_attention_grouped": [_P, _P, _P, _P, _P, _P, _P, _P, _I, _I, _P, _P, _I, _I, _I, _I, _L, _I, _L, _I, _I, _I, _F, _P],
+    "vdd_decode_attention_grouped": [_P, _P, _P, _P, _P, _P, _P, _P, _P, _I, _P, _P, _I, _I, _I, _I, _L, _I, _L, _I, _I, _I, _F, _P],
     "vdd_flash_attention": [_P, _P, _P, _P, _P, _P, _P, _I, _I, _I, _I, _I, _L, _I, _L, _I, _F, _I, _P],
     "vdd_layernorm": [_P, _P, _P, _P, _I, _I, _F, _P],
     "vdd_bias_act": [_P, _P, _P, _L, _I, _I, _P],
@@ -176,7 +176,17 @@ def attention_workspace(M, H, D, max_len, device):
     return torch.empty((lib.vdd_decode_attention_workspace_bytes(M, H, D, int(max_len)) + 3) // 4, dtype=torch.float32, device=device)
 
 
-def decode_attention_grouped(q, k_cache, v_cache, k_prefix, v_prefix, rows, groups, group_rows, n_groups, max_group_rows,
+def prefix_work_items(groups):
+    """groups [[row_off, n_rows, pslot, plen], ...] -> work list [[group, first_row, chunk, 0], ...] of the prefix pass."""
+    items = []
+    for gi, (_, n_rows, _, plen) in enumerate(groups):
+        for r0 in range(0, n_rows, 16):
+            for c in range((plen + 63) // 64):
+                items.append([gi, r0, c, 0])
+    return items
+
+
+def decode_attention_grouped(q, k_cache, v_cache, k_prefix, v_prefix, rows, groups, group_rows, items, n_items,
                              H, Hkv, D, max_prefix_len, max_own_len, out=None, workspace=None):
     """decode_attention with the shared prefixes attended once per group of rows (MFMA over the group's queries)."""
     _bf16(q, k_cache, v_cache, k_prefix, v_prefix)
@@ -193,7 +203,7 @@ def decode_attention_grouped(q, k_cache, v_cache, k_prefix, v_prefix, rows, grou
         _attn_ws[(q.device,)] = ws
     out = torch.empty_like(q) if out is None else out
     _lib.check(lib.vdd_decode_attention_grouped(q.data_ptr(), k_cache.data_ptr(), v_cache.data_ptr(), k_prefix.data_ptr(), v_prefix.data_ptr(),
-                                                rows.data_ptr(), groups.data_ptr(), group_rows.data_ptr(), n_groups, max_group_rows,
+                                                rows.data_ptr(), groups.data_ptr(), group_rows.data_ptr(), items.data_ptr(), n_items,
                                                 out.data_ptr(), ws.data_ptr(), M, H, Hkv, D, k_cache.stride(0), k_cache.shape[2],
                                                 k_prefix.stride(0), k_prefix.shape[2], int(max_prefix_len), int(max_own_len),
                                                 D ** -0.5, _st(q)))

@@ -184,8 +184,10 @@ def test_grouped_prefix_decode_attention_equals_per_row():
     q = bf(M, H * D, seed=45)
     rt = torch.tensor(rows_p, dtype=torch.int32, device=DEV)
     a = O.decode_attention(q, ko, vo, rt, H, Hkv, D, k_prefix=kp, v_prefix=vp, max_len=768)
+    items = O.prefix_work_items(groups)
     b = O.decode_attention_grouped(q, ko, vo, kp, vp, rt, torch.tensor(groups, dtype=torch.int32, device=DEV),
-                                   torch.tensor(grp_rows_p, dtype=torch.int32, device=DEV), 2, 21, H, Hkv, D, 611, 128)
+                                   torch.tensor(grp_rows_p, dtype=torch.int32, device=DEV),
+                                   torch.tensor(items, dtype=torch.int32, device=DEV), len(items), H, Hkv, D, 611, 128)
     assert torch.allclose(a.float(), b.float(), rtol=2e-2, atol=2e-2)
     rep = H // Hkv
     for m, (slot, ln, ps, pl) in enumerate(rows_p):
