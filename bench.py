@@ -226,6 +226,7 @@ def main():
                 "tokens_per_s_per_gpu": round(Q * N_NEW * a.steps / dt, 1),
                 "decode_only_tokens_per_s_per_gpu": round(Q / (ms_decode * 1e-3), 1),
                 "prefill_plus_first_token_s": round(t_pre, 4),
+                "pope_like_questions_per_s_per_gpu": round(Q / t_pre, 1),   # real POPE answers are 1-2 tokens: prefill-dominated
                 "decode_step": {"ms": round(ms_decode, 3), "rows": 2 * Q, "lm_weight_bytes": wbytes,
                                 "weight_stream_GBs": round(wbytes / (ms_decode * 1e-3) / 1e9, 1),
                                 "note": "per step the LM weights are streamed once for all rows; KV reads come on top"},

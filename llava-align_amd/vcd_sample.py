@@ -22,6 +22,8 @@ Reference-compat behaviours kept on purpose, each covered by a t
 """
 from __future__ import annotations
 
+import copy
+import inspect
 import warnings
 from typing import List, Optional, Union
 
@@ -81,6 +83,47 @@ def _strip_image_slot(ids: torch.Tensor, mask: torch.Tensor):
     the mask is re-indexed with ROW indices, i.e. column 0 repeated."""
     keep_rows = torch.where(ids != IMAGE_TOKEN_INDEX)[0]
     return ids[ids != IMAGE_TOKEN_INDEX].unsqueeze(0), mask[:, keep_rows]
+
+
+def _is_mutable_cache(obj) -> bool:
+    """transformers >= 4.36 caches are objects updated IN PLACE by forward(); the reference era used immutable tuples."""
+    return obj is not None and not isinstance(obj, (tuple, list)) and hasattr(obj, "get_seq_length")
+
+
+def _branch_kwargs(model_kwargs: dict) -> dict:
+    """`model_kwargs.copy()` (vcd_sample.py:149,152,172) plus a private copy of a mutable cache object: with the
+    reference's shallow copy two branches would append to the SAME cache under transformers 5.x."""
+    kw = model_kwargs.copy()
+    for k, v in model_kwargs.items():
+        if _is_mutable_cache(v):
+            kw[k] = copy.deepcopy(v)
+    return kw
+
+
+_PREP_EXTRAS = {}
+
+
+def _accepts(fn, name):
+    params = inspect.signature(fn).parameters
+    return name in params or any(p.kind is inspect.Parameter.VAR_KEYWORD for p in params.values())
+
+
+def _prepare(model, fn, ids, kwargs, step):
+    """Calls a prepare_inputs_for_generation[_cd] of either era.  Implementations of transformers >= 4.5x slice the ids
+    by `next_sequence_length` (the reference-era ones by `past_key_values`); the era is read off the model's main
+    prepare_inputs_for_generation, and the extras are handed to any variant that can take them (explicitly or via **kw)."""
+    key = (type(model), getattr(fn, "__func__", fn))
+    if key not in _PREP_EXTRAS:
+        main = inspect.signature(model.prepare_inputs_for_generation).parameters
+        _PREP_EXTRAS[key] = ("next_sequence_length" in main and _accepts(fn, "next_sequence_length"),
+                             "is_first_iteration" in main and _accepts(fn, "is_first_iteration"))
+    has_nsl, has_first = _PREP_EXTRAS[key]
+    extra = {}
+    if has_nsl:
+        extra["next_sequence_length"] = None if step == 0 else (1 if kwargs.get("use_cache", True) is not False else None)
+    if has_first:
+        extra["is_first_iteration"] = step == 0
+    return fn(ids, **extra, **kwargs)
 
 
 class _Branch:
@@ -175,36 +218,49 @@ def sample(self, input_ids: torch.LongTensor, logits_processor=None, stopping_cr
             if flag.item() == 0.0:
                 break
         ids = ids_buf[:, :cur]
-        out_main = self(**self.prepare_inputs_for_generation(ids, **model_kwargs), **fwd)       # :106-114
+        step = cur - L0
+        if step == 0 and contrast:
+            # pristine per-branch kwargs, taken BEFORE the main forward: a mutable cache object is filled in place by it
+            # (in the reference era model_kwargs still held no cache at this point, :149/:152/:172)
+            fresh = [_branch_kwargs(model_kwargs) for _ in range(2)]
+        out_main = self(**_prepare(self, self.prepare_inputs_for_generation, ids, model_kwargs, step), **fwd)   # :106-114
         if synced_gpus and this_peer_finished:
             continue
         v = out_main.logits[:, -1, :]                                                            # :119
         c = d = None
         out_cd = out_dd = None
         if contrast:
-            if use_cd:
-                unk = _Branch(model_kwargs.copy(), ids)                                          # :149 (quirk #1)
-                cd_inputs = self.prepare_inputs_for_generation_cd(ids, **unk.kwargs)            # :150
+            vcd_shortcut = use_cd and step > 0 and _is_mutable_cache(model_kwargs.get("past_key_values"))
+            if vcd_shortcut:
+                # quirk #1 with a mutable cache object: re-running the cd branch on the main cache (what :149 amounts
+                # to) would append to it twice; its logits equal the main branch's anyway, so take c = v.
+                cd_inputs = None
+            elif use_cd:
+                unk = _Branch(model_kwargs.copy() if step > 0 else fresh[0], ids)                # :149 (quirk #1)
+                cd_inputs = _prepare(self, self.prepare_inputs_for_generation_cd, ids, unk.kwargs, step)      # :150
             else:
                 if unk is None:                                                                  # :152
                     if use_dd_unk:
                         b_ids = ids.clone()
                         b_ids[b_ids == IMAGE_TOKEN_INDEX] = 0                                    # :154-155 <unk>
-                        unk = _Branch(model_kwargs.copy(), b_ids)
+                        unk = _Branch(fresh[0], b_ids)
                     else:
-                        unk = _Branch(model_kwargs.copy(), None)
+                        unk = _Branch(fresh[0], None)
                 elif use_dd_unk:
                     unk.ids = torch.cat([unk.ids, ids[:, -1:]], dim=-1)                          # new token only
                 if not use_dd_unk:                                                               # use_dd alone
                     unk.drop_image_slot(ids, model_kwargs["attention_mask"])                     # :157-160
-                cd_inputs = self.prepare_inputs_for_generation_cd(unk.ids, **unk.kwargs)        # :161
-            out_cd = self(**cd_inputs, **fwd)                                                    # :163-168
-            c = out_cd.logits[:, -1, :]                                                          # :169
+                cd_inputs = _prepare(self, self.prepare_inputs_for_generation_cd, unk.ids, unk.kwargs, step)   # :161
+            if cd_inputs is not None:
+                out_cd = self(**cd_inputs, **fwd)                                                # :163-168
+                c = out_cd.logits[:, -1, :]                                                      # :169
+            else:
+                c = v
             if use_dd and use_dd_unk:                                                            # :171
                 if none is None:
-                    none = _Branch(model_kwargs.copy(), None)                                    # :172
+                    none = _Branch(fresh[1], None)                                               # :172
                 none.drop_image_slot(ids, model_kwargs["attention_mask"])                        # :173-176
-                out_dd = self(**self.prepare_inputs_for_generation_cd(none.ids, **none.kwargs), **fwd)   # :177-183
+                out_dd = self(**_prepare(self, self.prepare_inputs_for_generation_cd, none.ids, none.kwargs, step), **fwd)   # :177-183
                 d = out_dd.logits[:, -1, :]                                                      # :184
 
         if cur >= ids_buf.shape[1]:                                                              # unbounded run: grow
