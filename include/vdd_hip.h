@@ -160,9 +160,16 @@ int64_t vdd_decode_attention_workspace_bytes(int M, int H, int D, int max_len);
  * the split-KV kernel.
  * Workspace: vdd_decode_attention_workspace_bytes(M, H, D, round_up(max_prefix_len, 64) + round_up(max_own_len, 64)). */
 int vdd_decode_attention_grouped(const void* q, const void* k_cache, const void* v_cache, const void* k_prefix, const void* v_prefix,
+                                 const void* v_prefix_t8 /* optional: vdd_prefix_v_transpose image -> MFMA prefix pass */,
                                  const int32_t* rows, const int32_t* groups, const int32_t* group_rows, const int32_t* items, int n_items,
                                  void* out, void* workspace, int M, int H, int Hkv, int D, int64_t slot_stride, int t_max,
                                  int64_t prefix_stride, int prefix_tmax, int max_prefix_len, int max_own_len, float scale, void* hip_stream);
+
+/* Key-blocked transposed copy of the prefix pool's V: v_prefix_t8[slot][kv_head][t/8][d][t%8] for t < prefix_len_of_slot[slot]
+ * (same size and slot stride as v_prefix; t_max % 8 == 0).  Built once after the prefix prefill; lets the grouped decode
+ * pass run both contractions on the matrix cores with every fragment loaded straight from HBM. */
+int vdd_prefix_v_transpose(const void* v_prefix, void* v_prefix_t8, const int32_t* prefix_len_of_slot, int n_slots, int Hkv, int t_max,
+                           int D, void* hip_stream);
 
 /* Prefill attention (MFMA, flash-style).  q/out [Ttot, H*D] packed by sequence; seqs[s] = {q_row0, Tq, pos0,
  * slot, prefix_slot, prefix_len} (int32 x6): query i of sequence s sits at position pos0+i and attends keys

@@ -440,6 +440,131 @@ __global__ void __launch_bounds__(256) decode_attn_prefix_kernel(const uint16_t*
     }
 }
 
+// ------------------------------------------------------------------ prefix pass on the matrix cores
+// V of a shared prefix is static during decoding, so a second copy is kept key-blocked and transposed
+// (VT8: [slot][kv_head][t/8][d][t%8], built once per generate by vt8_transpose_kernel).  With it every operand of
+// both contractions is k-contiguous in HBM and the prefix pass needs no LDS and no barrier:
+//   S^T = K Q^T   A = K fragment (lane (i, g): 16 B of K[key(i)][32 ks + 8 g ..]), B = Q fragment (lane (query, g))
+//                 C layout: column = query, row i = 4 g + r.  The key assigned to MFMA row i is chosen as
+//                 key_a(i) = k0 + 8 (i/4) + i%4 for tile a and key_b(i) = key_a(i) + 4 for tile b, so that the 8
+//                 probabilities a lane holds after the softmax are the 8 CONSECUTIVE keys k0 + 8 g .. + 7:
+//   O = P V       A = P fragment = those 8 registers as they are (no re-layout), B = VT8 fragment (lane (dim, g):
+//                 16 B = V[k0 + 8 g .. + 7][dim]).
+// One wave = one (16-row slice of a group, head, 64-key chunk): 16 + 16 MFMAs, one-shot softmax over the chunk,
+// un-normalised partial to the workspace (merged by decode_attn_combine_kernel).
+__global__ void __launch_bounds__(256) vt8_transpose_kernel(const uint16_t* __restrict__ v, uint16_t* __restrict__ vt8, int t_max,
+                                                            int D, const int* __restrict__ plen_of_slot) {
+    // grid: (t_max / 8, n_kv_heads, n_slots); block 256: one 8-key x D tile
+    const int tb = blockIdx.x, head = blockIdx.y, slot = blockIdx.z;
+    if (tb * 8 >= plen_of_slot[slot]) return;
+    const size_t base = ((size_t)slot * gridDim.y + head) * (size_t)t_max * D;
+    __shared__ uint16_t tile[8][128 + 2];
+    const int plen = plen_of_slot[slot];
+    for (int e = threadIdx.x; e < 8 * D; e += 256)      // rows past the prefix are zeroed: they meet p = 0 in the MFMA and must be finite
+        tile[e / D][e % D] = (tb * 8 + e / D < plen) ? v[base + (size_t)(tb * 8) * D + e] : (uint16_t)0;
+    __syncthreads();
+    for (int e = threadIdx.x; e < 8 * D; e += 256) vt8[base + (size_t)(tb * 8) * D + e] = tile[e % 8][e / 8];
+}
+
+template <int D>
+__global__ void __launch_bounds__(256) decode_attn_prefix_mfma_kernel(const uint16_t* __restrict__ q, const uint16_t* __restrict__ kpre,
+                                                                      const uint16_t* __restrict__ vt8, const GroupDesc* __restrict__ groups,
+                                                                      const int* __restrict__ group_rows, const int4* __restrict__ items,
+                                                                      float* __restrict__ ws, int H, int Hkv, long long pre_stride,
+                                                                      int pre_tmax, float scale, int nchunk) {
+    static_assert(D == 128, "");
+    constexpr int KS = D / 32, NT = D / 16;
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, ln = lane & 15, g = lane >> 4;
+    const int head = blockIdx.y * 4 + wave;
+    if (head >= H) return;
+    const int4 item = items[blockIdx.x];
+    const GroupDesc gd = groups[item.x];
+    const int r0 = item.y, chunk = item.z, k0 = chunk * ATT_CH;
+    if (r0 >= gd.n_rows || k0 >= gd.plen) return;
+    const int k1 = min(gd.plen, k0 + ATT_CH);
+    const int kvh = head / (H / Hkv);
+    // B operand of S^T: this lane's query row
+    int rq = r0 + ln; if (rq >= gd.n_rows) rq = gd.n_rows - 1;
+    const int qrow = group_rows[gd.row_off + rq];
+    bf16x8_t qf[KS];
+    {
+        const uint16_t* qp = q + ((size_t)qrow * H + head) * D + g * 8;
+#pragma unroll
+        for (int ks = 0; ks < KS; ++ks) qf[ks] = *reinterpret_cast<const bf16x8_t*>(qp + ks * 32);
+    }
+    const size_t hbase = (size_t)gd.pslot * pre_stride + (size_t)kvh * pre_tmax * D;
+    const uint16_t* kb = kpre + hbase;
+    const uint16_t* vb = vt8 + hbase;
+    // S^T: 4 tiles (a0, b0 | a1, b1); MFMA row i = ln of the A operand
+    f32x4_t s[4];
+#pragma unroll
+    for (int t = 0; t < 4; ++t) {
+        s[t] = f32x4_t{0.f, 0.f, 0.f, 0.f};
+        int key = k0 + (t >> 1) * 32 + (ln >> 2) * 8 + (t & 1) * 4 + (ln & 3);
+        if (key >= k1) key = k1 - 1;
+        const uint16_t* kp = kb + (size_t)key * D + g * 8;
+#pragma unroll
+        for (int ks = 0; ks < KS; ++ks) {
+            const bf16x8_t kf = *reinterpret_cast<const bf16x8_t*>(kp + ks * 32);
+            s[t] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(kf, qf[ks], s[t], 0, 0, 0);
+        }
+    }
+    // column = query ln; this lane's rows 4 g + r are keys k0 + 32 (t>>1) + 8 g + 4 (t&1) + r
+    float mx = -INFINITY;
+#pragma unroll
+    for (int t = 0; t < 4; ++t)
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+            const int key = k0 + (t >> 1) * 32 + g * 8 + (t & 1) * 4 + r;
+            const float v = key < k1 ? s[t][r] * scale : -INFINITY;
+            s[t][r] = v; mx = fmaxf(mx, v);
+        }
+    mx = fmaxf(mx, __shfl_xor(mx, 16)); mx = fmaxf(mx, __shfl_xor(mx, 32));
+    float lsum = 0.f;
+    bf16x8_t pf[2];
+#pragma unroll
+    for (int kk = 0; kk < 2; ++kk)
+#pragma unroll
+        for (int e = 0; e < 8; ++e) {
+            const float pv = __expf(s[kk * 2 + (e >> 2)][e & 3] - mx);      // exp(-inf) = 0 for masked keys
+            lsum += pv;
+            pf[kk][e] = (short)f2bf(pv);
+        }
+    lsum += __shfl_xor(lsum, 16); lsum += __shfl_xor(lsum, 32);
+    // O = P V: B fragment lane (dim = 16 nt + ln, g) = V[k0 + 32 kk + 8 g .. + 7][dim] = 16 B of the VT8 image
+    f32x4_t o[NT];
+#pragma unroll
+    for (int nt = 0; nt < NT; ++nt) o[nt] = f32x4_t{0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+    for (int kk = 0; kk < 2; ++kk) {
+        int kblk = (k0 + kk * 32) / 8 + g;
+        if (kblk * 8 >= k1) kblk = (k1 - 1) / 8;      // fully masked 8-key block: any finite data will do (p = 0)
+        if (k0 + kk * 32 < k1) {
+            const uint16_t* vp = vb + ((size_t)kblk * D) * 8 + (size_t)ln * 8;
+#pragma unroll
+            for (int nt = 0; nt < NT; ++nt) {
+                const bf16x8_t vf = *reinterpret_cast<const bf16x8_t*>(vp + (size_t)nt * 16 * 8);
+                o[nt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(pf[kk], vf, o[nt], 0, 0, 0);
+            }
+        }
+    }
+    // O's C layout: column = dim 16 nt + ln, row = query 4 g + r
+#pragma unroll
+    for (int r = 0; r < 4; ++r) {
+        const int rr = r0 + g * 4 + r;
+        if (rr < gd.n_rows) {
+            const int orow = group_rows[gd.row_off + rr];
+            float* wsp = ws + (((size_t)orow * H + head) * nchunk + chunk) * (D + 2);
+#pragma unroll
+            for (int nt = 0; nt < NT; ++nt) wsp[nt * 16 + ln] = o[nt][r];
+        }
+    }
+    if (g == 0 && r0 + ln < gd.n_rows) {          // (m, l) of query ln live in the lanes of column ln
+        float* wsp = ws + (((size_t)qrow * H + head) * nchunk + chunk) * (D + 2);
+        wsp[D] = mx; wsp[D + 1] = lsum;
+    }
+}
+
 inline int ok(hipError_t) { return hipGetLastError() == hipSuccess ? VDD_OK : VDD_ERR_LAUNCH; }
 
 }  // namespace
@@ -515,16 +640,21 @@ int vdd_decode_attention(const void* q, const void* k_cache, const void* v_cache
 }
 
 int vdd_decode_attention_grouped(const void* q, const void* k_cache, const void* v_cache, const void* k_prefix, const void* v_prefix,
-                                 const int32_t* rows, const int32_t* groups, const int32_t* group_rows, const int32_t* items, int n_items,
-                                 void* out, void* workspace, int M, int H, int Hkv, int D, int64_t slot_stride, int t_max,
-                                 int64_t prefix_stride, int prefix_tmax, int max_prefix_len, int max_own_len, float scale, void* stream) {
+                                 const void* v_prefix_t8, const int32_t* rows, const int32_t* groups, const int32_t* group_rows,
+                                 const int32_t* items, int n_items, void* out, void* workspace, int M, int H, int Hkv, int D,
+                                 int64_t slot_stride, int t_max, int64_t prefix_stride, int prefix_tmax, int max_prefix_len,
+                                 int max_own_len, float scale, void* stream) {
     if (M <= 0) return VDD_OK;
     if (!q || !k_cache || !v_cache || !k_prefix || !v_prefix || !rows || !groups || !group_rows || !items || !out || !workspace || D != 128 ||
         H % Hkv != 0 || max_own_len <= 0 || max_prefix_len < 0 || n_items < 0) return VDD_ERR_INVALID_ARG;
     const int npre = (max_prefix_len + ATT_CH - 1) / ATT_CH, nown = (max_own_len + ATT_CH - 1) / ATT_CH;
     const int nchunk = npre + nown;
     hipStream_t st = (hipStream_t)stream;
-    if (n_items > 0 && npre > 0) {
+    if (n_items > 0 && npre > 0 && v_prefix_t8 != nullptr) {
+        hipLaunchKernelGGL(decode_attn_prefix_mfma_kernel<128>, dim3(n_items, (H + 3) / 4), dim3(256), 0, st,
+                           (const uint16_t*)q, (const uint16_t*)k_prefix, (const uint16_t*)v_prefix_t8, (const GroupDesc*)groups, group_rows,
+                           (const int4*)items, (float*)workspace, H, Hkv, (long long)prefix_stride, prefix_tmax, scale, nchunk);
+    } else if (n_items > 0 && npre > 0) {
         hipLaunchKernelGGL(decode_attn_prefix_kernel<128>, dim3(n_items, H), dim3(256), 0, st,
                            (const uint16_t*)q, (const uint16_t*)k_prefix, (const uint16_t*)v_prefix, (const GroupDesc*)groups, group_rows,
                            (const int4*)items, (float*)workspace, H, Hkv, (long long)prefix_stride, prefix_tmax, scale, nchunk);
@@ -535,6 +665,15 @@ int vdd_decode_attention_grouped(const void* q, const void* k_cache, const void*
                        prefix_tmax, scale, nchunk, 1, npre);
     hipLaunchKernelGGL(decode_attn_combine_kernel<128>, dim3((H + 3) / 4, M), dim3(256), 0, st, (const float*)workspace,
                        (const AttnRow*)rows, (uint16_t*)out, H, nchunk, npre);
+    return ok(hipSuccess);
+}
+
+int vdd_prefix_v_transpose(const void* v_prefix, void* v_prefix_t8, const int32_t* prefix_len_of_slot, int n_slots, int Hkv, int t_max,
+                           int D, void* stream) {
+    if (n_slots <= 0) return VDD_OK;
+    if (!v_prefix || !v_prefix_t8 || !prefix_len_of_slot || D != 128 || t_max % 8 != 0) return VDD_ERR_INVALID_ARG;
+    hipLaunchKernelGGL(vt8_transpose_kernel, dim3(t_max / 8, Hkv, n_slots), dim3(256), 0, (hipStream_t)stream, (const uint16_t*)v_prefix,
+                       (uint16_t*)v_prefix_t8, t_max, D, prefix_len_of_slot);
     return ok(hipSuccess);
 }
 

@@ -224,12 +224,14 @@ class KVCache:
                            for _ in range(lm.n_layers)]
         self.kp, self.vp = mk(n_pre, t_pre), mk(n_pre, t_pre)
         self.ko, self.vo = mk(n_own, t_own), mk(n_own, t_own)
+        # key-blocked transposed copy of the prefix V ([slot][head][t/8][d][t%8]) for the MFMA prefix pass of decode
+        self.vp8 = mk(n_pre, t_pre)
 
     def fits(self, n_pre, t_pre, n_own, t_own):
         return n_pre <= self.n_pre and t_pre <= self.t_pre and n_own <= self.n_own and t_own <= self.t_own
 
     def nbytes(self):
-        return sum(t.numel() * 2 for pool in (self.kp, self.vp, self.ko, self.vo) for t in pool)
+        return sum(t.numel() * 2 for pool in (self.kp, self.vp, self.vp8, self.ko, self.vo) for t in pool)
 
 
 class LanguageModel:
@@ -295,7 +297,8 @@ class LanguageModel:
             if grouping is not None:      # rows sharing a prompt prefix attend it once per group (MFMA), own tokens per row
                 att = ops.decode_attention_grouped(q, kv.ko[i], kv.vo[i], kv.kp[i], kv.vp[i], attn_rows, grouping["groups"],
                                                    grouping["group_rows"], grouping["items"], grouping["n_items"], H, Hkv, D,
-                                                   kv.t_pre, kv.t_own, workspace=grouping["workspace"])
+                                                   kv.t_pre, kv.t_own, workspace=grouping["workspace"],
+                                                   v_prefix_t8=kv.vp8[i] if grouping.get("mfma", True) else None)
             else:
                 att = ops.decode_attention(q, kv.ko[i], kv.vo[i], attn_rows, H, Hkv, D, k_prefix=kv.kp[i], v_prefix=kv.vp[i],
                                            max_len=kv.t_pre + kv.t_own)
@@ -551,6 +554,10 @@ class VddLlavaEngine:
                 continue
             x, pos, cpos, slot, seqs, max_tq = self._pack(segs)
             resid, delta = self.lm.prefill(x, pos, cpos, slot, seqs, len(segs), max_tq, kv, to_prefix_pool=(phase == "prefix"))
+            if phase == "prefix" and self.group_attention:
+                plen_t = torch.tensor([s_["T"] for s_ in segs], dtype=torch.int32, device=dev)
+                for li in range(lm.n_layers):
+                    ops.prefix_v_transpose(kv.vp[li], kv.vp8[li], plen_t)
             if phase == "suffix":
                 last = torch.tensor([s["q_row0"] + s["T"] - 1 for s in segs], device=dev)
                 logits0 = self.lm.logits(resid, delta, last)                                  # [nb*Q, V], rows ordered branch-major

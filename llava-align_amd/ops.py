@@ -19,7 +19,8 @@ _SIGS = {
     "vdd_embed": [_P, _P, _P, _I, _I, _P],
     "vdd_skinny_gemm": [_P, _P, _P, _P, _I, _I, _I, _L, _L, _L, _P],
     "vdd_decode_attention": [_P, _P, _P, _P, _P, _P, _P, _P, _I, _I, _I, _I, _L, _I, _L, _I, _I, _F, _P],
-    "vdd_decode_attention_grouped": [_P, _P, _P, _P, _P, _P, _P, _P, _P, _I, _P, _P, _I, _I, _I, _I, _L, _I, _L, _I, _I, _I, _F, _P],
+    "vdd_prefix_v_transpose": [_P, _P, _P, _I, _I, _I, _I, _P],
+    "vdd_decode_attention_grouped": [_P, _P, _P, _P, _P, _P, _P, _P, _P, _P, _I, _P, _P, _I, _I, _I, _I, _L, _I, _L, _I, _I, _I, _F, _P],
     "vdd_flash_attention": [_P, _P, _P, _P, _P, _P, _P, _I, _I, _I, _I, _I, _L, _I, _L, _I, _F, _I, _P],
     "vdd_layernorm": [_P, _P, _P, _P, _I, _I, _F, _P],
     "vdd_bias_act": [_P, _P, _P, _L, _I, _I, _P],
@@ -186,8 +187,17 @@ def prefix_work_items(groups):
     return items
 
 
+def prefix_v_transpose(v_prefix, v_prefix_t8, prefix_len_of_slot):
+    """v_prefix [n_slots, Hkv, t_max, D] -> v_prefix_t8 (same shape/bytes, layout [slot][head][t/8][d][t%8])."""
+    _bf16(v_prefix, v_prefix_t8)
+    n, Hkv, t_max, D = v_prefix.shape
+    _lib.check(_lib_ready().vdd_prefix_v_transpose(v_prefix.data_ptr(), v_prefix_t8.data_ptr(), prefix_len_of_slot.data_ptr(),
+                                                   prefix_len_of_slot.numel(), Hkv, t_max, D, _st(v_prefix)))
+    return v_prefix_t8
+
+
 def decode_attention_grouped(q, k_cache, v_cache, k_prefix, v_prefix, rows, groups, group_rows, items, n_items,
-                             H, Hkv, D, max_prefix_len, max_own_len, out=None, workspace=None):
+                             H, Hkv, D, max_prefix_len, max_own_len, out=None, workspace=None, v_prefix_t8=None):
     """decode_attention with the shared prefixes attended once per group of rows (MFMA over the group's queries)."""
     _bf16(q, k_cache, v_cache, k_prefix, v_prefix)
     M = q.shape[0]
@@ -203,7 +213,7 @@ def decode_attention_grouped(q, k_cache, v_cache, k_prefix, v_prefix, rows, grou
         _attn_ws[(q.device,)] = ws
     out = torch.empty_like(q) if out is None else out
     _lib.check(lib.vdd_decode_attention_grouped(q.data_ptr(), k_cache.data_ptr(), v_cache.data_ptr(), k_prefix.data_ptr(), v_prefix.data_ptr(),
-                                                rows.data_ptr(), groups.data_ptr(), group_rows.data_ptr(), items.data_ptr(), n_items,
+                                                v_prefix_t8.data_ptr() if v_prefix_t8 is not None else None, rows.data_ptr(), groups.data_ptr(), group_rows.data_ptr(), items.data_ptr(), n_items,
                                                 out.data_ptr(), ws.data_ptr(), M, H, Hkv, D, k_cache.stride(0), k_cache.shape[2],
                                                 k_prefix.stride(0), k_prefix.shape[2], int(max_prefix_len), int(max_own_len),
                                                 D ** -0.5, _st(q)))

@@ -189,6 +189,17 @@ def test_grouped_prefix_decode_attention_equals_per_row():
                                    torch.tensor(grp_rows_p, dtype=torch.int32, device=DEV),
                                    torch.tensor(items, dtype=torch.int32, device=DEV), len(items), H, Hkv, D, 611, 128)
     assert torch.allclose(a.float(), b.float(), rtol=2e-2, atol=2e-2)
+    # MFMA prefix pass on the key-blocked transposed copy of the prefix V
+    vp8 = torch.full_like(vp, float("nan"))
+    plen_of_slot = torch.tensor([611, 0, 36], dtype=torch.int32, device=DEV)
+    O.prefix_v_transpose(vp, vp8, plen_of_slot)
+    t8 = vp8[0].view(Hkv, 640 // 8, D, 8)
+    assert torch.equal(t8[:, :76].permute(0, 1, 3, 2).reshape(Hkv, 608, D), vp[0, :, :608])       # VT8[t/8][d][t%8] == V[t][d]
+    c = O.decode_attention_grouped(q, ko, vo, kp, vp, rt, torch.tensor(groups, dtype=torch.int32, device=DEV),
+                                   torch.tensor(grp_rows_p, dtype=torch.int32, device=DEV),
+                                   torch.tensor(items, dtype=torch.int32, device=DEV), len(items), H, Hkv, D, 611, 128, v_prefix_t8=vp8)
+    assert torch.allclose(a.float(), c.float(), rtol=3e-2, atol=3e-2)
+    b = c
     rep = H // Hkv
     for m, (slot, ln, ps, pl) in enumerate(rows_p):
         K = torch.cat([kp[ps, :, :pl], ko[slot, :, :ln - pl]], 1).float().repeat_interleave(rep, 0)
