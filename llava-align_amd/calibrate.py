@@ -151,3 +151,44 @@ class AnswerWriter:
 
     def __exit__(self, *a):
         self.close()
+
+
+# ------------------------------------------------------------------ MME scoring (experiments/eval/MME/eval_tool/calculation.py)
+MME_TASKS = {"Perception": ["existence", "count", "position", "color"],
+             "Cognition": ["commonsense_reasoning", "numerical_calculation", "text_translation", "code_reasoning"]}
+
+
+def mme_parse_pred(pred: str) -> str:
+    """calculation.py:22-36 — exact 'yes'/'no', else look for them in the first 4 characters, else 'other'."""
+    if pred in ("yes", "no"):
+        return pred
+    head = pred[:4]
+    return "yes" if "yes" in head else ("no" if "no" in head else "other")
+
+
+def mme_task_score(lines: Sequence[str]) -> dict:
+    """One task file: lines 'image<TAB>question<TAB>gt<TAB>prediction', two consecutive questions per image.
+    score = 100 * accuracy + 100 * accuracy+ (both questions of an image right), calculation.py:95-140."""
+    assert len(lines) % 2 == 0
+    hits, plus, other = 0, 0, 0
+    for i in range(0, len(lines), 2):
+        ok = 0
+        for item in lines[i:i + 2]:
+            _img, _q, gt, pred = item.split("\t")
+            gt, pred = gt.lower(), mme_parse_pred(pred.lower())
+            assert gt in ("yes", "no")
+            ok += int(gt == pred)
+            other += int(pred == "other")
+        hits += ok
+        plus += int(ok == 2)
+    acc, acc_plus = hits / len(lines), plus / (len(lines) // 2)
+    return {"acc": acc, "acc_plus": acc_plus, "other_num": other, "score": acc * 100 + acc_plus * 100}
+
+
+def mme_scores(results_dir: str) -> dict:
+    import os
+    out = {}
+    for group, tasks in MME_TASKS.items():
+        per = {t: mme_task_score(open(os.path.join(results_dir, t + ".txt")).readlines()) for t in tasks}
+        out[group] = {"total": sum(v["score"] for v in per.values()), "tasks": {t: v["score"] for t, v in per.items()}}
+    return out

@@ -64,3 +64,18 @@ def test_answer_writer_schema(tmp_path):
         w.write(7, "Is there a dog?", "Yes", "llava-1.5-7b", "x.jpg", [0.9, 0.1], {"yes": 0.9}, {"yes": 0.5}, {"no": 0.6})
         line = json.loads(open(p).read().splitlines()[0])      # flushed before close
     assert tuple(line.keys()) == C.AnswerWriter.FIELDS and line["question_id"] == 7 and line["metadata"] == {}
+
+
+def test_mme_scorer_matches_reference_on_its_own_answer_set(golden_dir):
+    """The one answer set the reference ships (experiments/eval_tool/answers/llava-v1.5-7b, copied as DATA) scored by the
+    reference's own experiments/eval/MME/eval_tool/calculation.py gives Perception 648.33 / Cognition 363.21."""
+    s = C.mme_scores(os.path.join(golden_dir, "mme_answers_llava15_7b"))
+    assert s["Perception"]["total"] == pytest.approx(648.3333333333333, abs=1e-9)
+    assert s["Cognition"]["total"] == pytest.approx(363.2142857142857, abs=1e-9)
+    want = {"existence": 190.0, "count": 155.0, "position": 133.33333333333334, "color": 170.0, "commonsense_reasoning": 110.71428571428571,
+            "numerical_calculation": 70.0, "text_translation": 107.5, "code_reasoning": 75.0}
+    got = {**s["Perception"]["tasks"], **s["Cognition"]["tasks"]}
+    for k, v in want.items():
+        assert got[k] == pytest.approx(v, abs=1e-9), k
+    assert C.mme_parse_pred("yes") == "yes" and C.mme_parse_pred("no, it") == "no" and C.mme_parse_pred("maybe") == "other"
+    assert C.mme_parse_pred("the yes") == "other"          # only the first 4 characters are searched
