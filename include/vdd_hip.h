@@ -131,9 +131,11 @@ int vdd_silu_mul(const void* gate_up, void* out, int64_t M, int F, void* hip_str
 
 int vdd_embed(const int64_t* ids, const void* table, void* out, int M, int d, void* hip_stream);
 
-/* Y[M,N] = X[M,K] W[N,K]^T (+ R[M,N]); M <= 64, K % 128 == 0; W is read from HBM exactly once. */
-int vdd_skinny_gemm(const void* X, const void* W, const void* R, void* Y, int M, int N, int K, int64_t ldx, int64_t ldr,
-                    int64_t ldy, void* hip_stream);
+/* Y[M,N] = X[M,K] W[N,K]^T (+ R[M,N]); M <= 64, K % (128 * n_split) == 0; W is read from HBM exactly once.
+ * n_split > 1 (with Y_slabs fp32 [n_split][M][N], Y may be NULL): split-K across blocks too, for projections whose N alone
+ * gives too few blocks (N = 4096: 256); the slabs are summed by vdd_rmsnorm's delta_slabs input. */
+int vdd_skinny_gemm(const void* X, const void* W, const void* R, void* Y, float* Y_slabs, int n_split, int M, int N, int K,
+                    int64_t ldx, int64_t ldr, int64_t ldy, void* hip_stream);
 
 /* Decode-regime GEMM, 9 <= M <= 256 rows: Y[M,N] = X[M,K] W[N,K]^T with W streamed from HBM exactly once and the X
  * tile shared through LDS (csrc/vdd_mid_gemm.hip).  Either Y (bf16, n_split == 1) or Y_slabs (fp32 [n_split][M][N]:

@@ -200,13 +200,16 @@ __global__ void __launch_bounds__(256) embed_kernel(const long long* __restrict_
 template <int MT>
 __global__ void __launch_bounds__(256) skinny_gemm_kernel(const uint16_t* __restrict__ X, const uint16_t* __restrict__ W,
                                                           const uint16_t* __restrict__ R, uint16_t* __restrict__ Y,
-                                                          int M, int N, int K, long long ldx, long long ldr, long long ldy) {
+                                                          float* __restrict__ Yslab, int M, int N, int K, long long ldx,
+                                                          long long ldr, long long ldy) {
     __shared__ float part[4][MT][64][4];
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int n0 = blockIdx.x * 16;
     const int ln = lane & 15, g = lane >> 4;
-    const int kq = K / 4;
-    const int kbeg = wave * kq;
+    // gridDim.y > 1: split-K across blocks as well (N = 4096 projections: 256 column blocks alone leave one block per CU);
+    // slice s writes the fp32 slab Yslab[s][M][N], summed by the RMSNorm that consumes it
+    const int kq = K / (4 * (int)gridDim.y);
+    const int kbeg = ((int)blockIdx.y * 4 + wave) * kq;
     int nrow = n0 + ln; if (nrow >= N) nrow = N - 1;
     const uint16_t* wp = W + (size_t)nrow * K + kbeg + g * 8;
     const uint16_t* xp[MT];
@@ -250,6 +253,7 @@ __global__ void __launch_bounds__(256) skinny_gemm_kernel(const uint16_t* __rest
             const int row = t * 16 + g * 4 + r, col = n0 + ln;
             float s = (part[0][t][lane][r] + part[1][t][lane][r]) + (part[2][t][lane][r] + part[3][t][lane][r]);
             if (row < M && col < N) {
+                if (Yslab != nullptr) { Yslab[((size_t)blockIdx.y * M + row) * N + col] = s; continue; }
                 float o = bf2f(f2bf(s));
                 if (R != nullptr) o = o + bf2f(R[(size_t)row * ldr + col]);
                 Y[(size_t)row * ldy + col] = (uint16_t)f2bf(o);
@@ -610,16 +614,17 @@ int vdd_embed(const int64_t* ids, const void* table, void* out, int M, int d, vo
     return ok(hipSuccess);
 }
 
-int vdd_skinny_gemm(const void* X, const void* W, const void* R, void* Y, int M, int N, int K, int64_t ldx, int64_t ldr,
-                    int64_t ldy, void* stream) {
+int vdd_skinny_gemm(const void* X, const void* W, const void* R, void* Y, float* Y_slabs, int n_split, int M, int N, int K,
+                    int64_t ldx, int64_t ldr, int64_t ldy, void* stream) {
     if (M <= 0 || N <= 0) return VDD_OK;
-    if (!X || !W || !Y || K % 128 != 0 || M > 64 || (ldx % 8) != 0) return VDD_ERR_INVALID_ARG;
+    if (!X || !W || (!Y && !Y_slabs) || n_split < 1 || K % (128 * n_split) != 0 || M > 64 || (ldx % 8) != 0) return VDD_ERR_INVALID_ARG;
+    if (!Y_slabs && n_split != 1) return VDD_ERR_INVALID_ARG;
     hipStream_t st = (hipStream_t)stream;
-    dim3 grid((N + 15) / 16), block(256);
+    dim3 grid((N + 15) / 16, n_split), block(256);
     auto x = (const uint16_t*)X; auto w = (const uint16_t*)W; auto r = (const uint16_t*)R; auto y = (uint16_t*)Y;
-    if (M <= 16) hipLaunchKernelGGL(skinny_gemm_kernel<1>, grid, block, 0, st, x, w, r, y, M, N, K, (long long)ldx, (long long)ldr, (long long)ldy);
-    else if (M <= 32) hipLaunchKernelGGL(skinny_gemm_kernel<2>, grid, block, 0, st, x, w, r, y, M, N, K, (long long)ldx, (long long)ldr, (long long)ldy);
-    else hipLaunchKernelGGL(skinny_gemm_kernel<4>, grid, block, 0, st, x, w, r, y, M, N, K, (long long)ldx, (long long)ldr, (long long)ldy);
+    if (M <= 16) hipLaunchKernelGGL(skinny_gemm_kernel<1>, grid, block, 0, st, x, w, r, y, Y_slabs, M, N, K, (long long)ldx, (long long)ldr, (long long)ldy);
+    else if (M <= 32) hipLaunchKernelGGL(skinny_gemm_kernel<2>, grid, block, 0, st, x, w, r, y, Y_slabs, M, N, K, (long long)ldx, (long long)ldr, (long long)ldy);
+    else hipLaunchKernelGGL(skinny_gemm_kernel<4>, grid, block, 0, st, x, w, r, y, Y_slabs, M, N, K, (long long)ldx, (long long)ldr, (long long)ldy);
     return ok(hipSuccess);
 }
 

@@ -302,10 +302,10 @@ class LanguageModel:
             else:
                 att = ops.decode_attention(q, kv.ko[i], kv.vo[i], attn_rows, H, Hkv, D, k_prefix=kv.kp[i], v_prefix=kv.vp[i],
                                            max_len=kv.t_pre + kv.t_own)
-            o = ops.linear(att, t[p + "wo"])
+            o = ops.linear_to_norm(att, t[p + "wo"])
             a = ops.rmsnorm(resid, t[p + "ln2"], c.eps, delta=o, resid_out=resid)
             gu = ops.linear(a, t[p + "wgu"])
-            delta = ops.linear(ops.silu_mul(gu), t[p + "wd"])
+            delta = ops.linear_to_norm(ops.silu_mul(gu), t[p + "wd"])
         a = ops.rmsnorm(resid, t["norm"], c.eps, delta=delta)
         return ops.linear(a, t["lm_head"])
 
@@ -575,6 +575,8 @@ class VddLlavaEngine:
         sel = [b * Q + q for b in keep for q in range(Q)]
         dec_rows = [[seg[i]["slot"], seg[i]["pos0"] + seg[i]["T"] + 1, seg[i]["pslot"], seg[i]["plen"]] for i in sel]
         grp, _members = group_rows_by_prefix(dec_rows) if self.group_attention else ([], [])
+        if grp and len(_members) < 2 * len(grp):      # (almost) nothing shared: the per-row split-KV kernel alone is cheaper
+            grp = []
         n_groups, n_items = len(grp), len(ops.prefix_work_items(grp))
         cfgkey = cfgkey + (n_groups, n_items)
         run = self._runner(cfgkey, Q, len(keep), max_new_tokens, dict(alpha=alpha, beta=beta, warp=warp, contrast=contrast,

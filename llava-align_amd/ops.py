@@ -17,7 +17,7 @@ _SIGS = {
     "vdd_rope_kv_write": [_P, _P, _P, _P, _P, _P, _P, _P, _I, _I, _I, _I, _L, _I, _P],
     "vdd_silu_mul": [_P, _P, _L, _I, _P],
     "vdd_embed": [_P, _P, _P, _I, _I, _P],
-    "vdd_skinny_gemm": [_P, _P, _P, _P, _I, _I, _I, _L, _L, _L, _P],
+    "vdd_skinny_gemm": [_P, _P, _P, _P, _P, _I, _I, _I, _I, _L, _L, _L, _P],
     "vdd_decode_attention": [_P, _P, _P, _P, _P, _P, _P, _P, _I, _I, _I, _I, _L, _I, _L, _I, _I, _F, _P],
     "vdd_prefix_v_transpose": [_P, _P, _P, _I, _I, _I, _I, _P],
     "vdd_decode_attention_grouped": [_P, _P, _P, _P, _P, _P, _P, _P, _P, _P, _I, _P, _P, _I, _I, _I, _I, _L, _I, _L, _I, _I, _I, _F, _P],
@@ -115,16 +115,32 @@ def embed(ids, table, out=None):
     return out
 
 
-def skinny_gemm(x, w, resid=None, out=None):
-    """x [M<=64, K] @ w[N, K]^T (+ resid [M, N]) -> [M, N]; streams w from HBM exactly once."""
+def skinny_gemm(x, w, resid=None, out=None, n_split=1, slabs=False):
+    """x [M<=64, K] @ w[N, K]^T (+ resid [M, N]) -> [M, N]; streams w from HBM exactly once.
+    slabs=True: returns the fp32 split-K partials [n_split, M, N] instead (feed them to rmsnorm as `delta`)."""
     _bf16(x, w, resid)
     M, K = x.shape
     N = w.shape[0]
+    if slabs:
+        out = torch.empty(n_split, M, N, dtype=torch.float32, device=x.device) if out is None else out
+        _lib.check(_lib_ready().vdd_skinny_gemm(x.data_ptr(), w.data_ptr(), None, None, out.data_ptr(), n_split, M, N, K, x.stride(0), 0, N, _st(x)))
+        return out
     out = torch.empty(M, N, dtype=x.dtype, device=x.device) if out is None else out
     _lib.check(_lib_ready().vdd_skinny_gemm(x.data_ptr(), w.data_ptr(), resid.data_ptr() if resid is not None else None,
-                                            out.data_ptr(), M, N, K, x.stride(0), resid.stride(0) if resid is not None else 0,
+                                            out.data_ptr(), None, 1, M, N, K, x.stride(0), resid.stride(0) if resid is not None else 0,
                                             out.stride(0), _st(x)))
     return out
+
+
+def linear_to_norm(x, w):
+    """Projection whose only consumer is the next RMSNorm's residual add (attention output / MLP down projection):
+    in the skinny regime it is split-K'd into fp32 slabs (N = d gives only d/16 column blocks) that the norm sums."""
+    M, K = x.shape
+    if M <= SKINNY_MAX_M and K % 128 == 0 and w.shape[0] <= 8192:
+        for ns in (4, 2):
+            if K % (128 * ns) == 0:
+                return skinny_gemm(x, w, n_split=ns, slabs=True)
+    return linear(x, w)
 
 
 SKINNY_MAX_M = 8      # measured on MI355X (tools/e2e_probe.py): 5.1-5.4 TB/s for M<=4 vs 4.0-5.0 for the library; slower past ~8 rows

@@ -89,6 +89,10 @@ def test_skinny_gemm(M, N, K):
     y2 = O.skinny_gemm(x, w, resid=r)
     ref2 = ref.to(torch.bfloat16).float() + r.float()
     assert (y2.float() - ref2).abs().max().item() <= 2e-2 * ref2.abs().max().item()
+    for ns in (2, 4):                                       # split-K slabs (consumed by rmsnorm)
+        if K % (128 * ns) == 0:
+            sl = O.skinny_gemm(x, w, n_split=ns, slabs=True)
+            assert sl.shape == (ns, M, N) and (sl.sum(0) - ref).abs().max().item() <= 1e-3 * ref.abs().max().item() + 1e-3
     # strided input view (rows of a bigger buffer)
     big = bf(M, K + 128, seed=10)
     y3 = O.skinny_gemm(big[:, :K], w)
