@@ -140,6 +140,54 @@ class LlavaWeights:
         w.t["mm.w2"], w.t["mm.b2"] = rnd(lm.d, lm.d), rnd(lm.d)
         return w
 
+    @staticmethod
+    def from_state_dict(cfg: LlavaConfig, sd: Dict[str, torch.Tensor], device, vision_sd: Optional[Dict[str, torch.Tensor]] = None,
+                        dtype=torch.bfloat16) -> "LlavaWeights":
+        """Maps an original-LLaVA-1.5 checkpoint (experiments/llava/model/builder.py:102-141 loads exactly these names):
+        `model.embed_tokens`, `model.layers.N.{self_attn.{q,k,v,o}_proj, mlp.{gate,up,down}_proj, input_layernorm,
+        post_attention_layernorm}`, `model.norm`, `lm_head`, `model.mm_projector.{0,2}`; the CLIP tower either inside the
+        checkpoint (`model.vision_tower.vision_tower.vision_model...`) or as a separate HF CLIP state dict (`vision_sd`,
+        keys `vision_model...`).  q/k/v and gate/up are concatenated for the fused projections."""
+        w = LlavaWeights(cfg, device)
+        lm, v = cfg.lm, cfg.vision
+
+        def get(d, k):
+            return d[k].detach().to(device=device, dtype=dtype).contiguous()
+        w.t["embed"] = get(sd, "model.embed_tokens.weight")
+        for i in range(lm.n_layers):
+            p, q = f"l{i}.", f"model.layers.{i}."
+            w.t[p + "ln1"], w.t[p + "ln2"] = get(sd, q + "input_layernorm.weight"), get(sd, q + "post_attention_layernorm.weight")
+            w.t[p + "wqkv"] = torch.cat([get(sd, q + f"self_attn.{n}_proj.weight") for n in ("q", "k", "v")], 0).contiguous()
+            w.t[p + "wo"] = get(sd, q + "self_attn.o_proj.weight")
+            w.t[p + "wgu"] = torch.cat([get(sd, q + "mlp.gate_proj.weight"), get(sd, q + "mlp.up_proj.weight")], 0).contiguous()
+            w.t[p + "wd"] = get(sd, q + "mlp.down_proj.weight")
+        w.t["norm"], w.t["lm_head"] = get(sd, "model.norm.weight"), get(sd, "lm_head.weight")
+        w.t["mm.w1"], w.t["mm.b1"] = get(sd, "model.mm_projector.0.weight"), get(sd, "model.mm_projector.0.bias")
+        w.t["mm.w2"], w.t["mm.b2"] = get(sd, "model.mm_projector.2.weight"), get(sd, "model.mm_projector.2.bias")
+        vs = vision_sd if vision_sd is not None else sd
+        # classic checkpoints: `vision_model.`; inside a LLaVA checkpoint: `model.vision_tower.vision_tower.vision_model.`;
+        # transformers 5.x CLIPVisionModel.state_dict(): no prefix at all
+        vp = next((c for c in ("vision_model.", "model.vision_tower.vision_tower.vision_model.", "model.vision_tower.vision_tower.", "")
+                   if c + "embeddings.patch_embedding.weight" in vs), None)
+        if vp is None:
+            raise KeyError("no CLIP vision tower found in the state dict (looked for *embeddings.patch_embedding.weight)")
+        pw = get(vs, vp + "embeddings.patch_embedding.weight").reshape(v.width, -1)        # [width, 3, P, P] -> [width, 3*P*P]
+        pd_pad = (pw.shape[1] + 7) // 8 * 8
+        w.t["v.patch"] = torch.nn.functional.pad(pw, (0, pd_pad - pw.shape[1])).contiguous()
+        w.t["v.cls"] = get(vs, vp + "embeddings.class_embedding")
+        w.t["v.pos"] = get(vs, vp + "embeddings.position_embedding.weight")
+        w.t["v.pre_ln.w"], w.t["v.pre_ln.b"] = get(vs, vp + "pre_layrnorm.weight"), get(vs, vp + "pre_layrnorm.bias")   # sic (HF spelling)
+        for i in range(v.run_layers):
+            p, q = f"v{i}.", vp + f"encoder.layers.{i}."
+            for a, b in (("ln1", "layer_norm1"), ("ln2", "layer_norm2")):
+                w.t[p + a + ".w"], w.t[p + a + ".b"] = get(vs, q + b + ".weight"), get(vs, q + b + ".bias")
+            w.t[p + "wqkv"] = torch.cat([get(vs, q + f"self_attn.{n}_proj.weight") for n in ("q", "k", "v")], 0).contiguous()
+            w.t[p + "bqkv"] = torch.cat([get(vs, q + f"self_attn.{n}_proj.bias") for n in ("q", "k", "v")], 0).contiguous()
+            w.t[p + "wo"], w.t[p + "bo"] = get(vs, q + "self_attn.out_proj.weight"), get(vs, q + "self_attn.out_proj.bias")
+            w.t[p + "fc1"], w.t[p + "b1"] = get(vs, q + "mlp.fc1.weight"), get(vs, q + "mlp.fc1.bias")
+            w.t[p + "fc2"], w.t[p + "b2"] = get(vs, q + "mlp.fc2.weight"), get(vs, q + "mlp.fc2.bias")
+        return w
+
     def nbytes(self) -> int:
         return sum(t.numel() * t.element_size() for t in self.t.values())
 
@@ -238,9 +286,6 @@ class LanguageModel:
     def __init__(self, w: LlavaWeights):
         self.w, self.cfg = w, w.cfg.lm
         self.cs = rope_table(self.cfg, w.device)
-
-    def _mlp_attn_out(self, i, h_resid, delta, x_norm_out=None):
-        raise NotImplementedError
 
     @torch.no_grad()
     def prefill(self, x: torch.Tensor, pos: torch.Tensor, cpos: torch.Tensor, slot: torch.Tensor, seqs: torch.Tensor, n_seq: int,
@@ -506,6 +551,8 @@ class VddLlavaEngine:
         ids_list = [r for r in input_ids] if torch.is_tensor(input_ids) else list(input_ids)
         ids_list = [r.reshape(-1).tolist() for r in ids_list]
         Q = len(ids_list)
+        if images is None and any(IMAGE_TOKEN_INDEX in r for r in ids_list):
+            raise ValueError("input_ids contain the image placeholder (-200) but no `images` were given")
         alpha = cd_alpha if cd_alpha is not None else 0.5                                     # vcd_sample.py:188
         beta = cd_beta if cd_beta is not None else 0.1                                        # :189
         use_cd = images_cd is not None
