@@ -541,17 +541,30 @@ class VddLlavaEngine:
                  top_p: Optional[float] = None, top_k: Optional[int] = None, max_new_tokens: int = 64,
                  eos_token_id=None, pad_token_id: Optional[int] = None, output_scores: bool = False,
                  return_dict_in_generate: bool = True, cd_greedy: bool = False, n_top: int = 0, seed: Optional[int] = None,
-                 share_prefix: bool = True, sync_every: int = 8, **_ignored) -> GenerateOutput:
+                 share_prefix: bool = True, sync_every: int = 8, inputs_embeds=None, **_ignored) -> GenerateOutput:
         """Same kwargs as the reference's model.generate(...) call (llava_calibrate.py:161-177); `input_ids` is a
         list of 1-D id tensors (one per question, each with one -200 image slot) or a [Q, L] tensor; `images` one
         image per question (repeat the SAME tensor for questions about the same image to share its features and
         prompt-prefix KV).  use_cache / output_attentions are accepted and ignored (attention maps are never
         materialised: flash-style kernels; the reference only reads them for a commented-out plot, :180-183)."""
         dev, lm = self.device, self.cfg.lm
+        if inputs_embeds is not None:
+            # LAVIS / InstructBLIP call shape (blip2_vicuna_instruct.py:380-410): the prompt arrives as embeddings
+            # [T, d] per question (Q-Former output ++ text embeddings) and `images_cd` holds the noisy-image EMBEDDINGS,
+            # which modeling_llama.py:778-782 feeds as inputs_embeds of the cd branch at step 0.
+            if use_dd or use_dd_unk:
+                raise ValueError("use_dd / use_dd_unk act on the image placeholder of input_ids; with inputs_embeds only "
+                                 "plain and VCD (images_cd = embeddings) decoding are defined")
+            emb_main = [e.reshape(-1, lm.d) for e in (inputs_embeds if not torch.is_tensor(inputs_embeds) else list(inputs_embeds))]
+            emb_cd = None
+            if images_cd is not None:
+                emb_cd = [e.reshape(-1, lm.d) for e in (images_cd if not torch.is_tensor(images_cd) else list(images_cd))]
+            input_ids = [torch.zeros(0, dtype=torch.long) for _ in emb_main]
+            images = None
         ids_list = [r for r in input_ids] if torch.is_tensor(input_ids) else list(input_ids)
         ids_list = [r.reshape(-1).tolist() for r in ids_list]
         Q = len(ids_list)
-        if images is None and any(IMAGE_TOKEN_INDEX in r for r in ids_list):
+        if inputs_embeds is None and images is None and any(IMAGE_TOKEN_INDEX in r for r in ids_list):
             raise ValueError("input_ids contain the image placeholder (-200) but no `images` were given")
         alpha = cd_alpha if cd_alpha is not None else 0.5                                     # vcd_sample.py:188
         beta = cd_beta if cd_beta is not None else 0.1                                        # :189
@@ -572,11 +585,16 @@ class VddLlavaEngine:
             imgs = [images[i] for i in range(Q)] if torch.is_tensor(images) else list(images)
             feats = self.image_features(imgs, image_keys)
         feats_cd = None
-        if use_cd:
+        if use_cd and inputs_embeds is None:
             imgs_cd = [images_cd[i] for i in range(Q)] if torch.is_tensor(images_cd) else list(images_cd)
             feats_cd = [self.vit(im.reshape(1, *im.shape[-3:]))[0] for im in imgs_cd]
-        branches = [("main", ids_list, feats)]
-        if use_cd:
+        if inputs_embeds is not None:
+            branches = [("main", ids_list, [e.to(dev, torch.bfloat16) for e in emb_main])]
+            if use_cd:
+                branches.append(("cd", ids_list, [e.to(dev, torch.bfloat16) for e in emb_cd]))
+        else:
+            branches = [("main", ids_list, feats)]
+        if use_cd and inputs_embeds is None:
             branches.append(("cd", ids_list, feats_cd))                                       # :148-150, takes precedence
         elif use_dd_unk:
             branches.append(("unk", [[0 if t == IMAGE_TOKEN_INDEX else t for t in r] for r in ids_list], None))   # :154-155
@@ -588,7 +606,7 @@ class VddLlavaEngine:
 
         # ---- plan prefill: split every (branch, question) sequence into shared prefix + own suffix -----
         n_img_tok = self.cfg.vision.n_patches
-        plan = self._plan(branches, n_img_tok, share_prefix)
+        plan = self._plan(branches, n_img_tok, share_prefix, embeds_only=inputs_embeds is not None)
         kv = self.kv(len(plan["prefix"]), max([s_["T"] for s_ in plan["prefix"]] + [0]), len(plan["suffix"]),
                      max(s_["T"] for s_ in plan["suffix"]) + max_new_tokens)
         assert plan["max_len"] + max_new_tokens <= self.cfg.lm.max_pos, "prompt + new tokens exceed the rotary table"
@@ -682,7 +700,7 @@ class VddLlavaEngine:
         return gen[:, : int(done_at.max().item()) + 1]
 
     # -- prefill planning ---------------------------------------------------------------------------------
-    def _plan(self, branches, n_img_tok, share_prefix):
+    def _plan(self, branches, n_img_tok, share_prefix, embeds_only=False):
         """Every (branch, question) sequence = [prefix | suffix].  Prefix = everything up to and including the
         image slot (main/cd: system prompt + 576 patch embeddings; unk: system prompt + <unk>; none: system prompt);
         identical prefixes (same tokens, same image features) are prefilled ONCE into a prefix slot."""
@@ -691,6 +709,12 @@ class VddLlavaEngine:
         n_slots, max_len, unshared = 0, 0, 0
         main_rows = branches[0][1]
         for name, rows, feats in branches:
+            if embeds_only:                                  # whole prompt given as embeddings: one own slot each, nothing shared
+                for qi in range(len(rows)):
+                    T = int(feats[qi].shape[0])
+                    suffix.append(dict(slot=len(suffix), tokens=None, pre=[], img=feats[qi], suf=[], T=T, pos0=0, pslot=0, plen=0))
+                    unshared += T; max_len = max(max_len, T); n_slots += 1
+                continue
             for qi, ids in enumerate(rows):
                 src = main_rows[qi]
                 s_img = src.index(IMAGE_TOKEN_INDEX) if IMAGE_TOKEN_INDEX in src else None

@@ -101,8 +101,13 @@ class RefLlava(_Proto):
 
     def __call__(self, input_ids=None, attention_mask=None, past_key_values=None, inputs_embeds=None, use_cache=None,
                  images=None, image_sizes=None, return_dict=True, output_attentions=None, output_hidden_states=None, **_):
-        ids = input_ids.to(self.device)
         past_len = int(past_key_values[0][0].shape[-2]) if past_key_values else 0
+        if inputs_embeds is not None:                           # LAVIS Llama (modeling_llama.py:764-792): prompt as embeddings
+            self.calls.append((tuple(inputs_embeds.shape[:2]), False, past_len))
+            emb = inputs_embeds.to(self.device, torch.bfloat16).to(self.dtype)
+            logits, past = self._lm(emb, past_key_values)
+            return SimpleNamespace(logits=logits.to(self.logit_dtype).cpu(), past_key_values=past, attentions=None, hidden_states=None)
+        ids = input_ids.to(self.device)
         self.calls.append((tuple(ids.shape), images is not None, past_len))
         if images is None or ids.shape[1] == 1:                 # llava_arch.py:91-94
             emb = self.w["embed"][ids]
@@ -114,3 +119,28 @@ class RefLlava(_Proto):
         emb = emb.to(torch.bfloat16).to(self.dtype)
         logits, past = self._lm(emb, past_key_values)
         return SimpleNamespace(logits=logits.to(self.logit_dtype).cpu(), past_key_values=past, attentions=None, hidden_states=None)
+
+
+class RefLavisLM(RefLlava):
+    """The LM side of InstructBLIP as the reference drives it: generate(inputs_embeds=..., images_cd=inputs_embeds_cd)
+    with prepare_inputs_for_generation[_cd] of experiments/lavis/models/blip2_models/modeling_llama.py:734-792."""
+
+    def prepare_inputs_for_generation(self, input_ids, past_key_values=None, attention_mask=None, inputs_embeds=None, **kw):
+        if past_key_values:
+            input_ids = input_ids[:, -1:]
+        if inputs_embeds is not None and past_key_values is None:
+            d = {"inputs_embeds": inputs_embeds}
+        else:
+            d = {"input_ids": input_ids}
+        d.update({"past_key_values": past_key_values, "use_cache": kw.get("use_cache"), "attention_mask": attention_mask})
+        return d
+
+    def prepare_inputs_for_generation_cd(self, input_ids, past_key_values=None, attention_mask=None, inputs_embeds=None, **kw):
+        if past_key_values:
+            input_ids = input_ids[:, -1:]
+        if inputs_embeds is not None and past_key_values is None:
+            d = {"inputs_embeds": kw.get("images_cd")}             # modeling_llama.py:778-782
+        else:
+            d = {"input_ids": input_ids}
+        d.update({"past_key_values": past_key_values, "use_cache": kw.get("use_cache"), "attention_mask": attention_mask})
+        return d

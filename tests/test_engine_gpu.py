@@ -212,3 +212,41 @@ def test_grouped_prefix_attention_is_transparent(eng):
             if a.tokens[q, step] != b.tokens[q, step]:
                 break
     assert checked >= len(ids)
+
+
+def test_lavis_call_shape_inputs_embeds_with_vcd_embeddings(eng):
+    """BASELINE config #5 call shape: the LM is driven with inputs_embeds (Q-Former output ++ text embeddings) and the
+    noisy-image branch arrives as EMBEDDINGS in images_cd (blip2_vicuna_instruct.py:380-410, modeling_llama.py:764-792)."""
+    from ref_llava import RefLavisLM
+    ref = RefLavisLM(eng.w, device=DEV)
+    g = torch.Generator().manual_seed(3)
+    d = eng.cfg.lm.d
+    embs = [torch.randn(32 + n, d, generator=g) * 0.3 for n in (9, 14, 11)]
+    embs_cd = [e + torch.randn(e.shape, generator=g) * 0.2 for e in embs]
+    n_new = 4
+    out = eng.generate(None, inputs_embeds=embs, images_cd=embs_cd, cd_alpha=0.5, cd_beta=0.1, temperature=0.5, max_new_tokens=n_new,
+                       cd_greedy=True, output_scores=True)
+    plain = eng.generate(None, inputs_embeds=embs, temperature=0.5, max_new_tokens=n_new, cd_greedy=True, output_scores=True)
+    assert out.tokens.shape == (3, n_new) and all(s.numel() == n_new for s in out.sequences)      # no prompt ids to echo
+    checked = 0
+    for q in range(3):
+        for o, cd in ((out, embs_cd[q]), (plain, None)):
+            kw = dict(inputs_embeds=embs[q][None], attention_mask=torch.ones(1, embs[q].shape[0], dtype=torch.long), use_cache=True,
+                      cd_alpha=0.5, cd_beta=0.1)
+            if cd is not None:
+                kw["images_cd"] = cd[None]
+            r = O.reference_loop(ref, torch.zeros(1, 0, dtype=torch.long), warp=O.WarpConfig(temperature=0.5), max_length=n_new,
+                                 pad_token_id=None, eos_token_id=None, pick=O.pick_argmax, **kw)
+            for step in range(n_new):
+                s_got, s_want = o.scores[step][q].float().cpu(), r.scores[step][0].float().cpu()
+                fin = torch.isfinite(s_got) & torch.isfinite(s_want)
+                assert fin.sum() >= 1 and (s_got[fin] - s_want[fin]).abs().max().item() <= 0.4
+                top2 = torch.topk(s_want, 2).values
+                if (top2[0] - top2[1]).item() > 0.8:
+                    assert o.tokens[q, step].item() == r.sequences[0, step].item()
+                    checked += 1
+                if o.tokens[q, step].item() != r.sequences[0, step].item():
+                    break
+    assert checked >= 4
+    with pytest.raises(ValueError, match="use_dd"):
+        eng.generate(None, inputs_embeds=embs, use_dd_unk=True, max_new_tokens=2)
