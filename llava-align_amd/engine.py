@@ -50,6 +50,7 @@ class LMConfig:
     rope_theta: float = 10000.0
     eps: float = 1e-5
     max_pos: int = 4096
+    qkv_bias: bool = False          # Qwen-7B: c_attn carries a bias (modeling_qwen.py:224-226); Llama/Vicuna: none
 
 
 @dataclass
@@ -84,6 +85,13 @@ def preset(name: str) -> LlavaConfig:
         return LlavaConfig(LMConfig(), VisionConfig(), name)
     if name == "llava-1.5-13b":
         return LlavaConfig(LMConfig(d=5120, n_layers=40, n_heads=40, n_kv_heads=40, ffn=13824), VisionConfig(), name)
+    if name == "qwen-vl-7b-lm":  # BASELINE config #4, LM side only (32 layers, d=4096, V=151936); the Qwen ViT + resampler
+        # are not on the north-star path: image slots arrive through `generate(inputs_embeds=...)`
+        return LlavaConfig(LMConfig(vocab=151936, eps=1e-6, qkv_bias=True, max_pos=8192), VisionConfig(), name)
+    if name == "tiny-qwen":      # test-sized Qwen-shaped LM: qkv bias, V beyond one LDS row (workspace path of the sampling kernel)
+        return LlavaConfig(LMConfig(d=256, n_layers=2, n_heads=2, n_kv_heads=2, ffn=512, vocab=151936, eps=1e-6, qkv_bias=True,
+                                    max_pos=512),
+                           VisionConfig(image=56, patch=14, width=128, layers=3, heads=2, mlp=256), name)
     if name == "tiny":          # test-sized: same structure, every kernel path exercised
         return LlavaConfig(LMConfig(d=256, n_layers=2, n_heads=2, n_kv_heads=2, ffn=512, vocab=1000, max_pos=512),
                            VisionConfig(image=56, patch=14, width=128, layers=3, heads=2, mlp=256), name)
@@ -116,6 +124,8 @@ class LlavaWeights:
             p = f"l{i}."
             w.t[p + "ln1"], w.t[p + "ln2"] = ones(lm.d), ones(lm.d)
             w.t[p + "wqkv"] = rnd(qkv_out, lm.d)
+            if lm.qkv_bias:
+                w.t[p + "bqkv_lm"] = rnd(qkv_out, s=0.1)
             w.t[p + "wo"] = rnd(lm.d, lm.n_heads * lm.head_dim)
             w.t[p + "wgu"] = rnd(2 * lm.ffn, lm.d)
             w.t[p + "wd"] = rnd(lm.d, lm.ffn)
@@ -158,6 +168,8 @@ class LlavaWeights:
             p, q = f"l{i}.", f"model.layers.{i}."
             w.t[p + "ln1"], w.t[p + "ln2"] = get(sd, q + "input_layernorm.weight"), get(sd, q + "post_attention_layernorm.weight")
             w.t[p + "wqkv"] = torch.cat([get(sd, q + f"self_attn.{n}_proj.weight") for n in ("q", "k", "v")], 0).contiguous()
+            if lm.qkv_bias:
+                w.t[p + "bqkv_lm"] = torch.cat([get(sd, q + f"self_attn.{n}_proj.bias") for n in ("q", "k", "v")], 0).contiguous()
             w.t[p + "wo"] = get(sd, q + "self_attn.o_proj.weight")
             w.t[p + "wgu"] = torch.cat([get(sd, q + "mlp.gate_proj.weight"), get(sd, q + "mlp.up_proj.weight")], 0).contiguous()
             w.t[p + "wd"] = get(sd, q + "mlp.down_proj.weight")
@@ -302,6 +314,8 @@ class LanguageModel:
             a = ops.rmsnorm(resid, t[p + "ln1"], c.eps, delta=delta, resid_out=new_resid)
             resid = new_resid if new_resid is not None else resid
             qkv = ops.linear(a, t[p + "wqkv"])
+            if c.qkv_bias:
+                ops.bias_act(qkv, t[p + "bqkv_lm"], out=qkv)
             kw_, vw_ = (kv.kp[i], kv.vp[i]) if to_prefix_pool else (kv.ko[i], kv.vo[i])
             q = ops.rope_kv_write(qkv, pos, slot, self.cs, kw_, vw_, H, Hkv, D, cpos=cpos)
             att = ops.flash_attention(q, kw_, vw_, seqs, n_seq, max_tq, H, Hkv, D, causal=True, k_prefix=kv.kp[i], v_prefix=kv.vp[i])
@@ -338,6 +352,8 @@ class LanguageModel:
             else:
                 a = ops.rmsnorm(resid, t[p + "ln1"], c.eps, delta=delta, resid_out=resid)
             qkv = ops.linear(a, t[p + "wqkv"])
+            if c.qkv_bias:
+                ops.bias_act(qkv, t[p + "bqkv_lm"], out=qkv)
             q = ops.rope_kv_write(qkv, pos, slot, self.cs, kv.ko[i], kv.vo[i], H, Hkv, D, cpos=cpos)
             if grouping is not None:      # rows sharing a prompt prefix attend it once per group (MFMA), own tokens per row
                 att = ops.decode_attention_grouped(q, kv.ko[i], kv.vo[i], kv.kp[i], kv.vp[i], attn_rows, grouping["groups"],

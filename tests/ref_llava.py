@@ -77,6 +77,8 @@ class RefLlava(_Proto):
             p = f"l{i}."
             a = rms(h, w[p + "ln1"])
             qkv = a @ w[p + "wqkv"].t()
+            if lm.qkv_bias:
+                qkv = qkv + w[p + "bqkv_lm"]
             q = qkv[..., : H * D].view(1, T, H, D).transpose(1, 2)
             k = qkv[..., H * D: (H + Hkv) * D].view(1, T, Hkv, D).transpose(1, 2)
             v = qkv[..., (H + Hkv) * D:].view(1, T, Hkv, D).transpose(1, 2)

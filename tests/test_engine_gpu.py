@@ -250,3 +250,50 @@ def test_lavis_call_shape_inputs_embeds_with_vcd_embeddings(eng):
     assert checked >= 4
     with pytest.raises(ValueError, match="use_dd"):
         eng.generate(None, inputs_embeds=embs, use_dd_unk=True, max_new_tokens=2)
+
+
+def test_qwen_shaped_lm_bias_and_large_vocab():
+    """BASELINE config #4 LM shape: qkv bias (modeling_qwen.py:224-226), V=151936 (a row larger than LDS: the sampling kernel's
+    workspace path inside the captured decode graph).  Image slots arrive as embeddings; quirk #4 (the cd branch re-runs the
+    same inputs, c == v) is the call below with images_cd = inputs_embeds; the calibration passes are text-only ids."""
+    from ref_llava import RefLavisLM
+    from llava_align_amd.engine import LlavaWeights, VddLlavaEngine, preset
+    cfg = preset("tiny-qwen")
+    w = LlavaWeights.random(cfg, DEV, seed=5, std=0.06)
+    e = VddLlavaEngine(cfg, weights=w, device=DEV)
+    ref = RefLavisLM(w, device=DEV)
+    g = torch.Generator().manual_seed(11)
+    embs = [torch.randn(n, cfg.lm.d, generator=g) * 0.3 for n in (20, 27)]
+    n_new = 3
+    out = e.generate(None, inputs_embeds=embs, images_cd=embs, cd_alpha=1.0, cd_beta=0.1, temperature=0.5, max_new_tokens=n_new,
+                     cd_greedy=True, output_scores=True, n_top=10)
+    noscore = e.generate(None, inputs_embeds=embs, images_cd=embs, cd_alpha=1.0, cd_beta=0.1, temperature=0.5, max_new_tokens=n_new,
+                         cd_greedy=True, output_scores=False)
+    assert torch.equal(out.tokens, noscore.tokens)                       # workspace path == scores path
+    checked = 0
+    for q in range(2):
+        r = O.reference_loop(ref, torch.zeros(1, 0, dtype=torch.long), warp=O.WarpConfig(temperature=0.5), max_length=n_new,
+                             pad_token_id=None, eos_token_id=None, pick=O.pick_argmax, inputs_embeds=embs[q][None],
+                             images_cd=embs[q][None], attention_mask=torch.ones(1, embs[q].shape[0], dtype=torch.long),
+                             use_cache=True, cd_alpha=1.0, cd_beta=0.1)
+        for step in range(n_new):
+            s_got, s_want = out.scores[step][q].float().cpu(), r.scores[step][0].float().cpu()
+            fin = torch.isfinite(s_got) & torch.isfinite(s_want)
+            assert fin.sum() >= 1 and (s_got[fin] - s_want[fin]).abs().max().item() <= 0.4
+            tok = out.tokens[q, step].item()                 # 152K near-flat logits: the pick must be a near-maximiser of the reference row
+            assert s_want[tok].item() >= s_want.max().item() - 0.8
+            checked += 1
+            if tok != r.sequences[0, step].item():
+                break
+    assert checked >= 2
+    assert out.top_tok.shape == (2, 10) and out.top_tok[:, 0].tolist() == out.tokens[:, 0].tolist()
+    # text-only calibration pass (MME/run_qwen.py:103-109): ids, no image
+    ids = [torch.randint(3, cfg.lm.vocab, (15,), generator=g), torch.randint(3, cfg.lm.vocab, (18,), generator=g)]
+    t = e.generate(ids, temperature=0.5, max_new_tokens=2, cd_greedy=True, output_scores=True)
+    ref2 = RefLlava(w, device=DEV)
+    for q in range(2):
+        r = O.reference_loop(ref2, ids[q][None], warp=O.WarpConfig(temperature=0.5), max_length=ids[q].numel() + 2, pad_token_id=None,
+                             eos_token_id=None, pick=O.pick_argmax, attention_mask=torch.ones(1, ids[q].numel(), dtype=torch.long),
+                             use_cache=True)
+        s_got, s_want = t.scores[0][q].float().cpu(), r.scores[0][0].float().cpu()
+        assert (s_got - s_want).abs().max().item() <= 0.4
