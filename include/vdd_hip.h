@@ -137,6 +137,11 @@ int vdd_embed(const int64_t* ids, const void* table, void* out, int M, int d, vo
 int vdd_skinny_gemm(const void* X, const void* W, const void* R, void* Y, float* Y_slabs, int n_split, int M, int N, int K,
                     int64_t ldx, int64_t ldr, int64_t ldy, void* hip_stream);
 
+/* act[M,F] = silu(X Wg^T) * (X Wu^T) for W_gate_up = [Wg; Wu] ([2F, K] row-major), M <= 16, K % 128 == 0: the gate/up
+ * projection and SiLU*mul of the Llama MLP (HF LlamaMLP.forward [ext] under llava_llama.py:88-103) in one weight-streaming
+ * launch; replaces vdd_skinny_gemm(N = 2F) + vdd_silu_mul with the same bf16 rounding points. */
+int vdd_skinny_swiglu(const void* X, const void* W_gate_up, void* act, int M, int F, int K, int64_t ldx, void* hip_stream);
+
 /* Decode-regime GEMM, 9 <= M <= 256 rows: Y[M,N] = X[M,K] W[N,K]^T with W streamed from HBM exactly once and the X
  * tile shared through LDS (csrc/vdd_mid_gemm.hip).  Either Y (bf16, n_split == 1) or Y_slabs (fp32 [n_split][M][N]:
  * split-K partial sums, summed by vdd_rmsnorm's delta_slabs input); K % (64 * n_split) == 0. */
@@ -153,6 +158,17 @@ int vdd_decode_attention(const void* q, const void* k_cache, const void* v_cache
                          const int32_t* rows, void* out, void* workspace, int M, int H, int Hkv, int D, int64_t slot_stride, int t_max,
                          int64_t prefix_stride, int prefix_tmax, int max_len, float scale, void* hip_stream);
 int64_t vdd_decode_attention_workspace_bytes(int M, int H, int D, int max_len);
+
+/* Small-M decode attention with RoPE, the KV-cache write and the chunk merge fused into ONE launch (the reference's own
+ * operating point: one question = 2-3 branch rows per step, where the step is launch-latency bound).  `qkv` is the
+ * un-rotated projection [M, (H + 2 Hkv) * D]; the new token's K/V are rotated in registers, stored at index cpos[row]
+ * of slot[row] and attended from registers; older tokens come from the prefix / own pools exactly as in
+ * vdd_decode_attention.  rows[i].len counts the new token.  Replaces vdd_rope_kv_write + vdd_decode_attention
+ * (HF LlamaAttention.forward [ext] under llava_llama.py:88-103) for M <= ~16. */
+int vdd_decode_attention_fused(const void* qkv, const int32_t* pos, const int32_t* cpos, const int32_t* slot, const float* cos_sin,
+                               void* k_cache, void* v_cache, const void* k_prefix, const void* v_prefix, const int32_t* rows, void* out,
+                               int M, int H, int Hkv, int D, int64_t slot_stride, int t_max, int64_t prefix_stride, int prefix_tmax,
+                               float scale, void* stream);
 
 /* Same result as vdd_decode_attention when every row with prefix_len > 0 is listed in exactly one group of rows
  * sharing (prefix_slot, prefix_len): groups[g] = {row_off, n_rows, prefix_slot, prefix_len} (int32 x4) indexes

@@ -109,6 +109,12 @@ __global__ void __launch_bounds__(256) rmsnorm_kernel(const uint16_t* __restrict
             f = lo(a.z); ss += f * f; f = hi(a.z); ss += f * f; f = lo(a.w); ss += f * f; f = hi(a.w); ss += f * f;
         }
     }
+    uint4 wv[VPT];                                   // issued before the barrier: off the dependent chain
+#pragma unroll
+    for (int i = 0; i < VPT; ++i) {
+        const int e = (i * 256 + tid) * 8;
+        wv[i] = e < d ? *reinterpret_cast<const uint4*>(w + e) : make_uint4(0, 0, 0, 0);
+    }
     ss = wave_sum(ss);
     if ((tid & 63) == 0) red[tid >> 6] = ss;
     __syncthreads();
@@ -117,7 +123,7 @@ __global__ void __launch_bounds__(256) rmsnorm_kernel(const uint16_t* __restrict
     for (int i = 0; i < VPT; ++i) {
         const int e = (i * 256 + tid) * 8;
         if (e < d) {
-            uint4 a = h[i], g = *reinterpret_cast<const uint4*>(w + e), o;
+            uint4 a = h[i], g = wv[i], o;
             auto nrm = [&](uint32_t hv, uint32_t gv) {
                 float n0 = bf2f(f2bf(lo(hv) * rstd)), n1 = bf2f(f2bf(hi(hv) * rstd));
                 return pack(n0 * lo(gv), n1 * hi(gv));
@@ -140,20 +146,28 @@ __global__ void __launch_bounds__(256) rope_kv_kernel(const uint16_t* __restrict
                                                       long long slot_stride, int t_max) {
     const int row = blockIdx.x, tid = threadIdx.x;
     const int p = pos[row], s = slot[row], cp = cpos[row];     // rotary position vs index inside the cache slot
-    const int half = D / 2;
-    const int nq = Hq * half, nk = Hkv * half;
+    const int half = D / 2, h8 = half / 8;                      // a work item = 8 consecutive pairs (i, i + D/2) of one head
     const uint16_t* src = qkv + (size_t)row * (size_t)((Hq + 2 * Hkv) * D);
-    for (int i = tid; i < nq + nk; i += 256) {          // one (head, pair) per iteration
-        const bool is_k = i >= nq;
-        const int j = is_k ? i - nq : i;
-        const int head = j / half, pi = j % half;
-        const uint16_t* hsrc = src + (is_k ? (size_t)Hq * D : 0) + (size_t)head * D;
-        const float c = cs_table[((size_t)p * half + pi) * 2], sn = cs_table[((size_t)p * half + pi) * 2 + 1];
-        const float a = bf2f(hsrc[pi]), b = bf2f(hsrc[pi + half]);
-        const uint16_t r0 = (uint16_t)f2bf(a * c - b * sn), r1 = (uint16_t)f2bf(b * c + a * sn);
-        uint16_t* dst = is_k ? k_cache + (size_t)s * slot_stride + ((size_t)head * t_max + cp) * D
+    const float* cs = cs_table + (size_t)p * half * 2;
+    for (int i = tid; i < (Hq + Hkv) * h8; i += 256) {
+        const int head = i / h8, pi = (i % h8) * 8;
+        const bool is_k = head >= Hq;
+        const uint16_t* hsrc = src + (size_t)head * D;           // q heads then k heads are contiguous in qkv
+        const uint4 a4 = *reinterpret_cast<const uint4*>(hsrc + pi), b4 = *reinterpret_cast<const uint4*>(hsrc + pi + half);
+        const float4 c0 = *reinterpret_cast<const float4*>(cs + pi * 2), c1 = *reinterpret_cast<const float4*>(cs + pi * 2 + 4),
+                     c2 = *reinterpret_cast<const float4*>(cs + pi * 2 + 8), c3 = *reinterpret_cast<const float4*>(cs + pi * 2 + 12);
+        auto rot = [](uint32_t av, uint32_t bv, float cA, float sA, float cB, float sB, uint32_t& r0, uint32_t& r1) {
+            const float a0 = lo(av), a1 = hi(av), b0 = lo(bv), b1 = hi(bv);
+            r0 = pack(a0 * cA - b0 * sA, a1 * cB - b1 * sB);
+            r1 = pack(b0 * cA + a0 * sA, b1 * cB + a1 * sB);
+        };
+        uint4 r0, r1;
+        rot(a4.x, b4.x, c0.x, c0.y, c0.z, c0.w, r0.x, r1.x); rot(a4.y, b4.y, c1.x, c1.y, c1.z, c1.w, r0.y, r1.y);
+        rot(a4.z, b4.z, c2.x, c2.y, c2.z, c2.w, r0.z, r1.z); rot(a4.w, b4.w, c3.x, c3.y, c3.z, c3.w, r0.w, r1.w);
+        uint16_t* dst = is_k ? k_cache + (size_t)s * slot_stride + ((size_t)(head - Hq) * t_max + cp) * D
                              : q_out + (size_t)row * Hq * D + (size_t)head * D;
-        dst[pi] = r0; dst[pi + half] = r1;
+        *reinterpret_cast<uint4*>(dst + pi) = r0;
+        *reinterpret_cast<uint4*>(dst + pi + half) = r1;
     }
     const uint16_t* vsrc = src + (size_t)(Hq + Hkv) * D;
     for (int i = tid; i < Hkv * D / 8; i += 256) {
@@ -166,19 +180,19 @@ __global__ void __launch_bounds__(256) rope_kv_kernel(const uint16_t* __restrict
 // ------------------------------------------------------------------ SiLU(gate) * up
 __global__ void __launch_bounds__(256) silu_mul_kernel(const uint16_t* __restrict__ gu, uint16_t* __restrict__ out,
                                                        long long M, int F) {
-    const long long n8 = M * (F / 8);
-    for (long long i = (long long)blockIdx.x * 256 + threadIdx.x; i < n8; i += (long long)gridDim.x * 256) {
-        const long long m = i / (F / 8); const int f = (int)(i % (F / 8)) * 8;
-        uint4 g = *reinterpret_cast<const uint4*>(gu + m * 2 * F + f);
-        uint4 u = *reinterpret_cast<const uint4*>(gu + m * 2 * F + F + f);
-        auto act = [](uint32_t gv, uint32_t uv) {
-            float g0 = lo(gv), g1 = hi(gv);
-            float s0 = bf2f(f2bf(g0 / (1.f + __expf(-g0)))), s1 = bf2f(f2bf(g1 / (1.f + __expf(-g1))));
-            return pack(s0 * lo(uv), s1 * hi(uv));
-        };
-        uint4 o; o.x = act(g.x, u.x); o.y = act(g.y, u.y); o.z = act(g.z, u.z); o.w = act(g.w, u.w);
-        *reinterpret_cast<uint4*>(out + m * F + f) = o;
-    }
+    // grid: (ceil(F / 8 / 256), M): a thread owns 8 consecutive features of one row
+    const int f = (blockIdx.x * 256 + threadIdx.x) * 8;
+    if (f >= F) return;
+    const size_t m = blockIdx.y;
+    const uint4 g = *reinterpret_cast<const uint4*>(gu + m * 2 * F + f);
+    const uint4 u = *reinterpret_cast<const uint4*>(gu + m * 2 * F + F + f);
+    auto act = [](uint32_t gv, uint32_t uv) {
+        const float g0 = lo(gv), g1 = hi(gv);
+        const float s0 = bf2f(f2bf(g0 / (1.f + __expf(-g0)))), s1 = bf2f(f2bf(g1 / (1.f + __expf(-g1))));
+        return pack(s0 * lo(uv), s1 * hi(uv));
+    };
+    uint4 o; o.x = act(g.x, u.x); o.y = act(g.y, u.y); o.z = act(g.z, u.z); o.w = act(g.w, u.w);
+    *reinterpret_cast<uint4*>(out + m * F + f) = o;
 }
 
 // ------------------------------------------------------------------ embedding gather
@@ -258,6 +272,53 @@ __global__ void __launch_bounds__(256) skinny_gemm_kernel(const uint16_t* __rest
                 if (R != nullptr) o = o + bf2f(R[(size_t)row * ldr + col]);
                 Y[(size_t)row * ldy + col] = (uint16_t)f2bf(o);
             }
+        }
+    }
+}
+
+// ------------------------------------------------------------------ skinny gate/up GEMM with the SwiGLU epilogue
+// act[M,F] = silu(X Wg^T) * (X Wu^T), W = [Wg; Wu] ([2F, K]).  The 16 MFMA columns of a block are 8 gate columns
+// (B-fragment lanes ln < 8 -> row f0 + ln) and the 8 matching up columns (ln >= 8 -> row F + f0 + ln - 8), so the
+// epilogue finds gate and up of one feature in the same LDS tile: no [M, 2F] round trip and no silu_mul launch.
+// Rounding as the unfused pair: gate, up -> bf16; silu(gate) -> bf16; product -> bf16.
+__global__ void __launch_bounds__(256) skinny_swiglu_kernel(const uint16_t* __restrict__ X, const uint16_t* __restrict__ W,
+                                                            uint16_t* __restrict__ A, int M, int F, int K, long long ldx) {
+    __shared__ float part[4][64][4];
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int f0 = blockIdx.x * 8;
+    const int ln = lane & 15, g = lane >> 4;
+    const int kq = K / 4, kbeg = wave * kq;
+    int f = f0 + (ln & 7); if (f >= F) f = F - 1;
+    const uint16_t* wp = W + ((size_t)(ln < 8 ? 0 : F) + f) * K + kbeg + g * 8;
+    int r = ln; if (r >= M) r = M - 1;
+    const uint16_t* xp = X + (size_t)r * ldx + kbeg + g * 8;
+    f32x4_t acc = f32x4_t{0.f, 0.f, 0.f, 0.f};
+    constexpr int U = 4;
+    int k = 0;
+    for (; k + 32 * U <= kq; k += 32 * U) {
+        bf16x8_t b[U], a[U];
+#pragma unroll
+        for (int u = 0; u < U; ++u) b[u] = *reinterpret_cast<const bf16x8_t*>(wp + k + 32 * u);
+#pragma unroll
+        for (int u = 0; u < U; ++u) a[u] = *reinterpret_cast<const bf16x8_t*>(xp + k + 32 * u);
+#pragma unroll
+        for (int u = 0; u < U; ++u) acc = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a[u], b[u], acc, 0, 0, 0);
+    }
+    for (; k < kq; k += 32)
+        acc = __builtin_amdgcn_mfma_f32_16x16x32_bf16(*reinterpret_cast<const bf16x8_t*>(xp + k), *reinterpret_cast<const bf16x8_t*>(wp + k), acc, 0, 0, 0);
+#pragma unroll
+    for (int rr = 0; rr < 4; ++rr) part[wave][lane][rr] = acc[rr];
+    __syncthreads();
+    // C map: col = lane & 15, row = (lane >> 4) * 4 + rr.  Threads 0..127: (row = tid / 8, feature = tid % 8)
+    if (tid < 128) {
+        const int row = tid >> 3, c = tid & 7;
+        if (row < M && f0 + c < F) {
+            const int lg = (row >> 2) * 16 + c, lu = lg + 8, rr = row & 3;
+            const float gs = (part[0][lg][rr] + part[1][lg][rr]) + (part[2][lg][rr] + part[3][lg][rr]);
+            const float us = (part[0][lu][rr] + part[1][lu][rr]) + (part[2][lu][rr] + part[3][lu][rr]);
+            const float gb = bf2f(f2bf(gs)), ub = bf2f(f2bf(us));
+            const float sl = bf2f(f2bf(gb / (1.f + __expf(-gb))));
+            A[(size_t)row * F + f0 + c] = (uint16_t)f2bf(sl * ub);
         }
     }
 }
@@ -370,6 +431,116 @@ __global__ void __launch_bounds__(256) decode_attn_combine_kernel(const float* _
     for (int c = 0; c < used_own; ++c) add(npre + c);
     const float inv = 1.f / L;
     reinterpret_cast<uint32_t*>(out + ((size_t)row * H + head) * D)[lane] = pack(a0 * inv, a1 * inv);
+}
+
+// ------------------------------------------------------------------ small-M fused decode attention
+// For a handful of rows (the reference's own operating point: ONE question = 2-3 branch rows) the step is a chain of
+// latency-bound launches, so RoPE, the KV-cache write, the whole-context attention and the merge run as ONE kernel:
+// block = (head, row), NW waves; key t belongs to 16-lane group (t mod 4 NW); the new token's K/V never round-trip
+// through the cache (they are rotated in registers, written once per KV head, and attended from registers).
+template <int D, int NW>
+__global__ void __launch_bounds__(NW * 64) decode_attn_fused_kernel(const uint16_t* __restrict__ qkv, const int* __restrict__ pos,
+                                                                    const int* __restrict__ cpos, const int* __restrict__ slot,
+                                                                    const float* __restrict__ cs_table, uint16_t* __restrict__ kc,
+                                                                    uint16_t* __restrict__ vc, const uint16_t* __restrict__ kpre,
+                                                                    const uint16_t* __restrict__ vpre, const AttnRow* __restrict__ rows,
+                                                                    uint16_t* __restrict__ out, int H, int Hkv, long long slot_stride,
+                                                                    int t_max, long long pre_stride, int pre_tmax, float scale) {
+    static_assert(D == 128, "lane map assumes 16 lanes x 8 dims");
+    __shared__ float part[NW][D + 2];
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, g = lane >> 4, j = lane & 15;
+    const int head = blockIdx.x, row = blockIdx.y;
+    const AttnRow ar = rows[row];
+    const int p = pos[row], cp = cpos[row];
+    const int kvh = head / (H / Hkv);
+    const uint16_t* src = qkv + (size_t)row * (size_t)((H + 2 * Hkv) * D);
+    // rotate_half RoPE: lane j < 8 holds dims 8j.. (first half), lane j + 8 the partner dims; same rounding as rope_kv_kernel
+    const float* cs = cs_table + ((size_t)p * (D / 2) + (j & 7) * 8) * 2;
+    const float4 c0 = *reinterpret_cast<const float4*>(cs), c1 = *reinterpret_cast<const float4*>(cs + 4),
+                 c2 = *reinterpret_cast<const float4*>(cs + 8), c3 = *reinterpret_cast<const float4*>(cs + 12);
+    const float sign = j < 8 ? -1.f : 1.f;
+    auto rope = [&](const uint16_t* hsrc) {
+        const uint4 own = *reinterpret_cast<const uint4*>(hsrc + j * 8);
+        uint4 oth;
+        oth.x = __shfl_xor(own.x, 8); oth.y = __shfl_xor(own.y, 8); oth.z = __shfl_xor(own.z, 8); oth.w = __shfl_xor(own.w, 8);
+        auto r2 = [&](uint32_t a, uint32_t b, float cA, float sA, float cB, float sB) {
+            return pack(lo(a) * cA + (sign * lo(b)) * sA, hi(a) * cB + (sign * hi(b)) * sB);
+        };
+        uint4 r;
+        r.x = r2(own.x, oth.x, c0.x, c0.y, c0.z, c0.w); r.y = r2(own.y, oth.y, c1.x, c1.y, c1.z, c1.w);
+        r.z = r2(own.z, oth.z, c2.x, c2.y, c2.z, c2.w); r.w = r2(own.w, oth.w, c3.x, c3.y, c3.z, c3.w);
+        return r;
+    };
+    const uint4 qv = rope(src + (size_t)head * D);
+    const uint4 kn = rope(src + (size_t)(H + kvh) * D);
+    const uint4 vn = *reinterpret_cast<const uint4*>(src + (size_t)(H + Hkv + kvh) * D + j * 8);
+    if (wave == 0 && g == 0 && head % (H / Hkv) == 0) {      // one writer per KV head
+        const size_t o = (size_t)slot[row] * slot_stride + ((size_t)kvh * t_max + cp) * D + j * 8;
+        *reinterpret_cast<uint4*>(kc + o) = kn;
+        *reinterpret_cast<uint4*>(vc + o) = vn;
+    }
+    const size_t hoff = (size_t)kvh * t_max * D + j * 8, poff = (size_t)kvh * pre_tmax * D + j * 8;
+    const uint16_t* k_own = kc + (size_t)ar.slot * slot_stride + hoff - (size_t)ar.plen * D;
+    const uint16_t* v_own = vc + (size_t)ar.slot * slot_stride + hoff - (size_t)ar.plen * D;
+    const uint16_t* k_pre = kpre + (size_t)ar.pslot * pre_stride + poff;
+    const uint16_t* v_pre = vpre + (size_t)ar.pslot * pre_stride + poff;
+    float m = -INFINITY, l = 0.f, acc[8] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+    const int n_old = ar.len - 1, kl = wave * 4 + g;
+    constexpr int U = 4, STEP = NW * 4;
+    for (int t0 = kl; t0 < n_old; t0 += STEP * U) {
+        uint4 kv[U], vv[U];
+#pragma unroll
+        for (int u = 0; u < U; ++u) {
+            const int t = t0 + STEP * u;
+            const int tt = t < n_old ? t : n_old - 1;
+            const bool pre = tt < ar.plen;
+            kv[u] = *reinterpret_cast<const uint4*>((pre ? k_pre : k_own) + (size_t)tt * D);
+            vv[u] = *reinterpret_cast<const uint4*>((pre ? v_pre : v_own) + (size_t)tt * D);
+        }
+#pragma unroll
+        for (int u = 0; u < U; ++u) {
+            float sc = dot8(qv, kv[u]);
+            sc += __shfl_xor(sc, 1); sc += __shfl_xor(sc, 2); sc += __shfl_xor(sc, 4); sc += __shfl_xor(sc, 8);
+            sc *= scale;
+            if (t0 + STEP * u < n_old) ATT_ONLINE_STEP(sc, vv[u], m, l, acc);
+        }
+    }
+    {   // the new token, from registers (last wave's last group is the least loaded)
+        float sc = dot8(qv, kn);
+        sc += __shfl_xor(sc, 1); sc += __shfl_xor(sc, 2); sc += __shfl_xor(sc, 4); sc += __shfl_xor(sc, 8);
+        sc *= scale;
+        if (kl == STEP - 1) ATT_ONLINE_STEP(sc, vn, m, l, acc);
+    }
+#pragma unroll
+    for (int o = 16; o <= 32; o <<= 1) {
+        const float mo = __shfl_xor(m, o), lo_ = __shfl_xor(l, o);
+        const float mn = fmaxf(m, mo);
+        const float e0 = (m == -INFINITY) ? 0.f : __expf(m - mn), e1 = (mo == -INFINITY) ? 0.f : __expf(mo - mn);
+        l = l * e0 + lo_ * e1;
+#pragma unroll
+        for (int e = 0; e < 8; ++e) { const float ao = __shfl_xor(acc[e], o); acc[e] = acc[e] * e0 + ao * e1; }
+        m = mn;
+    }
+    if (g == 0) {
+        *reinterpret_cast<float4*>(&part[wave][j * 8]) = make_float4(acc[0], acc[1], acc[2], acc[3]);
+        *reinterpret_cast<float4*>(&part[wave][j * 8 + 4]) = make_float4(acc[4], acc[5], acc[6], acc[7]);
+        if (j == 0) { part[wave][D] = m; part[wave][D + 1] = l; }
+    }
+    __syncthreads();
+    if (wave == 0) {
+        float Mx = -INFINITY;
+#pragma unroll
+        for (int w = 0; w < NW; ++w) Mx = fmaxf(Mx, part[w][D]);
+        float L = 0.f, a0 = 0.f, a1 = 0.f;
+#pragma unroll
+        for (int w = 0; w < NW; ++w) {
+            const float wgt = __expf(part[w][D] - Mx);       // empty waves: exp(-inf) = 0
+            L += wgt * part[w][D + 1];
+            a0 += wgt * part[w][2 * lane]; a1 += wgt * part[w][2 * lane + 1];
+        }
+        const float inv = 1.f / L;
+        reinterpret_cast<uint32_t*>(out + ((size_t)row * H + head) * D)[lane] = pack(a0 * inv, a1 * inv);
+    }
 }
 
 // ------------------------------------------------------------------ prefix-grouped decode attention
@@ -592,7 +763,7 @@ int vdd_rmsnorm(const void* x, const void* delta, const float* delta_slabs, int 
 int vdd_rope_kv_write(const void* qkv, const int* pos, const int* cpos, const int* slot, const float* cos_sin, void* q_out, void* k_cache,
                       void* v_cache, int M, int Hq, int Hkv, int D, int64_t slot_stride, int t_max, void* stream) {
     if (M <= 0) return VDD_OK;
-    if (!qkv || !pos || !cpos || !slot || !cos_sin || !q_out || !k_cache || !v_cache || D % 8 != 0) return VDD_ERR_INVALID_ARG;
+    if (!qkv || !pos || !cpos || !slot || !cos_sin || !q_out || !k_cache || !v_cache || D % 16 != 0) return VDD_ERR_INVALID_ARG;
     hipLaunchKernelGGL(rope_kv_kernel, dim3(M), dim3(256), 0, (hipStream_t)stream, (const uint16_t*)qkv, pos, cpos, slot, cos_sin,
                        (uint16_t*)q_out, (uint16_t*)k_cache, (uint16_t*)v_cache, Hq, Hkv, D, (long long)slot_stride, t_max);
     return ok(hipSuccess);
@@ -601,9 +772,15 @@ int vdd_rope_kv_write(const void* qkv, const int* pos, const int* cpos, const in
 int vdd_silu_mul(const void* gate_up, void* out, int64_t M, int F, void* stream) {
     if (M <= 0) return VDD_OK;
     if (!gate_up || !out || F % 8 != 0) return VDD_ERR_INVALID_ARG;
-    long long n8 = (long long)M * (F / 8);
-    int blocks = (int)((n8 + 255) / 256); if (blocks > 4096) blocks = 4096;
-    hipLaunchKernelGGL(silu_mul_kernel, dim3(blocks), dim3(256), 0, (hipStream_t)stream, (const uint16_t*)gate_up, (uint16_t*)out, (long long)M, F);
+    if (M > 65535) {        // gridDim.y limit: launch in row slabs
+        for (int m0 = 0; m0 < M; m0 += 65535) {
+            const int mm = M - m0 < 65535 ? M - m0 : 65535;
+            hipLaunchKernelGGL(silu_mul_kernel, dim3((F / 8 + 255) / 256, mm), dim3(256), 0, (hipStream_t)stream,
+                               (const uint16_t*)gate_up + (size_t)m0 * 2 * F, (uint16_t*)out + (size_t)m0 * F, (long long)mm, F);
+        }
+        return ok(hipSuccess);
+    }
+    hipLaunchKernelGGL(silu_mul_kernel, dim3((F / 8 + 255) / 256, M), dim3(256), 0, (hipStream_t)stream, (const uint16_t*)gate_up, (uint16_t*)out, (long long)M, F);
     return ok(hipSuccess);
 }
 
@@ -628,6 +805,14 @@ int vdd_skinny_gemm(const void* X, const void* W, const void* R, void* Y, float*
     return ok(hipSuccess);
 }
 
+int vdd_skinny_swiglu(const void* X, const void* W_gate_up, void* act, int M, int F, int K, int64_t ldx, void* stream) {
+    if (M <= 0 || F <= 0) return VDD_OK;
+    if (!X || !W_gate_up || !act || M > 16 || K % 128 != 0 || (ldx % 8) != 0) return VDD_ERR_INVALID_ARG;
+    hipLaunchKernelGGL(skinny_swiglu_kernel, dim3((F + 7) / 8), dim3(256), 0, (hipStream_t)stream, (const uint16_t*)X,
+                       (const uint16_t*)W_gate_up, (uint16_t*)act, M, F, K, (long long)ldx);
+    return ok(hipSuccess);
+}
+
 int vdd_decode_attention(const void* q, const void* k_cache, const void* v_cache, const void* k_prefix, const void* v_prefix,
                          const int32_t* rows, void* out, void* workspace, int M, int H, int Hkv, int D, int64_t slot_stride, int t_max,
                          int64_t prefix_stride, int prefix_tmax, int max_len, float scale, void* stream) {
@@ -641,6 +826,20 @@ int vdd_decode_attention(const void* q, const void* k_cache, const void* v_cache
                        prefix_tmax, scale, nchunk, 0, 0);
     hipLaunchKernelGGL(decode_attn_combine_kernel<128>, dim3((H + 3) / 4, M), dim3(256), 0, st, (const float*)workspace,
                        (const AttnRow*)rows, (uint16_t*)out, H, nchunk, 0);
+    return ok(hipSuccess);
+}
+
+int vdd_decode_attention_fused(const void* qkv, const int32_t* pos, const int32_t* cpos, const int32_t* slot, const float* cos_sin,
+                               void* k_cache, void* v_cache, const void* k_prefix, const void* v_prefix, const int32_t* rows, void* out,
+                               int M, int H, int Hkv, int D, int64_t slot_stride, int t_max, int64_t prefix_stride, int prefix_tmax,
+                               float scale, void* stream) {
+    if (M <= 0) return VDD_OK;
+    if (!qkv || !pos || !cpos || !slot || !cos_sin || !k_cache || !v_cache || !k_prefix || !v_prefix || !rows || !out || D != 128 ||
+        H % Hkv != 0 || M > 65535) return VDD_ERR_INVALID_ARG;
+    hipLaunchKernelGGL((decode_attn_fused_kernel<128, 16>), dim3(H, M), dim3(1024), 0, (hipStream_t)stream, (const uint16_t*)qkv, pos, cpos,
+                       slot, cos_sin, (uint16_t*)k_cache, (uint16_t*)v_cache, (const uint16_t*)k_prefix, (const uint16_t*)v_prefix,
+                       (const AttnRow*)rows, (uint16_t*)out, H, Hkv, (long long)slot_stride, t_max, (long long)prefix_stride, prefix_tmax,
+                       scale);
     return ok(hipSuccess);
 }
 

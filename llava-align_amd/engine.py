@@ -25,6 +25,7 @@ go to hipBLASLt through torch.matmul (a plain library GEMM).  bf16 storage, fp32
 """
 from __future__ import annotations
 
+import gc
 import math
 from dataclasses import dataclass, field
 from typing import Dict, List, Optional, Sequence
@@ -354,19 +355,23 @@ class LanguageModel:
             qkv = ops.linear(a, t[p + "wqkv"])
             if c.qkv_bias:
                 ops.bias_act(qkv, t[p + "bqkv_lm"], out=qkv)
-            q = ops.rope_kv_write(qkv, pos, slot, self.cs, kv.ko[i], kv.vo[i], H, Hkv, D, cpos=cpos)
-            if grouping is not None:      # rows sharing a prompt prefix attend it once per group (MFMA), own tokens per row
+            if grouping is None and tokens.shape[0] <= ops.FUSED_ATTN_MAX_M and D == 128:
+                # a few rows (one question in flight): RoPE + KV write + attention + merge in one launch
+                att = ops.decode_attention_fused(qkv, pos, cpos, slot, self.cs, kv.ko[i], kv.vo[i], attn_rows, H, Hkv, D,
+                                                 k_prefix=kv.kp[i], v_prefix=kv.vp[i])
+            elif grouping is not None:    # rows sharing a prompt prefix attend it once per group (MFMA), own tokens per row
+                q = ops.rope_kv_write(qkv, pos, slot, self.cs, kv.ko[i], kv.vo[i], H, Hkv, D, cpos=cpos)
                 att = ops.decode_attention_grouped(q, kv.ko[i], kv.vo[i], kv.kp[i], kv.vp[i], attn_rows, grouping["groups"],
                                                    grouping["group_rows"], grouping["items"], grouping["n_items"], H, Hkv, D,
                                                    kv.t_pre, kv.t_own, workspace=grouping["workspace"],
                                                    v_prefix_t8=kv.vp8[i] if grouping.get("mfma", True) else None)
             else:
+                q = ops.rope_kv_write(qkv, pos, slot, self.cs, kv.ko[i], kv.vo[i], H, Hkv, D, cpos=cpos)
                 att = ops.decode_attention(q, kv.ko[i], kv.vo[i], attn_rows, H, Hkv, D, k_prefix=kv.kp[i], v_prefix=kv.vp[i],
                                            max_len=kv.t_pre + kv.t_own)
             o = ops.linear_to_norm(att, t[p + "wo"])
             a = ops.rmsnorm(resid, t[p + "ln2"], c.eps, delta=o, resid_out=resid)
-            gu = ops.linear(a, t[p + "wgu"])
-            delta = ops.linear_to_norm(ops.silu_mul(gu), t[p + "wd"])
+            delta = ops.linear_to_norm(ops.swiglu_linear(a, t[p + "wgu"]), t[p + "wd"])
         a = ops.rmsnorm(resid, t["norm"], c.eps, delta=delta)
         return ops.linear(a, t["lm_head"])
 
@@ -488,8 +493,17 @@ class _DecodeRunner:
                         x.copy_(sv)                             # which the real step rewrites before reading it
             torch.cuda.current_stream(self.eng.device).wait_stream(side)
             g = torch.cuda.CUDAGraph()
-            with torch.cuda.graph(g):
-                self.body(kv)
+            # a cyclic-GC run inside the capture may destroy an older engine's graph (hipGraphDestroy / pool release are
+            # illegal while a stream is capturing -> abort): collect before, keep the collector off during the capture
+            gc.collect()
+            gc_was_on = gc.isenabled()
+            gc.disable()
+            try:
+                with torch.cuda.graph(g):
+                    self.body(kv)
+            finally:
+                if gc_was_on:
+                    gc.enable()
             self.graph = g
         if self.graph is not None:
             self.graph.replay()

@@ -12,6 +12,8 @@ from . import _lib
 
 _P, _I, _L, _F = C.c_void_p, C.c_int, C.c_int64, C.c_float
 _SIGS = {
+    "vdd_skinny_swiglu": [_P, _P, _P, _I, _I, _I, _L, _P],
+    "vdd_decode_attention_fused": [_P] * 11 + [_I, _I, _I, _I, _L, _I, _L, _I, _F, _P],
     "vdd_rmsnorm": [_P, _P, _P, _I, _P, _P, _P, _I, _I, _F, _P],
     "vdd_mid_gemm": [_P, _P, _P, _P, _I, _I, _I, _L, _L, _I, _P],
     "vdd_rope_kv_write": [_P, _P, _P, _P, _P, _P, _P, _P, _I, _I, _I, _I, _L, _I, _P],
@@ -161,6 +163,19 @@ def linear(x, w, out=None):
     return torch.matmul(x, w.t(), out=out) if out is not None else torch.matmul(x, w.t())
 
 
+def swiglu_linear(x, w_gate_up, out=None):
+    """silu(x Wg^T) * (x Wu^T) with w_gate_up = [Wg; Wu]: one fused weight-streaming launch for a handful of rows,
+    library GEMM + silu_mul otherwise."""
+    M, K = x.shape
+    F = w_gate_up.shape[0] // 2
+    if M <= SKINNY_MAX_M and K % 128 == 0:
+        _bf16(x, w_gate_up)
+        out = torch.empty(M, F, dtype=x.dtype, device=x.device) if out is None else out
+        _lib.check(_lib_ready().vdd_skinny_swiglu(x.data_ptr(), w_gate_up.data_ptr(), out.data_ptr(), M, F, K, x.stride(0), _st(x)))
+        return out
+    return silu_mul(linear(x, w_gate_up), out=out)
+
+
 _attn_ws = {}
 
 
@@ -184,6 +199,25 @@ def decode_attention(q, k_cache, v_cache, rows, H, Hkv, D, out=None, max_len=Non
     _lib.check(lib.vdd_decode_attention(q.data_ptr(), k_cache.data_ptr(), v_cache.data_ptr(), k_prefix.data_ptr(), v_prefix.data_ptr(),
                                         rows.data_ptr(), out.data_ptr(), ws.data_ptr(), M, H, Hkv, D, k_cache.stride(0), k_cache.shape[2],
                                         k_prefix.stride(0), k_prefix.shape[2], max_len, D ** -0.5, _st(q)))
+    return out
+
+
+FUSED_ATTN_MAX_M = 16     # rows up to which RoPE + KV write + attention + merge run as one launch
+
+
+def decode_attention_fused(qkv, pos, cpos, slot, cos_sin, k_cache, v_cache, rows, H, Hkv, D, out=None, k_prefix=None, v_prefix=None):
+    """Small-M decode attention straight from the un-rotated qkv projection [M, (H+2Hkv)*D]: RoPE, KV-cache write of the new
+    token (index cpos of slot), whole-context attention and merge in one kernel.  Same arguments as rope_kv_write +
+    decode_attention; rows[:, 1] (len) counts the new token."""
+    _bf16(qkv, k_cache, v_cache)
+    M = qkv.shape[0]
+    k_prefix = k_cache if k_prefix is None else k_prefix
+    v_prefix = v_cache if v_prefix is None else v_prefix
+    out = torch.empty(M, H * D, dtype=qkv.dtype, device=qkv.device) if out is None else out
+    _lib.check(_lib_ready().vdd_decode_attention_fused(qkv.data_ptr(), pos.data_ptr(), cpos.data_ptr(), slot.data_ptr(), cos_sin.data_ptr(),
+                                                      k_cache.data_ptr(), v_cache.data_ptr(), k_prefix.data_ptr(), v_prefix.data_ptr(),
+                                                      rows.data_ptr(), out.data_ptr(), M, H, Hkv, D, k_cache.stride(0), k_cache.shape[2],
+                                                      k_prefix.stride(0), k_prefix.shape[2], D ** -0.5, _st(qkv)))
     return out
 
 

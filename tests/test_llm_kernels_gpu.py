@@ -120,6 +120,45 @@ def test_decode_attention_ragged_and_prefix_shared():
         ref = attn_ref(q[m].view(H, D).float(), K, V)
         assert torch.allclose(out[m].float(), ref, rtol=2e-2, atol=2e-2), m
 
+@pytest.mark.parametrize("H,Hkv", [(8, 8), (8, 2)])
+def test_decode_attention_fused_equals_rope_write_then_attention(H, Hkv):
+    """Small-M kernel (RoPE + KV write + whole-context attention + merge in one launch) vs the three-kernel path it
+    replaces: identical cache contents (bit-exact: same RoPE rounding), outputs equal up to the softmax partition order."""
+    O = ops()
+    D, T, S, TP = 128, 720, 5, 640
+    cs = rope_table(800, D)
+    kc, vc = bf(S, Hkv, T, D, seed=31), bf(S, Hkv, T, D, seed=32)
+    kp, vp = bf(2, Hkv, TP, D, seed=33), bf(2, Hkv, TP, D, seed=34)
+    # (slot, len, pslot, plen): len counts the new token; own index = len - 1 - plen
+    rows = torch.tensor([[0, 1, 0, 0], [1, 2, 0, 0], [2, 66, 0, 0], [3, 700, 0, 0], [4, 650, 1, 611]], dtype=torch.int32, device=DEV)
+    M = rows.shape[0]
+    qkv = bf(M, (H + 2 * Hkv) * D, seed=35)
+    pos = (rows[:, 1] - 1).contiguous()
+    cpos = (rows[:, 1] - 1 - rows[:, 3]).contiguous()
+    slot = rows[:, 0].contiguous()
+    k1, v1, k2, v2 = kc.clone(), vc.clone(), kc.clone(), vc.clone()
+    q = O.rope_kv_write(qkv, pos, slot, cs, k1, v1, H, Hkv, D, cpos=cpos)
+    want = O.decode_attention(q, k1, v1, rows, H, Hkv, D, k_prefix=kp, v_prefix=vp)
+    got = O.decode_attention_fused(qkv, pos, cpos, slot, cs, k2, v2, rows, H, Hkv, D, k_prefix=kp, v_prefix=vp)
+    assert torch.equal(k1, k2) and torch.equal(v1, v2)
+    assert torch.allclose(got.float(), want.float(), rtol=2e-2, atol=2e-2), (got.float() - want.float()).abs().max().item()
+
+@pytest.mark.parametrize("M", [1, 2, 7, 8])
+def test_swiglu_linear_equals_gemm_then_silu_mul(M):
+    """Fused gate/up GEMV + SiLU*mul == vdd_skinny_gemm followed by vdd_silu_mul, bit for bit (same k order, same bf16
+    rounding points); a feature count that is not a multiple of the 8-feature block is checked against torch."""
+    O = ops()
+    for F, K in ((11008, 4096), (520, 256), (516, 256)):
+        x = bf(M, K, seed=41)
+        w = bf(2 * F, K, seed=42) * 0.05
+        got = O.swiglu_linear(x, w)
+        assert got.shape == (M, F)
+        if F % 8 == 0:
+            assert torch.equal(got, O.silu_mul(O.skinny_gemm(x, w)))
+        ref = torch.nn.functional.silu((x.float() @ w[:F].float().t()).to(torch.bfloat16).float()).to(torch.bfloat16).float() \
+            * (x.float() @ w[F:].float().t()).to(torch.bfloat16).float()
+        assert torch.allclose(got.float(), ref, rtol=3e-2, atol=3e-2)
+
 
 @pytest.mark.parametrize("D,H,Hkv,causal", [(128, 4, 4, True), (128, 8, 2, True), (64, 4, 4, False)])
 def test_flash_attention_prefill(D, H, Hkv, causal):
