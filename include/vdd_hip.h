@@ -142,6 +142,16 @@ int vdd_skinny_gemm(const void* X, const void* W, const void* R, void* Y, float*
  * launch; replaces vdd_skinny_gemm(N = 2F) + vdd_silu_mul with the same bf16 rounding points. */
 int vdd_skinny_swiglu(const void* X, const void* W_gate_up, void* act, int M, int F, int K, int64_t ldx, void* hip_stream);
 
+/* Pre-tiled weight layout for the skinny kernels: vdd_tile_weight rewrites a row-major W[N,K] (N % 16 == 0, K % 32 == 0) as
+ * [N/16][K/32][64 lanes][8 bf16] so that each wave load of the MFMA B fragment is one contiguous KiB and a wave walks one
+ * sequential HBM stream (the row-major form makes every wave walk 16 streams 2K bytes apart).  swiglu_pairs != 0: W = [Wg; Wu]
+ * and tile t holds rows 8t..8t+7 of Wg followed by rows 8t..8t+7 of Wu (the tile of vdd_skinny_swiglu).  Static weights are
+ * tiled once at load time; the *_tiled entry points compute exactly what their row-major twins compute. */
+int vdd_tile_weight(const void* W, void* W_tiled, int N, int K, int swiglu_pairs, void* hip_stream);
+int vdd_skinny_gemm_tiled(const void* X, const void* W_tiled, const void* R, void* Y, float* Y_slabs, int n_split, int M, int N, int K,
+                          int64_t ldx, int64_t ldr, int64_t ldy, void* hip_stream);
+int vdd_skinny_swiglu_tiled(const void* X, const void* W_gate_up_tiled, void* act, int M, int F, int K, int64_t ldx, void* hip_stream);
+
 /* Decode-regime GEMM, 9 <= M <= 256 rows: Y[M,N] = X[M,K] W[N,K]^T with W streamed from HBM exactly once and the X
  * tile shared through LDS (csrc/vdd_mid_gemm.hip).  Either Y (bf16, n_split == 1) or Y_slabs (fp32 [n_split][M][N]:
  * split-K partial sums, summed by vdd_rmsnorm's delta_slabs input); K % (64 * n_split) == 0. */

@@ -211,7 +211,9 @@ __global__ void __launch_bounds__(256) embed_kernel(const long long* __restrict_
 // is read from HBM exactly once and never staged.  X fragments (A operand, same lane map over
 // rows) are L2-resident re-reads.  MT = number of 16-row M tiles (M <= 16*MT); the four wave
 // partials are summed through LDS.
-template <int MT>
+// TILED: W pre-tiled per (16-row tile, 32-k chunk) as [N/16][K/32][lane = g*16 + ln][8] (vdd_tile_weight layout), so
+// that every wave load instruction reads ONE contiguous KiB and a wave walks a single sequential stream.
+template <int MT, bool TILED>
 __global__ void __launch_bounds__(256) skinny_gemm_kernel(const uint16_t* __restrict__ X, const uint16_t* __restrict__ W,
                                                           const uint16_t* __restrict__ R, uint16_t* __restrict__ Y,
                                                           float* __restrict__ Yslab, int M, int N, int K, long long ldx,
@@ -225,19 +227,21 @@ __global__ void __launch_bounds__(256) skinny_gemm_kernel(const uint16_t* __rest
     const int kq = K / (4 * (int)gridDim.y);
     const int kbeg = ((int)blockIdx.y * 4 + wave) * kq;
     int nrow = n0 + ln; if (nrow >= N) nrow = N - 1;
-    const uint16_t* wp = W + (size_t)nrow * K + kbeg + g * 8;
+    const uint16_t* wp = TILED ? W + (((size_t)blockIdx.x * (K / 32) + kbeg / 32) * 64 + lane) * 8
+                               : W + (size_t)nrow * K + kbeg + g * 8;
+    constexpr int WS = TILED ? 16 : 1;          // tiled: 32 k-elements further = 512 elements further in memory
     const uint16_t* xp[MT];
 #pragma unroll
     for (int t = 0; t < MT; ++t) { int r = t * 16 + ln; if (r >= M) r = M - 1; xp[t] = X + (size_t)r * ldx + kbeg + g * 8; }
     f32x4_t acc[MT];
 #pragma unroll
     for (int t = 0; t < MT; ++t) acc[t] = f32x4_t{0.f, 0.f, 0.f, 0.f};
-    constexpr int U = 4;
+    constexpr int U = 8;
     int k = 0;
     for (; k + 32 * U <= kq; k += 32 * U) {
         bf16x8_t b[U], a[U][MT];
 #pragma unroll
-        for (int u = 0; u < U; ++u) b[u] = *reinterpret_cast<const bf16x8_t*>(wp + k + 32 * u);
+        for (int u = 0; u < U; ++u) b[u] = *reinterpret_cast<const bf16x8_t*>(wp + (size_t)(k + 32 * u) * WS);
 #pragma unroll
         for (int u = 0; u < U; ++u)
 #pragma unroll
@@ -248,7 +252,7 @@ __global__ void __launch_bounds__(256) skinny_gemm_kernel(const uint16_t* __rest
             for (int t = 0; t < MT; ++t) acc[t] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a[u][t], b[u], acc[t], 0, 0, 0);
     }
     for (; k < kq; k += 32) {
-        bf16x8_t b = *reinterpret_cast<const bf16x8_t*>(wp + k);
+        bf16x8_t b = *reinterpret_cast<const bf16x8_t*>(wp + (size_t)k * WS);
 #pragma unroll
         for (int t = 0; t < MT; ++t) {
             bf16x8_t a = *reinterpret_cast<const bf16x8_t*>(xp[t] + k);
@@ -281,6 +285,7 @@ __global__ void __launch_bounds__(256) skinny_gemm_kernel(const uint16_t* __rest
 // (B-fragment lanes ln < 8 -> row f0 + ln) and the 8 matching up columns (ln >= 8 -> row F + f0 + ln - 8), so the
 // epilogue finds gate and up of one feature in the same LDS tile: no [M, 2F] round trip and no silu_mul launch.
 // Rounding as the unfused pair: gate, up -> bf16; silu(gate) -> bf16; product -> bf16.
+template <bool TILED>     // TILED: tile t = rows [8t..8t+7 of Wg, 8t..8t+7 of Wu], laid out as in skinny_gemm_kernel
 __global__ void __launch_bounds__(256) skinny_swiglu_kernel(const uint16_t* __restrict__ X, const uint16_t* __restrict__ W,
                                                             uint16_t* __restrict__ A, int M, int F, int K, long long ldx) {
     __shared__ float part[4][64][4];
@@ -289,23 +294,26 @@ __global__ void __launch_bounds__(256) skinny_swiglu_kernel(const uint16_t* __re
     const int ln = lane & 15, g = lane >> 4;
     const int kq = K / 4, kbeg = wave * kq;
     int f = f0 + (ln & 7); if (f >= F) f = F - 1;
-    const uint16_t* wp = W + ((size_t)(ln < 8 ? 0 : F) + f) * K + kbeg + g * 8;
+    const uint16_t* wp = TILED ? W + (((size_t)blockIdx.x * (K / 32) + kbeg / 32) * 64 + lane) * 8
+                               : W + ((size_t)(ln < 8 ? 0 : F) + f) * K + kbeg + g * 8;
+    constexpr int WS = TILED ? 16 : 1;
     int r = ln; if (r >= M) r = M - 1;
     const uint16_t* xp = X + (size_t)r * ldx + kbeg + g * 8;
     f32x4_t acc = f32x4_t{0.f, 0.f, 0.f, 0.f};
-    constexpr int U = 4;
+    constexpr int U = 8;
     int k = 0;
     for (; k + 32 * U <= kq; k += 32 * U) {
         bf16x8_t b[U], a[U];
 #pragma unroll
-        for (int u = 0; u < U; ++u) b[u] = *reinterpret_cast<const bf16x8_t*>(wp + k + 32 * u);
+        for (int u = 0; u < U; ++u) b[u] = *reinterpret_cast<const bf16x8_t*>(wp + (size_t)(k + 32 * u) * WS);
 #pragma unroll
         for (int u = 0; u < U; ++u) a[u] = *reinterpret_cast<const bf16x8_t*>(xp + k + 32 * u);
 #pragma unroll
         for (int u = 0; u < U; ++u) acc = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a[u], b[u], acc, 0, 0, 0);
     }
     for (; k < kq; k += 32)
-        acc = __builtin_amdgcn_mfma_f32_16x16x32_bf16(*reinterpret_cast<const bf16x8_t*>(xp + k), *reinterpret_cast<const bf16x8_t*>(wp + k), acc, 0, 0, 0);
+        acc = __builtin_amdgcn_mfma_f32_16x16x32_bf16(*reinterpret_cast<const bf16x8_t*>(xp + k),
+                                                      *reinterpret_cast<const bf16x8_t*>(wp + (size_t)k * WS), acc, 0, 0, 0);
 #pragma unroll
     for (int rr = 0; rr < 4; ++rr) part[wave][lane][rr] = acc[rr];
     __syncthreads();
@@ -454,6 +462,26 @@ __global__ void __launch_bounds__(NW * 64) decode_attn_fused_kernel(const uint16
     const int p = pos[row], cp = cpos[row];
     const int kvh = head / (H / Hkv);
     const uint16_t* src = qkv + (size_t)row * (size_t)((H + 2 * Hkv) * D);
+    // context pointers and the FIRST batch of K/V loads go out before the RoPE arithmetic (they do not depend on q)
+    const size_t hoff = (size_t)kvh * t_max * D + j * 8, poff = (size_t)kvh * pre_tmax * D + j * 8;
+    const uint16_t* k_own = kc + (size_t)ar.slot * slot_stride + hoff - (size_t)ar.plen * D;
+    const uint16_t* v_own = vc + (size_t)ar.slot * slot_stride + hoff - (size_t)ar.plen * D;
+    const uint16_t* k_pre = kpre + (size_t)ar.pslot * pre_stride + poff;
+    const uint16_t* v_pre = vpre + (size_t)ar.pslot * pre_stride + poff;
+    const int n_old = ar.len - 1, kl = wave * 4 + g;
+    constexpr int U = 4, STEP = NW * 4;
+    uint4 kn_[U], vn_[U];
+    auto fetch = [&](int t0) {
+#pragma unroll
+        for (int u = 0; u < U; ++u) {
+            const int t = t0 + STEP * u;
+            const int tt = t < n_old ? t : n_old - 1;
+            const bool pre = tt < ar.plen;
+            kn_[u] = *reinterpret_cast<const uint4*>((pre ? k_pre : k_own) + (size_t)tt * D);
+            vn_[u] = *reinterpret_cast<const uint4*>((pre ? v_pre : v_own) + (size_t)tt * D);
+        }
+    };
+    if (kl < n_old) fetch(kl);
     // rotate_half RoPE: lane j < 8 holds dims 8j.. (first half), lane j + 8 the partner dims; same rounding as rope_kv_kernel
     const float* cs = cs_table + ((size_t)p * (D / 2) + (j & 7) * 8) * 2;
     const float4 c0 = *reinterpret_cast<const float4*>(cs), c1 = *reinterpret_cast<const float4*>(cs + 4),
@@ -479,24 +507,12 @@ __global__ void __launch_bounds__(NW * 64) decode_attn_fused_kernel(const uint16
         *reinterpret_cast<uint4*>(kc + o) = kn;
         *reinterpret_cast<uint4*>(vc + o) = vn;
     }
-    const size_t hoff = (size_t)kvh * t_max * D + j * 8, poff = (size_t)kvh * pre_tmax * D + j * 8;
-    const uint16_t* k_own = kc + (size_t)ar.slot * slot_stride + hoff - (size_t)ar.plen * D;
-    const uint16_t* v_own = vc + (size_t)ar.slot * slot_stride + hoff - (size_t)ar.plen * D;
-    const uint16_t* k_pre = kpre + (size_t)ar.pslot * pre_stride + poff;
-    const uint16_t* v_pre = vpre + (size_t)ar.pslot * pre_stride + poff;
     float m = -INFINITY, l = 0.f, acc[8] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
-    const int n_old = ar.len - 1, kl = wave * 4 + g;
-    constexpr int U = 4, STEP = NW * 4;
     for (int t0 = kl; t0 < n_old; t0 += STEP * U) {
         uint4 kv[U], vv[U];
 #pragma unroll
-        for (int u = 0; u < U; ++u) {
-            const int t = t0 + STEP * u;
-            const int tt = t < n_old ? t : n_old - 1;
-            const bool pre = tt < ar.plen;
-            kv[u] = *reinterpret_cast<const uint4*>((pre ? k_pre : k_own) + (size_t)tt * D);
-            vv[u] = *reinterpret_cast<const uint4*>((pre ? v_pre : v_own) + (size_t)tt * D);
-        }
+        for (int u = 0; u < U; ++u) { kv[u] = kn_[u]; vv[u] = vn_[u]; }
+        if (t0 + STEP * U < n_old) fetch(t0 + STEP * U);      // next batch in flight under this batch's arithmetic
 #pragma unroll
         for (int u = 0; u < U; ++u) {
             float sc = dot8(qv, kv[u]);
@@ -740,6 +756,20 @@ __global__ void __launch_bounds__(256) decode_attn_prefix_mfma_kernel(const uint
     }
 }
 
+// Weight re-layout for the TILED skinny kernels: out[tile][k/32][g*16 + ln][8] = W[row(tile, ln)][k32*32 + g*8 .. +7], with
+// row = 16 tile + ln, or for swiglu_pairs (W = [Wg; Wu], N = 2F): ln < 8 -> Wg row 8 tile + ln, else Wu row 8 tile + ln - 8.
+__global__ void __launch_bounds__(256) tile_weight_kernel(const uint16_t* __restrict__ W, uint16_t* __restrict__ out, int N, int K,
+                                                          int swiglu_pairs) {
+    const long long i = (long long)blockIdx.x * 256 + threadIdx.x;       // one 16-byte fragment
+    if (i >= (long long)N * K / 8) return;
+    const int lane = (int)(i & 63), ln = lane & 15, g = lane >> 4;
+    const long long c = i >> 6;
+    const int kc = (int)(c % (K / 32));
+    const int tile = (int)(c / (K / 32));
+    const int row = swiglu_pairs ? (ln < 8 ? 8 * tile + ln : N / 2 + 8 * tile + ln - 8) : 16 * tile + ln;
+    reinterpret_cast<uint4*>(out)[i] = *reinterpret_cast<const uint4*>(W + (size_t)row * K + kc * 32 + g * 8);
+}
+
 inline int ok(hipError_t) { return hipGetLastError() == hipSuccess ? VDD_OK : VDD_ERR_LAUNCH; }
 
 }  // namespace
@@ -791,26 +821,57 @@ int vdd_embed(const int64_t* ids, const void* table, void* out, int M, int d, vo
     return ok(hipSuccess);
 }
 
-int vdd_skinny_gemm(const void* X, const void* W, const void* R, void* Y, float* Y_slabs, int n_split, int M, int N, int K,
-                    int64_t ldx, int64_t ldr, int64_t ldy, void* stream) {
+static int skinny_gemm_launch(const void* X, const void* W, const void* R, void* Y, float* Y_slabs, int n_split, int M, int N, int K,
+                              int64_t ldx, int64_t ldr, int64_t ldy, void* stream, bool tiled) {
     if (M <= 0 || N <= 0) return VDD_OK;
     if (!X || !W || (!Y && !Y_slabs) || n_split < 1 || K % (128 * n_split) != 0 || M > 64 || (ldx % 8) != 0) return VDD_ERR_INVALID_ARG;
     if (!Y_slabs && n_split != 1) return VDD_ERR_INVALID_ARG;
+    if (tiled && N % 16 != 0) return VDD_ERR_INVALID_ARG;
     hipStream_t st = (hipStream_t)stream;
     dim3 grid((N + 15) / 16, n_split), block(256);
     auto x = (const uint16_t*)X; auto w = (const uint16_t*)W; auto r = (const uint16_t*)R; auto y = (uint16_t*)Y;
-    if (M <= 16) hipLaunchKernelGGL(skinny_gemm_kernel<1>, grid, block, 0, st, x, w, r, y, Y_slabs, M, N, K, (long long)ldx, (long long)ldr, (long long)ldy);
-    else if (M <= 32) hipLaunchKernelGGL(skinny_gemm_kernel<2>, grid, block, 0, st, x, w, r, y, Y_slabs, M, N, K, (long long)ldx, (long long)ldr, (long long)ldy);
-    else hipLaunchKernelGGL(skinny_gemm_kernel<4>, grid, block, 0, st, x, w, r, y, Y_slabs, M, N, K, (long long)ldx, (long long)ldr, (long long)ldy);
+#define VDD_SKINNY(MT, TL) hipLaunchKernelGGL((skinny_gemm_kernel<MT, TL>), grid, block, 0, st, x, w, r, y, Y_slabs, M, N, K, (long long)ldx, (long long)ldr, (long long)ldy)
+    if (tiled) { if (M <= 16) VDD_SKINNY(1, true); else if (M <= 32) VDD_SKINNY(2, true); else VDD_SKINNY(4, true); }
+    else { if (M <= 16) VDD_SKINNY(1, false); else if (M <= 32) VDD_SKINNY(2, false); else VDD_SKINNY(4, false); }
+#undef VDD_SKINNY
+    return ok(hipSuccess);
+}
+
+int vdd_skinny_gemm(const void* X, const void* W, const void* R, void* Y, float* Y_slabs, int n_split, int M, int N, int K,
+                    int64_t ldx, int64_t ldr, int64_t ldy, void* stream) {
+    return skinny_gemm_launch(X, W, R, Y, Y_slabs, n_split, M, N, K, ldx, ldr, ldy, stream, false);
+}
+
+int vdd_skinny_gemm_tiled(const void* X, const void* W_tiled, const void* R, void* Y, float* Y_slabs, int n_split, int M, int N, int K,
+                          int64_t ldx, int64_t ldr, int64_t ldy, void* stream) {
+    return skinny_gemm_launch(X, W_tiled, R, Y, Y_slabs, n_split, M, N, K, ldx, ldr, ldy, stream, true);
+}
+
+int vdd_tile_weight(const void* W, void* W_tiled, int N, int K, int swiglu_pairs, void* stream) {
+    if (N <= 0) return VDD_OK;
+    if (!W || !W_tiled || N % 16 != 0 || K % 32 != 0 || (swiglu_pairs && N % 32 != 0)) return VDD_ERR_INVALID_ARG;
+    const long long n = (long long)N * K / 8;
+    hipLaunchKernelGGL(tile_weight_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, (hipStream_t)stream, (const uint16_t*)W,
+                       (uint16_t*)W_tiled, N, K, swiglu_pairs);
+    return ok(hipSuccess);
+}
+
+static int skinny_swiglu_launch(const void* X, const void* W, void* act, int M, int F, int K, int64_t ldx, void* stream, bool tiled) {
+    if (M <= 0 || F <= 0) return VDD_OK;
+    if (!X || !W || !act || M > 16 || K % 128 != 0 || (ldx % 8) != 0 || (tiled && F % 16 != 0)) return VDD_ERR_INVALID_ARG;
+    if (tiled) hipLaunchKernelGGL(skinny_swiglu_kernel<true>, dim3((F + 7) / 8), dim3(256), 0, (hipStream_t)stream, (const uint16_t*)X,
+                                  (const uint16_t*)W, (uint16_t*)act, M, F, K, (long long)ldx);
+    else hipLaunchKernelGGL(skinny_swiglu_kernel<false>, dim3((F + 7) / 8), dim3(256), 0, (hipStream_t)stream, (const uint16_t*)X,
+                            (const uint16_t*)W, (uint16_t*)act, M, F, K, (long long)ldx);
     return ok(hipSuccess);
 }
 
 int vdd_skinny_swiglu(const void* X, const void* W_gate_up, void* act, int M, int F, int K, int64_t ldx, void* stream) {
-    if (M <= 0 || F <= 0) return VDD_OK;
-    if (!X || !W_gate_up || !act || M > 16 || K % 128 != 0 || (ldx % 8) != 0) return VDD_ERR_INVALID_ARG;
-    hipLaunchKernelGGL(skinny_swiglu_kernel, dim3((F + 7) / 8), dim3(256), 0, (hipStream_t)stream, (const uint16_t*)X,
-                       (const uint16_t*)W_gate_up, (uint16_t*)act, M, F, K, (long long)ldx);
-    return ok(hipSuccess);
+    return skinny_swiglu_launch(X, W_gate_up, act, M, F, K, ldx, stream, false);
+}
+
+int vdd_skinny_swiglu_tiled(const void* X, const void* W_gate_up_tiled, void* act, int M, int F, int K, int64_t ldx, void* stream) {
+    return skinny_swiglu_launch(X, W_gate_up_tiled, act, M, F, K, ldx, stream, true);
 }
 
 int vdd_decode_attention(const void* q, const void* k_cache, const void* v_cache, const void* k_prefix, const void* v_prefix,

@@ -12,6 +12,8 @@ from . import _lib
 
 _P, _I, _L, _F = C.c_void_p, C.c_int, C.c_int64, C.c_float
 _SIGS = {
+    "vdd_tile_weight": [_P, _P, _I, _I, _I, _P],
+    "vdd_skinny_swiglu_tiled": [_P, _P, _P, _I, _I, _I, _L, _P],
     "vdd_skinny_swiglu": [_P, _P, _P, _I, _I, _I, _L, _P],
     "vdd_decode_attention_fused": [_P] * 11 + [_I, _I, _I, _I, _L, _I, _L, _I, _F, _P],
     "vdd_rmsnorm": [_P, _P, _P, _I, _P, _P, _P, _I, _I, _F, _P],
@@ -20,6 +22,7 @@ _SIGS = {
     "vdd_silu_mul": [_P, _P, _L, _I, _P],
     "vdd_embed": [_P, _P, _P, _I, _I, _P],
     "vdd_skinny_gemm": [_P, _P, _P, _P, _P, _I, _I, _I, _I, _L, _L, _L, _P],
+    "vdd_skinny_gemm_tiled": [_P, _P, _P, _P, _P, _I, _I, _I, _I, _L, _L, _L, _P],
     "vdd_decode_attention": [_P, _P, _P, _P, _P, _P, _P, _P, _I, _I, _I, _I, _L, _I, _L, _I, _I, _F, _P],
     "vdd_prefix_v_transpose": [_P, _P, _P, _I, _I, _I, _I, _P],
     "vdd_decode_attention_grouped": [_P, _P, _P, _P, _P, _P, _P, _P, _P, _P, _I, _P, _P, _I, _I, _I, _I, _L, _I, _L, _I, _I, _I, _F, _P],
@@ -117,18 +120,40 @@ def embed(ids, table, out=None):
     return out
 
 
+class TiledWeight:
+    """A static [N, K] weight re-laid out by vdd_tile_weight for the skinny kernels (one contiguous KiB per wave load)."""
+
+    def __init__(self, w, swiglu_pairs=False):
+        _bf16(w)
+        N, K = w.shape
+        self.shape, self.swiglu_pairs = (N, K), bool(swiglu_pairs)
+        self.data = torch.empty_like(w)
+        _lib.check(_lib_ready().vdd_tile_weight(w.data_ptr(), self.data.data_ptr(), N, K, int(self.swiglu_pairs), _st(w)))
+
+    @staticmethod
+    def supports(w, swiglu_pairs=False):
+        return w.shape[0] % (32 if swiglu_pairs else 16) == 0 and w.shape[1] % 128 == 0
+
+
 def skinny_gemm(x, w, resid=None, out=None, n_split=1, slabs=False):
-    """x [M<=64, K] @ w[N, K]^T (+ resid [M, N]) -> [M, N]; streams w from HBM exactly once.
+    """x [M<=64, K] @ w[N, K]^T (+ resid [M, N]) -> [M, N]; streams w from HBM exactly once.  w: tensor or TiledWeight.
     slabs=True: returns the fp32 split-K partials [n_split, M, N] instead (feed them to rmsnorm as `delta`)."""
+    tiled = isinstance(w, TiledWeight)
+    if tiled:
+        assert not w.swiglu_pairs
+        N = w.shape[0]
+        fn, w = _lib_ready().vdd_skinny_gemm_tiled, w.data
+    else:
+        N = w.shape[0]
+        fn = _lib_ready().vdd_skinny_gemm
     _bf16(x, w, resid)
     M, K = x.shape
-    N = w.shape[0]
     if slabs:
         out = torch.empty(n_split, M, N, dtype=torch.float32, device=x.device) if out is None else out
-        _lib.check(_lib_ready().vdd_skinny_gemm(x.data_ptr(), w.data_ptr(), None, None, out.data_ptr(), n_split, M, N, K, x.stride(0), 0, N, _st(x)))
+        _lib.check(fn(x.data_ptr(), w.data_ptr(), None, None, out.data_ptr(), n_split, M, N, K, x.stride(0), 0, N, _st(x)))
         return out
     out = torch.empty(M, N, dtype=x.dtype, device=x.device) if out is None else out
-    _lib.check(_lib_ready().vdd_skinny_gemm(x.data_ptr(), w.data_ptr(), resid.data_ptr() if resid is not None else None,
+    _lib.check(fn(x.data_ptr(), w.data_ptr(), resid.data_ptr() if resid is not None else None,
                                             out.data_ptr(), None, 1, M, N, K, x.stride(0), resid.stride(0) if resid is not None else 0,
                                             out.stride(0), _st(x)))
     return out
@@ -168,6 +193,12 @@ def swiglu_linear(x, w_gate_up, out=None):
     library GEMM + silu_mul otherwise."""
     M, K = x.shape
     F = w_gate_up.shape[0] // 2
+    if isinstance(w_gate_up, TiledWeight):
+        assert w_gate_up.swiglu_pairs and M <= 16
+        _bf16(x)
+        out = torch.empty(M, F, dtype=x.dtype, device=x.device) if out is None else out
+        _lib.check(_lib_ready().vdd_skinny_swiglu_tiled(x.data_ptr(), w_gate_up.data.data_ptr(), out.data_ptr(), M, F, K, x.stride(0), _st(x)))
+        return out
     if M <= SKINNY_MAX_M and K % 128 == 0:
         _bf16(x, w_gate_up)
         out = torch.empty(M, F, dtype=x.dtype, device=x.device) if out is None else out
