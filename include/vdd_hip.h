@@ -182,16 +182,20 @@ int vdd_decode_attention_fused(const void* qkv, const int32_t* pos, const int32_
 
 /* Same result as vdd_decode_attention when every row with prefix_len > 0 is listed in exactly one group of rows
  * sharing (prefix_slot, prefix_len): groups[g] = {row_off, n_rows, prefix_slot, prefix_len} (int32 x4) indexes
- * group_rows[]; items[i] = {group, first_row_of_16_row_slice, 64-key chunk, 0} (int32 x4) is the host-built work
- * list of the prefix pass (one block per item and head).  Each 64-key prefix K/V tile is staged ONCE per group (per 16 rows of it) in LDS and every row of the
- * group attends it from there (each prefix byte fetched once per group, not once per row); own tokens go through
- * the split-KV kernel.
+ * group_rows[]; items[i] = {group, first_row_of_16_row_slice, item index inside the prefix, 0} (int32 x4) is the
+ * host-built work list of the prefix pass (one wave per item and head); item j of a group covers keys
+ * [j * 64 * prefix_chunks_per_item, (j + 1) * 64 * prefix_chunks_per_item) of its prefix.
+ * With v_prefix_t8 (the vdd_prefix_v_transpose image of v_prefix) the prefix pass runs on MFMA: the rows of a slice are
+ * the M dimension, each prefix byte leaves HBM once per group, and an item walks its 64-key chunks with an online
+ * softmax so that it leaves ONE partial per (row, head).  Without it (prefix_chunks_per_item must be 1) a 64-key K/V tile
+ * is staged once per slice in LDS.  Own tokens go through the split-KV kernel; one combine merges all partials.
  * Workspace: vdd_decode_attention_workspace_bytes(M, H, D, round_up(max_prefix_len, 64) + round_up(max_own_len, 64)). */
 int vdd_decode_attention_grouped(const void* q, const void* k_cache, const void* v_cache, const void* k_prefix, const void* v_prefix,
                                  const void* v_prefix_t8 /* optional: vdd_prefix_v_transpose image -> MFMA prefix pass */,
                                  const int32_t* rows, const int32_t* groups, const int32_t* group_rows, const int32_t* items, int n_items,
                                  void* out, void* workspace, int M, int H, int Hkv, int D, int64_t slot_stride, int t_max,
-                                 int64_t prefix_stride, int prefix_tmax, int max_prefix_len, int max_own_len, float scale, void* hip_stream);
+                                 int64_t prefix_stride, int prefix_tmax, int max_prefix_len, int max_own_len,
+                                 int prefix_chunks_per_item, float scale, void* hip_stream);
 
 /* Key-blocked transposed copy of the prefix pool's V: v_prefix_t8[slot][kv_head][t/8][d][t%8] for t < prefix_len_of_slot[slot]
  * (same size and slot stride as v_prefix; t_max % 8 == 0).  Built once after the prefix prefill; lets the grouped decode

@@ -415,12 +415,13 @@ __global__ void __launch_bounds__(256) decode_attn_kernel(const uint16_t* __rest
 // kernel; only when grouped), then own/whole-context chunks.
 template <int D>
 __global__ void __launch_bounds__(256) decode_attn_combine_kernel(const float* __restrict__ ws, const AttnRow* __restrict__ rows,
-                                                                  uint16_t* __restrict__ out, int H, int nchunk, int npre) {
+                                                                  uint16_t* __restrict__ out, int H, int nchunk, int npre,
+                                                                  int pre_keys) {
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     const int head = blockIdx.x * 4 + wave, row = blockIdx.y;
     if (head >= H) return;
     const AttnRow ar = rows[row];
-    const int used_pre = npre > 0 ? (ar.plen + ATT_CH - 1) / ATT_CH : 0;
+    const int used_pre = npre > 0 ? (ar.plen + pre_keys - 1) / pre_keys : 0;
     const int own_len = npre > 0 ? ar.len - ar.plen : ar.len;
     const int used_own = min(nchunk - npre, (own_len + ATT_CH - 1) / ATT_CH);
     const float* base = ws + ((size_t)row * H + head) * nchunk * (D + 2);
@@ -662,7 +663,7 @@ __global__ void __launch_bounds__(256) decode_attn_prefix_mfma_kernel(const uint
                                                                       const uint16_t* __restrict__ vt8, const GroupDesc* __restrict__ groups,
                                                                       const int* __restrict__ group_rows, const int4* __restrict__ items,
                                                                       float* __restrict__ ws, int H, int Hkv, long long pre_stride,
-                                                                      int pre_tmax, float scale, int nchunk) {
+                                                                      int pre_tmax, float scale, int nchunk, int sub) {
     static_assert(D == 128, "");
     constexpr int KS = D / 32, NT = D / 16;
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, ln = lane & 15, g = lane >> 4;
@@ -670,9 +671,10 @@ __global__ void __launch_bounds__(256) decode_attn_prefix_mfma_kernel(const uint
     if (head >= H) return;
     const int4 item = items[blockIdx.x];
     const GroupDesc gd = groups[item.x];
-    const int r0 = item.y, chunk = item.z, k0 = chunk * ATT_CH;
-    if (r0 >= gd.n_rows || k0 >= gd.plen) return;
-    const int k1 = min(gd.plen, k0 + ATT_CH);
+    // an item = `sub` consecutive 64-key chunks (online softmax across them): one partial per (row, head, item)
+    const int r0 = item.y, part = item.z, kbeg = part * ATT_CH * sub;
+    if (r0 >= gd.n_rows || kbeg >= gd.plen) return;
+    const int k1 = min(gd.plen, kbeg + ATT_CH * sub);
     const int kvh = head / (H / Hkv);
     // B operand of S^T: this lane's query row
     int rq = r0 + ln; if (rq >= gd.n_rows) rq = gd.n_rows - 1;
@@ -686,56 +688,71 @@ __global__ void __launch_bounds__(256) decode_attn_prefix_mfma_kernel(const uint
     const size_t hbase = (size_t)gd.pslot * pre_stride + (size_t)kvh * pre_tmax * D;
     const uint16_t* kb = kpre + hbase;
     const uint16_t* vb = vt8 + hbase;
-    // S^T: 4 tiles (a0, b0 | a1, b1); MFMA row i = ln of the A operand
-    f32x4_t s[4];
-#pragma unroll
-    for (int t = 0; t < 4; ++t) {
-        s[t] = f32x4_t{0.f, 0.f, 0.f, 0.f};
-        int key = k0 + (t >> 1) * 32 + (ln >> 2) * 8 + (t & 1) * 4 + (ln & 3);
-        if (key >= k1) key = k1 - 1;
-        const uint16_t* kp = kb + (size_t)key * D + g * 8;
-#pragma unroll
-        for (int ks = 0; ks < KS; ++ks) {
-            const bf16x8_t kf = *reinterpret_cast<const bf16x8_t*>(kp + ks * 32);
-            s[t] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(kf, qf[ks], s[t], 0, 0, 0);
-        }
-    }
-    // column = query ln; this lane's rows 4 g + r are keys k0 + 32 (t>>1) + 8 g + 4 (t&1) + r
-    float mx = -INFINITY;
-#pragma unroll
-    for (int t = 0; t < 4; ++t)
-#pragma unroll
-        for (int r = 0; r < 4; ++r) {
-            const int key = k0 + (t >> 1) * 32 + g * 8 + (t & 1) * 4 + r;
-            const float v = key < k1 ? s[t][r] * scale : -INFINITY;
-            s[t][r] = v; mx = fmaxf(mx, v);
-        }
-    mx = fmaxf(mx, __shfl_xor(mx, 16)); mx = fmaxf(mx, __shfl_xor(mx, 32));
-    float lsum = 0.f;
-    bf16x8_t pf[2];
-#pragma unroll
-    for (int kk = 0; kk < 2; ++kk)
-#pragma unroll
-        for (int e = 0; e < 8; ++e) {
-            const float pv = __expf(s[kk * 2 + (e >> 2)][e & 3] - mx);      // exp(-inf) = 0 for masked keys
-            lsum += pv;
-            pf[kk][e] = (short)f2bf(pv);
-        }
-    lsum += __shfl_xor(lsum, 16); lsum += __shfl_xor(lsum, 32);
-    // O = P V: B fragment lane (dim = 16 nt + ln, g) = V[k0 + 32 kk + 8 g .. + 7][dim] = 16 B of the VT8 image
     f32x4_t o[NT];
 #pragma unroll
     for (int nt = 0; nt < NT; ++nt) o[nt] = f32x4_t{0.f, 0.f, 0.f, 0.f};
+    float mrun = -INFINITY, lrun = 0.f;          // of query ln (replicated over g)
+    for (int k0 = kbeg; k0 < k1; k0 += ATT_CH) {
+        // S^T: 4 tiles (a0, b0 | a1, b1); MFMA row i = ln of the A operand
+        f32x4_t s[4];
 #pragma unroll
-    for (int kk = 0; kk < 2; ++kk) {
-        int kblk = (k0 + kk * 32) / 8 + g;
-        if (kblk * 8 >= k1) kblk = (k1 - 1) / 8;      // fully masked 8-key block: any finite data will do (p = 0)
-        if (k0 + kk * 32 < k1) {
-            const uint16_t* vp = vb + ((size_t)kblk * D) * 8 + (size_t)ln * 8;
+        for (int t = 0; t < 4; ++t) {
+            s[t] = f32x4_t{0.f, 0.f, 0.f, 0.f};
+            int key = k0 + (t >> 1) * 32 + (ln >> 2) * 8 + (t & 1) * 4 + (ln & 3);
+            if (key >= k1) key = k1 - 1;
+            const uint16_t* kp = kb + (size_t)key * D + g * 8;
 #pragma unroll
-            for (int nt = 0; nt < NT; ++nt) {
-                const bf16x8_t vf = *reinterpret_cast<const bf16x8_t*>(vp + (size_t)nt * 16 * 8);
-                o[nt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(pf[kk], vf, o[nt], 0, 0, 0);
+            for (int ks = 0; ks < KS; ++ks) {
+                const bf16x8_t kf = *reinterpret_cast<const bf16x8_t*>(kp + ks * 32);
+                s[t] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(kf, qf[ks], s[t], 0, 0, 0);
+            }
+        }
+        // column = query ln; this lane's rows 4 g + r are keys k0 + 32 (t>>1) + 8 g + 4 (t&1) + r
+        float mx = -INFINITY;
+#pragma unroll
+        for (int t = 0; t < 4; ++t)
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                const int key = k0 + (t >> 1) * 32 + g * 8 + (t & 1) * 4 + r;
+                const float v = key < k1 ? s[t][r] * scale : -INFINITY;
+                s[t][r] = v; mx = fmaxf(mx, v);
+            }
+        mx = fmaxf(mx, __shfl_xor(mx, 16)); mx = fmaxf(mx, __shfl_xor(mx, 32));
+        const float mnew = fmaxf(mrun, mx);                      // finite: every chunk holds >= 1 valid key
+        const float corr = __expf(mrun - mnew);                  // exp(-inf) = 0 on the first chunk
+        float lsum = 0.f;
+        bf16x8_t pf[2];
+#pragma unroll
+        for (int kk = 0; kk < 2; ++kk)
+#pragma unroll
+            for (int e = 0; e < 8; ++e) {
+                const float pv = __expf(s[kk * 2 + (e >> 2)][e & 3] - mnew);      // exp(-inf) = 0 for masked keys
+                lsum += pv;
+                pf[kk][e] = (short)f2bf(pv);
+            }
+        lsum += __shfl_xor(lsum, 16); lsum += __shfl_xor(lsum, 32);
+        lrun = lrun * corr + lsum;
+        mrun = mnew;
+        if (k0 > kbeg) {        // O rows are queries 4 g + r: their rescale factor lives in the lanes of column 4 g + r
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                const float cr = __shfl(corr, 4 * g + r);
+#pragma unroll
+                for (int nt = 0; nt < NT; ++nt) o[nt][r] *= cr;
+            }
+        }
+        // O += P V: B fragment lane (dim = 16 nt + ln, g) = V[k0 + 32 kk + 8 g .. + 7][dim] = 16 B of the VT8 image
+#pragma unroll
+        for (int kk = 0; kk < 2; ++kk) {
+            int kblk = (k0 + kk * 32) / 8 + g;
+            if (kblk * 8 >= k1) kblk = (k1 - 1) / 8;      // fully masked 8-key block: any finite data will do (p = 0)
+            if (k0 + kk * 32 < k1) {
+                const uint16_t* vp = vb + ((size_t)kblk * D) * 8 + (size_t)ln * 8;
+#pragma unroll
+                for (int nt = 0; nt < NT; ++nt) {
+                    const bf16x8_t vf = *reinterpret_cast<const bf16x8_t*>(vp + (size_t)nt * 16 * 8);
+                    o[nt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(pf[kk], vf, o[nt], 0, 0, 0);
+                }
             }
         }
     }
@@ -745,14 +762,14 @@ __global__ void __launch_bounds__(256) decode_attn_prefix_mfma_kernel(const uint
         const int rr = r0 + g * 4 + r;
         if (rr < gd.n_rows) {
             const int orow = group_rows[gd.row_off + rr];
-            float* wsp = ws + (((size_t)orow * H + head) * nchunk + chunk) * (D + 2);
+            float* wsp = ws + (((size_t)orow * H + head) * nchunk + part) * (D + 2);
 #pragma unroll
             for (int nt = 0; nt < NT; ++nt) wsp[nt * 16 + ln] = o[nt][r];
         }
     }
     if (g == 0 && r0 + ln < gd.n_rows) {          // (m, l) of query ln live in the lanes of column ln
-        float* wsp = ws + (((size_t)qrow * H + head) * nchunk + chunk) * (D + 2);
-        wsp[D] = mx; wsp[D + 1] = lsum;
+        float* wsp = ws + (((size_t)qrow * H + head) * nchunk + part) * (D + 2);
+        wsp[D] = mrun; wsp[D + 1] = lrun;
     }
 }
 
@@ -886,7 +903,7 @@ int vdd_decode_attention(const void* q, const void* k_cache, const void* v_cache
                        (const AttnRow*)rows, (float*)workspace, H, Hkv, (long long)slot_stride, t_max, (long long)prefix_stride,
                        prefix_tmax, scale, nchunk, 0, 0);
     hipLaunchKernelGGL(decode_attn_combine_kernel<128>, dim3((H + 3) / 4, M), dim3(256), 0, st, (const float*)workspace,
-                       (const AttnRow*)rows, (uint16_t*)out, H, nchunk, 0);
+                       (const AttnRow*)rows, (uint16_t*)out, H, nchunk, 0, ATT_CH);
     return ok(hipSuccess);
 }
 
@@ -908,17 +925,21 @@ int vdd_decode_attention_grouped(const void* q, const void* k_cache, const void*
                                  const void* v_prefix_t8, const int32_t* rows, const int32_t* groups, const int32_t* group_rows,
                                  const int32_t* items, int n_items, void* out, void* workspace, int M, int H, int Hkv, int D,
                                  int64_t slot_stride, int t_max, int64_t prefix_stride, int prefix_tmax, int max_prefix_len,
-                                 int max_own_len, float scale, void* stream) {
+                                 int max_own_len, int prefix_chunks_per_item, float scale, void* stream) {
     if (M <= 0) return VDD_OK;
     if (!q || !k_cache || !v_cache || !k_prefix || !v_prefix || !rows || !groups || !group_rows || !items || !out || !workspace || D != 128 ||
-        H % Hkv != 0 || max_own_len <= 0 || max_prefix_len < 0 || n_items < 0) return VDD_ERR_INVALID_ARG;
-    const int npre = (max_prefix_len + ATT_CH - 1) / ATT_CH, nown = (max_own_len + ATT_CH - 1) / ATT_CH;
+        H % Hkv != 0 || max_own_len <= 0 || max_prefix_len < 0 || n_items < 0 || prefix_chunks_per_item < 1) return VDD_ERR_INVALID_ARG;
+    // the LDS fallback kernel leaves one partial per 64-key chunk; the MFMA kernel one per item of `sub` chunks
+    const int sub = v_prefix_t8 != nullptr ? prefix_chunks_per_item : 1;
+    if (v_prefix_t8 == nullptr && prefix_chunks_per_item != 1) return VDD_ERR_INVALID_ARG;
+    const int pre_keys = ATT_CH * sub;
+    const int npre = (max_prefix_len + pre_keys - 1) / pre_keys, nown = (max_own_len + ATT_CH - 1) / ATT_CH;
     const int nchunk = npre + nown;
     hipStream_t st = (hipStream_t)stream;
     if (n_items > 0 && npre > 0 && v_prefix_t8 != nullptr) {
         hipLaunchKernelGGL(decode_attn_prefix_mfma_kernel<128>, dim3(n_items, (H + 3) / 4), dim3(256), 0, st,
                            (const uint16_t*)q, (const uint16_t*)k_prefix, (const uint16_t*)v_prefix_t8, (const GroupDesc*)groups, group_rows,
-                           (const int4*)items, (float*)workspace, H, Hkv, (long long)prefix_stride, prefix_tmax, scale, nchunk);
+                           (const int4*)items, (float*)workspace, H, Hkv, (long long)prefix_stride, prefix_tmax, scale, nchunk, sub);
     } else if (n_items > 0 && npre > 0) {
         hipLaunchKernelGGL(decode_attn_prefix_kernel<128>, dim3(n_items, H), dim3(256), 0, st,
                            (const uint16_t*)q, (const uint16_t*)k_prefix, (const uint16_t*)v_prefix, (const GroupDesc*)groups, group_rows,
@@ -929,7 +950,7 @@ int vdd_decode_attention_grouped(const void* q, const void* k_cache, const void*
                        (const AttnRow*)rows, (float*)workspace, H, Hkv, (long long)slot_stride, t_max, (long long)prefix_stride,
                        prefix_tmax, scale, nchunk, 1, npre);
     hipLaunchKernelGGL(decode_attn_combine_kernel<128>, dim3((H + 3) / 4, M), dim3(256), 0, st, (const float*)workspace,
-                       (const AttnRow*)rows, (uint16_t*)out, H, nchunk, npre);
+                       (const AttnRow*)rows, (uint16_t*)out, H, nchunk, npre, pre_keys);
     return ok(hipSuccess);
 }
 

@@ -364,7 +364,7 @@ class LanguageModel:
                 att = ops.decode_attention_grouped(q, kv.ko[i], kv.vo[i], kv.kp[i], kv.vp[i], attn_rows, grouping["groups"],
                                                    grouping["group_rows"], grouping["items"], grouping["n_items"], H, Hkv, D,
                                                    kv.t_pre, kv.t_own, workspace=grouping["workspace"],
-                                                   v_prefix_t8=kv.vp8[i] if grouping.get("mfma", True) else None)
+                                                   v_prefix_t8=kv.vp8[i], chunks_per_item=grouping["cpi"])
             else:
                 q = ops.rope_kv_write(qkv, pos, slot, self.cs, kv.ko[i], kv.vo[i], H, Hkv, D, cpos=cpos)
                 att = ops.decode_attention(q, kv.ko[i], kv.vo[i], attn_rows, H, Hkv, D, k_prefix=kv.kp[i], v_prefix=kv.vp[i],
@@ -430,6 +430,7 @@ class _DecodeRunner:
             lm = eng.cfg.lm
             self.grouping = dict(groups=torch.zeros(max(1, tail["n_groups"]), 4, **i32), group_rows=torch.zeros(R, **i32),
                                  n_groups=tail["n_groups"], items=torch.zeros(max(1, tail["n_items"]), 4, **i32), n_items=tail["n_items"],
+                                 cpi=tail.get("cpi", 1),
                                  workspace=ops.attention_workspace(R, lm.n_heads, lm.head_dim, eng._kv.t_pre + eng._kv.t_own, dev))
 
     def reset(self, ctr0):
@@ -443,7 +444,7 @@ class _DecodeRunner:
         self.cpos.copy_(torch.tensor(cpos, dtype=torch.int32))
         if self.grouping is not None:
             groups, members = group_rows_by_prefix(rows)
-            items = ops.prefix_work_items(groups)
+            items = ops.prefix_work_items(groups, self.grouping["cpi"])
             assert len(groups) == self.grouping["n_groups"] and len(items) == self.grouping["n_items"]
             self.grouping["groups"].copy_(torch.tensor(groups, dtype=torch.int32))
             self.grouping["items"].copy_(torch.tensor(items, dtype=torch.int32))
@@ -672,11 +673,12 @@ class VddLlavaEngine:
         grp, _members = group_rows_by_prefix(dec_rows) if self.group_attention else ([], [])
         if grp and len(_members) < 2 * len(grp):      # (almost) nothing shared: the per-row split-KV kernel alone is cheaper
             grp = []
-        n_groups, n_items = len(grp), len(ops.prefix_work_items(grp))
-        cfgkey = cfgkey + (n_groups, n_items)
+        cpi = ops.prefix_chunks_per_item(grp, lm.n_heads)
+        n_groups, n_items = len(grp), len(ops.prefix_work_items(grp, cpi))
+        cfgkey = cfgkey + (n_groups, n_items, cpi)
         run = self._runner(cfgkey, Q, len(keep), max_new_tokens, dict(alpha=alpha, beta=beta, warp=warp, contrast=contrast,
                            is_vcd=use_cd, both=(use_dd and use_dd_unk), greedy=cd_greedy, eos_t=eos_t, pad=pad_token_id,
-                           output_scores=output_scores, n_groups=n_groups, n_items=n_items))
+                           output_scores=output_scores, n_groups=n_groups, n_items=n_items, cpi=cpi))
         run.reset(ctr0)
         scores = [] if output_scores else None
         v0 = logits0[:Q]

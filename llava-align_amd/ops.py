@@ -25,7 +25,7 @@ _SIGS = {
     "vdd_skinny_gemm_tiled": [_P, _P, _P, _P, _P, _I, _I, _I, _I, _L, _L, _L, _P],
     "vdd_decode_attention": [_P, _P, _P, _P, _P, _P, _P, _P, _I, _I, _I, _I, _L, _I, _L, _I, _I, _F, _P],
     "vdd_prefix_v_transpose": [_P, _P, _P, _I, _I, _I, _I, _P],
-    "vdd_decode_attention_grouped": [_P, _P, _P, _P, _P, _P, _P, _P, _P, _P, _I, _P, _P, _I, _I, _I, _I, _L, _I, _L, _I, _I, _I, _F, _P],
+    "vdd_decode_attention_grouped": [_P, _P, _P, _P, _P, _P, _P, _P, _P, _P, _I, _P, _P, _I, _I, _I, _I, _L, _I, _L, _I, _I, _I, _I, _F, _P],
     "vdd_flash_attention": [_P, _P, _P, _P, _P, _P, _P, _I, _I, _I, _I, _I, _L, _I, _L, _I, _F, _I, _P],
     "vdd_layernorm": [_P, _P, _P, _P, _I, _I, _F, _P],
     "vdd_bias_act": [_P, _P, _P, _L, _I, _I, _P],
@@ -258,12 +258,22 @@ def attention_workspace(M, H, D, max_len, device):
     return torch.empty((lib.vdd_decode_attention_workspace_bytes(M, H, D, int(max_len)) + 3) // 4, dtype=torch.float32, device=device)
 
 
-def prefix_work_items(groups):
-    """groups [[row_off, n_rows, pslot, plen], ...] -> work list [[group, first_row, chunk, 0], ...] of the prefix pass."""
+def prefix_chunks_per_item(groups, n_heads, target_waves=4096, max_chunks=16):
+    """How many 64-key chunks one work item of the MFMA prefix pass should walk: as many as possible (fewer partials for
+    the combine to merge; measured 338 -> 314 us per layer at 768 rows, tools/attn_probe.py) while the pass still has
+    ~target_waves waves (one question in flight must stay split: 10 chunks x 32 heads is all the parallelism there is)."""
+    total = sum(-(-n_rows // 16) * -(-plen // 64) for _, n_rows, _, plen in groups)
+    return max(1, min(max_chunks, total * n_heads // target_waves))
+
+
+def prefix_work_items(groups, chunks_per_item=1):
+    """groups [[row_off, n_rows, pslot, plen], ...] -> work list [[group, first_row, item, 0], ...] of the prefix pass; item j
+    covers keys [j * 64 * chunks_per_item, (j + 1) * 64 * chunks_per_item) of the group's prefix."""
     items = []
+    keys = 64 * chunks_per_item
     for gi, (_, n_rows, _, plen) in enumerate(groups):
         for r0 in range(0, n_rows, 16):
-            for c in range((plen + 63) // 64):
+            for c in range((plen + keys - 1) // keys):
                 items.append([gi, r0, c, 0])
     return items
 
@@ -278,7 +288,7 @@ def prefix_v_transpose(v_prefix, v_prefix_t8, prefix_len_of_slot):
 
 
 def decode_attention_grouped(q, k_cache, v_cache, k_prefix, v_prefix, rows, groups, group_rows, items, n_items,
-                             H, Hkv, D, max_prefix_len, max_own_len, out=None, workspace=None, v_prefix_t8=None):
+                             H, Hkv, D, max_prefix_len, max_own_len, out=None, workspace=None, v_prefix_t8=None, chunks_per_item=1):
     """decode_attention with the shared prefixes attended once per group of rows (MFMA over the group's queries)."""
     _bf16(q, k_cache, v_cache, k_prefix, v_prefix)
     M = q.shape[0]
@@ -297,7 +307,7 @@ def decode_attention_grouped(q, k_cache, v_cache, k_prefix, v_prefix, rows, grou
                                                 v_prefix_t8.data_ptr() if v_prefix_t8 is not None else None, rows.data_ptr(), groups.data_ptr(), group_rows.data_ptr(), items.data_ptr(), n_items,
                                                 out.data_ptr(), ws.data_ptr(), M, H, Hkv, D, k_cache.stride(0), k_cache.shape[2],
                                                 k_prefix.stride(0), k_prefix.shape[2], int(max_prefix_len), int(max_own_len),
-                                                D ** -0.5, _st(q)))
+                                                int(chunks_per_item), D ** -0.5, _st(q)))
     return out
 
 

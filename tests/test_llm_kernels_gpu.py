@@ -242,7 +242,17 @@ def test_grouped_prefix_decode_attention_equals_per_row():
                                    torch.tensor(grp_rows_p, dtype=torch.int32, device=DEV),
                                    torch.tensor(items, dtype=torch.int32, device=DEV), len(items), H, Hkv, D, 611, 128, v_prefix_t8=vp8)
     assert torch.allclose(a.float(), c.float(), rtol=3e-2, atol=3e-2)
-    b = c
+    # several 64-key chunks per work item (online softmax inside the wave, one partial per item): 2 -> 5 items cover 611 keys,
+    # 4 -> 3 items with a ragged last one, 16 -> the whole prefix in one item
+    for cpi in (2, 4, 16):
+        it = O.prefix_work_items(groups, cpi)
+        assert len(it) == sum(-(-n // 16) * -(-pl // (64 * cpi)) for _, n, _, pl in groups)
+        cc = O.decode_attention_grouped(q, ko, vo, kp, vp, rt, torch.tensor(groups, dtype=torch.int32, device=DEV),
+                                        torch.tensor(grp_rows_p, dtype=torch.int32, device=DEV),
+                                        torch.tensor(it, dtype=torch.int32, device=DEV), len(it), H, Hkv, D, 611, 128, v_prefix_t8=vp8,
+                                        chunks_per_item=cpi)
+        assert torch.allclose(a.float(), cc.float(), rtol=3e-2, atol=3e-2), cpi
+    b = cc
     rep = H // Hkv
     for m, (slot, ln, ps, pl) in enumerate(rows_p):
         K = torch.cat([kp[ps, :, :pl], ko[slot, :, :ln - pl]], 1).float().repeat_interleave(rep, 0)
