@@ -377,6 +377,11 @@ __global__ void __launch_bounds__(BLOCK, 8) vdd_contrast_sample_kernel(KP p) {
 
     float m = -INFINITY; int nfin = 0; int t_nan = 0, t_pinf = 0;
     const bool recip = (p.flags & VDD_TEMP_RECIPROCAL) != 0;
+    // Bit k set <=> this thread's k-th chunk (ch = tid + k * BLOCK) may hold a finite score.  After the plausibility mask a
+    // row keeps a handful of candidates, and every pass over the working row costs ~10 VALU instructions per ELEMENT
+    // (measured: 2.7 us per row for the mass pass alone, the passes after the scores store were 1/3 of the kernel), so
+    // the passes of the sampling tail walk only the flagged chunks.  Chunks past bit 63 (V > 2^19) count as flagged.
+    unsigned long long livemask = 0ull;
 
     if (p.c != nullptr) {
         // ---- pass A: v -> working row, row max (vcd_sample.py:191) --------------------
@@ -404,7 +409,8 @@ __global__ void __launch_bounds__(BLOCK, 8) vdd_contrast_sample_kernel(KP p) {
         // Where v < cutoff the result is -inf whatever c/d hold (:194), so the contrast
         // branches are only READ for chunks that contain a survivor: with the usual beta the
         // c/d rows cost a few 64-B sectors instead of V*e bytes each.
-        for (int base = tid; base < nch; base += UNR * BLOCK) {
+        int kb = 0;
+        for (int base = tid; base < nch; base += UNR * BLOCK, kb += UNR) {
             uint32_t qv[UNR][4];
             if constexpr (!LDSROW) {       // global working row: batch the v re-reads (L2 / Infinity-Cache hits)
 #pragma unroll
@@ -425,6 +431,7 @@ __global__ void __launch_bounds__(BLOCK, 8) vdd_contrast_sample_kernel(KP p) {
                 if constexpr (Tr<DT>::KEYBITS == 16) { x4[0] = x4[1] = x4[2] = x4[3] = NINF | (NINF << 16); }
                 else { x4[0] = x4[1] = x4[2] = x4[3] = NINF; }
                 if (live) {
+                    if (kb + u < 64) livemask |= 1ull << (kb + u);
                     uint32_t qc[4], qd[4];
                     gload<DT>(p.c, oc, ch, V, p.vec_in, qc);
                     if (both) gload<DT>(p.d, od, ch, V, p.vec_in, qd);
@@ -452,6 +459,7 @@ __global__ void __launch_bounds__(BLOCK, 8) vdd_contrast_sample_kernel(KP p) {
         }
     } else {
         // ---- plain path (vcd_sample.py:204-205): x = warp(v) ---------------------------
+        livemask = ~0ull;
         for (int base = tid; base < nch; base += UNR * BLOCK) {
             uint32_t q[UNR][4];
 #pragma unroll
@@ -493,7 +501,8 @@ __global__ void __launch_bounds__(BLOCK, 8) vdd_contrast_sample_kernel(KP p) {
     // ---- top-p (HF TopPLogitsWarper) ----------------------------------------------
     if (p.use_topp && !row_bad) {
         float z = 0.f;
-        for (int ch = tid; ch < nch; ch += BLOCK) {
+        for (int ch = tid, k = 0; ch < nch; ch += BLOCK, ++k) {
+            if (!(k >= 64 || ((livemask >> k) & 1ull) != 0ull)) continue;
             uint32_t w[4]; R.get(ch, w);
 #pragma unroll
             for (int j = 0; j < EPC; ++j) { uint32_t b = getb<DT>(w, j); if (b != NINF) z += __expf(Tr<DT>::to_f(b) - m); }
@@ -510,15 +519,18 @@ __global__ void __launch_bounds__(BLOCK, 8) vdd_contrast_sample_kernel(KP p) {
         mask_below_key<DT, LDSROW>(R, nch, thr_key, tid);
     }
 
-    // ---- scores row out -----------------------------------------------------------
-    if (p.scores != nullptr) {
-        if constexpr (LDSROW) {
-            for (int ch = tid; ch < nch; ch += BLOCK) { uint32_t w[4]; R.get(ch, w); gstore<DT>(p.scores, (long long)row * p.ss, ch, V, p.vec_out, w); }
-        } else if (p.scores != p.work) {
-            for (int ch = tid; ch < nch; ch += BLOCK) { uint32_t w[4]; R.get(ch, w); gstore<DT>(p.scores, (long long)row * p.ss, ch, V, p.vec_out, w); }
+    // ---- scores row out: issued LAST (after the token), see the end of the kernel ----------------
+    auto store_scores = [&]() {
+        if (p.scores != nullptr) {
+            if constexpr (LDSROW) {
+                for (int ch = tid; ch < nch; ch += BLOCK) { uint32_t w[4]; R.get(ch, w); gstore<DT>(p.scores, (long long)row * p.ss, ch, V, p.vec_out, w); }
+            } else if (p.scores != p.work) {
+                for (int ch = tid; ch < nch; ch += BLOCK) { uint32_t w[4]; R.get(ch, w); gstore<DT>(p.scores, (long long)row * p.ss, ch, V, p.vec_out, w); }
+            }
         }
-    }
+    };
     if (row_bad) {
+        store_scores();
         if (tid == 0) {
             if (p.status) p.status[row] = VDD_ROW_EMPTY;
             if (p.next_tokens && !(p.flags & VDD_NO_SAMPLE)) p.next_tokens[(long long)row * p.st] = -1;
@@ -528,11 +540,13 @@ __global__ void __launch_bounds__(BLOCK, 8) vdd_contrast_sample_kernel(KP p) {
     }
     if (tid == 0 && p.status) p.status[row] = VDD_ROW_OK;
     const bool want_top = p.top_prob != nullptr && p.n_top > 0;
-    if ((p.flags & VDD_NO_SAMPLE) && !want_top) return;
+    if ((p.flags & VDD_NO_SAMPLE) && !want_top) { store_scores(); return; }
 
     // ---- per-thread mass, block scan (thread-major order) ---------------------------
+    auto flagged = [&](int k) { return k >= 64 || ((livemask >> k) & 1ull) != 0ull; };
     float t = 0.f;
-    for (int ch = tid; ch < nch; ch += BLOCK) {
+    for (int ch = tid, k = 0; ch < nch; ch += BLOCK, ++k) {
+        if (!flagged(k)) continue;
         uint32_t w[4]; R.get(ch, w);
 #pragma unroll
         for (int j = 0; j < EPC; ++j) { uint32_t b = getb<DT>(w, j); if (b != NINF) t += __expf(Tr<DT>::to_f(b) - m); }
@@ -555,7 +569,8 @@ __global__ void __launch_bounds__(BLOCK, 8) vdd_contrast_sample_kernel(KP p) {
         float pv = INFINITY; int pi = -1;     // previous pick (value desc, index asc)
         for (int r = 0; r < p.n_top; ++r) {
             float bv = -INFINITY; int bi = 0x7fffffff;
-            for (int ch = tid; ch < nch; ch += BLOCK) {
+            for (int ch = tid, k = 0; ch < nch; ch += BLOCK, ++k) {
+                if (!flagged(k)) continue;
                 uint32_t w[4]; R.get(ch, w);
 #pragma unroll
                 for (int j = 0; j < EPC; ++j) {
@@ -588,14 +603,15 @@ __global__ void __launch_bounds__(BLOCK, 8) vdd_contrast_sample_kernel(KP p) {
             pv = have ? bv : -INFINITY; pi = bi;
         }
     }
-    if (p.flags & VDD_NO_SAMPLE) return;
+    if (p.flags & VDD_NO_SAMPLE) { store_scores(); return; }
 
     // ---- token: argmax or inverse-CDF draw in thread-major order ---------------------
     if (tid == 0) sm.sel[3] = 0xFFFFFFFFu;
     __syncthreads();
     if (p.flags & VDD_PICK_ARGMAX) {
         float bv = -INFINITY; int bi = 0x7fffffff;
-        for (int ch = tid; ch < nch; ch += BLOCK) {
+        for (int ch = tid, k = 0; ch < nch; ch += BLOCK, ++k) {
+            if (!flagged(k)) continue;
             uint32_t w[4]; R.get(ch, w);
 #pragma unroll
             for (int j = 0; j < EPC; ++j) {
@@ -621,7 +637,8 @@ __global__ void __launch_bounds__(BLOCK, 8) vdd_contrast_sample_kernel(KP p) {
         if (!any) hit = (tid == last);
         if (hit) {
             float acc = excl; int pick = -1, lastfin = -1;
-            for (int ch = tid; ch < nch; ch += BLOCK) {
+            for (int ch = tid, k = 0; ch < nch; ch += BLOCK, ++k) {
+                if (!flagged(k)) continue;
                 uint32_t w[4]; R.get(ch, w);
 #pragma unroll
                 for (int j = 0; j < EPC; ++j) {
@@ -649,6 +666,7 @@ __global__ void __launch_bounds__(BLOCK, 8) vdd_contrast_sample_kernel(KP p) {
         }
         p.next_tokens[(long long)row * p.st] = tok;
     }
+    store_scores();
 }
 
 // ------------------------------------------------------------------ host side
