@@ -118,6 +118,11 @@ struct Smem {
     float histf[4][256];
     unsigned sel[4];
     float self[2];
+    // compact candidate list of the single-wave tail (rows with <= 64 finite scores)
+    unsigned cand_n;
+    unsigned cand_rank[64];
+    float cand_x[64];
+    int cand_idx[64];
 };
 
 __device__ __forceinline__ float wave_max(float v) {
@@ -377,6 +382,7 @@ __global__ void __launch_bounds__(BLOCK, 8) vdd_contrast_sample_kernel(KP p) {
 
     float m = -INFINITY; int nfin = 0; int t_nan = 0, t_pinf = 0;
     const bool recip = (p.flags & VDD_TEMP_RECIPROCAL) != 0;
+    if (tid == 0) sm.cand_n = 0u;
     // Bit k set <=> this thread's k-th chunk (ch = tid + k * BLOCK) may hold a finite score.  After the plausibility mask a
     // row keeps a handful of candidates, and every pass over the working row costs ~10 VALU instructions per ELEMENT
     // (measured: 2.7 us per row for the mass pass alone, the passes after the scores store were 1/3 of the kernel), so
@@ -544,6 +550,101 @@ __global__ void __launch_bounds__(BLOCK, 8) vdd_contrast_sample_kernel(KP p) {
 
     // ---- per-thread mass, block scan (thread-major order) ---------------------------
     auto flagged = [&](int k) { return k >= 64 || ((livemask >> k) & 1ull) != 0ull; };
+
+    // ---- single-wave tail: rows that kept <= 64 candidates (the usual case after the plausibility mask) ------------
+    // The candidates are gathered into a 64-entry LDS list; ONE barrier later every wave but wave 0 only has its share
+    // of the scores row left to store, and wave 0 finishes the row alone: sort the list into the same thread-major
+    // enumeration order the general path uses, softmax numerators, wave scan, inverse-CDF draw (or argmax), top-n.
+    // This replaces three passes and five block-wide barriers, during which the 64 KiB LDS row and all 16 wave slots
+    // of the workgroup were held.
+    if (nfin <= 64 && p.top_k == 0 && !p.use_topp && nch <= 64 * BLOCK) {
+        const int kmax = (nch + BLOCK - 1) / BLOCK;
+        for (int ch = tid, k = 0; ch < nch; ch += BLOCK, ++k) {
+            if (!flagged(k)) continue;
+            uint32_t w[4]; R.get(ch, w);
+#pragma unroll
+            for (int j = 0; j < EPC; ++j) {
+                const uint32_t b = getb<DT>(w, j);
+                if (b != NINF) {
+                    const unsigned slot = atomicAdd(&sm.cand_n, 1u);
+                    sm.cand_rank[slot] = (unsigned)((tid * kmax + k) * EPC + j);
+                    sm.cand_x[slot] = Tr<DT>::to_f(b);
+                    sm.cand_idx[slot] = ch * EPC + j;
+                }
+            }
+        }
+        __syncthreads();
+        store_scores();
+        if (wave != 0) return;
+        const int n = nfin;
+        const bool act = lane < n;
+        const unsigned rk = act ? sm.cand_rank[lane] : 0xFFFFFFFFu;
+        const float xv = act ? sm.cand_x[lane] : -INFINITY;
+        const int id = act ? sm.cand_idx[lane] : 0x7fffffff;
+        // ---- top-n of softmax(scores): value descending, index ascending -------------------------------
+        float zsum = 0.f;
+        {
+            int pos = 0;
+            for (int q = 0; q < n; ++q) { const unsigned rq = __shfl(rk, q); pos += (rq < rk) ? 1 : 0; }
+            // numerators in enumeration order (sorted through LDS: every lane has its entry in registers by now)
+            if (act) { sm.cand_x[pos] = __expf(xv - m); sm.cand_idx[pos] = id; }
+        }
+        const float e_s = act ? sm.cand_x[lane] : 0.f;           // same wave: LDS program order
+        const int id_s = act ? sm.cand_idx[lane] : -1;
+        float incl = e_s;
+#pragma unroll
+        for (int o = 1; o < 64; o <<= 1) { const float nb = __shfl_up(incl, o); if (lane >= o) incl += nb; }
+        zsum = __shfl(incl, 63);
+        if (want_top) {
+            float pv = INFINITY; int pi = -1;
+            for (int r = 0; r < p.n_top; ++r) {
+                const bool after = act && (xv < pv || (xv == pv && id > pi));
+                float bv = after ? xv : -INFINITY; int bi = after ? id : 0x7fffffff;
+#pragma unroll
+                for (int o = 32; o > 0; o >>= 1) {
+                    const float ov2 = __shfl_xor(bv, o); const int oi = __shfl_xor(bi, o);
+                    if (ov2 > bv || (ov2 == bv && oi < bi)) { bv = ov2; bi = oi; }
+                }
+                const bool have = bi != 0x7fffffff;
+                if (lane == 0) {
+                    p.top_prob[(long long)row * p.n_top + r] = have ? rnd<DT>(__fdiv_rn(__expf(bv - m), zsum)) : 0.f;
+                    p.top_tok[(long long)row * p.n_top + r] = have ? bi : -1;
+                }
+                pv = have ? bv : -INFINITY; pi = bi;
+            }
+        }
+        if (p.flags & VDD_NO_SAMPLE) return;
+        int tok_i;
+        if (p.flags & VDD_PICK_ARGMAX) {
+            float bv = xv; int bi = id;
+#pragma unroll
+            for (int o = 32; o > 0; o >>= 1) {
+                const float ov2 = __shfl_xor(bv, o); const int oi = __shfl_xor(bi, o);
+                if (ov2 > bv || (ov2 == bv && oi < bi)) { bv = ov2; bi = oi; }
+            }
+            tok_i = bi;
+        } else {
+            const float u = p.uniforms ? p.uniforms[row] : philox_uniform(p.seed, p.offset + (p.offset_ptr ? *p.offset_ptr : 0ull), (unsigned)row);
+            const float target = u * zsum;
+            const unsigned long long hits = __ballot(act && e_s > 0.f && target < incl);
+            const unsigned long long mass = __ballot(act && e_s > 0.f);
+            const int pl = hits ? (int)__builtin_ctzll(hits) : (mass ? 63 - (int)__clzll((long long)mass) : n - 1);   // rounding: last entry holding mass
+            tok_i = __shfl(id_s, pl);
+        }
+        if (lane == 0) {
+            long long tok = (long long)tok_i;
+            if (p.unfinished != nullptr && p.n_eos > 0) {
+                long long uf = p.unfinished[row];
+                tok = tok * uf + p.pad * (1 - uf);                                              // :260
+                long long keep = 1;
+                for (int e = 0; e < p.n_eos; ++e) keep *= (tok != p.eos[e]) ? 1 : 0;             // :286-288
+                p.unfinished[row] = uf * keep;
+            }
+            p.next_tokens[(long long)row * p.st] = tok;
+        }
+        return;
+    }
+
     float t = 0.f;
     for (int ch = tid, k = 0; ch < nch; ch += BLOCK, ++k) {
         if (!flagged(k)) continue;

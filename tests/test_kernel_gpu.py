@@ -135,6 +135,53 @@ def test_explicit_uniform_draws_follow_the_inverse_cdf():
             hi = cdf[pos].item()
             assert p[pos] > 0 and lo - 2e-5 <= u[b].item() <= hi + 2e-5, (b, tok, lo, u[b].item(), hi)
 
+@pytest.mark.parametrize("beta,expect_fast", [(0.2, True), (0.06, True), (0.02, False), (1e-4, False)])
+def test_contrast_rows_draw_by_inverse_cdf_in_both_tails(beta, expect_fast):
+    """Rows that keep <= 64 candidates after the plausibility mask finish in the single-wave tail, the others in the
+    block-wide one; both enumerate the candidates in the documented thread-major order, so the token drawn for an
+    explicit uniform can be recomputed from the scores row.  Also: top-n and the argmax pick agree with torch."""
+    L = _L()
+    from llava_align_amd.sampling import thread_major_order
+    torch.manual_seed(21)
+    V, B, dt = 32000, 48, torch.bfloat16
+    v1 = (torch.randn(1, V) * 3).to(dt)
+    c1 = (v1.float() + torch.randn(1, V)).to(dt)
+    v, c = v1.repeat(B, 1).to(DEV), c1.repeat(B, 1).to(DEV)
+    u = torch.linspace(0, 0.999999, B, device=DEV, dtype=torch.float32)
+    out = L.contrast_sample(v, c, alpha=1.0, beta=beta, warp=L.WarpSpec(temperature=1.3), uniforms=u, return_scores=True, n_top=10)
+    sc = out.scores[0].cpu()
+    nfin = int(torch.isfinite(sc).sum())
+    assert (nfin <= 64) == expect_fast and nfin >= 2, nfin
+    assert all(torch.equal(out.scores[b].cpu(), sc) for b in (1, B - 1))
+    order = torch.tensor(thread_major_order(V, dt))
+    p = torch.softmax(sc.double(), -1)[order]
+    cdf = p.cumsum(0)
+    seen = set()
+    for b in range(B):
+        tok = out.tokens[b].item()
+        seen.add(tok)
+        pos = int((order == tok).nonzero()[0])
+        lo = cdf[pos - 1].item() if pos > 0 else 0.0
+        assert p[pos] > 0 and lo - 2e-5 <= u[b].item() <= cdf[pos].item() + 2e-5, (b, tok, lo, u[b].item(), cdf[pos].item())
+    assert len(seen) >= 2
+    probs = torch.softmax(sc, -1).float()
+    pt, tt = torch.topk(probs, 10)
+    assert torch.allclose(out.top_prob[0].cpu(), pt, rtol=1.6e-2, atol=1e-6)
+    for j in range(min(10, nfin)):
+        g = out.top_tok[0, j].item()
+        assert g == tt[j].item() or abs(probs[g] - pt[j]) <= 1.6e-2 * pt[j]
+    if nfin < 10:
+        assert out.top_tok[0, nfin:].tolist() == [-1] * (10 - nfin) and out.top_prob[0, nfin:].abs().max().item() == 0.0
+    am = L.contrast_sample(v[:2], c[:2], alpha=1.0, beta=beta, warp=L.WarpSpec(temperature=1.3), pick_argmax=True)
+    best = torch.nonzero(sc == sc.max()).min().item()
+    assert am.tokens.tolist() == [best, best]
+    # pad / EOS bookkeeping through the same tail
+    unf = torch.tensor([1, 0], dtype=torch.long, device=DEV)
+    eos = torch.tensor([best], dtype=torch.long, device=DEV)
+    e = L.contrast_sample(v[:2], c[:2], alpha=1.0, beta=beta, warp=L.WarpSpec(temperature=1.3), pick_argmax=True, eos_ids=eos, pad_id=7,
+                          unfinished=unf)
+    assert e.tokens.tolist() == [best, 7] and unf.tolist() == [0, 0]
+
 
 def test_philox_sampling_matches_the_distribution():
     L = _L()
