@@ -658,8 +658,10 @@ __global__ void __launch_bounds__(256) vt8_transpose_kernel(const uint16_t* __re
     for (int e = threadIdx.x; e < 8 * D; e += 256) vt8[base + (size_t)(tb * 8) * D + e] = tile[e % 8][e / 8];
 }
 
+// waves-per-SIMD hint 4: left alone the compiler hoists all 16 K (then V) fragment loads of a chunk and lands at 140
+// registers = 3 waves per SIMD; capped at 128 the pass is 10 % faster (tools/attn_probe.py: 314 -> 274 us per layer).
 template <int D>
-__global__ void __launch_bounds__(256) decode_attn_prefix_mfma_kernel(const uint16_t* __restrict__ q, const uint16_t* __restrict__ kpre,
+__global__ void __launch_bounds__(256, 4) decode_attn_prefix_mfma_kernel(const uint16_t* __restrict__ q, const uint16_t* __restrict__ kpre,
                                                                       const uint16_t* __restrict__ vt8, const GroupDesc* __restrict__ groups,
                                                                       const int* __restrict__ group_rows, const int4* __restrict__ items,
                                                                       float* __restrict__ ws, int H, int Hkv, long long pre_stride,

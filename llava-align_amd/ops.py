@@ -258,9 +258,9 @@ def attention_workspace(M, H, D, max_len, device):
     return torch.empty((lib.vdd_decode_attention_workspace_bytes(M, H, D, int(max_len)) + 3) // 4, dtype=torch.float32, device=device)
 
 
-def prefix_chunks_per_item(groups, n_heads, target_waves=4096, max_chunks=16):
+def prefix_chunks_per_item(groups, n_heads, target_waves=2048, max_chunks=16):
     """How many 64-key chunks one work item of the MFMA prefix pass should walk: as many as possible (fewer partials for
-    the combine to merge; measured 338 -> 314 us per layer at 768 rows, tools/attn_probe.py) while the pass still has
+    the combine to merge; measured 304 -> 274 us per layer at 768 rows, tools/attn_probe.py) while the pass still has
     ~target_waves waves (one question in flight must stay split: 10 chunks x 32 heads is all the parallelism there is)."""
     total = sum(-(-n_rows // 16) * -(-plen // 64) for _, n_rows, _, plen in groups)
     return max(1, min(max_chunks, total * n_heads // target_waves))

@@ -78,8 +78,8 @@ def test_grouping_and_work_items():
     assert big == [[0, 0, 0, 0], [0, 16, 0, 0], [0, 32, 0, 0]]
     # several 64-key chunks per item: 611 keys -> 3 items of 256 keys (ragged last); item index, not chunk index, in column 2
     assert ops.prefix_work_items([[0, 6, 0, 611]], 4) == [[0, 0, 0, 0], [0, 0, 1, 0], [0, 0, 2, 0]]
-    # one question in flight stays fully split; the bench shape (64 image groups of 6 + one 384-row group) merges 5 chunks
+    # one question in flight stays fully split; the bench shape (64 image groups of 6 + one 384-row group) walks a whole 611-key prefix per item
     assert ops.prefix_chunks_per_item([[0, 1, 0, 611], [1, 1, 1, 36]], 32) == 1
     bench_groups = [[6 * g, 6, g, 611] for g in range(64)] + [[384, 384, 64, 36]]
-    assert ops.prefix_chunks_per_item(bench_groups, 32) == 5
+    assert ops.prefix_chunks_per_item(bench_groups, 32) == 10
     assert ops.prefix_chunks_per_item([[0, 16, 0, 4000]] * 512, 32) == 16        # capped
