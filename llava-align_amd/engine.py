@@ -295,6 +295,16 @@ class KVCache:
         return sum(t.numel() * 2 for pool in (self.kp, self.vp, self.vp8, self.ko, self.vo) for t in pool)
 
 
+def grouping_pays(groups, rows, min_saved=0.25) -> bool:
+    """The grouped prefix pass reads a shared prefix once per group instead of once per row; it only beats the per-row
+    split-KV kernel when that removes a real share of the step's KV bytes.  BASELINE config #3 (one image per question:
+    the only shared prefixes are the 35-token system prompts of the image-free branches) saves 7 % and runs 13 % FASTER
+    ungrouped (tools/config3_probe.py: 2,212 vs 2,511 tokens/s); the POPE batch (6 questions per image) saves 72 %."""
+    saved = sum((n_rows - 1) * plen for _, n_rows, _, plen in groups)
+    total = sum(r[1] for r in rows)
+    return total > 0 and saved >= min_saved * total
+
+
 class LanguageModel:
     def __init__(self, w: LlavaWeights):
         self.w, self.cfg = w, w.cfg.lm
@@ -671,7 +681,7 @@ class VddLlavaEngine:
         sel = [b * Q + q for b in keep for q in range(Q)]
         dec_rows = [[seg[i]["slot"], seg[i]["pos0"] + seg[i]["T"] + 1, seg[i]["pslot"], seg[i]["plen"]] for i in sel]
         grp, _members = group_rows_by_prefix(dec_rows) if self.group_attention else ([], [])
-        if grp and len(_members) < 2 * len(grp):      # (almost) nothing shared: the per-row split-KV kernel alone is cheaper
+        if grp and not grouping_pays(grp, dec_rows):
             grp = []
         cpi = ops.prefix_chunks_per_item(grp, lm.n_heads)
         n_groups, n_items = len(grp), len(ops.prefix_work_items(grp, cpi))

@@ -4,7 +4,7 @@ decode-attention pass."""
 import torch
 
 from llava_align_amd import ops
-from llava_align_amd.engine import IMAGE_TOKEN_INDEX, VddLlavaEngine, group_rows_by_prefix, preset
+from llava_align_amd.engine import grouping_pays, IMAGE_TOKEN_INDEX, VddLlavaEngine, group_rows_by_prefix, preset
 
 IMG = IMAGE_TOKEN_INDEX
 
@@ -83,3 +83,15 @@ def test_grouping_and_work_items():
     bench_groups = [[6 * g, 6, g, 611] for g in range(64)] + [[384, 384, 64, 36]]
     assert ops.prefix_chunks_per_item(bench_groups, 32) == 10
     assert ops.prefix_chunks_per_item([[0, 16, 0, 4000]] * 512, 32) == 16        # capped
+
+
+def test_grouping_only_when_it_removes_kv_traffic():
+    # POPE batch: 6 questions per image share a 611-token prefix, every image-free row shares 36 tokens
+    rows = [[i, 611 + 60, i // 6, 611] for i in range(384)] + [[384 + i, 36 + 60, 64, 36] for i in range(384)]
+    groups, _ = group_rows_by_prefix(rows)
+    assert grouping_pays(groups, rows)
+    # LLaVA-Bench shape: one image per question -> only the short image-free prefixes are shared
+    rows = [[i, 611 + 100, i, 611] for i in range(90)] + [[90 + i, 36 + 100, 90, 36] for i in range(90)] + [[180 + i, 35 + 100, 91, 35] for i in range(90)]
+    groups, _ = group_rows_by_prefix(rows)
+    assert len(groups) == 92 and not grouping_pays(groups, rows)
+    assert not grouping_pays([], [])

@@ -17,6 +17,8 @@ for q in range(90):
     ids.append(torch.tensor(sys_tok + [-200] + rng.integers(3, 32000, size=n).tolist()))
     imgs.append(torch.randn(3, 336, 336, generator=g))
 eng = VddLlavaEngine("llava-1.5-13b", device=dev, use_graph=True)
+if os.environ.get("VDD_NO_GROUP"):
+    eng.group_attention = False
 kw = dict(images=imgs, use_dd=True, use_dd_unk=True, cd_alpha=1.0, cd_beta=0.1, temperature=1.0, top_p=0.9, max_new_tokens=256, seed=1)
 eng.generate(ids, **kw); torch.cuda.synchronize()
 t0 = time.perf_counter(); out = eng.generate(ids, **kw); torch.cuda.synchronize(); dt = time.perf_counter() - t0
