@@ -38,7 +38,7 @@ struct SeqDesc { int q_row0, Tq, pos0, slot, pslot, plen; };
 constexpr float NEG_BIG = -1.0e30f;
 
 template <int D, bool CAUSAL>
-__global__ void __launch_bounds__(256) flash_attn_kernel(const uint16_t* __restrict__ q, const uint16_t* __restrict__ kc,
+__global__ void __launch_bounds__(256, 4) flash_attn_kernel(const uint16_t* __restrict__ q, const uint16_t* __restrict__ kc,
                                                          const uint16_t* __restrict__ vc, const uint16_t* __restrict__ kpre,
                                                          const uint16_t* __restrict__ vpre, const SeqDesc* __restrict__ seqs,
                                                          uint16_t* __restrict__ out, int H, int Hkv, long long slot_stride,
