@@ -495,6 +495,174 @@ __global__ void __launch_bounds__(BLOCK, 8) vdd_contrast_sample_kernel(KP p) {
     const bool has_pinf = (flags2 / 2048) != 0;
     const bool row_bad = (nfin == 0) || has_nan || has_pinf;
 
+    auto flagged = [&](int k) { return k >= 64 || ((livemask >> k) & 1ull) != 0ull; };
+    auto store_scores = [&]() {
+        if (p.scores != nullptr) {
+            if constexpr (LDSROW) {
+                for (int ch = tid; ch < nch; ch += BLOCK) { uint32_t w[4]; R.get(ch, w); gstore<DT>(p.scores, (long long)row * p.ss, ch, V, p.vec_out, w); }
+            } else if (p.scores != p.work) {
+                for (int ch = tid; ch < nch; ch += BLOCK) { uint32_t w[4]; R.get(ch, w); gstore<DT>(p.scores, (long long)row * p.ss, ch, V, p.vec_out, w); }
+            }
+        }
+    };
+    const bool want_top = p.top_prob != nullptr && p.n_top > 0;
+
+    // ---- single-wave path: rows that kept <= 64 candidates (the usual case after the plausibility mask) -------------
+    // The candidates are gathered into a 64-entry LDS list; wave 0 alone applies the warpers (top-k by counting, top-p by
+    // mass, same definitions as the block-wide radix selection below), then - while the other 15 waves only store their
+    // share of the scores row - sorts the list into the thread-major enumeration order of the general path, scans,
+    // draws (or arg-maxes) and extracts the top-n.  One or two barriers instead of three passes over the row and five
+    // block-wide barriers, during which the 64 KiB LDS row and all 16 wave slots of the workgroup were held.
+    if (!row_bad && nfin <= 64 && nch <= 64 * BLOCK) {
+        const bool warp_on = p.top_k > 0 || p.use_topp;
+        const bool tail_on = !((p.flags & VDD_NO_SAMPLE) && !want_top);
+        if (warp_on || tail_on) {
+            const int kmax = (nch + BLOCK - 1) / BLOCK;
+            for (int ch = tid, k = 0; ch < nch; ch += BLOCK, ++k) {
+                if (!flagged(k)) continue;
+                uint32_t w[4]; R.get(ch, w);
+#pragma unroll
+                for (int j = 0; j < EPC; ++j) {
+                    const uint32_t b = getb<DT>(w, j);
+                    if (b != NINF) {
+                        const unsigned slot = atomicAdd(&sm.cand_n, 1u);
+                        sm.cand_rank[slot] = (unsigned)((tid * kmax + k) * EPC + j);
+                        sm.cand_x[slot] = Tr<DT>::to_f(b);
+                        sm.cand_idx[slot] = ch * EPC + j;
+                    }
+                }
+            }
+            __syncthreads();
+        }
+        const int n = nfin;
+        const bool act = lane < n;
+        unsigned rk = 0xFFFFFFFFu; float xv = -INFINITY; int id = 0x7fffffff;
+        bool alive = false;
+        if (wave == 0 && (warp_on || tail_on)) {
+            if (act) { rk = sm.cand_rank[lane]; xv = sm.cand_x[lane]; id = sm.cand_idx[lane]; }
+            alive = act;
+        }
+        if (warp_on) {
+            if (wave == 0) {
+                float T = -INFINITY;
+                if (p.top_k > 0) {                                   // HF TopKLogitsWarper: scores < k-th largest -> -inf, ties kept
+                    const int k = p.top_k < p.min_keep ? p.min_keep : p.top_k;
+                    if (k < n) {
+                        int ge = 0;
+                        for (int q = 0; q < n; ++q) { const float xq = __shfl(xv, q); ge += (xq >= xv) ? 1 : 0; }
+                        const float vk = wave_max((act && ge >= k) ? xv : -INFINITY);
+                        T = vk;
+                        alive = alive && xv >= vk;
+                    }
+                }
+                if (p.use_topp) {                                    // HF TopPLogitsWarper: ascending cumulative mass <= fl(1-p) removed
+                    const float e = alive ? __expf(xv - m) : 0.f;
+                    const float z = wave_sum(e);
+                    const float thr = rnd<DT>(p.one_minus_p) * z;
+                    float mass_le = 0.f;
+                    for (int q = 0; q < n; ++q) { const float xq = __shfl(xv, q), eq = __shfl(e, q); mass_le += (xq <= xv) ? eq : 0.f; }
+                    const bool crossed = alive && mass_le > thr;
+                    float pv = crossed ? xv : INFINITY;
+#pragma unroll
+                    for (int o = 32; o > 0; o >>= 1) pv = fminf(pv, __shfl_xor(pv, o));
+                    float keepv = m;                                 // never remove the top min_keep entries
+                    if (p.min_keep > 1) {
+                        const int n_alive = __popcll(__ballot(alive));
+                        keepv = -INFINITY;
+                        if (p.min_keep < n_alive) {
+                            int ge = 0;
+                            for (int q = 0; q < n; ++q) { const float xq = __shfl(alive ? xv : -INFINITY, q); ge += (xq >= xv) ? 1 : 0; }
+                            keepv = wave_max((alive && ge >= p.min_keep) ? xv : -INFINITY);
+                        }
+                    }
+                    const float Tp = (pv < INFINITY) ? fminf(pv, keepv) : keepv;
+                    T = fmaxf(T, Tp);
+                    alive = alive && xv >= Tp;
+                }
+                if (lane == 0) sm.sel[0] = (T == -INFINITY) ? 0u : okey<DT>(Tr<DT>::from_f(T));
+            }
+            __syncthreads();
+            const uint32_t thr_key = sm.sel[0];
+            if (thr_key != 0u) {
+                for (int ch = tid, k = 0; ch < nch; ch += BLOCK, ++k) {
+                    if (!flagged(k)) continue;
+                    uint32_t w[4]; R.get(ch, w);
+                    bool changed = false;
+#pragma unroll
+                    for (int j = 0; j < EPC; ++j) {
+                        const uint32_t b = getb<DT>(w, j);
+                        if (b != NINF && okey<DT>(b) < thr_key) { setb<DT>(w, j, NINF); changed = true; }
+                    }
+                    if (changed) R.put(ch, w);
+                }
+            }
+        }
+        if (tid == 0 && p.status) p.status[row] = VDD_ROW_OK;
+        store_scores();
+        if (wave != 0 || !tail_on) return;
+        if (!alive) xv = -INFINITY;
+        // numerators in enumeration order (sorted through LDS: every lane has its entry in registers by now)
+        {
+            int pos = 0;
+            for (int q = 0; q < n; ++q) { const unsigned rq = __shfl(rk, q); pos += (rq < rk) ? 1 : 0; }
+            if (act) { sm.cand_x[pos] = alive ? __expf(xv - m) : 0.f; sm.cand_idx[pos] = id; }
+        }
+        const float e_s = act ? sm.cand_x[lane] : 0.f;           // same wave: LDS program order
+        const int id_s = act ? sm.cand_idx[lane] : -1;
+        float incl = e_s;
+#pragma unroll
+        for (int o = 1; o < 64; o <<= 1) { const float nb = __shfl_up(incl, o); if (lane >= o) incl += nb; }
+        const float zsum = __shfl(incl, 63);
+        if (want_top) {                                              // value descending, index ascending
+            float pv = INFINITY; int pi = -1;
+            for (int r = 0; r < p.n_top; ++r) {
+                const bool after = alive && (xv < pv || (xv == pv && id > pi));
+                float bv = after ? xv : -INFINITY; int bi = after ? id : 0x7fffffff;
+#pragma unroll
+                for (int o = 32; o > 0; o >>= 1) {
+                    const float ov2 = __shfl_xor(bv, o); const int oi = __shfl_xor(bi, o);
+                    if (ov2 > bv || (ov2 == bv && oi < bi)) { bv = ov2; bi = oi; }
+                }
+                const bool have = bi != 0x7fffffff;
+                if (lane == 0) {
+                    p.top_prob[(long long)row * p.n_top + r] = have ? rnd<DT>(__fdiv_rn(__expf(bv - m), zsum)) : 0.f;
+                    p.top_tok[(long long)row * p.n_top + r] = have ? bi : -1;
+                }
+                pv = have ? bv : -INFINITY; pi = bi;
+            }
+        }
+        if (p.flags & VDD_NO_SAMPLE) return;
+        int tok_i;
+        if (p.flags & VDD_PICK_ARGMAX) {
+            float bv = xv; int bi = alive ? id : 0x7fffffff;
+#pragma unroll
+            for (int o = 32; o > 0; o >>= 1) {
+                const float ov2 = __shfl_xor(bv, o); const int oi = __shfl_xor(bi, o);
+                if (ov2 > bv || (ov2 == bv && oi < bi)) { bv = ov2; bi = oi; }
+            }
+            tok_i = bi;
+        } else {
+            const float u = p.uniforms ? p.uniforms[row] : philox_uniform(p.seed, p.offset + (p.offset_ptr ? *p.offset_ptr : 0ull), (unsigned)row);
+            const float target = u * zsum;
+            const unsigned long long hits = __ballot(act && e_s > 0.f && target < incl);
+            const unsigned long long mass = __ballot(act && e_s > 0.f);
+            const int pl = hits ? (int)__builtin_ctzll(hits) : (mass ? 63 - (int)__clzll((long long)mass) : n - 1);   // rounding: last entry holding mass
+            tok_i = __shfl(id_s, pl);
+        }
+        if (lane == 0) {
+            long long tok = (long long)tok_i;
+            if (p.unfinished != nullptr && p.n_eos > 0) {
+                long long uf = p.unfinished[row];
+                tok = tok * uf + p.pad * (1 - uf);                                              // :260
+                long long keep = 1;
+                for (int e = 0; e < p.n_eos; ++e) keep *= (tok != p.eos[e]) ? 1 : 0;             // :286-288
+                p.unfinished[row] = uf * keep;
+            }
+            p.next_tokens[(long long)row * p.st] = tok;
+        }
+        return;
+    }
+
     // ---- top-k (HF TopKLogitsWarper: scores < kth -> -inf, ties kept) ------------
     if (p.top_k > 0 && !has_nan && nfin > 0) {
         int k = p.top_k < p.min_keep ? p.min_keep : p.top_k;
@@ -526,15 +694,6 @@ __global__ void __launch_bounds__(BLOCK, 8) vdd_contrast_sample_kernel(KP p) {
     }
 
     // ---- scores row out: issued LAST (after the token), see the end of the kernel ----------------
-    auto store_scores = [&]() {
-        if (p.scores != nullptr) {
-            if constexpr (LDSROW) {
-                for (int ch = tid; ch < nch; ch += BLOCK) { uint32_t w[4]; R.get(ch, w); gstore<DT>(p.scores, (long long)row * p.ss, ch, V, p.vec_out, w); }
-            } else if (p.scores != p.work) {
-                for (int ch = tid; ch < nch; ch += BLOCK) { uint32_t w[4]; R.get(ch, w); gstore<DT>(p.scores, (long long)row * p.ss, ch, V, p.vec_out, w); }
-            }
-        }
-    };
     if (row_bad) {
         store_scores();
         if (tid == 0) {
@@ -545,105 +704,9 @@ __global__ void __launch_bounds__(BLOCK, 8) vdd_contrast_sample_kernel(KP p) {
         return;
     }
     if (tid == 0 && p.status) p.status[row] = VDD_ROW_OK;
-    const bool want_top = p.top_prob != nullptr && p.n_top > 0;
     if ((p.flags & VDD_NO_SAMPLE) && !want_top) { store_scores(); return; }
 
     // ---- per-thread mass, block scan (thread-major order) ---------------------------
-    auto flagged = [&](int k) { return k >= 64 || ((livemask >> k) & 1ull) != 0ull; };
-
-    // ---- single-wave tail: rows that kept <= 64 candidates (the usual case after the plausibility mask) ------------
-    // The candidates are gathered into a 64-entry LDS list; ONE barrier later every wave but wave 0 only has its share
-    // of the scores row left to store, and wave 0 finishes the row alone: sort the list into the same thread-major
-    // enumeration order the general path uses, softmax numerators, wave scan, inverse-CDF draw (or argmax), top-n.
-    // This replaces three passes and five block-wide barriers, during which the 64 KiB LDS row and all 16 wave slots
-    // of the workgroup were held.
-    if (nfin <= 64 && p.top_k == 0 && !p.use_topp && nch <= 64 * BLOCK) {
-        const int kmax = (nch + BLOCK - 1) / BLOCK;
-        for (int ch = tid, k = 0; ch < nch; ch += BLOCK, ++k) {
-            if (!flagged(k)) continue;
-            uint32_t w[4]; R.get(ch, w);
-#pragma unroll
-            for (int j = 0; j < EPC; ++j) {
-                const uint32_t b = getb<DT>(w, j);
-                if (b != NINF) {
-                    const unsigned slot = atomicAdd(&sm.cand_n, 1u);
-                    sm.cand_rank[slot] = (unsigned)((tid * kmax + k) * EPC + j);
-                    sm.cand_x[slot] = Tr<DT>::to_f(b);
-                    sm.cand_idx[slot] = ch * EPC + j;
-                }
-            }
-        }
-        __syncthreads();
-        store_scores();
-        if (wave != 0) return;
-        const int n = nfin;
-        const bool act = lane < n;
-        const unsigned rk = act ? sm.cand_rank[lane] : 0xFFFFFFFFu;
-        const float xv = act ? sm.cand_x[lane] : -INFINITY;
-        const int id = act ? sm.cand_idx[lane] : 0x7fffffff;
-        // ---- top-n of softmax(scores): value descending, index ascending -------------------------------
-        float zsum = 0.f;
-        {
-            int pos = 0;
-            for (int q = 0; q < n; ++q) { const unsigned rq = __shfl(rk, q); pos += (rq < rk) ? 1 : 0; }
-            // numerators in enumeration order (sorted through LDS: every lane has its entry in registers by now)
-            if (act) { sm.cand_x[pos] = __expf(xv - m); sm.cand_idx[pos] = id; }
-        }
-        const float e_s = act ? sm.cand_x[lane] : 0.f;           // same wave: LDS program order
-        const int id_s = act ? sm.cand_idx[lane] : -1;
-        float incl = e_s;
-#pragma unroll
-        for (int o = 1; o < 64; o <<= 1) { const float nb = __shfl_up(incl, o); if (lane >= o) incl += nb; }
-        zsum = __shfl(incl, 63);
-        if (want_top) {
-            float pv = INFINITY; int pi = -1;
-            for (int r = 0; r < p.n_top; ++r) {
-                const bool after = act && (xv < pv || (xv == pv && id > pi));
-                float bv = after ? xv : -INFINITY; int bi = after ? id : 0x7fffffff;
-#pragma unroll
-                for (int o = 32; o > 0; o >>= 1) {
-                    const float ov2 = __shfl_xor(bv, o); const int oi = __shfl_xor(bi, o);
-                    if (ov2 > bv || (ov2 == bv && oi < bi)) { bv = ov2; bi = oi; }
-                }
-                const bool have = bi != 0x7fffffff;
-                if (lane == 0) {
-                    p.top_prob[(long long)row * p.n_top + r] = have ? rnd<DT>(__fdiv_rn(__expf(bv - m), zsum)) : 0.f;
-                    p.top_tok[(long long)row * p.n_top + r] = have ? bi : -1;
-                }
-                pv = have ? bv : -INFINITY; pi = bi;
-            }
-        }
-        if (p.flags & VDD_NO_SAMPLE) return;
-        int tok_i;
-        if (p.flags & VDD_PICK_ARGMAX) {
-            float bv = xv; int bi = id;
-#pragma unroll
-            for (int o = 32; o > 0; o >>= 1) {
-                const float ov2 = __shfl_xor(bv, o); const int oi = __shfl_xor(bi, o);
-                if (ov2 > bv || (ov2 == bv && oi < bi)) { bv = ov2; bi = oi; }
-            }
-            tok_i = bi;
-        } else {
-            const float u = p.uniforms ? p.uniforms[row] : philox_uniform(p.seed, p.offset + (p.offset_ptr ? *p.offset_ptr : 0ull), (unsigned)row);
-            const float target = u * zsum;
-            const unsigned long long hits = __ballot(act && e_s > 0.f && target < incl);
-            const unsigned long long mass = __ballot(act && e_s > 0.f);
-            const int pl = hits ? (int)__builtin_ctzll(hits) : (mass ? 63 - (int)__clzll((long long)mass) : n - 1);   // rounding: last entry holding mass
-            tok_i = __shfl(id_s, pl);
-        }
-        if (lane == 0) {
-            long long tok = (long long)tok_i;
-            if (p.unfinished != nullptr && p.n_eos > 0) {
-                long long uf = p.unfinished[row];
-                tok = tok * uf + p.pad * (1 - uf);                                              // :260
-                long long keep = 1;
-                for (int e = 0; e < p.n_eos; ++e) keep *= (tok != p.eos[e]) ? 1 : 0;             // :286-288
-                p.unfinished[row] = uf * keep;
-            }
-            p.next_tokens[(long long)row * p.st] = tok;
-        }
-        return;
-    }
 
     float t = 0.f;
     for (int ch = tid, k = 0; ch < nch; ch += BLOCK, ++k) {

@@ -46,11 +46,15 @@ def topp_boundary_ok(pre: torch.Tensor, ref: torch.Tensor, got: torch.Tensor, to
             continue
         x = pre[r].double()
         srt, idx = torch.sort(x)
-        cum = torch.softmax(srt, -1).cumsum(-1)
-        cum_at = torch.empty_like(cum)
+        prob = torch.softmax(srt, -1)
+        cum = prob.cumsum(-1)
+        cum_at, prob_at = torch.empty_like(cum), torch.empty_like(cum)
         cum_at[idx] = cum
-        near = (cum_at - (1 - top_p)).abs() <= tol
-        # ties: same value as some near-boundary entry
+        prob_at[idx] = prob
+        # on the boundary: the entry's own slice [cum - p_i, cum] of the ascending cumulative mass reaches 1 - p (+- tol)
+        near = (cum_at + tol >= 1 - top_p) & (cum_at - prob_at - tol <= 1 - top_p)
+        # ties: same value as such an entry (which of several equal scores an unstable sort drops is implementation-defined;
+        # the kernel keeps or drops equal scores together)
         near_vals = set(x[near].tolist())
         for i in torch.nonzero(diff).reshape(-1).tolist():
             if not (bool(near[i]) or x[i].item() in near_vals):
@@ -181,6 +185,37 @@ def test_contrast_rows_draw_by_inverse_cdf_in_both_tails(beta, expect_fast):
     e = L.contrast_sample(v[:2], c[:2], alpha=1.0, beta=beta, warp=L.WarpSpec(temperature=1.3), pick_argmax=True, eos_ids=eos, pad_id=7,
                           unfinished=unf)
     assert e.tokens.tolist() == [best, 7] and unf.tolist() == [0, 0]
+
+@pytest.mark.parametrize("dt", ["fp16", "bf16"])
+@pytest.mark.parametrize("beta,regime", [(0.3, "few"), (0.08, "mixed"), (1e-3, "many")])
+def test_warpers_after_the_mask_in_both_candidate_regimes(dt, beta, regime):
+    """VDD + top-k / top-p (llava_sampling.py sweeps exactly these): rows with <= 64 candidates apply the warpers inside one
+    wave, the others through the block-wide radix selection; both must reproduce the oracle's scores rows (top-k exact,
+    top-p up to the cumulative-mass boundary) and, for top-k = 1, the token."""
+    L = _L()
+    torch.manual_seed(33)
+    V, B, dtype = 32000, 6, DTYPES[dt]
+    v = (torch.randn(B, V) * 3).to(dtype)
+    c = (v.float() + torch.randn(B, V)).to(dtype)
+    for warp in ({"top_k": 1}, {"top_k": 5}, {"temperature": 0.7, "top_k": 40}, {"top_p": 0.6}, {"temperature": 1.5, "top_p": 0.9},
+                 {"temperature": 0.7, "top_k": 20, "top_p": 0.8}, {"top_p": 0.0}, {"top_k": 100000}):
+        spec = L.WarpSpec(temperature=warp.get("temperature"), top_k=warp.get("top_k"), top_p=warp.get("top_p"))
+        out = L.contrast_sample(v.to(DEV), c.to(DEV), alpha=1.0, beta=beta, warp=spec, return_scores=True, pick_argmax=True)
+        got = out.scores.cpu()
+        pre_mask = O.step_scores(v, c, None, 1.0, beta, O.WarpConfig())
+        nfin = torch.isfinite(pre_mask).sum(-1)
+        assert {"few": bool((nfin <= 64).all()), "many": bool((nfin > 64).all()), "mixed": bool((nfin <= 64).any() and (nfin > 64).any())}[regime], nfin.tolist()
+        want = O.step_scores(v, c, None, 1.0, beta, O.WarpConfig(**warp))
+        if warp.get("top_p") is None:
+            assert torch.equal(_bits(got), _bits(want)), warp
+        else:
+            pre = O.step_scores(v, c, None, 1.0, beta, O.WarpConfig(temperature=warp.get("temperature"), top_k=warp.get("top_k")))
+            # bf16: the reference's softmax + cumsum run in bf16 (8-bit mantissa: cumulative values near 0.1-0.4 move in steps of
+            # 5e-4..2e-3 and drift over hundreds of terms); the kernel integrates the mass in fp32, so the boundary zone is wider
+            assert topp_boundary_ok(pre, want, got, warp["top_p"], tol=4e-3 if dt == "fp16" else 1.2e-2), warp
+        if warp.get("top_k") == 1 or warp.get("top_p") == 0.0:
+            assert int(torch.isfinite(got).sum(-1).max()) == 1 or warp.get("top_k") == 1
+            assert out.tokens.cpu().tolist() == torch.argmax(want.float(), -1).tolist()
 
 
 def test_philox_sampling_matches_the_distribution():
