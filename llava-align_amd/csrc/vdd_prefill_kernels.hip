@@ -33,22 +33,37 @@ __device__ __forceinline__ float lo(uint32_t w) { return bf2f(w & 0xFFFFu); }
 __device__ __forceinline__ float hi(uint32_t w) { return __builtin_bit_cast(float, w & 0xFFFF0000u); }
 __device__ __forceinline__ uint32_t pack(float a, float b) { return f2bf(a) | (f2bf(b) << 16); }
 
+typedef __attribute__((ext_vector_type(2))) float f32x2_t;
+typedef __attribute__((ext_vector_type(2))) __bf16 bf16x2_t;
+// two fp32 -> packed bf16, round-to-nearest-even, in ONE instruction (v_cvt_pk_bf16_f32)
+__device__ __forceinline__ uint32_t cvt_pk_bf16(float a, float b) {
+    return __builtin_bit_cast(uint32_t, __builtin_convertvector(f32x2_t{a, b}, bf16x2_t));
+}
+
 struct SeqDesc { int q_row0, Tq, pos0, slot, pslot, plen; };
 
 constexpr float NEG_BIG = -1.0e30f;
 
+// Per 32-key step and wave (16 query rows):
+//   S^T = K Q^T   A = K fragment straight from the cache, with the key -> MFMA-row assignment
+//                 key(i) = kt + 8 (i / 4) + (i % 4) (+ 4 for the second tile), B = Q fragment (held in registers);
+//                 in the C layout lane (query ln, g) then owns the scores of keys kt + 8 g .. + 7: exactly the A fragment
+//                 of the PV product, so P never leaves registers (no LDS patch, no barrier for it);
+//   softmax       per query column: 8 local scores + 2 cross-group shuffles; the rescale factor of O row 4 g + r is
+//                 fetched from the lanes of column 4 g + r;
+//   O += P V      B = V fragment = 8 consecutive keys of one dim: one 16-byte LDS read from a TRANSPOSED, double-buffered
+//                 V tile [dim][32 keys] (conflict-free with the 80-byte row pitch) that the block stages once per step.
+// One barrier per step (the tile hand-off); 24 LDS instructions per lane and step instead of 75.
 template <int D, bool CAUSAL>
 __global__ void __launch_bounds__(256, 4) flash_attn_kernel(const uint16_t* __restrict__ q, const uint16_t* __restrict__ kc,
-                                                         const uint16_t* __restrict__ vc, const uint16_t* __restrict__ kpre,
-                                                         const uint16_t* __restrict__ vpre, const SeqDesc* __restrict__ seqs,
-                                                         uint16_t* __restrict__ out, int H, int Hkv, long long slot_stride,
-                                                         int t_max, long long pre_stride, int pre_tmax, float scale) {
+                                                            const uint16_t* __restrict__ vc, const uint16_t* __restrict__ kpre,
+                                                            const uint16_t* __restrict__ vpre, const SeqDesc* __restrict__ seqs,
+                                                            uint16_t* __restrict__ out, int H, int Hkv, long long slot_stride,
+                                                            int t_max, long long pre_stride, int pre_tmax, float scale) {
     constexpr int KS = D / 32;        // k-steps of the QK^T contraction
     constexpr int NT = D / 16;        // 16-wide output tiles over the head dim
-    constexpr int VLD = D + 8;        // padded V row (elements)
-    constexpr int PLD = 40;           // padded P row (elements)
-    __shared__ __attribute__((aligned(16))) uint16_t v_lds[32 * VLD];
-    __shared__ __attribute__((aligned(16))) uint16_t p_lds[4][16 * PLD];
+    constexpr int VTLD = 40;          // pitch of a transposed V row: 32 keys + 8 pad (80 B: 16-B aligned, conflict-free b128 reads)
+    __shared__ __attribute__((aligned(16))) uint16_t vt_lds[2][D * VTLD];
 
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int ln = lane & 15, g = lane >> 4;
@@ -61,7 +76,7 @@ __global__ void __launch_bounds__(256, 4) flash_attn_kernel(const uint16_t* __re
     const int last_row = min(qt0 + 63, sd.Tq - 1);
     const int kend = CAUSAL ? min(Tk, sd.pos0 + last_row + 1) : Tk;   // block-uniform key bound
 
-    // Q fragments (A operand): lane (m = ln, g) holds Q[r0 + m][32 ks + 8 g .. +7]
+    // Q fragments (B operand of S^T): lane (n = query ln, g) holds Q[r0 + ln][32 ks + 8 g .. +7]
     bf16x8_t qf[KS];
     {
         int qr = r0 + ln; if (qr >= sd.Tq) qr = sd.Tq - 1;
@@ -69,6 +84,7 @@ __global__ void __launch_bounds__(256, 4) flash_attn_kernel(const uint16_t* __re
 #pragma unroll
         for (int ks = 0; ks < KS; ++ks) qf[ks] = *reinterpret_cast<const bf16x8_t*>(qp + ks * 32);
     }
+    const int qpos = sd.pos0 + r0 + ln;                       // position of this lane's query column
     // own pool: token t at index t - plen (compact slots); prefix pool: token t at index t
     const size_t head_off = (size_t)kvh * t_max * D, pre_off = (size_t)kvh * pre_tmax * D;
     const uint16_t* kbase_own = kc + (size_t)sd.slot * slot_stride + head_off - (size_t)sd.plen * D;
@@ -79,83 +95,109 @@ __global__ void __launch_bounds__(256, 4) flash_attn_kernel(const uint16_t* __re
     f32x4_t o[NT];
 #pragma unroll
     for (int nt = 0; nt < NT; ++nt) o[nt] = f32x4_t{0.f, 0.f, 0.f, 0.f};
-    float mrow[4] = {NEG_BIG, NEG_BIG, NEG_BIG, NEG_BIG}, lrow[4] = {0.f, 0.f, 0.f, 0.f};
+    float mq = NEG_BIG, lq = 0.f;                             // running max / sum of query column ln (replicated over g)
 
-    for (int kt = 0; kt < kend; kt += 32) {
-        // ---- stage V[kt .. kt+31][0..D) into LDS (whole block) ----
-        __syncthreads();
-        for (int i = tid; i < 32 * (D / 8); i += 256) {
-            const int key = i / (D / 8), dd = (i % (D / 8)) * 8;
+    // staging map: consecutive lanes take consecutive KEYS of one 8-dim slab (2-byte-consecutive transposed LDS writes)
+    constexpr int SLABS = D / 8, PER = 32 * SLABS / 256;      // uint4 per thread per tile (D=128: 2, D=64: 1)
+    auto stage = [&](int kt, int buf) {
+#pragma unroll
+        for (int i = 0; i < PER; ++i) {
+            const int e = tid + i * 256;
+            const int key = e & 31, dd = (e >> 5) * 8;
             int t = kt + key; if (t >= Tk) t = Tk - 1;
-            const uint16_t* vp = (t < sd.plen ? vbase_pre : vbase_own) + (size_t)t * D + dd;
-            *reinterpret_cast<uint4*>(&v_lds[key * VLD + dd]) = *reinterpret_cast<const uint4*>(vp);
+            const uint4 v4 = *reinterpret_cast<const uint4*>((t < sd.plen ? vbase_pre : vbase_own) + (size_t)t * D + dd);
+            uint16_t* dst = &vt_lds[buf][dd * VTLD + key];
+            dst[0 * VTLD] = (uint16_t)(v4.x & 0xFFFFu); dst[1 * VTLD] = (uint16_t)(v4.x >> 16);
+            dst[2 * VTLD] = (uint16_t)(v4.y & 0xFFFFu); dst[3 * VTLD] = (uint16_t)(v4.y >> 16);
+            dst[4 * VTLD] = (uint16_t)(v4.z & 0xFFFFu); dst[5 * VTLD] = (uint16_t)(v4.z >> 16);
+            dst[6 * VTLD] = (uint16_t)(v4.w & 0xFFFFu); dst[7 * VTLD] = (uint16_t)(v4.w >> 16);
         }
-        // ---- S = Q K^T for 2 x 16 keys ----
+    };
+    stage(0, 0);
+    int buf = 0;
+    for (int kt = 0; kt < kend; kt += 32, buf ^= 1) {
+        // ---- S^T = K Q^T for 2 x 16 keys (MFMA row i of tile j is key kt + 8 (i / 4) + (i % 4) + 4 j) ----
         f32x4_t s[2] = {f32x4_t{0.f, 0.f, 0.f, 0.f}, f32x4_t{0.f, 0.f, 0.f, 0.f}};
 #pragma unroll
         for (int j = 0; j < 2; ++j) {
-            int t = kt + 16 * j + ln; if (t >= Tk) t = Tk - 1;
+            int t = kt + (ln >> 2) * 8 + (ln & 3) + 4 * j; if (t >= Tk) t = Tk - 1;
             const uint16_t* kp = (t < sd.plen ? kbase_pre : kbase_own) + (size_t)t * D + g * 8;
 #pragma unroll
             for (int ks = 0; ks < KS; ++ks) {
-                bf16x8_t kf = *reinterpret_cast<const bf16x8_t*>(kp + ks * 32);
-                s[j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(qf[ks], kf, s[j], 0, 0, 0);
+                const bf16x8_t kf = *reinterpret_cast<const bf16x8_t*>(kp + ks * 32);
+                s[j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(kf, qf[ks], s[j], 0, 0, 0);
             }
         }
-        // ---- mask + online softmax (C layout: row = 4 g + r, col = key ln (+16 j)) ----
-        float p[2][4];
+        __syncthreads();                                      // tile `buf` staged by everyone; tile buf^1 no longer read
+        if (kt + 32 < kend) stage(kt + 32, buf ^ 1);          // next tile's loads fly under this step's arithmetic
+        // ---- mask + online softmax of query column ln: this lane's scores are keys kt + 8 g + 4 j + r ----
+        // masking is only needed on the causal diagonal and on the ragged last tile (wave-uniform test)
+        const bool need_mask = (kt + 32 > Tk) || (CAUSAL && kt + 31 > sd.pos0 + r0);
+        float mx = NEG_BIG;
+        if (need_mask) {
 #pragma unroll
-        for (int r = 0; r < 4; ++r) {
-            const int qpos = sd.pos0 + r0 + g * 4 + r;
-            float mx = NEG_BIG;
+            for (int j = 0; j < 2; ++j)
 #pragma unroll
-            for (int j = 0; j < 2; ++j) {
-                const int key = kt + 16 * j + ln;
-                float v = s[j][r] * scale;
-                if (key >= Tk || (CAUSAL && key > qpos)) v = NEG_BIG;
-                p[j][r] = v;
-                mx = fmaxf(mx, v);
-            }
-            mx = fmaxf(mx, __shfl_xor(mx, 1)); mx = fmaxf(mx, __shfl_xor(mx, 2));
-            mx = fmaxf(mx, __shfl_xor(mx, 4)); mx = fmaxf(mx, __shfl_xor(mx, 8));
-            const float mn = fmaxf(mrow[r], mx);
-            const float corr = __expf(mrow[r] - mn);
-            float ps = 0.f;
+                for (int r = 0; r < 4; ++r) {
+                    const int key = kt + 8 * g + 4 * j + r;
+                    float v = s[j][r] * scale;
+                    if (key >= Tk || (CAUSAL && key > qpos)) v = NEG_BIG;
+                    s[j][r] = v; mx = fmaxf(mx, v);
+                }
+        } else {
 #pragma unroll
-            for (int j = 0; j < 2; ++j) { p[j][r] = (p[j][r] <= NEG_BIG * 0.5f) ? 0.f : __expf(p[j][r] - mn); ps += p[j][r]; }
-            lrow[r] = lrow[r] * corr + ps;                    // per-lane partial row sum (reduced at the end)
-            mrow[r] = mn;
+            for (int j = 0; j < 2; ++j)
 #pragma unroll
-            for (int nt = 0; nt < NT; ++nt) o[nt][r] *= corr;
+                for (int r = 0; r < 4; ++r) { s[j][r] *= scale; mx = fmaxf(mx, s[j][r]); }
         }
-        // ---- P (C layout) -> LDS -> A fragment ----
-        uint16_t* pw = p_lds[wave];
+        mx = fmaxf(mx, __shfl_xor(mx, 16)); mx = fmaxf(mx, __shfl_xor(mx, 32));
+        const float mn = fmaxf(mq, mx);
+        float pv[8], ps = 0.f;
 #pragma unroll
-        for (int r = 0; r < 4; ++r)
+        for (int j = 0; j < 2; ++j)
 #pragma unroll
-            for (int j = 0; j < 2; ++j) pw[(g * 4 + r) * PLD + 16 * j + ln] = (uint16_t)f2bf(p[j][r]);
-        __syncthreads();                                      // V tile staged (all waves) and P patch written
-        const bf16x8_t pf = *reinterpret_cast<const bf16x8_t*>(&pw[ln * PLD + g * 8]);
-        // ---- O += P V : B fragment lane (dim = 16 nt + ln, g) holds V[kt + 8 g + i][dim], i < 8 ----
+            for (int r = 0; r < 4; ++r) {
+                const float e = __expf(s[j][r] - mn);            // masked scores: exp(-1e30 - mn) = 0
+                pv[4 * j + r] = e; ps += e;
+            }
+        bf16x8_t pf;
+        {
+            const uint4 pk = make_uint4(cvt_pk_bf16(pv[0], pv[1]), cvt_pk_bf16(pv[2], pv[3]), cvt_pk_bf16(pv[4], pv[5]), cvt_pk_bf16(pv[6], pv[7]));
+            pf = __builtin_bit_cast(bf16x8_t, pk);
+        }
+        ps += __shfl_xor(ps, 16); ps += __shfl_xor(ps, 32);
+        // the running maximum moves on few steps: rescale (l, O) lazily behind a wave-uniform test.  O rows are queries
+        // 4 g + r: their factor lives in the lanes of column 4 g + r.
+        if (__any(mn > mq)) {
+            const float corr = __expf(mq - mn);
+            lq *= corr;
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                const float cr = __shfl(corr, 4 * g + r);
+#pragma unroll
+                for (int nt = 0; nt < NT; ++nt) o[nt][r] *= cr;
+            }
+        }
+        lq += ps;
+        mq = mn;
+        // ---- O += P V : B fragment lane (dim = 16 nt + ln, g) = V[kt + 8 g .. + 7][dim] = 16 B of the transposed tile ----
+        const uint16_t* vt = &vt_lds[buf][(size_t)ln * VTLD + g * 8];
 #pragma unroll
         for (int nt = 0; nt < NT; ++nt) {
-            bf16x8_t vf;
-#pragma unroll
-            for (int i = 0; i < 8; ++i) vf[i] = (short)v_lds[(g * 8 + i) * VLD + nt * 16 + ln];
+            const bf16x8_t vf = *reinterpret_cast<const bf16x8_t*>(vt + nt * 16 * VTLD);
             o[nt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(pf, vf, o[nt], 0, 0, 0);
         }
     }
-    // ---- finish: reduce row sums over the 16 lanes of a group, normalise, store ----
+    // ---- finish: normalise (row sum of query 4 g + r from the lanes of that column), store ----
 #pragma unroll
     for (int r = 0; r < 4; ++r) {
-        float l = lrow[r];
-        l += __shfl_xor(l, 1); l += __shfl_xor(l, 2); l += __shfl_xor(l, 4); l += __shfl_xor(l, 8);
+        const float l = __shfl(lq, 4 * g + r);
         const int qr = r0 + g * 4 + r;
         if (qr < sd.Tq) {
             const float inv = 1.f / l;
             uint16_t* op = out + ((size_t)(sd.q_row0 + qr) * H + head) * D + ln;
 #pragma unroll
-            for (int nt = 0; nt < NT; ++nt) op[nt * 16] = (uint16_t)f2bf(o[nt][r] * inv);
+            for (int nt = 0; nt < NT; ++nt) op[nt * 16] = (uint16_t)(cvt_pk_bf16(o[nt][r] * inv, 0.f) & 0xFFFFu);
         }
     }
 }
