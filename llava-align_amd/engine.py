@@ -295,6 +295,23 @@ class KVCache:
         return sum(t.numel() * 2 for pool in (self.kp, self.vp, self.vp8, self.ko, self.vo) for t in pool)
 
 
+def h2d_int32(device, *arrays):
+    """Several small host integer arrays -> device int32 tensors through ONE pinned staging buffer and ONE async copy.
+    (Each `torch.tensor(list, device=...)` is a synchronous pageable copy: a dozen of them per generate() call were a
+    third of the host time of a one-question prefill.)"""
+    flat = [torch.as_tensor(a, dtype=torch.int32).reshape(-1) for a in arrays]
+    sizes = [int(f.numel()) for f in flat]
+    host = torch.empty(sum(sizes), dtype=torch.int32).pin_memory()
+    torch.cat(flat, out=host) if flat else None
+    dev_buf = host.to(device, non_blocking=True)
+    out, o = [], 0
+    for a, n in zip(arrays, sizes):
+        shape = torch.as_tensor(a).shape if not torch.is_tensor(a) else a.shape
+        out.append(dev_buf[o:o + n].view(*shape) if n else dev_buf[o:o])
+        o += n
+    return out
+
+
 def grouping_pays(groups, rows, min_saved=0.25) -> bool:
     """The grouped prefix pass reads a shared prefix once per group instead of once per row; it only beats the per-row
     split-KV kernel when that removes a real share of the step's KV bytes.  BASELINE config #3 (one image per question:
@@ -450,16 +467,18 @@ class _DecodeRunner:
         self.ctr.fill_(ctr0)
 
     def load(self, pos, cpos, slot, rows):
-        self.pos.copy_(torch.tensor(pos, dtype=torch.int32)); self.slot.copy_(torch.tensor(slot, dtype=torch.int32))
-        self.cpos.copy_(torch.tensor(cpos, dtype=torch.int32))
+        dev = self.pos.device
         if self.grouping is not None:
             groups, members = group_rows_by_prefix(rows)
             items = ops.prefix_work_items(groups, self.grouping["cpi"])
             assert len(groups) == self.grouping["n_groups"] and len(items) == self.grouping["n_items"]
-            self.grouping["groups"].copy_(torch.tensor(groups, dtype=torch.int32))
-            self.grouping["items"].copy_(torch.tensor(items, dtype=torch.int32))
-            self.grouping["group_rows"][: len(members)].copy_(torch.tensor(members, dtype=torch.int32))
-        self.rows.copy_(torch.tensor(rows, dtype=torch.int32))
+            p_, c_, s_, r_, g_, i_, m_ = h2d_int32(dev, pos, cpos, slot, rows, groups, items, members)
+            self.grouping["groups"].copy_(g_)
+            self.grouping["items"].copy_(i_)
+            self.grouping["group_rows"][: len(members)].copy_(m_)
+        else:
+            p_, c_, s_, r_ = h2d_int32(dev, pos, cpos, slot, rows)
+        self.pos.copy_(p_); self.cpos.copy_(c_); self.slot.copy_(s_); self.rows.copy_(r_)
         self.gen[:, 0] = self.tok
         self.step_idx.fill_(1)
         self.ctr += 1
@@ -661,11 +680,12 @@ class VddLlavaEngine:
             x, pos, cpos, slot, seqs, max_tq = self._pack(segs)
             resid, delta = self.lm.prefill(x, pos, cpos, slot, seqs, len(segs), max_tq, kv, to_prefix_pool=(phase == "prefix"))
             if phase == "prefix" and self.group_attention:
-                plen_t = torch.tensor([s_["T"] for s_ in segs], dtype=torch.int32, device=dev)
+                (plen_t,) = h2d_int32(dev, [s_["T"] for s_ in segs])
                 for li in range(lm.n_layers):
                     ops.prefix_v_transpose(kv.vp[li], kv.vp8[li], plen_t)
             if phase == "suffix":
-                last = torch.tensor([s["q_row0"] + s["T"] - 1 for s in segs], device=dev)
+                (last,) = h2d_int32(dev, [s["q_row0"] + s["T"] - 1 for s in segs])
+                last = last.long()
                 logits0 = self.lm.logits(resid, delta, last)                                  # [nb*Q, V], rows ordered branch-major
                 self.debug_logits0 = logits0
         V = lm.vocab
@@ -818,11 +838,14 @@ class VddLlavaEngine:
                 x[r + len(pre): r + len(pre) + s["img"].shape[0]] = s["img"]
                 r2 = r + len(pre) + s["img"].shape[0]
                 flat_ids += suf; flat_rows += list(range(r2, r2 + len(suf)))
+        pos_h = torch.cat([torch.arange(s["pos0"], s["pos0"] + s["T"], dtype=torch.int32) for s in segs])
+        cpos_h = torch.cat([torch.arange(0, s["T"], dtype=torch.int32) for s in segs])           # index inside the slot (= pos - plen)
+        slot_h = torch.cat([torch.full((s["T"],), s["slot"], dtype=torch.int32) for s in segs])
+        seqs_h = torch.tensor([[s["q_row0"], s["T"], s["pos0"], s["slot"], s["pslot"], s["plen"]] for s in segs], dtype=torch.int32)
+        ids_h = torch.tensor(flat_ids, dtype=torch.int32)
+        rows_h = torch.tensor(flat_rows, dtype=torch.int32)
+        pos, cpos, slot, seqs, ids_d, rows_d = h2d_int32(dev, pos_h, cpos_h, slot_h, seqs_h, ids_h, rows_h)
         if flat_ids:
-            emb = ops.embed(torch.tensor(flat_ids, dtype=torch.long, device=dev), t["embed"])
-            x[torch.tensor(flat_rows, dtype=torch.long, device=dev)] = emb
-        pos = torch.cat([torch.arange(s["pos0"], s["pos0"] + s["T"], dtype=torch.int32) for s in segs]).to(dev)
-        cpos = torch.cat([torch.arange(0, s["T"], dtype=torch.int32) for s in segs]).to(dev)      # index inside the slot (= pos - plen)
-        slot = torch.cat([torch.full((s["T"],), s["slot"], dtype=torch.int32) for s in segs]).to(dev)
-        seqs = torch.tensor([[s["q_row0"], s["T"], s["pos0"], s["slot"], s["pslot"], s["plen"]] for s in segs], dtype=torch.int32, device=dev)
+            emb = ops.embed(ids_d.long(), t["embed"])
+            x[rows_d.long()] = emb
         return x, pos, cpos, slot, seqs, max(s["T"] for s in segs)
