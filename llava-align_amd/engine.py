@@ -26,6 +26,7 @@ go to hipBLASLt through torch.matmul (a plain library GEMM).  bf16 storage, fp32
 from __future__ import annotations
 
 import gc
+import os
 import math
 from dataclasses import dataclass, field
 from typing import Dict, List, Optional, Sequence
@@ -228,6 +229,15 @@ class VisionTower:
         dh = v.width // v.heads
         assert dh == 64, "the ViT attention kernel is instantiated for head_dim 64"
         self._kv = None
+        self.use_graph = False               # set by the engine; a full GRAPH_BATCH of images then replays a HIP graph
+        self._graph = self._g_in = self._g_out = None
+        self._seq_desc: Dict[int, torch.Tensor] = {}
+
+    def _seqs(self, n):
+        if n not in self._seq_desc:
+            T = self.T
+            self._seq_desc[n] = torch.tensor([[i * T, T, 0, i, 0, 0] for i in range(n)], dtype=torch.int32, device=self.w.device)
+        return self._seq_desc[n]
 
     def _kv_cache(self, n_img):
         v = self.cfg
@@ -236,9 +246,42 @@ class VisionTower:
             self._kv = (mk(), mk())
         return self._kv
 
+    GRAPH_BATCH = 16
+
     @torch.no_grad()
     def __call__(self, images: torch.Tensor) -> torch.Tensor:
-        """images [n, 3, S, S] (any float dtype) -> projected patch features [n, n_patches, d_lm] bf16."""
+        """images [n, 3, S, S] (any float dtype) -> projected patch features [n, n_patches, d_lm] bf16.
+        A full GRAPH_BATCH of images replays a captured HIP graph: the tower is ~400 small launches per batch and runs
+        when nothing else is queued, so issued from Python it is launch-bound (98 ms of host time for 43 ms of GPU work
+        per 64 images, tools/host_phase_probe.py)."""
+        if self.use_graph and images.shape[0] == self.GRAPH_BATCH and self.w.device.type == "cuda" and os.environ.get("VDD_VIT_GRAPH", "1") != "0":
+            if self._graph is None:
+                self._g_in = torch.empty(self.GRAPH_BATCH, *images.shape[1:], dtype=torch.bfloat16, device=self.w.device)
+                self._g_in.copy_(images)
+                side = torch.cuda.Stream(self.w.device)
+                side.wait_stream(torch.cuda.current_stream(self.w.device))
+                with torch.cuda.stream(side):
+                    for _ in range(2):
+                        self._forward(self._g_in)
+                torch.cuda.current_stream(self.w.device).wait_stream(side)
+                g = torch.cuda.CUDAGraph()
+                gc.collect()
+                gc_on = gc.isenabled()
+                gc.disable()
+                try:
+                    with torch.cuda.graph(g):
+                        self._g_out = self._forward(self._g_in)
+                finally:
+                    if gc_on:
+                        gc.enable()
+                self._graph = g
+            self._g_in.copy_(images.to(self.w.device, non_blocking=True))      # H2D in the caller's dtype, bf16 cast on the device
+            self._graph.replay()
+            return self._g_out.clone()
+        return self._forward(images)
+
+    @torch.no_grad()
+    def _forward(self, images: torch.Tensor) -> torch.Tensor:
         v, t = self.cfg, self.w.t
         n = images.shape[0]
         dev = self.w.device
@@ -253,7 +296,7 @@ class VisionTower:
         T, H, D = self.T, v.heads, v.width // v.heads
         h = ops.layernorm(h.reshape(n * T, v.width).contiguous(), t["v.pre_ln.w"], t["v.pre_ln.b"], v.eps)
         kc, vc = self._kv_cache(n)
-        seqs = torch.tensor([[i * T, T, 0, i, 0, 0] for i in range(n)], dtype=torch.int32, device=dev)
+        seqs = self._seqs(n)
         for i in range(v.run_layers):
             p = f"v{i}."
             a = ops.layernorm(h, t[p + "ln1.w"], t[p + "ln1.b"], v.eps)
@@ -296,17 +339,18 @@ class KVCache:
 
 
 def h2d_int32(device, *arrays):
-    """Several small host integer arrays -> device int32 tensors through ONE pinned staging buffer and ONE async copy.
-    (Each `torch.tensor(list, device=...)` is a synchronous pageable copy: a dozen of them per generate() call were a
-    third of the host time of a one-question prefill.)"""
+    """Several small host integer arrays -> device int32 tensors through ONE pinned staging buffer (torch's caching host
+    allocator recycles it) and ONE async copy.  Each `torch.tensor(list, device=...)` is a synchronous pageable copy; a
+    dozen of them sat in every generate()."""
     flat = [torch.as_tensor(a, dtype=torch.int32).reshape(-1) for a in arrays]
+    shapes = [tuple(torch.as_tensor(a).shape) if not torch.is_tensor(a) else tuple(a.shape) for a in arrays]
     sizes = [int(f.numel()) for f in flat]
-    host = torch.empty(sum(sizes), dtype=torch.int32).pin_memory()
-    torch.cat(flat, out=host) if flat else None
+    host = torch.empty(sum(sizes), dtype=torch.int32, pin_memory=True)
+    if flat:
+        torch.cat(flat, out=host)
     dev_buf = host.to(device, non_blocking=True)
     out, o = [], 0
-    for a, n in zip(arrays, sizes):
-        shape = torch.as_tensor(a).shape if not torch.is_tensor(a) else a.shape
+    for shape, n in zip(shapes, sizes):
         out.append(dev_buf[o:o + n].view(*shape) if n else dev_buf[o:o])
         o += n
     return out
@@ -550,6 +594,7 @@ class VddLlavaEngine:
         self.device = torch.device(device)
         self.w = weights if weights is not None else LlavaWeights.random(self.cfg, self.device, seed)
         self.vit = VisionTower(self.w)
+        self.vit.use_graph = use_graph
         self.lm = LanguageModel(self.w)
         self.max_q, self.t_max, self.use_graph = max_questions, t_max, use_graph
         # decode attention reads each shared prompt prefix once per GROUP of rows (K/V tiles staged in LDS)
@@ -594,8 +639,21 @@ class VddLlavaEngine:
         self._feat_cache.clear()
 
     # -- generate -------------------------------------------------------------------------------
+    def generate(self, *args, **kwargs) -> "GenerateOutput":
+        """See `_generate`.  Runs it with the cyclic garbage collector paused: the prefill issues ~2,000 launches from
+        Python while holding a few thousand small planning objects, and a generation-2 collection landing in the middle
+        stalls the launch queue for 50-200 ms (rocprofv3 kernel trace of `bench.py`: prefill GPU-busy time 740 ms in
+        every call, wall 764-1,061 ms with one or two such holes) - reference counting still frees everything promptly."""
+        was_on = gc.isenabled()
+        gc.disable()
+        try:
+            return self._generate(*args, **kwargs)
+        finally:
+            if was_on:
+                gc.enable()
+
     @torch.no_grad()
-    def generate(self, input_ids: Sequence[torch.Tensor] | torch.Tensor, images=None, images_cd=None, image_keys=None,
+    def _generate(self, input_ids: Sequence[torch.Tensor] | torch.Tensor, images=None, images_cd=None, image_keys=None,
                  cd_alpha: Optional[float] = None, cd_beta: Optional[float] = None, use_dd: bool = False,
                  use_dd_unk: bool = False, do_sample: bool = True, temperature: Optional[float] = None,
                  top_p: Optional[float] = None, top_k: Optional[int] = None, max_new_tokens: int = 64,
@@ -818,34 +876,39 @@ class VddLlavaEngine:
         return 0
 
     def _pack(self, segs):
-        """Builds the packed embedding matrix and the per-token / per-sequence descriptors of a prefill pass."""
+        """Builds the packed embedding matrix and the per-token / per-sequence descriptors of a prefill pass (numpy on the
+        host: one Python iteration per SEQUENCE, none per token; the descriptors go to the device in one copy)."""
+        import numpy as np
         dev, t = self.device, self.w.t
-        tok_ids, spans = [], []
-        row = 0
-        for s in segs:
-            s["q_row0"] = row
-            row += s["T"]
-        x = torch.empty(row, self.cfg.lm.d, dtype=torch.bfloat16, device=dev)
-        flat_ids, flat_rows = [], []
-        for s in segs:
-            r = s["q_row0"]
+        T = np.fromiter((s["T"] for s in segs), dtype=np.int64, count=len(segs))
+        q0 = np.concatenate([[0], np.cumsum(T)[:-1]])
+        total = int(T.sum())
+        for s, r in zip(segs, q0.tolist()):
+            s["q_row0"] = r
+        x = torch.empty(total, self.cfg.lm.d, dtype=torch.bfloat16, device=dev)
+        id_chunks, row_chunks = [], []
+        for s, r in zip(segs, q0.tolist()):
             if s.get("tokens") is not None and s["img"] is None:
-                flat_ids += s["tokens"]; flat_rows += list(range(r, r + s["T"]))
+                id_chunks.append(s["tokens"]); row_chunks.append(np.arange(r, r + s["T"]))
             else:
                 pre = s["tokens"] if s.get("tokens") is not None else s["pre"]
                 suf = s.get("suf", [])
-                flat_ids += pre; flat_rows += list(range(r, r + len(pre)))
-                x[r + len(pre): r + len(pre) + s["img"].shape[0]] = s["img"]
-                r2 = r + len(pre) + s["img"].shape[0]
-                flat_ids += suf; flat_rows += list(range(r2, r2 + len(suf)))
-        pos_h = torch.cat([torch.arange(s["pos0"], s["pos0"] + s["T"], dtype=torch.int32) for s in segs])
-        cpos_h = torch.cat([torch.arange(0, s["T"], dtype=torch.int32) for s in segs])           # index inside the slot (= pos - plen)
-        slot_h = torch.cat([torch.full((s["T"],), s["slot"], dtype=torch.int32) for s in segs])
-        seqs_h = torch.tensor([[s["q_row0"], s["T"], s["pos0"], s["slot"], s["pslot"], s["plen"]] for s in segs], dtype=torch.int32)
-        ids_h = torch.tensor(flat_ids, dtype=torch.int32)
-        rows_h = torch.tensor(flat_rows, dtype=torch.int32)
-        pos, cpos, slot, seqs, ids_d, rows_d = h2d_int32(dev, pos_h, cpos_h, slot_h, seqs_h, ids_h, rows_h)
-        if flat_ids:
+                n_img = int(s["img"].shape[0])
+                x[r + len(pre): r + len(pre) + n_img] = s["img"]
+                if pre:
+                    id_chunks.append(pre); row_chunks.append(np.arange(r, r + len(pre)))
+                if suf:
+                    r2 = r + len(pre) + n_img
+                    id_chunks.append(suf); row_chunks.append(np.arange(r2, r2 + len(suf)))
+        ids_h = np.concatenate([np.asarray(c, dtype=np.int32) for c in id_chunks]) if id_chunks else np.zeros(0, np.int32)
+        rows_h = np.concatenate(row_chunks).astype(np.int32) if row_chunks else np.zeros(0, np.int32)
+        within = np.arange(total) - np.repeat(q0, T)                                      # index inside the slot (= pos - plen)
+        pos_h = (within + np.repeat(np.fromiter((s["pos0"] for s in segs), dtype=np.int64, count=len(segs)), T)).astype(np.int32)
+        cpos_h = within.astype(np.int32)
+        slot_h = np.repeat(np.fromiter((s["slot"] for s in segs), dtype=np.int64, count=len(segs)), T).astype(np.int32)
+        seqs_h = np.array([[s["q_row0"], s["T"], s["pos0"], s["slot"], s["pslot"], s["plen"]] for s in segs], dtype=np.int32)
+        pos, cpos, slot, seqs, ids_d, rows_d = h2d_int32(dev, *(torch.from_numpy(a) for a in (pos_h, cpos_h, slot_h, seqs_h, ids_h, rows_h)))
+        if ids_h.size:
             emb = ops.embed(ids_d.long(), t["embed"])
             x[rows_d.long()] = emb
         return x, pos, cpos, slot, seqs, max(s["T"] for s in segs)

@@ -297,3 +297,28 @@ def test_qwen_shaped_lm_bias_and_large_vocab():
                              use_cache=True)
         s_got, s_want = t.scores[0][q].float().cpu(), r.scores[0][0].float().cpu()
         assert (s_got - s_want).abs().max().item() <= 0.4
+
+
+def test_vit_graph_replay_equals_eager_forward():
+    """A full batch of VisionTower.GRAPH_BATCH images replays a captured HIP graph; smaller batches and the first call of a
+    process run eagerly: same features either way, and replays see NEW images (static input buffer refreshed)."""
+    from llava_align_amd.engine import LlavaWeights, VddLlavaEngine, preset
+    cfg = preset("tiny")
+    e = VddLlavaEngine(cfg, weights=LlavaWeights.random(cfg, DEV, seed=3, std=0.06), device=DEV, use_graph=True)
+    nb = e.vit.GRAPH_BATCH
+    g = torch.Generator().manual_seed(4)
+    for rep in range(3):
+        imgs = torch.randn(nb, 3, cfg.vision.image, cfg.vision.image, generator=g)
+        got = e.vit(imgs)
+        assert e.vit._graph is not None
+        want = e.vit._forward(imgs)
+        assert got.shape == want.shape and torch.equal(got, want), rep
+    small = torch.randn(3, 3, cfg.vision.image, cfg.vision.image, generator=g)
+    assert torch.equal(e.vit(small), e.vit._forward(small))
+    # through generate(): 16 distinct images -> the graph path feeds the prefill
+    ids = [torch.tensor([1, 5, 6, -200, 7 + i, 8]) for i in range(nb)]
+    imgs = [torch.randn(3, cfg.vision.image, cfg.vision.image, generator=g) for _ in range(nb)]
+    a = e.generate(ids, images=imgs, use_dd_unk=True, cd_alpha=1.0, cd_beta=0.1, temperature=0.5, max_new_tokens=3, cd_greedy=True)
+    e2 = VddLlavaEngine(cfg, weights=e.w, device=DEV, use_graph=False)
+    b = e2.generate(ids, images=imgs, use_dd_unk=True, cd_alpha=1.0, cd_beta=0.1, temperature=0.5, max_new_tokens=3, cd_greedy=True)
+    assert torch.equal(a.tokens, b.tokens)
