@@ -204,6 +204,14 @@ __global__ void __launch_bounds__(256) embed_kernel(const long long* __restrict_
         *reinterpret_cast<uint4*>(out + (size_t)row * d + e) = *reinterpret_cast<const uint4*>(table + (size_t)id * d + e);
 }
 
+__global__ void __launch_bounds__(256) embed_scatter_kernel(const int* __restrict__ ids, const int* __restrict__ rows,
+                                                            const uint16_t* __restrict__ table, uint16_t* __restrict__ out, int d) {
+    const long long id = ids[blockIdx.x];
+    const size_t row = (size_t)rows[blockIdx.x];
+    for (int e = threadIdx.x * 8; e < d; e += 256 * 8)
+        *reinterpret_cast<uint4*>(out + row * d + e) = *reinterpret_cast<const uint4*>(table + (size_t)id * d + e);
+}
+
 // ------------------------------------------------------------------ skinny GEMM (weight streaming)
 // Y[M,N] = X[M,K] * W[N,K]^T (+ R[M,N]).  One 256-thread block owns 16 output columns; its 4
 // waves split K four ways and each streams its quarter of the 16 W rows straight into MFMA B
@@ -837,6 +845,13 @@ int vdd_embed(const int64_t* ids, const void* table, void* out, int M, int d, vo
     if (M <= 0) return VDD_OK;
     if (!ids || !table || !out || d % 8 != 0) return VDD_ERR_INVALID_ARG;
     hipLaunchKernelGGL(embed_kernel, dim3(M), dim3(256), 0, (hipStream_t)stream, (const long long*)ids, (const uint16_t*)table, (uint16_t*)out, d);
+    return ok(hipSuccess);
+}
+
+int vdd_embed_scatter(const int32_t* ids, const int32_t* rows, const void* table, void* out, int M, int d, void* stream) {
+    if (M <= 0) return VDD_OK;
+    if (!ids || !rows || !table || !out || d % 8 != 0) return VDD_ERR_INVALID_ARG;
+    hipLaunchKernelGGL(embed_scatter_kernel, dim3(M), dim3(256), 0, (hipStream_t)stream, ids, rows, (const uint16_t*)table, (uint16_t*)out, d);
     return ok(hipSuccess);
 }
 

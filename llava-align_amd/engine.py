@@ -909,6 +909,5 @@ class VddLlavaEngine:
         seqs_h = np.array([[s["q_row0"], s["T"], s["pos0"], s["slot"], s["pslot"], s["plen"]] for s in segs], dtype=np.int32)
         pos, cpos, slot, seqs, ids_d, rows_d = h2d_int32(dev, *(torch.from_numpy(a) for a in (pos_h, cpos_h, slot_h, seqs_h, ids_h, rows_h)))
         if ids_h.size:
-            emb = ops.embed(ids_d.long(), t["embed"])
-            x[rows_d.long()] = emb
+            ops.embed_scatter(ids_d, rows_d, t["embed"], x)
         return x, pos, cpos, slot, seqs, max(s["T"] for s in segs)

@@ -12,6 +12,7 @@ from . import _lib
 
 _P, _I, _L, _F = C.c_void_p, C.c_int, C.c_int64, C.c_float
 _SIGS = {
+    "vdd_embed_scatter": [_P, _P, _P, _P, _I, _I, _P],
     "vdd_tile_weight": [_P, _P, _I, _I, _I, _P],
     "vdd_skinny_swiglu_tiled": [_P, _P, _P, _I, _I, _I, _L, _P],
     "vdd_skinny_swiglu": [_P, _P, _P, _I, _I, _I, _L, _P],
@@ -117,6 +118,15 @@ def embed(ids, table, out=None):
     M, d = ids.numel(), table.shape[1]
     out = torch.empty(M, d, dtype=table.dtype, device=table.device) if out is None else out
     _lib.check(_lib_ready().vdd_embed(ids.data_ptr(), table.data_ptr(), out.data_ptr(), M, d, _st(table)))
+    return out
+
+
+def embed_scatter(ids, rows, table, out):
+    """out[rows[m]] = table[ids[m]] (int32 ids / rows): the text chunks of a packed multimodal prompt, in place."""
+    _bf16(table, out)
+    if ids.dtype != torch.int32 or rows.dtype != torch.int32 or ids.numel() != rows.numel():
+        raise ValueError("embed_scatter takes int32 ids and rows of equal length")
+    _lib.check(_lib_ready().vdd_embed_scatter(ids.data_ptr(), rows.data_ptr(), table.data_ptr(), out.data_ptr(), ids.numel(), table.shape[1], _st(table)))
     return out
 
 

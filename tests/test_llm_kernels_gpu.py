@@ -64,6 +64,18 @@ def test_rope_kv_write():
     assert int((kc != 0).any(-1).sum()) == M * Hkv      # nothing else touched
 
 
+def test_embed_scatter_writes_rows_in_place():
+    O = ops()
+    table = bf(1000, 256, seed=61)
+    out = torch.full((40, 256), 7.0, dtype=torch.bfloat16, device=DEV)
+    ids = torch.tensor([5, 999, 0, 5], dtype=torch.int32, device=DEV)
+    rows = torch.tensor([3, 0, 39, 17], dtype=torch.int32, device=DEV)
+    O.embed_scatter(ids, rows, table, out)
+    want = torch.full((40, 256), 7.0, dtype=torch.bfloat16, device=DEV)
+    want[rows.long()] = table[ids.long()]
+    assert torch.equal(out, want)
+
+
 def test_silu_mul_and_embed():
     O = ops()
     gu = bf(5, 2 * 11008, seed=5)
