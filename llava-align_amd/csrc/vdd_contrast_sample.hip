@@ -13,14 +13,16 @@
 // fl() = round-to-nearest-even into the MODEL dtype after every torch op, exactly as
 // eager torch does, so the scores row is bit-identical to the reference's.
 //
-// Mapping: one 1024-thread workgroup (16 waves) per row; the row is cut into 16-byte
-// chunks and chunk ch belongs to thread ch % 1024 in EVERY pass, so a wave reads 1 KiB
+// Mapping: one 512-thread workgroup (8 waves) per row; the row is cut into 16-byte
+// chunks and chunk ch belongs to thread ch % 512 in EVERY pass, so a wave reads 1 KiB
 // contiguous per load and no pass ever reads another thread's chunk (no data barriers,
-// only the 16-entry reduction exchanges).  The working row lives in LDS (V=32000 bf16 =
-// 62.5 KiB -> two workgroups per CU, 2048 threads); v is read from HBM once, c/d once,
-// scores written once: HBM traffic = the algorithmic (n_in + n_out) * V * sizeof(dtype)
-// bytes per row.  Rows too large for LDS (Qwen, V=151936) keep the working row in the
-// caller's scores/workspace buffer instead (re-reads served by L2 / Infinity Cache).
+// only the 8-entry reduction exchanges).  The working row lives on chip: the first chunks
+// of every thread in LDS, its last three in registers (V=32000 bf16: 40 KiB of LDS + 12
+// VGPRs -> THREE workgroups per CU; rows in flight per CU, not threads per row, is what
+// the kernel's throughput follows); v is read from HBM once, c/d once (only where a
+// candidate survives), scores written once.  Rows too large for that (Qwen, V=151936)
+// keep the working row in the caller's scores/workspace buffer instead (re-reads served
+// by L2 / Infinity Cache).
 // Every later pass (softmax statistics, radix threshold selection for top-k / top-p,
 // inverse-CDF sampling, top-n extraction) runs over the LDS row.
 //
@@ -35,8 +37,10 @@
 
 namespace {
 
-constexpr int BLOCK = 1024;
+constexpr int BLOCK = 512;               // threads per row: 3 rows in flight per CU instead of 2
 constexpr int NWAVE = BLOCK / 64;
+constexpr int NCOPY = BLOCK / 256;       // copies of the selection histograms (one per 256 threads)
+constexpr int NREG = 3;                  // chunks per thread held in REGISTERS instead of the LDS row
 constexpr int UNR = 4;                   // chunks in flight per thread per batch
 constexpr int LDS_ROW_BYTES_MAX = 150 * 1024;
 
@@ -89,6 +93,7 @@ template <int DT> __device__ __forceinline__ void setb(uint32_t* w, int j, uint3
 
 // ------------------------------------------------------------------ kernel params (by value)
 struct KP {
+    int kl;                    // chunks per thread kept in LDS; the remaining (<= NREG) ones live in registers
     const void* v; const void* c; const void* d;
     long long sv, sc, sd, ss, sw, st;
     int B, V;
@@ -114,8 +119,10 @@ struct KP {
 struct Smem {
     float f[2][NWAVE];
     int i[2][NWAVE];
-    unsigned hist[4][256];     // 4 copies (wave & 3) to thin same-address atomic contention
-    float histf[4][256];
+    union {                    // NCOPY copies (wave % NCOPY) to thin same-address atomic contention; the count-based and
+        unsigned hist[NCOPY][256];      // the mass-based selection never run at the same time
+        float histf[NCOPY][256];
+    };
     unsigned sel[4];
     float self[2];
     // compact candidate list of the single-wave tail (rows with <= 64 finite scores)
@@ -213,17 +220,30 @@ __device__ __forceinline__ void gstore(void* base, long long row_off, int ch, in
     }
 }
 
-// The working row: LDS (one uint4 per chunk) or the caller's global buffer.
+// The working row.  LDSROW: chunk k of a thread (ch = tid + k * BLOCK) lives in LDS for k < kl and in one of the thread's
+// NREG register chunks for k >= kl - a 64 KB row would allow two workgroups per CU; with the last three chunks of every
+// thread in registers (12 VGPRs) the LDS part of a V = 32000 bf16 row is 40 KB and three fit.  !LDSROW: the caller's
+// global scores / workspace buffer (rows too large for LDS).
 template <int DT, bool LDSROW>
 struct Row {
-    uint4* lds; void* g; long long goff; int V; int vec;
+    uint4* lds; void* g; long long goff; int V; int vec; int kl; uint32_t (*rc)[4];
     __device__ __forceinline__ void get(int ch, uint32_t* w) const {
-        if constexpr (LDSROW) { uint4 a = lds[ch]; w[0] = a.x; w[1] = a.y; w[2] = a.z; w[3] = a.w; }
-        else gload<DT>(g, goff, ch, V, vec, w);
+        if constexpr (LDSROW) {
+            const int r = ch / BLOCK - kl;
+            if (r < 0) { uint4 a = lds[ch]; w[0] = a.x; w[1] = a.y; w[2] = a.z; w[3] = a.w; }
+            else if (r == 0) { w[0] = rc[0][0]; w[1] = rc[0][1]; w[2] = rc[0][2]; w[3] = rc[0][3]; }
+            else if (r == 1) { w[0] = rc[1][0]; w[1] = rc[1][1]; w[2] = rc[1][2]; w[3] = rc[1][3]; }
+            else { w[0] = rc[2][0]; w[1] = rc[2][1]; w[2] = rc[2][2]; w[3] = rc[2][3]; }
+        } else gload<DT>(g, goff, ch, V, vec, w);
     }
     __device__ __forceinline__ void put(int ch, const uint32_t* w) const {
-        if constexpr (LDSROW) lds[ch] = make_uint4(w[0], w[1], w[2], w[3]);
-        else gstore<DT>(g, goff, ch, V, vec, w);
+        if constexpr (LDSROW) {
+            const int r = ch / BLOCK - kl;
+            if (r < 0) lds[ch] = make_uint4(w[0], w[1], w[2], w[3]);
+            else if (r == 0) { rc[0][0] = w[0]; rc[0][1] = w[1]; rc[0][2] = w[2]; rc[0][3] = w[3]; }
+            else if (r == 1) { rc[1][0] = w[0]; rc[1][1] = w[1]; rc[1][2] = w[2]; rc[1][3] = w[3]; }
+            else { rc[2][0] = w[0]; rc[2][1] = w[1]; rc[2][2] = w[2]; rc[2][3] = w[3]; }
+        } else gstore<DT>(g, goff, ch, V, vec, w);
     }
 };
 
@@ -235,9 +255,9 @@ __device__ __forceinline__ uint32_t select_kth_key(const Row<DT, L>& R, int nch,
     uint32_t prefix = 0, pmask = 0;
     unsigned rem = k;
     for (int shift = KB - 8; shift >= 0; shift -= 8) {
-        sm.hist[tid >> 8][tid & 255] = 0;
+        sm.hist[tid >> 8][tid & 255] = 0;        // BLOCK / 256 = NCOPY copies
         __syncthreads();
-        unsigned* h = sm.hist[wave & 3];
+        unsigned* h = sm.hist[wave % NCOPY];
         for (int ch = tid; ch < nch; ch += BLOCK) {
             uint32_t w[4]; R.get(ch, w);
 #pragma unroll
@@ -253,7 +273,11 @@ __device__ __forceinline__ uint32_t select_kth_key(const Row<DT, L>& R, int nch,
         if (wave == 0) {
             unsigned c[4];
 #pragma unroll
-            for (int q = 0; q < 4; ++q) { int bin = 4 * lane + q; c[q] = sm.hist[0][bin] + sm.hist[1][bin] + sm.hist[2][bin] + sm.hist[3][bin]; }
+            for (int q = 0; q < 4; ++q) {
+                const int bin = 4 * lane + q; c[q] = 0;
+#pragma unroll
+                for (int cp = 0; cp < NCOPY; ++cp) c[q] += sm.hist[cp][bin];
+            }
             unsigned loc = c[0] + c[1] + c[2] + c[3];
             unsigned suf = loc;   // inclusive suffix sum over lanes >= lane
 #pragma unroll
@@ -292,7 +316,7 @@ __device__ __forceinline__ bool select_mass_key(const Row<DT, L>& R, int nch, fl
     for (int shift = KB - 8; shift >= 0; shift -= 8) {
         sm.histf[tid >> 8][tid & 255] = 0.f;
         __syncthreads();
-        float* h = sm.histf[wave & 3];
+        float* h = sm.histf[wave % NCOPY];
         for (int ch = tid; ch < nch; ch += BLOCK) {
             uint32_t w[4]; R.get(ch, w);
 #pragma unroll
@@ -308,7 +332,11 @@ __device__ __forceinline__ bool select_mass_key(const Row<DT, L>& R, int nch, fl
         if (wave == 0) {
             float c[4];
 #pragma unroll
-            for (int q = 0; q < 4; ++q) { int bin = 4 * lane + q; c[q] = (sm.histf[0][bin] + sm.histf[1][bin]) + (sm.histf[2][bin] + sm.histf[3][bin]); }
+            for (int q = 0; q < 4; ++q) {
+                const int bin = 4 * lane + q; c[q] = 0.f;
+#pragma unroll
+                for (int cp = 0; cp < NCOPY; ++cp) c[q] += sm.histf[cp][bin];
+            }
             float loc = (c[0] + c[1]) + (c[2] + c[3]);
             float pre = loc;   // inclusive prefix over lanes <= lane
 #pragma unroll
@@ -368,7 +396,7 @@ __device__ __forceinline__ void mask_below_key(const Row<DT, L>& R, int nch, uin
 
 // ------------------------------------------------------------------ the kernel
 template <int DT, bool LDSROW>
-__global__ void __launch_bounds__(BLOCK, 8) vdd_contrast_sample_kernel(KP p) {
+__global__ void __launch_bounds__(BLOCK, 6) vdd_contrast_sample_kernel(KP p) {
     constexpr int EPC = Tr<DT>::EPC;
     constexpr uint32_t NINF = Tr<DT>::NEG_INF;
     extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
@@ -376,8 +404,10 @@ __global__ void __launch_bounds__(BLOCK, 8) vdd_contrast_sample_kernel(KP p) {
     const int row = blockIdx.x;
     const int V = p.V;
     const int nch = (V + EPC - 1) / EPC;
-    Smem& sm = *reinterpret_cast<Smem*>(smem_raw + (LDSROW ? (size_t)nch * 16 : 0));
-    Row<DT, LDSROW> R{reinterpret_cast<uint4*>(smem_raw), p.work, (long long)row * p.sw, V, p.vec_work};
+    const int lds_chunks = LDSROW ? (nch < p.kl * BLOCK ? nch : p.kl * BLOCK) : 0;
+    Smem& sm = *reinterpret_cast<Smem*>(smem_raw + (size_t)lds_chunks * 16);
+    uint32_t rc[NREG][4];
+    Row<DT, LDSROW> R{reinterpret_cast<uint4*>(smem_raw), p.work, (long long)row * p.sw, V, p.vec_work, p.kl, rc};
     const long long ov = (long long)row * p.sv, oc = (long long)row * p.sc, od = (long long)row * p.sd;
 
     float m = -INFINITY; int nfin = 0; int t_nan = 0, t_pinf = 0;
@@ -860,7 +890,12 @@ extern "C" {
 
 int vdd_abi_version(void) { return VDD_ABI_VERSION; }
 const char* vdd_last_error(void) { return g_err; }
-int vdd_lds_row_capacity(int dtype) { return (int)(LDS_ROW_BYTES_MAX / esize(dtype)); }
+// Largest V whose working row stays on chip: LDS part (<= LDS_ROW_BYTES_MAX) + NREG register chunks per thread.
+int vdd_lds_row_capacity(int dtype) {
+    const int epc = (int)(16 / esize(dtype));
+    const int kl_max = LDS_ROW_BYTES_MAX / (BLOCK * 16);
+    return (kl_max + NREG) * BLOCK * epc;
+}
 
 const char* vdd_kernel_name(int dtype, int V) {
     (void)dtype; (void)V;
@@ -885,13 +920,18 @@ int vdd_contrast_sample(const vdd_sample_params* p, void* hip_stream) {
 
     const size_t es = esize(p->dtype);
     const int epc = (int)(16 / es);
-    const size_t row_bytes = (size_t)((p->V + epc - 1) / epc) * 16;
+    const int nch_h = (p->V + epc - 1) / epc;
+    const int kmax_h = (nch_h + BLOCK - 1) / BLOCK;                 // chunks per thread
+    const int nreg_h = kmax_h < NREG ? kmax_h : NREG;               // the LAST nreg chunks of every thread live in registers
+    const int kl_h = kmax_h - nreg_h;
+    const size_t row_bytes = (size_t)(nch_h < kl_h * BLOCK ? nch_h : kl_h * BLOCK) * 16;   // LDS part of the row
     const bool ldsrow = row_bytes <= (size_t)LDS_ROW_BYTES_MAX;
     auto al = [&](const void* ptr, long long stride) { return ptr == nullptr || ((((uintptr_t)ptr) & 15u) == 0 && ((stride * (long long)es) & 15) == 0); };
     KP kp{};
     kp.v = p->logit_v; kp.c = p->logit_cd; kp.d = p->logit_dd;
     kp.sv = p->stride_v; kp.sc = p->stride_cd; kp.sd = p->stride_dd; kp.ss = p->stride_scores;
     kp.B = p->B; kp.V = p->V; kp.flags = p->flags;
+    kp.kl = ldsrow ? kl_h : (1 << 20);
     kp.min_keep = p->min_keep; kp.top_k = p->top_k > 0 ? p->top_k : 0; kp.n_eos = p->n_eos;
     kp.n_top = p->top_prob ? p->n_top : 0;
     kp.s1 = (float)(1.0 + p->alpha); kp.s2 = (float)p->alpha; kp.log_beta = (float)p->log_beta;

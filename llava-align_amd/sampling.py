@@ -165,14 +165,17 @@ def contrast_sample(logits_v: torch.Tensor, logits_cd: Optional[torch.Tensor] = 
     return SampleOutput(tokens, scores, top_prob, top_tok, status)
 
 
+KERNEL_THREADS = 512      # threads per row of vdd_contrast_sample_kernel (csrc/vdd_contrast_sample.hip: BLOCK)
+
+
 def thread_major_order(V: int, dtype: torch.dtype) -> "list[int]":
     """Element enumeration order of the kernel's inverse-CDF draw (chunk ch -> thread
-    ch % 1024; a thread walks its chunks in increasing ch).  Any fixed order gives an
+    ch % KERNEL_THREADS; a thread walks its chunks in increasing ch).  Any fixed order gives an
     exact categorical sample; this is exposed so tests can recompute the drawn token."""
     epc = 4 if dtype == torch.float32 else 8
     nch = (V + epc - 1) // epc
     order = []
-    for t in range(min(1024, nch)):
-        for ch in range(t, nch, 1024):
+    for t in range(min(KERNEL_THREADS, nch)):
+        for ch in range(t, nch, KERNEL_THREADS):
             order.extend(i for i in range(ch * epc, min(V, ch * epc + epc)))
     return order

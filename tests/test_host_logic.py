@@ -60,7 +60,8 @@ def test_thread_major_order_is_a_permutation():
         o = thread_major_order(V, dt)
         assert sorted(o) == list(range(V))
     o = thread_major_order(20000, torch.float16)
-    assert o[:8] == list(range(8)) and o[8:16] == list(range(8192, 8200))   # thread 0: chunk 0 then chunk 1024
+    from llava_align_amd.sampling import KERNEL_THREADS
+    assert o[:8] == list(range(8)) and o[8:16] == list(range(8 * KERNEL_THREADS, 8 * KERNEL_THREADS + 8))   # thread 0: chunk 0, then chunk KERNEL_THREADS
 
 
 def test_install_hook_is_idempotent():
