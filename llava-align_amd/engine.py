@@ -254,7 +254,7 @@ class VisionTower:
         A full GRAPH_BATCH of images replays a captured HIP graph: the tower is ~400 small launches per batch and runs
         when nothing else is queued, so issued from Python it is launch-bound (98 ms of host time for 43 ms of GPU work
         per 64 images, tools/host_phase_probe.py)."""
-        if self.use_graph and images.shape[0] == self.GRAPH_BATCH and self.w.device.type == "cuda" and os.environ.get("VDD_VIT_GRAPH", "1") != "0":
+        if self.use_graph and images.shape[0] == self.GRAPH_BATCH and self.w.device.type == "cuda":
             if self._graph is None:
                 self._g_in = torch.empty(self.GRAPH_BATCH, *images.shape[1:], dtype=torch.bfloat16, device=self.w.device)
                 self._g_in.copy_(images)
