@@ -26,7 +26,6 @@ go to hipBLASLt through torch.matmul (a plain library GEMM).  bf16 storage, fp32
 from __future__ import annotations
 
 import gc
-import os
 import math
 from dataclasses import dataclass, field
 from typing import Dict, List, Optional, Sequence
