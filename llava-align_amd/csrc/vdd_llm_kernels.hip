@@ -419,6 +419,79 @@ __global__ void __launch_bounds__(256) decode_attn_kernel(const uint16_t* __rest
     }
 }
 
+// Grouped mode, short own ranges (a question's own prompt tokens + what it generated so far: <= 256 keys): ONE wave per
+// (row, head) walks the whole own range [plen, len), then folds in the row's prefix partials left by the MFMA prefix pass
+// and writes the normalised bf16 output - no own partials, no separate combine launch.
+template <int D>
+__global__ void __launch_bounds__(256) decode_attn_own_merge_kernel(const uint16_t* __restrict__ q, const uint16_t* __restrict__ kc,
+                                                                    const uint16_t* __restrict__ vc, const AttnRow* __restrict__ rows,
+                                                                    const float* __restrict__ ws, uint16_t* __restrict__ out, int H, int Hkv,
+                                                                    long long slot_stride, int t_max, float scale, int nchunk, int npre,
+                                                                    int pre_keys) {
+    static_assert(D == 128, "lane map assumes 16 lanes x 8 dims");
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int head = blockIdx.x * 4 + wave, row = blockIdx.y;
+    if (head >= H) return;
+    const int g = lane >> 4, j = lane & 15;
+    const AttnRow ar = rows[row];
+    const int kvh = head / (H / Hkv);
+    const uint4 qv = *reinterpret_cast<const uint4*>(q + ((size_t)row * H + head) * D + j * 8);
+    const size_t hoff = (size_t)kvh * t_max * D + j * 8;
+    const uint16_t* k_own = kc + (size_t)ar.slot * slot_stride + hoff;       // compact slot: own token i at index i
+    const uint16_t* v_own = vc + (size_t)ar.slot * slot_stride + hoff;
+    const int n_own = ar.len - ar.plen;
+    float m = -INFINITY, l = 0.f, acc[8] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+    constexpr int U = 4;
+    for (int t0 = g; t0 < n_own; t0 += 4 * U) {
+        uint4 kv[U], vv[U];
+#pragma unroll
+        for (int u = 0; u < U; ++u) {
+            const int t = t0 + 4 * u;
+            const int tt = t < n_own ? t : n_own - 1;
+            kv[u] = *reinterpret_cast<const uint4*>(k_own + (size_t)tt * D);
+            vv[u] = *reinterpret_cast<const uint4*>(v_own + (size_t)tt * D);
+        }
+#pragma unroll
+        for (int u = 0; u < U; ++u) {
+            float s = dot8(qv, kv[u]);
+            s += __shfl_xor(s, 1); s += __shfl_xor(s, 2); s += __shfl_xor(s, 4); s += __shfl_xor(s, 8);
+            s *= scale;
+            if (t0 + 4 * u < n_own) ATT_ONLINE_STEP(s, vv[u], m, l, acc);
+        }
+    }
+#pragma unroll
+    for (int o = 16; o <= 32; o <<= 1) {
+        const float mo = __shfl_xor(m, o), lo_ = __shfl_xor(l, o);
+        const float mn = fmaxf(m, mo);
+        const float c0 = (m == -INFINITY) ? 0.f : __expf(m - mn), c1 = (mo == -INFINITY) ? 0.f : __expf(mo - mn);
+        l = l * c0 + lo_ * c1;
+#pragma unroll
+        for (int e = 0; e < 8; ++e) { const float ao = __shfl_xor(acc[e], o); acc[e] = acc[e] * c0 + ao * c1; }
+        m = mn;
+    }
+    // fold in the prefix partials (every lane of a 16-lane group reads its 8 dims; group 0 stores)
+    const int used_pre = npre > 0 ? (ar.plen + pre_keys - 1) / pre_keys : 0;
+    const float* base = ws + ((size_t)row * H + head) * nchunk * (D + 2);
+    for (int c = 0; c < used_pre; ++c) {
+        const float* pp = base + (size_t)c * (D + 2);
+        const float mo = pp[D], lo_ = pp[D + 1];
+        const float mn = fmaxf(m, mo);
+        const float c0 = (m == -INFINITY) ? 0.f : __expf(m - mn), c1 = (mo == -INFINITY) ? 0.f : __expf(mo - mn);
+        const float4 a0 = *reinterpret_cast<const float4*>(pp + j * 8), a1 = *reinterpret_cast<const float4*>(pp + j * 8 + 4);
+        l = l * c0 + lo_ * c1;
+        acc[0] = acc[0] * c0 + a0.x * c1; acc[1] = acc[1] * c0 + a0.y * c1; acc[2] = acc[2] * c0 + a0.z * c1; acc[3] = acc[3] * c0 + a0.w * c1;
+        acc[4] = acc[4] * c0 + a1.x * c1; acc[5] = acc[5] * c0 + a1.y * c1; acc[6] = acc[6] * c0 + a1.z * c1; acc[7] = acc[7] * c0 + a1.w * c1;
+        m = mn;
+    }
+    if (g == 0) {
+        const float inv = 1.f / l;
+        uint4 o4;
+        o4.x = pack(acc[0] * inv, acc[1] * inv); o4.y = pack(acc[2] * inv, acc[3] * inv);
+        o4.z = pack(acc[4] * inv, acc[5] * inv); o4.w = pack(acc[6] * inv, acc[7] * inv);
+        *reinterpret_cast<uint4*>(out + ((size_t)row * H + head) * D + j * 8) = o4;
+    }
+}
+
 // one wave per (row, head): lane owns dims 2*lane, 2*lane+1.  Chunk space: [0, npre) prefix chunks (grouped
 // kernel; only when grouped), then own/whole-context chunks.
 template <int D>
@@ -961,6 +1034,12 @@ int vdd_decode_attention_grouped(const void* q, const void* k_cache, const void*
         hipLaunchKernelGGL(decode_attn_prefix_kernel<128>, dim3(n_items, H), dim3(256), 0, st,
                            (const uint16_t*)q, (const uint16_t*)k_prefix, (const uint16_t*)v_prefix, (const GroupDesc*)groups, group_rows,
                            (const int4*)items, (float*)workspace, H, Hkv, (long long)prefix_stride, prefix_tmax, scale, nchunk);
+    }
+    if (max_own_len <= 256) {        // short own ranges: one wave per (row, head) finishes the row (own keys + prefix partials)
+        hipLaunchKernelGGL(decode_attn_own_merge_kernel<128>, dim3((H + 3) / 4, M), dim3(256), 0, st, (const uint16_t*)q,
+                           (const uint16_t*)k_cache, (const uint16_t*)v_cache, (const AttnRow*)rows, (const float*)workspace,
+                           (uint16_t*)out, H, Hkv, (long long)slot_stride, t_max, scale, nchunk, npre, pre_keys);
+        return ok(hipSuccess);
     }
     hipLaunchKernelGGL(decode_attn_kernel<128>, dim3((H + 3) / 4, M, nown), dim3(256), 0, st, (const uint16_t*)q,
                        (const uint16_t*)k_cache, (const uint16_t*)v_cache, (const uint16_t*)k_prefix, (const uint16_t*)v_prefix,

@@ -264,6 +264,13 @@ def test_grouped_prefix_decode_attention_equals_per_row():
                                         torch.tensor(it, dtype=torch.int32, device=DEV), len(it), H, Hkv, D, 611, 128, v_prefix_t8=vp8,
                                         chunks_per_item=cpi)
         assert torch.allclose(a.float(), cc.float(), rtol=3e-2, atol=3e-2), cpi
+    # own ranges declared longer than 256 keys keep the split-KV own pass + combine; shorter ones finish in one wave per (row, head)
+    it = O.prefix_work_items(groups, 4)
+    long_own = O.decode_attention_grouped(q, ko, vo, kp, vp, rt, torch.tensor(groups, dtype=torch.int32, device=DEV),
+                                          torch.tensor(grp_rows_p, dtype=torch.int32, device=DEV),
+                                          torch.tensor(it, dtype=torch.int32, device=DEV), len(it), H, Hkv, D, 611, 320, v_prefix_t8=vp8,
+                                          chunks_per_item=4)
+    assert torch.allclose(a.float(), long_own.float(), rtol=3e-2, atol=3e-2)
     b = cc
     rep = H // Hkv
     for m, (slot, ln, ps, pl) in enumerate(rows_p):
