@@ -15,11 +15,12 @@ from toy_lm import IMAGE_TOKEN_INDEX, _Proto, _gen_cfg
 
 class RefLlava(_Proto):
     def __init__(self, weights, device="cpu", logit_dtype=torch.bfloat16, pad=0, eos=None, dtype=torch.float32,
-                 output_attentions=False):
+                 output_attentions=False, logits_on_device=False):
         """dtype=float32: numerics reference.  dtype=bfloat16/float16: what the reference's eager HF stack executes
         (weights and matmuls in the model dtype, fp32 softmax / norm statistics, KV cache grown by torch.cat)."""
         self.cfg = weights.cfg
         self.dtype = dtype
+        self.logits_on_device = logits_on_device              # the eager GPU pipeline keeps the logits where they were computed
         self.materialize_attn = output_attentions            # llava_calibrate.py:175 asks for the [H, T, S] maps every step
         self.w = {k: v.detach().to(device=device, dtype=dtype) for k, v in weights.t.items()}
         self.device = torch.device(device)
@@ -108,7 +109,7 @@ class RefLlava(_Proto):
             self.calls.append((tuple(inputs_embeds.shape[:2]), False, past_len))
             emb = inputs_embeds.to(self.device, torch.bfloat16).to(self.dtype)
             logits, past = self._lm(emb, past_key_values)
-            return SimpleNamespace(logits=logits.to(self.logit_dtype).cpu(), past_key_values=past, attentions=None, hidden_states=None)
+            return SimpleNamespace(logits=logits.to(self.logit_dtype) if self.logits_on_device else logits.to(self.logit_dtype).cpu(), past_key_values=past, attentions=None, hidden_states=None)
         ids = input_ids.to(self.device)
         self.calls.append((tuple(ids.shape), images is not None, past_len))
         if images is None or ids.shape[1] == 1:                 # llava_arch.py:91-94
@@ -120,7 +121,7 @@ class RefLlava(_Proto):
             emb = torch.cat([self.w["embed"][row[:s]], feat, self.w["embed"][row[s + 1:]]], 0)[None]
         emb = emb.to(torch.bfloat16).to(self.dtype)
         logits, past = self._lm(emb, past_key_values)
-        return SimpleNamespace(logits=logits.to(self.logit_dtype).cpu(), past_key_values=past, attentions=None, hidden_states=None)
+        return SimpleNamespace(logits=logits.to(self.logit_dtype) if self.logits_on_device else logits.to(self.logit_dtype).cpu(), past_key_values=past, attentions=None, hidden_states=None)
 
 
 class RefLavisLM(RefLlava):
