@@ -217,6 +217,41 @@ def test_warpers_after_the_mask_in_both_candidate_regimes(dt, beta, regime):
             assert int(torch.isfinite(got).sum(-1).max()) == 1 or warp.get("top_k") == 1
             assert out.tokens.cpu().tolist() == torch.argmax(want.float(), -1).tolist()
 
+_FUZZ_V = [8, 9, 511, 4096, 4104, 8200, 12289, 16385, 20000, 24577, 28673, 33000, 40961, 70000, 86016, 86017, 100003]
+
+
+@pytest.mark.parametrize("V", _FUZZ_V)
+def test_row_layouts_across_vocabulary_sizes(V):
+    """The working row is split between LDS and up to three register chunks per thread (and falls back to a global row past
+    86,016 bf16 elements): sweep vocabulary sizes that put 1..N chunks on a thread in every dtype, ragged last chunks included,
+    and compare scores (+ arg-max token, + top-n) with the oracle for contrast / temperature / top-k / both-branch inputs."""
+    L = _L()
+    g = torch.Generator().manual_seed(1000 + V)
+    for dt in ("bf16", "fp16", "fp32"):
+        dtype = DTYPES[dt]
+        B = 3
+        v = (torch.randn(B, V, generator=g) * 3).to(dtype)
+        c = (v.float() + torch.randn(B, V, generator=g)).to(dtype)
+        d = (v.float() + torch.randn(B, V, generator=g)).to(dtype)
+        for beta, warp, three in ((0.1, {"temperature": 0.7}, False), (0.02, {"top_k": 7}, True), (1e-4, {"temperature": 1.3, "top_k": 50}, False)):
+            if V < 64 and warp.get("top_k", 0) > V:
+                continue
+            spec = L.WarpSpec(temperature=warp.get("temperature"), top_k=warp.get("top_k"))
+            out = L.contrast_sample(v.to(DEV), c.to(DEV), d.to(DEV) if three else None, alpha=1.0, beta=beta, warp=spec,
+                                    return_scores=True, pick_argmax=True, n_top=3)
+            want = O.step_scores(v, c, d if three else None, 1.0, beta, O.WarpConfig(**warp))
+            got = out.scores.cpu()
+            assert torch.equal(_bits(got), _bits(want)), (dt, beta, warp)
+            assert out.status.cpu().tolist() == [0] * B
+            for b in range(B):
+                row = want[b].float()
+                best = torch.nonzero(row == row.max()).min().item()
+                assert out.tokens[b].item() == best, (dt, beta, warp, b)
+                assert out.top_tok[b, 0].item() == best
+        # plain path (no contrast): every chunk live
+        out = L.contrast_sample(v.to(DEV), None, warp=L.WarpSpec(temperature=0.9), return_scores=True, pick_argmax=True)
+        assert torch.equal(_bits(out.scores.cpu()), _bits(O.step_scores(v, None, None, 1.0, 0.1, O.WarpConfig(temperature=0.9))))
+
 
 def test_philox_sampling_matches_the_distribution():
     L = _L()
