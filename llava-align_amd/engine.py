@@ -409,9 +409,10 @@ class LanguageModel:
 
     @torch.no_grad()
     def decode_step(self, tokens: torch.Tensor, pos: torch.Tensor, cpos: torch.Tensor, slot: torch.Tensor, attn_rows: torch.Tensor,
-                    kv: KVCache, grouping: Optional[dict] = None) -> torch.Tensor:
+                    kv: KVCache, grouping: Optional[dict] = None, workspace: Optional[torch.Tensor] = None) -> torch.Tensor:
         """One token for each of M rows: tokens int64 [M], pos/slot int32 [M], attn_rows int32 [M,4] (slot, len, pslot, plen)
-        with len already counting the new token.  Returns logits [M, V]."""
+        with len already counting the new token.  Returns logits [M, V].  `workspace`: split-KV partials buffer of the
+        ungrouped attention; a captured step must own it (the module-level one is re-allocated when a later call needs more)."""
         c, t = self.cfg, self.w.t
         H, Hkv, D = c.n_heads, c.n_kv_heads, c.head_dim
         resid = ops.embed(tokens, t["embed"])
@@ -438,7 +439,7 @@ class LanguageModel:
             else:
                 q = ops.rope_kv_write(qkv, pos, slot, self.cs, kv.ko[i], kv.vo[i], H, Hkv, D, cpos=cpos)
                 att = ops.decode_attention(q, kv.ko[i], kv.vo[i], attn_rows, H, Hkv, D, k_prefix=kv.kp[i], v_prefix=kv.vp[i],
-                                           max_len=kv.t_pre + kv.t_own)
+                                           max_len=kv.t_pre + kv.t_own, workspace=workspace)
             o = ops.linear_to_norm(att, t[p + "wo"])
             a = ops.rmsnorm(resid, t[p + "ln2"], c.eps, delta=o, resid_out=resid)
             delta = ops.linear_to_norm(ops.swiglu_linear(a, t[p + "wgu"]), t[p + "wd"])
@@ -496,12 +497,15 @@ class _DecodeRunner:
         self.graph = None
         self._tried = False
         self.grouping = None
+        lm = eng.cfg.lm
+        # the step's own partials buffer (also for the ungrouped split-KV pass): a captured graph must not point into a
+        # shared buffer that a later, larger call re-allocates
+        self.workspace = ops.attention_workspace(R, lm.n_heads, lm.head_dim, eng._kv.t_pre + eng._kv.t_own, dev)
         if tail.get("n_groups", 0) > 0:
-            lm = eng.cfg.lm
             self.grouping = dict(groups=torch.zeros(max(1, tail["n_groups"]), 4, **i32), group_rows=torch.zeros(R, **i32),
                                  n_groups=tail["n_groups"], items=torch.zeros(max(1, tail["n_items"]), 4, **i32), n_items=tail["n_items"],
                                  cpi=tail.get("cpi", 1),
-                                 workspace=ops.attention_workspace(R, lm.n_heads, lm.head_dim, eng._kv.t_pre + eng._kv.t_own, dev))
+                                 workspace=self.workspace)
 
     def reset(self, ctr0):
         self.unfinished.fill_(1)
@@ -529,7 +533,8 @@ class _DecodeRunner:
     def body(self, kv):
         t, Q, nb = self.tail, self.Q, self.nb
         self.tokens_rows.view(nb, Q).copy_(self.tok[None].expand(nb, Q))        # same new token for every branch of a question
-        logits = self.eng.lm.decode_step(self.tokens_rows, self.pos, self.cpos, self.slot, self.rows, kv, self.grouping)
+        logits = self.eng.lm.decode_step(self.tokens_rows, self.pos, self.cpos, self.slot, self.rows, kv, self.grouping,
+                                         workspace=self.workspace)
         v, c, d = logits[:Q], None, None
         if t["contrast"]:
             if t["is_vcd"]:

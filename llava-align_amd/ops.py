@@ -220,7 +220,7 @@ def swiglu_linear(x, w_gate_up, out=None):
 _attn_ws = {}
 
 
-def decode_attention(q, k_cache, v_cache, rows, H, Hkv, D, out=None, max_len=None, k_prefix=None, v_prefix=None):
+def decode_attention(q, k_cache, v_cache, rows, H, Hkv, D, out=None, max_len=None, k_prefix=None, v_prefix=None, workspace=None):
     """q [M, H*D]; rows int32 [M, 4] = (slot, len, prefix_slot, prefix_len); max_len bounds every len.
     k_prefix/v_prefix: separate pool holding the shared prefixes (default: the same buffers, index t)."""
     _bf16(q, k_cache, v_cache)
@@ -232,10 +232,15 @@ def decode_attention(q, k_cache, v_cache, rows, H, Hkv, D, out=None, max_len=Non
     lib.vdd_decode_attention_workspace_bytes.restype = C.c_int64
     need = lib.vdd_decode_attention_workspace_bytes(M, H, D, max_len)
     key = (q.device, )
-    ws = _attn_ws.get(key)
-    if ws is None or ws.numel() * 4 < need:
-        ws = torch.empty((need + 3) // 4, dtype=torch.float32, device=q.device)
-        _attn_ws[key] = ws
+    if workspace is not None:
+        if workspace.numel() * 4 < need:
+            raise ValueError("attention workspace too small")
+        ws = workspace
+    else:
+        ws = _attn_ws.get(key)
+        if ws is None or ws.numel() * 4 < need:
+            ws = torch.empty((need + 3) // 4, dtype=torch.float32, device=q.device)
+            _attn_ws[key] = ws
     out = torch.empty_like(q) if out is None else out
     _lib.check(lib.vdd_decode_attention(q.data_ptr(), k_cache.data_ptr(), v_cache.data_ptr(), k_prefix.data_ptr(), v_prefix.data_ptr(),
                                         rows.data_ptr(), out.data_ptr(), ws.data_ptr(), M, H, Hkv, D, k_cache.stride(0), k_cache.shape[2],

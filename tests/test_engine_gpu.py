@@ -322,3 +322,27 @@ def test_vit_graph_replay_equals_eager_forward():
     e2 = VddLlavaEngine(cfg, weights=e.w, device=DEV, use_graph=False)
     b = e2.generate(ids, images=imgs, use_dd_unk=True, cd_alpha=1.0, cd_beta=0.1, temperature=0.5, max_new_tokens=3, cd_greedy=True)
     assert torch.equal(a.tokens, b.tokens)
+
+
+def test_captured_steps_survive_a_later_larger_batch():
+    """Every captured decode step owns its split-KV partials buffer: replaying the graph of a small ungrouped batch after a
+    larger batch has run (which would have re-allocated a shared workspace) must give the same tokens as before."""
+    from llava_align_amd.engine import LlavaWeights, VddLlavaEngine, preset
+    cfg = preset("tiny")
+    e = VddLlavaEngine(cfg, weights=LlavaWeights.random(cfg, DEV, seed=3, std=0.06), device=DEV, use_graph=True)
+    g = torch.Generator().manual_seed(8)
+
+    def batch(n):
+        ids = [torch.tensor([1, 5, 6, -200] + torch.randint(3, 900, (4 + i % 3,), generator=g).tolist()) for i in range(n)]
+        imgs = [torch.randn(3, cfg.vision.image, cfg.vision.image, generator=g) for _ in range(n)]     # distinct images: ungrouped
+        return ids, imgs
+    kw = dict(use_dd_unk=True, cd_alpha=1.0, cd_beta=0.1, temperature=0.5, max_new_tokens=6, cd_greedy=True)
+    ids_a, imgs_a = batch(9)          # 18 rows: split-KV attention (more than the fused small-M kernel takes)
+    ids_b, imgs_b = batch(20)
+    first = e.generate(ids_a, images=imgs_a, **kw)
+    assert first.stats["graph"]
+    e.generate(ids_b, images=imgs_b, **kw)
+    again = e.generate(ids_a, images=imgs_a, **kw)
+    assert torch.equal(first.tokens, again.tokens)
+    eager = VddLlavaEngine(cfg, weights=e.w, device=DEV, use_graph=False).generate(ids_a, images=imgs_a, **kw)
+    assert torch.equal(first.tokens, eager.tokens)
