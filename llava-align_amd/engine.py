@@ -241,8 +241,10 @@ class VisionTower:
     def _kv_cache(self, n_img):
         v = self.cfg
         if self._kv is None or self._kv[0].shape[0] < n_img:
-            mk = lambda: torch.empty(n_img, v.heads, self.T, v.width // v.heads, dtype=torch.bfloat16, device=self.w.device)
+            n_alloc = max(n_img, self.GRAPH_BATCH)
+            mk = lambda: torch.empty(n_alloc, v.heads, self.T, v.width // v.heads, dtype=torch.bfloat16, device=self.w.device)
             self._kv = (mk(), mk())
+            self._graph = None                   # a captured forward points at the old buffers
         return self._kv
 
     GRAPH_BATCH = 16
