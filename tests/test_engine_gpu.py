@@ -346,3 +346,36 @@ def test_captured_steps_survive_a_later_larger_batch():
     assert torch.equal(first.tokens, again.tokens)
     eager = VddLlavaEngine(cfg, weights=e.w, device=DEV, use_graph=False).generate(ids_a, images=imgs_a, **kw)
     assert torch.equal(first.tokens, eager.tokens)
+
+
+def test_soak_graph_engine_equals_eager_engine_over_mixed_calls():
+    """A long-lived engine (cached graphs, cached KV pools, reused runners) must give what a fresh eager engine gives for every
+    call of a mixed sequence: different batch sizes, image sharing patterns, decoding modes, EOS on/off."""
+    import random
+    from llava_align_amd.engine import LlavaWeights, VddLlavaEngine, preset
+    cfg = preset("tiny")
+    w = LlavaWeights.random(cfg, DEV, seed=3, std=0.06)
+    eg = VddLlavaEngine(cfg, weights=w, device=DEV, use_graph=True)
+    ee = VddLlavaEngine(cfg, weights=w, device=DEV, use_graph=False)
+    rnd = random.Random(5)
+    g = torch.Generator().manual_seed(5)
+    pool = [torch.randn(3, cfg.vision.image, cfg.vision.image, generator=g) for _ in range(6)]
+    modes = [dict(), dict(use_dd_unk=True), dict(use_dd=True), dict(use_dd=True, use_dd_unk=True), dict(images_cd="noise")]
+    for call in range(14):
+        Q = rnd.choice([1, 2, 3, 6, 7, 12, 18])
+        share = rnd.choice([1, 2, 6])                                   # questions per image
+        ids, imgs = [], []
+        for q in range(Q):
+            n = rnd.randint(2, 7)
+            ids.append(torch.tensor([1, 5, 6, -200] + [rnd.randint(3, 900) for _ in range(n)]))
+            imgs.append(pool[(q // share) % len(pool)])
+        kw = dict(modes[call % len(modes)])
+        if kw.get("images_cd") == "noise":
+            kw["images_cd"] = [im + 0.5 for im in imgs]
+        if kw.get("use_dd") and not kw.get("use_dd_unk"):
+            pass                                                         # use_dd alone is B=1-only in the reference; the engine batches it
+        eos = dict(eos_token_id=[rnd.randint(3, 900)], pad_token_id=0) if call % 3 == 0 else {}
+        args = dict(images=imgs, cd_alpha=1.0, cd_beta=0.1, temperature=0.6, max_new_tokens=rnd.choice([2, 5, 9]), cd_greedy=(call % 2 == 0),
+                    seed=100 + call, **kw, **eos)     # odd calls SAMPLE: same Philox (seed, step, row) stream in both engines
+        a, b = eg.generate(ids, **args), ee.generate(ids, **args)
+        assert torch.equal(a.tokens, b.tokens), (call, Q, share, kw.keys())
