@@ -803,7 +803,14 @@ class VddLlavaEngine:
             gen = self._trim_after_all_finished(gen, eos_t, pad_token_id)
             if scores is not None:
                 scores = scores[:gen.shape[1]]
-        seqs_out = [torch.cat([torch.tensor(ids_list[q], device=dev), gen[q]]) for q in range(Q)]
+        # prompt ids back on the device in ONE copy (a torch.tensor(..., device=) per question is a synchronous pageable copy each)
+        lens = [len(r) for r in ids_list]
+        (flat,) = h2d_int32(dev, [t for r in ids_list for t in r]) if sum(lens) else (torch.zeros(0, dtype=torch.int32, device=dev),)
+        flat = flat.long()
+        offs = [0]
+        for n in lens:
+            offs.append(offs[-1] + n)
+        seqs_out = [torch.cat([flat[offs[q]:offs[q + 1]], gen[q]]) for q in range(Q)]
         stats["steps"] = int(gen.shape[1])
         stats["graph"] = run.graph is not None
         return GenerateOutput(seqs_out, gen, scores, top_prob, top_tok, stats)
