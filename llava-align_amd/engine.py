@@ -374,15 +374,21 @@ class LanguageModel:
 
     @torch.no_grad()
     def prefill(self, x: torch.Tensor, pos: torch.Tensor, cpos: torch.Tensor, slot: torch.Tensor, seqs: torch.Tensor, n_seq: int,
-                max_tq: int, kv: KVCache, to_prefix_pool: bool) -> torch.Tensor:
+                max_tq: int, kv: KVCache, to_prefix_pool: bool, last_rows: Optional[torch.Tensor] = None,
+                last_seqs: Optional[torch.Tensor] = None):
         """x [T, d] packed embeddings; pos (rotary) / cpos (index inside the slot) / slot int32 [T]; seqs [n_seq, 6]
         (ops.flash_attention).  Writes K/V into the prefix pool (prefix pass) or the own pool (suffix pass) and returns
-        (residual, delta): the final hidden state is their sum (added inside the last norm)."""
+        (residual, delta) of the LAST token of every sequence: the final hidden state is their sum (added inside the last
+        norm).  The last decoder layer only computes what someone reads: its K/V for every token (decode attends them), but
+        attention / o-proj / MLP for the last token of each sequence alone (`last_rows` int64 [n_seq], `last_seqs` [n_seq, 6]
+        one-query descriptors) - and nothing past the KV write in the prefix pass, whose hidden states feed no logits
+        (the reference runs all positions through everything, llava_llama.py:88-103)."""
         c, t = self.cfg, self.w.t
         H, Hkv, D = c.n_heads, c.n_kv_heads, c.head_dim
         resid, delta = x, None
         for i in range(c.n_layers):
             p = f"l{i}."
+            final = i == c.n_layers - 1
             new_resid = torch.empty_like(resid) if delta is not None else None
             a = ops.rmsnorm(resid, t[p + "ln1"], c.eps, delta=delta, resid_out=new_resid)
             resid = new_resid if new_resid is not None else resid
@@ -391,13 +397,18 @@ class LanguageModel:
                 ops.bias_act(qkv, t[p + "bqkv_lm"], out=qkv)
             kw_, vw_ = (kv.kp[i], kv.vp[i]) if to_prefix_pool else (kv.ko[i], kv.vo[i])
             q = ops.rope_kv_write(qkv, pos, slot, self.cs, kw_, vw_, H, Hkv, D, cpos=cpos)
-            att = ops.flash_attention(q, kw_, vw_, seqs, n_seq, max_tq, H, Hkv, D, causal=True, k_prefix=kv.kp[i], v_prefix=kv.vp[i])
+            if final and last_rows is None:
+                return None, None                              # prefix pass: only this layer's K/V were still needed
+            if final:
+                q, resid = q[last_rows].contiguous(), resid[last_rows].contiguous()
+                att = ops.flash_attention(q, kw_, vw_, last_seqs, n_seq, 1, H, Hkv, D, causal=True, k_prefix=kv.kp[i], v_prefix=kv.vp[i])
+            else:
+                att = ops.flash_attention(q, kw_, vw_, seqs, n_seq, max_tq, H, Hkv, D, causal=True, k_prefix=kv.kp[i], v_prefix=kv.vp[i])
             o = ops.linear(att, t[p + "wo"])
             new_resid = torch.empty_like(resid)
             a = ops.rmsnorm(resid, t[p + "ln2"], c.eps, delta=o, resid_out=new_resid)
             resid = new_resid
-            gu = ops.linear(a, t[p + "wgu"])
-            delta = ops.linear(ops.silu_mul(gu), t[p + "wd"])
+            delta = ops.linear(ops.silu_mul(ops.linear(a, t[p + "wgu"])), t[p + "wd"])
         return resid, delta
 
     @torch.no_grad()
@@ -742,15 +753,18 @@ class VddLlavaEngine:
             if not segs:
                 continue
             x, pos, cpos, slot, seqs, max_tq = self._pack(segs)
-            resid, delta = self.lm.prefill(x, pos, cpos, slot, seqs, len(segs), max_tq, kv, to_prefix_pool=(phase == "prefix"))
-            if phase == "prefix" and self.group_attention:
-                (plen_t,) = h2d_int32(dev, [s_["T"] for s_ in segs])
-                for li in range(lm.n_layers):
-                    ops.prefix_v_transpose(kv.vp[li], kv.vp8[li], plen_t)
-            if phase == "suffix":
-                (last,) = h2d_int32(dev, [s["q_row0"] + s["T"] - 1 for s in segs])
-                last = last.long()
-                logits0 = self.lm.logits(resid, delta, last)                                  # [nb*Q, V], rows ordered branch-major
+            if phase == "prefix":
+                self.lm.prefill(x, pos, cpos, slot, seqs, len(segs), max_tq, kv, to_prefix_pool=True)     # K/V only: no logits from here
+                if self.group_attention:
+                    (plen_t,) = h2d_int32(dev, [s_["T"] for s_ in segs])
+                    for li in range(lm.n_layers):
+                        ops.prefix_v_transpose(kv.vp[li], kv.vp8[li], plen_t)
+            else:
+                last, last_seqs = h2d_int32(dev, [s["q_row0"] + s["T"] - 1 for s in segs],
+                                            [[i, 1, s["pos0"] + s["T"] - 1, s["slot"], s["pslot"], s["plen"]] for i, s in enumerate(segs)])
+                resid, delta = self.lm.prefill(x, pos, cpos, slot, seqs, len(segs), max_tq, kv, to_prefix_pool=False,
+                                               last_rows=last.long(), last_seqs=last_seqs)
+                logits0 = self.lm.logits(resid, delta)                                        # [nb*Q, V], rows ordered branch-major
                 self.debug_logits0 = logits0
         V = lm.vocab
 
