@@ -115,9 +115,14 @@ __global__ void __launch_bounds__(256, 4) flash_attn_kernel(const uint16_t* __re
     };
     stage(0, 0);
     int buf = 0;
+    // a wave whose 16 query rows lie past the end of the sequence (suffixes are ~25 tokens: half of the block) only helps
+    // staging the V tiles; a wave whose rows all precede a key tile (causal) has nothing to add from it either
+    const bool wave_has_rows = r0 < sd.Tq;
     for (int kt = 0; kt < kend; kt += 32, buf ^= 1) {
+        const bool active = wave_has_rows && !(CAUSAL && kt > sd.pos0 + min(r0 + 15, sd.Tq - 1));
         // ---- S^T = K Q^T for 2 x 16 keys (MFMA row i of tile j is key kt + 8 (i / 4) + (i % 4) + 4 j) ----
         f32x4_t s[2] = {f32x4_t{0.f, 0.f, 0.f, 0.f}, f32x4_t{0.f, 0.f, 0.f, 0.f}};
+        if (active) {
 #pragma unroll
         for (int j = 0; j < 2; ++j) {
             int t = kt + (ln >> 2) * 8 + (ln & 3) + 4 * j; if (t >= Tk) t = Tk - 1;
@@ -128,8 +133,10 @@ __global__ void __launch_bounds__(256, 4) flash_attn_kernel(const uint16_t* __re
                 s[j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(kf, qf[ks], s[j], 0, 0, 0);
             }
         }
+        }
         __syncthreads();                                      // tile `buf` staged by everyone; tile buf^1 no longer read
         if (kt + 32 < kend) stage(kt + 32, buf ^ 1);          // next tile's loads fly under this step's arithmetic
+        if (!active) continue;
         // ---- mask + online softmax of query column ln: this lane's scores are keys kt + 8 g + 4 j + r ----
         // masking is only needed on the causal diagonal and on the ragged last tile (wave-uniform test)
         const bool need_mask = (kt + 32 > Tk) || (CAUSAL && kt + 31 > sd.pos0 + r0);
