@@ -229,7 +229,7 @@ class VisionTower:
         assert dh == 64, "the ViT attention kernel is instantiated for head_dim 64"
         self._kv = None
         self.use_graph = False               # set by the engine; a full GRAPH_BATCH of images then replays a HIP graph
-        self._graph = self._g_in = self._g_out = None
+        self._graphs: Dict[int, tuple] = {}
         self._seq_desc: Dict[int, torch.Tensor] = {}
 
     def _seqs(self, n):
@@ -244,26 +244,30 @@ class VisionTower:
             n_alloc = max(n_img, self.GRAPH_BATCH)
             mk = lambda: torch.empty(n_alloc, v.heads, self.T, v.width // v.heads, dtype=torch.bfloat16, device=self.w.device)
             self._kv = (mk(), mk())
-            self._graph = None                   # a captured forward points at the old buffers
+            self._graphs.clear()                 # a captured forward points at the old buffers
         return self._kv
 
     GRAPH_BATCH = 16
+    GRAPH_SIZES = (1, 16)                    # batch sizes replayed from a captured graph: one question's image, a full batch
 
     @torch.no_grad()
     def __call__(self, images: torch.Tensor) -> torch.Tensor:
         """images [n, 3, S, S] (any float dtype) -> projected patch features [n, n_patches, d_lm] bf16.
-        A full GRAPH_BATCH of images replays a captured HIP graph: the tower is ~400 small launches per batch and runs
+        Batches of GRAPH_SIZES images replay a captured HIP graph: the tower is ~400 small launches per batch and runs
         when nothing else is queued, so issued from Python it is launch-bound (98 ms of host time for 43 ms of GPU work
         per 64 images, tools/host_phase_probe.py)."""
-        if self.use_graph and images.shape[0] == self.GRAPH_BATCH and self.w.device.type == "cuda":
-            if self._graph is None:
-                self._g_in = torch.empty(self.GRAPH_BATCH, *images.shape[1:], dtype=torch.bfloat16, device=self.w.device)
-                self._g_in.copy_(images)
+        n = images.shape[0]
+        if self.use_graph and n in self.GRAPH_SIZES and self.w.device.type == "cuda":
+            st = self._graphs.get(n)
+            if st is None:
+                self._kv_cache(self.GRAPH_BATCH)
+                g_in = torch.empty(n, *images.shape[1:], dtype=torch.bfloat16, device=self.w.device)
+                g_in.copy_(images)
                 side = torch.cuda.Stream(self.w.device)
                 side.wait_stream(torch.cuda.current_stream(self.w.device))
                 with torch.cuda.stream(side):
                     for _ in range(2):
-                        self._forward(self._g_in)
+                        self._forward(g_in)
                 torch.cuda.current_stream(self.w.device).wait_stream(side)
                 g = torch.cuda.CUDAGraph()
                 gc.collect()
@@ -271,14 +275,15 @@ class VisionTower:
                 gc.disable()
                 try:
                     with torch.cuda.graph(g):
-                        self._g_out = self._forward(self._g_in)
+                        g_out = self._forward(g_in)
                 finally:
                     if gc_on:
                         gc.enable()
-                self._graph = g
-            self._g_in.copy_(images.to(self.w.device, non_blocking=True))      # H2D in the caller's dtype, bf16 cast on the device
-            self._graph.replay()
-            return self._g_out.clone()
+                st = self._graphs[n] = (g, g_in, g_out)
+            g, g_in, g_out = st
+            g_in.copy_(images.to(self.w.device, non_blocking=True))      # H2D in the caller's dtype, bf16 cast on the device
+            g.replay()
+            return g_out.clone()
         return self._forward(images)
 
     @torch.no_grad()

@@ -310,11 +310,14 @@ def test_vit_graph_replay_equals_eager_forward():
     for rep in range(3):
         imgs = torch.randn(nb, 3, cfg.vision.image, cfg.vision.image, generator=g)
         got = e.vit(imgs)
-        assert e.vit._graph is not None
+        assert nb in e.vit._graphs
         want = e.vit._forward(imgs)
         assert got.shape == want.shape and torch.equal(got, want), rep
     small = torch.randn(3, 3, cfg.vision.image, cfg.vision.image, generator=g)
-    assert torch.equal(e.vit(small), e.vit._forward(small))
+    assert torch.equal(e.vit(small), e.vit._forward(small)) and 3 not in e.vit._graphs
+    one = torch.randn(1, 3, cfg.vision.image, cfg.vision.image, generator=g)      # a single question's image: graphed too
+    assert torch.equal(e.vit(one), e.vit._forward(one)) and 1 in e.vit._graphs
+    assert torch.equal(e.vit(one + 1), e.vit._forward(one + 1))
     # through generate(): 16 distinct images -> the graph path feeds the prefill
     ids = [torch.tensor([1, 5, 6, -200, 7 + i, 8]) for i in range(nb)]
     imgs = [torch.randn(3, cfg.vision.image, cfg.vision.image, generator=g) for _ in range(nb)]
