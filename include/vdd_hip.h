@@ -163,6 +163,29 @@ int vdd_skinny_swiglu_tiled(const void* X, const void* W_gate_up_tiled, void* ac
 int vdd_mid_gemm(const void* X, const void* W, void* Y, float* Y_slabs, int M, int N, int K, int64_t ldx, int64_t ldy,
                  int n_split, void* hip_stream);
 
+/* Row-batched projection GEMM, any M above the skinny regime (csrc/vdd_gemm.hip): Y[M,N] = epilogue(X[M,K] W[N,K]^T), bf16 in,
+ * fp32 accumulate (32x32x16 MFMA, both operands LDS-DMA'd into swizzled LDS tiles, persistent stream-K over one workgroup
+ * per CU), bf16 out.  K % 128 == 0, N % 4 == 0, ldx/ldw % 8 == 0 (elements).  Replaces the eager nn.Linear calls of HF
+ * LlamaModel / CLIPVisionModel / the mlp2x_gelu projector (llava_llama.py:88-103, clip_encoder.py:39-51,
+ * multimodal_projector/builder.py:33-46) at batch.
+ * epilogue: VDD_GEMM_NONE; _BIAS y = bf16(acc + bias[n]); _BIAS_QUICK_GELU / _BIAS_GELU act(bf16(acc + bias));
+ *   _SWIGLU  W = [Wgate; Wup] (2N rows), Y[M, N] = bf16(bf16(silu(bf16 gate)) * bf16 up), N % 128 == 0;
+ *   _BIAS_RESID y = bf16(bf16(acc + bias) + resid[m, n]).
+ * workspace: caller-owned device scratch of >= vdd_gemm_workspace_bytes(M, N) bytes whose first (tile-count) int32 words are
+ *   ZERO before the first call (arrival counters of tiles cut across workgroups; every call leaves them zero again) - one
+ *   buffer per stream, launches on a stream may share it.
+ * config: 0 = chosen from the shape; 1..3 force the 256x256 / 128x256 / 256x128 macro tile (tests, tuning). */
+#define VDD_GEMM_NONE 0
+#define VDD_GEMM_BIAS 1
+#define VDD_GEMM_BIAS_QUICK_GELU 2
+#define VDD_GEMM_BIAS_GELU 3
+#define VDD_GEMM_SWIGLU 4
+#define VDD_GEMM_BIAS_RESID 5
+int64_t vdd_gemm_workspace_bytes(int M, int N);
+int vdd_gemm(const void* X, const void* W, void* Y, const void* bias, const void* resid, int M, int N, int K,
+             int64_t ldx, int64_t ldw, int64_t ldy, int64_t ldr, int epilogue, int config, void* workspace, int64_t workspace_bytes,
+             void* hip_stream);
+
 /* One query per (row, head) over that row's KV: rows[m] = {slot, len, prefix_slot, prefix_len} (int32 x4);
  * tokens [0, prefix_len) are read from the PREFIX pool (k_prefix/v_prefix, slot prefix_slot, index t: a shared
  * prompt prefix), tokens [prefix_len, len) from the OWN pool (k_cache/v_cache, slot `slot`, index t - prefix_len).

@@ -1,0 +1,441 @@
+// Row-batched projection GEMM for gfx950:  Y[M, N] = epilogue(X[M, K] . W[N, K]^T), bf16 in / fp32 accumulate / bf16 out.
+//
+// This is every dense contraction of the path above 8 rows: the four decoder projections + lm_head at the decode batch
+// (M = questions x branches, 384-1536 rows), the same projections at prefill size (M = 20k-40k packed prompt tokens), and
+// the ViT / projector GEMMs.  It replaces the eager nn.Linear calls under
+// experiments/llava/model/language_model/llava_llama.py:88-103 (HF LlamaModel), multimodal_encoder/clip_encoder.py:39-51
+// (HF CLIPVisionModel) and multimodal_projector/builder.py:33-46 of the reference.
+//
+// Design (MI355X: 256 CUs, 160 KiB LDS, 512-entry unified VGPR/AGPR file per SIMD lane, MFMA 32x32x16 bf16 = 32 cycles/SIMD):
+//   * macro tile BM x BN (256 x 256 by default), 8 waves as WM x WN; a wave owns a (BM/WM) x (BN/WN) block as 32x32 MFMA
+//     tiles with W as the MFMA "A" operand and X as the "B" operand, so the accumulator of a lane is 4 CONSECUTIVE output
+//     columns of one output row per register quad (8-byte stores; the SwiGLU pair of a feature sits in the same lane);
+//   * both operands are K-contiguous, so both go HBM/L2 -> LDS with buffer_load_dwordx4 ... lds (LDS-DMA: no staging
+//     VGPRs, no ds_write pass).  One wave instruction moves 8 rows x 128 B: full 128-byte lines on the memory side
+//     (fragment-shaped 32-byte pieces cost 4x the address-coalescer cycles), a lane-linear 1-KiB image on the LDS side;
+//   * LDS tile = [BM + BN rows][64 k] bf16, row-major 128-B rows, the 16-B chunk index XOR-swizzled with (row >> 1) & 7.
+//     LDS-DMA cannot scatter, so the permutation is applied to the SOURCE address of each lane and again on the fragment
+//     reads; a ds_read_b128 lane group (16 rows x one chunk) then covers all 16 bank slots: conflict-free;
+//   * K-tile = 64, two LDS buffers (2 x 64 KiB at 256 x 256), ONE barrier per K-tile placed behind the last fragment read
+//     of the tile (the middle of its MFMAs): fragments are read two 16-deep k-steps ahead of their MFMAs, also across the
+//     tile boundary, so MFMAs always issue from registers; the LDS-DMA of tile t+2 goes out right behind that barrier, one
+//     instruction per MFMA, and has a whole tile of MFMAs to land;
+//   * PERSISTENT stream-K: the grid is one workgroup per CU; the iteration space (tiles x 128-deep K units, tiles in an
+//     XCD-contiguous, L2-grouped order) is cut into equal contiguous ranges, so 144 or 258 tiles load 256 CUs evenly (the
+//     decode batch is where tile-count quantisation costs more than the inner loop: 768 x 12288 is 144 tiles of 256 x 256).
+//     A tile cut across workgroups is finished by the workgroup that owns its FIRST K unit - that part is the LAST thing
+//     that workgroup computes, while the other parts are the FIRST thing their workgroups compute, so the fp32 partials
+//     (one 256-KiB slab per workgroup, written once) are long complete when the finisher asks for them: agent-scope
+//     release + per-tile arrival counter on the producer side, relaxed poll + one agent-scope acquire on the finisher;
+//   * epilogues in registers: bias, bias + quick-GELU / GELU (ViT, projector), bias + residual (ViT), SwiGLU (gate and up
+//     rows of one feature are interleaved into the same W tile, so silu(g) * u never round-trips through HBM).
+// Bound: MFMA (2.5 PF/s dense bf16).
+
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+#include <type_traits>
+
+#include "vdd_hip.h"
+
+namespace {
+
+typedef __attribute__((ext_vector_type(8))) __bf16 bf16x8_t;
+typedef __attribute__((ext_vector_type(16))) float f32x16_t;
+typedef __attribute__((ext_vector_type(4))) __bf16 bf16x4_t;
+typedef __attribute__((ext_vector_type(4))) float f32x4_t;
+typedef __attribute__((ext_vector_type(4))) uint32_t u32x4_t;
+typedef __attribute__((address_space(3))) void* lds_ptr_t;
+
+__device__ __forceinline__ float bf2f(uint32_t h) { return __builtin_bit_cast(float, h << 16); }
+__device__ __forceinline__ float rbf(float f) { return (float)(__bf16)f; }     // round to bf16 (RNE, v_cvt_pk_bf16_f32), keep as float
+__device__ __forceinline__ uint2 pack4(float a, float b, float c, float d) {
+    const f32x4_t v = {a, b, c, d};
+    return __builtin_bit_cast(uint2, __builtin_convertvector(v, bf16x4_t));
+}
+__device__ __forceinline__ float act_quick_gelu(float x) { return x / (1.f + __expf(-1.702f * x)); }
+__device__ __forceinline__ float act_gelu(float x) { return 0.5f * x * (1.f + erff(x * 0.70710678118654752440f)); }
+
+enum { EPI_NONE = VDD_GEMM_NONE, EPI_BIAS = VDD_GEMM_BIAS, EPI_BIAS_QUICK_GELU = VDD_GEMM_BIAS_QUICK_GELU,
+       EPI_BIAS_GELU = VDD_GEMM_BIAS_GELU, EPI_SWIGLU = VDD_GEMM_SWIGLU, EPI_BIAS_RESID = VDD_GEMM_BIAS_RESID };
+
+struct GemmArgs {
+    const uint16_t* X; const uint16_t* W; uint16_t* Y;
+    const uint16_t* bias; const uint16_t* resid;
+    float* partial;              // [P][BM * BN] fp32: the partial tile a workgroup hands to a finisher
+    int* counter;                // [Mt * Nt] arrival counters, zero between launches (the finisher resets its tile's)
+    int M, N, K;                 // N: OUTPUT columns (SwiGLU: the F features; W then has 2 F rows, gate rows first)
+    long long ldx, ldw, ldy, ldr;
+    int Mt, Nt, GM;              // tile counts, row-tiles per L2 group
+    int UP, U, P;                // K units (128 deep) per tile, units in total, workgroups
+    int dp_rounds;               // whole-tile rounds before the stream-K part (host-chosen schedule)
+};
+
+template <int BM, int BN, int WM, int WN, int EPI>
+__global__ void __launch_bounds__(WM * WN * 64) gemm_kernel(const GemmArgs a) {
+#if defined(__HIP_DEVICE_COMPILE__)   // the host pass only needs the launch stub: it drops a kernel whose body holds LDS-DMA builtins
+    constexpr int NW = WM * WN, NT = NW * 64;
+    constexpr int TM = BM / WM, TN = BN / WN, MI = TM / 32, NI = TN / 32;
+    constexpr int XIMG = BM / 8, WIMG = BN / 8;            // 1-KiB LDS-DMA images (8 rows x 128 B) per K-tile
+    constexpr int XJ = XIMG / NW, WJ = WIMG / NW;          // images per wave
+    constexpr int BUF = (BM + BN) * 128;                   // bytes of one K-tile buffer
+    constexpr int NMMA = NI * MI, NRD = NI + MI, NLD = XJ + WJ;
+    static_assert(XIMG % NW == 0 && WIMG % NW == 0 && TM % 32 == 0 && TN % 32 == 0, "tile / wave shape");
+    static_assert(EPI != EPI_SWIGLU || NI % 2 == 0, "SwiGLU pairs gate/up 32-column blocks inside a wave");
+    extern __shared__ __attribute__((aligned(16))) char lds[];
+
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int wr = wave / WN, wc = wave % WN;
+
+    // fragment addresses: row * 128 + ((kk * 2 + (lane >> 5)) ^ ((lane >> 1) & 7)) * 16
+    const int c0 = ((lane >> 5) ^ ((lane >> 1) & 7)) * 16;
+    const int xrow = (wr * TM + (lane & 31)) * 128 + c0;
+    const int wrow = (BM + wc * TN + (lane & 31)) * 128 + c0;
+
+    // ---- this workgroup's work list.  Whole tiles first: round i of the data-parallel part hands tile i * P + rng to
+    // workgroup rng, and workgroup b runs on XCD b % 8, so rng is XCD-contiguous: the 32 CUs of an XCD work on 32 neighbouring
+    // tiles at any time (shared X row-panels / W column-panels in its L2).  Then the stream-K part: the tiles that do not
+    // fill a round, as one contiguous range of 128-deep K units per workgroup.
+    const int rng = (a.P & 7) ? (int)blockIdx.x : (int)((blockIdx.x & 7) * (a.P >> 3) + (blockIdx.x >> 3));
+    const int T = a.Mt * a.Nt, rounds = a.dp_rounds, dp_tiles = min(T, rounds * a.P);
+    const long long SU = (long long)(T - dp_tiles) * a.UP;            // stream-K units
+    const int Psk = (int)min((long long)a.P, SU);                      // never more ranges than units: no empty range
+    long long u = 0, u_end = 0;
+    if (rng < Psk) { u = (long long)rng * SU / Psk; u_end = (long long)(rng + 1) * SU / Psk; }
+    auto owner = [&](long long uu) { return (int)(((uu + 1) * Psk + SU - 1) / SU - 1); };     // stream-K range that holds unit uu
+    int dp_i = 0;
+    int L = 0, ku0 = 0, ku1 = 0;
+    auto advance = [&]() -> bool {
+        if (dp_i < rounds && dp_i * a.P + rng < T) { L = dp_i * a.P + rng; ku0 = 0; ku1 = a.UP; ++dp_i; return true; }
+        dp_i = rounds;
+        if (u < u_end) {
+            const int ls = (int)(u / a.UP);
+            L = dp_tiles + ls; ku0 = (int)(u - (long long)ls * a.UP);
+            ku1 = (int)min((long long)a.UP, ku0 + (u_end - u));
+            u += ku1 - ku0;
+            return true;
+        }
+        return false;
+    };
+    // per-segment state: tile origin, LDS-DMA descriptors (one buffer descriptor per operand, per-lane byte offsets constant over K)
+    int tn = 0, m0 = 0, n0 = 0, nk = 0;
+    __amdgpu_buffer_rsrc_t rx, rw;
+    uint32_t xoff[XJ], woff[WJ];
+    auto setup = [&]() {
+        // tile order: groups of GM row-tiles x all column tiles, row-tile fastest (neighbours share a W column panel)
+        const int per_group = a.GM * a.Nt, gid = L / per_group, first_m = gid * a.GM;
+        const int gsz = min(a.Mt - first_m, a.GM), in_g = L - gid * per_group;
+        const int tm = first_m + in_g % gsz;
+        tn = in_g / gsz;
+        m0 = tm * BM; n0 = tn * BN;
+        const int kbeg = ku0 * 128;
+        nk = (ku1 - ku0) * 2;
+        const int rows_x = min(BM, a.M - m0);
+        const uint16_t* xb = a.X + (size_t)m0 * a.ldx + kbeg;
+        const uint16_t* wb;
+        int rows_w;
+        if constexpr (EPI == EPI_SWIGLU) { wb = a.W + (size_t)(tn * (BN / 2)) * a.ldw + kbeg; rows_w = BN; }
+        else { wb = a.W + (size_t)n0 * a.ldw + kbeg; rows_w = min(BN, a.N - n0); }
+        rx = __builtin_amdgcn_make_buffer_rsrc((void*)xb, 0, 0x7fffffff, 0x00020000);
+        rw = __builtin_amdgcn_make_buffer_rsrc((void*)wb, 0, 0x7fffffff, 0x00020000);
+#pragma unroll
+        for (int j = 0; j < XJ; ++j) {
+            const int row = (j * NW + wave) * 8 + (lane >> 3);
+            const int c = (lane & 7) ^ ((row >> 1) & 7);
+            xoff[j] = (uint32_t)min(row, rows_x - 1) * (uint32_t)(a.ldx * 2) + c * 16;
+        }
+#pragma unroll
+        for (int j = 0; j < WJ; ++j) {
+            const int row = (j * NW + wave) * 8 + (lane >> 3);
+            const int c = (lane & 7) ^ ((row >> 1) & 7);
+            int src;
+            if constexpr (EPI == EPI_SWIGLU) {      // tile rows: [g 0-31 | u 0-31 | g 32-63 | u 32-63 | ...] of features tn*BN/2 ..
+                const int blk = row >> 5;
+                src = (blk & 1) * a.N + (blk >> 1) * 32 + (row & 31);
+            } else {
+                src = min(row, rows_w - 1);
+            }
+            woff[j] = (uint32_t)src * (uint32_t)(a.ldw * 2) + c * 16;
+        }
+    };
+    auto stage = [&](int t, int buf) {
+        const int so = t * 128;
+#pragma unroll
+        for (int j = 0; j < XJ; ++j)
+            __builtin_amdgcn_raw_ptr_buffer_load_lds(rx, (lds_ptr_t)(lds + buf * BUF + (j * NW + wave) * 1024), 16, xoff[j], so, 0, 0);
+#pragma unroll
+        for (int j = 0; j < WJ; ++j)
+            __builtin_amdgcn_raw_ptr_buffer_load_lds(rw, (lds_ptr_t)(lds + buf * BUF + (XIMG + j * NW + wave) * 1024), 16, woff[j], so, 0, 0);
+    };
+
+    bool more = advance();
+    if (more) { setup(); stage(0, 0); stage(1, 1); }
+    while (more) {
+        const int cL = L, cku0 = ku0, cku1 = ku1, ctn = tn, cm0 = m0, cn0 = n0;      // this segment (the state moves on to the next one below)
+        f32x16_t acc[NI][MI];
+#pragma unroll
+        for (int i = 0; i < NI; ++i)
+#pragma unroll
+            for (int j = 0; j < MI; ++j)
+#pragma unroll
+                for (int e = 0; e < 16; ++e) acc[i][j][e] = 0.f;
+
+        // ---- K pipeline.  Fragments are read TWO 16-deep k-steps ahead of their MFMAs (sets kk = 0..3, three live at a
+        // time), one LDS read (and, behind the barrier, one LDS-DMA of tile t+2) issued behind each MFMA.
+        // (the first two K-tiles of this segment were staged before the previous segment's epilogue)
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        __builtin_amdgcn_s_barrier();
+        auto interleave = [&](bool with_dma, bool with_reads) {             // MFMA, [DMA], [read], MFMA, ...
+#pragma unroll
+            for (int i = 0; i < NMMA; ++i) {
+                __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
+                if (with_dma && i < NLD) __builtin_amdgcn_sched_group_barrier(0x020, 1, 0);
+                if (with_reads && i < NRD) __builtin_amdgcn_sched_group_barrier(0x100, 1, 0);
+            }
+        };
+        bf16x8_t xg[4][MI], wg[4][NI];
+        auto rd = [&](int buf, int kk) {
+#pragma unroll
+            for (int i = 0; i < NI; ++i) wg[kk][i] = *reinterpret_cast<const bf16x8_t*>(lds + buf * BUF + ((wrow + i * 4096) ^ (kk << 5)));
+#pragma unroll
+            for (int i = 0; i < MI; ++i) xg[kk][i] = *reinterpret_cast<const bf16x8_t*>(lds + buf * BUF + ((xrow + i * 4096) ^ (kk << 5)));
+        };
+        auto mm = [&](int kk) {
+#pragma unroll
+            for (int i = 0; i < NI; ++i)
+#pragma unroll
+                for (int j = 0; j < MI; ++j) acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(wg[kk][i], xg[kk][j], acc[i][j], 0, 0, 0);
+        };
+        rd(0, 0); rd(0, 1);
+        __builtin_amdgcn_sched_barrier(0);
+        auto tile = [&](int t, int buf, auto do_stage, auto do_next) {           // buf is a literal at every call site
+            constexpr bool ST = decltype(do_stage)::value, NX = decltype(do_next)::value;
+            rd(buf, 2); mm(0); interleave(false, true); __builtin_amdgcn_sched_barrier(0);
+            rd(buf, 3); mm(1); interleave(false, true); __builtin_amdgcn_sched_barrier(0);
+            asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");   // own fragment reads of this tile done; tile t+1 landed
+            __builtin_amdgcn_s_barrier();
+            __builtin_amdgcn_sched_barrier(0);
+            if constexpr (ST) stage(t + 2, buf);
+            if constexpr (NX) rd(buf ^ 1, 0);
+            mm(2); interleave(ST, NX); __builtin_amdgcn_sched_barrier(0);
+            if constexpr (NX) rd(buf ^ 1, 1);
+            mm(3); interleave(false, NX); __builtin_amdgcn_sched_barrier(0);
+        };
+        using T_ = std::true_type; using F_ = std::false_type;
+        int t = 0;                                  // nk is even: tiles alternate between the two buffers
+        for (; t + 2 < nk; t += 2) { tile(t, 0, T_{}, T_{}); tile(t + 1, 1, T_{}, T_{}); }
+        tile(t, 0, F_{}, T_{});
+        tile(t + 1, 1, F_{}, F_{});
+        // nobody reads LDS behind the last barrier of a segment: stage the next segment's first two K-tiles now, so that
+        // they land under this segment's epilogue
+        more = advance();
+        if (more) { setup(); stage(0, 0); stage(1, 1); }
+
+        // ---- a tile cut across workgroups
+        const bool whole = (cku0 == 0 && cku1 == a.UP);
+        if (!whole) {
+            if (cku0 != 0) {            // not the first part: hand the partial sums to the finisher
+                // write-through (sc1) stores: the slab leaves this XCD's L2 at once, so no release fence (an agent-scope release
+                // is a write-back of the whole L2 - with 32 workgroups per XCD publishing 256 KiB each that costs tens of us)
+                const __amdgpu_buffer_rsrc_t rp = __builtin_amdgcn_make_buffer_rsrc((void*)(a.partial + (size_t)rng * (BM * BN)), 0, BM * BN * 4, 0x00020000);
+#pragma unroll
+                for (int i = 0; i < NI; ++i)
+#pragma unroll
+                    for (int j = 0; j < MI; ++j)
+#pragma unroll
+                        for (int q = 0; q < 4; ++q) {
+                            const f32x4_t vf = {acc[i][j][q * 4], acc[i][j][q * 4 + 1], acc[i][j][q * 4 + 2], acc[i][j][q * 4 + 3]};
+                            __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4_t, vf), rp, (((i * MI + j) * 4 + q) * NT + tid) * 16, 0, 16);
+                        }
+                asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+                __syncthreads();
+                if (tid == 0) __hip_atomic_fetch_add(a.counter + cL, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                continue;
+            }
+            // first part (the last thing this workgroup computes): wait for the others, add their partial sums
+            const long long tu = (long long)(cL - dp_tiles) * a.UP;
+            const int r_last = owner(tu + a.UP - 1), others = r_last - rng;
+            if (tid == 0) {
+                while (__hip_atomic_load(a.counter + cL, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) < others) __builtin_amdgcn_s_sleep(8);
+                __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
+                __hip_atomic_store(a.counter + cL, 0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);     // ready for the next launch
+            }
+            __syncthreads();
+            for (int r = rng + 1; r <= r_last; ++r) {
+                const float* ps = a.partial + (size_t)r * (BM * BN);
+#pragma unroll
+                for (int i = 0; i < NI; ++i)
+#pragma unroll
+                    for (int j = 0; j < MI; ++j)
+#pragma unroll
+                        for (int q = 0; q < 4; ++q) {
+                            const f32x4_t v = *reinterpret_cast<const f32x4_t*>(ps + ((size_t)((i * MI + j) * 4 + q) * NT + tid) * 4);
+                            acc[i][j][q * 4] += v[0]; acc[i][j][q * 4 + 1] += v[1]; acc[i][j][q * 4 + 2] += v[2]; acc[i][j][q * 4 + 3] += v[3];
+                        }
+            }
+        }
+
+        // ---- epilogue.  acc[i][j][e]: n = wc*TN + i*32 + (e&3) + 8*(e>>2) + 4*(lane>>5),  m = wr*TM + j*32 + (lane&31)
+        const int mrow = cm0 + wr * TM + (lane & 31);
+        if constexpr (EPI == EPI_SWIGLU) {
+            const int f0 = ctn * (BN / 2) + wc * (TN / 2) + 4 * (lane >> 5);
+#pragma unroll
+            for (int i = 0; i < NI; i += 2)
+#pragma unroll
+                for (int j = 0; j < MI; ++j) {
+                    const int m = mrow + j * 32;
+                    if (m >= a.M) continue;
+#pragma unroll
+                    for (int q = 0; q < 4; ++q) {
+                        float o[4];
+#pragma unroll
+                        for (int e = 0; e < 4; ++e) {
+                            const float g = rbf(acc[i][j][q * 4 + e]), up = rbf(acc[i + 1][j][q * 4 + e]);
+                            o[e] = rbf(g / (1.f + __expf(-g))) * up;
+                        }
+                        *reinterpret_cast<uint2*>(a.Y + (size_t)m * a.ldy + f0 + (i / 2) * 32 + q * 8) = pack4(o[0], o[1], o[2], o[3]);
+                    }
+                }
+        } else {
+#pragma unroll
+            for (int i = 0; i < NI; ++i)
+#pragma unroll
+                for (int j = 0; j < MI; ++j) {
+                    const int m = mrow + j * 32;
+                    if (m >= a.M) continue;
+#pragma unroll
+                    for (int q = 0; q < 4; ++q) {
+                        const int n = cn0 + wc * TN + i * 32 + q * 8 + 4 * (lane >> 5);
+                        if (n >= a.N) continue;
+                        float v[4];
+#pragma unroll
+                        for (int e = 0; e < 4; ++e) v[e] = acc[i][j][q * 4 + e];
+                        if constexpr (EPI != EPI_NONE) {
+                            const uint2 bb = *reinterpret_cast<const uint2*>(a.bias + n);
+                            v[0] += bf2f(bb.x & 0xffffu); v[1] += bf2f(bb.x >> 16); v[2] += bf2f(bb.y & 0xffffu); v[3] += bf2f(bb.y >> 16);
+                        }
+                        if constexpr (EPI == EPI_BIAS_QUICK_GELU) {
+#pragma unroll
+                            for (int e = 0; e < 4; ++e) v[e] = act_quick_gelu(rbf(v[e]));
+                        } else if constexpr (EPI == EPI_BIAS_GELU) {
+#pragma unroll
+                            for (int e = 0; e < 4; ++e) v[e] = act_gelu(rbf(v[e]));
+                        } else if constexpr (EPI == EPI_BIAS_RESID) {
+                            const uint2 rr = *reinterpret_cast<const uint2*>(a.resid + (size_t)m * a.ldr + n);
+                            v[0] = rbf(v[0]) + bf2f(rr.x & 0xffffu); v[1] = rbf(v[1]) + bf2f(rr.x >> 16);
+                            v[2] = rbf(v[2]) + bf2f(rr.y & 0xffffu); v[3] = rbf(v[3]) + bf2f(rr.y >> 16);
+                        }
+                        *reinterpret_cast<uint2*>(a.Y + (size_t)m * a.ldy + n) = pack4(v[0], v[1], v[2], v[3]);
+                    }
+                }
+        }
+    }
+#endif
+}
+
+int g_num_cu = 0;
+
+int num_workgroups() {
+    if (g_num_cu == 0) {
+        int dev = 0, n = 0;
+        if (hipGetDevice(&dev) != hipSuccess || hipDeviceGetAttribute(&n, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess || n <= 0) n = 256;
+        g_num_cu = n & ~7;       // one workgroup per CU, a multiple of the 8 XCDs
+        if (g_num_cu < 8) g_num_cu = 8;
+    }
+    return g_num_cu;
+}
+
+template <int BM, int BN, int WM, int WN>
+int launch_cfg(const GemmArgs& a0, int epi, int sched, void* workspace, int64_t workspace_bytes, hipStream_t st) {
+    GemmArgs a = a0;
+    const int ncols = epi == EPI_SWIGLU ? 2 * a.N : a.N;
+    a.Mt = (a.M + BM - 1) / BM;
+    a.Nt = (ncols + BN - 1) / BN;
+    a.GM = a.Mt < 8 ? a.Mt : 8;
+    a.UP = a.K / 128;
+    const long long U = (long long)a.Mt * a.Nt * a.UP;
+    if (U > 0x7fffffffLL) return VDD_ERR_INVALID_ARG;
+    a.U = (int)U;
+    const int P = num_workgroups();
+    a.P = P;
+    {   // schedule: whole-tile rounds, then stream-K over what is left.  The stream-K part always spans at least one tile per
+        // workgroup when it exists beside full rounds ("two-tile" stream-K), so a tile is cut into 2 (rarely 3) parts.
+        const int T = a.Mt * a.Nt, full = T / P, rem = T % P;
+        if (sched == 1) a.dp_rounds = (T + P - 1) / P;            // data-parallel only
+        else if (sched == 2) a.dp_rounds = 0;                     // stream-K only
+        else a.dp_rounds = rem == 0 ? full : (full > 0 ? full - 1 : 0);
+    }
+    const size_t need = (size_t)a.Mt * a.Nt * sizeof(int) + 256 + (size_t)P * BM * BN * sizeof(float);
+    if (!workspace || (size_t)workspace_bytes < need) return VDD_ERR_INVALID_ARG;
+    a.counter = (int*)workspace;
+    a.partial = (float*)((char*)workspace + (((size_t)a.Mt * a.Nt * sizeof(int) + 255) & ~(size_t)255));
+    const dim3 grid(P), block(WM * WN * 64);
+    const size_t smem = 2 * (BM + BN) * 128;
+#define VDD_GEMM_LAUNCH(E)                                                                                            \
+    case E: {                                                                                                         \
+        auto kfn = gemm_kernel<BM, BN, WM, WN, E>;                                                                    \
+        static bool attr_set = false;                                                                                 \
+        if (!attr_set) { (void)hipFuncSetAttribute((const void*)kfn, hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem); attr_set = true; } \
+        hipLaunchKernelGGL(kfn, grid, block, smem, st, a);                                                            \
+        break;                                                                                                        \
+    }
+    switch (epi) {
+        VDD_GEMM_LAUNCH(EPI_NONE)
+        VDD_GEMM_LAUNCH(EPI_BIAS)
+        VDD_GEMM_LAUNCH(EPI_BIAS_QUICK_GELU)
+        VDD_GEMM_LAUNCH(EPI_BIAS_GELU)
+        VDD_GEMM_LAUNCH(EPI_BIAS_RESID)
+        case EPI_SWIGLU:
+            if constexpr ((BN / WN / 32) % 2 == 0) {
+                switch (epi) { VDD_GEMM_LAUNCH(EPI_SWIGLU) }
+                break;
+            } else {
+                return VDD_ERR_INVALID_ARG;          // this tile shape cannot pair gate / up blocks inside a wave
+            }
+        default: return VDD_ERR_INVALID_ARG;
+    }
+#undef VDD_GEMM_LAUNCH
+    return hipGetLastError() == hipSuccess ? VDD_OK : VDD_ERR_LAUNCH;
+}
+
+}  // namespace
+
+extern "C" {
+
+int64_t vdd_gemm_workspace_bytes(int M, int N) {
+    // arrival counters of the smallest tile shape + one 256 x 256 fp32 partial per workgroup
+    const int64_t tiles = ((int64_t)(M + 127) / 128) * ((2 * (int64_t)N + 127) / 128);
+    return tiles * 4 + 512 + (int64_t)num_workgroups() * 256 * 256 * 4;
+}
+
+int vdd_gemm(const void* X, const void* W, void* Y, const void* bias, const void* resid, int M, int N, int K,
+             int64_t ldx, int64_t ldw, int64_t ldy, int64_t ldr, int epilogue, int config, void* workspace, int64_t workspace_bytes,
+             void* stream) {
+    if (M <= 0 || N <= 0) return VDD_OK;
+    if (!X || !W || !Y || K <= 0 || K % 128 != 0 || (ldx % 8) || (ldw % 8) || (ldy % 4) || N % 4 != 0) return VDD_ERR_INVALID_ARG;
+    if ((epilogue == EPI_BIAS || epilogue == EPI_BIAS_QUICK_GELU || epilogue == EPI_BIAS_GELU || epilogue == EPI_BIAS_RESID) && !bias) return VDD_ERR_INVALID_ARG;
+    if (epilogue == EPI_BIAS_RESID && (!resid || (ldr % 4))) return VDD_ERR_INVALID_ARG;
+    if (epilogue == EPI_SWIGLU && N % 128 != 0) return VDD_ERR_INVALID_ARG;
+    // per-lane byte offsets inside a tile are 32-bit: 256 rows of X, and for SwiGLU the gate -> up distance in W
+    if ((uint64_t)256 * (uint64_t)ldx * 2 >= 0x7fffffffull) return VDD_ERR_INVALID_ARG;
+    if ((uint64_t)((epilogue == EPI_SWIGLU ? (uint64_t)N : 0) + 256) * (uint64_t)ldw * 2 >= 0x7fffffffull) return VDD_ERR_INVALID_ARG;
+    GemmArgs a{};
+    a.X = (const uint16_t*)X; a.W = (const uint16_t*)W; a.Y = (uint16_t*)Y;
+    a.bias = (const uint16_t*)bias; a.resid = (const uint16_t*)resid;
+    a.M = M; a.N = N; a.K = K; a.ldx = ldx; a.ldw = ldw; a.ldy = ldy; a.ldr = ldr;
+    hipStream_t st = (hipStream_t)stream;
+    const int sched = (config >> 4) & 3;            // tuning: 0 hybrid, 1 data-parallel only, 2 stream-K only
+    config &= 15;
+    if (config == 0) config = 1;
+    switch (config) {
+        case 1: return launch_cfg<256, 256, 2, 4>(a, epilogue, sched, workspace, workspace_bytes, st);
+        case 2: return launch_cfg<128, 256, 2, 4>(a, epilogue, sched, workspace, workspace_bytes, st);
+        case 3: return launch_cfg<256, 128, 4, 2>(a, epilogue, sched, workspace, workspace_bytes, st);
+        case 4: return launch_cfg<192, 256, 2, 4>(a, epilogue, sched, workspace, workspace_bytes, st);
+        case 5: return launch_cfg<256, 192, 4, 2>(a, epilogue, sched, workspace, workspace_bytes, st);
+        default: return VDD_ERR_INVALID_ARG;
+    }
+}
+
+}  // extern "C"
