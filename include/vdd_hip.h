@@ -114,7 +114,7 @@ int vdd_add_diffusion_noise(const void* x, void* y, int64_t n, int dtype, float 
  * ------------------------------------------------------------------------------------------- */
 
 /* h = x (+ delta); resid_out = h (optional); y = bf16(bf16(h * rsqrt(mean h^2 + eps)) * w).  d % 8 == 0, d <= 8192.
- * delta is either bf16 [M, d] or, as delta_slabs, the n_slabs fp32 split-K partials [n_slabs][M][d] of vdd_mid_gemm
+ * delta is either bf16 [M, d] or, as delta_slabs, the n_slabs fp32 split-K partials [n_slabs][M][d] of vdd_skinny_gemm
  * (summed, rounded to bf16, then added - the same roundings as a bf16 GEMM output followed by the residual add). */
 int vdd_rmsnorm(const void* x, const void* delta, const float* delta_slabs, int n_slabs, const void* w, void* y, void* resid_out,
                 int M, int d, float eps, void* hip_stream);
@@ -146,22 +146,6 @@ int vdd_skinny_gemm(const void* X, const void* W, const void* R, void* Y, float*
  * projection and SiLU*mul of the Llama MLP (HF LlamaMLP.forward [ext] under llava_llama.py:88-103) in one weight-streaming
  * launch; replaces vdd_skinny_gemm(N = 2F) + vdd_silu_mul with the same bf16 rounding points. */
 int vdd_skinny_swiglu(const void* X, const void* W_gate_up, void* act, int M, int F, int K, int64_t ldx, void* hip_stream);
-
-/* Pre-tiled weight layout for the skinny kernels: vdd_tile_weight rewrites a row-major W[N,K] (N % 16 == 0, K % 32 == 0) as
- * [N/16][K/32][64 lanes][8 bf16] so that each wave load of the MFMA B fragment is one contiguous KiB and a wave walks one
- * sequential HBM stream (the row-major form makes every wave walk 16 streams 2K bytes apart).  swiglu_pairs != 0: W = [Wg; Wu]
- * and tile t holds rows 8t..8t+7 of Wg followed by rows 8t..8t+7 of Wu (the tile of vdd_skinny_swiglu).  Static weights are
- * tiled once at load time; the *_tiled entry points compute exactly what their row-major twins compute. */
-int vdd_tile_weight(const void* W, void* W_tiled, int N, int K, int swiglu_pairs, void* hip_stream);
-int vdd_skinny_gemm_tiled(const void* X, const void* W_tiled, const void* R, void* Y, float* Y_slabs, int n_split, int M, int N, int K,
-                          int64_t ldx, int64_t ldr, int64_t ldy, void* hip_stream);
-int vdd_skinny_swiglu_tiled(const void* X, const void* W_gate_up_tiled, void* act, int M, int F, int K, int64_t ldx, void* hip_stream);
-
-/* Decode-regime GEMM, 9 <= M <= 256 rows: Y[M,N] = X[M,K] W[N,K]^T with W streamed from HBM exactly once and the X
- * tile shared through LDS (csrc/vdd_mid_gemm.hip).  Either Y (bf16, n_split == 1) or Y_slabs (fp32 [n_split][M][N]:
- * split-K partial sums, summed by vdd_rmsnorm's delta_slabs input); K % (64 * n_split) == 0. */
-int vdd_mid_gemm(const void* X, const void* W, void* Y, float* Y_slabs, int M, int N, int K, int64_t ldx, int64_t ldy,
-                 int n_split, void* hip_stream);
 
 /* Row-batched projection GEMM, any M above the skinny regime (csrc/vdd_gemm.hip): Y[M,N] = epilogue(X[M,K] W[N,K]^T), bf16 in,
  * fp32 accumulate (32x32x16 MFMA, both operands LDS-DMA'd into swizzled LDS tiles, persistent stream-K over one workgroup
@@ -240,6 +224,15 @@ int vdd_prefix_v_transpose(const void* v_prefix, void* v_prefix_t8, const int32_
 int vdd_flash_attention(const void* q, const void* k_cache, const void* v_cache, const void* k_prefix, const void* v_prefix,
                         const int32_t* seqs, void* out, int n_seq, int max_tq, int H, int Hkv, int D, int64_t slot_stride, int t_max,
                         int64_t prefix_stride, int prefix_tmax, float scale, int causal, void* hip_stream);
+
+/* ViT front-end glue around the patch-embed GEMM (HF CLIPVisionEmbeddings / CLIPAttention as run by clip_encoder.py:39-51):
+ * im2col of the stride-P patch convolution (images [n,3,S,S] of vdd_dtype `dtype` -> bf16 patches [n*(S/P)^2, Kp], zero
+ * padded from 3*P*P to Kp columns); class token + position embeddings (h[i,t] = (t ? emb[i*(T-1)+t-1] : cls) + pos[t]);
+ * the fused qkv projection [n*T, 3, H, D] split into q [n*T, H*D] and the K / V caches [image][H][t_max][D]. */
+int vdd_vit_im2col(const void* images, int dtype, void* patches, int n, int S, int P, int Kp, void* hip_stream);
+int vdd_vit_assemble(const void* emb, const void* cls, const void* pos, void* out, int n, int T, int width, void* hip_stream);
+int vdd_vit_qkv_split(const void* qkv, void* q, void* k_cache, void* v_cache, int n, int T, int H, int D, int64_t slot_stride, int t_max,
+                      void* hip_stream);
 
 /* CLIP ViT LayerNorm (with bias); d % 8 == 0, d <= 4096. */
 int vdd_layernorm(const void* x, const void* w, const void* b, void* y, int M, int d, float eps, void* hip_stream);

@@ -219,9 +219,7 @@ __global__ void __launch_bounds__(256) embed_scatter_kernel(const int* __restric
 // is read from HBM exactly once and never staged.  X fragments (A operand, same lane map over
 // rows) are L2-resident re-reads.  MT = number of 16-row M tiles (M <= 16*MT); the four wave
 // partials are summed through LDS.
-// TILED: W pre-tiled per (16-row tile, 32-k chunk) as [N/16][K/32][lane = g*16 + ln][8] (vdd_tile_weight layout), so
-// that every wave load instruction reads ONE contiguous KiB and a wave walks a single sequential stream.
-template <int MT, bool TILED>
+template <int MT>
 __global__ void __launch_bounds__(256) skinny_gemm_kernel(const uint16_t* __restrict__ X, const uint16_t* __restrict__ W,
                                                           const uint16_t* __restrict__ R, uint16_t* __restrict__ Y,
                                                           float* __restrict__ Yslab, int M, int N, int K, long long ldx,
@@ -235,9 +233,8 @@ __global__ void __launch_bounds__(256) skinny_gemm_kernel(const uint16_t* __rest
     const int kq = K / (4 * (int)gridDim.y);
     const int kbeg = ((int)blockIdx.y * 4 + wave) * kq;
     int nrow = n0 + ln; if (nrow >= N) nrow = N - 1;
-    const uint16_t* wp = TILED ? W + (((size_t)blockIdx.x * (K / 32) + kbeg / 32) * 64 + lane) * 8
-                               : W + (size_t)nrow * K + kbeg + g * 8;
-    constexpr int WS = TILED ? 16 : 1;          // tiled: 32 k-elements further = 512 elements further in memory
+    const uint16_t* wp = W + (size_t)nrow * K + kbeg + g * 8;
+    constexpr int WS = 1;
     const uint16_t* xp[MT];
 #pragma unroll
     for (int t = 0; t < MT; ++t) { int r = t * 16 + ln; if (r >= M) r = M - 1; xp[t] = X + (size_t)r * ldx + kbeg + g * 8; }
@@ -293,7 +290,6 @@ __global__ void __launch_bounds__(256) skinny_gemm_kernel(const uint16_t* __rest
 // (B-fragment lanes ln < 8 -> row f0 + ln) and the 8 matching up columns (ln >= 8 -> row F + f0 + ln - 8), so the
 // epilogue finds gate and up of one feature in the same LDS tile: no [M, 2F] round trip and no silu_mul launch.
 // Rounding as the unfused pair: gate, up -> bf16; silu(gate) -> bf16; product -> bf16.
-template <bool TILED>     // TILED: tile t = rows [8t..8t+7 of Wg, 8t..8t+7 of Wu], laid out as in skinny_gemm_kernel
 __global__ void __launch_bounds__(256) skinny_swiglu_kernel(const uint16_t* __restrict__ X, const uint16_t* __restrict__ W,
                                                             uint16_t* __restrict__ A, int M, int F, int K, long long ldx) {
     __shared__ float part[4][64][4];
@@ -302,9 +298,8 @@ __global__ void __launch_bounds__(256) skinny_swiglu_kernel(const uint16_t* __re
     const int ln = lane & 15, g = lane >> 4;
     const int kq = K / 4, kbeg = wave * kq;
     int f = f0 + (ln & 7); if (f >= F) f = F - 1;
-    const uint16_t* wp = TILED ? W + (((size_t)blockIdx.x * (K / 32) + kbeg / 32) * 64 + lane) * 8
-                               : W + ((size_t)(ln < 8 ? 0 : F) + f) * K + kbeg + g * 8;
-    constexpr int WS = TILED ? 16 : 1;
+    const uint16_t* wp = W + ((size_t)(ln < 8 ? 0 : F) + f) * K + kbeg + g * 8;
+    constexpr int WS = 1;
     int r = ln; if (r >= M) r = M - 1;
     const uint16_t* xp = X + (size_t)r * ldx + kbeg + g * 8;
     f32x4_t acc = f32x4_t{0.f, 0.f, 0.f, 0.f};
@@ -642,76 +637,9 @@ __global__ void __launch_bounds__(NW * 64) decode_attn_fused_kernel(const uint16
 }
 
 // ------------------------------------------------------------------ prefix-grouped decode attention
-// Rows that share a prompt prefix (the 6 POPE questions of one image; ALL image-free branch rows) form a group.
-// A block = (16-row slice of a group, head, 64-key chunk of the prefix): it stages that K/V tile ONCE in LDS
-// (2 x 16 KiB, 16 B per lane, 1 KiB contiguous per wave instruction) and every row of the slice attends it from
-// LDS, so each prefix K/V byte leaves HBM/L2 once per group instead of once per row.  Per row the arithmetic is the
-// split-KV kernel's (16-lane group per key, online softmax per group, 4-way merge); partials go to the same
-// workspace and are merged by decode_attn_combine_kernel.
+// Rows that share a prompt prefix (the 6 POPE questions of one image; ALL image-free branch rows) form a group: each
+// prefix K/V byte leaves HBM/L2 once per group instead of once per row.
 struct GroupDesc { int row_off, n_rows, pslot, plen; };
-
-template <int D>
-__global__ void __launch_bounds__(256) decode_attn_prefix_kernel(const uint16_t* __restrict__ q, const uint16_t* __restrict__ kpre,
-                                                                 const uint16_t* __restrict__ vpre, const GroupDesc* __restrict__ groups,
-                                                                 const int* __restrict__ group_rows, const int4* __restrict__ items,
-                                                                 float* __restrict__ ws, int H, int Hkv,
-                                                                 long long pre_stride, int pre_tmax, float scale, int nchunk) {
-    static_assert(D == 128, "");
-    __shared__ __attribute__((aligned(16))) uint16_t k_lds[ATT_CH * D];
-    __shared__ __attribute__((aligned(16))) uint16_t v_lds[ATT_CH * D];
-    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, g = lane >> 4, j = lane & 15;
-    const int4 item = items[blockIdx.x];                          // {group, first row of the slice, chunk, -}: host-built work list
-    const GroupDesc gd = groups[item.x];
-    const int chunk = item.z;
-    const int head = blockIdx.y, kvh = head / (H / Hkv);
-    const int r0 = item.y;
-    const int k0 = chunk * ATT_CH;
-    if (r0 >= gd.n_rows || k0 >= gd.plen) return;                 // block-uniform
-    const int k1 = min(gd.plen, k0 + ATT_CH), nk = k1 - k0;
-    {   // stage the tile: 64 keys x 256 B for K and V
-        const uint16_t* kb = kpre + (size_t)gd.pslot * pre_stride + ((size_t)kvh * pre_tmax + k0) * D;
-        const uint16_t* vb = vpre + (size_t)gd.pslot * pre_stride + ((size_t)kvh * pre_tmax + k0) * D;
-#pragma unroll
-        for (int i = 0; i < ATT_CH * D / 8 / 256; ++i) {
-            const int e = (i * 256 + tid) * 8;
-            if (e < nk * D) {
-                *reinterpret_cast<uint4*>(&k_lds[e]) = *reinterpret_cast<const uint4*>(kb + e);
-                *reinterpret_cast<uint4*>(&v_lds[e]) = *reinterpret_cast<const uint4*>(vb + e);
-            }
-        }
-    }
-    __syncthreads();
-    const int nrows = min(16, gd.n_rows - r0);
-    for (int rr = wave; rr < nrows; rr += 4) {
-        const int row = group_rows[gd.row_off + r0 + rr];
-        const uint4 qv = *reinterpret_cast<const uint4*>(q + ((size_t)row * H + head) * D + j * 8);
-        float m = -INFINITY, l = 0.f, acc[8] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
-        for (int t = g; t < nk; t += 4) {
-            const uint4 kv = *reinterpret_cast<const uint4*>(&k_lds[t * D + j * 8]);
-            const uint4 vv = *reinterpret_cast<const uint4*>(&v_lds[t * D + j * 8]);
-            float s = dot8(qv, kv);
-            s += __shfl_xor(s, 1); s += __shfl_xor(s, 2); s += __shfl_xor(s, 4); s += __shfl_xor(s, 8);
-            s *= scale;
-            ATT_ONLINE_STEP(s, vv, m, l, acc);
-        }
-#pragma unroll
-        for (int o = 16; o <= 32; o <<= 1) {
-            const float mo = __shfl_xor(m, o), lo_ = __shfl_xor(l, o);
-            const float mn = fmaxf(m, mo);
-            const float c0 = (m == -INFINITY) ? 0.f : __expf(m - mn), c1 = (mo == -INFINITY) ? 0.f : __expf(mo - mn);
-            l = l * c0 + lo_ * c1;
-#pragma unroll
-            for (int e = 0; e < 8; ++e) { const float ao = __shfl_xor(acc[e], o); acc[e] = acc[e] * c0 + ao * c1; }
-            m = mn;
-        }
-        if (g == 0) {
-            float* wsp = ws + (((size_t)row * H + head) * nchunk + chunk) * (D + 2);
-            *reinterpret_cast<float4*>(wsp + j * 8) = make_float4(acc[0], acc[1], acc[2], acc[3]);
-            *reinterpret_cast<float4*>(wsp + j * 8 + 4) = make_float4(acc[4], acc[5], acc[6], acc[7]);
-            if (j == 0) { wsp[D] = m; wsp[D + 1] = l; }
-        }
-    }
-}
 
 // ------------------------------------------------------------------ prefix pass on the matrix cores
 // V of a shared prefix is static during decoding, so a second copy is kept key-blocked and transposed
@@ -856,19 +784,6 @@ __global__ void __launch_bounds__(256, 4) decode_attn_prefix_mfma_kernel(const u
     }
 }
 
-// Weight re-layout for the TILED skinny kernels: out[tile][k/32][g*16 + ln][8] = W[row(tile, ln)][k32*32 + g*8 .. +7], with
-// row = 16 tile + ln, or for swiglu_pairs (W = [Wg; Wu], N = 2F): ln < 8 -> Wg row 8 tile + ln, else Wu row 8 tile + ln - 8.
-__global__ void __launch_bounds__(256) tile_weight_kernel(const uint16_t* __restrict__ W, uint16_t* __restrict__ out, int N, int K,
-                                                          int swiglu_pairs) {
-    const long long i = (long long)blockIdx.x * 256 + threadIdx.x;       // one 16-byte fragment
-    if (i >= (long long)N * K / 8) return;
-    const int lane = (int)(i & 63), ln = lane & 15, g = lane >> 4;
-    const long long c = i >> 6;
-    const int kc = (int)(c % (K / 32));
-    const int tile = (int)(c / (K / 32));
-    const int row = swiglu_pairs ? (ln < 8 ? 8 * tile + ln : N / 2 + 8 * tile + ln - 8) : 16 * tile + ln;
-    reinterpret_cast<uint4*>(out)[i] = *reinterpret_cast<const uint4*>(W + (size_t)row * K + kc * 32 + g * 8);
-}
 
 inline int ok(hipError_t) { return hipGetLastError() == hipSuccess ? VDD_OK : VDD_ERR_LAUNCH; }
 
@@ -929,56 +844,34 @@ int vdd_embed_scatter(const int32_t* ids, const int32_t* rows, const void* table
 }
 
 static int skinny_gemm_launch(const void* X, const void* W, const void* R, void* Y, float* Y_slabs, int n_split, int M, int N, int K,
-                              int64_t ldx, int64_t ldr, int64_t ldy, void* stream, bool tiled) {
+                              int64_t ldx, int64_t ldr, int64_t ldy, void* stream) {
     if (M <= 0 || N <= 0) return VDD_OK;
     if (!X || !W || (!Y && !Y_slabs) || n_split < 1 || K % (128 * n_split) != 0 || M > 64 || (ldx % 8) != 0) return VDD_ERR_INVALID_ARG;
     if (!Y_slabs && n_split != 1) return VDD_ERR_INVALID_ARG;
-    if (tiled && N % 16 != 0) return VDD_ERR_INVALID_ARG;
     hipStream_t st = (hipStream_t)stream;
     dim3 grid((N + 15) / 16, n_split), block(256);
     auto x = (const uint16_t*)X; auto w = (const uint16_t*)W; auto r = (const uint16_t*)R; auto y = (uint16_t*)Y;
-#define VDD_SKINNY(MT, TL) hipLaunchKernelGGL((skinny_gemm_kernel<MT, TL>), grid, block, 0, st, x, w, r, y, Y_slabs, M, N, K, (long long)ldx, (long long)ldr, (long long)ldy)
-    if (tiled) { if (M <= 16) VDD_SKINNY(1, true); else if (M <= 32) VDD_SKINNY(2, true); else VDD_SKINNY(4, true); }
-    else { if (M <= 16) VDD_SKINNY(1, false); else if (M <= 32) VDD_SKINNY(2, false); else VDD_SKINNY(4, false); }
+#define VDD_SKINNY(MT) hipLaunchKernelGGL((skinny_gemm_kernel<MT>), grid, block, 0, st, x, w, r, y, Y_slabs, M, N, K, (long long)ldx, (long long)ldr, (long long)ldy)
+    if (M <= 16) VDD_SKINNY(1); else if (M <= 32) VDD_SKINNY(2); else VDD_SKINNY(4);
 #undef VDD_SKINNY
     return ok(hipSuccess);
 }
 
 int vdd_skinny_gemm(const void* X, const void* W, const void* R, void* Y, float* Y_slabs, int n_split, int M, int N, int K,
                     int64_t ldx, int64_t ldr, int64_t ldy, void* stream) {
-    return skinny_gemm_launch(X, W, R, Y, Y_slabs, n_split, M, N, K, ldx, ldr, ldy, stream, false);
+    return skinny_gemm_launch(X, W, R, Y, Y_slabs, n_split, M, N, K, ldx, ldr, ldy, stream);
 }
 
-int vdd_skinny_gemm_tiled(const void* X, const void* W_tiled, const void* R, void* Y, float* Y_slabs, int n_split, int M, int N, int K,
-                          int64_t ldx, int64_t ldr, int64_t ldy, void* stream) {
-    return skinny_gemm_launch(X, W_tiled, R, Y, Y_slabs, n_split, M, N, K, ldx, ldr, ldy, stream, true);
-}
-
-int vdd_tile_weight(const void* W, void* W_tiled, int N, int K, int swiglu_pairs, void* stream) {
-    if (N <= 0) return VDD_OK;
-    if (!W || !W_tiled || N % 16 != 0 || K % 32 != 0 || (swiglu_pairs && N % 32 != 0)) return VDD_ERR_INVALID_ARG;
-    const long long n = (long long)N * K / 8;
-    hipLaunchKernelGGL(tile_weight_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, (hipStream_t)stream, (const uint16_t*)W,
-                       (uint16_t*)W_tiled, N, K, swiglu_pairs);
-    return ok(hipSuccess);
-}
-
-static int skinny_swiglu_launch(const void* X, const void* W, void* act, int M, int F, int K, int64_t ldx, void* stream, bool tiled) {
+static int skinny_swiglu_launch(const void* X, const void* W, void* act, int M, int F, int K, int64_t ldx, void* stream) {
     if (M <= 0 || F <= 0) return VDD_OK;
-    if (!X || !W || !act || M > 16 || K % 128 != 0 || (ldx % 8) != 0 || (tiled && F % 16 != 0)) return VDD_ERR_INVALID_ARG;
-    if (tiled) hipLaunchKernelGGL(skinny_swiglu_kernel<true>, dim3((F + 7) / 8), dim3(256), 0, (hipStream_t)stream, (const uint16_t*)X,
-                                  (const uint16_t*)W, (uint16_t*)act, M, F, K, (long long)ldx);
-    else hipLaunchKernelGGL(skinny_swiglu_kernel<false>, dim3((F + 7) / 8), dim3(256), 0, (hipStream_t)stream, (const uint16_t*)X,
+    if (!X || !W || !act || M > 16 || K % 128 != 0 || (ldx % 8) != 0) return VDD_ERR_INVALID_ARG;
+    hipLaunchKernelGGL(skinny_swiglu_kernel, dim3((F + 7) / 8), dim3(256), 0, (hipStream_t)stream, (const uint16_t*)X,
                             (const uint16_t*)W, (uint16_t*)act, M, F, K, (long long)ldx);
     return ok(hipSuccess);
 }
 
 int vdd_skinny_swiglu(const void* X, const void* W_gate_up, void* act, int M, int F, int K, int64_t ldx, void* stream) {
-    return skinny_swiglu_launch(X, W_gate_up, act, M, F, K, ldx, stream, false);
-}
-
-int vdd_skinny_swiglu_tiled(const void* X, const void* W_gate_up_tiled, void* act, int M, int F, int K, int64_t ldx, void* stream) {
-    return skinny_swiglu_launch(X, W_gate_up_tiled, act, M, F, K, ldx, stream, true);
+    return skinny_swiglu_launch(X, W_gate_up, act, M, F, K, ldx, stream);
 }
 
 int vdd_decode_attention(const void* q, const void* k_cache, const void* v_cache, const void* k_prefix, const void* v_prefix,
@@ -1019,21 +912,16 @@ int vdd_decode_attention_grouped(const void* q, const void* k_cache, const void*
     if (M <= 0) return VDD_OK;
     if (!q || !k_cache || !v_cache || !k_prefix || !v_prefix || !rows || !groups || !group_rows || !items || !out || !workspace || D != 128 ||
         H % Hkv != 0 || max_own_len <= 0 || max_prefix_len < 0 || n_items < 0 || prefix_chunks_per_item < 1) return VDD_ERR_INVALID_ARG;
-    // the LDS fallback kernel leaves one partial per 64-key chunk; the MFMA kernel one per item of `sub` chunks
-    const int sub = v_prefix_t8 != nullptr ? prefix_chunks_per_item : 1;
-    if (v_prefix_t8 == nullptr && prefix_chunks_per_item != 1) return VDD_ERR_INVALID_ARG;
+    if (n_items > 0 && v_prefix_t8 == nullptr) return VDD_ERR_INVALID_ARG;     // the MFMA prefix pass needs the transposed prefix V
+    const int sub = prefix_chunks_per_item;                                     // it leaves one partial per item of `sub` 64-key chunks
     const int pre_keys = ATT_CH * sub;
     const int npre = (max_prefix_len + pre_keys - 1) / pre_keys, nown = (max_own_len + ATT_CH - 1) / ATT_CH;
     const int nchunk = npre + nown;
     hipStream_t st = (hipStream_t)stream;
-    if (n_items > 0 && npre > 0 && v_prefix_t8 != nullptr) {
+    if (n_items > 0 && npre > 0) {
         hipLaunchKernelGGL(decode_attn_prefix_mfma_kernel<128>, dim3(n_items, (H + 3) / 4), dim3(256), 0, st,
                            (const uint16_t*)q, (const uint16_t*)k_prefix, (const uint16_t*)v_prefix_t8, (const GroupDesc*)groups, group_rows,
                            (const int4*)items, (float*)workspace, H, Hkv, (long long)prefix_stride, prefix_tmax, scale, nchunk, sub);
-    } else if (n_items > 0 && npre > 0) {
-        hipLaunchKernelGGL(decode_attn_prefix_kernel<128>, dim3(n_items, H), dim3(256), 0, st,
-                           (const uint16_t*)q, (const uint16_t*)k_prefix, (const uint16_t*)v_prefix, (const GroupDesc*)groups, group_rows,
-                           (const int4*)items, (float*)workspace, H, Hkv, (long long)prefix_stride, prefix_tmax, scale, nchunk);
     }
     if (max_own_len <= 256) {        // short own ranges: one wave per (row, head) finishes the row (own keys + prefix partials)
         hipLaunchKernelGGL(decode_attn_own_merge_kernel<128>, dim3((H + 3) / 4, M), dim3(256), 0, st, (const uint16_t*)q,

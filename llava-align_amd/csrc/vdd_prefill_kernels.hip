@@ -272,6 +272,53 @@ __global__ void __launch_bounds__(256) bias_act_kernel(const uint16_t* __restric
     }
 }
 
+
+// ------------------------------------------------------------------ ViT front-end glue (clip_encoder.py:39-51 -> HF CLIPVisionEmbeddings)
+// im2col of the stride-P patch convolution: images [n, 3, S, S] (fp32 / fp16 / bf16) -> patches [n * G * G, Kp] bf16, column
+// (c * P + py) * P + px, zero-padded to Kp (the K of the patch-embed GEMM: a multiple of 128).  One block per patch.
+template <typename T>
+__global__ void __launch_bounds__(256) vit_im2col_kernel(const T* __restrict__ img, uint16_t* __restrict__ out, int S, int P, int G, int Kp) {
+    const int patch = blockIdx.x, gi = patch / (G * G), gy = (patch / G) % G, gx = patch % G;
+    const int K = 3 * P * P;
+    const T* base = img + (size_t)gi * 3 * S * S + (size_t)(gy * P) * S + gx * P;
+    for (int col = threadIdx.x; col < Kp; col += 256) {
+        float v = 0.f;
+        if (col < K) {
+            const int c = col / (P * P), r = col - c * P * P, py = r / P, px = r - py * P;
+            v = (float)base[(size_t)c * S * S + (size_t)py * S + px];
+        }
+        out[(size_t)patch * Kp + col] = (uint16_t)f2bf(v);
+    }
+}
+
+// h[i, t, :] = (t == 0 ? cls : emb[i * (T - 1) + t - 1, :]) + pos[t, :]      (class token + position embedding, bf16 add)
+__global__ void __launch_bounds__(256) vit_assemble_kernel(const uint16_t* __restrict__ emb, const uint16_t* __restrict__ cls,
+                                                           const uint16_t* __restrict__ pos, uint16_t* __restrict__ out, int T, int w) {
+    const int row = blockIdx.x, i = row / T, t = row - i * T;
+    const uint16_t* src = t == 0 ? cls : emb + (size_t)(i * (T - 1) + t - 1) * w;
+    for (int e = threadIdx.x * 8; e < w; e += 256 * 8) {
+        const uint4 a = *reinterpret_cast<const uint4*>(src + e), b = *reinterpret_cast<const uint4*>(pos + (size_t)t * w + e);
+        uint4 o;
+        o.x = pack(lo(a.x) + lo(b.x), hi(a.x) + hi(b.x)); o.y = pack(lo(a.y) + lo(b.y), hi(a.y) + hi(b.y));
+        o.z = pack(lo(a.z) + lo(b.z), hi(a.z) + hi(b.z)); o.w = pack(lo(a.w) + lo(b.w), hi(a.w) + hi(b.w));
+        *reinterpret_cast<uint4*>(out + (size_t)row * w + e) = o;
+    }
+}
+
+// qkv [n * T, 3, H, D] (one fused projection) -> q [n * T, H * D] and the K / V caches [slot = image][H][t][D] the attention reads
+__global__ void __launch_bounds__(256) vit_qkv_split_kernel(const uint16_t* __restrict__ qkv, uint16_t* __restrict__ q,
+                                                            uint16_t* __restrict__ kc, uint16_t* __restrict__ vc, int T, int H, int D,
+                                                            long long slot_stride, int t_max) {
+    const int row = blockIdx.x, i = row / T, t = row - i * T, hd = H * D;
+    for (int e = threadIdx.x * 8; e < 3 * hd; e += 256 * 8) {
+        const uint4 v = *reinterpret_cast<const uint4*>(qkv + (size_t)row * 3 * hd + e);
+        const int which = e / hd, r = e - which * hd, h = r / D, d = r - h * D;
+        uint16_t* dst = which == 0 ? q + (size_t)row * hd + r
+                                   : (which == 1 ? kc : vc) + (size_t)i * slot_stride + ((size_t)h * t_max + t) * D + d;
+        *reinterpret_cast<uint4*>(dst) = v;
+    }
+}
+
 inline int ok() { return hipGetLastError() == hipSuccess ? VDD_OK : VDD_ERR_LAUNCH; }
 
 }  // namespace
@@ -313,6 +360,36 @@ int vdd_bias_act(const void* x, const void* bias, void* y, int64_t M, int d, int
     int blocks = (int)((n8 + 255) / 256); if (blocks > 4096) blocks = 4096;
     hipLaunchKernelGGL(bias_act_kernel, dim3(blocks), dim3(256), 0, (hipStream_t)stream, (const uint16_t*)x, (const uint16_t*)bias,
                        (uint16_t*)y, (long long)M, d, act);
+    return ok();
+}
+
+int vdd_vit_im2col(const void* images, int dtype, void* patches, int n, int S, int P, int Kp, void* stream) {
+    if (n <= 0) return VDD_OK;
+    if (!images || !patches || P <= 0 || S % P != 0 || Kp < 3 * P * P) return VDD_ERR_INVALID_ARG;
+    const int G = S / P;
+    const dim3 grid(n * G * G), block(256);
+    hipStream_t st = (hipStream_t)stream;
+    if (dtype == VDD_F32) hipLaunchKernelGGL(vit_im2col_kernel<float>, grid, block, 0, st, (const float*)images, (uint16_t*)patches, S, P, G, Kp);
+    else if (dtype == VDD_F16) hipLaunchKernelGGL(vit_im2col_kernel<_Float16>, grid, block, 0, st, (const _Float16*)images, (uint16_t*)patches, S, P, G, Kp);
+    else if (dtype == VDD_BF16) hipLaunchKernelGGL(vit_im2col_kernel<__bf16>, grid, block, 0, st, (const __bf16*)images, (uint16_t*)patches, S, P, G, Kp);
+    else return VDD_ERR_INVALID_ARG;
+    return ok();
+}
+
+int vdd_vit_assemble(const void* emb, const void* cls, const void* pos, void* out, int n, int T, int width, void* stream) {
+    if (n <= 0) return VDD_OK;
+    if (!emb || !cls || !pos || !out || width % 8 != 0 || T < 2) return VDD_ERR_INVALID_ARG;
+    hipLaunchKernelGGL(vit_assemble_kernel, dim3(n * T), dim3(256), 0, (hipStream_t)stream, (const uint16_t*)emb, (const uint16_t*)cls,
+                       (const uint16_t*)pos, (uint16_t*)out, T, width);
+    return ok();
+}
+
+int vdd_vit_qkv_split(const void* qkv, void* q, void* k_cache, void* v_cache, int n, int T, int H, int D, int64_t slot_stride, int t_max,
+                      void* stream) {
+    if (n <= 0) return VDD_OK;
+    if (!qkv || !q || !k_cache || !v_cache || D % 8 != 0 || T > t_max) return VDD_ERR_INVALID_ARG;
+    hipLaunchKernelGGL(vit_qkv_split_kernel, dim3(n * T), dim3(256), 0, (hipStream_t)stream, (const uint16_t*)qkv, (uint16_t*)q,
+                       (uint16_t*)k_cache, (uint16_t*)v_cache, T, H, D, (long long)slot_stride, t_max);
     return ok();
 }
 

@@ -20,8 +20,8 @@ Reference-compat details: <unk> is ONE token (#3), so image-free
 575 positions shorter; the VCD branch (images_cd) contributes its own logits at step 0 only and
 c == v afterwards (#1); use_dd alone or with use_dd_unk adds the image-token-dropped branch.
 
-Every compute op is a hand-written HIP kernel (ops.py) except the large-M prefill GEMMs, which
-go to hipBLASLt through torch.matmul (a plain library GEMM).  bf16 storage, fp32 accumulation.
+Every compute op is a hand-written HIP kernel (ops.py), the GEMMs included (csrc/vdd_gemm.hip above 8 rows,
+the weight-streaming GEMV kernels below).  bf16 storage, fp32 accumulation.
 """
 from __future__ import annotations
 
@@ -133,10 +133,10 @@ class LlavaWeights:
         w.t["norm"] = ones(lm.d)
         w.t["lm_head"] = rnd(lm.vocab, lm.d)
         pd = 3 * v.patch * v.patch
-        pd_pad = (pd + 7) // 8 * 8
+        pd_pad = (pd + 127) // 128 * 128                         # K of the patch-embed GEMM: a multiple of its 128-deep unit
         pw = torch.zeros(v.width, pd_pad, dtype=torch.bfloat16, device=device)
         pw[:, :pd] = rnd(v.width, pd)
-        w.t["v.patch"] = pw                                      # conv14x14/stride14 as a [width, 588(+pad)] GEMM
+        w.t["v.patch"] = pw                                      # conv14x14/stride14 as a [width, 588 -> 640] GEMM
         w.t["v.cls"], w.t["v.pos"] = rnd(v.width), rnd(v.n_patches + 1, v.width)
         w.t["v.pre_ln.w"], w.t["v.pre_ln.b"] = ones(v.width), rnd(v.width)
         for i in range(v.run_layers):
@@ -185,7 +185,7 @@ class LlavaWeights:
         if vp is None:
             raise KeyError("no CLIP vision tower found in the state dict (looked for *embeddings.patch_embedding.weight)")
         pw = get(vs, vp + "embeddings.patch_embedding.weight").reshape(v.width, -1)        # [width, 3, P, P] -> [width, 3*P*P]
-        pd_pad = (pw.shape[1] + 7) // 8 * 8
+        pd_pad = (pw.shape[1] + 127) // 128 * 128
         w.t["v.patch"] = torch.nn.functional.pad(pw, (0, pd_pad - pw.shape[1])).contiguous()
         w.t["v.cls"] = get(vs, vp + "embeddings.class_embedding")
         w.t["v.pos"] = get(vs, vp + "embeddings.position_embedding.weight")
@@ -288,37 +288,36 @@ class VisionTower:
 
     @torch.no_grad()
     def _forward(self, images: torch.Tensor) -> torch.Tensor:
+        """Every op is a kernel of this package: im2col -> patch-embed GEMM -> class token + positions -> pre-LN -> layers
+        (LN, qkv GEMM + bias, split into the attention's q / K / V layout, flash attention, o-proj GEMM + bias + residual, LN,
+        fc1 GEMM + bias + quick-GELU, fc2 GEMM + bias + residual) -> projector GEMMs (+ bias + GELU, + bias)."""
         v, t = self.cfg, self.w.t
         n = images.shape[0]
         dev = self.w.device
-        x = images.to(device=dev, dtype=torch.bfloat16)
-        P, G = v.patch, v.image // v.patch
-        patches = x.view(n, 3, G, P, G, P).permute(0, 2, 4, 1, 3, 5).reshape(n * G * G, 3 * P * P)   # im2col of the stride-14 conv
-        pd_pad = t["v.patch"].shape[1]
-        if pd_pad != patches.shape[1]:
-            patches = torch.nn.functional.pad(patches, (0, pd_pad - patches.shape[1]))
-        emb = torch.matmul(patches, t["v.patch"].t()).view(n, G * G, v.width)                       # patch-embed GEMM (hipBLASLt)
-        h = torch.cat([t["v.cls"].view(1, 1, -1).expand(n, 1, -1), emb], dim=1) + t["v.pos"][None]
+        x = images.to(device=dev)
+        if x.dtype not in (torch.float32, torch.float16, torch.bfloat16):
+            x = x.float()
         T, H, D = self.T, v.heads, v.width // v.heads
-        h = ops.layernorm(h.reshape(n * T, v.width).contiguous(), t["v.pre_ln.w"], t["v.pre_ln.b"], v.eps)
+        patches = ops.vit_im2col(x.contiguous(), v.patch, t["v.patch"].shape[1])          # [n * 576, 640] bf16
+        emb = ops.gemm(patches, t["v.patch"])                                              # CLIP's patch conv has no bias
+        h = ops.vit_assemble(emb, t["v.cls"], t["v.pos"], n, T)
+        h = ops.layernorm(h, t["v.pre_ln.w"], t["v.pre_ln.b"], v.eps)
         kc, vc = self._kv_cache(n)
         seqs = self._seqs(n)
         for i in range(v.run_layers):
             p = f"v{i}."
             a = ops.layernorm(h, t[p + "ln1.w"], t[p + "ln1.b"], v.eps)
-            qkv = ops.bias_act(torch.matmul(a, t[p + "wqkv"].t()), t[p + "bqkv"]).view(n, T, 3, H, D)
-            kc[:n].copy_(qkv[:, :, 1].permute(0, 2, 1, 3))
-            vc[:n].copy_(qkv[:, :, 2].permute(0, 2, 1, 3))
-            q = qkv[:, :, 0].reshape(n * T, H * D)
-            att = ops.flash_attention(q.contiguous(), kc, vc, seqs, n, T, H, H, D, causal=False)
-            h = h + ops.bias_act(torch.matmul(att, t[p + "wo"].t()), t[p + "bo"])
+            qkv = ops.gemm(a, t[p + "wqkv"], bias=t[p + "bqkv"], epi=ops.EPI_BIAS)
+            q = ops.vit_qkv_split(qkv, kc, vc, n, T, H, D)
+            att = ops.flash_attention(q, kc, vc, seqs, n, T, H, H, D, causal=False)
+            h = ops.gemm(att, t[p + "wo"], bias=t[p + "bo"], resid=h, epi=ops.EPI_BIAS_RESID)
             a = ops.layernorm(h, t[p + "ln2.w"], t[p + "ln2.b"], v.eps)
-            f = ops.bias_act(torch.matmul(a, t[p + "fc1"].t()), t[p + "b1"], ops.ACT_QUICK_GELU)
-            h = h + ops.bias_act(torch.matmul(f, t[p + "fc2"].t()), t[p + "b2"])
-        feat = h.view(n, T, v.width)[:, 1:].reshape(n * (T - 1), v.width)                            # drop CLS ('patch')
-        z = ops.bias_act(torch.matmul(feat, t["mm.w1"].t()), t["mm.b1"], ops.ACT_GELU)
-        z = ops.bias_act(torch.matmul(z, t["mm.w2"].t()), t["mm.b2"])
-        return z.view(n, T - 1, -1)
+            f = ops.gemm(a, t[p + "fc1"], bias=t[p + "b1"], epi=ops.EPI_BIAS_QUICK_GELU)
+            h = ops.gemm(f, t[p + "fc2"], bias=t[p + "b2"], resid=h, epi=ops.EPI_BIAS_RESID)
+        # the projector runs on all T rows (the class row is 1 of 577) and the class row is dropped by a VIEW ('patch', clip_encoder.py:33-37)
+        z = ops.gemm(h, t["mm.w1"], bias=t["mm.b1"], epi=ops.EPI_BIAS_GELU)
+        z = ops.gemm(z, t["mm.w2"], bias=t["mm.b2"], epi=ops.EPI_BIAS)
+        return z.view(n, T, -1)[:, 1:]
 
 
 # ------------------------------------------------------------------ language model
@@ -397,9 +396,7 @@ class LanguageModel:
             new_resid = torch.empty_like(resid) if delta is not None else None
             a = ops.rmsnorm(resid, t[p + "ln1"], c.eps, delta=delta, resid_out=new_resid)
             resid = new_resid if new_resid is not None else resid
-            qkv = ops.linear(a, t[p + "wqkv"])
-            if c.qkv_bias:
-                ops.bias_act(qkv, t[p + "bqkv_lm"], out=qkv)
+            qkv = ops.linear(a, t[p + "wqkv"], bias=t[p + "bqkv_lm"] if c.qkv_bias else None)
             kw_, vw_ = (kv.kp[i], kv.vp[i]) if to_prefix_pool else (kv.ko[i], kv.vo[i])
             q = ops.rope_kv_write(qkv, pos, slot, self.cs, kw_, vw_, H, Hkv, D, cpos=cpos)
             if final and last_rows is None:
@@ -413,7 +410,7 @@ class LanguageModel:
             new_resid = torch.empty_like(resid)
             a = ops.rmsnorm(resid, t[p + "ln2"], c.eps, delta=o, resid_out=new_resid)
             resid = new_resid
-            delta = ops.linear(ops.silu_mul(ops.linear(a, t[p + "wgu"])), t[p + "wd"])
+            delta = ops.linear(ops.swiglu_linear(a, t[p + "wgu"]), t[p + "wd"])
         return resid, delta
 
     @torch.no_grad()
@@ -441,9 +438,7 @@ class LanguageModel:
                 a = ops.rmsnorm(resid, t[p + "ln1"], c.eps)
             else:
                 a = ops.rmsnorm(resid, t[p + "ln1"], c.eps, delta=delta, resid_out=resid)
-            qkv = ops.linear(a, t[p + "wqkv"])
-            if c.qkv_bias:
-                ops.bias_act(qkv, t[p + "bqkv_lm"], out=qkv)
+            qkv = ops.linear(a, t[p + "wqkv"], bias=t[p + "bqkv_lm"] if c.qkv_bias else None)
             if grouping is None and tokens.shape[0] <= ops.FUSED_ATTN_MAX_M and D == 128:
                 # a few rows (one question in flight): RoPE + KV write + attention + merge in one launch
                 att = ops.decode_attention_fused(qkv, pos, cpos, slot, self.cs, kv.ko[i], kv.vo[i], attn_rows, H, Hkv, D,

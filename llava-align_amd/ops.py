@@ -13,23 +13,23 @@ from . import _lib
 _P, _I, _L, _F = C.c_void_p, C.c_int, C.c_int64, C.c_float
 _SIGS = {
     "vdd_embed_scatter": [_P, _P, _P, _P, _I, _I, _P],
-    "vdd_tile_weight": [_P, _P, _I, _I, _I, _P],
-    "vdd_skinny_swiglu_tiled": [_P, _P, _P, _I, _I, _I, _L, _P],
     "vdd_skinny_swiglu": [_P, _P, _P, _I, _I, _I, _L, _P],
     "vdd_decode_attention_fused": [_P] * 11 + [_I, _I, _I, _I, _L, _I, _L, _I, _F, _P],
     "vdd_rmsnorm": [_P, _P, _P, _I, _P, _P, _P, _I, _I, _F, _P],
-    "vdd_mid_gemm": [_P, _P, _P, _P, _I, _I, _I, _L, _L, _I, _P],
+    "vdd_gemm": [_P, _P, _P, _P, _P, _I, _I, _I, _L, _L, _L, _L, _I, _I, _P, _L, _P],
     "vdd_rope_kv_write": [_P, _P, _P, _P, _P, _P, _P, _P, _I, _I, _I, _I, _L, _I, _P],
     "vdd_silu_mul": [_P, _P, _L, _I, _P],
     "vdd_embed": [_P, _P, _P, _I, _I, _P],
     "vdd_skinny_gemm": [_P, _P, _P, _P, _P, _I, _I, _I, _I, _L, _L, _L, _P],
-    "vdd_skinny_gemm_tiled": [_P, _P, _P, _P, _P, _I, _I, _I, _I, _L, _L, _L, _P],
     "vdd_decode_attention": [_P, _P, _P, _P, _P, _P, _P, _P, _I, _I, _I, _I, _L, _I, _L, _I, _I, _F, _P],
     "vdd_prefix_v_transpose": [_P, _P, _P, _I, _I, _I, _I, _P],
     "vdd_decode_attention_grouped": [_P, _P, _P, _P, _P, _P, _P, _P, _P, _P, _I, _P, _P, _I, _I, _I, _I, _L, _I, _L, _I, _I, _I, _I, _F, _P],
     "vdd_flash_attention": [_P, _P, _P, _P, _P, _P, _P, _I, _I, _I, _I, _I, _L, _I, _L, _I, _F, _I, _P],
     "vdd_layernorm": [_P, _P, _P, _P, _I, _I, _F, _P],
     "vdd_bias_act": [_P, _P, _P, _L, _I, _I, _P],
+    "vdd_vit_im2col": [_P, _I, _P, _I, _I, _I, _I, _P],
+    "vdd_vit_assemble": [_P, _P, _P, _P, _I, _I, _I, _P],
+    "vdd_vit_qkv_split": [_P, _P, _P, _P, _I, _I, _I, _I, _L, _I, _P],
 }
 _bound = False
 
@@ -58,7 +58,7 @@ def _bf16(*ts):
 
 def rmsnorm(x, w, eps, delta=None, resid_out=None, out=None):
     """h = x (+ delta); resid_out <- h; returns h * rsqrt(mean h^2 + eps) * w.   x: [M, d].
-    delta: bf16 [M, d], or fp32 [S, M, d] split-K slabs from mid_gemm(..., n_split=S)."""
+    delta: bf16 [M, d], or fp32 [S, M, d] split-K slabs from skinny_gemm(..., n_split=S, slabs=True)."""
     _bf16(x, w, resid_out)
     M, d = x.shape
     out = torch.empty_like(x) if out is None else out
@@ -74,21 +74,6 @@ def rmsnorm(x, w, eps, delta=None, resid_out=None, out=None):
             dptr = delta.data_ptr()
     _lib.check(_lib_ready().vdd_rmsnorm(x.data_ptr(), dptr, sptr, ns, w.data_ptr(), out.data_ptr(),
                                         resid_out.data_ptr() if resid_out is not None else None, M, d, eps, _st(x)))
-    return out
-
-
-def mid_gemm(x, w, n_split=1, slabs=False, out=None):
-    """x [9..256 rows, K] @ w[N, K]^T: weight-streaming MFMA kernel for the decode regime.  slabs=True returns the fp32
-    split-K partials [n_split, M, N] (feed them to rmsnorm as `delta`); otherwise bf16 [M, N]."""
-    _bf16(x, w)
-    M, K = x.shape
-    N = w.shape[0]
-    if slabs:
-        out = torch.empty(n_split, M, N, dtype=torch.float32, device=x.device) if out is None else out
-        _lib.check(_lib_ready().vdd_mid_gemm(x.data_ptr(), w.data_ptr(), None, out.data_ptr(), M, N, K, x.stride(0), N, n_split, _st(x)))
-    else:
-        out = torch.empty(M, N, dtype=x.dtype, device=x.device) if out is None else out
-        _lib.check(_lib_ready().vdd_mid_gemm(x.data_ptr(), w.data_ptr(), out.data_ptr(), None, M, N, K, x.stride(0), out.stride(0), 1, _st(x)))
     return out
 
 
@@ -130,32 +115,11 @@ def embed_scatter(ids, rows, table, out):
     return out
 
 
-class TiledWeight:
-    """A static [N, K] weight re-laid out by vdd_tile_weight for the skinny kernels (one contiguous KiB per wave load)."""
-
-    def __init__(self, w, swiglu_pairs=False):
-        _bf16(w)
-        N, K = w.shape
-        self.shape, self.swiglu_pairs = (N, K), bool(swiglu_pairs)
-        self.data = torch.empty_like(w)
-        _lib.check(_lib_ready().vdd_tile_weight(w.data_ptr(), self.data.data_ptr(), N, K, int(self.swiglu_pairs), _st(w)))
-
-    @staticmethod
-    def supports(w, swiglu_pairs=False):
-        return w.shape[0] % (32 if swiglu_pairs else 16) == 0 and w.shape[1] % 128 == 0
-
-
 def skinny_gemm(x, w, resid=None, out=None, n_split=1, slabs=False):
-    """x [M<=64, K] @ w[N, K]^T (+ resid [M, N]) -> [M, N]; streams w from HBM exactly once.  w: tensor or TiledWeight.
+    """x [M<=64, K] @ w[N, K]^T (+ resid [M, N]) -> [M, N]; streams w from HBM exactly once.
     slabs=True: returns the fp32 split-K partials [n_split, M, N] instead (feed them to rmsnorm as `delta`)."""
-    tiled = isinstance(w, TiledWeight)
-    if tiled:
-        assert not w.swiglu_pairs
-        N = w.shape[0]
-        fn, w = _lib_ready().vdd_skinny_gemm_tiled, w.data
-    else:
-        N = w.shape[0]
-        fn = _lib_ready().vdd_skinny_gemm
+    N = w.shape[0]
+    fn = _lib_ready().vdd_skinny_gemm
     _bf16(x, w, resid)
     M, K = x.shape
     if slabs:
@@ -164,8 +128,8 @@ def skinny_gemm(x, w, resid=None, out=None, n_split=1, slabs=False):
         return out
     out = torch.empty(M, N, dtype=x.dtype, device=x.device) if out is None else out
     _lib.check(fn(x.data_ptr(), w.data_ptr(), resid.data_ptr() if resid is not None else None,
-                                            out.data_ptr(), None, 1, M, N, K, x.stride(0), resid.stride(0) if resid is not None else 0,
-                                            out.stride(0), _st(x)))
+                  out.data_ptr(), None, 1, M, N, K, x.stride(0), resid.stride(0) if resid is not None else 0,
+                  out.stride(0), _st(x)))
     return out
 
 
@@ -180,41 +144,106 @@ def linear_to_norm(x, w):
     return linear(x, w)
 
 
-SKINNY_MAX_M = 8      # measured on MI355X (tools/e2e_probe.py): 5.1-5.4 TB/s for M<=4 vs 4.0-5.0 for the library; slower past ~8 rows
+SKINNY_MAX_M = 8      # measured on MI355X (tools/e2e_probe.py): the weight-streaming GEMV wins up to ~8 rows
+
+# ---- row-batched MFMA GEMM (csrc/vdd_gemm.hip): every projection above SKINNY_MAX_M rows
+EPI_NONE, EPI_BIAS, EPI_BIAS_QUICK_GELU, EPI_BIAS_GELU, EPI_SWIGLU, EPI_BIAS_RESID = range(6)
+GEMM_TUNE_MAX_M = 4096          # shapes up to here (the decode batch, single images) pick their tile shape / schedule by a
+                                # one-off timing run; above, 256 x 256 tiles + the hybrid schedule (tools/gemm_sched.py)
+GEMM_CANDIDATES = [(c, s_) for c in (1, 2, 3, 4, 5) for s_ in (0, 1, 2)]     # (macro tile id, schedule) -> config = c + 16 * s
+GEMM_BATCH_INVARIANT = False    # True: data-parallel schedule only.  Every output element is then accumulated over K in one fixed
+                                # order whatever the macro tile, i.e. a row's result does not depend on which other rows are in the
+                                # batch (stream-K cuts K where the batch shape puts the cut); costs the load balance at decode size
+_gemm_ws = {}
+_gemm_choice = {}
 
 
-MID_MAX_M = 0         # csrc/vdd_mid_gemm.hip is correct (tests) but measured 2.5-4x SLOWER than hipBLASLt for M >= 48 on MI355X
-                      # (tools/gemm_probe2.py: X-tile latency exposed at 1 wave/SIMD); it only wins for split-K N=4096, M <= 32.
-                      # Not dispatched until it is pipelined properly.
+def _gemm_workspace(device, M, N):
+    """Per-device scratch of the persistent GEMM (arrival counters + one fp32 partial tile per workgroup).  The counters
+    must start at zero and every launch leaves them zero, so the buffer is only ever replaced by a larger zeroed one."""
+    lib = _lib_ready()
+    lib.vdd_gemm_workspace_bytes.restype = C.c_int64
+    lib.vdd_gemm_workspace_bytes.argtypes = [_I, _I]
+    need = lib.vdd_gemm_workspace_bytes(int(M), int(N))
+    ws = _gemm_ws.get(device)
+    if ws is None or ws.numel() < need:
+        if torch.cuda.is_current_stream_capturing():
+            raise RuntimeError("the GEMM workspace must exist before a graph capture (run the step once eagerly)")
+        ws = _gemm_ws[device] = torch.zeros(max(need, 1 << 27), dtype=torch.uint8, device=device)
+    return ws
 
 
-def linear(x, w, out=None):
-    """Row-batched projection: hand-written weight-streaming MFMA kernel up to 64 rows (the decode
-    regime), the vendor GEMM library (hipBLASLt via torch.matmul) for the large-M prefill GEMMs."""
+def _gemm_call(x, w, out, bias, resid, M, N, K, epi, config, ws):
+    _lib.check(_lib_ready().vdd_gemm(x.data_ptr(), w.data_ptr(), out.data_ptr(), bias.data_ptr() if bias is not None else None,
+                                     resid.data_ptr() if resid is not None else None, M, N, K, x.stride(0), w.stride(0), out.stride(0),
+                                     resid.stride(0) if resid is not None else 0, epi, config, ws.data_ptr(), ws.numel(), _st(x)))
+
+
+def gemm(x, w, bias=None, resid=None, epi=EPI_NONE, out=None, config=None):
+    """out[M, N] = epilogue(x[M, K] @ w[N, K]^T) on the hand-written MFMA kernel (bf16, fp32 accumulate).  epi=EPI_SWIGLU:
+    w = [Wgate; Wup], N = w.shape[0] // 2.  No library fallback: unsupported shapes raise."""
+    _bf16(x, w, bias, resid)
+    M, K = x.shape
+    N = w.shape[0] // 2 if epi == EPI_SWIGLU else w.shape[0]
+    if K % 128 != 0 or N % 4 != 0 or x.stride(1) != 1 or w.stride(1) != 1:
+        raise ValueError(f"vdd_gemm needs K % 128 == 0, N % 4 == 0 and K-contiguous operands (got M={M} N={N} K={K})")
+    out = torch.empty(M, N, dtype=x.dtype, device=x.device) if out is None else out
+    if M == 0:
+        return out
+    ws = _gemm_workspace(x.device, M, N)
+    if config is None:
+        key = (M if M <= GEMM_TUNE_MAX_M else 0, N, K, epi, GEMM_BATCH_INVARIANT)
+        config = _gemm_choice.get(key)
+        if config is None:
+            config = 1 + 16 if GEMM_BATCH_INVARIANT else 1
+            if M <= GEMM_TUNE_MAX_M and not torch.cuda.is_current_stream_capturing():
+                config = _gemm_tune(x, w, out, bias, resid, M, N, K, epi, ws)
+            _gemm_choice[key] = config
+    _gemm_call(x, w, out, bias, resid, M, N, K, epi, config, ws)
+    return out
+
+
+def _gemm_tune(x, w, out, bias, resid, M, N, K, epi, ws, iters=3):
+    """Times every (tile shape, schedule) candidate on the real operands and keeps the fastest (all write the same result)."""
+    best, best_t = 1, float("inf")
+    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    for c, sch in GEMM_CANDIDATES:
+        if (epi == EPI_SWIGLU and c == 5) or (GEMM_BATCH_INVARIANT and sch != 1):
+            continue
+        cfg = c + 16 * sch
+        _gemm_call(x, w, out, bias, resid, M, N, K, epi, cfg, ws)
+        e0.record()
+        for _ in range(iters):
+            _gemm_call(x, w, out, bias, resid, M, N, K, epi, cfg, ws)
+        e1.record()
+        e1.synchronize()
+        t = e0.elapsed_time(e1)
+        if t < best_t:
+            best, best_t = cfg, t
+    return best
+
+
+def linear(x, w, out=None, bias=None):
+    """Row-batched projection: weight-streaming GEMV kernel up to SKINNY_MAX_M rows, the MFMA GEMM above."""
     if x.shape[0] <= SKINNY_MAX_M and x.shape[1] % 128 == 0:
-        return skinny_gemm(x, w, out=out)
-    if x.shape[0] <= MID_MAX_M and x.shape[1] % 64 == 0:
-        return mid_gemm(x, w, out=out)
-    return torch.matmul(x, w.t(), out=out) if out is not None else torch.matmul(x, w.t())
+        y = skinny_gemm(x, w, out=out)
+        return bias_act(y, bias, out=y) if bias is not None else y
+    return gemm(x, w, bias=bias, epi=EPI_BIAS if bias is not None else EPI_NONE, out=out)
 
 
 def swiglu_linear(x, w_gate_up, out=None):
-    """silu(x Wg^T) * (x Wu^T) with w_gate_up = [Wg; Wu]: one fused weight-streaming launch for a handful of rows,
-    library GEMM + silu_mul otherwise."""
+    """silu(x Wg^T) * (x Wu^T) with w_gate_up = [Wg; Wu]: one launch either way - the fused weight-streaming kernel for a
+    handful of rows, the MFMA GEMM with the SwiGLU epilogue above (no [M, 2F] round trip, no silu_mul launch)."""
     M, K = x.shape
     F = w_gate_up.shape[0] // 2
-    if isinstance(w_gate_up, TiledWeight):
-        assert w_gate_up.swiglu_pairs and M <= 16
-        _bf16(x)
-        out = torch.empty(M, F, dtype=x.dtype, device=x.device) if out is None else out
-        _lib.check(_lib_ready().vdd_skinny_swiglu_tiled(x.data_ptr(), w_gate_up.data.data_ptr(), out.data_ptr(), M, F, K, x.stride(0), _st(x)))
-        return out
     if M <= SKINNY_MAX_M and K % 128 == 0:
         _bf16(x, w_gate_up)
         out = torch.empty(M, F, dtype=x.dtype, device=x.device) if out is None else out
         _lib.check(_lib_ready().vdd_skinny_swiglu(x.data_ptr(), w_gate_up.data_ptr(), out.data_ptr(), M, F, K, x.stride(0), _st(x)))
         return out
-    return silu_mul(linear(x, w_gate_up), out=out)
+    if F % 128 == 0:
+        return gemm(x, w_gate_up, epi=EPI_SWIGLU, out=out)
+    return silu_mul(gemm(x, w_gate_up), out=out)
 
 
 _attn_ws = {}
@@ -359,3 +388,35 @@ def bias_act(x, bias, act=ACT_NONE, out=None):
     out = torch.empty_like(x) if out is None else out
     _lib.check(_lib_ready().vdd_bias_act(x.data_ptr(), bias.data_ptr() if bias is not None else None, out.data_ptr(), M, d, act, _st(x)))
     return out
+
+
+_IMG_DT = {torch.float32: _lib.VDD_F32, torch.float16: _lib.VDD_F16, torch.bfloat16: _lib.VDD_BF16}
+
+
+def vit_im2col(images, patch, k_pad, out=None):
+    """images [n, 3, S, S] (fp32 / fp16 / bf16, device) -> bf16 patches [n * (S/patch)^2, k_pad] (zero padded columns)."""
+    if not images.is_cuda or images.dtype not in _IMG_DT or not images.is_contiguous():
+        raise ValueError("vit_im2col takes a contiguous fp32 / fp16 / bf16 device tensor [n, 3, S, S]")
+    n, _, S, _ = images.shape
+    G = S // patch
+    out = torch.empty(n * G * G, k_pad, dtype=torch.bfloat16, device=images.device) if out is None else out
+    _lib.check(_lib_ready().vdd_vit_im2col(images.data_ptr(), _IMG_DT[images.dtype], out.data_ptr(), n, S, patch, k_pad, _st(images)))
+    return out
+
+
+def vit_assemble(emb, cls, pos, n, T, out=None):
+    """h[i, t] = (cls if t == 0 else emb[i * (T - 1) + t - 1]) + pos[t]  ->  [n * T, width]."""
+    _bf16(emb, cls, pos)
+    w = emb.shape[1]
+    out = torch.empty(n * T, w, dtype=emb.dtype, device=emb.device) if out is None else out
+    _lib.check(_lib_ready().vdd_vit_assemble(emb.data_ptr(), cls.data_ptr(), pos.data_ptr(), out.data_ptr(), n, T, w, _st(emb)))
+    return out
+
+
+def vit_qkv_split(qkv, k_cache, v_cache, n, T, H, D, q_out=None):
+    """qkv [n * T, 3 * H * D] -> q [n * T, H * D]; K / V written to caches [>= n, H, t_max, D]."""
+    _bf16(qkv, k_cache, v_cache)
+    q_out = torch.empty(n * T, H * D, dtype=qkv.dtype, device=qkv.device) if q_out is None else q_out
+    _lib.check(_lib_ready().vdd_vit_qkv_split(qkv.data_ptr(), q_out.data_ptr(), k_cache.data_ptr(), v_cache.data_ptr(), n, T, H, D,
+                                              k_cache.stride(0), k_cache.shape[2], _st(qkv)))
+    return q_out

@@ -114,16 +114,35 @@ def test_generation_matches_reference_semantics(eng, ref, mode, share):
         assert out.stats["prefill_tokens"] < out.stats["unshared_prefill_tokens"]
 
 
-def test_prefix_sharing_is_transparent(eng):
+@pytest.fixture
+def batch_invariant():
+    """Data-parallel GEMM schedule only: a row's projections are then accumulated in one fixed order whatever else is in the
+    batch, so two differently batched runs can be compared token for token (ops.GEMM_BATCH_INVARIANT)."""
+    from llava_align_amd import ops
+    old, ops.GEMM_BATCH_INVARIANT = ops.GEMM_BATCH_INVARIANT, True
+    yield
+    ops.GEMM_BATCH_INVARIANT = old
+
+
+def test_prefix_sharing_is_transparent(eng, batch_invariant):
     ids, imgs = prompts(seed=5)
     kw = dict(images=imgs, cd_alpha=1.0, cd_beta=0.1, temperature=0.5, max_new_tokens=5, cd_greedy=True, output_scores=True,
               use_dd=True, use_dd_unk=True)
     a = eng.generate(ids, share_prefix=True, **kw)
     b = eng.generate(ids, share_prefix=False, **kw)
-    assert torch.equal(a.tokens, b.tokens)
-    for sa, sb in zip(a.scores, b.scores):
-        fin = torch.isfinite(sa) & torch.isfinite(sb)
-        assert (sa[fin].float() - sb[fin].float()).abs().max().item() <= 0.2      # grouped path rounds P to bf16 for the MFMA; x6 contrast gain
+    tol = 0.2                                  # grouped path rounds P to bf16 for the MFMA; x6 contrast gain
+    agree = 0
+    for q in range(len(ids)):                  # attention over [prefix | own] tiles its softmax differently from one segment, so
+        for step, (sa, sb) in enumerate(zip(a.scores, b.scores)):     # the two runs agree to rounding, not bit for bit
+            fin = torch.isfinite(sa[q]) & torch.isfinite(sb[q])
+            assert (sa[q][fin].float() - sb[q][fin].float()).abs().max().item() <= tol, (q, step)
+            top2 = torch.topk(sa[q].float(), 2).values
+            if (top2[0] - top2[1]).item() > 2 * tol:
+                assert a.tokens[q, step] == b.tokens[q, step], (q, step)
+            if a.tokens[q, step] != b.tokens[q, step]:
+                break                          # a near-tie went the other way: different continuations from here on
+            agree += 1
+    assert agree >= 4 * len(ids)               # and they do agree on almost every token
 
 
 def test_vcd_branch_only_counts_at_step_zero(eng, ref):
