@@ -46,6 +46,9 @@ typedef enum vdd_dtype { VDD_F32 = 0, VDD_F16 = 1, VDD_BF16 = 2 } vdd_dtype;
                                             CPU-scalar path); default demotes log_beta to dtype first
                                             (torch-CPU, what the golden vectors pin) */
 #define VDD_TEMP_RECIPROCAL    (1u << 2) /* scores * (1/T) (torch-GPU div-by-scalar) instead of scores / T */
+#define VDD_TOPP_FP32_MASS     (1u << 4) /* top-p by integrating the fp32 softmax mass (equal scores kept or dropped together)
+                                            instead of the reference's model-dtype softmax -> sequential cumsum arithmetic;
+                                            rows keeping more than vdd_topp_exact_max() candidates always take this form */
 #define VDD_NO_SAMPLE          (1u << 3) /* only produce scores_out (used when a Python logits_processor
                                             must run between contrast and warp) */
 
@@ -239,6 +242,9 @@ int vdd_layernorm(const void* x, const void* w, const void* b, void* y, int M, i
 
 /* y = act(x + bias): act 0 none, 1 quick_gelu (CLIP MLP), 2 gelu-erf (mlp2x_gelu projector, builder.py:33-46). */
 int vdd_bias_act(const void* x, const void* bias, void* y, int64_t M, int d, int act, void* hip_stream);
+
+/* Most candidates (finite scores left after top-k) a row may keep for the exact top-p arithmetic. */
+int vdd_topp_exact_max(void);
 
 /* Largest V whose working row stays in LDS; larger V need scores_out or workspace. */
 int vdd_lds_row_capacity(int dtype);

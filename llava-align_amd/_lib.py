@@ -9,7 +9,7 @@ PKG = os.path.dirname(os.path.abspath(__file__))
 ABI_VERSION = 1
 
 VDD_F32, VDD_F16, VDD_BF16 = 0, 1, 2
-PICK_ARGMAX, CUTOFF_F32_SCALAR, TEMP_RECIPROCAL, NO_SAMPLE = 1, 2, 4, 8
+PICK_ARGMAX, CUTOFF_F32_SCALAR, TEMP_RECIPROCAL, NO_SAMPLE, TOPP_FP32_MASS = 1, 2, 4, 8, 16
 ROW_OK, ROW_EMPTY = 0, 1
 
 
@@ -67,6 +67,7 @@ def load_lib():
     lib.vdd_last_error.restype = C.c_char_p
     lib.vdd_lds_row_capacity.argtypes = [C.c_int]
     lib.vdd_lds_row_capacity.restype = C.c_int
+    lib.vdd_topp_exact_max.restype = C.c_int
     lib.vdd_kernel_name.argtypes = [C.c_int, C.c_int]
     lib.vdd_kernel_name.restype = C.c_char_p
     _lib = lib

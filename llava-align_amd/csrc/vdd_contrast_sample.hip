@@ -42,7 +42,7 @@ constexpr int NWAVE = BLOCK / 64;
 constexpr int NCOPY = BLOCK / 256;       // copies of the selection histograms (one per 256 threads)
 constexpr int NREG = 3;                  // chunks per thread held in REGISTERS instead of the LDS row
 constexpr int UNR = 4;                   // chunks in flight per thread per batch
-constexpr int LDS_ROW_BYTES_MAX = 150 * 1024;
+constexpr int LDS_ROW_BYTES_MAX = 140 * 1024;       // + Smem + the top-p candidate list stay inside the CU's 160 KiB
 
 // ------------------------------------------------------------------ dtype traits
 template <int DT> struct Tr;
@@ -131,6 +131,12 @@ struct Smem {
     float cand_x[64];
     int cand_idx[64];
 };
+
+// Exact HF top-p (model-dtype softmax -> sequential cumulative sum in ascending (value, index) order -> cum <= fl(1-p)) needs the
+// candidates as an explicit list: up to TOPP_EXACT_MAX of them (all golden vectors; a row that keeps more after top-k falls
+// back to integrating the fp32 mass by radix selection).  Carved behind Smem only when a launch has top-p on.
+constexpr int TOPP_EXACT_MAX = 1024;
+struct ToppScratch { float gx[TOPP_EXACT_MAX]; int gi[TOPP_EXACT_MAX]; float sp[TOPP_EXACT_MAX]; };
 
 __device__ __forceinline__ float wave_max(float v) {
 #pragma unroll
@@ -380,7 +386,8 @@ __device__ __forceinline__ bool select_mass_key(const Row<DT, L>& R, int nch, fl
 }
 
 template <int DT, bool L>
-__device__ __forceinline__ void mask_below_key(const Row<DT, L>& R, int nch, uint32_t thr_key, int tid) {
+__device__ __forceinline__ void mask_below_key(const Row<DT, L>& R, int nch, uint32_t thr_key, int tid, int thr_idx = 0) {
+    // removes every element below (thr_key, thr_idx) in (value, index) order: thr_idx = 0 is the plain value threshold
     constexpr int EPC = Tr<DT>::EPC;
     for (int ch = tid; ch < nch; ch += BLOCK) {
         uint32_t w[4]; R.get(ch, w);
@@ -388,7 +395,9 @@ __device__ __forceinline__ void mask_below_key(const Row<DT, L>& R, int nch, uin
 #pragma unroll
         for (int j = 0; j < EPC; ++j) {
             uint32_t b = getb<DT>(w, j);
-            if (b != Tr<DT>::NEG_INF && okey<DT>(b) < thr_key) { setb<DT>(w, j, Tr<DT>::NEG_INF); changed = true; }
+            if (b == Tr<DT>::NEG_INF) continue;
+            const uint32_t k = okey<DT>(b);
+            if (k < thr_key || (k == thr_key && ch * EPC + j < thr_idx)) { setb<DT>(w, j, Tr<DT>::NEG_INF); changed = true; }
         }
         if (changed) R.put(ch, w);
     }
@@ -585,7 +594,42 @@ __global__ void __launch_bounds__(BLOCK, 6) vdd_contrast_sample_kernel(KP p) {
                         alive = alive && xv >= vk;
                     }
                 }
-                if (p.use_topp) {                                    // HF TopPLogitsWarper: ascending cumulative mass <= fl(1-p) removed
+                int Tidx = 0;                                        // tie rule of the exact top-p: (value, index) threshold
+                if (p.use_topp && !(p.flags & VDD_TOPP_FP32_MASS)) {
+                    // HF TopPLogitsWarper as torch-CPU computes it: probabilities rounded to the model dtype, summed one by one in
+                    // ascending (value, index) order in fp32 (fp64 for an fp32 model), every partial sum rounded to the model dtype
+                    // and compared with fl(1 - p); the last min_keep of the order are never removed
+                    const unsigned long long am = __ballot(alive);
+                    const int n_alive = __popcll(am);
+                    int pos = 0;
+                    for (int q = 0; q < n; ++q) {
+                        const float xq = __shfl(xv, q); const int iq = __shfl(id, q);
+                        pos += (((am >> q) & 1ull) != 0ull && (xq < xv || (xq == xv && iq < id))) ? 1 : 0;
+                    }
+                    const float e = alive ? expf(xv - m) : 0.f;
+                    const float z = wave_sum(e);
+                    if (alive) sm.cand_x[pos] = rnd<DT>(__fdiv_rn(e, z));       // xv / id are in registers by now
+                    const float thr = rnd<DT>(p.one_minus_p);
+                    int kdrop = 0;
+                    if constexpr (DT == VDD_F32) {
+                        double acc = 0.0;
+                        for (int q = 0; q < n_alive; ++q) { acc += (double)sm.cand_x[q]; if ((float)acc <= thr) kdrop = q + 1; else break; }
+                    } else {
+                        float acc = 0.f;
+                        for (int q = 0; q < n_alive; ++q) { acc += sm.cand_x[q]; if (rnd<DT>(acc) <= thr) kdrop = q + 1; else break; }
+                    }
+                    const int kd = min(kdrop, max(0, n_alive - p.min_keep));
+                    if (kd > 0) {
+                        const bool first_kept = alive && pos == kd;
+                        const float tv = wave_max(first_kept ? xv : -INFINITY);
+                        T = tv;                                      // >= the top-k threshold: top-p works on what top-k kept
+                        int ti = first_kept ? id : 0;
+#pragma unroll
+                        for (int o = 32; o > 0; o >>= 1) ti = max(ti, __shfl_xor(ti, o));
+                        Tidx = ti;
+                        alive = alive && pos >= kd;
+                    }
+                } else if (p.use_topp) {                             // VDD_TOPP_FP32_MASS: cumulative fp32 mass <= fl(1-p) * Z removed, ties together
                     const float e = alive ? __expf(xv - m) : 0.f;
                     const float z = wave_sum(e);
                     const float thr = rnd<DT>(p.one_minus_p) * z;
@@ -609,10 +653,11 @@ __global__ void __launch_bounds__(BLOCK, 6) vdd_contrast_sample_kernel(KP p) {
                     T = fmaxf(T, Tp);
                     alive = alive && xv >= Tp;
                 }
-                if (lane == 0) sm.sel[0] = (T == -INFINITY) ? 0u : okey<DT>(Tr<DT>::from_f(T));
+                if (lane == 0) { sm.sel[0] = (T == -INFINITY) ? 0u : okey<DT>(Tr<DT>::from_f(T)); sm.sel[1] = (unsigned)Tidx; }
             }
             __syncthreads();
             const uint32_t thr_key = sm.sel[0];
+            const int thr_idx = (int)sm.sel[1];
             if (thr_key != 0u) {
                 for (int ch = tid, k = 0; ch < nch; ch += BLOCK, ++k) {
                     if (!flagged(k)) continue;
@@ -621,7 +666,9 @@ __global__ void __launch_bounds__(BLOCK, 6) vdd_contrast_sample_kernel(KP p) {
 #pragma unroll
                     for (int j = 0; j < EPC; ++j) {
                         const uint32_t b = getb<DT>(w, j);
-                        if (b != NINF && okey<DT>(b) < thr_key) { setb<DT>(w, j, NINF); changed = true; }
+                        if (b == NINF) continue;
+                        const uint32_t kk = okey<DT>(b);
+                        if (kk < thr_key || (kk == thr_key && ch * EPC + j < thr_idx)) { setb<DT>(w, j, NINF); changed = true; }
                     }
                     if (changed) R.put(ch, w);
                 }
@@ -703,7 +750,70 @@ __global__ void __launch_bounds__(BLOCK, 6) vdd_contrast_sample_kernel(KP p) {
     }
 
     // ---- top-p (HF TopPLogitsWarper) ----------------------------------------------
-    if (p.use_topp && !row_bad) {
+    bool topp_done = false;
+    if (p.use_topp && !row_bad && !(p.flags & VDD_TOPP_FP32_MASS) &&
+        (p.top_k > 0 ? (p.top_k < p.min_keep ? p.min_keep : p.top_k) <= TOPP_EXACT_MAX : nfin <= TOPP_EXACT_MAX)) {
+        // exact form on an explicit candidate list (what survived top-k), same arithmetic as the single-wave path
+        ToppScratch& ts = *reinterpret_cast<ToppScratch*>(reinterpret_cast<unsigned char*>(&sm) + ((sizeof(Smem) + 15) & ~(size_t)15));
+        if (tid == 0) sm.cand_n = 0u;
+        __syncthreads();
+        for (int ch = tid, k = 0; ch < nch; ch += BLOCK, ++k) {
+            if (!flagged(k)) continue;
+            uint32_t w[4]; R.get(ch, w);
+#pragma unroll
+            for (int j = 0; j < EPC; ++j) {
+                const uint32_t b = getb<DT>(w, j);
+                if (b != NINF) {
+                    const unsigned slot = atomicAdd(&sm.cand_n, 1u);
+                    if (slot < (unsigned)TOPP_EXACT_MAX) { ts.gx[slot] = Tr<DT>::to_f(b); ts.gi[slot] = ch * EPC + j; }
+                }
+            }
+        }
+        __syncthreads();
+        const int n = (int)sm.cand_n;
+        if (n <= TOPP_EXACT_MAX) {                                  // (ties at the top-k threshold can push a row past the bound)
+            float x2[2]; int i2[2], pos2[2]; float e2[2];
+            float zp = 0.f;
+#pragma unroll
+            for (int u = 0; u < 2; ++u) {
+                const int c = tid + u * BLOCK;
+                x2[u] = c < n ? ts.gx[c] : INFINITY; i2[u] = c < n ? ts.gi[c] : 0x7fffffff; pos2[u] = 0;
+                e2[u] = c < n ? expf(x2[u] - m) : 0.f;
+                zp += e2[u];
+            }
+            for (int q = 0; q < n; ++q) {
+                const float xq = ts.gx[q]; const int iq = ts.gi[q];
+#pragma unroll
+                for (int u = 0; u < 2; ++u) pos2[u] += (xq < x2[u] || (xq == x2[u] && iq < i2[u])) ? 1 : 0;
+            }
+            const float z = block_sum(zp, sm, lane, wave);
+#pragma unroll
+            for (int u = 0; u < 2; ++u) if (tid + u * BLOCK < n) ts.sp[pos2[u]] = rnd<DT>(__fdiv_rn(e2[u], z));
+            __syncthreads();
+            if (tid == 0) {
+                const float thr = rnd<DT>(p.one_minus_p);
+                int kdrop = 0;
+                if constexpr (DT == VDD_F32) {
+                    double acc = 0.0;
+                    for (int q = 0; q < n; ++q) { acc += (double)ts.sp[q]; if ((float)acc <= thr) kdrop = q + 1; else break; }
+                } else {
+                    float acc = 0.f;
+                    for (int q = 0; q < n; ++q) { acc += ts.sp[q]; if (rnd<DT>(acc) <= thr) kdrop = q + 1; else break; }
+                }
+                sm.sel[2] = (unsigned)min(kdrop, max(0, n - p.min_keep));
+                sm.sel[0] = 0u; sm.sel[1] = 0u;
+            }
+            __syncthreads();
+            const int kd = (int)sm.sel[2];
+#pragma unroll
+            for (int u = 0; u < 2; ++u)
+                if (kd > 0 && tid + u * BLOCK < n && pos2[u] == kd) { sm.sel[0] = okey<DT>(Tr<DT>::from_f(x2[u])); sm.sel[1] = (unsigned)i2[u]; }
+            __syncthreads();
+            if (kd > 0) mask_below_key<DT, LDSROW>(R, nch, sm.sel[0], tid, (int)sm.sel[1]);
+            topp_done = true;
+        }
+    }
+    if (p.use_topp && !row_bad && !topp_done) {                     // more candidates than the list holds (or VDD_TOPP_FP32_MASS):
         float z = 0.f;
         for (int ch = tid, k = 0; ch < nch; ch += BLOCK, ++k) {
             if (!(k >= 64 || ((livemask >> k) & 1ull) != 0ull)) continue;
@@ -897,6 +1007,8 @@ int vdd_lds_row_capacity(int dtype) {
     return (kl_max + NREG) * BLOCK * epc;
 }
 
+int vdd_topp_exact_max(void) { return TOPP_EXACT_MAX; }
+
 const char* vdd_kernel_name(int dtype, int V) {
     (void)dtype; (void)V;
     return "vdd_contrast_sample_kernel";
@@ -955,7 +1067,7 @@ int vdd_contrast_sample(const vdd_sample_params* p, void* hip_stream) {
         else return fail(VDD_ERR_INVALID_ARG, "V exceeds vdd_lds_row_capacity(dtype): pass scores_out or workspace [B,V]");
         kp.vec_work = al(kp.work, kp.sw);
     }
-    const size_t lds = sizeof(Smem) + (ldsrow ? row_bytes : 0);
+    const size_t lds = ((sizeof(Smem) + 15) & ~(size_t)15) + (kp.use_topp ? sizeof(ToppScratch) : 0) + (ldsrow ? row_bytes : 0);
     hipStream_t st = (hipStream_t)hip_stream;
     int rc;
     switch (p->dtype) {

@@ -82,6 +82,7 @@ def contrast_sample(logits_v: torch.Tensor, logits_cd: Optional[torch.Tensor] = 
                     out_tokens: Optional[torch.Tensor] = None, return_scores: bool = False,
                     out_scores: Optional[torch.Tensor] = None, n_top: int = 0, pick_argmax: bool = False,
                     no_sample: bool = False, cutoff_f32_scalar: bool = False, temp_reciprocal: bool = False,
+                    topp_fp32_mass: bool = False,
                     workspace: Optional[torch.Tensor] = None, stream: Optional[int] = None,
                     offset_ptr: Optional[torch.Tensor] = None, status_out: Optional[torch.Tensor] = None) -> SampleOutput:
     """Fused contrastive sampling tail on [B, V] last-position logits (any row stride).
@@ -101,7 +102,8 @@ def contrast_sample(logits_v: torch.Tensor, logits_cd: Optional[torch.Tensor] = 
     prm = _lib.VddSampleParams()
     prm.abi_version = _lib.ABI_VERSION
     prm.flags = ((_lib.PICK_ARGMAX if pick_argmax else 0) | (_lib.CUTOFF_F32_SCALAR if cutoff_f32_scalar else 0)
-                 | (_lib.TEMP_RECIPROCAL if temp_reciprocal else 0) | (_lib.NO_SAMPLE if no_sample else 0))
+                 | (_lib.TEMP_RECIPROCAL if temp_reciprocal else 0) | (_lib.NO_SAMPLE if no_sample else 0)
+                 | (_lib.TOPP_FP32_MASS if topp_fp32_mass else 0))
     prm.logit_v, prm.stride_v = v.data_ptr(), v.stride(0)
     keep = [v]
     if logits_cd is not None:
