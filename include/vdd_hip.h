@@ -132,12 +132,12 @@ int vdd_rope_kv_write(const void* qkv, const int* pos, const int* cpos, const in
 /* out[m, f] = silu(gate_up[m, f]) * gate_up[m, F + f]. */
 int vdd_silu_mul(const void* gate_up, void* out, int64_t M, int F, void* hip_stream);
 
-int vdd_embed(const int64_t* ids, const void* table, void* out, int M, int d, void* hip_stream);
+int vdd_embed(const int64_t* ids, const void* table, void* out, int M, int d, int vocab, void* hip_stream);
 
 /* Token-embedding gather written straight into the packed prefill matrix: out[rows[m], :] = table[ids[m], :] (int32 ids and
  * rows; the splice of llava_arch.py:122-163 - text chunks embedded around the image features - without an intermediate
  * [M, d] tensor and an index_put). */
-int vdd_embed_scatter(const int32_t* ids, const int32_t* rows, const void* table, void* out, int M, int d, void* hip_stream);
+int vdd_embed_scatter(const int32_t* ids, const int32_t* rows, const void* table, void* out, int M, int d, int vocab, void* hip_stream);
 
 /* Y[M,N] = X[M,K] W[N,K]^T (+ R[M,N]); M <= 64, K % (128 * n_split) == 0; W is read from HBM exactly once.
  * n_split > 1 (with Y_slabs fp32 [n_split][M][N], Y may be NULL): split-K across blocks too, for projections whose N alone

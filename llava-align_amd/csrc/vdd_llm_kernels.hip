@@ -196,17 +196,21 @@ __global__ void __launch_bounds__(256) silu_mul_kernel(const uint16_t* __restric
 }
 
 // ------------------------------------------------------------------ embedding gather
+// ids outside [0, vocab) read row 0 instead of wild memory: a row whose distribution had no finite score gets token -1
+// from the sampling kernel (its status is what the host raises on), and the captured decode step embeds it before any check
 __global__ void __launch_bounds__(256) embed_kernel(const long long* __restrict__ ids, const uint16_t* __restrict__ table,
-                                                    uint16_t* __restrict__ out, int d) {
+                                                    uint16_t* __restrict__ out, int d, int vocab) {
     const int row = blockIdx.x;
-    const long long id = ids[row];
+    long long id = ids[row];
+    if (id < 0 || id >= vocab) id = 0;
     for (int e = threadIdx.x * 8; e < d; e += 256 * 8)
         *reinterpret_cast<uint4*>(out + (size_t)row * d + e) = *reinterpret_cast<const uint4*>(table + (size_t)id * d + e);
 }
 
 __global__ void __launch_bounds__(256) embed_scatter_kernel(const int* __restrict__ ids, const int* __restrict__ rows,
-                                                            const uint16_t* __restrict__ table, uint16_t* __restrict__ out, int d) {
-    const long long id = ids[blockIdx.x];
+                                                            const uint16_t* __restrict__ table, uint16_t* __restrict__ out, int d, int vocab) {
+    long long id = ids[blockIdx.x];
+    if (id < 0 || id >= vocab) id = 0;
     const size_t row = (size_t)rows[blockIdx.x];
     for (int e = threadIdx.x * 8; e < d; e += 256 * 8)
         *reinterpret_cast<uint4*>(out + row * d + e) = *reinterpret_cast<const uint4*>(table + (size_t)id * d + e);
@@ -829,17 +833,17 @@ int vdd_silu_mul(const void* gate_up, void* out, int64_t M, int F, void* stream)
     return ok(hipSuccess);
 }
 
-int vdd_embed(const int64_t* ids, const void* table, void* out, int M, int d, void* stream) {
+int vdd_embed(const int64_t* ids, const void* table, void* out, int M, int d, int vocab, void* stream) {
     if (M <= 0) return VDD_OK;
-    if (!ids || !table || !out || d % 8 != 0) return VDD_ERR_INVALID_ARG;
-    hipLaunchKernelGGL(embed_kernel, dim3(M), dim3(256), 0, (hipStream_t)stream, (const long long*)ids, (const uint16_t*)table, (uint16_t*)out, d);
+    if (!ids || !table || !out || d % 8 != 0 || vocab <= 0) return VDD_ERR_INVALID_ARG;
+    hipLaunchKernelGGL(embed_kernel, dim3(M), dim3(256), 0, (hipStream_t)stream, (const long long*)ids, (const uint16_t*)table, (uint16_t*)out, d, vocab);
     return ok(hipSuccess);
 }
 
-int vdd_embed_scatter(const int32_t* ids, const int32_t* rows, const void* table, void* out, int M, int d, void* stream) {
+int vdd_embed_scatter(const int32_t* ids, const int32_t* rows, const void* table, void* out, int M, int d, int vocab, void* stream) {
     if (M <= 0) return VDD_OK;
-    if (!ids || !rows || !table || !out || d % 8 != 0) return VDD_ERR_INVALID_ARG;
-    hipLaunchKernelGGL(embed_scatter_kernel, dim3(M), dim3(256), 0, (hipStream_t)stream, ids, rows, (const uint16_t*)table, (uint16_t*)out, d);
+    if (!ids || !rows || !table || !out || d % 8 != 0 || vocab <= 0) return VDD_ERR_INVALID_ARG;
+    hipLaunchKernelGGL(embed_scatter_kernel, dim3(M), dim3(256), 0, (hipStream_t)stream, ids, rows, (const uint16_t*)table, (uint16_t*)out, d, vocab);
     return ok(hipSuccess);
 }
 

@@ -109,7 +109,10 @@ class LlavaWeights:
         self.t: Dict[str, torch.Tensor] = {}
 
     @staticmethod
-    def random(cfg: LlavaConfig, device, seed: int = 0, std: float = 0.02) -> "LlavaWeights":
+    def random(cfg: LlavaConfig, device, seed: int = 0, std: float = 0.02, lm_head_gain: float = 1.0) -> "LlavaWeights":
+        """lm_head_gain scales the output projection: N(0, 0.02) everywhere gives logits of sigma ~ 1.3 (d = 4096), so flat that
+        the plausibility mask of a contrastive step keeps ~1000 tokens; a trained LLaVA answers POPE with a few candidates.
+        gain 4 (sigma ~ 5) puts a random model in that regime (benchmarks use it; parity tests keep 1)."""
         w = LlavaWeights(cfg, device)
         g = torch.Generator(device=device).manual_seed(seed)
 
@@ -131,7 +134,7 @@ class LlavaWeights:
             w.t[p + "wgu"] = rnd(2 * lm.ffn, lm.d)
             w.t[p + "wd"] = rnd(lm.d, lm.ffn)
         w.t["norm"] = ones(lm.d)
-        w.t["lm_head"] = rnd(lm.vocab, lm.d)
+        w.t["lm_head"] = rnd(lm.vocab, lm.d, s=std * lm_head_gain)
         pd = 3 * v.patch * v.patch
         pd_pad = (pd + 127) // 128 * 128                         # K of the patch-embed GEMM: a multiple of its 128-deep unit
         pw = torch.zeros(v.width, pd_pad, dtype=torch.bfloat16, device=device)
@@ -606,10 +609,10 @@ class VddLlavaEngine:
     """model.generate()-compatible surface (llava_calibrate.py:161-177) over the native kernels."""
 
     def __init__(self, cfg: LlavaConfig | str = "llava-1.5-7b", weights: Optional[LlavaWeights] = None, device="cuda:0",
-                 seed: int = 0, max_questions: int = 64, t_max: int = 0, use_graph: bool = True):
+                 seed: int = 0, max_questions: int = 64, t_max: int = 0, use_graph: bool = True, lm_head_gain: float = 1.0):
         self.cfg = preset(cfg) if isinstance(cfg, str) else cfg
         self.device = torch.device(device)
-        self.w = weights if weights is not None else LlavaWeights.random(self.cfg, self.device, seed)
+        self.w = weights if weights is not None else LlavaWeights.random(self.cfg, self.device, seed, lm_head_gain=lm_head_gain)
         self.vit = VisionTower(self.w)
         self.vit.use_graph = use_graph
         self.lm = LanguageModel(self.w)
@@ -699,6 +702,13 @@ class VddLlavaEngine:
         ids_list = [r for r in input_ids] if torch.is_tensor(input_ids) else list(input_ids)
         ids_list = [r.reshape(-1).tolist() for r in ids_list]
         Q = len(ids_list)
+        for q_, r in enumerate(ids_list):                     # ids index the embedding table on the device: validate them here
+            n_slot = sum(1 for t_ in r if t_ == IMAGE_TOKEN_INDEX)
+            if n_slot > 1:
+                raise ValueError(f"prompt {q_}: {n_slot} image placeholders (-200); the LLaVA path splices exactly one image per prompt")
+            bad = [t_ for t_ in r if t_ != IMAGE_TOKEN_INDEX and not (0 <= t_ < lm.vocab)]
+            if bad:
+                raise ValueError(f"prompt {q_}: token id {bad[0]} outside [0, {lm.vocab}) (only -200 marks the image slot)")
         if inputs_embeds is None and images is None and any(IMAGE_TOKEN_INDEX in r for r in ids_list):
             raise ValueError("input_ids contain the image placeholder (-200) but no `images` were given")
         alpha = cd_alpha if cd_alpha is not None else 0.5                                     # vcd_sample.py:188
@@ -770,8 +780,12 @@ class VddLlavaEngine:
 
         # ---- step 0: sample from the prefill logits (eager; also yields the top-n for calibration) -----------
         seg = plan["suffix"]
-        sd = (torch.initial_seed() if seed is None else int(seed)) & 0xFFFFFFFF
-        ctr0 = sd << 24                                       # device-side Philox counter = (seed, step): graphs are seed-agnostic
+        # device-side Philox counter = (stream, step): graphs are seed-agnostic.  seed=None: the stream id is drawn from torch's
+        # default generator, so every generate() call samples fresh numbers (the reference's torch.multinomial advances the
+        # generator too) and torch.manual_seed() reproduces a run; an explicit seed is a pure function of the seed
+        from .sampling import fresh_offset
+        sd = (fresh_offset() if seed is None else int(seed)) & 0x3FFFFFFFFF
+        ctr0 = sd << 24
         eos_t = torch.tensor(eos_token_id, dtype=torch.long, device=dev) if eos_token_id is not None else None
         cfgkey = (Q, nb, max_new_tokens, alpha, beta, warp.t, warp.k, warp.p, use_cd, use_dd, use_dd_unk, cd_greedy,
                   tuple(eos_token_id) if eos_token_id is not None else None, pad_token_id, output_scores)
@@ -808,7 +822,10 @@ class VddLlavaEngine:
                 scores.append(run.scores_buf.clone())
             n_new += 1
             if eos_t is not None and (n_new % sync_every == 0 or n_new == max_new_tokens):
-                if bool((run.unfinished.max() == 0).item()):                                  # :291, amortised over sync_every steps
+                done_bad = torch.stack([run.unfinished.max() == 0, (run.status | run.status0).ne(0).any()]).tolist()   # ONE sync
+                if done_bad[1]:                                 # a row lost every finite score: stop decoding from token -1
+                    break
+                if done_bad[0]:                                                               # :291, amortised over sync_every steps
                     break
         if bool((run.status | run.status0).ne(0).any().item()):
             raise RuntimeError("probability tensor contains either `inf`, `nan` or element < 0")   # torch.multinomial, :202

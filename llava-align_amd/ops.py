@@ -12,14 +12,14 @@ from . import _lib
 
 _P, _I, _L, _F = C.c_void_p, C.c_int, C.c_int64, C.c_float
 _SIGS = {
-    "vdd_embed_scatter": [_P, _P, _P, _P, _I, _I, _P],
+    "vdd_embed_scatter": [_P, _P, _P, _P, _I, _I, _I, _P],
     "vdd_skinny_swiglu": [_P, _P, _P, _I, _I, _I, _L, _P],
     "vdd_decode_attention_fused": [_P] * 11 + [_I, _I, _I, _I, _L, _I, _L, _I, _F, _P],
     "vdd_rmsnorm": [_P, _P, _P, _I, _P, _P, _P, _I, _I, _F, _P],
     "vdd_gemm": [_P, _P, _P, _P, _P, _I, _I, _I, _L, _L, _L, _L, _I, _I, _P, _L, _P],
     "vdd_rope_kv_write": [_P, _P, _P, _P, _P, _P, _P, _P, _I, _I, _I, _I, _L, _I, _P],
     "vdd_silu_mul": [_P, _P, _L, _I, _P],
-    "vdd_embed": [_P, _P, _P, _I, _I, _P],
+    "vdd_embed": [_P, _P, _P, _I, _I, _I, _P],
     "vdd_skinny_gemm": [_P, _P, _P, _P, _P, _I, _I, _I, _I, _L, _L, _L, _P],
     "vdd_decode_attention": [_P, _P, _P, _P, _P, _P, _P, _P, _I, _I, _I, _I, _L, _I, _L, _I, _I, _F, _P],
     "vdd_prefix_v_transpose": [_P, _P, _P, _I, _I, _I, _I, _P],
@@ -102,7 +102,7 @@ def embed(ids, table, out=None):
     _bf16(table)
     M, d = ids.numel(), table.shape[1]
     out = torch.empty(M, d, dtype=table.dtype, device=table.device) if out is None else out
-    _lib.check(_lib_ready().vdd_embed(ids.data_ptr(), table.data_ptr(), out.data_ptr(), M, d, _st(table)))
+    _lib.check(_lib_ready().vdd_embed(ids.data_ptr(), table.data_ptr(), out.data_ptr(), M, d, table.shape[0], _st(table)))
     return out
 
 
@@ -111,7 +111,7 @@ def embed_scatter(ids, rows, table, out):
     _bf16(table, out)
     if ids.dtype != torch.int32 or rows.dtype != torch.int32 or ids.numel() != rows.numel():
         raise ValueError("embed_scatter takes int32 ids and rows of equal length")
-    _lib.check(_lib_ready().vdd_embed_scatter(ids.data_ptr(), rows.data_ptr(), table.data_ptr(), out.data_ptr(), ids.numel(), table.shape[1], _st(table)))
+    _lib.check(_lib_ready().vdd_embed_scatter(ids.data_ptr(), rows.data_ptr(), table.data_ptr(), out.data_ptr(), ids.numel(), table.shape[1], table.shape[0], _st(table)))
     return out
 
 

@@ -8,7 +8,6 @@ torch is used only for device memory and the stream handle.
 from __future__ import annotations
 
 import ctypes as C
-import itertools
 import math
 from dataclasses import dataclass
 from typing import Optional, Sequence
@@ -57,7 +56,11 @@ class SampleOutput:
                                "(vdd_contrast_sample: no finite score survived)")
 
 
-_offset_counter = itertools.count()
+def fresh_offset() -> int:
+    """A Philox counter offset drawn from torch's default generator: every call advances the generator (as the reference's
+    torch.multinomial does, vcd_sample.py:202), so repeated generations differ, and torch.manual_seed() reproduces a run."""
+    return int(torch.randint(0, 1 << 62, (1,), dtype=torch.int64).item())
+
 
 
 def log_beta_f32(beta: float) -> float:
@@ -125,7 +128,7 @@ def contrast_sample(logits_v: torch.Tensor, logits_cd: Optional[torch.Tensor] = 
     prm.log_beta = log_beta_f32(beta) if logits_cd is not None else 0.0
     prm.temperature, prm.top_p, prm.top_k = warp.t, warp.p, warp.k
     prm.philox_seed = (torch.initial_seed() if seed is None else int(seed)) & 0xFFFFFFFFFFFFFFFF
-    prm.philox_offset = next(_offset_counter) if offset is None else int(offset)
+    prm.philox_offset = fresh_offset() if offset is None else int(offset)
     if offset_ptr is not None:                     # int64 device scalar added to the offset at run time (graph replay)
         prm.philox_offset_ptr = offset_ptr.data_ptr()
     if uniforms is not None:

@@ -33,18 +33,65 @@ def gather_tokens(local_ids: torch.Tensor, local_tokens: torch.Tensor, n_total: 
         return out
     world = dist.get_world_size()
     dev = local_tokens.device
-    T = local_tokens.shape[1]
-    n_local = torch.tensor([local_ids.numel()], dtype=torch.long, device=dev)
-    counts = [torch.zeros(1, dtype=torch.long, device=dev) for _ in range(world)]
-    dist.all_gather(counts, n_local)
-    cap = int(max(c.item() for c in counts))
+    meta = torch.tensor([local_ids.numel(), local_tokens.shape[1]], dtype=torch.long, device=dev)
+    metas = [torch.zeros(2, dtype=torch.long, device=dev) for _ in range(world)]
+    dist.all_gather(metas, meta)
+    cap = int(max(c[0].item() for c in metas))
+    T = int(max(c[1].item() for c in metas))               # a rank whose batch hit EOS early returns fewer columns: pad to the longest
     buf = torch.full((cap, T + 1), -1, dtype=torch.long, device=dev)          # column 0: question index, -1 = padding row
+    buf[:, 1:] = pad
     buf[: local_ids.numel(), 0] = local_ids
-    buf[: local_ids.numel(), 1:] = local_tokens
+    buf[: local_ids.numel(), 1: 1 + local_tokens.shape[1]] = local_tokens
     bufs = [torch.empty_like(buf) for _ in range(world)]
     dist.all_gather(bufs, buf)
     out = torch.full((n_total, T), pad, dtype=torch.long, device=dev)
     for b in bufs:
         ok = b[:, 0] >= 0
         out[b[ok, 0]] = b[ok, 1:]
+    return out
+
+
+def gather_results(local_ids: torch.Tensor, tokens: torch.Tensor, n_tokens: torch.Tensor, top_tok: torch.Tensor | None,
+                   top_prob: torch.Tensor | None, n_total: int, pad: int = 0) -> dict:
+    """The per-question payload of SURVEY.md section 8(e) in ONE all_gather: {qid, n_tokens, tokens[T], top10_tok, top10_prob}.
+    Everything rides in one int64 matrix (the fp32 probabilities bit-cast into it), a few hundred bytes per question.
+    Returns, on every rank, tensors ordered by question index."""
+    dev = tokens.device
+    n_local, T = tokens.shape
+    k = 0 if top_tok is None else int(top_tok.shape[1])
+    cols = [local_ids.view(-1, 1).long(), n_tokens.view(-1, 1).long(), tokens.long()]
+    if k:
+        cols += [top_tok.long(), top_prob.float().contiguous().view(torch.int32).long()]
+    packed = torch.cat(cols, dim=1)
+    if not (dist.is_available() and dist.is_initialized()) or dist.get_world_size() == 1:
+        blocks = [packed]
+    else:
+        world = dist.get_world_size()
+        meta = torch.tensor([n_local, T, k], dtype=torch.long, device=dev)
+        metas = [torch.zeros(3, dtype=torch.long, device=dev) for _ in range(world)]
+        dist.all_gather(metas, meta)
+        cap, Tm = int(max(m[0].item() for m in metas)), int(max(m[1].item() for m in metas))
+        if any(int(m[2].item()) != k for m in metas):
+            raise ValueError("ranks disagree on the number of top-n entries")
+        buf = torch.full((cap, 2 + Tm + 2 * k), -1, dtype=torch.long, device=dev)       # qid -1 = padding row
+        buf[:, 2: 2 + Tm] = pad
+        buf[:n_local, :2] = packed[:, :2]
+        buf[:n_local, 2: 2 + T] = packed[:, 2: 2 + T]
+        if k:
+            buf[:n_local, 2 + Tm:] = packed[:, 2 + T:]
+        bufs = [torch.empty_like(buf) for _ in range(world)]
+        dist.all_gather(bufs, buf)
+        blocks, T = bufs, Tm
+    out = {"tokens": torch.full((n_total, T), pad, dtype=torch.long, device=dev), "n_tokens": torch.zeros(n_total, dtype=torch.long, device=dev)}
+    if k:
+        out["top_tok"] = torch.full((n_total, k), -1, dtype=torch.long, device=dev)
+        out["top_prob"] = torch.zeros(n_total, k, dtype=torch.float32, device=dev)
+    for b in blocks:
+        ok = b[:, 0] >= 0
+        q = b[ok, 0]
+        out["n_tokens"][q] = b[ok, 1]
+        out["tokens"][q] = b[ok, 2: 2 + T]
+        if k:
+            out["top_tok"][q] = b[ok, 2 + T: 2 + T + k]
+            out["top_prob"][q] = b[ok, 2 + T + k:].to(torch.int32).view(torch.float32)
     return out

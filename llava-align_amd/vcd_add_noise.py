@@ -10,7 +10,6 @@ kernel and returned on its original device; without a GPU this raises — no CPU
 from __future__ import annotations
 
 import ctypes as C
-import itertools
 from typing import Optional
 
 import torch
@@ -18,7 +17,6 @@ import torch
 from . import _lib
 
 _schedule = None
-_calls = itertools.count()
 _DT = {torch.float32: _lib.VDD_F32, torch.float16: _lib.VDD_F16, torch.bfloat16: _lib.VDD_BF16}
 
 
@@ -54,7 +52,10 @@ def add_diffusion_noise(image_tensor: torch.Tensor, noise_step: int, noise: Opti
                                             C.c_void_p, C.c_uint64, C.c_uint64, C.c_void_p]
     lib.vdd_add_diffusion_noise.restype = C.c_int
     sd = (torch.initial_seed() if seed is None else int(seed)) & 0xFFFFFFFFFFFFFFFF
-    off = next(_calls) << 40      # disjoint counter ranges per call
+    # counter range of this call: drawn from torch's generator when no seed is given (each call advances it, manual_seed
+    # reproduces a run); an explicit seed is a pure function of (seed, image shape)
+    from .sampling import fresh_offset
+    off = ((fresh_offset() if seed is None else 0) & ((1 << 23) - 1)) << 40
     with torch.cuda.device(x.device):
         _lib.check(lib.vdd_add_diffusion_noise(x.data_ptr(), y.data_ptr(), x.numel(), _DT[x.dtype], a[t], b[t],
                                                eps_ptr, sd, off, torch.cuda.current_stream(x.device).cuda_stream))

@@ -334,9 +334,13 @@ def _sample_v5(self, input_ids, logits_processor, stopping_criteria, generation_
             model_kwargs.pop(k, None)
         from transformers.generation.logits_process import TopKLogitsWarper
         logits_processor = list(logits_processor) + [TopKLogitsWarper(top_k=1)]
+        model_kwargs["cd_greedy"] = True            # HF greedy takes the FIRST index of the maximum: arg-max, not a draw among ties
     pad = getattr(generation_config, "_pad_token_tensor", None)
+    eos = getattr(generation_config, "_eos_token_tensor", None)
+    if eos is None:
+        eos = generation_config.eos_token_id         # the per-call config wins over the model's (generate(eos_token_id=X))
     return sample(self, input_ids, logits_processor=logits_processor, stopping_criteria=stopping_criteria,
-                  pad_token_id=pad if pad is not None else generation_config.pad_token_id,
+                  pad_token_id=pad if pad is not None else generation_config.pad_token_id, eos_token_id=eos,
                   output_attentions=generation_config.output_attentions,
                   output_hidden_states=generation_config.output_hidden_states,
                   output_scores=generation_config.output_scores,

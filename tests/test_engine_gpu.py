@@ -401,3 +401,52 @@ def test_soak_graph_engine_equals_eager_engine_over_mixed_calls():
                     seed=100 + call, **kw, **eos)     # odd calls SAMPLE: same Philox (seed, step, row) stream in both engines
         a, b = eg.generate(ids, **args), ee.generate(ids, **args)
         assert torch.equal(a.tokens, b.tokens), (call, Q, share, kw.keys())
+
+
+def test_generate_validates_prompt_ids_on_the_host(eng):
+    """The embedding gather runs on the device inside a captured step: ids are checked before anything is launched."""
+    ids, imgs = prompts(n_img=1, per_img=1)
+    two_slots = torch.cat([ids[0], torch.tensor([-200, 5])])
+    with pytest.raises(ValueError, match="image placeholders"):
+        eng.generate([two_slots], images=imgs[:1], max_new_tokens=2)
+    for bad in (-3, 1000, 10 ** 9):
+        with pytest.raises(ValueError, match="outside"):
+            eng.generate([torch.cat([ids[0], torch.tensor([bad])])], images=imgs[:1], max_new_tokens=2)
+
+
+def test_embed_kernels_clamp_ids_instead_of_reading_wild_memory():
+    from llava_align_amd import ops
+    table = (torch.arange(50 * 8, device=DEV).view(50, 8) % 251).to(torch.bfloat16)
+    ids = torch.tensor([3, -1, 49, 50, 1 << 40], device=DEV)
+    got = ops.embed(ids, table)
+    assert torch.equal(got, table[torch.tensor([3, 0, 49, 0, 0], device=DEV)])
+    out = torch.zeros(5, 8, dtype=torch.bfloat16, device=DEV)
+    ops.embed_scatter(torch.tensor([7, -200, 50, 2, 0], dtype=torch.int32, device=DEV), torch.arange(5, dtype=torch.int32, device=DEV), table, out)
+    assert torch.equal(out, table[torch.tensor([7, 0, 0, 2, 0], device=DEV)])
+
+
+def test_sampling_stream_advances_between_calls_and_follows_manual_seed(eng):
+    """with seed=None every generate() draws fresh numbers (the reference's multinomial advances torch's generator) and
+    torch.manual_seed() reproduces a run; an explicit seed is a pure function of the seed."""
+    ids, imgs = prompts(seed=11)
+    kw = dict(images=imgs, use_dd_unk=True, cd_alpha=1.0, cd_beta=1e-4, temperature=1.5, max_new_tokens=6)   # wide distributions
+    torch.manual_seed(1234)
+    a1 = eng.generate(ids, **kw).tokens
+    a2 = eng.generate(ids, **kw).tokens
+    torch.manual_seed(1234)
+    b1 = eng.generate(ids, **kw).tokens
+    b2 = eng.generate(ids, **kw).tokens
+    assert torch.equal(a1, b1) and torch.equal(a2, b2)            # reproducible from the seed
+    assert not torch.equal(a1, a2)                                 # but two calls do not share their random numbers
+    s1, s2 = eng.generate(ids, seed=5, **kw).tokens, eng.generate(ids, seed=5, **kw).tokens
+    assert torch.equal(s1, s2) and not torch.equal(s1, eng.generate(ids, seed=6, **kw).tokens)
+    # the drop-in tail and the noise op draw from the same generator
+    from llava_align_amd import contrast_sample, add_diffusion_noise
+    v = torch.randn(8, 500, device=DEV)
+    torch.manual_seed(7); t1 = contrast_sample(v).tokens.clone(); t2 = contrast_sample(v).tokens.clone()
+    torch.manual_seed(7); u1 = contrast_sample(v).tokens.clone()
+    assert torch.equal(t1, u1) and not torch.equal(t1, t2)
+    img = torch.randn(3, 16, 16, device=DEV)
+    torch.manual_seed(9); n1 = add_diffusion_noise(img, 500); n2 = add_diffusion_noise(img, 500)
+    torch.manual_seed(9); m1 = add_diffusion_noise(img, 500)
+    assert torch.equal(n1, m1) and not torch.equal(n1, n2)

@@ -8,7 +8,7 @@ import torch
 import torch.distributed as dist
 import torch.multiprocessing as mp
 
-from llava_align_amd.shard import gather_tokens, get_chunk
+from llava_align_amd.shard import gather_results, gather_tokens, get_chunk
 
 
 def test_chunks_partition_and_keep_image_groups_together():
@@ -31,7 +31,22 @@ def _worker(rank, world, port, ret):
     toks = (mine[:, None] * 100 + torch.arange(T)[None]).long()
     out = gather_tokens(mine, toks, n_total)
     want = (torch.arange(n_total)[:, None] * 100 + torch.arange(T)[None]).long()
-    ret[rank] = bool(torch.equal(out, want))
+    ok = bool(torch.equal(out, want))
+    # ranks whose batches stopped at EOS after different numbers of steps hold different T: padded to the longest
+    t_r = T - rank
+    out2 = gather_tokens(mine, toks[:, :t_r], n_total, pad=-7)
+    want2 = want.clone()
+    other = torch.tensor(list(get_chunk(n_total, world, 1, group=3)))
+    want2[other, T - 1:] = -7
+    # the full section-8(e) payload {qid, n_tokens, tokens, top10_tok, top10_prob} in one all_gather
+    tt = (mine[:, None] * 7 + torch.arange(10)[None]).long()
+    tp = (mine[:, None].float() * 0.01 + torch.arange(10)[None].float() * 1e-3)
+    res = gather_results(mine, toks[:, :t_r], torch.full((mine.numel(),), t_r), tt, tp, n_total, pad=-7)
+    allq = torch.arange(n_total)
+    ok3 = (torch.equal(res["tokens"], want2) and torch.equal(res["top_tok"], (allq[:, None] * 7 + torch.arange(10)[None]).long())
+           and torch.equal(res["top_prob"], allq[:, None].float() * 0.01 + torch.arange(10)[None].float() * 1e-3)
+           and res["n_tokens"][other].tolist() == [T - 1] * other.numel())
+    ret[rank] = ok and bool(torch.equal(out2, want2)) and ok3
     dist.barrier()
     dist.destroy_process_group()
 
