@@ -1,0 +1,84 @@
+"""The engine against the fp32 reference LLaVA at REAL model dimensions (the `tiny` presets of test_engine_gpu.py exercise every
+code path but at d = 256 / 2 heads):
+  * LLaVA-1.5-7B widths (d 4096, 32 heads, ffn 11008, CLIP width 1024 / 336 px -> 611-token shared prefixes), 2 decoder layers,
+    8 images x 6 questions x 2 branches = 96 decode rows: the grouped MFMA prefix pass with several 64-key chunks per work item,
+    the own-token merge pass, the persistent GEMM at decode and prefill sizes and the captured HIP graph all run at their real
+    head counts and sequence lengths;
+  * LLaVA-1.5-13B widths (d 5120, 40 heads, ffn 13824; BASELINE config #3: use_dd + use_dd_unk = 3 branches, top-p 0.9, T = 1),
+    2 decoder layers.
+Reference = tests/ref_llava.py in fp32 driven by the oracle restatement of the reference loop, one question at a time."""
+import numpy as np
+import pytest
+import torch
+
+from oracle import vdd_oracle as O
+from ref_llava import RefLlava
+
+pytestmark = pytest.mark.gpu
+DEV = "cuda:0"
+
+
+def _engine(lm_kw, n_layers=2, vit_layers=3, use_graph=True, seed=5):
+    from llava_align_amd.engine import LlavaConfig, LlavaWeights, LMConfig, VddLlavaEngine, VisionConfig
+    cfg = LlavaConfig(LMConfig(n_layers=n_layers, max_pos=1024, **lm_kw), VisionConfig(layers=vit_layers), "shapes-test")
+    w = LlavaWeights.random(cfg, DEV, seed=seed, std=0.02, lm_head_gain=2.0)
+    return VddLlavaEngine(cfg, weights=w, device=DEV, use_graph=use_graph)
+
+
+def _prompts(n_img, per_img, vocab, seed, image=336):
+    rng = np.random.default_rng(seed)
+    sys_tok = [1] + rng.integers(3, vocab, size=34).tolist()
+    ids, imgs = [], []
+    for i in range(n_img):
+        im = torch.randn(3, image, image, generator=torch.Generator().manual_seed(500 + i))
+        for _ in range(per_img):
+            ids.append(torch.tensor(sys_tok + [-200] + rng.integers(3, vocab, size=int(rng.integers(19, 29))).tolist()))
+            imgs.append(im)
+    return ids, imgs
+
+
+def _compare(eng, ref, ids, imgs, mode_kw, warp_kw, n_new, questions, tol):
+    out = eng.generate(ids, images=imgs, cd_alpha=1.0, cd_beta=0.1, max_new_tokens=n_new, cd_greedy=True, output_scores=True, **mode_kw, **warp_kw)
+    checked = 0
+    for q in questions:
+        kw = dict(images=imgs[q][None], attention_mask=torch.ones(1, ids[q].numel(), dtype=torch.long), use_cache=True, cd_alpha=1.0,
+                  cd_beta=0.1, **mode_kw)
+        r = O.reference_loop(ref, ids[q][None].clone(), warp=O.WarpConfig(**warp_kw), max_length=ids[q].numel() + n_new, pad_token_id=None,
+                             eos_token_id=None, pick=O.pick_argmax, **kw)
+        want, got = r.sequences[0, ids[q].numel():].tolist(), out.tokens[q].tolist()
+        for step in range(n_new):
+            s_got, s_want = out.scores[step][q].float().cpu(), r.scores[step][0].float().cpu()
+            fin = torch.isfinite(s_got) & torch.isfinite(s_want)
+            # tokens whose main-branch logit (or cumulative mass) sits within bf16 noise of a cutoff may fall on either side
+            assert fin.sum() >= 1 and (torch.isfinite(s_got) ^ torch.isfinite(s_want)).sum() <= 3 + 0.25 * int(fin.sum()), (q, step)   # candidate density x logit noise
+            tol_s = tol + 0.02 * s_want[fin].abs().max().item()                  # the scores are bf16: 2-3 ulps of their own magnitude
+            assert (s_got[fin] - s_want[fin]).abs().max().item() <= tol_s, (q, step)
+            top2 = torch.topk(s_want, 2).values
+            if (top2[0] - top2[1]).item() > 2 * tol_s:
+                assert got[step] == want[step], (q, step)
+                checked += 1
+            if got[step] != want[step]:
+                break
+    return out, checked
+
+
+def test_llava_7b_widths_grouped_decode_and_graph_match_reference():
+    eng = _engine(dict(d=4096, n_heads=32, n_kv_heads=32, head_dim=128, ffn=11008, vocab=32000))
+    ref = RefLlava(eng.w, device=DEV)
+    ids, imgs = _prompts(8, 6, 32000, seed=21)                       # 48 questions, 96 rows, 8 + 1 shared prefixes of 611 / 36 tokens
+    # bf16 engine vs fp32 reference; the contrast multiplies logit noise by ((1+a) + a) / T = 6
+    out, checked = _compare(eng, ref, ids, imgs, dict(use_dd_unk=True), dict(temperature=0.5), n_new=4, questions=range(0, 48, 5), tol=0.5)
+    assert out.stats["graph"] and out.stats["n_rows"] == 96 and checked >= 10
+    assert out.stats["prefill_tokens"] < 0.3 * out.stats["unshared_prefill_tokens"]
+    # same batch through the eager step: the captured graph replays exactly that
+    eng2 = _engine(dict(d=4096, n_heads=32, n_kv_heads=32, head_dim=128, ffn=11008, vocab=32000), use_graph=False)
+    o2 = eng2.generate(ids, images=imgs, cd_alpha=1.0, cd_beta=0.1, max_new_tokens=4, cd_greedy=True, use_dd_unk=True, temperature=0.5)
+    assert torch.equal(o2.tokens, out.tokens)
+
+
+def test_llava_13b_widths_three_branches_top_p_match_reference():
+    eng = _engine(dict(d=5120, n_heads=40, n_kv_heads=40, head_dim=128, ffn=13824, vocab=32000))
+    ref = RefLlava(eng.w, device=DEV)
+    ids, imgs = _prompts(6, 1, 32000, seed=22)                       # BASELINE config #3: one image per question, nothing to group
+    out, checked = _compare(eng, ref, ids, imgs, dict(use_dd=True, use_dd_unk=True), dict(top_p=0.9), n_new=4, questions=range(6), tol=0.25)
+    assert out.stats["n_rows"] == 18 and checked >= 6
