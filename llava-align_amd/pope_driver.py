@@ -1,0 +1,169 @@
+"""POPE / yes-no evaluation driver over the native engine: the batched replacement of the reference's per-question loop
+(experiments/eval/calibrate/llava_calibrate.py:130-219), same per-question inputs and outputs.
+
+Per question the reference runs THREE generate() calls, each B = 1:
+  main   image + question, VDD / VCD kwargs, 64 new tokens            -> `text`, `naive` (step-0 top-10 label dict), `logits_score`
+  none   the question WITHOUT the image token, no image (llava_calibrate.py:46-61 with images=None)      -> `none`
+  unk    the image token replaced by <unk>, no image (:59-61)                                            -> `unk`
+The `none` / `unk` calls only ever use their step-0 scores (:80-85), so here they decode ONE token instead of up to 1024.
+This driver runs each of the three as one engine call over a whole batch of questions (questions of one image adjacent, so
+they share its ViT features and prompt-prefix KV), takes the step-0 top-10 probabilities from the fused sampling kernel,
+builds the label dicts / label probabilities with the reference's first-wins rule (calibrate.py), writes the reference's JSONL
+schema and scores it with the plain and the calibrated POPE scorers.
+
+Tokenisation stays outside (the reference's conv template + tokenizer_image_token are tokenizer-specific): the caller passes
+`encode(text, with_image) -> list[int]` (with -200 where the image goes) and `decode(ids) -> str`.
+"""
+from __future__ import annotations
+
+from typing import Callable, Dict, List, Optional, Sequence
+
+import torch
+
+from . import calibrate as C
+from .engine import IMAGE_TOKEN_INDEX, VddLlavaEngine
+
+QUESTION_SUFFIX = " Please answer this question with one word."      # llava_calibrate.py:52,146
+
+
+def llava_v1_prompt(question: str, with_image: bool) -> str:
+    """conv_templates['llava_v1'] with one user turn (experiments/llava/conversation.py:335-345, get_prompt for SeparatorStyle.TWO)."""
+    system = ("A chat between a curious human and an artificial intelligence assistant. "
+              "The assistant gives helpful, detailed, and polite answers to the human's questions.")
+    qs = ("<image>\n" if with_image else "") + question + QUESTION_SUFFIX
+    return f"{system} USER: {qs} ASSISTANT:"
+
+
+def _top_dicts(out, decode_token: Callable[[int], str]) -> List[Dict[str, float]]:
+    tt, tp = out.top_tok.cpu().tolist(), out.top_prob.cpu().tolist()
+    return [C.label_dict_from_top(t, p, decode_token) for t, p in zip(tt, tp)]
+
+
+def run_pope(engine: VddLlavaEngine, questions: Sequence[dict], encode: Callable[[str, bool], List[int]],
+             decode: Callable[[List[int]], str], load_image: Callable[[str], torch.Tensor], answers_path: Optional[str] = None,
+             model_id: str = "llava-align_amd", batch_questions: int = 384, unk_token_id: int = 0, eos_token_id=None,
+             pad_token_id: Optional[int] = None, stop_str: Optional[str] = "</s>", max_new_tokens: int = 64, noise_step: Optional[int] = None,
+             **generate_kw) -> dict:
+    """questions: dicts with question_id, image, text, label (the POPE json lines).  generate_kw: cd_alpha, cd_beta, use_dd,
+    use_dd_unk, temperature, top_p, top_k, seed ... exactly the reference's model.generate kwargs (llava_calibrate.py:161-177);
+    noise_step adds the VCD branch (images_cd = add_diffusion_noise(image, noise_step), :152-155).
+    Returns {"answers": [...], "scores": {"string_match": ..., "naive": ..., "none": ..., "unk": ..., "none_unk": ...}}."""
+    order = sorted(range(len(questions)), key=lambda i: (questions[i]["image"], i))      # one image's questions adjacent
+    decode_token = lambda t: decode([t])
+    answers: Dict[int, dict] = {}
+    img_cache: Dict[str, torch.Tensor] = {}
+    for b0 in range(0, len(order), batch_questions):
+        idx = order[b0:b0 + batch_questions]
+        qs = [questions[i] for i in idx]
+        for q in qs:
+            if q["image"] not in img_cache:
+                img_cache[q["image"]] = load_image(q["image"]).to(engine.device)
+        imgs = [img_cache[q["image"]] for q in qs]
+        ids_main = [torch.tensor(encode(q["text"], True)) for q in qs]
+        ids_none = [torch.tensor(encode(q["text"], False)) for q in qs]
+        ids_unk = [torch.tensor([unk_token_id if t == IMAGE_TOKEN_INDEX else t for t in r.tolist()]) for r in ids_main]    # :59-60
+        kw = dict(generate_kw)
+        if noise_step is not None:
+            from .vcd_add_noise import add_diffusion_noise
+            noisy = {k: add_diffusion_noise(v, noise_step) for k, v in img_cache.items() if any(q["image"] == k for q in qs)}
+            kw["images_cd"] = [noisy[q["image"]] for q in qs]
+        main = engine.generate(ids_main, images=imgs, max_new_tokens=max_new_tokens, n_top=10, eos_token_id=eos_token_id,
+                               pad_token_id=pad_token_id, **kw)
+        # content-free priors: plain sampling (no image -> no contrast branch), step-0 distribution only
+        plain_kw = {k: v for k, v in generate_kw.items() if k in ("temperature", "top_p", "top_k", "seed", "cd_alpha", "cd_beta")}
+        none = engine.generate(ids_none, images=None, max_new_tokens=1, n_top=10, **plain_kw)
+        unk = engine.generate(ids_unk, images=None, max_new_tokens=1, n_top=10, **plain_kw)
+        naive_d, none_d, unk_d = _top_dicts(main, decode_token), _top_dicts(none, decode_token), _top_dicts(unk, decode_token)
+        eos_set = set([eos_token_id] if isinstance(eos_token_id, int) else (eos_token_id or []))
+        for j, i in enumerate(idx):
+            toks = main.tokens[j].tolist()
+            for k, t in enumerate(toks):                       # cut at the first EOS (the rest is padding)
+                if t in eos_set:
+                    toks = toks[:k + 1]
+                    break
+            text = decode(toks).strip()
+            if stop_str and text.endswith(stop_str):
+                text = text[:-len(stop_str)]
+            answers[i] = {"question_id": qs[j]["question_id"], "prompt": qs[j]["text"], "text": text.strip(), "model_id": model_id,
+                          "image": qs[j]["image"], "logits_score": C.get_prob_from_logits(naive_d[j]), "naive": naive_d[j],
+                          "unk": unk_d[j], "none": none_d[j], "metadata": {}}
+        for k in [k for k in img_cache if not any(questions[i]["image"] == k for i in order[b0 + batch_questions:b0 + 2 * batch_questions])]:
+            img_cache.pop(k)                                   # images are revisited only within a sorted neighbourhood
+        engine.clear_image_cache()
+    ordered = [answers[i] for i in range(len(questions))]
+    if answers_path is not None:
+        with C.AnswerWriter(answers_path) as w:
+            for a in ordered:
+                w.write(a["question_id"], a["prompt"], a["text"], a["model_id"], a["image"], a["logits_score"], a["naive"], a["unk"], a["none"])
+    scores = {}
+    if all("label" in q for q in questions):
+        gt = [{"question_id": q["question_id"], "label": q["label"]} for q in questions]
+        scores["string_match"] = _try(C.pope_scores, gt, ordered)
+        for name in ("naive", "none", "unk", "none_unk"):
+            scores[name] = _try(C.pope_scores_calibrated, gt, ordered, name)
+    return {"answers": ordered, "scores": scores}
+
+
+def _try(f, *a):
+    try:
+        return f(*a)
+    except ZeroDivisionError:            # the reference scorers divide by tp + fp etc.: undefined on degenerate (tiny / random) runs
+        return None
+
+
+def main(argv=None):
+    """python -m llava_align_amd.pope_driver --model-path DIR --question-file Q.json --image-folder IMGS --answers-file OUT.jsonl
+    [--use_dd --use_dd_unk --cd_alpha 1 --cd_beta 0.1 --temperature 0.2 --noise_step N]: the reference CLI's arguments
+    (llava_calibrate.py:222-246) over the native engine.  Needs a LLaVA-1.5 checkpoint directory (HF safetensors + tokenizer)."""
+    import argparse
+    import json
+    import os
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--model-path", required=True)
+    ap.add_argument("--question-file", required=True)
+    ap.add_argument("--image-folder", required=True)
+    ap.add_argument("--answers-file", required=True)
+    ap.add_argument("--preset", default="llava-1.5-7b")
+    ap.add_argument("--temperature", type=float, default=1.0)
+    ap.add_argument("--top_p", type=float, default=None)
+    ap.add_argument("--top_k", type=int, default=None)
+    ap.add_argument("--noise_step", type=int, default=None)
+    ap.add_argument("--use_dd", action="store_true")
+    ap.add_argument("--use_dd_unk", action="store_true")
+    ap.add_argument("--cd_alpha", type=float, default=1.0)
+    ap.add_argument("--cd_beta", type=float, default=0.1)
+    ap.add_argument("--batch", type=int, default=384)
+    a = ap.parse_args(argv)
+    from PIL import Image
+    from safetensors.torch import load_file
+    from transformers import AutoTokenizer, CLIPImageProcessor
+    from .engine import LlavaWeights, preset
+    tok = AutoTokenizer.from_pretrained(a.model_path, use_fast=False)
+    sd = {}
+    for f in sorted(os.listdir(a.model_path)):
+        if f.endswith(".safetensors"):
+            sd.update(load_file(os.path.join(a.model_path, f)))
+    cfg = preset(a.preset)
+    eng = VddLlavaEngine(cfg, weights=LlavaWeights.from_state_dict(cfg, sd, "cuda:0"))
+    proc = CLIPImageProcessor.from_pretrained(a.model_path)
+
+    def encode(text, with_image):              # tokenizer_image_token (experiments/llava/mm_utils.py): split at <image>, join with -200
+        chunks = [tok(c).input_ids for c in llava_v1_prompt(text, with_image).split("<image>")]
+        ids = list(chunks[0])
+        for c in chunks[1:]:
+            ids += [IMAGE_TOKEN_INDEX] + c[1:]  # drop the BOS of later chunks
+        return ids
+
+    questions = [json.loads(q) for q in open(os.path.expanduser(a.question_file))]
+    os.makedirs(os.path.dirname(os.path.abspath(a.answers_file)), exist_ok=True)
+    res = run_pope(eng, questions, encode, lambda ids: tok.decode(ids, skip_special_tokens=True),
+                   lambda name: proc.preprocess(Image.open(os.path.join(a.image_folder, name)).convert("RGB"), return_tensors="pt")["pixel_values"][0],
+                   answers_path=a.answers_file, model_id=os.path.basename(a.model_path.rstrip("/")), batch_questions=a.batch,
+                   unk_token_id=tok.unk_token_id, eos_token_id=tok.eos_token_id, pad_token_id=tok.pad_token_id or 0,
+                   noise_step=a.noise_step, use_dd=a.use_dd, use_dd_unk=a.use_dd_unk, cd_alpha=a.cd_alpha, cd_beta=a.cd_beta,
+                   temperature=a.temperature, top_p=a.top_p, top_k=a.top_k)
+    print(json.dumps(res["scores"], indent=1))
+
+
+if __name__ == "__main__":
+    main()
