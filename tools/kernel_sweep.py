@@ -36,6 +36,9 @@ def point(B, V, dtype, n_in, scores, warp, iters=100, beta=0.1):
 if __name__ == "__main__":
     W = L.WarpSpec
     pts = []
+    if "--only-canonical" in sys.argv:          # the PMC passes of tools/profile_round.sh: the roofline shape alone
+        print(json.dumps(point(4096, 32000, torch.bfloat16, 2, True, W(temperature=0.2), iters=40)))
+        sys.exit(0)
     for B in (1, 8, 64, 256, 512, 1024, 4096):
         pts.append(point(B, 32000, torch.bfloat16, 2, True, W(temperature=0.2)))
     pts.append(point(4096, 32000, torch.bfloat16, 2, False, W(temperature=0.2)))
