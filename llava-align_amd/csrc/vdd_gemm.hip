@@ -71,7 +71,7 @@ struct GemmArgs {
     int dp_rounds;               // whole-tile rounds before the stream-K part (host-chosen schedule)
 };
 
-template <int BM, int BN, int WM, int WN, int EPI>
+template <int BM, int BN, int WM, int WN, int EPI, int VAR = 0>     // VAR: schedule experiments (bit 0 s_setprio around MFMA runs, bit 1 DMA over two k-steps)
 __global__ void __launch_bounds__(WM * WN * 64) gemm_kernel(const GemmArgs a) {
 #if defined(__HIP_DEVICE_COMPILE__)   // the host pass only needs the launch stub: it drops a kernel whose body holds LDS-DMA builtins
     constexpr int NW = WM * WN, NT = NW * 64;
@@ -97,18 +97,28 @@ __global__ void __launch_bounds__(WM * WN * 64) gemm_kernel(const GemmArgs a) {
     // workgroup rng, and workgroup b runs on XCD b % 8, so rng is XCD-contiguous: the 32 CUs of an XCD work on 32 neighbouring
     // tiles at any time (shared X row-panels / W column-panels in its L2).  Then the stream-K part: the tiles that do not
     // fill a round, as one contiguous range of 128-deep K units per workgroup.
-    const int rng = (a.P & 7) ? (int)blockIdx.x : (int)((blockIdx.x & 7) * (a.P >> 3) + (blockIdx.x >> 3));
     const int T = a.Mt * a.Nt, rounds = a.dp_rounds, dp_tiles = min(T, rounds * a.P);
     const long long SU = (long long)(T - dp_tiles) * a.UP;            // stream-K units
     const int Psk = (int)min((long long)a.P, SU);                      // never more ranges than units: no empty range
+    // n work items for the P workgroups of a round: XCD x (= blockIdx % 8) takes a contiguous run of ceil / floor (n / 8) items,
+    // so a partial round still spreads over all eight L2s and neighbours stay together; -1 = nothing for this workgroup
+    const int bx = blockIdx.x & 7, by = blockIdx.x >> 3;
+    auto spread = [&](int n) {
+        const int q = n >> 3, r = n & 7, cnt = q + (bx < r ? 1 : 0);
+        return by < cnt ? (bx < r ? bx * (q + 1) : r * (q + 1) + (bx - r) * q) + by : -1;
+    };
+    const int rng = spread(Psk);                                       // stream-K range of this workgroup
     long long u = 0, u_end = 0;
-    if (rng < Psk) { u = (long long)rng * SU / Psk; u_end = (long long)(rng + 1) * SU / Psk; }
+    if (rng >= 0) { u = (long long)rng * SU / Psk; u_end = (long long)(rng + 1) * SU / Psk; }
     auto owner = [&](long long uu) { return (int)(((uu + 1) * Psk + SU - 1) / SU - 1); };     // stream-K range that holds unit uu
     int dp_i = 0;
     int L = 0, ku0 = 0, ku1 = 0;
     auto advance = [&]() -> bool {
-        if (dp_i < rounds && dp_i * a.P + rng < T) { L = dp_i * a.P + rng; ku0 = 0; ku1 = a.UP; ++dp_i; return true; }
-        dp_i = rounds;
+        while (dp_i < rounds) {
+            const int j = spread(min(a.P, T - dp_i * a.P));
+            ++dp_i;
+            if (j >= 0) { L = (dp_i - 1) * a.P + j; ku0 = 0; ku1 = a.UP; return true; }
+        }
         if (u < u_end) {
             const int ls = (int)(u / a.UP);
             L = dp_tiles + ls; ku0 = (int)(u - (long long)ls * a.UP);
@@ -194,6 +204,25 @@ __global__ void __launch_bounds__(WM * WN * 64) gemm_kernel(const GemmArgs a) {
                 if (with_reads && i < NRD) __builtin_amdgcn_sched_group_barrier(0x100, 1, 0);
             }
         };
+        auto interleave_n = [&](int n_dma, bool with_reads) {
+#pragma unroll
+            for (int i = 0; i < NMMA; ++i) {
+                __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
+                if (i < n_dma) __builtin_amdgcn_sched_group_barrier(0x020, 1, 0);
+                if (with_reads && i < NRD) __builtin_amdgcn_sched_group_barrier(0x100, 1, 0);
+            }
+        };
+        auto stage_part = [&](int t, int buf, int half) {       // first / second half of the tile's LDS-DMA instructions
+            const int so = t * 128;
+#pragma unroll
+            for (int j = 0; j < XJ; ++j)
+                if ((j < (XJ + 1) / 2) == (half == 0))
+                    __builtin_amdgcn_raw_ptr_buffer_load_lds(rx, (lds_ptr_t)(lds + buf * BUF + (j * NW + wave) * 1024), 16, xoff[j], so, 0, 0);
+#pragma unroll
+            for (int j = 0; j < WJ; ++j)
+                if ((j < (WJ + 1) / 2) == (half == 0))
+                    __builtin_amdgcn_raw_ptr_buffer_load_lds(rw, (lds_ptr_t)(lds + buf * BUF + (XIMG + j * NW + wave) * 1024), 16, woff[j], so, 0, 0);
+        };
         bf16x8_t xg[4][MI], wg[4][NI];
         auto rd = [&](int buf, int kk) {
 #pragma unroll
@@ -211,16 +240,29 @@ __global__ void __launch_bounds__(WM * WN * 64) gemm_kernel(const GemmArgs a) {
         __builtin_amdgcn_sched_barrier(0);
         auto tile = [&](int t, int buf, auto do_stage, auto do_next) {           // buf is a literal at every call site
             constexpr bool ST = decltype(do_stage)::value, NX = decltype(do_next)::value;
+            if constexpr (VAR & 1) __builtin_amdgcn_s_setprio(1);
             rd(buf, 2); mm(0); interleave(false, true); __builtin_amdgcn_sched_barrier(0);
             rd(buf, 3); mm(1); interleave(false, true); __builtin_amdgcn_sched_barrier(0);
+            if constexpr (VAR & 1) __builtin_amdgcn_s_setprio(0);
             asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");   // own fragment reads of this tile done; tile t+1 landed
             __builtin_amdgcn_s_barrier();
             __builtin_amdgcn_sched_barrier(0);
-            if constexpr (ST) stage(t + 2, buf);
-            if constexpr (NX) rd(buf ^ 1, 0);
-            mm(2); interleave(ST, NX); __builtin_amdgcn_sched_barrier(0);
-            if constexpr (NX) rd(buf ^ 1, 1);
-            mm(3); interleave(false, NX); __builtin_amdgcn_sched_barrier(0);
+            if constexpr (VAR & 1) __builtin_amdgcn_s_setprio(1);
+            if constexpr (VAR & 2) {
+                if constexpr (ST) stage_part(t + 2, buf, 0);
+                if constexpr (NX) rd(buf ^ 1, 0);
+                mm(2); interleave_n(ST ? NLD / 2 : 0, NX); __builtin_amdgcn_sched_barrier(0);
+                if constexpr (ST) stage_part(t + 2, buf, 1);
+                if constexpr (NX) rd(buf ^ 1, 1);
+                mm(3); interleave_n(ST ? NLD - NLD / 2 : 0, NX); __builtin_amdgcn_sched_barrier(0);
+            } else {
+                if constexpr (ST) stage(t + 2, buf);
+                if constexpr (NX) rd(buf ^ 1, 0);
+                mm(2); interleave(ST, NX); __builtin_amdgcn_sched_barrier(0);
+                if constexpr (NX) rd(buf ^ 1, 1);
+                mm(3); interleave(false, NX); __builtin_amdgcn_sched_barrier(0);
+            }
+            if constexpr (VAR & 1) __builtin_amdgcn_s_setprio(0);
         };
         using T_ = std::true_type; using F_ = std::false_type;
         int t = 0;                                  // nk is even: tiles alternate between the two buffers
@@ -346,7 +388,7 @@ int num_workgroups() {
     return g_num_cu;
 }
 
-template <int BM, int BN, int WM, int WN>
+template <int BM, int BN, int WM, int WN, int VAR = 0>
 int launch_cfg(const GemmArgs& a0, int epi, int sched, void* workspace, int64_t workspace_bytes, hipStream_t st) {
     GemmArgs a = a0;
     const int ncols = epi == EPI_SWIGLU ? 2 * a.N : a.N;
@@ -374,12 +416,15 @@ int launch_cfg(const GemmArgs& a0, int epi, int sched, void* workspace, int64_t 
     const size_t smem = 2 * (BM + BN) * 128;
 #define VDD_GEMM_LAUNCH(E)                                                                                            \
     case E: {                                                                                                         \
-        auto kfn = gemm_kernel<BM, BN, WM, WN, E>;                                                                    \
+        auto kfn = gemm_kernel<BM, BN, WM, WN, E, VAR>;                                                                  \
         static bool attr_set = false;                                                                                 \
         if (!attr_set) { (void)hipFuncSetAttribute((const void*)kfn, hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem); attr_set = true; } \
         hipLaunchKernelGGL(kfn, grid, block, smem, st, a);                                                            \
         break;                                                                                                        \
     }
+    if constexpr (VAR != 0) {
+        switch (epi) { VDD_GEMM_LAUNCH(EPI_NONE) default: return VDD_ERR_INVALID_ARG; }
+    } else
     switch (epi) {
         VDD_GEMM_LAUNCH(EPI_NONE)
         VDD_GEMM_LAUNCH(EPI_BIAS)
@@ -434,6 +479,9 @@ int vdd_gemm(const void* X, const void* W, void* Y, const void* bias, const void
         case 3: return launch_cfg<256, 128, 4, 2>(a, epilogue, sched, workspace, workspace_bytes, st);
         case 4: return launch_cfg<192, 256, 2, 4>(a, epilogue, sched, workspace, workspace_bytes, st);
         case 5: return launch_cfg<256, 192, 4, 2>(a, epilogue, sched, workspace, workspace_bytes, st);
+        case 9: return launch_cfg<256, 256, 2, 4, 1>(a, epilogue, sched, workspace, workspace_bytes, st);
+        case 10: return launch_cfg<256, 256, 2, 4, 2>(a, epilogue, sched, workspace, workspace_bytes, st);
+        case 11: return launch_cfg<256, 256, 2, 4, 3>(a, epilogue, sched, workspace, workspace_bytes, st);
         default: return VDD_ERR_INVALID_ARG;
     }
 }

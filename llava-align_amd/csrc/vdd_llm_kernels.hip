@@ -674,7 +674,7 @@ __global__ void __launch_bounds__(256) vt8_transpose_kernel(const uint16_t* __re
 // waves-per-SIMD hint 4: left alone the compiler hoists all 16 K (then V) fragment loads of a chunk and lands at 140
 // registers = 3 waves per SIMD; capped at 128 the pass is 10 % faster (tools/attn_probe.py: 314 -> 274 us per layer).
 template <int D>
-__global__ void __launch_bounds__(256, 4) decode_attn_prefix_mfma_kernel(const uint16_t* __restrict__ q, const uint16_t* __restrict__ kpre,
+__global__ void __launch_bounds__(256, 2) decode_attn_prefix_mfma_kernel(const uint16_t* __restrict__ q, const uint16_t* __restrict__ kpre,
                                                                       const uint16_t* __restrict__ vt8, const GroupDesc* __restrict__ groups,
                                                                       const int* __restrict__ group_rows, const int4* __restrict__ items,
                                                                       float* __restrict__ ws, int H, int Hkv, long long pre_stride,
@@ -707,20 +707,43 @@ __global__ void __launch_bounds__(256, 4) decode_attn_prefix_mfma_kernel(const u
 #pragma unroll
     for (int nt = 0; nt < NT; ++nt) o[nt] = f32x4_t{0.f, 0.f, 0.f, 0.f};
     float mrun = -INFINITY, lrun = 0.f;          // of query ln (replicated over g)
-    for (int k0 = kbeg; k0 < k1; k0 += ATT_CH) {
+    // Chunks in a ROTATED order (the online softmax does not care): every (group, head) stream starts at t = 0 of a region that
+    // is a multiple of 32 KiB away from the others', so waves walking in step would all sit on the same HBM channels
+    const int nch_i = (k1 - kbeg + ATT_CH - 1) / ATT_CH;
+    const int rot = (int)((unsigned)(head * 5 + item.x * 3 + r0) % (unsigned)nch_i);
+    for (int ci = 0; ci < nch_i; ++ci) {
+        const int cc = ci + rot < nch_i ? ci + rot : ci + rot - nch_i;
+        const int k0 = kbeg + cc * ATT_CH;
+        // The pass is a pure stream of K and V^T (one wave reads 2 x 16 KiB per chunk and nobody else reads them), so what
+        // matters is bytes in flight: ALL 32 fragment loads of the chunk (32 KiB per wave) are issued before the first MFMA.
+        // Issued a few at a time behind their consumers (as the compiler schedules them under a 128-VGPR cap) the pass ran at
+        // 4.2 TB/s with 1-2 loads in flight per wave in its P V half.
+        bf16x8_t kf[4][KS], vf[2][NT];
+#pragma unroll
+        for (int t = 0; t < 4; ++t) {
+            int key = k0 + (t >> 1) * 32 + (ln >> 2) * 8 + (t & 1) * 4 + (ln & 3);
+            if (key >= k1) key = k1 - 1;
+            const uint16_t* kp = kb + (size_t)key * D + g * 8;
+#pragma unroll
+            for (int ks = 0; ks < KS; ++ks) kf[t][ks] = *reinterpret_cast<const bf16x8_t*>(kp + ks * 32);
+        }
+#pragma unroll
+        for (int kk = 0; kk < 2; ++kk) {
+            // B fragment lane (dim = 16 nt + ln, g) = V[k0 + 32 kk + 8 g .. + 7][dim] = 16 B of the VT8 image
+            int kblk = (k0 + kk * 32) / 8 + g;
+            if (kblk * 8 >= k1) kblk = (k1 - 1) / 8;      // fully masked 8-key block: any finite data will do (p = 0)
+            const uint16_t* vp = vb + ((size_t)kblk * D) * 8 + (size_t)ln * 8;
+#pragma unroll
+            for (int nt = 0; nt < NT; ++nt) vf[kk][nt] = *reinterpret_cast<const bf16x8_t*>(vp + (size_t)nt * 16 * 8);
+        }
+        __builtin_amdgcn_sched_barrier(0);
         // S^T: 4 tiles (a0, b0 | a1, b1); MFMA row i = ln of the A operand
         f32x4_t s[4];
 #pragma unroll
         for (int t = 0; t < 4; ++t) {
             s[t] = f32x4_t{0.f, 0.f, 0.f, 0.f};
-            int key = k0 + (t >> 1) * 32 + (ln >> 2) * 8 + (t & 1) * 4 + (ln & 3);
-            if (key >= k1) key = k1 - 1;
-            const uint16_t* kp = kb + (size_t)key * D + g * 8;
 #pragma unroll
-            for (int ks = 0; ks < KS; ++ks) {
-                const bf16x8_t kf = *reinterpret_cast<const bf16x8_t*>(kp + ks * 32);
-                s[t] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(kf, qf[ks], s[t], 0, 0, 0);
-            }
+            for (int ks = 0; ks < KS; ++ks) s[t] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(kf[t][ks], qf[ks], s[t], 0, 0, 0);
         }
         // column = query ln; this lane's rows 4 g + r are keys k0 + 32 (t>>1) + 8 g + 4 (t&1) + r
         float mx = -INFINITY;
@@ -748,7 +771,7 @@ __global__ void __launch_bounds__(256, 4) decode_attn_prefix_mfma_kernel(const u
         lsum += __shfl_xor(lsum, 16); lsum += __shfl_xor(lsum, 32);
         lrun = lrun * corr + lsum;
         mrun = mnew;
-        if (k0 > kbeg) {        // O rows are queries 4 g + r: their rescale factor lives in the lanes of column 4 g + r
+        if (ci > 0) {           // O rows are queries 4 g + r: their rescale factor lives in the lanes of column 4 g + r
 #pragma unroll
             for (int r = 0; r < 4; ++r) {
                 const float cr = __shfl(corr, 4 * g + r);
@@ -756,18 +779,12 @@ __global__ void __launch_bounds__(256, 4) decode_attn_prefix_mfma_kernel(const u
                 for (int nt = 0; nt < NT; ++nt) o[nt][r] *= cr;
             }
         }
-        // O += P V: B fragment lane (dim = 16 nt + ln, g) = V[k0 + 32 kk + 8 g .. + 7][dim] = 16 B of the VT8 image
+        // O += P V
 #pragma unroll
         for (int kk = 0; kk < 2; ++kk) {
-            int kblk = (k0 + kk * 32) / 8 + g;
-            if (kblk * 8 >= k1) kblk = (k1 - 1) / 8;      // fully masked 8-key block: any finite data will do (p = 0)
             if (k0 + kk * 32 < k1) {
-                const uint16_t* vp = vb + ((size_t)kblk * D) * 8 + (size_t)ln * 8;
 #pragma unroll
-                for (int nt = 0; nt < NT; ++nt) {
-                    const bf16x8_t vf = *reinterpret_cast<const bf16x8_t*>(vp + (size_t)nt * 16 * 8);
-                    o[nt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(pf[kk], vf, o[nt], 0, 0, 0);
-                }
+                for (int nt = 0; nt < NT; ++nt) o[nt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(pf[kk], vf[kk][nt], o[nt], 0, 0, 0);
             }
         }
     }
