@@ -235,7 +235,11 @@ int vdd_flash_attention(const void* q, const void* k_cache, const void* v_cache,
 int vdd_vit_im2col(const void* images, int dtype, void* patches, int n, int S, int P, int Kp, void* hip_stream);
 int vdd_vit_assemble(const void* emb, const void* cls, const void* pos, void* out, int n, int T, int width, void* hip_stream);
 int vdd_vit_qkv_split(const void* qkv, void* q, void* k_cache, void* v_cache, int n, int T, int H, int D, int64_t slot_stride, int t_max,
-                      void* hip_stream);
+                      int parts /* 3: [q,k,v]; 2: a fused [k,v] projection (cross-attention), q unused */, void* hip_stream);
+
+/* out = a + b elementwise (bf16, n % 8 == 0 elements): word + position embeddings of the InstructBLIP Q-Former's text input
+ * (lavis Qformer.py:95-99). */
+int vdd_add(const void* a, const void* b, void* out, int64_t n, void* hip_stream);
 
 /* CLIP ViT LayerNorm (with bias); d % 8 == 0, d <= 4096. */
 int vdd_layernorm(const void* x, const void* w, const void* b, void* y, int M, int d, float eps, void* hip_stream);

@@ -305,17 +305,29 @@ __global__ void __launch_bounds__(256) vit_assemble_kernel(const uint16_t* __res
     }
 }
 
-// qkv [n * T, 3, H, D] (one fused projection) -> q [n * T, H * D] and the K / V caches [slot = image][H][t][D] the attention reads
+// qkv [n * T, 3, H, D] (one fused projection) -> q [n * T, H * D] and the K / V caches [slot = image][H][t][D] the attention reads;
+// parts = 2: the input is a fused [k, v] projection only (cross-attention keys / values)
 __global__ void __launch_bounds__(256) vit_qkv_split_kernel(const uint16_t* __restrict__ qkv, uint16_t* __restrict__ q,
                                                             uint16_t* __restrict__ kc, uint16_t* __restrict__ vc, int T, int H, int D,
-                                                            long long slot_stride, int t_max) {
+                                                            long long slot_stride, int t_max, int parts) {
     const int row = blockIdx.x, i = row / T, t = row - i * T, hd = H * D;
-    for (int e = threadIdx.x * 8; e < 3 * hd; e += 256 * 8) {
-        const uint4 v = *reinterpret_cast<const uint4*>(qkv + (size_t)row * 3 * hd + e);
-        const int which = e / hd, r = e - which * hd, h = r / D, d = r - h * D;
+    for (int e = threadIdx.x * 8; e < parts * hd; e += 256 * 8) {
+        const uint4 v = *reinterpret_cast<const uint4*>(qkv + (size_t)row * parts * hd + e);
+        const int part = e / hd, which = part + (3 - parts), r = e - part * hd, h = r / D, d = r - h * D;
         uint16_t* dst = which == 0 ? q + (size_t)row * hd + r
                                    : (which == 1 ? kc : vc) + (size_t)i * slot_stride + ((size_t)h * t_max + t) * D + d;
         *reinterpret_cast<uint4*>(dst) = v;
+    }
+}
+
+// out = a + b (bf16, one rounding): word + position embeddings of the Q-Former's text input
+__global__ void __launch_bounds__(256) add_kernel(const uint16_t* __restrict__ a, const uint16_t* __restrict__ b, uint16_t* __restrict__ out, long long n8) {
+    for (long long i = (long long)blockIdx.x * 256 + threadIdx.x; i < n8; i += (long long)gridDim.x * 256) {
+        const uint4 x = reinterpret_cast<const uint4*>(a)[i], y = reinterpret_cast<const uint4*>(b)[i];
+        uint4 o;
+        o.x = pack(lo(x.x) + lo(y.x), hi(x.x) + hi(y.x)); o.y = pack(lo(x.y) + lo(y.y), hi(x.y) + hi(y.y));
+        o.z = pack(lo(x.z) + lo(y.z), hi(x.z) + hi(y.z)); o.w = pack(lo(x.w) + lo(y.w), hi(x.w) + hi(y.w));
+        reinterpret_cast<uint4*>(out)[i] = o;
     }
 }
 
@@ -385,11 +397,20 @@ int vdd_vit_assemble(const void* emb, const void* cls, const void* pos, void* ou
 }
 
 int vdd_vit_qkv_split(const void* qkv, void* q, void* k_cache, void* v_cache, int n, int T, int H, int D, int64_t slot_stride, int t_max,
-                      void* stream) {
+                      int parts, void* stream) {
     if (n <= 0) return VDD_OK;
-    if (!qkv || !q || !k_cache || !v_cache || D % 8 != 0 || T > t_max) return VDD_ERR_INVALID_ARG;
+    if (!qkv || (!q && parts == 3) || !k_cache || !v_cache || D % 8 != 0 || T > t_max || (parts != 2 && parts != 3)) return VDD_ERR_INVALID_ARG;
     hipLaunchKernelGGL(vit_qkv_split_kernel, dim3(n * T), dim3(256), 0, (hipStream_t)stream, (const uint16_t*)qkv, (uint16_t*)q,
-                       (uint16_t*)k_cache, (uint16_t*)v_cache, T, H, D, (long long)slot_stride, t_max);
+                       (uint16_t*)k_cache, (uint16_t*)v_cache, T, H, D, (long long)slot_stride, t_max, parts);
+    return ok();
+}
+
+int vdd_add(const void* a, const void* b, void* out, int64_t n, void* stream) {
+    if (n <= 0) return VDD_OK;
+    if (!a || !b || !out || n % 8 != 0) return VDD_ERR_INVALID_ARG;
+    const long long n8 = n / 8;
+    int blocks = (int)((n8 + 255) / 256); if (blocks > 4096) blocks = 4096;
+    hipLaunchKernelGGL(add_kernel, dim3(blocks), dim3(256), 0, (hipStream_t)stream, (const uint16_t*)a, (const uint16_t*)b, (uint16_t*)out, n8);
     return ok();
 }
 

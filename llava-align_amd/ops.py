@@ -27,9 +27,10 @@ _SIGS = {
     "vdd_flash_attention": [_P, _P, _P, _P, _P, _P, _P, _I, _I, _I, _I, _I, _L, _I, _L, _I, _F, _I, _P],
     "vdd_layernorm": [_P, _P, _P, _P, _I, _I, _F, _P],
     "vdd_bias_act": [_P, _P, _P, _L, _I, _I, _P],
+    "vdd_add": [_P, _P, _P, _L, _P],
     "vdd_vit_im2col": [_P, _I, _P, _I, _I, _I, _I, _P],
     "vdd_vit_assemble": [_P, _P, _P, _P, _I, _I, _I, _P],
-    "vdd_vit_qkv_split": [_P, _P, _P, _P, _I, _I, _I, _I, _L, _I, _P],
+    "vdd_vit_qkv_split": [_P, _P, _P, _P, _I, _I, _I, _I, _L, _I, _I, _P],
 }
 _bound = False
 
@@ -355,7 +356,7 @@ def decode_attention_grouped(q, k_cache, v_cache, k_prefix, v_prefix, rows, grou
     return out
 
 
-def flash_attention(q, k_cache, v_cache, seqs, n_seq, max_tq, H, Hkv, D, causal=True, out=None, k_prefix=None, v_prefix=None):
+def flash_attention(q, k_cache, v_cache, seqs, n_seq, max_tq, H, Hkv, D, causal=True, out=None, k_prefix=None, v_prefix=None, scale=None):
     """Prefill attention.  q [Ttot, H*D] packed by sequence; seqs int32 [n_seq, 6] =
     (q_row0, Tq, pos0, slot, prefix_slot, prefix_len): query i of a sequence sits at position pos0+i and
     attends keys [0, pos0+i] (causal) or [0, pos0+Tq) (non-causal) of its slot / prefix slot."""
@@ -365,7 +366,7 @@ def flash_attention(q, k_cache, v_cache, seqs, n_seq, max_tq, H, Hkv, D, causal=
     v_prefix = v_cache if v_prefix is None else v_prefix
     _lib.check(_lib_ready().vdd_flash_attention(q.data_ptr(), k_cache.data_ptr(), v_cache.data_ptr(), k_prefix.data_ptr(), v_prefix.data_ptr(),
                                                 seqs.data_ptr(), out.data_ptr(), n_seq, max_tq, H, Hkv, D, k_cache.stride(0),
-                                                k_cache.shape[2], k_prefix.stride(0), k_prefix.shape[2], D ** -0.5,
+                                                k_cache.shape[2], k_prefix.stride(0), k_prefix.shape[2], D ** -0.5 if scale is None else float(scale),
                                                 1 if causal else 0, _st(q)))
     return out
 
@@ -413,10 +414,22 @@ def vit_assemble(emb, cls, pos, n, T, out=None):
     return out
 
 
-def vit_qkv_split(qkv, k_cache, v_cache, n, T, H, D, q_out=None):
-    """qkv [n * T, 3 * H * D] -> q [n * T, H * D]; K / V written to caches [>= n, H, t_max, D]."""
+def vit_qkv_split(qkv, k_cache, v_cache, n, T, H, D, q_out=None, kv_only=False):
+    """qkv [n * T, 3 * H * D] -> q [n * T, H * D]; K / V written to caches [>= n, H, t_max, D] (or views of them starting at a later
+    token).  kv_only: the input is a fused [k, v] projection [n * T, 2 * H * D] (cross-attention); returns None."""
     _bf16(qkv, k_cache, v_cache)
-    q_out = torch.empty(n * T, H * D, dtype=qkv.dtype, device=qkv.device) if q_out is None else q_out
-    _lib.check(_lib_ready().vdd_vit_qkv_split(qkv.data_ptr(), q_out.data_ptr(), k_cache.data_ptr(), v_cache.data_ptr(), n, T, H, D,
-                                              k_cache.stride(0), k_cache.shape[2], _st(qkv)))
-    return q_out
+    if not kv_only:
+        q_out = torch.empty(n * T, H * D, dtype=qkv.dtype, device=qkv.device) if q_out is None else q_out
+    _lib.check(_lib_ready().vdd_vit_qkv_split(qkv.data_ptr(), q_out.data_ptr() if not kv_only else None, k_cache.data_ptr(), v_cache.data_ptr(),
+                                              n, T, H, D, k_cache.stride(0), k_cache.stride(1) // D, 2 if kv_only else 3, _st(qkv)))
+    return None if kv_only else q_out
+
+
+def add(a, b, out=None):
+    """out = a + b (bf16, same shape, contiguous)."""
+    _bf16(a, b)
+    if a.shape != b.shape or not a.is_contiguous() or not b.is_contiguous():
+        raise ValueError("add takes two contiguous tensors of one shape")
+    out = torch.empty_like(a) if out is None else out
+    _lib.check(_lib_ready().vdd_add(a.data_ptr(), b.data_ptr(), out.data_ptr(), a.numel(), _st(a)))
+    return out
