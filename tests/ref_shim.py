@@ -1,9 +1,8 @@
 """Build-container-only loader for the REAL reference sample() (read-only import from
 /root/reference; nothing is copied).  Recipe: SURVEY.md Appendix B.
 
-Used by tests/golden/make_golden.py (fixture generation) and by
-tests/test_oracle_vs_reference.py (skipped wherever /root/reference is absent — it
-does not exist on the GPU box).
+Used by tests/golden/make_golden.py (fixture generation) only; /root/reference does not exist
+on the GPU box, and no test imports this module.
 """
 from __future__ import annotations
 
