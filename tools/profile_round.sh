@@ -21,6 +21,11 @@ for r in csv.DictReader(open(sys.argv[1])):
         rows[int(r["Grid_Size_X"]) // 512].append((int(r["End_Timestamp"]) - int(r["Start_Timestamp"])) / 1e3)
 for b, v in sorted(rows.items()):
     print(f"B={b:5d} n={len(v):5d} mean={statistics.mean(v):8.2f} us median={statistics.median(v):8.2f} us")
+# bench.py launches the roofline shape first (10 warm-up + 100 timed, beta = 0.1), then the beta = 1e-6 extra point (10 + 50) at the same grid
+v = rows.get(4096, [])
+if len(v) >= 170:
+    print(f"B= 4096 roofline leg (launches 11-110, the timed ones of `roofline`): mean={statistics.mean(v[10:110]):8.2f} us")
+    print(f"B= 4096 beta=1e-6 extra point (launches 121-170): mean={statistics.mean(v[120:170]):8.2f} us")
 PY
 rm -rf $OUT/trace
 for C in FETCH_SIZE WRITE_SIZE; do
