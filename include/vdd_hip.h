@@ -200,23 +200,24 @@ int vdd_decode_attention_fused(const void* qkv, const int32_t* pos, const int32_
  * group_rows[]; items[i] = {group, first_row_of_16_row_slice, item index inside the prefix, 0} (int32 x4) is the
  * host-built work list of the prefix pass (one wave per item and head); item j of a group covers keys
  * [j * 64 * prefix_chunks_per_item, (j + 1) * 64 * prefix_chunks_per_item) of its prefix.
- * With v_prefix_t8 (the vdd_prefix_v_transpose image of v_prefix) the prefix pass runs on MFMA: the rows of a slice are
- * the M dimension, each prefix byte leaves HBM once per group, and an item walks its 64-key chunks with an online
- * softmax so that it leaves ONE partial per (row, head).  Without it (prefix_chunks_per_item must be 1) a 64-key K/V tile
- * is staged once per slice in LDS.  Own tokens go through the split-KV kernel; one combine merges all partials.
+ * The prefix pass runs on MFMA from prefix_frag (the vdd_prefix_fragments image of k_prefix / v_prefix; required when
+ * n_items > 0): the rows of a slice are the M dimension, each prefix byte leaves HBM once per group, and an item walks its
+ * 64-key chunks with an online softmax so that it leaves ONE partial per (row, head).  Own tokens: one wave per (row, head)
+ * that also merges the prefix partials (own ranges <= 256 keys), else the split-KV kernel + one combine.
  * Workspace: vdd_decode_attention_workspace_bytes(M, H, D, round_up(max_prefix_len, 64) + round_up(max_own_len, 64)). */
 int vdd_decode_attention_grouped(const void* q, const void* k_cache, const void* v_cache, const void* k_prefix, const void* v_prefix,
-                                 const void* v_prefix_t8 /* optional: vdd_prefix_v_transpose image -> MFMA prefix pass */,
+                                 const void* prefix_frag /* vdd_prefix_fragments image, [n_slots][Hkv][2 * prefix_tmax][D] */,
                                  const int32_t* rows, const int32_t* groups, const int32_t* group_rows, const int32_t* items, int n_items,
                                  void* out, void* workspace, int M, int H, int Hkv, int D, int64_t slot_stride, int t_max,
                                  int64_t prefix_stride, int prefix_tmax, int max_prefix_len, int max_own_len,
                                  int prefix_chunks_per_item, float scale, void* hip_stream);
 
-/* Key-blocked transposed copy of the prefix pool's V: v_prefix_t8[slot][kv_head][t/8][d][t%8] for t < prefix_len_of_slot[slot]
- * (same size and slot stride as v_prefix; t_max % 8 == 0).  Built once after the prefix prefill; lets the grouped decode
- * pass run both contractions on the matrix cores with every fragment loaded straight from HBM. */
-int vdd_prefix_v_transpose(const void* v_prefix, void* v_prefix_t8, const int32_t* prefix_len_of_slot, int n_slots, int Hkv, int t_max,
-                           int D, void* hip_stream);
+/* Fragment-major copy of the prefix pool for the MFMA prefix pass: prefix_frag[slot][kv_head][chunk] = one 32-KiB block per
+ * 64-key chunk (t_max % 64 == 0; twice the bytes and slot stride of k_prefix), 16 K fragments then 16 V^T fragments, each
+ * the 1-KiB lane-linear image of one 16x16x32 MFMA operand; keys >= prefix_len_of_slot[slot] are zero-filled.  Built once
+ * after the prefix prefill; every fragment load of the decode pass is then one contiguous KiB straight from HBM. */
+int vdd_prefix_fragments(const void* k_prefix, const void* v_prefix, void* prefix_frag, const int32_t* prefix_len_of_slot, int n_slots,
+                         int Hkv, int t_max, int D, void* hip_stream);
 
 /* Prefill attention (MFMA, flash-style).  q/out [Ttot, H*D] packed by sequence; seqs[s] = {q_row0, Tq, pos0,
  * slot, prefix_slot, prefix_len} (int32 x6): query i of sequence s sits at position pos0+i and attends keys

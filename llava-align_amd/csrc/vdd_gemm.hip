@@ -71,7 +71,7 @@ struct GemmArgs {
     int dp_rounds;               // whole-tile rounds before the stream-K part (host-chosen schedule)
 };
 
-template <int BM, int BN, int WM, int WN, int EPI, int VAR = 0>     // VAR: schedule experiments (bit 0 s_setprio around MFMA runs, bit 1 DMA over two k-steps)
+template <int BM, int BN, int WM, int WN, int EPI>
 __global__ void __launch_bounds__(WM * WN * 64) gemm_kernel(const GemmArgs a) {
 #if defined(__HIP_DEVICE_COMPILE__)   // the host pass only needs the launch stub: it drops a kernel whose body holds LDS-DMA builtins
     constexpr int NW = WM * WN, NT = NW * 64;
@@ -204,25 +204,6 @@ __global__ void __launch_bounds__(WM * WN * 64) gemm_kernel(const GemmArgs a) {
                 if (with_reads && i < NRD) __builtin_amdgcn_sched_group_barrier(0x100, 1, 0);
             }
         };
-        auto interleave_n = [&](int n_dma, bool with_reads) {
-#pragma unroll
-            for (int i = 0; i < NMMA; ++i) {
-                __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
-                if (i < n_dma) __builtin_amdgcn_sched_group_barrier(0x020, 1, 0);
-                if (with_reads && i < NRD) __builtin_amdgcn_sched_group_barrier(0x100, 1, 0);
-            }
-        };
-        auto stage_part = [&](int t, int buf, int half) {       // first / second half of the tile's LDS-DMA instructions
-            const int so = t * 128;
-#pragma unroll
-            for (int j = 0; j < XJ; ++j)
-                if ((j < (XJ + 1) / 2) == (half == 0))
-                    __builtin_amdgcn_raw_ptr_buffer_load_lds(rx, (lds_ptr_t)(lds + buf * BUF + (j * NW + wave) * 1024), 16, xoff[j], so, 0, 0);
-#pragma unroll
-            for (int j = 0; j < WJ; ++j)
-                if ((j < (WJ + 1) / 2) == (half == 0))
-                    __builtin_amdgcn_raw_ptr_buffer_load_lds(rw, (lds_ptr_t)(lds + buf * BUF + (XIMG + j * NW + wave) * 1024), 16, woff[j], so, 0, 0);
-        };
         bf16x8_t xg[4][MI], wg[4][NI];
         auto rd = [&](int buf, int kk) {
 #pragma unroll
@@ -240,29 +221,16 @@ __global__ void __launch_bounds__(WM * WN * 64) gemm_kernel(const GemmArgs a) {
         __builtin_amdgcn_sched_barrier(0);
         auto tile = [&](int t, int buf, auto do_stage, auto do_next) {           // buf is a literal at every call site
             constexpr bool ST = decltype(do_stage)::value, NX = decltype(do_next)::value;
-            if constexpr (VAR & 1) __builtin_amdgcn_s_setprio(1);
             rd(buf, 2); mm(0); interleave(false, true); __builtin_amdgcn_sched_barrier(0);
             rd(buf, 3); mm(1); interleave(false, true); __builtin_amdgcn_sched_barrier(0);
-            if constexpr (VAR & 1) __builtin_amdgcn_s_setprio(0);
             asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");   // own fragment reads of this tile done; tile t+1 landed
             __builtin_amdgcn_s_barrier();
             __builtin_amdgcn_sched_barrier(0);
-            if constexpr (VAR & 1) __builtin_amdgcn_s_setprio(1);
-            if constexpr (VAR & 2) {
-                if constexpr (ST) stage_part(t + 2, buf, 0);
-                if constexpr (NX) rd(buf ^ 1, 0);
-                mm(2); interleave_n(ST ? NLD / 2 : 0, NX); __builtin_amdgcn_sched_barrier(0);
-                if constexpr (ST) stage_part(t + 2, buf, 1);
-                if constexpr (NX) rd(buf ^ 1, 1);
-                mm(3); interleave_n(ST ? NLD - NLD / 2 : 0, NX); __builtin_amdgcn_sched_barrier(0);
-            } else {
-                if constexpr (ST) stage(t + 2, buf);
-                if constexpr (NX) rd(buf ^ 1, 0);
-                mm(2); interleave(ST, NX); __builtin_amdgcn_sched_barrier(0);
-                if constexpr (NX) rd(buf ^ 1, 1);
-                mm(3); interleave(false, NX); __builtin_amdgcn_sched_barrier(0);
-            }
-            if constexpr (VAR & 1) __builtin_amdgcn_s_setprio(0);
+            if constexpr (ST) stage(t + 2, buf);
+            if constexpr (NX) rd(buf ^ 1, 0);
+            mm(2); interleave(ST, NX); __builtin_amdgcn_sched_barrier(0);
+            if constexpr (NX) rd(buf ^ 1, 1);
+            mm(3); interleave(false, NX); __builtin_amdgcn_sched_barrier(0);
         };
         using T_ = std::true_type; using F_ = std::false_type;
         int t = 0;                                  // nk is even: tiles alternate between the two buffers
@@ -388,7 +356,7 @@ int num_workgroups() {
     return g_num_cu;
 }
 
-template <int BM, int BN, int WM, int WN, int VAR = 0>
+template <int BM, int BN, int WM, int WN>
 int launch_cfg(const GemmArgs& a0, int epi, int sched, void* workspace, int64_t workspace_bytes, hipStream_t st) {
     GemmArgs a = a0;
     const int ncols = epi == EPI_SWIGLU ? 2 * a.N : a.N;
@@ -416,15 +384,12 @@ int launch_cfg(const GemmArgs& a0, int epi, int sched, void* workspace, int64_t 
     const size_t smem = 2 * (BM + BN) * 128;
 #define VDD_GEMM_LAUNCH(E)                                                                                            \
     case E: {                                                                                                         \
-        auto kfn = gemm_kernel<BM, BN, WM, WN, E, VAR>;                                                                  \
+        auto kfn = gemm_kernel<BM, BN, WM, WN, E>;                                                                       \
         static bool attr_set = false;                                                                                 \
         if (!attr_set) { (void)hipFuncSetAttribute((const void*)kfn, hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem); attr_set = true; } \
         hipLaunchKernelGGL(kfn, grid, block, smem, st, a);                                                            \
         break;                                                                                                        \
     }
-    if constexpr (VAR != 0) {
-        switch (epi) { VDD_GEMM_LAUNCH(EPI_NONE) default: return VDD_ERR_INVALID_ARG; }
-    } else
     switch (epi) {
         VDD_GEMM_LAUNCH(EPI_NONE)
         VDD_GEMM_LAUNCH(EPI_BIAS)
@@ -479,9 +444,6 @@ int vdd_gemm(const void* X, const void* W, void* Y, const void* bias, const void
         case 3: return launch_cfg<256, 128, 4, 2>(a, epilogue, sched, workspace, workspace_bytes, st);
         case 4: return launch_cfg<192, 256, 2, 4>(a, epilogue, sched, workspace, workspace_bytes, st);
         case 5: return launch_cfg<256, 192, 4, 2>(a, epilogue, sched, workspace, workspace_bytes, st);
-        case 9: return launch_cfg<256, 256, 2, 4, 1>(a, epilogue, sched, workspace, workspace_bytes, st);
-        case 10: return launch_cfg<256, 256, 2, 4, 2>(a, epilogue, sched, workspace, workspace_bytes, st);
-        case 11: return launch_cfg<256, 256, 2, 4, 3>(a, epilogue, sched, workspace, workspace_bytes, st);
         default: return VDD_ERR_INVALID_ARG;
     }
 }

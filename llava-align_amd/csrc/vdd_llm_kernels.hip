@@ -351,6 +351,9 @@ struct AttnRow { int slot, len, pslot, plen; };
 // The split turns one ~650-iteration latency chain per (row, head) into <= CH/4 iterations with
 // 8 x 16-B loads in flight per lane, and multiplies the number of independent waves by T/CH.
 constexpr int ATT_CH = 64;
+// a partial of the split-KV attention: D un-normalised output floats, then (running max, sum); records are 528 B so that every
+// store of one is 16-byte aligned (520-byte records cost the prefix pass 10 us of partial-line write traffic: tools/probes/hbm_stream_probe.hip)
+constexpr int ATT_PS = 128 + 4;
 
 template <int D>   // head dim 128
 __global__ void __launch_bounds__(256) decode_attn_kernel(const uint16_t* __restrict__ q, const uint16_t* __restrict__ kc,
@@ -365,7 +368,7 @@ __global__ void __launch_bounds__(256) decode_attn_kernel(const uint16_t* __rest
     if (head >= H) return;
     const int g = lane >> 4, j = lane & 15;
     const AttnRow ar = rows[row];
-    float* wsp = ws + (((size_t)row * H + head) * nchunk + chunk_base + chunk) * (D + 2);
+    float* wsp = ws + (((size_t)row * H + head) * nchunk + chunk_base + chunk) * ATT_PS;
     // own_only: the shared prefix [0, plen) is handled by the grouped MFMA kernel; this one starts at plen
     const int k0 = (own_only ? ar.plen : 0) + chunk * ATT_CH, k1 = min(ar.len, k0 + ATT_CH);
     if (k0 >= ar.len) {                                   // empty chunk: neutral partial
@@ -470,9 +473,9 @@ __global__ void __launch_bounds__(256) decode_attn_own_merge_kernel(const uint16
     }
     // fold in the prefix partials (every lane of a 16-lane group reads its 8 dims; group 0 stores)
     const int used_pre = npre > 0 ? (ar.plen + pre_keys - 1) / pre_keys : 0;
-    const float* base = ws + ((size_t)row * H + head) * nchunk * (D + 2);
+    const float* base = ws + ((size_t)row * H + head) * nchunk * ATT_PS;
     for (int c = 0; c < used_pre; ++c) {
-        const float* pp = base + (size_t)c * (D + 2);
+        const float* pp = base + (size_t)c * ATT_PS;
         const float mo = pp[D], lo_ = pp[D + 1];
         const float mn = fmaxf(m, mo);
         const float c0 = (m == -INFINITY) ? 0.f : __expf(m - mn), c1 = (mo == -INFINITY) ? 0.f : __expf(mo - mn);
@@ -504,13 +507,13 @@ __global__ void __launch_bounds__(256) decode_attn_combine_kernel(const float* _
     const int used_pre = npre > 0 ? (ar.plen + pre_keys - 1) / pre_keys : 0;
     const int own_len = npre > 0 ? ar.len - ar.plen : ar.len;
     const int used_own = min(nchunk - npre, (own_len + ATT_CH - 1) / ATT_CH);
-    const float* base = ws + ((size_t)row * H + head) * nchunk * (D + 2);
+    const float* base = ws + ((size_t)row * H + head) * nchunk * ATT_PS;
     float M = -INFINITY;
-    for (int c = 0; c < used_pre; ++c) M = fmaxf(M, base[c * (D + 2) + D]);
-    for (int c = 0; c < used_own; ++c) M = fmaxf(M, base[(npre + c) * (D + 2) + D]);
+    for (int c = 0; c < used_pre; ++c) M = fmaxf(M, base[c * ATT_PS + D]);
+    for (int c = 0; c < used_own; ++c) M = fmaxf(M, base[(npre + c) * ATT_PS + D]);
     float L = 0.f, a0 = 0.f, a1 = 0.f;
     auto add = [&](int c) {
-        const float* p = base + c * (D + 2);
+        const float* p = base + c * ATT_PS;
         const float w = __expf(p[D] - M);
         L += w * p[D + 1];
         const float2 v = *reinterpret_cast<const float2*>(p + 2 * lane);
@@ -646,45 +649,66 @@ __global__ void __launch_bounds__(NW * 64) decode_attn_fused_kernel(const uint16
 struct GroupDesc { int row_off, n_rows, pslot, plen; };
 
 // ------------------------------------------------------------------ prefix pass on the matrix cores
-// V of a shared prefix is static during decoding, so a second copy is kept key-blocked and transposed
-// (VT8: [slot][kv_head][t/8][d][t%8], built once per generate by vt8_transpose_kernel).  With it every operand of
-// both contractions is k-contiguous in HBM and the prefix pass needs no LDS and no barrier:
-//   S^T = K Q^T   A = K fragment (lane (i, g): 16 B of K[key(i)][32 ks + 8 g ..]), B = Q fragment (lane (query, g))
+// K and V of a shared prefix are static during decoding, so a second copy is kept in FRAGMENT-MAJOR order, built once per
+// generate by prefix_fragments_kernel: per (slot, kv head) and 64-key chunk one 32-KiB block = 16 K fragments + 16 V^T
+// fragments, each the 1-KiB lane-linear image of one MFMA operand (lane l at byte 16 l).  Every fragment load of the pass is
+// then one contiguous KiB (8 whole 128-byte lines) instead of 16 half-lines (K rows) or 4 x 256 B (a key-blocked V^T), both
+// contractions take their operands straight from HBM, and the pass needs no LDS and no barrier:
+//   S^T = K Q^T   A = K fragment (t, ks): lane (i, g) = 16 B of K[key_t(i)][32 ks + 8 g ..], B = Q fragment (lane (query, g))
 //                 C layout: column = query, row i = 4 g + r.  The key assigned to MFMA row i is chosen as
 //                 key_a(i) = k0 + 8 (i/4) + i%4 for tile a and key_b(i) = key_a(i) + 4 for tile b, so that the 8
 //                 probabilities a lane holds after the softmax are the 8 CONSECUTIVE keys k0 + 8 g .. + 7:
-//   O = P V       A = P fragment = those 8 registers as they are (no re-layout), B = VT8 fragment (lane (dim, g):
-//                 16 B = V[k0 + 8 g .. + 7][dim]).
-// One wave = one (16-row slice of a group, head, 64-key chunk): 16 + 16 MFMAs, one-shot softmax over the chunk,
-// un-normalised partial to the workspace (merged by decode_attn_combine_kernel).
-__global__ void __launch_bounds__(256) vt8_transpose_kernel(const uint16_t* __restrict__ v, uint16_t* __restrict__ vt8, int t_max,
-                                                            int D, const int* __restrict__ plen_of_slot) {
-    // grid: (t_max / 8, n_kv_heads, n_slots); block 256: one 8-key x D tile
-    const int tb = blockIdx.x, head = blockIdx.y, slot = blockIdx.z;
-    if (tb * 8 >= plen_of_slot[slot]) return;
+//   O = P V       A = P fragment = those 8 registers as they are (no re-layout), B = V^T fragment (kk, nt): lane (j, g) =
+//                 V[k0 + 32 kk + 8 g .. + 7][8 j + nt]: column j of output tile nt is head dim 8 j + nt, so a lane ends up with
+//                 8 CONSECUTIVE dims of its 4 query rows and a partial row leaves as 16 lanes x 32 B = one contiguous 512 B.
+// One wave = one (16-row slice of a group, head, item of 64-key chunks): 16 + 16 MFMAs per chunk, online softmax across the
+// chunks, un-normalised partial to the workspace (merged by the own pass / decode_attn_combine_kernel).
+constexpr int FRAG_CHUNK_ELEMS = 2 * ATT_CH * 128;      // bf16 elements of one chunk's block (K then V^T)
+__global__ void __launch_bounds__(256) prefix_fragments_kernel(const uint16_t* __restrict__ k, const uint16_t* __restrict__ v,
+                                                               uint16_t* __restrict__ frag, int t_max, const int* __restrict__ plen_of_slot) {
+    // grid: (t_max / 64, n_kv_heads, n_slots); block 256: one 64-key chunk, D = 128
+    constexpr int D = 128;
+    const int chunk = blockIdx.x, head = blockIdx.y, slot = blockIdx.z, plen = plen_of_slot[slot], k0 = chunk * ATT_CH;
+    if (k0 >= plen) return;
     const size_t base = ((size_t)slot * gridDim.y + head) * (size_t)t_max * D;
-    __shared__ uint16_t tile[8][128 + 2];
-    const int plen = plen_of_slot[slot];
-    for (int e = threadIdx.x; e < 8 * D; e += 256)      // rows past the prefix are zeroed: they meet p = 0 in the MFMA and must be finite
-        tile[e / D][e % D] = (tb * 8 + e / D < plen) ? v[base + (size_t)(tb * 8) * D + e] : (uint16_t)0;
+    uint16_t* out = frag + 2 * base + (size_t)chunk * FRAG_CHUNK_ELEMS;
+    const uint4 zero = make_uint4(0, 0, 0, 0);          // keys past the prefix: they meet p = 0 in the MFMA and must be finite
+    __shared__ uint16_t tile[ATT_CH][D + 8];
+    for (int p = threadIdx.x; p < ATT_CH * D / 8; p += 256) {
+        const int key = p / (D / 8), c = p % (D / 8);
+        *reinterpret_cast<uint4*>(&tile[key][c * 8]) = k0 + key < plen ? *reinterpret_cast<const uint4*>(v + base + (size_t)(k0 + key) * D + c * 8) : zero;
+    }
+    for (int p = threadIdx.x; p < 1024; p += 256) {     // K fragments: 16-byte pieces of K rows, re-ordered
+        const int t = p >> 8, ks = (p >> 6) & 3, lane = p & 63, ln = lane & 15, g = lane >> 4;
+        const int key = k0 + (t >> 1) * 32 + (ln >> 2) * 8 + (t & 1) * 4 + (ln & 3);
+        *reinterpret_cast<uint4*>(out + (size_t)p * 8) = key < plen ? *reinterpret_cast<const uint4*>(k + base + (size_t)key * D + ks * 32 + g * 8) : zero;
+    }
     __syncthreads();
-    for (int e = threadIdx.x; e < 8 * D; e += 256) vt8[base + (size_t)(tb * 8) * D + e] = tile[e % 8][e / 8];
+    for (int p = threadIdx.x; p < 1024; p += 256) {     // V^T fragments: 8 keys of one dim per lane
+        const int kk = p >> 9, nt = (p >> 6) & 7, lane = p & 63, ln = lane & 15, g = lane >> 4;
+        uint16_t e[8];
+#pragma unroll
+        for (int i = 0; i < 8; ++i) e[i] = tile[kk * 32 + g * 8 + i][ln * 8 + nt];
+        uint4 o;
+        o.x = e[0] | ((uint32_t)e[1] << 16); o.y = e[2] | ((uint32_t)e[3] << 16); o.z = e[4] | ((uint32_t)e[5] << 16); o.w = e[6] | ((uint32_t)e[7] << 16);
+        *reinterpret_cast<uint4*>(out + ATT_CH * D + (size_t)p * 8) = o;
+    }
 }
 
 // waves-per-SIMD hint 4: left alone the compiler hoists all 16 K (then V) fragment loads of a chunk and lands at 140
 // registers = 3 waves per SIMD; capped at 128 the pass is 10 % faster (tools/attn_probe.py: 314 -> 274 us per layer).
 template <int D>
-__global__ void __launch_bounds__(256, 2) decode_attn_prefix_mfma_kernel(const uint16_t* __restrict__ q, const uint16_t* __restrict__ kpre,
-                                                                      const uint16_t* __restrict__ vt8, const GroupDesc* __restrict__ groups,
+__global__ void __launch_bounds__(256, 2) decode_attn_prefix_mfma_kernel(const uint16_t* __restrict__ q, const uint16_t* __restrict__ frag,
+                                                                      const GroupDesc* __restrict__ groups,
                                                                       const int* __restrict__ group_rows, const int4* __restrict__ items,
                                                                       float* __restrict__ ws, int H, int Hkv, long long pre_stride,
                                                                       int pre_tmax, float scale, int nchunk, int sub) {
     static_assert(D == 128, "");
     constexpr int KS = D / 32, NT = D / 16;
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, ln = lane & 15, g = lane >> 4;
-    const int head = blockIdx.y * 4 + wave;
+    const int head = blockIdx.x * 4 + wave;               // head groups fastest: the (long-first) item list is walked in order
     if (head >= H) return;
-    const int4 item = items[blockIdx.x];
+    const int4 item = items[blockIdx.y];
     const GroupDesc gd = groups[item.x];
     // an item = `sub` consecutive 64-key chunks (online softmax across them): one partial per (row, head, item)
     const int r0 = item.y, part = item.z, kbeg = part * ATT_CH * sub;
@@ -700,9 +724,7 @@ __global__ void __launch_bounds__(256, 2) decode_attn_prefix_mfma_kernel(const u
 #pragma unroll
         for (int ks = 0; ks < KS; ++ks) qf[ks] = *reinterpret_cast<const bf16x8_t*>(qp + ks * 32);
     }
-    const size_t hbase = (size_t)gd.pslot * pre_stride + (size_t)kvh * pre_tmax * D;
-    const uint16_t* kb = kpre + hbase;
-    const uint16_t* vb = vt8 + hbase;
+    const uint16_t* fb = frag + 2 * ((size_t)gd.pslot * pre_stride + (size_t)kvh * pre_tmax * D) + (size_t)lane * 8;
     f32x4_t o[NT];
 #pragma unroll
     for (int nt = 0; nt < NT; ++nt) o[nt] = f32x4_t{0.f, 0.f, 0.f, 0.f};
@@ -714,28 +736,20 @@ __global__ void __launch_bounds__(256, 2) decode_attn_prefix_mfma_kernel(const u
     for (int ci = 0; ci < nch_i; ++ci) {
         const int cc = ci + rot < nch_i ? ci + rot : ci + rot - nch_i;
         const int k0 = kbeg + cc * ATT_CH;
-        // The pass is a pure stream of K and V^T (one wave reads 2 x 16 KiB per chunk and nobody else reads them), so what
-        // matters is bytes in flight: ALL 32 fragment loads of the chunk (32 KiB per wave) are issued before the first MFMA.
-        // Issued a few at a time behind their consumers (as the compiler schedules them under a 128-VGPR cap) the pass ran at
-        // 4.2 TB/s with 1-2 loads in flight per wave in its P V half.
+        // The pass is a pure stream (one wave reads the chunk's 32-KiB block and nobody else does), so what matters is bytes in
+        // flight: ALL 32 fragment loads of the chunk are issued before the first MFMA.  Issued a few at a time behind their
+        // consumers (as the compiler schedules them under a 128-VGPR cap) the pass ran at 4.2 TB/s with 1-2 loads in flight
+        // per wave in its P V half.
         bf16x8_t kf[4][KS], vf[2][NT];
+        const uint16_t* cb = fb + (size_t)(k0 / ATT_CH) * FRAG_CHUNK_ELEMS;
 #pragma unroll
-        for (int t = 0; t < 4; ++t) {
-            int key = k0 + (t >> 1) * 32 + (ln >> 2) * 8 + (t & 1) * 4 + (ln & 3);
-            if (key >= k1) key = k1 - 1;
-            const uint16_t* kp = kb + (size_t)key * D + g * 8;
+        for (int t = 0; t < 4; ++t)
 #pragma unroll
-            for (int ks = 0; ks < KS; ++ks) kf[t][ks] = *reinterpret_cast<const bf16x8_t*>(kp + ks * 32);
-        }
+            for (int ks = 0; ks < KS; ++ks) kf[t][ks] = *reinterpret_cast<const bf16x8_t*>(cb + (t * KS + ks) * 512);
 #pragma unroll
-        for (int kk = 0; kk < 2; ++kk) {
-            // B fragment lane (dim = 16 nt + ln, g) = V[k0 + 32 kk + 8 g .. + 7][dim] = 16 B of the VT8 image
-            int kblk = (k0 + kk * 32) / 8 + g;
-            if (kblk * 8 >= k1) kblk = (k1 - 1) / 8;      // fully masked 8-key block: any finite data will do (p = 0)
-            const uint16_t* vp = vb + ((size_t)kblk * D) * 8 + (size_t)ln * 8;
+        for (int kk = 0; kk < 2; ++kk)
 #pragma unroll
-            for (int nt = 0; nt < NT; ++nt) vf[kk][nt] = *reinterpret_cast<const bf16x8_t*>(vp + (size_t)nt * 16 * 8);
-        }
+            for (int nt = 0; nt < NT; ++nt) vf[kk][nt] = *reinterpret_cast<const bf16x8_t*>(cb + ATT_CH * D + (kk * NT + nt) * 512);
         __builtin_amdgcn_sched_barrier(0);
         // S^T: 4 tiles (a0, b0 | a1, b1); MFMA row i = ln of the A operand
         f32x4_t s[4];
@@ -788,20 +802,20 @@ __global__ void __launch_bounds__(256, 2) decode_attn_prefix_mfma_kernel(const u
             }
         }
     }
-    // O's C layout: column = dim 16 nt + ln, row = query 4 g + r
+    // O's C layout: column ln of tile nt = dim 8 ln + nt, row = query 4 g + r
 #pragma unroll
     for (int r = 0; r < 4; ++r) {
         const int rr = r0 + g * 4 + r;
         if (rr < gd.n_rows) {
             const int orow = group_rows[gd.row_off + rr];
-            float* wsp = ws + (((size_t)orow * H + head) * nchunk + part) * (D + 2);
-#pragma unroll
-            for (int nt = 0; nt < NT; ++nt) wsp[nt * 16 + ln] = o[nt][r];
+            float* wsp = ws + (((size_t)orow * H + head) * nchunk + part) * ATT_PS + ln * 8;
+            *reinterpret_cast<float4*>(wsp) = make_float4(o[0][r], o[1][r], o[2][r], o[3][r]);
+            *reinterpret_cast<float4*>(wsp + 4) = make_float4(o[4][r], o[5][r], o[6][r], o[7][r]);
         }
     }
     if (g == 0 && r0 + ln < gd.n_rows) {          // (m, l) of query ln live in the lanes of column ln
-        float* wsp = ws + (((size_t)qrow * H + head) * nchunk + part) * (D + 2);
-        wsp[D] = mrun; wsp[D + 1] = lrun;
+        float* wsp = ws + (((size_t)qrow * H + head) * nchunk + part) * ATT_PS;
+        *reinterpret_cast<float2*>(wsp + D) = make_float2(mrun, lrun);
     }
 }
 
@@ -926,22 +940,22 @@ int vdd_decode_attention_fused(const void* qkv, const int32_t* pos, const int32_
 }
 
 int vdd_decode_attention_grouped(const void* q, const void* k_cache, const void* v_cache, const void* k_prefix, const void* v_prefix,
-                                 const void* v_prefix_t8, const int32_t* rows, const int32_t* groups, const int32_t* group_rows,
+                                 const void* prefix_frag, const int32_t* rows, const int32_t* groups, const int32_t* group_rows,
                                  const int32_t* items, int n_items, void* out, void* workspace, int M, int H, int Hkv, int D,
                                  int64_t slot_stride, int t_max, int64_t prefix_stride, int prefix_tmax, int max_prefix_len,
                                  int max_own_len, int prefix_chunks_per_item, float scale, void* stream) {
     if (M <= 0) return VDD_OK;
     if (!q || !k_cache || !v_cache || !k_prefix || !v_prefix || !rows || !groups || !group_rows || !items || !out || !workspace || D != 128 ||
-        H % Hkv != 0 || max_own_len <= 0 || max_prefix_len < 0 || n_items < 0 || prefix_chunks_per_item < 1) return VDD_ERR_INVALID_ARG;
-    if (n_items > 0 && v_prefix_t8 == nullptr) return VDD_ERR_INVALID_ARG;     // the MFMA prefix pass needs the transposed prefix V
+        H % Hkv != 0 || max_own_len <= 0 || max_prefix_len < 0 || n_items < 0 || n_items > 65535 || prefix_chunks_per_item < 1) return VDD_ERR_INVALID_ARG;
+    if (n_items > 0 && (prefix_frag == nullptr || prefix_tmax % ATT_CH != 0)) return VDD_ERR_INVALID_ARG;     // the MFMA prefix pass reads the fragment-major image
     const int sub = prefix_chunks_per_item;                                     // it leaves one partial per item of `sub` 64-key chunks
     const int pre_keys = ATT_CH * sub;
     const int npre = (max_prefix_len + pre_keys - 1) / pre_keys, nown = (max_own_len + ATT_CH - 1) / ATT_CH;
     const int nchunk = npre + nown;
     hipStream_t st = (hipStream_t)stream;
     if (n_items > 0 && npre > 0) {
-        hipLaunchKernelGGL(decode_attn_prefix_mfma_kernel<128>, dim3(n_items, (H + 3) / 4), dim3(256), 0, st,
-                           (const uint16_t*)q, (const uint16_t*)k_prefix, (const uint16_t*)v_prefix_t8, (const GroupDesc*)groups, group_rows,
+        hipLaunchKernelGGL(decode_attn_prefix_mfma_kernel<128>, dim3((H + 3) / 4, n_items), dim3(256), 0, st,
+                           (const uint16_t*)q, (const uint16_t*)prefix_frag, (const GroupDesc*)groups, group_rows,
                            (const int4*)items, (float*)workspace, H, Hkv, (long long)prefix_stride, prefix_tmax, scale, nchunk, sub);
     }
     if (max_own_len <= 256) {        // short own ranges: one wave per (row, head) finishes the row (own keys + prefix partials)
@@ -959,17 +973,17 @@ int vdd_decode_attention_grouped(const void* q, const void* k_cache, const void*
     return ok(hipSuccess);
 }
 
-int vdd_prefix_v_transpose(const void* v_prefix, void* v_prefix_t8, const int32_t* prefix_len_of_slot, int n_slots, int Hkv, int t_max,
-                           int D, void* stream) {
+int vdd_prefix_fragments(const void* k_prefix, const void* v_prefix, void* prefix_frag, const int32_t* prefix_len_of_slot, int n_slots,
+                         int Hkv, int t_max, int D, void* stream) {
     if (n_slots <= 0) return VDD_OK;
-    if (!v_prefix || !v_prefix_t8 || !prefix_len_of_slot || D != 128 || t_max % 8 != 0) return VDD_ERR_INVALID_ARG;
-    hipLaunchKernelGGL(vt8_transpose_kernel, dim3(t_max / 8, Hkv, n_slots), dim3(256), 0, (hipStream_t)stream, (const uint16_t*)v_prefix,
-                       (uint16_t*)v_prefix_t8, t_max, D, prefix_len_of_slot);
+    if (!k_prefix || !v_prefix || !prefix_frag || !prefix_len_of_slot || D != 128 || t_max % ATT_CH != 0) return VDD_ERR_INVALID_ARG;
+    hipLaunchKernelGGL(prefix_fragments_kernel, dim3(t_max / ATT_CH, Hkv, n_slots), dim3(256), 0, (hipStream_t)stream,
+                       (const uint16_t*)k_prefix, (const uint16_t*)v_prefix, (uint16_t*)prefix_frag, t_max, prefix_len_of_slot);
     return ok(hipSuccess);
 }
 
 int64_t vdd_decode_attention_workspace_bytes(int M, int H, int D, int max_len) {
-    return (int64_t)M * H * ((max_len + ATT_CH - 1) / ATT_CH) * (D + 2) * 4;
+    return (int64_t)M * H * ((max_len + ATT_CH - 1) / ATT_CH) * ATT_PS * 4;
 }
 
 }  // extern "C"

@@ -336,14 +336,14 @@ class KVCache:
                            for _ in range(lm.n_layers)]
         self.kp, self.vp = mk(n_pre, t_pre), mk(n_pre, t_pre)
         self.ko, self.vo = mk(n_own, t_own), mk(n_own, t_own)
-        # key-blocked transposed copy of the prefix V ([slot][head][t/8][d][t%8]) for the MFMA prefix pass of decode
-        self.vp8 = mk(n_pre, t_pre)
+        # fragment-major copy of the prefix K / V (one 32-KiB block of MFMA operand images per 64-key chunk) for the decode prefix pass
+        self.pfrag = mk(n_pre, 2 * t_pre)
 
     def fits(self, n_pre, t_pre, n_own, t_own):
         return n_pre <= self.n_pre and t_pre <= self.t_pre and n_own <= self.n_own and t_own <= self.t_own
 
     def nbytes(self):
-        return sum(t.numel() * 2 for pool in (self.kp, self.vp, self.vp8, self.ko, self.vo) for t in pool)
+        return sum(t.numel() * 2 for pool in (self.kp, self.vp, self.pfrag, self.ko, self.vo) for t in pool)
 
 
 def h2d_int32(device, *arrays):
@@ -451,7 +451,7 @@ class LanguageModel:
                 att = ops.decode_attention_grouped(q, kv.ko[i], kv.vo[i], kv.kp[i], kv.vp[i], attn_rows, grouping["groups"],
                                                    grouping["group_rows"], grouping["items"], grouping["n_items"], H, Hkv, D,
                                                    kv.t_pre, kv.t_own, workspace=grouping["workspace"],
-                                                   v_prefix_t8=kv.vp8[i], chunks_per_item=grouping["cpi"])
+                                                   prefix_frag=kv.pfrag[i], chunks_per_item=grouping["cpi"])
             else:
                 q = ops.rope_kv_write(qkv, pos, slot, self.cs, kv.ko[i], kv.vo[i], H, Hkv, D, cpos=cpos)
                 att = ops.decode_attention(q, kv.ko[i], kv.vo[i], attn_rows, H, Hkv, D, k_prefix=kv.kp[i], v_prefix=kv.vp[i],
@@ -768,7 +768,7 @@ class VddLlavaEngine:
                 if self.group_attention:
                     (plen_t,) = h2d_int32(dev, [s_["T"] for s_ in segs])
                     for li in range(lm.n_layers):
-                        ops.prefix_v_transpose(kv.vp[li], kv.vp8[li], plen_t)
+                        ops.prefix_fragments(kv.kp[li], kv.vp[li], kv.pfrag[li], plen_t)
             else:
                 last, last_seqs = h2d_int32(dev, [s["q_row0"] + s["T"] - 1 for s in segs],
                                             [[i, 1, s["pos0"] + s["T"] - 1, s["slot"], s["pslot"], s["plen"]] for i, s in enumerate(segs)])

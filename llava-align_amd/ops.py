@@ -22,7 +22,7 @@ _SIGS = {
     "vdd_embed": [_P, _P, _P, _I, _I, _I, _P],
     "vdd_skinny_gemm": [_P, _P, _P, _P, _P, _I, _I, _I, _I, _L, _L, _L, _P],
     "vdd_decode_attention": [_P, _P, _P, _P, _P, _P, _P, _P, _I, _I, _I, _I, _L, _I, _L, _I, _I, _F, _P],
-    "vdd_prefix_v_transpose": [_P, _P, _P, _I, _I, _I, _I, _P],
+    "vdd_prefix_fragments": [_P, _P, _P, _P, _I, _I, _I, _I, _P],
     "vdd_decode_attention_grouped": [_P, _P, _P, _P, _P, _P, _P, _P, _P, _P, _I, _P, _P, _I, _I, _I, _I, _L, _I, _L, _I, _I, _I, _I, _F, _P],
     "vdd_flash_attention": [_P, _P, _P, _P, _P, _P, _P, _I, _I, _I, _I, _I, _L, _I, _L, _I, _F, _I, _P],
     "vdd_layernorm": [_P, _P, _P, _P, _I, _I, _F, _P],
@@ -313,27 +313,31 @@ def prefix_chunks_per_item(groups, n_heads, target_waves=2048, max_chunks=16):
 
 def prefix_work_items(groups, chunks_per_item=1):
     """groups [[row_off, n_rows, pslot, plen], ...] -> work list [[group, first_row, item, 0], ...] of the prefix pass; item j
-    covers keys [j * 64 * chunks_per_item, (j + 1) * 64 * chunks_per_item) of the group's prefix."""
+    covers keys [j * 64 * chunks_per_item, (j + 1) * 64 * chunks_per_item) of the group's prefix.  Longest items first: the pass
+    is one wave per (item, head) with no other load balancing, so the short ones (the image-free group's) fill the tail."""
     items = []
     keys = 64 * chunks_per_item
     for gi, (_, n_rows, _, plen) in enumerate(groups):
         for r0 in range(0, n_rows, 16):
             for c in range((plen + keys - 1) // keys):
-                items.append([gi, r0, c, 0])
-    return items
+                items.append((-min(keys, plen - c * keys), len(items), [gi, r0, c, 0]))
+    return [it for _, _, it in sorted(items)]
 
 
-def prefix_v_transpose(v_prefix, v_prefix_t8, prefix_len_of_slot):
-    """v_prefix [n_slots, Hkv, t_max, D] -> v_prefix_t8 (same shape/bytes, layout [slot][head][t/8][d][t%8])."""
-    _bf16(v_prefix, v_prefix_t8)
-    n, Hkv, t_max, D = v_prefix.shape
-    _lib.check(_lib_ready().vdd_prefix_v_transpose(v_prefix.data_ptr(), v_prefix_t8.data_ptr(), prefix_len_of_slot.data_ptr(),
-                                                   prefix_len_of_slot.numel(), Hkv, t_max, D, _st(v_prefix)))
-    return v_prefix_t8
+def prefix_fragments(k_prefix, v_prefix, prefix_frag, prefix_len_of_slot):
+    """k_prefix / v_prefix [n_slots, Hkv, t_max, D] -> prefix_frag [n_slots, Hkv, 2 * t_max, D]: per 64-key chunk one 32-KiB block of
+    MFMA operand images (16 K fragments, 16 V^T fragments) for the grouped decode pass."""
+    _bf16(k_prefix, v_prefix, prefix_frag)
+    n, Hkv, t_max, D = k_prefix.shape
+    if tuple(prefix_frag.shape) != (n, Hkv, 2 * t_max, D) or v_prefix.shape != k_prefix.shape or not prefix_frag.is_contiguous():
+        raise ValueError("prefix_frag must be a contiguous [n_slots, Hkv, 2 * t_max, D] tensor")
+    _lib.check(_lib_ready().vdd_prefix_fragments(k_prefix.data_ptr(), v_prefix.data_ptr(), prefix_frag.data_ptr(), prefix_len_of_slot.data_ptr(),
+                                                 prefix_len_of_slot.numel(), Hkv, t_max, D, _st(k_prefix)))
+    return prefix_frag
 
 
 def decode_attention_grouped(q, k_cache, v_cache, k_prefix, v_prefix, rows, groups, group_rows, items, n_items,
-                             H, Hkv, D, max_prefix_len, max_own_len, out=None, workspace=None, v_prefix_t8=None, chunks_per_item=1):
+                             H, Hkv, D, max_prefix_len, max_own_len, out=None, workspace=None, prefix_frag=None, chunks_per_item=1, scale=None):
     """decode_attention with the shared prefixes attended once per group of rows (MFMA over the group's queries)."""
     _bf16(q, k_cache, v_cache, k_prefix, v_prefix)
     M = q.shape[0]
@@ -349,10 +353,10 @@ def decode_attention_grouped(q, k_cache, v_cache, k_prefix, v_prefix, rows, grou
         _attn_ws[(q.device,)] = ws
     out = torch.empty_like(q) if out is None else out
     _lib.check(lib.vdd_decode_attention_grouped(q.data_ptr(), k_cache.data_ptr(), v_cache.data_ptr(), k_prefix.data_ptr(), v_prefix.data_ptr(),
-                                                v_prefix_t8.data_ptr() if v_prefix_t8 is not None else None, rows.data_ptr(), groups.data_ptr(), group_rows.data_ptr(), items.data_ptr(), n_items,
+                                                prefix_frag.data_ptr() if prefix_frag is not None else None, rows.data_ptr(), groups.data_ptr(), group_rows.data_ptr(), items.data_ptr(), n_items,
                                                 out.data_ptr(), ws.data_ptr(), M, H, Hkv, D, k_cache.stride(0), k_cache.shape[2],
                                                 k_prefix.stride(0), k_prefix.shape[2], int(max_prefix_len), int(max_own_len),
-                                                int(chunks_per_item), D ** -0.5, _st(q)))
+                                                int(chunks_per_item), D ** -0.5 if scale is None else scale, _st(q)))
     return out
 
 

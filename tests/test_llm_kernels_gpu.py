@@ -241,19 +241,32 @@ def test_grouped_prefix_decode_attention_equals_per_row():
     rt = torch.tensor(rows_p, dtype=torch.int32, device=DEV)
     a = O.decode_attention(q, ko, vo, rt, H, Hkv, D, k_prefix=kp, v_prefix=vp, max_len=768)
     items = O.prefix_work_items(groups)
-    with pytest.raises(ValueError):                     # the prefix pass needs the key-blocked transposed copy of the prefix V
+    with pytest.raises(ValueError):                     # the prefix pass needs the fragment-major image of the prefix K / V
         O.decode_attention_grouped(q, ko, vo, kp, vp, rt, torch.tensor(groups, dtype=torch.int32, device=DEV),
                                    torch.tensor(grp_rows_p, dtype=torch.int32, device=DEV),
                                    torch.tensor(items, dtype=torch.int32, device=DEV), len(items), H, Hkv, D, 611, 128)
-    # MFMA prefix pass on the key-blocked transposed copy of the prefix V
-    vp8 = torch.full_like(vp, float("nan"))
+    # MFMA prefix pass on the fragment-major image: per 64-key chunk 16 K fragments then 16 V^T fragments of 1 KiB (lane-linear)
+    pf = torch.full((kp.shape[0], Hkv, 2 * 640, D), float("nan"), dtype=torch.bfloat16, device=DEV)
     plen_of_slot = torch.tensor([611, 0, 36], dtype=torch.int32, device=DEV)
-    O.prefix_v_transpose(vp, vp8, plen_of_slot)
-    t8 = vp8[0].view(Hkv, 640 // 8, D, 8)
-    assert torch.equal(t8[:, :76].permute(0, 1, 3, 2).reshape(Hkv, 608, D), vp[0, :, :608])       # VT8[t/8][d][t%8] == V[t][d]
+    O.prefix_fragments(kp, vp, pf, plen_of_slot)
+    blk = pf[0].view(Hkv, 10, 2, 16, 64, 8)             # [head][chunk][K | V^T][fragment][lane][8]
+    ln, g = torch.arange(64, device=DEV) % 16, torch.arange(64, device=DEV) // 16
+    kz, vz = kp[0].clone(), vp[0].clone()
+    kz[:, 611:], vz[:, 611:] = 0, 0                     # keys past the prefix are zero-filled in the image
+    for t in range(4):
+        key = (t >> 1) * 32 + (ln >> 2) * 8 + (t & 1) * 4 + (ln & 3)                 # MFMA row -> key of tile t
+        for ks in range(4):
+            want = torch.stack([kz[:, c * 64 + key].view(Hkv, 64, 4, 4, 8)[:, torch.arange(64), ks, g] for c in range(10)], 1)
+            assert torch.equal(blk[:, :, 0, t * 4 + ks], want), (t, ks)
+    for kk in range(2):
+        for nt in range(8):
+            rows = (kk * 32 + g * 8)[:, None] + torch.arange(8, device=DEV)[None]     # [lane][8 keys]
+            want = torch.stack([vz[:, c * 64 + rows, (ln * 8 + nt)[:, None]] for c in range(10)], 1)          # column ln of tile nt = dim 8 ln + nt
+            assert torch.equal(blk[:, :, 1, kk * 8 + nt], want), (kk, nt)
+    assert torch.isnan(pf[1].float()).all() and not torch.isnan(pf[2, :, :128].float()).any()     # empty slot untouched; 36 keys = 1 chunk
     c = O.decode_attention_grouped(q, ko, vo, kp, vp, rt, torch.tensor(groups, dtype=torch.int32, device=DEV),
                                    torch.tensor(grp_rows_p, dtype=torch.int32, device=DEV),
-                                   torch.tensor(items, dtype=torch.int32, device=DEV), len(items), H, Hkv, D, 611, 128, v_prefix_t8=vp8)
+                                   torch.tensor(items, dtype=torch.int32, device=DEV), len(items), H, Hkv, D, 611, 128, prefix_frag=pf)
     assert torch.allclose(a.float(), c.float(), rtol=3e-2, atol=3e-2)
     # several 64-key chunks per work item (online softmax inside the wave, one partial per item): 2 -> 5 items cover 611 keys,
     # 4 -> 3 items with a ragged last one, 16 -> the whole prefix in one item
@@ -262,14 +275,14 @@ def test_grouped_prefix_decode_attention_equals_per_row():
         assert len(it) == sum(-(-n // 16) * -(-pl // (64 * cpi)) for _, n, _, pl in groups)
         cc = O.decode_attention_grouped(q, ko, vo, kp, vp, rt, torch.tensor(groups, dtype=torch.int32, device=DEV),
                                         torch.tensor(grp_rows_p, dtype=torch.int32, device=DEV),
-                                        torch.tensor(it, dtype=torch.int32, device=DEV), len(it), H, Hkv, D, 611, 128, v_prefix_t8=vp8,
+                                        torch.tensor(it, dtype=torch.int32, device=DEV), len(it), H, Hkv, D, 611, 128, prefix_frag=pf,
                                         chunks_per_item=cpi)
         assert torch.allclose(a.float(), cc.float(), rtol=3e-2, atol=3e-2), cpi
     # own ranges declared longer than 256 keys keep the split-KV own pass + combine; shorter ones finish in one wave per (row, head)
     it = O.prefix_work_items(groups, 4)
     long_own = O.decode_attention_grouped(q, ko, vo, kp, vp, rt, torch.tensor(groups, dtype=torch.int32, device=DEV),
                                           torch.tensor(grp_rows_p, dtype=torch.int32, device=DEV),
-                                          torch.tensor(it, dtype=torch.int32, device=DEV), len(it), H, Hkv, D, 611, 320, v_prefix_t8=vp8,
+                                          torch.tensor(it, dtype=torch.int32, device=DEV), len(it), H, Hkv, D, 611, 320, prefix_frag=pf,
                                           chunks_per_item=4)
     assert torch.allclose(a.float(), long_own.float(), rtol=3e-2, atol=3e-2)
     b = cc

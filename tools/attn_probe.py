@@ -12,8 +12,8 @@ T_OWN, T_PRE = (int(sys.argv[2]), int(sys.argv[3])) if len(sys.argv) > 3 else (1
 bf = lambda *s: torch.randn(*s, device=dev, dtype=torch.bfloat16)
 ko, vo = bf(2 * Q, Hkv, T_OWN, D), bf(2 * Q, Hkv, T_OWN, D)
 kp, vp = bf(G + 1, Hkv, T_PRE, D), bf(G + 1, Hkv, T_PRE, D)
-vp8 = torch.empty_like(vp)
-ops.prefix_v_transpose(vp, vp8, torch.tensor([PL] * G + [UPL], dtype=torch.int32, device=dev))
+pf = torch.empty((vp.shape[0], vp.shape[1], 2 * vp.shape[2], vp.shape[3]), dtype=vp.dtype, device=dev)
+ops.prefix_fragments(kp, vp, pf, torch.tensor([PL] * G + [UPL], dtype=torch.int32, device=dev))
 rows, groups, members = [], [], []
 for g in range(G):
     groups.append([len(members), PER, g, PL])
@@ -43,13 +43,15 @@ def timeit(fn, iters=50, warm=5):
     return e0.elapsed_time(e1) / iters * 1e3
 
 
+import os as _os
+SCALE = float(_os.environ["ATTN_SCALE"]) if "ATTN_SCALE" in _os.environ else None
 ref = None
 for rep in range(2):
     for cpi in (2, 4, 10):
         it = ops.prefix_work_items(groups, cpi)
         itt = torch.tensor(it, dtype=torch.int32, device=dev)
         f = lambda: ops.decode_attention_grouped(q, ko, vo, kp, vp, rt, gt, mt, itt, len(it), H, Hkv, D, PL, OWN, workspace=ws,
-                                                 v_prefix_t8=vp8, chunks_per_item=cpi)
+                                                 prefix_frag=pf, chunks_per_item=cpi, scale=SCALE)
         out = f()
         if ref is None:
             ref = out

@@ -13,8 +13,8 @@ M = 2 * Q
 bf = lambda *s: torch.randn(*s, device=dev, dtype=torch.bfloat16)
 ko, vo = bf(2 * Q, Hkv, 128, D), bf(2 * Q, Hkv, 128, D)
 kp, vp = bf(G + 1, Hkv, 640, D), bf(G + 1, Hkv, 640, D)
-vp8 = torch.empty_like(vp)
-ops.prefix_v_transpose(vp, vp8, torch.tensor([PL] * G + [UPL], dtype=torch.int32, device=dev))
+pf = torch.empty((vp.shape[0], vp.shape[1], 2 * vp.shape[2], vp.shape[3]), dtype=vp.dtype, device=dev)
+ops.prefix_fragments(kp, vp, pf, torch.tensor([PL] * G + [UPL], dtype=torch.int32, device=dev))
 rows, groups, members = [], [], []
 for g in range(G):
     groups.append([len(members), PER, g, PL])
@@ -36,7 +36,7 @@ Y = [torch.empty(M, w.shape[0], device=dev, dtype=torch.bfloat16) for w in W]
 
 
 def attn():
-    ops.decode_attention_grouped(q, ko, vo, kp, vp, rt, gt, mt, itt, len(it), H, Hkv, D, PL, OWN, out=out, workspace=ws, v_prefix_t8=vp8,
+    ops.decode_attention_grouped(q, ko, vo, kp, vp, rt, gt, mt, itt, len(it), H, Hkv, D, PL, OWN, out=out, workspace=ws, prefix_frag=pf,
                                  chunks_per_item=cpi)
 
 
