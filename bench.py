@@ -50,7 +50,7 @@ def parse_args():
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=3)
     ap.add_argument("--warmup", type=int, default=1)
-    ap.add_argument("--questions", type=int, default=384, help="questions per generate() batch per GPU (6 per image)")
+    ap.add_argument("--questions", type=int, default=768, help="questions per generate() batch per GPU (6 per image); 768 = 1,536 decode rows, ~220 GB of KV pools + weights")
     ap.add_argument("--model", default="llava-1.5-7b")
     ap.add_argument("--no-baselines", action="store_true")
     return ap.parse_args()
@@ -355,6 +355,7 @@ def main():
                 "decode_step": {"ms": round(ms_decode, 3), "rows": 2 * Q, "lm_weight_bytes": wbytes,
                                 "weight_stream_GBs": round(wbytes / (ms_decode * 1e-3) / 1e9, 1),
                                 "note": "per step the LM weights are streamed once for all rows; KV reads come on top"},
+                "hbm_peak_GB": round(torch.cuda.max_memory_allocated(dev) / 1e9, 1),
                 "prefill_tokens": out.stats["prefill_tokens"], "unshared_prefill_tokens": out.stats["unshared_prefill_tokens"],
                 "gemm": "hand-written MFMA kernels for every projection (csrc/vdd_gemm.hip; no hipBLASLt on the path)",
                 "roofline": roof, "roofline_extra": roof_extra}
@@ -379,7 +380,7 @@ def main():
             torch.cuda.synchronize(dev)
             t3 = time.perf_counter(); eng.generate(ids, **kw_h); torch.cuda.synchronize(dev); t_h = time.perf_counter() - t3
             line["pcie_inclusive"] = {"value": round(Q * n_new / t_h, 1), "unit": "tokens/s",
-                                      "note": "images passed as host fp32 tensors (64 x 1.35 MB pageable): upload and cast inside generate()"}
+                                      "note": f"images passed as host fp32 tensors ({n_img} x 1.35 MB pageable): upload and cast inside generate()"}
         if world == 1 and not a.no_baselines and not tiny:
             # single question in flight (the reference's own B=1 regime): latency-mode tokens/s of the engine
             ids1, imgs1 = pope_prompts(1, per_img=1, seed=99)
