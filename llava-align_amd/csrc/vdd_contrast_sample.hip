@@ -29,6 +29,7 @@
 // Roofline: HBM-bound; nothing here is a contraction, so no MFMA.
 
 #include <hip/hip_runtime.h>
+#include <type_traits>
 #include <stdint.h>
 #include <string.h>
 #include <stdio.h>
@@ -57,11 +58,9 @@ template <> struct Tr<VDD_BF16> {
     using bits_t = uint16_t;
     static constexpr int KEYBITS = 16, EPC = 8;
     static __device__ __forceinline__ float to_f(uint32_t b) { return __builtin_bit_cast(float, b << 16); }
-    static __device__ __forceinline__ uint32_t from_f(float f) {
-        uint32_t u = __builtin_bit_cast(uint32_t, f);
-        if ((u & 0x7fffffffu) > 0x7f800000u) return (u >> 16) | 0x40u;   // quiet NaN
-        return (u + 0x7fffu + ((u >> 16) & 1u)) >> 16;                    // RNE
-    }
+    // v_cvt_pk_bf16_f32: round to nearest even in one instruction (the shift / add / select form costs 7 per element, and the
+    // contrast arithmetic rounds four times per element like the reference's bf16 tensors do)
+    static __device__ __forceinline__ uint32_t from_f(float f) { return __builtin_bit_cast(uint16_t, (__bf16)f); }
     static constexpr uint32_t NEG_INF = 0xFF80u;
 };
 template <> struct Tr<VDD_F32> {
@@ -127,6 +126,7 @@ struct Smem {
     float self[2];
     // compact candidate list of the single-wave tail (rows with <= 64 finite scores)
     unsigned cand_n;
+    unsigned live_n;           // live chunks of pass B appended to the LiveList so far
     unsigned cand_rank[64];
     float cand_x[64];
     int cand_idx[64];
@@ -137,6 +137,11 @@ struct Smem {
 // back to integrating the fp32 mass by radix selection).  Carved behind Smem only when a launch has top-p on.
 constexpr int TOPP_EXACT_MAX = 1024;
 struct ToppScratch { float gx[TOPP_EXACT_MAX]; int gi[TOPP_EXACT_MAX]; float sp[TOPP_EXACT_MAX]; };
+
+// Pass B's compacted work list (same place as ToppScratch, which is only used after it): chunk index + the v chunk in, the
+// contrasted chunk out.  448 entries keep three 32000-wide bf16 rows per CU (40 KiB LDS row part + Smem + the list each).
+constexpr int LIVE_CAP = 448;
+struct LiveList { uint4 data[LIVE_CAP]; int ch[LIVE_CAP]; };
 
 __device__ __forceinline__ float wave_max(float v) {
 #pragma unroll
@@ -421,7 +426,7 @@ __global__ void __launch_bounds__(BLOCK, 6) vdd_contrast_sample_kernel(KP p) {
 
     float m = -INFINITY; int nfin = 0; int t_nan = 0, t_pinf = 0;
     const bool recip = (p.flags & VDD_TEMP_RECIPROCAL) != 0;
-    if (tid == 0) sm.cand_n = 0u;
+    if (tid == 0) { sm.cand_n = 0u; sm.live_n = 0u; }
     // Bit k set <=> this thread's k-th chunk (ch = tid + k * BLOCK) may hold a finite score.  After the plausibility mask a
     // row keeps a handful of candidates, and every pass over the working row costs ~10 VALU instructions per ELEMENT
     // (measured: 2.7 us per row for the mass pass alone, the passes after the scores store were 1/3 of the kernel), so
@@ -454,54 +459,108 @@ __global__ void __launch_bounds__(BLOCK, 6) vdd_contrast_sample_kernel(KP p) {
         // Where v < cutoff the result is -inf whatever c/d hold (:194), so the contrast
         // branches are only READ for chunks that contain a survivor: with the usual beta the
         // c/d rows cost a few 64-B sectors instead of V*e bytes each.
-        int kb = 0;
-        for (int base = tid; base < nch; base += UNR * BLOCK, kb += UNR) {
-            uint32_t qv[UNR][4];
-            if constexpr (!LDSROW) {       // global working row: batch the v re-reads (L2 / Infinity-Cache hits)
+        // A chunk with a survivor costs ~300 VALU instructions (8 elements x four roundings, an IEEE division, the mask),
+        // and run where the chunk is found it runs for ONE live lane of a wave at the price of 64: at 12 survivors per row that
+        // was +30 % on the launch, at 80 +105 %.  So the live chunks of the row are COMPACTED first: every thread appends its
+        // live chunks (index + the v chunk) to an LDS list, then the list is processed one entry per thread with all lanes busy
+        // (the c / d loads of a pass go out together), and the results are copied back into the row: by any thread for the LDS
+        // (or global) part, by the owner for its register-resident chunks.  Past LIVE_CAP entries a chunk is done in place.
+        LiveList& LL = *reinterpret_cast<LiveList*>(reinterpret_cast<unsigned char*>(&sm) + ((sizeof(Smem) + 15) & ~(size_t)15));
+        auto contrast_chunk = [&](auto both_c, int ch, const uint32_t* qv, const uint32_t* qc, const uint32_t* qd, uint32_t* x4) {
+            constexpr bool BOTH = decltype(both_c)::value;
+            if constexpr (Tr<DT>::KEYBITS == 16) { x4[0] = x4[1] = x4[2] = x4[3] = NINF | (NINF << 16); }
+            else { x4[0] = x4[1] = x4[2] = x4[3] = NINF; }
 #pragma unroll
-                for (int u = 0; u < UNR; ++u) { const int ch = base + u * BLOCK; if (ch < nch) gload<DT>(p.v, ov, ch, V, p.vec_in, qv[u]); }
-            }
-#pragma unroll
-            for (int u = 0; u < UNR; ++u) {
-                const int ch = base + u * BLOCK;
-                if (ch >= nch) continue;
-                if constexpr (LDSROW) R.get(ch, qv[u]);
-                bool live = false;
-#pragma unroll
-                for (int j = 0; j < EPC; ++j) {
-                    float vf = Tr<DT>::to_f(getb<DT>(qv[u], j));
-                    live |= !(vf < cutoff) && (ch * EPC + j < V);
+            for (int j = 0; j < EPC; ++j) {
+                const int idx = ch * EPC + j;
+                float vf = Tr<DT>::to_f(getb<DT>(qv, j)), cf = Tr<DT>::to_f(getb<DT>(qc, j));
+                if constexpr (BOTH) {
+                    float df = Tr<DT>::to_f(getb<DT>(qd, j));
+                    cf = rnd<DT>(__fmul_rn(rnd<DT>(__fadd_rn(cf, df)), 0.5f));                 // :185
                 }
-                uint32_t x4[4];
-                if constexpr (Tr<DT>::KEYBITS == 16) { x4[0] = x4[1] = x4[2] = x4[3] = NINF | (NINF << 16); }
-                else { x4[0] = x4[1] = x4[2] = x4[3] = NINF; }
-                if (live) {
-                    if (kb + u < 64) livemask |= 1ull << (kb + u);
-                    uint32_t qc[4], qd[4];
-                    gload<DT>(p.c, oc, ch, V, p.vec_in, qc);
-                    if (both) gload<DT>(p.d, od, ch, V, p.vec_in, qd);
+                float a = rnd<DT>(__fmul_rn(vf, p.s1));
+                float b = rnd<DT>(__fmul_rn(cf, p.s2));
+                float x = rnd<DT>(__fsub_rn(a, b));                                           // :193
+                if (p.use_temp) x = rnd<DT>(recip ? __fmul_rn(x, p.inv_temp) : __fdiv_rn(x, p.temp));   // HF temperature
+                const bool masked = (vf < cutoff) || (idx >= V);                              // :194
+                if (!masked) {
+                    setb<DT>(x4, j, Tr<DT>::from_f(x));
+                    nfin += 1; m = fmaxf(m, x); t_nan |= (x != x) ? 1 : 0; t_pinf |= (x == INFINITY) ? 1 : 0;
+                }
+            }
+        };
+        auto pass_b = [&](auto both_c) {
+            constexpr bool BOTH = decltype(both_c)::value;
+            uint32_t ninf4[4];
+            if constexpr (Tr<DT>::KEYBITS == 16) { ninf4[0] = ninf4[1] = ninf4[2] = ninf4[3] = NINF | (NINF << 16); }
+            else { ninf4[0] = ninf4[1] = ninf4[2] = ninf4[3] = NINF; }
+            int rslot[NREG];                       // list slots of this thread's register-resident live chunks
+#pragma unroll
+            for (int r = 0; r < NREG; ++r) rslot[r] = -1;
+            int kb = 0;
+            for (int base = tid; base < nch; base += UNR * BLOCK, kb += UNR) {
+                uint32_t qv[UNR][4];
+                if constexpr (!LDSROW) {       // global working row: batch the v re-reads (L2 / Infinity-Cache hits)
+#pragma unroll
+                    for (int u = 0; u < UNR; ++u) { const int ch = base + u * BLOCK; if (ch < nch) gload<DT>(p.v, ov, ch, V, p.vec_in, qv[u]); }
+                }
+#pragma unroll
+                for (int u = 0; u < UNR; ++u) {
+                    const int ch = base + u * BLOCK;
+                    if (ch >= nch) continue;
+                    if constexpr (LDSROW) R.get(ch, qv[u]);
+                    bool live = false;
 #pragma unroll
                     for (int j = 0; j < EPC; ++j) {
-                        const int idx = ch * EPC + j;
-                        float vf = Tr<DT>::to_f(getb<DT>(qv[u], j)), cf = Tr<DT>::to_f(getb<DT>(qc, j));
-                        if (both) {
-                            float df = Tr<DT>::to_f(getb<DT>(qd, j));
-                            cf = rnd<DT>(__fmul_rn(rnd<DT>(__fadd_rn(cf, df)), 0.5f));                 // :185
+                        float vf = Tr<DT>::to_f(getb<DT>(qv[u], j));
+                        live |= !(vf < cutoff) && (ch * EPC + j < V);
+                    }
+                    if (!live) { R.put(ch, ninf4); continue; }
+                    if (kb + u < 64) livemask |= 1ull << (kb + u);
+                    const unsigned slot = atomicAdd(&sm.live_n, 1u);
+                    if (slot < (unsigned)LIVE_CAP) {
+                        LL.ch[slot] = ch;
+                        LL.data[slot] = make_uint4(qv[u][0], qv[u][1], qv[u][2], qv[u][3]);
+                        if constexpr (LDSROW) {
+                            const int r = ch / BLOCK - p.kl;
+                            if (r == 0) rslot[0] = (int)slot; else if (r == 1) rslot[1] = (int)slot; else if (r == 2) rslot[2] = (int)slot;
                         }
-                        float a = rnd<DT>(__fmul_rn(vf, p.s1));
-                        float b = rnd<DT>(__fmul_rn(cf, p.s2));
-                        float x = rnd<DT>(__fsub_rn(a, b));                                           // :193
-                        if (p.use_temp) x = rnd<DT>(recip ? __fmul_rn(x, p.inv_temp) : __fdiv_rn(x, p.temp));   // HF temperature
-                        const bool masked = (vf < cutoff) || (idx >= V);                              // :194
-                        if (!masked) {
-                            setb<DT>(x4, j, Tr<DT>::from_f(x));
-                            nfin += 1; m = fmaxf(m, x); t_nan |= (x != x) ? 1 : 0; t_pinf |= (x == INFINITY) ? 1 : 0;
-                        }
+                    } else {                   // list full: in place
+                        uint32_t qc[4], qd[4], x4[4];
+                        gload<DT>(p.c, oc, ch, V, p.vec_in, qc);
+                        if constexpr (BOTH) gload<DT>(p.d, od, ch, V, p.vec_in, qd);
+                        contrast_chunk(both_c, ch, qv[u], qc, qd, x4);
+                        R.put(ch, x4);
                     }
                 }
-                R.put(ch, x4);
             }
-        }
+            __syncthreads();
+            const int n_live = (int)min(sm.live_n, (unsigned)LIVE_CAP);
+            for (int s0 = tid; s0 < n_live; s0 += BLOCK) {
+                const int ch = LL.ch[s0];
+                const uint4 vq = LL.data[s0];
+                const uint32_t qv[4] = {vq.x, vq.y, vq.z, vq.w};
+                uint32_t qc[4], qd[4], x4[4];
+                gload<DT>(p.c, oc, ch, V, p.vec_in, qc);
+                if constexpr (BOTH) gload<DT>(p.d, od, ch, V, p.vec_in, qd);
+                contrast_chunk(both_c, ch, qv, qc, qd, x4);
+                LL.data[s0] = make_uint4(x4[0], x4[1], x4[2], x4[3]);
+            }
+            __syncthreads();
+            for (int s0 = tid; s0 < n_live; s0 += BLOCK) {
+                const int ch = LL.ch[s0];
+                bool shared_part = true;
+                if constexpr (LDSROW) shared_part = ch / BLOCK < p.kl;
+                if (shared_part) { const uint4 x = LL.data[s0]; const uint32_t w[4] = {x.x, x.y, x.z, x.w}; R.put(ch, w); }
+            }
+            if constexpr (LDSROW) {
+#pragma unroll
+                for (int r = 0; r < NREG; ++r)
+                    if (rslot[r] >= 0) { const uint4 x = LL.data[rslot[r]]; rc[r][0] = x.x; rc[r][1] = x.y; rc[r][2] = x.z; rc[r][3] = x.w; }
+            }
+        };
+        if (both) pass_b(std::true_type{});
+        else pass_b(std::false_type{});
     } else {
         // ---- plain path (vcd_sample.py:204-205): x = warp(v) ---------------------------
         livemask = ~0ull;
@@ -844,7 +903,8 @@ __global__ void __launch_bounds__(BLOCK, 6) vdd_contrast_sample_kernel(KP p) {
         return;
     }
     if (tid == 0 && p.status) p.status[row] = VDD_ROW_OK;
-    if ((p.flags & VDD_NO_SAMPLE) && !want_top) { store_scores(); return; }
+    store_scores();          // the row is final: its stores drain while the tail below runs on LDS / registers
+    if ((p.flags & VDD_NO_SAMPLE) && !want_top) return;
 
     // ---- per-thread mass, block scan (thread-major order) ---------------------------
 
@@ -907,7 +967,7 @@ __global__ void __launch_bounds__(BLOCK, 6) vdd_contrast_sample_kernel(KP p) {
             pv = have ? bv : -INFINITY; pi = bi;
         }
     }
-    if (p.flags & VDD_NO_SAMPLE) { store_scores(); return; }
+    if (p.flags & VDD_NO_SAMPLE) return;
 
     // ---- token: argmax or inverse-CDF draw in thread-major order ---------------------
     if (tid == 0) sm.sel[3] = 0xFFFFFFFFu;
@@ -970,7 +1030,6 @@ __global__ void __launch_bounds__(BLOCK, 6) vdd_contrast_sample_kernel(KP p) {
         }
         p.next_tokens[(long long)row * p.st] = tok;
     }
-    store_scores();
 }
 
 // ------------------------------------------------------------------ host side
@@ -1067,7 +1126,8 @@ int vdd_contrast_sample(const vdd_sample_params* p, void* hip_stream) {
         else return fail(VDD_ERR_INVALID_ARG, "V exceeds vdd_lds_row_capacity(dtype): pass scores_out or workspace [B,V]");
         kp.vec_work = al(kp.work, kp.sw);
     }
-    const size_t lds = ((sizeof(Smem) + 15) & ~(size_t)15) + (kp.use_topp ? sizeof(ToppScratch) : 0) + (ldsrow ? row_bytes : 0);
+    const size_t scratch = kp.c == nullptr ? 0 : sizeof(LiveList);          // the two scratch users never overlap in time
+    const size_t lds = ((sizeof(Smem) + 15) & ~(size_t)15) + (kp.use_topp && sizeof(ToppScratch) > scratch ? sizeof(ToppScratch) : scratch) + (ldsrow ? row_bytes : 0);
     hipStream_t st = (hipStream_t)hip_stream;
     int rc;
     switch (p->dtype) {

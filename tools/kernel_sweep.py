@@ -39,6 +39,18 @@ if __name__ == "__main__":
     if "--only-canonical" in sys.argv:          # the PMC passes of tools/profile_round.sh: the roofline shape alone
         print(json.dumps(point(4096, 32000, torch.bfloat16, 2, True, W(temperature=0.2), iters=40)))
         sys.exit(0)
+    if "--slow" in sys.argv:                    # the regimes VERDICT r1 #7 names (block-wide tail / plain warpers / V = 151,936 without a scores row)
+        for pt in (point(4096, 32000, torch.bfloat16, 2, True, W(temperature=0.2)),
+                   point(4096, 32000, torch.bfloat16, 2, True, W(temperature=0.2), beta=1e-6),
+                   point(4096, 32000, torch.bfloat16, 2, True, W(temperature=0.2), beta=1e-9),
+                   point(4096, 32000, torch.bfloat16, 1, True, W(temperature=0.7)),
+                   point(4096, 32000, torch.bfloat16, 1, True, W(temperature=0.7, top_k=50)),
+                   point(4096, 32000, torch.bfloat16, 1, True, W(top_p=0.9)),
+                   point(4096, 32000, torch.bfloat16, 2, True, W(temperature=0.7, top_k=50, top_p=0.9)),
+                   point(1024, 151936, torch.bfloat16, 2, True, W(temperature=0.2)),
+                   point(1024, 151936, torch.bfloat16, 2, False, W(temperature=0.2))):
+            print(json.dumps(pt), flush=True)
+        sys.exit(0)
     for B in (1, 8, 64, 256, 512, 1024, 4096):
         pts.append(point(B, 32000, torch.bfloat16, 2, True, W(temperature=0.2)))
     pts.append(point(4096, 32000, torch.bfloat16, 2, False, W(temperature=0.2)))
