@@ -73,7 +73,9 @@ def test_grouping_and_work_items():
     groups, members = group_rows_by_prefix(rows)
     assert groups == [[0, 2, 0, 611], [2, 1, 1, 611], [3, 2, 2, 36]] and members == [0, 1, 2, 3, 4]      # row 5 has no prefix
     items = ops.prefix_work_items(groups)
-    assert len(items) == 10 + 10 + 1 and items[0] == [0, 0, 0, 0] and items[-1] == [2, 0, 0, 0]
+    assert len(items) == 10 + 10 + 1 and items[0] == [0, 0, 0, 0] and sorted(items)[-1] == [2, 0, 0, 0]
+    keys = [min(64, groups[g][3] - 64 * c) for g, _, c, _ in items]
+    assert keys == sorted(keys, reverse=True) and keys[-3:] == [36, 35, 35]          # longest items first: the short ones fill the tail
     big = ops.prefix_work_items([[0, 40, 7, 36]])         # 40 rows -> three 16-row slices, one 64-key chunk each
     assert big == [[0, 0, 0, 0], [0, 16, 0, 0], [0, 32, 0, 0]]
     # several 64-key chunks per item: 611 keys -> 3 items of 256 keys (ragged last); item index, not chunk index, in column 2
