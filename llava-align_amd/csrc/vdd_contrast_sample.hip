@@ -261,7 +261,8 @@ struct Row {
 // ------------------------------------------------------------------ radix threshold selection
 // Count-based: ordered key of the k-th largest among finite entries (k <= #finite).
 template <int DT, bool L>
-__device__ __forceinline__ uint32_t select_kth_key(const Row<DT, L>& R, int nch, unsigned k, Smem& sm, int tid, int lane, int wave) {
+__device__ __forceinline__ uint32_t select_kth_key(const Row<DT, L>& R, int nch, unsigned k, Smem& sm, int tid, int lane, int wave,
+                                                   unsigned long long live) {
     constexpr int KB = Tr<DT>::KEYBITS, EPC = Tr<DT>::EPC;
     uint32_t prefix = 0, pmask = 0;
     unsigned rem = k;
@@ -269,7 +270,8 @@ __device__ __forceinline__ uint32_t select_kth_key(const Row<DT, L>& R, int nch,
         sm.hist[tid >> 8][tid & 255] = 0;        // BLOCK / 256 = NCOPY copies
         __syncthreads();
         unsigned* h = sm.hist[wave % NCOPY];
-        for (int ch = tid; ch < nch; ch += BLOCK) {
+        for (int ch = tid, kq = 0; ch < nch; ch += BLOCK, ++kq) {
+            if (kq < 64 && ((live >> kq) & 1ull) == 0ull) continue;        // chunk without a finite score (never written in sparse mode)
             uint32_t w[4]; R.get(ch, w);
 #pragma unroll
             for (int j = 0; j < EPC; ++j) {
@@ -319,7 +321,7 @@ __device__ __forceinline__ uint32_t select_kth_key(const Row<DT, L>& R, int nch,
 // whole row's mass never exceeds thr (then only min_keep survive).
 template <int DT, bool L>
 __device__ __forceinline__ bool select_mass_key(const Row<DT, L>& R, int nch, float m, float thr, Smem& sm,
-                                                int tid, int lane, int wave, uint32_t& out_key) {
+                                                int tid, int lane, int wave, uint32_t& out_key, unsigned long long live) {
     constexpr int KB = Tr<DT>::KEYBITS, EPC = Tr<DT>::EPC;
     uint32_t prefix = 0, pmask = 0;
     float below = 0.f;
@@ -328,7 +330,8 @@ __device__ __forceinline__ bool select_mass_key(const Row<DT, L>& R, int nch, fl
         sm.histf[tid >> 8][tid & 255] = 0.f;
         __syncthreads();
         float* h = sm.histf[wave % NCOPY];
-        for (int ch = tid; ch < nch; ch += BLOCK) {
+        for (int ch = tid, kq = 0; ch < nch; ch += BLOCK, ++kq) {
+            if (kq < 64 && ((live >> kq) & 1ull) == 0ull) continue;        // chunk without a finite score (never written in sparse mode)
             uint32_t w[4]; R.get(ch, w);
 #pragma unroll
             for (int j = 0; j < EPC; ++j) {
@@ -391,10 +394,11 @@ __device__ __forceinline__ bool select_mass_key(const Row<DT, L>& R, int nch, fl
 }
 
 template <int DT, bool L>
-__device__ __forceinline__ void mask_below_key(const Row<DT, L>& R, int nch, uint32_t thr_key, int tid, int thr_idx = 0) {
+__device__ __forceinline__ void mask_below_key(const Row<DT, L>& R, int nch, uint32_t thr_key, int tid, unsigned long long live, int thr_idx = 0) {
     // removes every element below (thr_key, thr_idx) in (value, index) order: thr_idx = 0 is the plain value threshold
     constexpr int EPC = Tr<DT>::EPC;
-    for (int ch = tid; ch < nch; ch += BLOCK) {
+    for (int ch = tid, kq = 0; ch < nch; ch += BLOCK, ++kq) {
+        if (kq < 64 && ((live >> kq) & 1ull) == 0ull) continue;        // chunk without a finite score (never written in sparse mode)
         uint32_t w[4]; R.get(ch, w);
         bool changed = false;
 #pragma unroll
@@ -494,6 +498,9 @@ __global__ void __launch_bounds__(BLOCK, 6) vdd_contrast_sample_kernel(KP p) {
             uint32_t ninf4[4];
             if constexpr (Tr<DT>::KEYBITS == 16) { ninf4[0] = ninf4[1] = ninf4[2] = ninf4[3] = NINF | (NINF << 16); }
             else { ninf4[0] = ninf4[1] = ninf4[2] = ninf4[3] = NINF; }
+            // a global working row that nobody asked for (no scores row) only ever gets its LIVE chunks: every later pass skips
+            // the chunks without a livemask bit, so the -inf chunks need not exist (V = 151,936: the [B, V] round trip was half the launch)
+            const bool sparse = !LDSROW && p.scores == nullptr && nch <= 64 * BLOCK;
             int rslot[NREG];                       // list slots of this thread's register-resident live chunks
 #pragma unroll
             for (int r = 0; r < NREG; ++r) rslot[r] = -1;
@@ -515,7 +522,7 @@ __global__ void __launch_bounds__(BLOCK, 6) vdd_contrast_sample_kernel(KP p) {
                         float vf = Tr<DT>::to_f(getb<DT>(qv[u], j));
                         live |= !(vf < cutoff) && (ch * EPC + j < V);
                     }
-                    if (!live) { R.put(ch, ninf4); continue; }
+                    if (!live) { if (!sparse) R.put(ch, ninf4); continue; }
                     if (kb + u < 64) livemask |= 1ull << (kb + u);
                     const unsigned slot = atomicAdd(&sm.live_n, 1u);
                     if (slot < (unsigned)LIVE_CAP) {
@@ -803,8 +810,8 @@ __global__ void __launch_bounds__(BLOCK, 6) vdd_contrast_sample_kernel(KP p) {
     if (p.top_k > 0 && !has_nan && nfin > 0) {
         int k = p.top_k < p.min_keep ? p.min_keep : p.top_k;
         if (k < nfin) {
-            uint32_t kth = select_kth_key<DT, LDSROW>(R, nch, (unsigned)k, sm, tid, lane, wave);
-            mask_below_key<DT, LDSROW>(R, nch, kth, tid);
+            uint32_t kth = select_kth_key<DT, LDSROW>(R, nch, (unsigned)k, sm, tid, lane, wave, livemask);
+            mask_below_key<DT, LDSROW>(R, nch, kth, tid, livemask);
         }
     }
 
@@ -868,7 +875,7 @@ __global__ void __launch_bounds__(BLOCK, 6) vdd_contrast_sample_kernel(KP p) {
             for (int u = 0; u < 2; ++u)
                 if (kd > 0 && tid + u * BLOCK < n && pos2[u] == kd) { sm.sel[0] = okey<DT>(Tr<DT>::from_f(x2[u])); sm.sel[1] = (unsigned)i2[u]; }
             __syncthreads();
-            if (kd > 0) mask_below_key<DT, LDSROW>(R, nch, sm.sel[0], tid, (int)sm.sel[1]);
+            if (kd > 0) mask_below_key<DT, LDSROW>(R, nch, sm.sel[0], tid, livemask, (int)sm.sel[1]);
             topp_done = true;
         }
     }
@@ -883,13 +890,13 @@ __global__ void __launch_bounds__(BLOCK, 6) vdd_contrast_sample_kernel(KP p) {
         z = block_sum(z, sm, lane, wave);
         const float thr = rnd<DT>(p.one_minus_p) * z;      // cum <= fl(1-p)  <=>  mass <= fl(1-p) * Z
         uint32_t pkey = 0;
-        bool crossed = select_mass_key<DT, LDSROW>(R, nch, m, thr, sm, tid, lane, wave, pkey);
+        bool crossed = select_mass_key<DT, LDSROW>(R, nch, m, thr, sm, tid, lane, wave, pkey, livemask);
         // never remove the top min_keep entries
         uint32_t keep_key;
         if (p.min_keep <= 1) keep_key = okey<DT>(Tr<DT>::from_f(m));
-        else keep_key = (p.min_keep < nfin) ? select_kth_key<DT, LDSROW>(R, nch, (unsigned)p.min_keep, sm, tid, lane, wave) : 0u;
+        else keep_key = (p.min_keep < nfin) ? select_kth_key<DT, LDSROW>(R, nch, (unsigned)p.min_keep, sm, tid, lane, wave, livemask) : 0u;
         uint32_t thr_key = crossed ? (pkey < keep_key ? pkey : keep_key) : keep_key;
-        mask_below_key<DT, LDSROW>(R, nch, thr_key, tid);
+        mask_below_key<DT, LDSROW>(R, nch, thr_key, tid, livemask);
     }
 
     // ---- scores row out: issued LAST (after the token), see the end of the kernel ----------------

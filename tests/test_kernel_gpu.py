@@ -296,6 +296,17 @@ def test_row_layouts_across_vocabulary_sizes(V):
                 best = torch.nonzero(row == row.max()).min().item()
                 assert out.tokens[b].item() == best, (dt, beta, warp, b)
                 assert out.top_tok[b, 0].item() == best
+            if V > 86016 and dt != "fp32":
+                # global working row WITHOUT a scores row (workspace path): only the live chunks are ever written and every
+                # later pass walks the livemask; tokens / top-n must not notice, with warpers and with a drawn token too
+                for extra in ({}, {"top_p": 0.7}):
+                    spec2 = L.WarpSpec(temperature=warp.get("temperature"), top_k=warp.get("top_k"), top_p=extra.get("top_p"))
+                    for argmax in (True, False):
+                        kw = dict(alpha=1.0, beta=beta, warp=spec2, pick_argmax=argmax, n_top=3, seed=11, offset=5)
+                        a = L.contrast_sample(v.to(DEV), c.to(DEV), d.to(DEV) if three else None, return_scores=True, **kw)
+                        b_ = L.contrast_sample(v.to(DEV), c.to(DEV), d.to(DEV) if three else None, return_scores=False, **kw)
+                        assert torch.equal(a.tokens, b_.tokens) and torch.equal(a.top_tok, b_.top_tok) and torch.equal(a.top_prob, b_.top_prob), (dt, beta, warp, extra, argmax)
+                        assert b_.status.cpu().tolist() == [0] * B
         # plain path (no contrast): every chunk live
         out = L.contrast_sample(v.to(DEV), None, warp=L.WarpSpec(temperature=0.9), return_scores=True, pick_argmax=True)
         assert torch.equal(_bits(out.scores.cpu()), _bits(O.step_scores(v, None, None, 1.0, 0.1, O.WarpConfig(temperature=0.9))))
