@@ -3,18 +3,16 @@
 // reference runs at step 0 of every branch (experiments/llava/model/llava_arch.py:82-204 ->
 // CLIPVisionModel / LlamaModel [ext]; clip_encoder.py:39-51; multimodal_projector/builder.py:33-46).
 //
-// vdd_flash_attention: one 256-thread block = 64 query rows of one (sequence, head); each of
-// its 4 waves owns 16 rows.  Per 32-key tile a wave issues S = Q K^T as 16x16x32 bf16 MFMAs with
-// the K fragments loaded straight from the KV cache (lane (key = l&15, g = l>>4) reads 16 B of
-// K[key][32 ks + 8 g ..], k-contiguous, no staging), runs the online softmax in the C layout
-// (row statistics via 4 intra-16-lane shuffles), re-lays P out as an A fragment through a
-// 1.25-KiB per-wave LDS patch, and multiplies by V, which the block stages once per tile in
-// LDS ([32][D+8] bf16) because the MFMA B operand wants key-contiguous data while the cache
-// is dim-contiguous.  Keys come from [prefix slot | own slot] like the decode kernel.
-// Bound: MFMA (dense contraction), but attention is ~2.5 % of prefill FLOPs at T=635, d=4096.
+// vdd_flash_attention: one 256-thread block = 128 query rows of one (sequence, head), 32 per wave; 64-key K / V tiles shared by
+// the block through LDS (LDS-DMA, double-buffered), 32x32x16 bf16 MFMAs for S^T = K Q^T and O^T = V^T P^T, softmax and
+// rescale lane-local, V read transposed with ds_read_b64_tr_b16 (see flash_attn2_kernel).  Keys come from
+// [prefix slot | own slot] like the decode kernel.  Bound: MFMA in the long-sequence limit (0.9 PF/s at 5,120 keys), block
+// start-up and causal tile waste at the bench's 611-token prefixes (0.37 PF/s of useful flops).
 
 #include <hip/hip_runtime.h>
 #include <stdint.h>
+
+#include <type_traits>
 
 #include "vdd_hip.h"
 
@@ -44,169 +42,239 @@ struct SeqDesc { int q_row0, Tq, pos0, slot, pslot, plen; };
 
 constexpr float NEG_BIG = -1.0e30f;
 
-// Per 32-key step and wave (16 query rows):
-//   S^T = K Q^T   A = K fragment straight from the cache, with the key -> MFMA-row assignment
-//                 key(i) = kt + 8 (i / 4) + (i % 4) (+ 4 for the second tile), B = Q fragment (held in registers);
-//                 in the C layout lane (query ln, g) then owns the scores of keys kt + 8 g .. + 7: exactly the A fragment
-//                 of the PV product, so P never leaves registers (no LDS patch, no barrier for it);
-//   softmax       per query column: 8 local scores + 2 cross-group shuffles; the rescale factor of O row 4 g + r is
-//                 fetched from the lanes of column 4 g + r;
-//   O += P V      B = V fragment = 8 consecutive keys of one dim: one 16-byte LDS read from a TRANSPOSED, double-buffered
-//                 V tile [dim][32 keys] (conflict-free with the 80-byte row pitch) that the block stages once per step.
-// One barrier per step (the tile hand-off); 24 LDS instructions per lane and step instead of 75.
+// ------------------------------------------------------------------ prefill attention, 128-query blocks
+// 4 waves x 32 query rows, 64-key tiles, 32x32x16 MFMA, K and V tiles shared by the block through LDS:
+//   * K / V tiles go HBM -> LDS by LDS-DMA (global_load_lds, per-lane 64-bit source addresses: a tile may straddle the prefix
+//     and the own pool), two tiles ahead of nothing: tile t+1 is issued right behind the barrier that opens tile t (double buffer);
+//   * K tile [64 keys][D] row-major, 16-byte chunks XOR-swizzled on the SOURCE side (the DMA image is lane-linear) so that the
+//     ds_read_b128 of a K fragment (32 keys x one chunk) is conflict-free;
+//   * S^T = K Q^T (A = K fragment, B = Q fragment held in registers): lane (query q = lane & 31, hi) ends up with the scores of
+//     its query for keys (r & 3) + 8 (r >> 2) + 4 hi of each 32-key block: max / sum are 32 local values + ONE exchange with
+//     lane ^ 32, and the 8 scores r = 8 j .. 8 j + 7 are exactly the k-slice of a 16-key MFMA step: P never leaves registers;
+//   * O^T = V^T P^T (A = V^T fragment, B = P fragment): the accumulator column is the lane's OWN query, so the online-softmax
+//     rescale and the final normalisation are lane-local (no shuffles);
+//   * V tile as 1-KiB [32 keys][16 dims] subtiles (1152 bytes apart: the two dim-halves of a 32-dim MFMA tile land on different
+//     banks), read TRANSPOSED with ds_read_b64_tr_b16: within a 16-lane group lane i receives element i % 4 of the 8 bytes
+//     addressed by lane 4 j + i / 4 (tools/probes/tr_read_probe.hip), i.e. 4 consecutive keys of one dim from a row-major image.
+// One barrier per tile.  Same sequence descriptors and prefix indirection as before.
+typedef __attribute__((ext_vector_type(16))) float f32x16_t;
+typedef __attribute__((address_space(3))) void* lds_ptr_t;
+typedef __attribute__((address_space(1))) void* g_ptr_t;
+
 template <int D, bool CAUSAL>
-__global__ void __launch_bounds__(256, 4) flash_attn_kernel(const uint16_t* __restrict__ q, const uint16_t* __restrict__ kc,
-                                                            const uint16_t* __restrict__ vc, const uint16_t* __restrict__ kpre,
-                                                            const uint16_t* __restrict__ vpre, const SeqDesc* __restrict__ seqs,
-                                                            uint16_t* __restrict__ out, int H, int Hkv, long long slot_stride,
-                                                            int t_max, long long pre_stride, int pre_tmax, float scale) {
-    constexpr int KS = D / 32;        // k-steps of the QK^T contraction
-    constexpr int NT = D / 16;        // 16-wide output tiles over the head dim
-    constexpr int VTLD = 40;          // pitch of a transposed V row: 32 keys + 8 pad (80 B: 16-B aligned, conflict-free b128 reads)
-    __shared__ __attribute__((aligned(16))) uint16_t vt_lds[2][D * VTLD];
+__global__ void __launch_bounds__(256, 2) flash_attn2_kernel(const uint16_t* __restrict__ q, const uint16_t* __restrict__ kc,
+                                                             const uint16_t* __restrict__ vc, const uint16_t* __restrict__ kpre,
+                                                             const uint16_t* __restrict__ vpre, const SeqDesc* __restrict__ seqs,
+                                                             uint16_t* __restrict__ out, int H, int Hkv, long long slot_stride,
+                                                             int t_max, long long pre_stride, int pre_tmax, float scale, int nx, int n_seq) {
+#if defined(__HIP_DEVICE_COMPILE__)
+    constexpr int KS = D / 16;                 // 16-deep k-steps of S^T per 32-key block
+    constexpr int NT = D / 32;                 // 32-dim tiles of O^T
+    constexpr int KROW = D * 2;                // bytes of a K row
+    constexpr int KTILE = 64 * KROW;           // K tile bytes
+    constexpr int NKI = KTILE / 1024;          // 1-KiB DMA images of the K tile
+    constexpr int KPI = 1024 / KROW;           // keys per K image (4 at D = 128, 8 at D = 64)
+    constexpr int CPR = KROW / 16;             // 16-byte chunks per K row
+    constexpr int DSUB = D / 16;               // 16-dim V subtiles per 32-key half
+    constexpr int NVI = 2 * DSUB;              // V subtiles (= DMA images) per tile
+    constexpr int VSUB = 1152;                 // bytes between V subtiles (the tr-read offsets below are written out for this value)
+    static_assert(NT == 4 || NT == 2, "");
+    constexpr int BUF = KTILE + NVI * VSUB;    // one tile buffer
+    extern __shared__ __attribute__((aligned(16))) char lds[];
 
-    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-    const int ln = lane & 15, g = lane >> 4;
-    const SeqDesc sd = seqs[blockIdx.z];
-    const int head = blockIdx.y, kvh = head / (H / Hkv);
-    const int qt0 = blockIdx.x * 64;
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int ql = lane & 31, hi = lane >> 5;
+    // 1-D grid, XCD-aware: workgroup b runs on XCD b % 8, and the NX query blocks of one (sequence, head) read the same K / V, so
+    // they take CONSECUTIVE slots of ONE XCD (its L2 then serves all but the first read of a tile; spread round-robin over the
+    // XCDs the causal prefix pass pulled every K / V byte 3 times from HBM / Infinity Cache).  Long (late) query blocks first.
+    const int NX = nx, xcd = blockIdx.x & 7, local = blockIdx.x >> 3;
+    const int pair = (local / NX) * 8 + xcd;
+    if (pair >= H * n_seq) return;
+    const SeqDesc sd = seqs[pair / H];
+    const int head = pair % H, kvh = head / (H / Hkv);
+    const int qt0 = (NX - 1 - local % NX) * 128;
     if (qt0 >= sd.Tq) return;
-    const int r0 = qt0 + wave * 16;                           // this wave's first query row (within the sequence)
-    const int Tk = sd.pos0 + sd.Tq;                           // keys that exist
-    const int last_row = min(qt0 + 63, sd.Tq - 1);
-    const int kend = CAUSAL ? min(Tk, sd.pos0 + last_row + 1) : Tk;   // block-uniform key bound
+    const int r0 = qt0 + wave * 32;
+    const int Tk = sd.pos0 + sd.Tq;
+    const int last_row = min(qt0 + 127, sd.Tq - 1);
+    const int kend = CAUSAL ? min(Tk, sd.pos0 + last_row + 1) : Tk;          // block-uniform key bound
+    const bool wave_has_rows = r0 < sd.Tq;
+    const int wave_last_pos = sd.pos0 + min(r0 + 31, sd.Tq - 1);
 
-    // Q fragments (B operand of S^T): lane (n = query ln, g) holds Q[r0 + ln][32 ks + 8 g .. +7]
+    // Q fragments (B operand of S^T): lane (q, hi) holds Q[r0 + q][16 ks + 8 hi .. + 7]
     bf16x8_t qf[KS];
     {
-        int qr = r0 + ln; if (qr >= sd.Tq) qr = sd.Tq - 1;
-        const uint16_t* qp = q + ((size_t)(sd.q_row0 + qr) * H + head) * D + g * 8;
+        int qr = r0 + ql; if (qr >= sd.Tq) qr = sd.Tq - 1;
+        const uint16_t* qp = q + ((size_t)(sd.q_row0 + qr) * H + head) * D + hi * 8;
 #pragma unroll
-        for (int ks = 0; ks < KS; ++ks) qf[ks] = *reinterpret_cast<const bf16x8_t*>(qp + ks * 32);
+        for (int ks = 0; ks < KS; ++ks) qf[ks] = *reinterpret_cast<const bf16x8_t*>(qp + ks * 16);
     }
-    const int qpos = sd.pos0 + r0 + ln;                       // position of this lane's query column
-    // own pool: token t at index t - plen (compact slots); prefix pool: token t at index t
+    const int qpos = sd.pos0 + r0 + ql;
     const size_t head_off = (size_t)kvh * t_max * D, pre_off = (size_t)kvh * pre_tmax * D;
     const uint16_t* kbase_own = kc + (size_t)sd.slot * slot_stride + head_off - (size_t)sd.plen * D;
     const uint16_t* vbase_own = vc + (size_t)sd.slot * slot_stride + head_off - (size_t)sd.plen * D;
     const uint16_t* kbase_pre = kpre + (size_t)sd.pslot * pre_stride + pre_off;
     const uint16_t* vbase_pre = vpre + (size_t)sd.pslot * pre_stride + pre_off;
 
-    f32x4_t o[NT];
-#pragma unroll
-    for (int nt = 0; nt < NT; ++nt) o[nt] = f32x4_t{0.f, 0.f, 0.f, 0.f};
-    float mq = NEG_BIG, lq = 0.f;                             // running max / sum of query column ln (replicated over g)
-
-    // staging map: consecutive lanes take consecutive KEYS of one 8-dim slab (2-byte-consecutive transposed LDS writes)
-    constexpr int SLABS = D / 8, PER = 32 * SLABS / 256;      // uint4 per thread per tile (D=128: 2, D=64: 1)
+    // ---- LDS-DMA of one tile: (NKI + NVI) 1-KiB images, (NKI + NVI) / 4 per wave; a key past the sequence is clamped (its score is masked)
     auto stage = [&](int kt, int buf) {
+        char* base = lds + buf * BUF;
 #pragma unroll
-        for (int i = 0; i < PER; ++i) {
-            const int e = tid + i * 256;
-            const int key = e & 31, dd = (e >> 5) * 8;
+        for (int m0 = 0; m0 < NKI / 4; ++m0) {
+            const int m = m0 * 4 + wave;
+            const int key = m * KPI + lane / CPR, slot = lane % CPR;
+            const int c = D == 128 ? (slot ^ (key & 15)) : (slot ^ ((key >> 1) & 7));
             int t = kt + key; if (t >= Tk) t = Tk - 1;
-            const uint4 v4 = *reinterpret_cast<const uint4*>((t < sd.plen ? vbase_pre : vbase_own) + (size_t)t * D + dd);
-            uint16_t* dst = &vt_lds[buf][dd * VTLD + key];
-            dst[0 * VTLD] = (uint16_t)(v4.x & 0xFFFFu); dst[1 * VTLD] = (uint16_t)(v4.x >> 16);
-            dst[2 * VTLD] = (uint16_t)(v4.y & 0xFFFFu); dst[3 * VTLD] = (uint16_t)(v4.y >> 16);
-            dst[4 * VTLD] = (uint16_t)(v4.z & 0xFFFFu); dst[5 * VTLD] = (uint16_t)(v4.z >> 16);
-            dst[6 * VTLD] = (uint16_t)(v4.w & 0xFFFFu); dst[7 * VTLD] = (uint16_t)(v4.w >> 16);
+            const uint16_t* src = (t < sd.plen ? kbase_pre : kbase_own) + (size_t)t * D + c * 8;
+            __builtin_amdgcn_global_load_lds((g_ptr_t)src, (lds_ptr_t)(base + m * 1024), 16, 0, 0);
+        }
+#pragma unroll
+        for (int m0 = 0; m0 < NVI / 4; ++m0) {
+            const int sI = m0 * 4 + wave, kh = sI / DSUB, ds = sI % DSUB;
+            const int key = 32 * kh + lane / 2, d = 16 * ds + 8 * (lane & 1);
+            int t = kt + key; if (t >= Tk) t = Tk - 1;
+            const uint16_t* src = (t < sd.plen ? vbase_pre : vbase_own) + (size_t)t * D + d;
+            __builtin_amdgcn_global_load_lds((g_ptr_t)src, (lds_ptr_t)(base + KTILE + sI * VSUB), 16, 0, 0);
         }
     };
+
+    f32x16_t o[NT];
+#pragma unroll
+    for (int nt = 0; nt < NT; ++nt)
+#pragma unroll
+        for (int e = 0; e < 16; ++e) o[nt][e] = 0.f;
+    float mq = NEG_BIG, lq = 0.f;              // running max (scaled, log2 domain) of query q; partial sum of this lane's keys
+    const float sc2 = scale * 1.44269504088896340736f;
+
+    // fragment read offsets (bytes inside a tile buffer)
+    const int krow = D == 128 ? (ql * KROW) : (ql * KROW);
+    const int kswz = D == 128 ? (ql & 15) : ((ql >> 1) & 7);
+    const int vrd = ((lane >> 4) & 1) * VSUB + (4 * hi + ((lane & 15) >> 2)) * 32 + (lane & 3) * 8;      // + (b * DSUB + 2 nt) * VSUB + (16 j + 8 h) * 32
+
     stage(0, 0);
-    int buf = 0;
-    // a wave whose 16 query rows lie past the end of the sequence (suffixes are ~25 tokens: half of the block) only helps
-    // staging the V tiles; a wave whose rows all precede a key tile (causal) has nothing to add from it either
-    const bool wave_has_rows = r0 < sd.Tq;
-    for (int kt = 0; kt < kend; kt += 32, buf ^= 1) {
-        const bool active = wave_has_rows && !(CAUSAL && kt > sd.pos0 + min(r0 + 15, sd.Tq - 1));
-        // ---- S^T = K Q^T for 2 x 16 keys (MFMA row i of tile j is key kt + 8 (i / 4) + (i % 4) + 4 j) ----
-        f32x4_t s[2] = {f32x4_t{0.f, 0.f, 0.f, 0.f}, f32x4_t{0.f, 0.f, 0.f, 0.f}};
-        if (active) {
+    for (int kt = 0, buf = 0; kt < kend; kt += 64, buf ^= 1) {
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        __syncthreads();                                      // tile `buf` landed for everyone; tile buf ^ 1 no longer read
+        if (kt + 64 < kend) stage(kt + 64, buf ^ 1);
+        if (!wave_has_rows || (CAUSAL && kt > wave_last_pos)) continue;
+        const char* kb = lds + buf * BUF;
+        const char* vb = kb + KTILE;
+        // ---- S^T = K Q^T: all 2 KS fragment reads in flight, then the two independent accumulator chains interleaved ----
+        f32x16_t s[2];
+        {
+            bf16x8_t kf[2][KS];
 #pragma unroll
-        for (int j = 0; j < 2; ++j) {
-            int t = kt + (ln >> 2) * 8 + (ln & 3) + 4 * j; if (t >= Tk) t = Tk - 1;
-            const uint16_t* kp = (t < sd.plen ? kbase_pre : kbase_own) + (size_t)t * D + g * 8;
+            for (int ks = 0; ks < KS; ++ks)
 #pragma unroll
-            for (int ks = 0; ks < KS; ++ks) {
-                const bf16x8_t kf = *reinterpret_cast<const bf16x8_t*>(kp + ks * 32);
-                s[j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(kf, qf[ks], s[j], 0, 0, 0);
-            }
+                for (int b = 0; b < 2; ++b)
+                    kf[b][ks] = *reinterpret_cast<const bf16x8_t*>(kb + b * 32 * KROW + krow + (((2 * ks + hi) ^ kswz) * 16));
+            __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+            for (int b = 0; b < 2; ++b)
+#pragma unroll
+                for (int e = 0; e < 16; ++e) s[b][e] = 0.f;
+#pragma unroll
+            for (int ks = 0; ks < KS; ++ks)
+#pragma unroll
+                for (int b = 0; b < 2; ++b) s[b] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(kf[b][ks], qf[ks], s[b], 0, 0, 0);
         }
-        }
-        __syncthreads();                                      // tile `buf` staged by everyone; tile buf^1 no longer read
-        if (kt + 32 < kend) stage(kt + 32, buf ^ 1);          // next tile's loads fly under this step's arithmetic
-        if (!active) continue;
-        // ---- mask + online softmax of query column ln: this lane's scores are keys kt + 8 g + 4 j + r ----
-        // masking is only needed on the causal diagonal and on the ragged last tile (wave-uniform test)
-        const bool need_mask = (kt + 32 > Tk) || (CAUSAL && kt + 31 > sd.pos0 + r0);
+        // ---- mask + online softmax: this lane's scores are keys kt + 32 b + (r & 3) + 8 (r >> 2) + 4 hi of query q ----
+        // (masking only on the causal diagonal and on the ragged last tile: one wave-uniform branch)
         float mx = NEG_BIG;
-        if (need_mask) {
+        if ((kt + 64 > Tk) || (CAUSAL && kt + 63 > sd.pos0 + r0)) {
 #pragma unroll
-            for (int j = 0; j < 2; ++j)
+            for (int b = 0; b < 2; ++b)
 #pragma unroll
-                for (int r = 0; r < 4; ++r) {
-                    const int key = kt + 8 * g + 4 * j + r;
-                    float v = s[j][r] * scale;
+                for (int r = 0; r < 16; ++r) {
+                    const int key = kt + 32 * b + (r & 3) + 8 * (r >> 2) + 4 * hi;
+                    float v = s[b][r] * sc2;
                     if (key >= Tk || (CAUSAL && key > qpos)) v = NEG_BIG;
-                    s[j][r] = v; mx = fmaxf(mx, v);
+                    s[b][r] = v; mx = fmaxf(mx, v);
                 }
         } else {
 #pragma unroll
-            for (int j = 0; j < 2; ++j)
+            for (int b = 0; b < 2; ++b)
 #pragma unroll
-                for (int r = 0; r < 4; ++r) { s[j][r] *= scale; mx = fmaxf(mx, s[j][r]); }
+                for (int r = 0; r < 16; ++r) { s[b][r] *= sc2; mx = fmaxf(mx, s[b][r]); }
         }
-        mx = fmaxf(mx, __shfl_xor(mx, 16)); mx = fmaxf(mx, __shfl_xor(mx, 32));
+        mx = fmaxf(mx, __shfl_xor(mx, 32));
         const float mn = fmaxf(mq, mx);
-        float pv[8], ps = 0.f;
-#pragma unroll
-        for (int j = 0; j < 2; ++j)
-#pragma unroll
-            for (int r = 0; r < 4; ++r) {
-                const float e = __expf(s[j][r] - mn);            // masked scores: exp(-1e30 - mn) = 0
-                pv[4 * j + r] = e; ps += e;
-            }
-        bf16x8_t pf;
-        {
-            const uint4 pk = make_uint4(cvt_pk_bf16(pv[0], pv[1]), cvt_pk_bf16(pv[2], pv[3]), cvt_pk_bf16(pv[4], pv[5]), cvt_pk_bf16(pv[6], pv[7]));
-            pf = __builtin_bit_cast(bf16x8_t, pk);
-        }
-        ps += __shfl_xor(ps, 16); ps += __shfl_xor(ps, 32);
-        // the running maximum moves on few steps: rescale (l, O) lazily behind a wave-uniform test.  O rows are queries
-        // 4 g + r: their factor lives in the lanes of column 4 g + r.
-        if (__any(mn > mq)) {
-            const float corr = __expf(mq - mn);
+        if (__any(mn > mq)) {                                 // lazily: the running maximum moves on few tiles
+            const float corr = __builtin_amdgcn_exp2f(mq - mn);
             lq *= corr;
 #pragma unroll
-            for (int r = 0; r < 4; ++r) {
-                const float cr = __shfl(corr, 4 * g + r);
+            for (int nt = 0; nt < NT; ++nt)
 #pragma unroll
-                for (int nt = 0; nt < NT; ++nt) o[nt][r] *= cr;
+                for (int e = 0; e < 16; ++e) o[nt][e] *= corr;
+            mq = mn;
+        }
+        bf16x8_t pf[4];                                       // step st = 2 b + j: keys 32 b + 16 j ..
+#pragma unroll
+        for (int st = 0; st < 4; ++st) {
+            float e[8];
+#pragma unroll
+            for (int i = 0; i < 8; ++i) { e[i] = __builtin_amdgcn_exp2f(s[st >> 1][8 * (st & 1) + i] - mq); lq += e[i]; }    // masked: exp2(-1e30) = 0
+            const uint4 pk = make_uint4(cvt_pk_bf16(e[0], e[1]), cvt_pk_bf16(e[2], e[3]), cvt_pk_bf16(e[4], e[5]), cvt_pk_bf16(e[6], e[7]));
+            pf[st] = __builtin_bit_cast(bf16x8_t, pk);
+        }
+        // ---- O^T += V^T P^T: the 2 NT transposed reads of step st + 1 are issued before the NT MFMAs of step st ----
+        uint2 va[2 * NT], vn[2 * NT];
+        const uint32_t a0 = (uint32_t)(uintptr_t)vb + vrd;
+        auto issue = [&](int st, uint2 (&v)[2 * NT]) {       // st is a literal at every call site
+            const uint32_t a = a0 + ((st >> 1) * DSUB) * VSUB + (16 * (st & 1)) * 32;
+            if constexpr (NT == 4) {
+                asm volatile("ds_read_b64_tr_b16 %0, %8\n\tds_read_b64_tr_b16 %1, %8 offset:256\n\t"
+                             "ds_read_b64_tr_b16 %2, %8 offset:2304\n\tds_read_b64_tr_b16 %3, %8 offset:2560\n\t"
+                             "ds_read_b64_tr_b16 %4, %8 offset:4608\n\tds_read_b64_tr_b16 %5, %8 offset:4864\n\t"
+                             "ds_read_b64_tr_b16 %6, %8 offset:6912\n\tds_read_b64_tr_b16 %7, %8 offset:7168"
+                             : "=&v"(v[0]), "=&v"(v[1]), "=&v"(v[2]), "=&v"(v[3]), "=&v"(v[4]), "=&v"(v[5]), "=&v"(v[6]), "=&v"(v[7])
+                             : "v"(a) : "memory");
+            } else {
+                asm volatile("ds_read_b64_tr_b16 %0, %4\n\tds_read_b64_tr_b16 %1, %4 offset:256\n\t"
+                             "ds_read_b64_tr_b16 %2, %4 offset:2304\n\tds_read_b64_tr_b16 %3, %4 offset:2560"
+                             : "=&v"(v[0]), "=&v"(v[1]), "=&v"(v[2]), "=&v"(v[3]) : "v"(a) : "memory");
             }
-        }
-        lq += ps;
-        mq = mn;
-        // ---- O += P V : B fragment lane (dim = 16 nt + ln, g) = V[kt + 8 g .. + 7][dim] = 16 B of the transposed tile ----
-        const uint16_t* vt = &vt_lds[buf][(size_t)ln * VTLD + g * 8];
+        };
+        auto landed = [&](uint2 (&v)[2 * NT], auto more) {   // wait-only statement that (re)defines the set: its consumers cannot move above it
+            if constexpr (NT == 4) {
+                if constexpr (decltype(more)::value) asm volatile("s_waitcnt lgkmcnt(8)" : "+v"(v[0]), "+v"(v[1]), "+v"(v[2]), "+v"(v[3]), "+v"(v[4]), "+v"(v[5]), "+v"(v[6]), "+v"(v[7]) :: "memory");
+                else asm volatile("s_waitcnt lgkmcnt(0)" : "+v"(v[0]), "+v"(v[1]), "+v"(v[2]), "+v"(v[3]), "+v"(v[4]), "+v"(v[5]), "+v"(v[6]), "+v"(v[7]) :: "memory");
+            } else {
+                if constexpr (decltype(more)::value) asm volatile("s_waitcnt lgkmcnt(4)" : "+v"(v[0]), "+v"(v[1]), "+v"(v[2]), "+v"(v[3]) :: "memory");
+                else asm volatile("s_waitcnt lgkmcnt(0)" : "+v"(v[0]), "+v"(v[1]), "+v"(v[2]), "+v"(v[3]) :: "memory");
+            }
+        };
+        auto pv = [&](int st, uint2 (&v)[2 * NT]) {
 #pragma unroll
-        for (int nt = 0; nt < NT; ++nt) {
-            const bf16x8_t vf = *reinterpret_cast<const bf16x8_t*>(vt + nt * 16 * VTLD);
-            o[nt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(pf, vf, o[nt], 0, 0, 0);
-        }
+            for (int nt = 0; nt < NT; ++nt) {
+                const bf16x8_t vf = __builtin_bit_cast(bf16x8_t, make_uint4(v[2 * nt].x, v[2 * nt].y, v[2 * nt + 1].x, v[2 * nt + 1].y));
+                o[nt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(vf, pf[st], o[nt], 0, 0, 0);
+            }
+        };
+        __builtin_amdgcn_sched_barrier(0);
+        issue(0, va);
+        issue(1, vn); landed(va, std::true_type{}); pv(0, va); __builtin_amdgcn_sched_barrier(0);
+        issue(2, va); landed(vn, std::true_type{}); pv(1, vn); __builtin_amdgcn_sched_barrier(0);
+        issue(3, vn); landed(va, std::true_type{}); pv(2, va); __builtin_amdgcn_sched_barrier(0);
+        landed(vn, std::false_type{}); pv(3, vn);
     }
-    // ---- finish: normalise (row sum of query 4 g + r from the lanes of that column), store ----
+    // ---- finish: this lane holds O[q][32 nt + (r & 3) + 8 (r >> 2) + 4 hi]; the row sum is split over lanes q and q + 32 ----
+    if (!wave_has_rows) return;
+    const float l = lq + __shfl_xor(lq, 32);
+    const int qr = r0 + ql;
+    if (qr < sd.Tq) {
+        const float inv = 1.f / l;
+        uint16_t* op = out + ((size_t)(sd.q_row0 + qr) * H + head) * D + 4 * hi;
 #pragma unroll
-    for (int r = 0; r < 4; ++r) {
-        const float l = __shfl(lq, 4 * g + r);
-        const int qr = r0 + g * 4 + r;
-        if (qr < sd.Tq) {
-            const float inv = 1.f / l;
-            uint16_t* op = out + ((size_t)(sd.q_row0 + qr) * H + head) * D + ln;
+        for (int nt = 0; nt < NT; ++nt)
 #pragma unroll
-            for (int nt = 0; nt < NT; ++nt) op[nt * 16] = (uint16_t)(cvt_pk_bf16(o[nt][r] * inv, 0.f) & 0xFFFFu);
-        }
+            for (int r4 = 0; r4 < 4; ++r4) {
+                const uint2 w = make_uint2(cvt_pk_bf16(o[nt][4 * r4] * inv, o[nt][4 * r4 + 1] * inv), cvt_pk_bf16(o[nt][4 * r4 + 2] * inv, o[nt][4 * r4 + 3] * inv));
+                *reinterpret_cast<uint2*>(op + 32 * nt + 8 * r4) = w;
+            }
     }
+#endif
 }
 
 // ------------------------------------------------------------------ LayerNorm (CLIP ViT)
@@ -342,18 +410,23 @@ int vdd_flash_attention(const void* q, const void* k_cache, const void* v_cache,
                         int64_t prefix_stride, int prefix_tmax, float scale, int causal, void* stream) {
     if (n_seq <= 0 || max_tq <= 0) return VDD_OK;
     if (!q || !k_cache || !v_cache || !k_prefix || !v_prefix || !seqs || !out || (D != 128 && D != 64) || H % Hkv != 0) return VDD_ERR_INVALID_ARG;
-    dim3 grid((max_tq + 63) / 64, H, n_seq), block(256);
+    const int nx = (max_tq + 127) / 128;
+    dim3 grid((unsigned)(((long long)H * n_seq + 7) / 8 * 8 * nx)), block(256);
     hipStream_t st = (hipStream_t)stream;
     auto Q = (const uint16_t*)q; auto K = (const uint16_t*)k_cache; auto V = (const uint16_t*)v_cache; auto O = (uint16_t*)out;
     auto S = (const SeqDesc*)seqs; auto KP = (const uint16_t*)k_prefix; auto VP = (const uint16_t*)v_prefix;
     const long long ps = (long long)prefix_stride;
-    if (D == 128) {
-        if (causal) hipLaunchKernelGGL((flash_attn_kernel<128, true>), grid, block, 0, st, Q, K, V, KP, VP, S, O, H, Hkv, (long long)slot_stride, t_max, ps, prefix_tmax, scale);
-        else hipLaunchKernelGGL((flash_attn_kernel<128, false>), grid, block, 0, st, Q, K, V, KP, VP, S, O, H, Hkv, (long long)slot_stride, t_max, ps, prefix_tmax, scale);
-    } else {
-        if (causal) hipLaunchKernelGGL((flash_attn_kernel<64, true>), grid, block, 0, st, Q, K, V, KP, VP, S, O, H, Hkv, (long long)slot_stride, t_max, ps, prefix_tmax, scale);
-        else hipLaunchKernelGGL((flash_attn_kernel<64, false>), grid, block, 0, st, Q, K, V, KP, VP, S, O, H, Hkv, (long long)slot_stride, t_max, ps, prefix_tmax, scale);
+#define VDD_FLASH(DD, CC)                                                                                                        \
+    {                                                                                                                            \
+        auto kfn = flash_attn2_kernel<DD, CC>;                                                                                   \
+        constexpr int smem = 2 * (64 * DD * 2 + 2 * (DD / 16) * 1152);                                                           \
+        static bool attr_set = false;                                                                                            \
+        if (!attr_set) { (void)hipFuncSetAttribute((const void*)kfn, hipFuncAttributeMaxDynamicSharedMemorySize, smem); attr_set = true; } \
+        hipLaunchKernelGGL(kfn, grid, block, smem, st, Q, K, V, KP, VP, S, O, H, Hkv, (long long)slot_stride, t_max, ps, prefix_tmax, scale, nx, n_seq); \
     }
+    if (D == 128) { if (causal) VDD_FLASH(128, true) else VDD_FLASH(128, false) }
+    else { if (causal) VDD_FLASH(64, true) else VDD_FLASH(64, false) }
+#undef VDD_FLASH
     return ok();
 }
 

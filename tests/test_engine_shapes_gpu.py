@@ -50,7 +50,14 @@ def _compare(eng, ref, ids, imgs, mode_kw, warp_kw, n_new, questions, tol):
             s_got, s_want = out.scores[step][q].float().cpu(), r.scores[step][0].float().cpu()
             fin = torch.isfinite(s_got) & torch.isfinite(s_want)
             # tokens whose main-branch logit (or cumulative mass) sits within bf16 noise of a cutoff may fall on either side
-            assert fin.sum() >= 1 and (torch.isfinite(s_got) ^ torch.isfinite(s_want)).sum() <= 3 + 0.25 * int(fin.sum()), (q, step)   # candidate density x logit noise
+            flip = torch.isfinite(s_got) ^ torch.isfinite(s_want)
+            assert fin.sum() >= 1, (q, step)
+            if flip.sum() > 3 + 0.25 * int(fin.sum()):               # candidate density x logit noise
+                # top-p on a knife edge (the kept mass crosses p within noise of a token boundary): one side stops, the other
+                # goes on through the flat tail - whatever it adds carries at most the (1 - p) mass top-p may remove
+                assert "top_p" in warp_kw, (q, step)
+                big = s_got if torch.isfinite(s_got).sum() > torch.isfinite(s_want).sum() else s_want
+                assert torch.softmax(big, -1)[flip].sum().item() <= (1.0 - warp_kw["top_p"]) + 0.02, (q, step)
             tol_s = tol + 0.02 * s_want[fin].abs().max().item()                  # the scores are bf16: 2-3 ulps of their own magnitude
             assert (s_got[fin] - s_want[fin]).abs().max().item() <= tol_s, (q, step)
             top2 = torch.topk(s_want, 2).values
