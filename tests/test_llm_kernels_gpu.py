@@ -175,12 +175,13 @@ def test_swiglu_linear_equals_gemm_then_silu_mul(M):
 
 @pytest.mark.parametrize("D,H,Hkv,causal", [(128, 4, 4, True), (128, 8, 2, True), (64, 4, 4, False)])
 def test_flash_attention_prefill(D, H, Hkv, causal):
-    """Packed sequences, ragged lengths, a sequence that continues a shared prefix held in another slot."""
+    """Packed sequences, ragged lengths (several 128-row query blocks with causally skipped tiles, a single row), sequences that
+    continue a shared prefix held in another slot (a K / V tile then straddles the two pools)."""
     O = ops()
     T, S = 700, 4
     kc, vc = bf(S, Hkv, T, D, seed=21), bf(S, Hkv, T, D, seed=22)
     # (q_row0, Tq, pos0, slot, pslot, plen)
-    seqs = [(0, 100, 0, 0, 0, 0), (100, 1, 0, 1, 0, 0), (101, 65, 0, 2, 0, 0), (166, 30, 611, 3, 0, 611)] if causal else \
+    seqs = [(0, 300, 0, 0, 0, 0), (300, 1, 0, 1, 0, 0), (301, 65, 0, 2, 0, 0), (366, 30, 611, 3, 0, 611), (396, 130, 36, 1, 2, 36)] if causal else \
            [(0, 577, 0, 0, 0, 0), (577, 33, 0, 1, 0, 0)]
     Ttot = sum(s[1] for s in seqs)
     q = bf(Ttot, H * D, seed=23)
