@@ -516,7 +516,7 @@ class _DecodeRunner:
         lm = eng.cfg.lm
         # the step's own partials buffer (also for the ungrouped split-KV pass): a captured graph must not point into a
         # shared buffer that a later, larger call re-allocates
-        self.workspace = ops.attention_workspace(R, lm.n_heads, lm.head_dim, eng._kv.t_pre + eng._kv.t_own, dev)
+        self.workspace = ops.attention_workspace(R, lm.n_heads, lm.head_dim, eng._kv.t_pre + (eng._kv.t_own + 63) // 64 * 64, dev)
         if tail.get("n_groups", 0) > 0:
             self.grouping = dict(groups=torch.zeros(max(1, tail["n_groups"]), 4, **i32), group_rows=torch.zeros(R, **i32),
                                  n_groups=tail["n_groups"], items=torch.zeros(max(1, tail["n_items"]), 4, **i32), n_items=tail["n_items"],
@@ -625,8 +625,9 @@ class VddLlavaEngine:
 
     # -- plumbing ---------------------------------------------------------------------------
     def kv(self, n_pre, t_pre, n_own, t_own):
-        r64 = lambda v: (v + 63) // 64 * 64
-        t_pre, t_own = r64(max(t_pre, 64)), r64(max(t_own, 64))
+        # prefix slots are whole 64-key chunks (the fragment image); own slots only need whole 16-key groups: 92 own tokens take
+        # 96 rows, not 128 (a quarter of the own pool, 26 GB at 768 questions)
+        t_pre, t_own = (max(t_pre, 64) + 63) // 64 * 64, (max(t_own, 64) + 15) // 16 * 16
         if self._kv is None or not self._kv.fits(n_pre, t_pre, n_own, t_own):
             old = self._kv
             self._kv = None
