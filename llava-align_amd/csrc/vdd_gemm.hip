@@ -268,19 +268,20 @@ __global__ void __launch_bounds__(WM * WN * 64) gemm_kernel(const GemmArgs a) {
             const int r_last = owner(tu + a.UP - 1), others = r_last - rng;
             if (tid == 0) {
                 while (__hip_atomic_load(a.counter + cL, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) < others) __builtin_amdgcn_s_sleep(8);
-                __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
                 __hip_atomic_store(a.counter + cL, 0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);     // ready for the next launch
             }
             __syncthreads();
+            // the slabs are read with agent-scope (sc1) loads, straight from where the write-through stores put them: an acquire
+            // FENCE here is a buffer_inv sc1, which drops this XCD's whole L2 under the 31 workgroups still streaming through it
             for (int r = rng + 1; r <= r_last; ++r) {
-                const float* ps = a.partial + (size_t)r * (BM * BN);
+                const __amdgpu_buffer_rsrc_t rq = __builtin_amdgcn_make_buffer_rsrc((void*)(a.partial + (size_t)r * (BM * BN)), 0, BM * BN * 4, 0x00020000);
 #pragma unroll
                 for (int i = 0; i < NI; ++i)
 #pragma unroll
                     for (int j = 0; j < MI; ++j)
 #pragma unroll
                         for (int q = 0; q < 4; ++q) {
-                            const f32x4_t v = *reinterpret_cast<const f32x4_t*>(ps + ((size_t)((i * MI + j) * 4 + q) * NT + tid) * 4);
+                            const f32x4_t v = __builtin_bit_cast(f32x4_t, __builtin_amdgcn_raw_buffer_load_b128(rq, (((i * MI + j) * 4 + q) * NT + tid) * 16, 0, 16));
                             acc[i][j][q * 4] += v[0]; acc[i][j][q * 4 + 1] += v[1]; acc[i][j][q * 4 + 2] += v[2]; acc[i][j][q * 4 + 3] += v[3];
                         }
             }
@@ -397,7 +398,7 @@ int launch_cfg(const GemmArgs& a0, int epi, int sched, void* workspace, int64_t 
         VDD_GEMM_LAUNCH(EPI_BIAS_GELU)
         VDD_GEMM_LAUNCH(EPI_BIAS_RESID)
         case EPI_SWIGLU:
-            if constexpr ((BN / WN / 32) % 2 == 0) {
+            if constexpr ((BN / WN / 32) % 2 == 0 && 256 % BN == 0) {           // gate / up pairs inside a wave; F % 128 == 0 tiles the features
                 switch (epi) { VDD_GEMM_LAUNCH(EPI_SWIGLU) }
                 break;
             } else {
@@ -444,6 +445,8 @@ int vdd_gemm(const void* X, const void* W, void* Y, const void* bias, const void
         case 3: return launch_cfg<256, 128, 4, 2>(a, epilogue, sched, workspace, workspace_bytes, st);
         case 4: return launch_cfg<192, 256, 2, 4>(a, epilogue, sched, workspace, workspace_bytes, st);
         case 5: return launch_cfg<256, 192, 4, 2>(a, epilogue, sched, workspace, workspace_bytes, st);
+        case 6: return launch_cfg<192, 192, 2, 3>(a, epilogue, sched, workspace, workspace_bytes, st);      // 6 waves of 96 x 64
+        case 7: return launch_cfg<192, 128, 2, 4>(a, epilogue, sched, workspace, workspace_bytes, st);      // 8 waves of 96 x 32
         default: return VDD_ERR_INVALID_ARG;
     }
 }

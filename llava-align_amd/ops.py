@@ -151,7 +151,7 @@ SKINNY_MAX_M = 8      # measured on MI355X (tools/e2e_probe.py): the weight-stre
 EPI_NONE, EPI_BIAS, EPI_BIAS_QUICK_GELU, EPI_BIAS_GELU, EPI_SWIGLU, EPI_BIAS_RESID = range(6)
 GEMM_TUNE_MAX_M = 4096          # shapes up to here (the decode batch, single images) pick their tile shape / schedule by a
                                 # one-off timing run; above, 256 x 256 tiles + the hybrid schedule (tools/gemm_sched.py)
-GEMM_CANDIDATES = [(c, s_) for c in (1, 2, 3, 4, 5) for s_ in (0, 1, 2)]     # (macro tile id, schedule) -> config = c + 16 * s
+GEMM_CANDIDATES = [(c, s_) for c in (1, 2, 3, 4, 5, 6, 7) for s_ in (0, 1, 2)]     # (macro tile id, schedule) -> config = c + 16 * s
 GEMM_BATCH_INVARIANT = False    # True: data-parallel schedule only.  Every output element is then accumulated over K in one fixed
                                 # order whatever the macro tile, i.e. a row's result does not depend on which other rows are in the
                                 # batch (stream-K cuts K where the batch shape puts the cut); costs the load balance at decode size
@@ -209,7 +209,7 @@ def _gemm_tune(x, w, out, bias, resid, M, N, K, epi, ws, iters=3):
     best, best_t = 1, float("inf")
     e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
     for c, sch in GEMM_CANDIDATES:
-        if (epi == EPI_SWIGLU and c == 5) or (GEMM_BATCH_INVARIANT and sch != 1):
+        if (epi == EPI_SWIGLU and c in (5, 6, 7)) or (GEMM_BATCH_INVARIANT and sch != 1):
             continue
         cfg = c + 16 * sch
         _gemm_call(x, w, out, bias, resid, M, N, K, epi, cfg, ws)
