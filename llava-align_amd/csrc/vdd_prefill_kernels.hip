@@ -259,20 +259,34 @@ __global__ void __launch_bounds__(256, 2) flash_attn2_kernel(const uint16_t* __r
         issue(3, vn); landed(va, std::true_type{}); pv(2, va); __builtin_amdgcn_sched_barrier(0);
         landed(vn, std::false_type{}); pv(3, vn);
     }
-    // ---- finish: this lane holds O[q][32 nt + (r & 3) + 8 (r >> 2) + 4 hi]; the row sum is split over lanes q and q + 32 ----
+    // ---- finish: this lane holds O[q][32 nt + (r & 3) + 8 (r >> 2) + 4 hi]; the row sum is split over lanes q and q + 32.
+    // Stored from the registers that is 16 stores of 8 B per lane at a row stride (every store instruction touches 32 rows, every
+    // 128-byte line is written 8 times): 14 % of the kernel at 611-token prefixes.  So the wave's 32 x D tile goes through LDS
+    // (the K / V buffers are free now) and leaves as whole rows, 16 B per lane, 4 rows per instruction.
+    __syncthreads();                                          // every wave is done with the tile buffers
     if (!wave_has_rows) return;
-    const float l = lq + __shfl_xor(lq, 32);
-    const int qr = r0 + ql;
-    if (qr < sd.Tq) {
-        const float inv = 1.f / l;
-        uint16_t* op = out + ((size_t)(sd.q_row0 + qr) * H + head) * D + 4 * hi;
+    const float inv = 1.f / (lq + __shfl_xor(lq, 32));
+    constexpr int OP = D * 2 + 16;                            // row pitch of the staging tile (16-byte aligned, off the 256-byte bank period)
+    char* ot = lds + wave * (32 * OP);
 #pragma unroll
-        for (int nt = 0; nt < NT; ++nt)
+    for (int nt = 0; nt < NT; ++nt)
 #pragma unroll
-            for (int r4 = 0; r4 < 4; ++r4) {
-                const uint2 w = make_uint2(cvt_pk_bf16(o[nt][4 * r4] * inv, o[nt][4 * r4 + 1] * inv), cvt_pk_bf16(o[nt][4 * r4 + 2] * inv, o[nt][4 * r4 + 3] * inv));
-                *reinterpret_cast<uint2*>(op + 32 * nt + 8 * r4) = w;
-            }
+        for (int r4 = 0; r4 < 4; ++r4) {
+            const uint2 w = make_uint2(cvt_pk_bf16(o[nt][4 * r4] * inv, o[nt][4 * r4 + 1] * inv), cvt_pk_bf16(o[nt][4 * r4 + 2] * inv, o[nt][4 * r4 + 3] * inv));
+            *reinterpret_cast<uint2*>(ot + ql * OP + (32 * nt + 8 * r4 + 4 * hi) * 2) = w;
+        }
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");    // same wave reads it back: LDS program order
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+    constexpr int CPRO = D / 8;                               // 16-byte chunks per output row
+    constexpr int RPI = 64 / CPRO;                            // rows per store instruction (4 at D = 128, 8 at D = 64)
+#pragma unroll
+    for (int i = 0; i < 32 / RPI; ++i) {
+        const int row = i * RPI + lane / CPRO, c = lane % CPRO;
+        const int qr = r0 + row;
+        if (qr < sd.Tq) {
+            const uint4 v = *reinterpret_cast<const uint4*>(ot + row * OP + c * 16);
+            *reinterpret_cast<uint4*>(out + ((size_t)(sd.q_row0 + qr) * H + head) * D + c * 8) = v;
+        }
     }
 #endif
 }
