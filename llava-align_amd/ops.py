@@ -204,7 +204,7 @@ def gemm(x, w, bias=None, resid=None, epi=EPI_NONE, out=None, config=None):
     return out
 
 
-def _gemm_tune(x, w, out, bias, resid, M, N, K, epi, ws, iters=3):
+def _gemm_tune(x, w, out, bias, resid, M, N, K, epi, ws, iters=8):
     """Times every (tile shape, schedule) candidate on the real operands and keeps the fastest (all write the same result)."""
     best, best_t = 1, float("inf")
     e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
