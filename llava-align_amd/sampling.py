@@ -77,6 +77,11 @@ def _row_view(t: torch.Tensor, name: str):
     return t
 
 
+# True: every contrast_sample call that does not say otherwise (the drop-in sample() and the engine included) uses torch-GPU's
+# scalar arithmetic for the plausibility cutoff and the temperature - what the reference computes when its tensors live on a GPU.
+GPU_SCALAR_SEMANTICS = False
+
+
 def contrast_sample(logits_v: torch.Tensor, logits_cd: Optional[torch.Tensor] = None,
                     logits_dd: Optional[torch.Tensor] = None, *, alpha: float = 0.5, beta: float = 0.1,
                     warp: Optional[WarpSpec] = None, seed: Optional[int] = None, offset: Optional[int] = None,
@@ -84,7 +89,7 @@ def contrast_sample(logits_v: torch.Tensor, logits_cd: Optional[torch.Tensor] = 
                     pad_id: Optional[int] = None, unfinished: Optional[torch.Tensor] = None,
                     out_tokens: Optional[torch.Tensor] = None, return_scores: bool = False,
                     out_scores: Optional[torch.Tensor] = None, n_top: int = 0, pick_argmax: bool = False,
-                    no_sample: bool = False, cutoff_f32_scalar: bool = False, temp_reciprocal: bool = False,
+                    no_sample: bool = False, cutoff_f32_scalar: Optional[bool] = None, temp_reciprocal: Optional[bool] = None,
                     topp_fp32_mass: bool = False,
                     workspace: Optional[torch.Tensor] = None, stream: Optional[int] = None,
                     offset_ptr: Optional[torch.Tensor] = None, status_out: Optional[torch.Tensor] = None) -> SampleOutput:
@@ -92,7 +97,16 @@ def contrast_sample(logits_v: torch.Tensor, logits_cd: Optional[torch.Tensor] = 
 
     logits_cd=None is the reference's plain path (:204-207); logits_dd selects the
     both-branches average (:185).  Asynchronous on the current stream.
+
+    cutoff_f32_scalar / temp_reciprocal select torch-GPU's scalar arithmetic (log(beta) added in fp32 before the rounding, the
+    temperature division as a multiply by the reciprocal) instead of torch-CPU's, which the golden vectors were made with; None =
+    the module default GPU_SCALAR_SEMANTICS (False).  Both forms are bit-exact against their own torch backend
+    (tests/test_kernel_gpu.py::test_torch_gpu_eager_agrees_within_reference_tolerance); they differ by at most 1 ulp.
     """
+    if cutoff_f32_scalar is None:
+        cutoff_f32_scalar = GPU_SCALAR_SEMANTICS
+    if temp_reciprocal is None:
+        temp_reciprocal = GPU_SCALAR_SEMANTICS
     if not logits_v.is_cuda:
         raise _lib.VddLibraryError("contrast_sample needs device tensors: this package has no CPU path")
     lib = _lib.load_lib()

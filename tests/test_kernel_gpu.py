@@ -426,6 +426,14 @@ def test_torch_gpu_eager_agrees_within_reference_tolerance():
     n_diff = int((_bits(out2.scores) != _bits(eager)).sum())
     print("torch-GPU eager vs kernel(gpu-scalar flags): differing elements =", n_diff,
           "| default flags:", int((_bits(out.scores) != _bits(eager)).sum()))
+    assert n_diff == 0
+    import llava_align_amd.sampling as S                       # the process-wide switch reaches calls that do not pass the flags
+    try:
+        S.GPU_SCALAR_SEMANTICS = True
+        out3 = L.contrast_sample(v, c, alpha=alpha, beta=beta, warp=L.WarpSpec(temperature=T), return_scores=True)
+    finally:
+        S.GPU_SCALAR_SEMANTICS = False
+    assert torch.equal(_bits(out3.scores), _bits(out2.scores))
 
 
 def test_add_diffusion_noise_matches_oracle_with_explicit_noise(golden_dir):
