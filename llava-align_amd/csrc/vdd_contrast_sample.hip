@@ -880,17 +880,25 @@ __global__ void __launch_bounds__(BLOCK, 6) vdd_contrast_sample_kernel(KP p) {
         }
     }
     if (p.use_topp && !row_bad && !topp_done) {                     // more candidates than the list holds (or VDD_TOPP_FP32_MASS):
-        float z = 0.f;
+        float z = 0.f, zb = 0.f;                            // total mass; mass of everything below the row maximum
         for (int ch = tid, k = 0; ch < nch; ch += BLOCK, ++k) {
             if (!(k >= 64 || ((livemask >> k) & 1ull) != 0ull)) continue;
             uint32_t w[4]; R.get(ch, w);
 #pragma unroll
-            for (int j = 0; j < EPC; ++j) { uint32_t b = getb<DT>(w, j); if (b != NINF) z += __expf(Tr<DT>::to_f(b) - m); }
+            for (int j = 0; j < EPC; ++j) {
+                uint32_t b = getb<DT>(w, j);
+                if (b != NINF) { const float x = Tr<DT>::to_f(b), e = __expf(x - m); z += e; zb += (x < m) ? e : 0.f; }
+            }
         }
         z = block_sum(z, sm, lane, wave);
+        zb = block_sum(zb, sm, lane, wave);
         const float thr = rnd<DT>(p.one_minus_p) * z;      // cum <= fl(1-p)  <=>  mass <= fl(1-p) * Z
         uint32_t pkey = 0;
-        bool crossed = select_mass_key<DT, LDSROW>(R, nch, m, thr, sm, tid, lane, wave, pkey, livemask);
+        bool crossed;
+        // a peaked row (the usual one when a model is confident): everything below the maximum together is mass top-p removes, so
+        // the threshold is the maximum itself and the two radix passes over the row are not needed
+        if (zb <= thr) { crossed = true; pkey = okey<DT>(Tr<DT>::from_f(m)); }
+        else crossed = select_mass_key<DT, LDSROW>(R, nch, m, thr, sm, tid, lane, wave, pkey, livemask);
         // never remove the top min_keep entries
         uint32_t keep_key;
         if (p.min_keep <= 1) keep_key = okey<DT>(Tr<DT>::from_f(m));
