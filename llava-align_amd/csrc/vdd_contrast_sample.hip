@@ -142,6 +142,8 @@ struct ToppScratch { float gx[TOPP_EXACT_MAX]; int gi[TOPP_EXACT_MAX]; float sp[
 // contrasted chunk out.  448 entries keep three 32000-wide bf16 rows per CU (40 KiB LDS row part + Smem + the list each).
 constexpr int LIVE_CAP = 448;
 struct LiveList { uint4 data[LIVE_CAP]; int ch[LIVE_CAP]; };
+constexpr int TOPK_LIST_MAX = 1024;      // ordered keys of the top-k candidate list (same scratch region)
+static_assert(TOPK_LIST_MAX * 4 <= (int)sizeof(LiveList), "");
 
 __device__ __forceinline__ float wave_max(float v) {
 #pragma unroll
@@ -594,6 +596,7 @@ __global__ void __launch_bounds__(BLOCK, 6) vdd_contrast_sample_kernel(KP p) {
             }
         }
     }
+    const float m_thr = m;                                   // this thread's own maximum (the top-k candidate bound below)
     int flags2 = t_nan + 2048 * t_pinf;                      // per-thread 0/1 flags: sums stay < 2^22
     block_max_count2(m, nfin, flags2, sm, lane, wave);
     const bool has_nan = (flags2 % 2048) != 0;
@@ -601,6 +604,76 @@ __global__ void __launch_bounds__(BLOCK, 6) vdd_contrast_sample_kernel(KP p) {
     const bool row_bad = (nfin == 0) || has_nan || has_pinf;
 
     auto flagged = [&](int k) { return k >= 64 || ((livemask >> k) & 1ull) != 0ull; };
+
+    // ---- top-k on a row with many candidates (plain sampling: all V of them): by a candidate LIST instead of the radix selection.
+    // In every wave take the j-th largest of the 64 per-thread maxima, j = ceil(k / 8); the smallest of those eight values, L, has at
+    // least 8 j >= k elements at or above it, so the k-th largest element of the row is among {x >= L} - a few dozen to a few
+    // hundred entries for k = 50.  They are gathered into an LDS list, the k-th largest is found by counting, and the row is
+    // masked in ONE pass that also recounts the survivors and rebuilds the livemask (usually <= 64 survive: the single-wave tail
+    // takes over).  The radix selection it replaces makes two passes over the row with one LDS atomic per element, most of them
+    // on a handful of exponent bins (same-address atomics serialise): 175 us of a 357-us launch at B = 4096, V = 32000, k = 50.
+    bool topk_done = false;
+    if (!row_bad && p.top_k > 0 && nfin > 64 && nch <= 64 * BLOCK) {
+        const int k = p.top_k < p.min_keep ? p.min_keep : p.top_k;
+        if (k < nfin && k <= BLOCK) {
+            uint32_t* ck = reinterpret_cast<uint32_t*>(reinterpret_cast<unsigned char*>(&sm) + ((sizeof(Smem) + 15) & ~(size_t)15));
+            const int jj = (k + NWAVE - 1) / NWAVE;
+            int gt = 0;
+            for (int q = 0; q < 64; ++q) { const float o = __shfl(m_thr, q); gt += (o > m_thr || (o == m_thr && q < lane)) ? 1 : 0; }
+            const float wl = -wave_max((gt == jj - 1) ? -m_thr : -INFINITY);          // the wave's jj-th largest thread maximum
+            if (lane == 0) sm.f[0][wave] = wl;
+            if (tid == 0) sm.cand_n = 0u;
+            __syncthreads();
+            float L = sm.f[0][0];
+#pragma unroll
+            for (int w = 1; w < NWAVE; ++w) L = fminf(L, sm.f[0][w]);
+            for (int ch = tid, kq = 0; ch < nch; ch += BLOCK, ++kq) {
+                if (!flagged(kq)) continue;
+                uint32_t w[4]; R.get(ch, w);
+#pragma unroll
+                for (int j = 0; j < EPC; ++j) {
+                    const uint32_t b = getb<DT>(w, j);
+                    if (b != NINF && Tr<DT>::to_f(b) >= L) {
+                        const unsigned slot = atomicAdd(&sm.cand_n, 1u);
+                        if (slot < (unsigned)TOPK_LIST_MAX) ck[slot] = okey<DT>(b);
+                    }
+                }
+            }
+            __syncthreads();
+            const int n = (int)sm.cand_n;
+            if (n <= TOPK_LIST_MAX) {                   // (n >= k by construction; a row of ties can overflow the list: radix path below)
+                for (int e = tid; e < n; e += BLOCK) {
+                    const uint32_t key = ck[e];
+                    int g = 0, ge = 0;
+                    for (int q = 0; q < n; ++q) { const uint32_t o = ck[q]; g += (o > key) ? 1 : 0; ge += (o >= key) ? 1 : 0; }
+                    if (g < k && k <= ge) sm.sel[0] = key;     // every entry holding the k-th largest value writes the same key
+                }
+                __syncthreads();
+                const uint32_t kth = sm.sel[0];
+                int cnt = 0, zero = 0; unsigned long long lm2 = 0ull;
+                for (int ch = tid, kq = 0; ch < nch; ch += BLOCK, ++kq) {
+                    if (!flagged(kq)) continue;
+                    uint32_t w[4]; R.get(ch, w);
+                    bool changed = false, any = false;
+#pragma unroll
+                    for (int j = 0; j < EPC; ++j) {
+                        const uint32_t b = getb<DT>(w, j);
+                        if (b == NINF) continue;
+                        if (okey<DT>(b) < kth) { setb<DT>(w, j, NINF); changed = true; } else { ++cnt; any = true; }
+                    }
+                    if (changed) R.put(ch, w);
+                    if (any && kq < 64) lm2 |= 1ull << kq;
+                }
+                livemask = lm2;
+                float mm = m;
+                block_max_count2(mm, cnt, zero, sm, lane, wave);
+                nfin = cnt;
+                topk_done = true;
+            }
+            if (tid == 0) sm.cand_n = 0u;               // the single-wave tail gathers into the same counter
+            __syncthreads();
+        }
+    }
     auto store_scores = [&]() {
         if (p.scores != nullptr) {
             if constexpr (LDSROW) {
@@ -807,7 +880,7 @@ __global__ void __launch_bounds__(BLOCK, 6) vdd_contrast_sample_kernel(KP p) {
     }
 
     // ---- top-k (HF TopKLogitsWarper: scores < kth -> -inf, ties kept) ------------
-    if (p.top_k > 0 && !has_nan && nfin > 0) {
+    if (p.top_k > 0 && !has_nan && nfin > 0 && !topk_done) {
         int k = p.top_k < p.min_keep ? p.min_keep : p.top_k;
         if (k < nfin) {
             uint32_t kth = select_kth_key<DT, LDSROW>(R, nch, (unsigned)k, sm, tid, lane, wave, livemask);
@@ -1141,7 +1214,7 @@ int vdd_contrast_sample(const vdd_sample_params* p, void* hip_stream) {
         else return fail(VDD_ERR_INVALID_ARG, "V exceeds vdd_lds_row_capacity(dtype): pass scores_out or workspace [B,V]");
         kp.vec_work = al(kp.work, kp.sw);
     }
-    const size_t scratch = kp.c == nullptr ? 0 : sizeof(LiveList);          // the two scratch users never overlap in time
+    const size_t scratch = (kp.c == nullptr && kp.top_k == 0) ? 0 : sizeof(LiveList);     // pass B's work list / the top-k candidate list; the scratch users never overlap in time
     const size_t lds = ((sizeof(Smem) + 15) & ~(size_t)15) + (kp.use_topp && sizeof(ToppScratch) > scratch ? sizeof(ToppScratch) : scratch) + (ldsrow ? row_bytes : 0);
     hipStream_t st = (hipStream_t)hip_stream;
     int rc;
