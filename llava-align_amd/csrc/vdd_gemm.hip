@@ -69,6 +69,7 @@ struct GemmArgs {
     int Mt, Nt, GM;              // tile counts, row-tiles per L2 group
     int UP, U, P;                // K units (128 deep) per tile, units in total, workgroups
     int dp_rounds;               // whole-tile rounds before the stream-K part (host-chosen schedule)
+    int stage_out;               // Y rows are 16-byte aligned: the epilogue may store whole rows out of LDS
 };
 
 template <int BM, int BN, int WM, int WN, int EPI>
@@ -291,55 +292,117 @@ __global__ void __launch_bounds__(WM * WN * 64) gemm_kernel(const GemmArgs a) {
         const int mrow = cm0 + wr * TM + (lane & 31);
         if constexpr (EPI == EPI_SWIGLU) {
             const int f0 = ctn * (BN / 2) + wc * (TN / 2) + 4 * (lane >> 5);
+            auto gated = [&](int i, int j, int q, float (&o)[4]) {
 #pragma unroll
-            for (int i = 0; i < NI; i += 2)
+                for (int e = 0; e < 4; ++e) {
+                    const float g = rbf(acc[i][j][q * 4 + e]), up = rbf(acc[i + 1][j][q * 4 + e]);
+                    o[e] = rbf(g / (1.f + __expf(-g))) * up;
+                }
+            };
+            if ((TN == 64) && a.stage_out) {       // 32 feature columns per wave: 64-byte rows through LDS, 16 rows per store instruction
+                char* st = lds + 2 * BUF + wave * 4096;
+                const int r = lane & 31, hi = lane >> 5;
 #pragma unroll
                 for (int j = 0; j < MI; ++j) {
-                    const int m = mrow + j * 32;
-                    if (m >= a.M) continue;
 #pragma unroll
                     for (int q = 0; q < 4; ++q) {
                         float o[4];
+                        gated(0, j, q, o);
+                        *reinterpret_cast<uint2*>(st + r * 64 + ((q ^ ((r >> 2) & 3)) * 16) + hi * 8) = pack4(o[0], o[1], o[2], o[3]);
+                    }
 #pragma unroll
-                        for (int e = 0; e < 4; ++e) {
-                            const float g = rbf(acc[i][j][q * 4 + e]), up = rbf(acc[i + 1][j][q * 4 + e]);
-                            o[e] = rbf(g / (1.f + __expf(-g))) * up;
-                        }
-                        *reinterpret_cast<uint2*>(a.Y + (size_t)m * a.ldy + f0 + (i / 2) * 32 + q * 8) = pack4(o[0], o[1], o[2], o[3]);
+                    for (int t = 0; t < 2; ++t) {
+                        const int row = t * 16 + (lane >> 2), c = lane & 3;
+                        const int mm = cm0 + wr * TM + j * 32 + row;
+                        const uint4 val = *reinterpret_cast<const uint4*>(st + row * 64 + ((c ^ ((row >> 2) & 3)) * 16));
+                        if (mm < a.M) *reinterpret_cast<uint4*>(a.Y + (size_t)mm * a.ldy + ctn * (BN / 2) + wc * (TN / 2) + c * 8) = val;
                     }
                 }
-        } else {
+            } else {
 #pragma unroll
-            for (int i = 0; i < NI; ++i)
+                for (int i = 0; i < NI; i += 2)
+#pragma unroll
+                    for (int j = 0; j < MI; ++j) {
+                        const int m = mrow + j * 32;
+                        if (m >= a.M) continue;
+#pragma unroll
+                        for (int q = 0; q < 4; ++q) {
+                            float o[4];
+                            gated(i, j, q, o);
+                            *reinterpret_cast<uint2*>(a.Y + (size_t)m * a.ldy + f0 + (i / 2) * 32 + q * 8) = pack4(o[0], o[1], o[2], o[3]);
+                        }
+                    }
+            }
+        } else {
+            // one quad of the tile: the 4 consecutive columns n .. n + 3 of row m this lane holds in acc[i][j][4 q ..], epilogue applied
+            auto quad = [&](int i, int j, int q, int m, int n, float (&v)[4]) {
+#pragma unroll
+                for (int e = 0; e < 4; ++e) v[e] = acc[i][j][q * 4 + e];
+                if constexpr (EPI != EPI_NONE) {
+                    const uint2 bb = *reinterpret_cast<const uint2*>(a.bias + n);
+                    v[0] += bf2f(bb.x & 0xffffu); v[1] += bf2f(bb.x >> 16); v[2] += bf2f(bb.y & 0xffffu); v[3] += bf2f(bb.y >> 16);
+                }
+                if constexpr (EPI == EPI_BIAS_QUICK_GELU) {
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) v[e] = act_quick_gelu(rbf(v[e]));
+                } else if constexpr (EPI == EPI_BIAS_GELU) {
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) v[e] = act_gelu(rbf(v[e]));
+                } else if constexpr (EPI == EPI_BIAS_RESID) {
+                    const uint2 rr = *reinterpret_cast<const uint2*>(a.resid + (size_t)m * a.ldr + n);
+                    v[0] = rbf(v[0]) + bf2f(rr.x & 0xffffu); v[1] = rbf(v[1]) + bf2f(rr.x >> 16);
+                    v[2] = rbf(v[2]) + bf2f(rr.y & 0xffffu); v[3] = rbf(v[3]) + bf2f(rr.y >> 16);
+                }
+            };
+            // Stored from the accumulator layout a quad is 8 bytes and a store instruction touches 32 rows: every 128-byte line of Y
+            // is written by 8 instructions (5-12 % of a prefill-size GEMM, measured with the stores switched off).  With 64-column
+            // wave tiles a 32-row block of the wave goes through 4 KiB of LDS behind the two K-tile buffers instead and leaves as
+            // whole 128-byte rows, 16 B per lane, 8 rows per instruction (chunks XOR-swizzled with the row: conflict-free reads).
+            const bool staged = (TN == 64) && a.stage_out;
+            if (staged) {
+                char* st = lds + 2 * BUF + wave * 4096;
+                const int r = lane & 31, hi = lane >> 5;
 #pragma unroll
                 for (int j = 0; j < MI; ++j) {
                     const int m = mrow + j * 32;
-                    if (m >= a.M) continue;
 #pragma unroll
-                    for (int q = 0; q < 4; ++q) {
-                        const int n = cn0 + wc * TN + i * 32 + q * 8 + 4 * (lane >> 5);
-                        if (n >= a.N) continue;
-                        float v[4];
+                    for (int i = 0; i < NI; ++i)
 #pragma unroll
-                        for (int e = 0; e < 4; ++e) v[e] = acc[i][j][q * 4 + e];
-                        if constexpr (EPI != EPI_NONE) {
-                            const uint2 bb = *reinterpret_cast<const uint2*>(a.bias + n);
-                            v[0] += bf2f(bb.x & 0xffffu); v[1] += bf2f(bb.x >> 16); v[2] += bf2f(bb.y & 0xffffu); v[3] += bf2f(bb.y >> 16);
+                        for (int q = 0; q < 4; ++q) {
+                            const int n = cn0 + wc * TN + i * 32 + q * 8 + 4 * hi;
+                            float v[4] = {0.f, 0.f, 0.f, 0.f};
+                            if (m < a.M && n < a.N) quad(i, j, q, m, n, v);
+                            *reinterpret_cast<uint2*>(st + r * 128 + (((i * 4 + q) ^ (r & 7)) * 16) + hi * 8) = pack4(v[0], v[1], v[2], v[3]);
                         }
-                        if constexpr (EPI == EPI_BIAS_QUICK_GELU) {
 #pragma unroll
-                            for (int e = 0; e < 4; ++e) v[e] = act_quick_gelu(rbf(v[e]));
-                        } else if constexpr (EPI == EPI_BIAS_GELU) {
-#pragma unroll
-                            for (int e = 0; e < 4; ++e) v[e] = act_gelu(rbf(v[e]));
-                        } else if constexpr (EPI == EPI_BIAS_RESID) {
-                            const uint2 rr = *reinterpret_cast<const uint2*>(a.resid + (size_t)m * a.ldr + n);
-                            v[0] = rbf(v[0]) + bf2f(rr.x & 0xffffu); v[1] = rbf(v[1]) + bf2f(rr.x >> 16);
-                            v[2] = rbf(v[2]) + bf2f(rr.y & 0xffffu); v[3] = rbf(v[3]) + bf2f(rr.y >> 16);
+                    for (int t = 0; t < 4; ++t) {
+                        const int row = t * 8 + (lane >> 3), c = lane & 7;
+                        const int mm = cm0 + wr * TM + j * 32 + row, nn = cn0 + wc * TN + c * 8;
+                        const uint4 val = *reinterpret_cast<const uint4*>(st + row * 128 + ((c ^ (row & 7)) * 16));
+                        if (mm < a.M) {
+                            uint16_t* yp = a.Y + (size_t)mm * a.ldy + nn;
+                            if (nn + 8 <= a.N) *reinterpret_cast<uint4*>(yp) = val;
+                            else if (nn + 4 <= a.N) *reinterpret_cast<uint2*>(yp) = make_uint2(val.x, val.y);
                         }
-                        *reinterpret_cast<uint2*>(a.Y + (size_t)m * a.ldy + n) = pack4(v[0], v[1], v[2], v[3]);
                     }
                 }
+            } else {
+#pragma unroll
+                for (int i = 0; i < NI; ++i)
+#pragma unroll
+                    for (int j = 0; j < MI; ++j) {
+                        const int m = mrow + j * 32;
+                        if (m >= a.M) continue;
+#pragma unroll
+                        for (int q = 0; q < 4; ++q) {
+                            const int n = cn0 + wc * TN + i * 32 + q * 8 + 4 * (lane >> 5);
+                            if (n >= a.N) continue;
+                            float v[4];
+                            quad(i, j, q, m, n, v);
+                            *reinterpret_cast<uint2*>(a.Y + (size_t)m * a.ldy + n) = pack4(v[0], v[1], v[2], v[3]);
+                        }
+                    }
+            }
         }
     }
 #endif
@@ -382,7 +445,8 @@ int launch_cfg(const GemmArgs& a0, int epi, int sched, void* workspace, int64_t 
     a.counter = (int*)workspace;
     a.partial = (float*)((char*)workspace + (((size_t)a.Mt * a.Nt * sizeof(int) + 255) & ~(size_t)255));
     const dim3 grid(P), block(WM * WN * 64);
-    const size_t smem = 2 * (BM + BN) * 128;
+    const size_t smem = 2 * (BM + BN) * 128 + ((BN / WN == 64) ? WM * WN * 4096 : 0);      // + the epilogue's staging blocks
+    a.stage_out = ((a.ldy % 8) == 0 && (((uintptr_t)a.Y) & 15) == 0) ? 1 : 0;
 #define VDD_GEMM_LAUNCH(E)                                                                                            \
     case E: {                                                                                                         \
         auto kfn = gemm_kernel<BM, BN, WM, WN, E>;                                                                       \
