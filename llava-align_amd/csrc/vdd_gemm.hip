@@ -315,7 +315,7 @@ __global__ void __launch_bounds__(WM * WN * 64) gemm_kernel(const GemmArgs a) {
                         const int row = t * 16 + (lane >> 2), c = lane & 3;
                         const int mm = cm0 + wr * TM + j * 32 + row;
                         const uint4 val = *reinterpret_cast<const uint4*>(st + row * 64 + ((c ^ ((row >> 2) & 3)) * 16));
-                        if (mm < a.M) *reinterpret_cast<uint4*>(a.Y + (size_t)mm * a.ldy + ctn * (BN / 2) + wc * (TN / 2) + c * 8) = val;
+                        if (mm < a.M) __builtin_nontemporal_store(__builtin_bit_cast(u32x4_t, val), reinterpret_cast<u32x4_t*>(a.Y + (size_t)mm * a.ldy + ctn * (BN / 2) + wc * (TN / 2) + c * 8));
                     }
                 }
             } else {
@@ -381,7 +381,7 @@ __global__ void __launch_bounds__(WM * WN * 64) gemm_kernel(const GemmArgs a) {
                         const uint4 val = *reinterpret_cast<const uint4*>(st + row * 128 + ((c ^ (row & 7)) * 16));
                         if (mm < a.M) {
                             uint16_t* yp = a.Y + (size_t)mm * a.ldy + nn;
-                            if (nn + 8 <= a.N) *reinterpret_cast<uint4*>(yp) = val;
+                            if (nn + 8 <= a.N) __builtin_nontemporal_store(__builtin_bit_cast(u32x4_t, val), reinterpret_cast<u32x4_t*>(yp));
                             else if (nn + 4 <= a.N) *reinterpret_cast<uint2*>(yp) = make_uint2(val.x, val.y);
                         }
                     }
