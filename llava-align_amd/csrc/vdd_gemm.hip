@@ -45,6 +45,7 @@ typedef __attribute__((ext_vector_type(16))) float f32x16_t;
 typedef __attribute__((ext_vector_type(4))) __bf16 bf16x4_t;
 typedef __attribute__((ext_vector_type(4))) float f32x4_t;
 typedef __attribute__((ext_vector_type(4))) uint32_t u32x4_t;
+typedef __attribute__((ext_vector_type(2))) uint32_t u32x2_t;
 typedef __attribute__((address_space(3))) void* lds_ptr_t;
 
 __device__ __forceinline__ float bf2f(uint32_t h) { return __builtin_bit_cast(float, h << 16); }
@@ -329,7 +330,7 @@ __global__ void __launch_bounds__(WM * WN * 64) gemm_kernel(const GemmArgs a) {
                         for (int q = 0; q < 4; ++q) {
                             float o[4];
                             gated(i, j, q, o);
-                            *reinterpret_cast<uint2*>(a.Y + (size_t)m * a.ldy + f0 + (i / 2) * 32 + q * 8) = pack4(o[0], o[1], o[2], o[3]);
+                            __builtin_nontemporal_store(__builtin_bit_cast(u32x2_t, pack4(o[0], o[1], o[2], o[3])), reinterpret_cast<u32x2_t*>(a.Y + (size_t)m * a.ldy + f0 + (i / 2) * 32 + q * 8));
                         }
                     }
             }
@@ -399,7 +400,7 @@ __global__ void __launch_bounds__(WM * WN * 64) gemm_kernel(const GemmArgs a) {
                             if (n >= a.N) continue;
                             float v[4];
                             quad(i, j, q, m, n, v);
-                            *reinterpret_cast<uint2*>(a.Y + (size_t)m * a.ldy + n) = pack4(v[0], v[1], v[2], v[3]);
+                            __builtin_nontemporal_store(__builtin_bit_cast(u32x2_t, pack4(v[0], v[1], v[2], v[3])), reinterpret_cast<u32x2_t*>(a.Y + (size_t)m * a.ldy + n));
                         }
                     }
             }
