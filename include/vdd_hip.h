@@ -231,6 +231,14 @@ int vdd_flash_attention(const void* q, const void* k_cache, const void* v_cache,
                         const int32_t* seqs, void* out, int n_seq, int max_tq, int H, int Hkv, int D, int64_t slot_stride, int t_max,
                         int64_t prefix_stride, int prefix_tmax, float scale, int causal, void* hip_stream);
 
+/* The same attention for SHORT sequences (Tq <= 32 each, causal, D = 128) that continue shared prefixes - the suffix pass of the
+ * prefill: packs[p] = 4 sequence indices (int32 x4, -1 = none) with the SAME (prefix_slot, prefix_len); a workgroup takes one
+ * pack and head, stages the 64-key tiles inside the prefix once for its four waves and the rest of each sequence's keys one
+ * sequence after the other.  Same result as vdd_flash_attention on the same descriptors. */
+int vdd_flash_attention_packed(const void* q, const void* k_cache, const void* v_cache, const void* k_prefix, const void* v_prefix,
+                               const int32_t* seqs, const int32_t* packs, void* out, int n_packs, int H, int Hkv, int D,
+                               int64_t slot_stride, int t_max, int64_t prefix_stride, int prefix_tmax, float scale, void* hip_stream);
+
 /* ViT front-end glue around the patch-embed GEMM (HF CLIPVisionEmbeddings / CLIPAttention as run by clip_encoder.py:39-51):
  * im2col of the stride-P patch convolution (images [n,3,S,S] of vdd_dtype `dtype` -> bf16 patches [n*(S/P)^2, Kp], zero
  * padded from 3*P*P to Kp columns); class token + position embeddings (h[i,t] = (t ? emb[i*(T-1)+t-1] : cls) + pos[t]);

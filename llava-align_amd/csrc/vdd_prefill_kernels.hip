@@ -61,13 +61,15 @@ typedef __attribute__((ext_vector_type(16))) float f32x16_t;
 typedef __attribute__((address_space(3))) void* lds_ptr_t;
 typedef __attribute__((address_space(1))) void* g_ptr_t;
 
-template <int D, bool CAUSAL>
+template <int D, bool CAUSAL, bool PACK>
 __global__ void __launch_bounds__(256, 2) flash_attn2_kernel(const uint16_t* __restrict__ q, const uint16_t* __restrict__ kc,
                                                              const uint16_t* __restrict__ vc, const uint16_t* __restrict__ kpre,
                                                              const uint16_t* __restrict__ vpre, const SeqDesc* __restrict__ seqs,
                                                              uint16_t* __restrict__ out, int H, int Hkv, long long slot_stride,
-                                                             int t_max, long long pre_stride, int pre_tmax, float scale, int nx, int n_seq) {
+                                                             int t_max, long long pre_stride, int pre_tmax, float scale, int nx, int n_seq,
+                                                             const int4* __restrict__ packs) {
 #if defined(__HIP_DEVICE_COMPILE__)
+    static_assert(!PACK || CAUSAL, "packed mode is the causal suffix pass");
     constexpr int KS = D / 16;                 // 16-deep k-steps of S^T per 32-key block
     constexpr int NT = D / 32;                 // 32-dim tiles of O^T
     constexpr int KROW = D * 2;                // bytes of a K row
@@ -90,16 +92,29 @@ __global__ void __launch_bounds__(256, 2) flash_attn2_kernel(const uint16_t* __r
     // XCDs the causal prefix pass pulled every K / V byte 3 times from HBM / Infinity Cache).  Long (late) query blocks first.
     const int NX = nx, xcd = blockIdx.x & 7, local = blockIdx.x >> 3;
     const int pair = (local / NX) * 8 + xcd;
-    if (pair >= H * n_seq) return;
-    const SeqDesc sd = seqs[pair / H];
+    if (pair >= H * n_seq) return;                            // n_seq: sequences, or packs in packed mode
     const int head = pair % H, kvh = head / (H / Hkv);
-    const int qt0 = (NX - 1 - local % NX) * 128;
-    if (qt0 >= sd.Tq) return;
-    const int r0 = qt0 + wave * 32;
+    // PACKED mode (the suffix pass: ~25 query rows per sequence, one wave's worth): a block takes up to FOUR sequences that
+    // continue the same prefix (one per wave; the host lists them in packs[]).  The 64-key tiles lying wholly inside the prefix
+    // are staged ONCE and used by all four waves; the rest of each sequence's keys (prefix tail + own tokens) go through the
+    // same buffers one sequence after the other, computed by its wave alone.  Unpacked, every sequence staged all its tiles
+    // for one active wave in four: 7.8 GB of L2 -> LDS traffic per layer call at 768 questions, which is what bounded the pass.
+    int mine = pair / H;                                      // this wave's sequence
+    int pk[4] = {-1, -1, -1, -1};
+    if constexpr (PACK) {
+        const int4 p4 = packs[pair / H];
+        pk[0] = p4.x; pk[1] = p4.y; pk[2] = p4.z; pk[3] = p4.w;
+        mine = wave == 0 ? p4.x : (wave == 1 ? p4.y : (wave == 2 ? p4.z : p4.w));
+    }
+    const bool have_seq = mine >= 0;
+    const SeqDesc sd = seqs[have_seq ? mine : pk[0]];
+    const int qt0 = PACK ? 0 : (NX - 1 - local % NX) * 128;
+    if (qt0 >= sd.Tq && !PACK) return;
+    const int r0 = PACK ? 0 : qt0 + wave * 32;
     const int Tk = sd.pos0 + sd.Tq;
     const int last_row = min(qt0 + 127, sd.Tq - 1);
-    const int kend = CAUSAL ? min(Tk, sd.pos0 + last_row + 1) : Tk;          // block-uniform key bound
-    const bool wave_has_rows = r0 < sd.Tq;
+    const int kend = CAUSAL ? min(Tk, sd.pos0 + last_row + 1) : Tk;          // block-uniform key bound (unpacked mode)
+    const bool wave_has_rows = have_seq && r0 < sd.Tq;
     const int wave_last_pos = sd.pos0 + min(r0 + 31, sd.Tq - 1);
 
     // Q fragments (B operand of S^T): lane (q, hi) holds Q[r0 + q][16 ks + 8 hi .. + 7]
@@ -112,20 +127,21 @@ __global__ void __launch_bounds__(256, 2) flash_attn2_kernel(const uint16_t* __r
     }
     const int qpos = sd.pos0 + r0 + ql;
     const size_t head_off = (size_t)kvh * t_max * D, pre_off = (size_t)kvh * pre_tmax * D;
-    const uint16_t* kbase_own = kc + (size_t)sd.slot * slot_stride + head_off - (size_t)sd.plen * D;
-    const uint16_t* vbase_own = vc + (size_t)sd.slot * slot_stride + head_off - (size_t)sd.plen * D;
     const uint16_t* kbase_pre = kpre + (size_t)sd.pslot * pre_stride + pre_off;
     const uint16_t* vbase_pre = vpre + (size_t)sd.pslot * pre_stride + pre_off;
 
-    // ---- LDS-DMA of one tile: (NKI + NVI) 1-KiB images, (NKI + NVI) / 4 per wave; a key past the sequence is clamped (its score is masked)
-    auto stage = [&](int kt, int buf) {
+    // ---- LDS-DMA of one tile of the sequence in own-pool slot `slot_o` with `tk_o` keys (prefix = this block's): (NKI + NVI)
+    // 1-KiB images, (NKI + NVI) / 4 per wave; a key past the sequence is clamped (its score is masked)
+    auto stage = [&](int kt, int buf, int slot_o, int tk_o) {
         char* base = lds + buf * BUF;
+        const uint16_t* kbase_own = kc + (size_t)slot_o * slot_stride + head_off - (size_t)sd.plen * D;
+        const uint16_t* vbase_own = vc + (size_t)slot_o * slot_stride + head_off - (size_t)sd.plen * D;
 #pragma unroll
         for (int m0 = 0; m0 < NKI / 4; ++m0) {
             const int m = m0 * 4 + wave;
             const int key = m * KPI + lane / CPR, slot = lane % CPR;
             const int c = D == 128 ? (slot ^ (key & 15)) : (slot ^ ((key >> 1) & 7));
-            int t = kt + key; if (t >= Tk) t = Tk - 1;
+            int t = kt + key; if (t >= tk_o) t = tk_o - 1;
             const uint16_t* src = (t < sd.plen ? kbase_pre : kbase_own) + (size_t)t * D + c * 8;
             __builtin_amdgcn_global_load_lds((g_ptr_t)src, (lds_ptr_t)(base + m * 1024), 16, 0, 0);
         }
@@ -133,7 +149,7 @@ __global__ void __launch_bounds__(256, 2) flash_attn2_kernel(const uint16_t* __r
         for (int m0 = 0; m0 < NVI / 4; ++m0) {
             const int sI = m0 * 4 + wave, kh = sI / DSUB, ds = sI % DSUB;
             const int key = 32 * kh + lane / 2, d = 16 * ds + 8 * (lane & 1);
-            int t = kt + key; if (t >= Tk) t = Tk - 1;
+            int t = kt + key; if (t >= tk_o) t = tk_o - 1;
             const uint16_t* src = (t < sd.plen ? vbase_pre : vbase_own) + (size_t)t * D + d;
             __builtin_amdgcn_global_load_lds((g_ptr_t)src, (lds_ptr_t)(base + KTILE + sI * VSUB), 16, 0, 0);
         }
@@ -152,12 +168,7 @@ __global__ void __launch_bounds__(256, 2) flash_attn2_kernel(const uint16_t* __r
     const int kswz = D == 128 ? (ql & 15) : ((ql >> 1) & 7);
     const int vrd = ((lane >> 4) & 1) * VSUB + (4 * hi + ((lane & 15) >> 2)) * 32 + (lane & 3) * 8;      // + (b * DSUB + 2 nt) * VSUB + (16 j + 8 h) * 32
 
-    stage(0, 0);
-    for (int kt = 0, buf = 0; kt < kend; kt += 64, buf ^= 1) {
-        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-        __syncthreads();                                      // tile `buf` landed for everyone; tile buf ^ 1 no longer read
-        if (kt + 64 < kend) stage(kt + 64, buf ^ 1);
-        if (!wave_has_rows || (CAUSAL && kt > wave_last_pos)) continue;
+    auto compute = [&](int kt, int buf) {                     // this wave's 32 query rows against the tile in `buf`
         const char* kb = lds + buf * BUF;
         const char* vb = kb + KTILE;
         // ---- S^T = K Q^T: all 2 KS fragment reads in flight, then the two independent accumulator chains interleaved ----
@@ -258,6 +269,41 @@ __global__ void __launch_bounds__(256, 2) flash_attn2_kernel(const uint16_t* __r
         issue(2, va); landed(vn, std::true_type{}); pv(1, vn); __builtin_amdgcn_sched_barrier(0);
         issue(3, vn); landed(va, std::true_type{}); pv(2, va); __builtin_amdgcn_sched_barrier(0);
         landed(vn, std::false_type{}); pv(3, vn);
+    };
+    if constexpr (!PACK) {
+        stage(0, 0, sd.slot, Tk);
+        for (int kt = 0, buf = 0; kt < kend; kt += 64, buf ^= 1) {
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+            __syncthreads();                                  // tile `buf` landed for everyone; tile buf ^ 1 no longer read
+            if (kt + 64 < kend) stage(kt + 64, buf ^ 1, sd.slot, Tk);
+            if (wave_has_rows && !(CAUSAL && kt > wave_last_pos)) compute(kt, buf);
+        }
+    } else {
+        // steps: the shared tiles [0, S) (owner -1: every wave computes), then for each sequence w of the pack its tiles [S, Tk_w)
+        int slot4[4], tk4[4];
+#pragma unroll
+        for (int w = 0; w < 4; ++w) {
+            const SeqDesc sw = seqs[pk[w] >= 0 ? pk[w] : pk[0]];
+            slot4[w] = sw.slot; tk4[w] = pk[w] >= 0 ? sw.pos0 + sw.Tq : 0;
+        }
+        const int S = (sd.plen / 64) * 64;
+        auto first_owner = [&](int from) { int w = from; while (w < 4 && tk4[w] <= S) ++w; return w; };
+        int owner = S > 0 ? -1 : first_owner(0), kt = S > 0 ? 0 : S;
+        auto issue = [&](int o, int k, int buf) {
+            if (o < 0) stage(k, buf, sd.slot, 1 << 30);      // prefix keys only: no clamp, no own pool
+            else stage(k, buf, o == 0 ? slot4[0] : (o == 1 ? slot4[1] : (o == 2 ? slot4[2] : slot4[3])), o == 0 ? tk4[0] : (o == 1 ? tk4[1] : (o == 2 ? tk4[2] : tk4[3])));
+        };
+        if (owner < 4) issue(owner, kt, 0);
+        for (int buf = 0; owner < 4; buf ^= 1) {
+            int no = owner, nk = kt + 64;                      // the step after this one
+            if (owner < 0) { if (nk >= S) { no = first_owner(0); nk = S; } }
+            else if (nk >= (owner == 0 ? tk4[0] : (owner == 1 ? tk4[1] : (owner == 2 ? tk4[2] : tk4[3])))) { no = first_owner(owner + 1); nk = S; }
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+            __syncthreads();
+            if (no < 4) issue(no, nk, buf ^ 1);
+            if (wave_has_rows && (owner < 0 || owner == wave) && !(kt > wave_last_pos)) compute(kt, buf);
+            owner = no; kt = nk;
+        }
     }
     // ---- finish: this lane holds O[q][32 nt + (r & 3) + 8 (r >> 2) + 4 hi]; the row sum is split over lanes q and q + 32.
     // Stored from the registers that is 16 stores of 8 B per lane at a row stride (every store instruction touches 32 rows, every
@@ -432,15 +478,31 @@ int vdd_flash_attention(const void* q, const void* k_cache, const void* v_cache,
     const long long ps = (long long)prefix_stride;
 #define VDD_FLASH(DD, CC)                                                                                                        \
     {                                                                                                                            \
-        auto kfn = flash_attn2_kernel<DD, CC>;                                                                                   \
+        auto kfn = flash_attn2_kernel<DD, CC, false>;                                                                            \
         constexpr int smem = 2 * (64 * DD * 2 + 2 * (DD / 16) * 1152);                                                           \
         static bool attr_set = false;                                                                                            \
         if (!attr_set) { (void)hipFuncSetAttribute((const void*)kfn, hipFuncAttributeMaxDynamicSharedMemorySize, smem); attr_set = true; } \
-        hipLaunchKernelGGL(kfn, grid, block, smem, st, Q, K, V, KP, VP, S, O, H, Hkv, (long long)slot_stride, t_max, ps, prefix_tmax, scale, nx, n_seq); \
+        hipLaunchKernelGGL(kfn, grid, block, smem, st, Q, K, V, KP, VP, S, O, H, Hkv, (long long)slot_stride, t_max, ps, prefix_tmax, scale, nx, n_seq, (const int4*)nullptr); \
     }
     if (D == 128) { if (causal) VDD_FLASH(128, true) else VDD_FLASH(128, false) }
     else { if (causal) VDD_FLASH(64, true) else VDD_FLASH(64, false) }
 #undef VDD_FLASH
+    return ok();
+}
+
+int vdd_flash_attention_packed(const void* q, const void* k_cache, const void* v_cache, const void* k_prefix, const void* v_prefix,
+                               const int32_t* seqs, const int32_t* packs, void* out, int n_packs, int H, int Hkv, int D,
+                               int64_t slot_stride, int t_max, int64_t prefix_stride, int prefix_tmax, float scale, void* stream) {
+    if (n_packs <= 0) return VDD_OK;
+    if (!q || !k_cache || !v_cache || !k_prefix || !v_prefix || !seqs || !packs || !out || D != 128 || H % Hkv != 0) return VDD_ERR_INVALID_ARG;
+    auto kfn = flash_attn2_kernel<128, true, true>;
+    constexpr int smem = 2 * (64 * 128 * 2 + 2 * (128 / 16) * 1152);
+    static bool attr_set = false;
+    if (!attr_set) { (void)hipFuncSetAttribute((const void*)kfn, hipFuncAttributeMaxDynamicSharedMemorySize, smem); attr_set = true; }
+    dim3 grid((unsigned)(((long long)H * n_packs + 7) / 8 * 8)), block(256);
+    hipLaunchKernelGGL(kfn, grid, block, smem, (hipStream_t)stream, (const uint16_t*)q, (const uint16_t*)k_cache, (const uint16_t*)v_cache,
+                       (const uint16_t*)k_prefix, (const uint16_t*)v_prefix, (const SeqDesc*)seqs, (uint16_t*)out, H, Hkv, (long long)slot_stride,
+                       t_max, (long long)prefix_stride, prefix_tmax, scale, 1, n_packs, (const int4*)packs);
     return ok();
 }
 

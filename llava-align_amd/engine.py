@@ -382,7 +382,7 @@ class LanguageModel:
     @torch.no_grad()
     def prefill(self, x: torch.Tensor, pos: torch.Tensor, cpos: torch.Tensor, slot: torch.Tensor, seqs: torch.Tensor, n_seq: int,
                 max_tq: int, kv: KVCache, to_prefix_pool: bool, last_rows: Optional[torch.Tensor] = None,
-                last_seqs: Optional[torch.Tensor] = None):
+                last_seqs: Optional[torch.Tensor] = None, packs: Optional[torch.Tensor] = None):
         """x [T, d] packed embeddings; pos (rotary) / cpos (index inside the slot) / slot int32 [T]; seqs [n_seq, 6]
         (ops.flash_attention).  Writes K/V into the prefix pool (prefix pass) or the own pool (suffix pass) and returns
         (residual, delta) of the LAST token of every sequence: the final hidden state is their sum (added inside the last
@@ -406,9 +406,11 @@ class LanguageModel:
                 return None, None                              # prefix pass: only this layer's K/V were still needed
             if final:
                 q, resid = q[last_rows].contiguous(), resid[last_rows].contiguous()
-                att = ops.flash_attention(q, kw_, vw_, last_seqs, n_seq, 1, H, Hkv, D, causal=True, k_prefix=kv.kp[i], v_prefix=kv.vp[i])
+            sq, tq = (last_seqs, 1) if final else (seqs, max_tq)
+            if packs is not None:
+                att = ops.flash_attention_packed(q, kw_, vw_, sq, packs, packs.shape[0], H, Hkv, D, k_prefix=kv.kp[i], v_prefix=kv.vp[i])
             else:
-                att = ops.flash_attention(q, kw_, vw_, seqs, n_seq, max_tq, H, Hkv, D, causal=True, k_prefix=kv.kp[i], v_prefix=kv.vp[i])
+                att = ops.flash_attention(q, kw_, vw_, sq, n_seq, tq, H, Hkv, D, causal=True, k_prefix=kv.kp[i], v_prefix=kv.vp[i])
             o = ops.linear(att, t[p + "wo"])
             new_resid = torch.empty_like(resid)
             a = ops.rmsnorm(resid, t[p + "ln2"], c.eps, delta=o, resid_out=new_resid)
@@ -771,10 +773,13 @@ class VddLlavaEngine:
                     for li in range(lm.n_layers):
                         ops.prefix_fragments(kv.kp[li], kv.vp[li], kv.pfrag[li], plen_t)
             else:
-                last, last_seqs = h2d_int32(dev, [s["q_row0"] + s["T"] - 1 for s in segs],
-                                            [[i, 1, s["pos0"] + s["T"] - 1, s["slot"], s["pslot"], s["plen"]] for i, s in enumerate(segs)])
+                # short suffixes behind shared prefixes: four sequences of one prefix per attention workgroup (ops.flash_packs)
+                packs_h = ops.flash_packs([[0, 0, 0, 0, s["pslot"], s["plen"]] for s in segs]) if (max_tq <= 32 and lm.head_dim == 128) else None
+                last, last_seqs, packs = h2d_int32(dev, [s["q_row0"] + s["T"] - 1 for s in segs],
+                                                   [[i, 1, s["pos0"] + s["T"] - 1, s["slot"], s["pslot"], s["plen"]] for i, s in enumerate(segs)],
+                                                   packs_h if packs_h is not None else [[0, -1, -1, -1]])
                 resid, delta = self.lm.prefill(x, pos, cpos, slot, seqs, len(segs), max_tq, kv, to_prefix_pool=False,
-                                               last_rows=last.long(), last_seqs=last_seqs)
+                                               last_rows=last.long(), last_seqs=last_seqs, packs=packs if packs_h is not None else None)
                 logits0 = self.lm.logits(resid, delta)                                        # [nb*Q, V], rows ordered branch-major
                 self.debug_logits0 = logits0
         V = lm.vocab

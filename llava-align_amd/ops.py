@@ -25,6 +25,7 @@ _SIGS = {
     "vdd_prefix_fragments": [_P, _P, _P, _P, _I, _I, _I, _I, _P],
     "vdd_decode_attention_grouped": [_P, _P, _P, _P, _P, _P, _P, _P, _P, _P, _I, _P, _P, _I, _I, _I, _I, _L, _I, _L, _I, _I, _I, _I, _F, _P],
     "vdd_flash_attention": [_P, _P, _P, _P, _P, _P, _P, _I, _I, _I, _I, _I, _L, _I, _L, _I, _F, _I, _P],
+    "vdd_flash_attention_packed": [_P, _P, _P, _P, _P, _P, _P, _P, _I, _I, _I, _I, _L, _I, _L, _I, _F, _P],
     "vdd_layernorm": [_P, _P, _P, _P, _I, _I, _F, _P],
     "vdd_bias_act": [_P, _P, _P, _L, _I, _I, _P],
     "vdd_add": [_P, _P, _P, _L, _P],
@@ -382,6 +383,34 @@ def flash_attention(q, k_cache, v_cache, seqs, n_seq, max_tq, H, Hkv, D, causal=
                                                 seqs.data_ptr(), out.data_ptr(), n_seq, max_tq, H, Hkv, D, k_cache.stride(0),
                                                 k_cache.shape[2], k_prefix.stride(0), k_prefix.shape[2], D ** -0.5 if scale is None else float(scale),
                                                 1 if causal else 0, _st(q)))
+    return out
+
+
+def flash_packs(seq_rows, max_per_pack=4):
+    """Host side of the packed suffix pass: seq_rows = [(q_row0, Tq, pos0, slot, prefix_slot, prefix_len), ...] -> [[s0, s1, s2, s3], ...]
+    (sequence indices, -1 = none): consecutive sequences continuing the same (prefix_slot, prefix_len), at most four per pack."""
+    packs, cur, key = [], [], None
+    for i, r in enumerate(seq_rows):
+        k = (int(r[4]), int(r[5]))
+        if cur and (k != key or len(cur) == max_per_pack):
+            packs.append(cur + [-1] * (4 - len(cur))); cur = []
+        cur.append(i); key = k
+    if cur:
+        packs.append(cur + [-1] * (4 - len(cur)))
+    return packs
+
+
+def flash_attention_packed(q, k_cache, v_cache, seqs, packs, n_packs, H, Hkv, D, out=None, k_prefix=None, v_prefix=None, scale=None):
+    """flash_attention (causal) for sequences of at most 32 query rows that continue shared prefixes, four to a workgroup:
+    packs int32 [n_packs, 4] from flash_packs().  The tiles inside the prefix are staged once per pack, not once per sequence."""
+    _bf16(q, k_cache, v_cache)
+    out = torch.empty_like(q) if out is None else out
+    k_prefix = k_cache if k_prefix is None else k_prefix
+    v_prefix = v_cache if v_prefix is None else v_prefix
+    _lib.check(_lib_ready().vdd_flash_attention_packed(q.data_ptr(), k_cache.data_ptr(), v_cache.data_ptr(), k_prefix.data_ptr(), v_prefix.data_ptr(),
+                                                       seqs.data_ptr(), packs.data_ptr(), out.data_ptr(), n_packs, H, Hkv, D, k_cache.stride(0),
+                                                       k_cache.shape[2], k_prefix.stride(0), k_prefix.shape[2],
+                                                       D ** -0.5 if scale is None else float(scale), _st(q)))
     return out
 
 

@@ -202,6 +202,28 @@ def test_flash_attention_prefill(D, H, Hkv, causal):
         assert torch.allclose(got, ref, rtol=2e-2, atol=2e-2), (r0, (got - ref).abs().max().item())
 
 
+def test_flash_attention_packed_equals_one_sequence_per_block():
+    """The suffix pass packs four short sequences of one prefix into a workgroup (shared prefix tiles staged once): same tiles in the
+    same order per wave, so the result is bit-identical to the one-sequence-per-block launch."""
+    O = ops()
+    H, Hkv, D = 8, 4, 128
+    kp, vp = bf(3, Hkv, 640, D, seed=61), bf(3, Hkv, 640, D, seed=62)                 # prefixes: slot 0 (611 keys), slot 1 (36), slot 2 (100)
+    ko, vo = bf(16, Hkv, 64, D, seed=63), bf(16, Hkv, 64, D, seed=64)
+    rows, r = [], 0
+    for i, (tq, ps, pl) in enumerate([(25, 0, 611), (19, 0, 611), (28, 0, 611), (32, 0, 611), (1, 0, 611), (22, 0, 611),      # six of one image
+                                      (24, 1, 36), (20, 1, 36), (27, 1, 36),                                                # a short prefix: no shared tile
+                                      (30, 2, 100), (17, 2, 100),                                                            # one shared tile + a straddling one
+                                      (9, 0, 0)]):                                                                           # no prefix at all
+        rows.append([r, tq, pl, i, ps, pl]); r += tq
+    q = bf(r, H * D, seed=65)
+    sd = torch.tensor(rows, dtype=torch.int32, device=DEV)
+    a = O.flash_attention(q, ko, vo, sd, len(rows), 32, H, Hkv, D, causal=True, k_prefix=kp, v_prefix=vp)
+    packs = O.flash_packs(rows)
+    assert packs == [[0, 1, 2, 3], [4, 5, -1, -1], [6, 7, 8, -1], [9, 10, -1, -1], [11, -1, -1, -1]]
+    b = O.flash_attention_packed(q, ko, vo, sd, torch.tensor(packs, dtype=torch.int32, device=DEV), len(packs), H, Hkv, D, k_prefix=kp, v_prefix=vp)
+    assert torch.equal(a, b)
+
+
 def test_layernorm_and_bias_act():
     O = ops()
     x, w, b = bf(9, 1024, seed=31), bf(1024, seed=32) * 0.1 + 1, bf(1024, seed=33) * 0.1

@@ -44,6 +44,10 @@ seqs2 = torch.tensor(S, dtype=torch.int32, device=dev)
 us = timeit(lambda: ops.flash_attention(q2, ko, vo, seqs2, len(S), 25, H, H, D, causal=True, k_prefix=kp, v_prefix=vp))
 fl = sum(H * 4 * s[1] * (s[2] + s[1] / 2) * D for s in S)
 res["suffix 768x25 behind prefix"] = dict(us=round(us, 1), TFs=round(fl / us / 1e6, 1))
+packs = ops.flash_packs(S)
+pk = torch.tensor(packs, dtype=torch.int32, device=dev)
+us = timeit(lambda: ops.flash_attention_packed(q2, ko, vo, seqs2, pk, len(packs), H, H, D, k_prefix=kp, v_prefix=vp))
+res["suffix packed (4 per block)"] = dict(us=round(us, 1), TFs=round(fl / us / 1e6, 1), packs=len(packs))
 # (c) ViT
 Hv, Dv, Tv, N = 16, 64, 577, 64
 kc, vc = bf(N, Hv, 584, Dv), bf(N, Hv, 584, Dv)
