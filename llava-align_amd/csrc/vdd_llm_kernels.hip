@@ -22,6 +22,7 @@
 namespace {
 
 typedef __attribute__((ext_vector_type(8))) short bf16x8_t;   // MFMA A/B fragment: 8 bf16
+typedef __attribute__((ext_vector_type(4))) uint32_t u32x4_nt;
 typedef __attribute__((ext_vector_type(4))) float f32x4_t;    // MFMA C/D fragment
 
 __device__ __forceinline__ float bf2f(uint32_t b) { return __builtin_bit_cast(float, b << 16); }
@@ -450,8 +451,8 @@ __global__ void __launch_bounds__(256) decode_attn_own_merge_kernel(const uint16
         for (int u = 0; u < U; ++u) {
             const int t = t0 + 4 * u;
             const int tt = t < n_own ? t : n_own - 1;
-            kv[u] = *reinterpret_cast<const uint4*>(k_own + (size_t)tt * D);
-            vv[u] = *reinterpret_cast<const uint4*>(v_own + (size_t)tt * D);
+            kv[u] = __builtin_bit_cast(uint4, __builtin_nontemporal_load(reinterpret_cast<const u32x4_nt*>(k_own + (size_t)tt * D)));
+            vv[u] = __builtin_bit_cast(uint4, __builtin_nontemporal_load(reinterpret_cast<const u32x4_nt*>(v_own + (size_t)tt * D)));
         }
 #pragma unroll
         for (int u = 0; u < U; ++u) {
@@ -745,11 +746,11 @@ __global__ void __launch_bounds__(256, 2) decode_attn_prefix_mfma_kernel(const u
 #pragma unroll
         for (int t = 0; t < 4; ++t)
 #pragma unroll
-            for (int ks = 0; ks < KS; ++ks) kf[t][ks] = *reinterpret_cast<const bf16x8_t*>(cb + (t * KS + ks) * 512);
+            for (int ks = 0; ks < KS; ++ks) kf[t][ks] = __builtin_nontemporal_load(reinterpret_cast<const bf16x8_t*>(cb + (t * KS + ks) * 512));
 #pragma unroll
         for (int kk = 0; kk < 2; ++kk)
 #pragma unroll
-            for (int nt = 0; nt < NT; ++nt) vf[kk][nt] = *reinterpret_cast<const bf16x8_t*>(cb + ATT_CH * D + (kk * NT + nt) * 512);
+            for (int nt = 0; nt < NT; ++nt) vf[kk][nt] = __builtin_nontemporal_load(reinterpret_cast<const bf16x8_t*>(cb + ATT_CH * D + (kk * NT + nt) * 512));
         __builtin_amdgcn_sched_barrier(0);
         // S^T: 4 tiles (a0, b0 | a1, b1); MFMA row i = ln of the A operand
         f32x4_t s[4];
