@@ -45,6 +45,8 @@ constexpr int NREG = 3;                  // chunks per thread held in REGISTERS 
 constexpr int UNR = 4;                   // chunks in flight per thread per batch
 constexpr int LDS_ROW_BYTES_MAX = 140 * 1024;       // + Smem + the top-p candidate list stay inside the CU's 160 KiB
 
+typedef __attribute__((ext_vector_type(4))) uint32_t u32x4_s;
+
 // ------------------------------------------------------------------ dtype traits
 template <int DT> struct Tr;
 template <> struct Tr<VDD_F16> {
@@ -201,14 +203,17 @@ __device__ __forceinline__ float philox_uniform(unsigned long long seed, unsigne
 
 // ------------------------------------------------------------------ chunk loads / stores (global)
 // A chunk is 16 bytes = EPC elements held as 4 packed words.
-template <int DT>
+// STREAM: the chunk is read once by the whole launch (logits in, the LDS-resident row): nontemporal, it takes no L2 line from anyone
+template <int DT, bool STREAM = false>
 __device__ __forceinline__ void gload(const void* base, long long row_off, int ch, int V, int vec, uint32_t* w) {
     using B = typename Tr<DT>::bits_t;
     constexpr int EPC = Tr<DT>::EPC;
     const B* p = reinterpret_cast<const B*>(base) + row_off;
     const int idx0 = ch * EPC;
     if (vec && idx0 + EPC <= V) {
-        uint4 a = *reinterpret_cast<const uint4*>(p + idx0);
+        uint4 a;
+        if constexpr (STREAM) a = __builtin_bit_cast(uint4, __builtin_nontemporal_load(reinterpret_cast<const u32x4_s*>(p + idx0)));
+        else a = *reinterpret_cast<const uint4*>(p + idx0);
         w[0] = a.x; w[1] = a.y; w[2] = a.z; w[3] = a.w;
     } else {
         w[0] = w[1] = w[2] = w[3] = 0;
@@ -219,14 +224,15 @@ __device__ __forceinline__ void gload(const void* base, long long row_off, int c
         }
     }
 }
-template <int DT>
+template <int DT, bool STREAM = false>
 __device__ __forceinline__ void gstore(void* base, long long row_off, int ch, int V, int vec, const uint32_t* w) {
     using B = typename Tr<DT>::bits_t;
     constexpr int EPC = Tr<DT>::EPC;
     B* p = reinterpret_cast<B*>(base) + row_off;
     const int idx0 = ch * EPC;
     if (vec && idx0 + EPC <= V) {
-        *reinterpret_cast<uint4*>(p + idx0) = make_uint4(w[0], w[1], w[2], w[3]);
+        if constexpr (STREAM) __builtin_nontemporal_store(u32x4_s{w[0], w[1], w[2], w[3]}, reinterpret_cast<u32x4_s*>(p + idx0));
+        else *reinterpret_cast<uint4*>(p + idx0) = make_uint4(w[0], w[1], w[2], w[3]);
     } else {
 #pragma unroll
         for (int j = 0; j < EPC; ++j) if (idx0 + j < V) p[idx0 + j] = (B)getb<DT>(w, j);
@@ -445,7 +451,7 @@ __global__ void __launch_bounds__(BLOCK, 6) vdd_contrast_sample_kernel(KP p) {
         for (int base = tid; base < nch; base += UNR * BLOCK) {
             uint32_t q[UNR][4];
 #pragma unroll
-            for (int u = 0; u < UNR; ++u) { const int ch = base + u * BLOCK; if (ch < nch) gload<DT>(p.v, ov, ch, V, p.vec_in, q[u]); }
+            for (int u = 0; u < UNR; ++u) { const int ch = base + u * BLOCK; if (ch < nch) gload<DT, LDSROW>(p.v, ov, ch, V, p.vec_in, q[u]); }
 #pragma unroll
             for (int u = 0; u < UNR; ++u) {
                 const int ch = base + u * BLOCK;
@@ -536,8 +542,8 @@ __global__ void __launch_bounds__(BLOCK, 6) vdd_contrast_sample_kernel(KP p) {
                         }
                     } else {                   // list full: in place
                         uint32_t qc[4], qd[4], x4[4];
-                        gload<DT>(p.c, oc, ch, V, p.vec_in, qc);
-                        if constexpr (BOTH) gload<DT>(p.d, od, ch, V, p.vec_in, qd);
+                        gload<DT, true>(p.c, oc, ch, V, p.vec_in, qc);
+                        if constexpr (BOTH) gload<DT, true>(p.d, od, ch, V, p.vec_in, qd);
                         contrast_chunk(both_c, ch, qv[u], qc, qd, x4);
                         R.put(ch, x4);
                     }
@@ -550,8 +556,8 @@ __global__ void __launch_bounds__(BLOCK, 6) vdd_contrast_sample_kernel(KP p) {
                 const uint4 vq = LL.data[s0];
                 const uint32_t qv[4] = {vq.x, vq.y, vq.z, vq.w};
                 uint32_t qc[4], qd[4], x4[4];
-                gload<DT>(p.c, oc, ch, V, p.vec_in, qc);
-                if constexpr (BOTH) gload<DT>(p.d, od, ch, V, p.vec_in, qd);
+                gload<DT, true>(p.c, oc, ch, V, p.vec_in, qc);
+                if constexpr (BOTH) gload<DT, true>(p.d, od, ch, V, p.vec_in, qd);
                 contrast_chunk(both_c, ch, qv, qc, qd, x4);
                 LL.data[s0] = make_uint4(x4[0], x4[1], x4[2], x4[3]);
             }
@@ -576,7 +582,7 @@ __global__ void __launch_bounds__(BLOCK, 6) vdd_contrast_sample_kernel(KP p) {
         for (int base = tid; base < nch; base += UNR * BLOCK) {
             uint32_t q[UNR][4];
 #pragma unroll
-            for (int u = 0; u < UNR; ++u) { const int ch = base + u * BLOCK; if (ch < nch) gload<DT>(p.v, ov, ch, V, p.vec_in, q[u]); }
+            for (int u = 0; u < UNR; ++u) { const int ch = base + u * BLOCK; if (ch < nch) gload<DT, LDSROW>(p.v, ov, ch, V, p.vec_in, q[u]); }
 #pragma unroll
             for (int u = 0; u < UNR; ++u) {
                 const int ch = base + u * BLOCK;
@@ -677,7 +683,7 @@ __global__ void __launch_bounds__(BLOCK, 6) vdd_contrast_sample_kernel(KP p) {
     auto store_scores = [&]() {
         if (p.scores != nullptr) {
             if constexpr (LDSROW) {
-                for (int ch = tid; ch < nch; ch += BLOCK) { uint32_t w[4]; R.get(ch, w); gstore<DT>(p.scores, (long long)row * p.ss, ch, V, p.vec_out, w); }
+                for (int ch = tid; ch < nch; ch += BLOCK) { uint32_t w[4]; R.get(ch, w); gstore<DT, true>(p.scores, (long long)row * p.ss, ch, V, p.vec_out, w); }
             } else if (p.scores != p.work) {
                 for (int ch = tid; ch < nch; ch += BLOCK) { uint32_t w[4]; R.get(ch, w); gstore<DT>(p.scores, (long long)row * p.ss, ch, V, p.vec_out, w); }
             }
