@@ -23,6 +23,10 @@ namespace {
 
 typedef __attribute__((ext_vector_type(8))) short bf16x8_t;   // MFMA A/B fragment: 8 bf16
 typedef __attribute__((ext_vector_type(4))) uint32_t u32x4_nt;
+// data that crosses the chip once (an activation read by one kernel, a cache line written for a later step): nontemporal, so it
+// takes no L2 line from data that IS re-read (the GEMMs' shared operand panels, the next GEMM's X)
+__device__ __forceinline__ uint4 ld_stream(const uint16_t* p) { return __builtin_bit_cast(uint4, __builtin_nontemporal_load(reinterpret_cast<const u32x4_nt*>(p))); }
+__device__ __forceinline__ void st_stream(uint16_t* p, uint4 v) { __builtin_nontemporal_store(__builtin_bit_cast(u32x4_nt, v), reinterpret_cast<u32x4_nt*>(p)); }
 typedef __attribute__((ext_vector_type(4))) float f32x4_t;    // MFMA C/D fragment
 
 __device__ __forceinline__ float bf2f(uint32_t b) { return __builtin_bit_cast(float, b << 16); }
@@ -75,7 +79,7 @@ template <int VPT>   // uint4 (8 x bf16) per thread
 __global__ void __launch_bounds__(256) rmsnorm_kernel(const uint16_t* __restrict__ x, const uint16_t* __restrict__ delta,
                                                       const float* __restrict__ slabs, int n_slabs, long long slab_stride,
                                                       const uint16_t* __restrict__ w, uint16_t* __restrict__ y,
-                                                      uint16_t* __restrict__ resid_out, int d, float eps) {
+                                                      uint16_t* __restrict__ resid_out, int d, float eps, int stream) {
     __shared__ float red[4];
     const int row = blockIdx.x, tid = threadIdx.x;
     const size_t off = (size_t)row * d;
@@ -85,9 +89,9 @@ __global__ void __launch_bounds__(256) rmsnorm_kernel(const uint16_t* __restrict
     for (int i = 0; i < VPT; ++i) {
         const int e = (i * 256 + tid) * 8;
         if (e < d) {
-            uint4 a = *reinterpret_cast<const uint4*>(x + off + e);
+            uint4 a = stream ? ld_stream(x + off + e) : *reinterpret_cast<const uint4*>(x + off + e);
             if (delta != nullptr) {
-                uint4 b = *reinterpret_cast<const uint4*>(delta + off + e);
+                uint4 b = stream ? ld_stream(delta + off + e) : *reinterpret_cast<const uint4*>(delta + off + e);
                 a.x = pack(lo(a.x) + lo(b.x), hi(a.x) + hi(b.x)); a.y = pack(lo(a.y) + lo(b.y), hi(a.y) + hi(b.y));
                 a.z = pack(lo(a.z) + lo(b.z), hi(a.z) + hi(b.z)); a.w = pack(lo(a.w) + lo(b.w), hi(a.w) + hi(b.w));
             }
@@ -103,7 +107,7 @@ __global__ void __launch_bounds__(256) rmsnorm_kernel(const uint16_t* __restrict
                 a.x = addr(a.x, dsum[0], dsum[1]); a.y = addr(a.y, dsum[2], dsum[3]);
                 a.z = addr(a.z, dsum[4], dsum[5]); a.w = addr(a.w, dsum[6], dsum[7]);
             }
-            if (resid_out != nullptr) *reinterpret_cast<uint4*>(resid_out + off + e) = a;
+            if (resid_out != nullptr) { if (stream) st_stream(resid_out + off + e, a); else *reinterpret_cast<uint4*>(resid_out + off + e) = a; }
             h[i] = a;
             float f;
             f = lo(a.x); ss += f * f; f = hi(a.x); ss += f * f; f = lo(a.y); ss += f * f; f = hi(a.y); ss += f * f;
@@ -144,7 +148,7 @@ __global__ void __launch_bounds__(256) rope_kv_kernel(const uint16_t* __restrict
                                                       const float* __restrict__ cs_table,
                                                       uint16_t* __restrict__ q_out, uint16_t* __restrict__ k_cache,
                                                       uint16_t* __restrict__ v_cache, int Hq, int Hkv, int D,
-                                                      long long slot_stride, int t_max) {
+                                                      long long slot_stride, int t_max, int stream) {
     const int row = blockIdx.x, tid = threadIdx.x;
     const int p = pos[row], s = slot[row], cp = cpos[row];     // rotary position vs index inside the cache slot
     const int half = D / 2, h8 = half / 8;                      // a work item = 8 consecutive pairs (i, i + D/2) of one head
@@ -154,7 +158,8 @@ __global__ void __launch_bounds__(256) rope_kv_kernel(const uint16_t* __restrict
         const int head = i / h8, pi = (i % h8) * 8;
         const bool is_k = head >= Hq;
         const uint16_t* hsrc = src + (size_t)head * D;           // q heads then k heads are contiguous in qkv
-        const uint4 a4 = *reinterpret_cast<const uint4*>(hsrc + pi), b4 = *reinterpret_cast<const uint4*>(hsrc + pi + half);
+        const uint4 a4 = stream ? ld_stream(hsrc + pi) : *reinterpret_cast<const uint4*>(hsrc + pi);
+        const uint4 b4 = stream ? ld_stream(hsrc + pi + half) : *reinterpret_cast<const uint4*>(hsrc + pi + half);
         const float4 c0 = *reinterpret_cast<const float4*>(cs + pi * 2), c1 = *reinterpret_cast<const float4*>(cs + pi * 2 + 4),
                      c2 = *reinterpret_cast<const float4*>(cs + pi * 2 + 8), c3 = *reinterpret_cast<const float4*>(cs + pi * 2 + 12);
         auto rot = [](uint32_t av, uint32_t bv, float cA, float sA, float cB, float sB, uint32_t& r0, uint32_t& r1) {
@@ -167,14 +172,15 @@ __global__ void __launch_bounds__(256) rope_kv_kernel(const uint16_t* __restrict
         rot(a4.z, b4.z, c2.x, c2.y, c2.z, c2.w, r0.z, r1.z); rot(a4.w, b4.w, c3.x, c3.y, c3.z, c3.w, r0.w, r1.w);
         uint16_t* dst = is_k ? k_cache + (size_t)s * slot_stride + ((size_t)(head - Hq) * t_max + cp) * D
                              : q_out + (size_t)row * Hq * D + (size_t)head * D;
-        *reinterpret_cast<uint4*>(dst + pi) = r0;
-        *reinterpret_cast<uint4*>(dst + pi + half) = r1;
+        if (is_k && stream) { st_stream(dst + pi, r0); st_stream(dst + pi + half, r1); }
+        else { *reinterpret_cast<uint4*>(dst + pi) = r0; *reinterpret_cast<uint4*>(dst + pi + half) = r1; }
     }
     const uint16_t* vsrc = src + (size_t)(Hq + Hkv) * D;
     for (int i = tid; i < Hkv * D / 8; i += 256) {
         const int head = (i * 8) / D, dd = (i * 8) % D;
-        *reinterpret_cast<uint4*>(v_cache + (size_t)s * slot_stride + ((size_t)head * t_max + cp) * D + dd) =
-            *reinterpret_cast<const uint4*>(vsrc + (size_t)i * 8);
+        uint16_t* vd = v_cache + (size_t)s * slot_stride + ((size_t)head * t_max + cp) * D + dd;
+        if (stream) st_stream(vd, ld_stream(vsrc + (size_t)i * 8));
+        else *reinterpret_cast<uint4*>(vd) = *reinterpret_cast<const uint4*>(vsrc + (size_t)i * 8);
     }
 }
 
@@ -835,9 +841,12 @@ int vdd_rmsnorm(const void* x, const void* delta, const float* delta_slabs, int 
     hipStream_t st = (hipStream_t)stream;
     auto X = (const uint16_t*)x; auto Dl = (const uint16_t*)delta; auto Wt = (const uint16_t*)w; auto Y = (uint16_t*)y; auto Ro = (uint16_t*)resid_out;
     const int vpt = (d / 8 + 255) / 256;
-    if (vpt <= 1) hipLaunchKernelGGL(rmsnorm_kernel<1>, dim3(M), dim3(256), 0, st, X, Dl, Sl, n_slabs, ss, Wt, Y, Ro, d, eps);
-    else if (vpt <= 2) hipLaunchKernelGGL(rmsnorm_kernel<2>, dim3(M), dim3(256), 0, st, X, Dl, Sl, n_slabs, ss, Wt, Y, Ro, d, eps);
-    else hipLaunchKernelGGL(rmsnorm_kernel<4>, dim3(M), dim3(256), 0, st, X, Dl, Sl, n_slabs, ss, Wt, Y, Ro, d, eps);
+    // decode-size batches: the residual stream crosses the chip once per kernel (nontemporal); at prefill size the next kernel still
+    // finds part of it in the Infinity Cache, and there the hint costs 2 % of the prefill
+    const int stream_io = M <= 8192 ? 1 : 0;
+    if (vpt <= 1) hipLaunchKernelGGL(rmsnorm_kernel<1>, dim3(M), dim3(256), 0, st, X, Dl, Sl, n_slabs, ss, Wt, Y, Ro, d, eps, stream_io);
+    else if (vpt <= 2) hipLaunchKernelGGL(rmsnorm_kernel<2>, dim3(M), dim3(256), 0, st, X, Dl, Sl, n_slabs, ss, Wt, Y, Ro, d, eps, stream_io);
+    else hipLaunchKernelGGL(rmsnorm_kernel<4>, dim3(M), dim3(256), 0, st, X, Dl, Sl, n_slabs, ss, Wt, Y, Ro, d, eps, stream_io);
     return ok(hipSuccess);
 }
 
@@ -846,7 +855,7 @@ int vdd_rope_kv_write(const void* qkv, const int* pos, const int* cpos, const in
     if (M <= 0) return VDD_OK;
     if (!qkv || !pos || !cpos || !slot || !cos_sin || !q_out || !k_cache || !v_cache || D % 16 != 0) return VDD_ERR_INVALID_ARG;
     hipLaunchKernelGGL(rope_kv_kernel, dim3(M), dim3(256), 0, (hipStream_t)stream, (const uint16_t*)qkv, pos, cpos, slot, cos_sin,
-                       (uint16_t*)q_out, (uint16_t*)k_cache, (uint16_t*)v_cache, Hq, Hkv, D, (long long)slot_stride, t_max);
+                       (uint16_t*)q_out, (uint16_t*)k_cache, (uint16_t*)v_cache, Hq, Hkv, D, (long long)slot_stride, t_max, M <= 8192 ? 1 : 0);
     return ok(hipSuccess);
 }
 
