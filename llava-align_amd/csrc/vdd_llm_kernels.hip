@@ -399,8 +399,8 @@ __global__ void __launch_bounds__(256) decode_attn_kernel(const uint16_t* __rest
             const int t = t0 + 4 * u;
             const int tt = t < k1 ? t : k1 - 1;
             const bool pre = tt < ar.plen;
-            kv[u] = *reinterpret_cast<const uint4*>((pre ? k_pre : k_own) + (size_t)tt * D);
-            vv[u] = *reinterpret_cast<const uint4*>((pre ? v_pre : v_own) + (size_t)tt * D);
+            kv[u] = ld_stream((pre ? k_pre : k_own) + (size_t)tt * D);          // each K / V row is read by one wave of the launch
+            vv[u] = ld_stream((pre ? v_pre : v_own) + (size_t)tt * D);
         }
 #pragma unroll
         for (int u = 0; u < U; ++u) {
@@ -457,8 +457,8 @@ __global__ void __launch_bounds__(256) decode_attn_own_merge_kernel(const uint16
         for (int u = 0; u < U; ++u) {
             const int t = t0 + 4 * u;
             const int tt = t < n_own ? t : n_own - 1;
-            kv[u] = __builtin_bit_cast(uint4, __builtin_nontemporal_load(reinterpret_cast<const u32x4_nt*>(k_own + (size_t)tt * D)));
-            vv[u] = __builtin_bit_cast(uint4, __builtin_nontemporal_load(reinterpret_cast<const u32x4_nt*>(v_own + (size_t)tt * D)));
+            kv[u] = ld_stream(k_own + (size_t)tt * D);
+            vv[u] = ld_stream(v_own + (size_t)tt * D);
         }
 #pragma unroll
         for (int u = 0; u < U; ++u) {
@@ -688,7 +688,7 @@ __global__ void __launch_bounds__(256) prefix_fragments_kernel(const uint16_t* _
     for (int p = threadIdx.x; p < 1024; p += 256) {     // K fragments: 16-byte pieces of K rows, re-ordered
         const int t = p >> 8, ks = (p >> 6) & 3, lane = p & 63, ln = lane & 15, g = lane >> 4;
         const int key = k0 + (t >> 1) * 32 + (ln >> 2) * 8 + (t & 1) * 4 + (ln & 3);
-        *reinterpret_cast<uint4*>(out + (size_t)p * 8) = key < plen ? *reinterpret_cast<const uint4*>(k + base + (size_t)key * D + ks * 32 + g * 8) : zero;
+        st_stream(out + (size_t)p * 8, key < plen ? *reinterpret_cast<const uint4*>(k + base + (size_t)key * D + ks * 32 + g * 8) : zero);      // read again only by the decode steps
     }
     __syncthreads();
     for (int p = threadIdx.x; p < 1024; p += 256) {     // V^T fragments: 8 keys of one dim per lane
@@ -698,7 +698,7 @@ __global__ void __launch_bounds__(256) prefix_fragments_kernel(const uint16_t* _
         for (int i = 0; i < 8; ++i) e[i] = tile[kk * 32 + g * 8 + i][ln * 8 + nt];
         uint4 o;
         o.x = e[0] | ((uint32_t)e[1] << 16); o.y = e[2] | ((uint32_t)e[3] << 16); o.z = e[4] | ((uint32_t)e[5] << 16); o.w = e[6] | ((uint32_t)e[7] << 16);
-        *reinterpret_cast<uint4*>(out + ATT_CH * D + (size_t)p * 8) = o;
+        st_stream(out + ATT_CH * D + (size_t)p * 8, o);
     }
 }
 

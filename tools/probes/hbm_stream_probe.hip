@@ -9,7 +9,7 @@ typedef __attribute__((ext_vector_type(4))) uint32_t u32x4;
 
 // mode 0: every wave owns a contiguous stream of `per_wave` bytes at base + wave_id * stride; bursts of NB x 1 KiB loads, all
 // issued before any is consumed (the prefix pass's pattern).  rot: start the walk at a per-wave rotated burst.
-template <int NB, int SLEEP = 0, bool PIPE = false>
+template <int NB, int SLEEP = 0, bool PIPE = false, bool NT = false>
 __global__ void __launch_bounds__(256, 2) stream_kernel(const char* base, size_t stride, int per_wave, int rot_on, uint32_t* sink) {
     const int lane = threadIdx.x & 63, wave = blockIdx.x * 4 + (threadIdx.x >> 6);
     const char* p = base + (size_t)wave * stride;
@@ -21,7 +21,7 @@ __global__ void __launch_bounds__(256, 2) stream_kernel(const char* base, size_t
         const char* q = p + (size_t)bb * NB * 1024 + lane * 16;
         u32x4 v[NB];
 #pragma unroll
-        for (int i = 0; i < NB; ++i) v[i] = *reinterpret_cast<const u32x4*>(q + i * 1024);
+        for (int i = 0; i < NB; ++i) v[i] = NT ? __builtin_nontemporal_load(reinterpret_cast<const u32x4*>(q + i * 1024)) : *reinterpret_cast<const u32x4*>(q + i * 1024);
         if constexpr (PIPE) {            // consume the first half, sleep (the "compute"), consume the rest: the second half stays in flight over the gap
 #pragma unroll
             for (int i = 0; i < NB / 2; ++i) acc ^= v[i];
@@ -131,6 +131,12 @@ int main() {
         double d = time_us([&](int i) { hipLaunchKernelGGL((stream_kernel<32, 80>), dim3(waves / 4), dim3(256), 0, 0, buf + off(i, span), stride, per_wave, 1, sink); });
         double e = time_us([&](int i) { hipLaunchKernelGGL((stream_kernel<32, 40, true>), dim3(waves / 4), dim3(256), 0, 0, buf + off(i, span), stride, per_wave, 1, sink); });
         printf("32-KiB bursts + a gap per burst with nothing in flight: none %.1f us | 0.5 us %.1f | 1.1 us %.1f | 2.1 us %.1f | 1.1 us in mid-burst %.1f\n", a, b, c, d, e);
+    }
+    {   // nontemporal loads: the stream takes no L2 line
+        const size_t stride = per_wave, span = stride * waves + per_wave;
+        double a = time_us([&](int i) { hipLaunchKernelGGL((stream_kernel<32, 0, false, false>), dim3(waves / 4), dim3(256), 0, 0, buf + off(i, span), stride, per_wave, 1, sink); });
+        double b = time_us([&](int i) { hipLaunchKernelGGL((stream_kernel<32, 0, false, true>), dim3(waves / 4), dim3(256), 0, 0, buf + off(i, span), stride, per_wave, 1, sink); });
+        printf("32-KiB bursts, plain loads %.1f us = %.2f TB/s | nontemporal loads %.1f us = %.2f TB/s\n", a, bytes / a / 1e6, b, bytes / b / 1e6);
     }
     {   // the same stream launch alternating with a different streaming kernel (as the prefix pass alternates with the own pass)
         const size_t stride = per_wave, span = stride * waves + per_wave;
