@@ -50,7 +50,7 @@ def parse_args():
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=3)
     ap.add_argument("--warmup", type=int, default=1)
-    ap.add_argument("--questions", type=int, default=768, help="questions per generate() batch per GPU (6 per image); 768 = 1,536 decode rows, ~220 GB of KV pools + weights")
+    ap.add_argument("--questions", type=int, default=768, help="questions per generate() batch per GPU (6 per image); 768 = 1,536 decode rows, ~190 GB of KV pools + weights")
     ap.add_argument("--model", default="llava-1.5-7b")
     ap.add_argument("--no-baselines", action="store_true")
     return ap.parse_args()
