@@ -25,10 +25,15 @@
 //     decode batch is where tile-count quantisation costs more than the inner loop: 768 x 12288 is 144 tiles of 256 x 256).
 //     A tile cut across workgroups is finished by the workgroup that owns its FIRST K unit - that part is the LAST thing
 //     that workgroup computes, while the other parts are the FIRST thing their workgroups compute, so the fp32 partials
-//     (one 256-KiB slab per workgroup, written once) are long complete when the finisher asks for them: agent-scope
-//     release + per-tile arrival counter on the producer side, relaxed poll + one agent-scope acquire on the finisher;
+//     (one 256-KiB slab per workgroup, written once) are long complete when the finisher asks for them.  No fences: the
+//     slabs are written with write-through (sc1) stores and read with agent-scope (sc1) loads, the per-tile arrival
+//     counter is a relaxed agent-scope atomic (an agent-scope release / acquire FENCE writes back / drops the whole L2 of
+//     the XCD under the 31 workgroups still streaming through it);
 //   * epilogues in registers: bias, bias + quick-GELU / GELU (ViT, projector), bias + residual (ViT), SwiGLU (gate and up
-//     rows of one feature are interleaved into the same W tile, so silu(g) * u never round-trips through HBM).
+//     rows of one feature are interleaved into the same W tile, so silu(g) * u never round-trips through HBM); the bf16
+//     tile then leaves through 4 KiB of LDS per wave (behind the two K-tile buffers: the workgroup owns all 160 KiB) as
+//     whole rows, 16 B per lane, with NONTEMPORAL stores - Y must not displace the operand panels the workgroups of an
+//     XCD share in its L2 (8-byte quads at a row stride cost 5-12 % of a prefill-size GEMM).
 // Bound: MFMA (2.5 PF/s dense bf16).
 
 #include <hip/hip_runtime.h>
