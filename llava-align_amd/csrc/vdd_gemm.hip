@@ -335,7 +335,7 @@ __global__ void __launch_bounds__(WM * WN * 64) gemm_kernel(const GemmArgs a) {
                         for (int q = 0; q < 4; ++q) {
                             float o[4];
                             gated(i, j, q, o);
-                            __builtin_nontemporal_store(__builtin_bit_cast(u32x2_t, pack4(o[0], o[1], o[2], o[3])), reinterpret_cast<u32x2_t*>(a.Y + (size_t)m * a.ldy + f0 + (i / 2) * 32 + q * 8));
+                            *reinterpret_cast<uint2*>(a.Y + (size_t)m * a.ldy + f0 + (i / 2) * 32 + q * 8) = pack4(o[0], o[1], o[2], o[3]);
                         }
                     }
             }
@@ -405,7 +405,7 @@ __global__ void __launch_bounds__(WM * WN * 64) gemm_kernel(const GemmArgs a) {
                             if (n >= a.N) continue;
                             float v[4];
                             quad(i, j, q, m, n, v);
-                            __builtin_nontemporal_store(__builtin_bit_cast(u32x2_t, pack4(v[0], v[1], v[2], v[3])), reinterpret_cast<u32x2_t*>(a.Y + (size_t)m * a.ldy + n));
+                            *reinterpret_cast<uint2*>(a.Y + (size_t)m * a.ldy + n) = pack4(v[0], v[1], v[2], v[3]);       // (nontemporal 8-byte quads: -25 % at prefill size)
                         }
                     }
             }
