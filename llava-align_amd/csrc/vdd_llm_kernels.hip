@@ -450,7 +450,7 @@ __global__ void __launch_bounds__(256) decode_attn_own_merge_kernel(const uint16
     const uint16_t* v_own = vc + (size_t)ar.slot * slot_stride + hoff;
     const int n_own = ar.len - ar.plen;
     float m = -INFINITY, l = 0.f, acc[8] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
-    constexpr int U = 4;
+    constexpr int U = 8;
     for (int t0 = g; t0 < n_own; t0 += 4 * U) {
         uint4 kv[U], vv[U];
 #pragma unroll
