@@ -705,6 +705,12 @@ class VddLlavaEngine:
         ids_list = [r for r in input_ids] if torch.is_tensor(input_ids) else list(input_ids)
         ids_list = [r.reshape(-1).tolist() for r in ids_list]
         Q = len(ids_list)
+        # the vision tower needs nothing of the planning below: its launches go out first, so the host-side validation / planning
+        # of ~800 prompts (20-30 ms of Python) runs under its GPU time instead of in front of it
+        feats = None
+        if images is not None:
+            imgs = [images[i] for i in range(Q)] if torch.is_tensor(images) else list(images)
+            feats = self.image_features(imgs, image_keys)
         for q_, r in enumerate(ids_list):                     # ids index the embedding table on the device: validate them here
             n_slot = sum(1 for t_ in r if t_ == IMAGE_TOKEN_INDEX)
             if n_slot > 1:
@@ -728,10 +734,6 @@ class VddLlavaEngine:
         warp = WarpSpec(temperature=temperature, top_k=top_k, top_p=top_p)
 
         # ---- branches: (name, per-question token lists with image slot handling) ------------
-        feats = None
-        if images is not None:
-            imgs = [images[i] for i in range(Q)] if torch.is_tensor(images) else list(images)
-            feats = self.image_features(imgs, image_keys)
         feats_cd = None
         if use_cd and inputs_embeds is None:
             imgs_cd = [images_cd[i] for i in range(Q)] if torch.is_tensor(images_cd) else list(images_cd)
