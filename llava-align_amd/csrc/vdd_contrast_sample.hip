@@ -329,12 +329,13 @@ __device__ __forceinline__ uint32_t select_kth_key(const Row<DT, L>& R, int nch,
 // whole row's mass never exceeds thr (then only min_keep survive).
 template <int DT, bool L>
 __device__ __forceinline__ bool select_mass_key(const Row<DT, L>& R, int nch, float m, float thr, Smem& sm,
-                                                int tid, int lane, int wave, uint32_t& out_key, unsigned long long live) {
+                                                int tid, int lane, int wave, uint32_t& out_key, unsigned long long live,
+                                                int digits_known = 0, uint32_t prefix = 0, float below = 0.f) {
+    // digits_known = 1: the caller found the top digit (`prefix`) and the mass under it (`below`) without the histogram
     constexpr int KB = Tr<DT>::KEYBITS, EPC = Tr<DT>::EPC;
-    uint32_t prefix = 0, pmask = 0;
-    float below = 0.f;
+    uint32_t pmask = digits_known ? 0xFFu << (KB - 8) : 0u;
     bool ok = true;
-    for (int shift = KB - 8; shift >= 0; shift -= 8) {
+    for (int shift = KB - 8 - 8 * digits_known; shift >= 0; shift -= 8) {
         sm.histf[tid >> 8][tid & 255] = 0.f;
         __syncthreads();
         float* h = sm.histf[wave % NCOPY];
@@ -367,7 +368,7 @@ __device__ __forceinline__ bool select_mass_key(const Row<DT, L>& R, int nch, fl
             unsigned long long nonempty = __ballot(loc > 0.f);
             int hit_lane;
             if (cross) hit_lane = __ffsll((long long)cross) - 1;
-            else if (shift == KB - 8) hit_lane = -1;                               // whole row below thr
+            else if (shift == KB - 8) hit_lane = -1;                               // whole row below thr (top digit only)
             else hit_lane = nonempty ? 63 - __clzll((long long)nonempty) : -1;     // association fuzz: top non-empty
             if (hit_lane < 0) { if (lane == 0) sm.sel[2] = 0; }
             else if (lane == hit_lane) {
@@ -972,12 +973,52 @@ __global__ void __launch_bounds__(BLOCK, 6) vdd_contrast_sample_kernel(KP p) {
         z = block_sum(z, sm, lane, wave);
         zb = block_sum(zb, sm, lane, wave);
         const float thr = rnd<DT>(p.one_minus_p) * z;      // cum <= fl(1-p)  <=>  mass <= fl(1-p) * Z
+        constexpr int TOPD = 4, KB = Tr<DT>::KEYBITS;
+        const uint32_t mkey = okey<DT>(Tr<DT>::from_f(m)), mdig = mkey >> (KB - 8);
         uint32_t pkey = 0;
         bool crossed;
         // a peaked row (the usual one when a model is confident): everything below the maximum together is mass top-p removes, so
         // the threshold is the maximum itself and the two radix passes over the row are not needed
-        if (zb <= thr) { crossed = true; pkey = okey<DT>(Tr<DT>::from_f(m)); }
-        else crossed = select_mass_key<DT, LDSROW>(R, nch, m, thr, sm, tid, lane, wave, pkey, livemask);
+        if (zb <= thr) { crossed = true; pkey = mkey; }
+        else {
+            // The TOP DIGIT of the threshold key (sign + 7 exponent bits for bf16 / fp32: two octaves per digit) in registers: a
+            // row puts almost all of its elements into a handful of top digits, so the shared-memory histogram of that digit is
+            // thousands of same-address atomics per wave (956 us at B = 4096 on flat rows); the mass of the maximum's digit and
+            // of the TOPD - 1 under it is five selects per element.
+            float zd[TOPD] = {0.f, 0.f, 0.f, 0.f}, zrest = 0.f;
+            for (int ch = tid, k = 0; ch < nch; ch += BLOCK, ++k) {
+                if (!(k >= 64 || ((livemask >> k) & 1ull) != 0ull)) continue;
+                uint32_t w[4]; R.get(ch, w);
+#pragma unroll
+                for (int j = 0; j < EPC; ++j) {
+                    uint32_t b = getb<DT>(w, j);
+                    if (b != NINF) {
+                        const float e = __expf(Tr<DT>::to_f(b) - m);
+                        const uint32_t dd = mdig - (okey<DT>(b) >> (KB - 8));
+#pragma unroll
+                        for (int q = 0; q < TOPD; ++q) zd[q] += (dd == (uint32_t)q) ? e : 0.f;
+                        zrest += (dd >= (uint32_t)TOPD) ? e : 0.f;
+                    }
+                }
+            }
+            zrest = block_sum(zrest, sm, lane, wave);
+#pragma unroll
+            for (int q = 0; q < TOPD; ++q) zd[q] = block_sum(zd[q], sm, lane, wave);
+            if (zrest > thr) {
+                // the threshold lies more than TOPD digits under the maximum: full histogram passes
+                crossed = select_mass_key<DT, LDSROW>(R, nch, m, thr, sm, tid, lane, wave, pkey, livemask);
+            } else {
+                float below = zrest; int dq = -1;
+#pragma unroll
+                for (int q = TOPD - 1; q >= 0; --q)
+                    if (dq < 0) { if (below + zd[q] > thr) dq = q; else below += zd[q]; }
+                if (dq < 0) {             // rounding: zb > thr but the digit sums did not cross - the maximum's own digit holds it
+                    dq = 0; below -= zd[0];
+                }
+                crossed = select_mass_key<DT, LDSROW>(R, nch, m, thr, sm, tid, lane, wave, pkey, livemask, 1,
+                                                      (mdig - (uint32_t)dq) << (KB - 8), below);
+            }
+        }
         // never remove the top min_keep entries
         uint32_t keep_key;
         if (p.min_keep <= 1) keep_key = okey<DT>(Tr<DT>::from_f(m));

@@ -138,6 +138,41 @@ def test_top_p_fp32_mass_form_is_still_available_behind_its_flag():
         assert torch.equal(_bits(want[both]), _bits(got[both]))
 
 
+@pytest.mark.parametrize("dt", ["bf16", "fp16", "fp32"])
+def test_top_p_mass_form_threshold_on_flat_and_shifted_rows(dt):
+    """Rows with more candidates than the exact form lists: the kept set must be the float64 mass threshold's, except for values
+    whose cumulative mass sits within 2e-4 of the boundary (fp32 summation order).  Spreads from near-uniform to peaked and an
+    all-negative row: the top digit of the threshold key comes from the register pass for some and from the histogram for others."""
+    L = _L()
+    tdt = {"bf16": torch.bfloat16, "fp16": torch.float16, "fp32": torch.float32}[dt]
+    g = torch.Generator().manual_seed(5)
+    for V in (32000, 4099):
+        for sigma, shift in ((0.3, 0.0), (2.0, 0.0), (2.0, -30.0), (6.0, 3.0), (0.02, 100.0)):
+            v = (torch.randn(3, V, generator=g) * sigma + shift).to(tdt)
+            v[1, ::7] = float("-inf")
+            for top_p in (0.3, 0.9, 0.999):
+                got = L.contrast_sample(v.to(DEV), warp=L.WarpSpec(top_p=top_p), return_scores=True, pick_argmax=True).scores.cpu()
+                thr = torch.tensor(1.0 - top_p).to(tdt).double().item()
+                for r in range(3):
+                    x = v[r].double()
+                    fin = torch.isfinite(x)
+                    e = torch.where(fin, torch.exp(x - x[fin].max()), torch.zeros_like(x))
+                    srt, idx = torch.sort(x)
+                    cum = torch.cumsum(e[idx], 0) / e.sum()
+                    # mass of everything <= own value (whole tie classes move together)
+                    last_of_value = torch.searchsorted(srt, srt, right=True) - 1
+                    mass_le = torch.empty_like(cum)
+                    mass_le[idx] = cum[last_of_value]
+                    want_removed = fin & (mass_le <= thr)
+                    want_removed &= x < x[fin].max()          # min_tokens_to_keep = 1
+                    got_removed = fin & ~torch.isfinite(got[r].double())
+                    kept = fin & ~got_removed
+                    assert torch.equal(_bits(got[r][kept]), _bits(v[r][kept])), (dt, V, sigma, shift, top_p, r)
+                    diff = want_removed ^ got_removed
+                    assert bool(((mass_le[diff] - thr).abs() <= 2e-4).all()), (dt, V, sigma, shift, top_p, r, int(diff.sum()),
+                                                                              (mass_le[diff] - thr).abs().max().item())
+
+
 def test_all_masked_row_sets_status_and_raises():
     L = _L()
     v, c = [r.to(DEV) for r in logit_rows(77, 2, 97, torch.float16, 2)[0]]
