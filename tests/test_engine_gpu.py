@@ -346,6 +346,23 @@ def test_vit_graph_replay_equals_eager_forward():
     assert torch.equal(a.tokens, b.tokens)
 
 
+def test_host_images_through_the_pinned_staging_buffers_equal_device_images():
+    """CPU image tensors (what the reference's drivers hand to generate()) are stacked into two pinned staging buffers and uploaded
+    asynchronously, 16 at a time: 40 images = three chunks, so the first buffer is reused while its upload may still be in
+    flight.  Same features as the same images already on the device, repeatedly, and in fp16 as well as fp32."""
+    from llava_align_amd.engine import LlavaWeights, VddLlavaEngine, preset
+    cfg = preset("tiny")
+    e = VddLlavaEngine(cfg, weights=LlavaWeights.random(cfg, DEV, seed=3, std=0.06), device=DEV, use_graph=True)
+    g = torch.Generator().manual_seed(9)
+    for dt in (torch.float32, torch.float16):
+        for rep in range(2):
+            host = [torch.randn(3, cfg.vision.image, cfg.vision.image, generator=g).to(dt) for _ in range(40)]
+            dev = [im.to(DEV) for im in host]
+            fh, fd = e.image_features(host), e.image_features(dev)
+            assert all(torch.equal(a, b) for a, b in zip(fh, fd)), (dt, rep)
+    assert e._pin[0].is_pinned() and e._pin_key[0] == torch.float16
+
+
 def test_captured_steps_survive_a_later_larger_batch():
     """Every captured decode step owns its split-KV partials buffer: replaying the graph of a small ungrouped batch after a
     larger batch has run (which would have re-allocated a shared workspace) must give the same tokens as before."""
