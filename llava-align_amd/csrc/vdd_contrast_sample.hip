@@ -637,13 +637,16 @@ __global__ void __launch_bounds__(BLOCK, 6) vdd_contrast_sample_kernel(KP p) {
             for (int ch = tid, kq = 0; ch < nch; ch += BLOCK, ++kq) {
                 if (!flagged(kq)) continue;
                 uint32_t w[4]; R.get(ch, w);
+                unsigned hit = 0u;                          // branch-free test of the chunk first: nearly every chunk has no candidate
 #pragma unroll
-                for (int j = 0; j < EPC; ++j) {
-                    const uint32_t b = getb<DT>(w, j);
-                    if (b != NINF && Tr<DT>::to_f(b) >= L) {
-                        const unsigned slot = atomicAdd(&sm.cand_n, 1u);
-                        if (slot < (unsigned)TOPK_LIST_MAX) ck[slot] = okey<DT>(b);
-                    }
+                for (int j = 0; j < EPC; ++j) hit |= (Tr<DT>::to_f(getb<DT>(w, j)) >= L ? 1u : 0u) << j;       // -inf >= L is false
+                if (hit) {
+#pragma unroll
+                    for (int j = 0; j < EPC; ++j)
+                        if ((hit >> j) & 1u) {
+                            const unsigned slot = atomicAdd(&sm.cand_n, 1u);
+                            if (slot < (unsigned)TOPK_LIST_MAX) ck[slot] = okey<DT>(getb<DT>(w, j));
+                        }
                 }
             }
             __syncthreads();
@@ -661,15 +664,17 @@ __global__ void __launch_bounds__(BLOCK, 6) vdd_contrast_sample_kernel(KP p) {
                 for (int ch = tid, kq = 0; ch < nch; ch += BLOCK, ++kq) {
                     if (!flagged(kq)) continue;
                     uint32_t w[4]; R.get(ch, w);
-                    bool changed = false, any = false;
+                    int kept = 0;                               // branch-free: almost every chunk ends up all -inf
 #pragma unroll
                     for (int j = 0; j < EPC; ++j) {
                         const uint32_t b = getb<DT>(w, j);
-                        if (b == NINF) continue;
-                        if (okey<DT>(b) < kth) { setb<DT>(w, j, NINF); changed = true; } else { ++cnt; any = true; }
+                        const bool keep = b != NINF && okey<DT>(b) >= kth;
+                        setb<DT>(w, j, keep ? b : NINF);
+                        kept += keep ? 1 : 0;
                     }
-                    if (changed) R.put(ch, w);
-                    if (any && kq < 64) lm2 |= 1ull << kq;
+                    R.put(ch, w);
+                    cnt += kept;
+                    if (kept && kq < 64) lm2 |= 1ull << kq;
                 }
                 livemask = lm2;
                 float mm = m;
