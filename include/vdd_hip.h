@@ -174,8 +174,8 @@ int vdd_skinny_norm_swiglu(const void* resid, const void* delta, const void* nor
  * workspace: caller-owned device scratch of >= vdd_gemm_workspace_bytes(M, N) bytes whose first (tile-count) int32 words are
  *   ZERO before the first call (arrival counters of tiles cut across workgroups; every call leaves them zero again) - one
  *   buffer per stream, launches on a stream may share it.
- * config: low 4 bits = macro tile (0 = 256x256; 1..7 = 256x256, 128x256, 256x128, 192x256, 256x192, 192x192, 192x128 (the last
- *         three: no SwiGLU)); bits 4-5 = schedule (0 hybrid: whole-tile rounds + stream-K remainder, 1 data-parallel only,
+ * config: low 4 bits = macro tile (0 = 256x256; 1..8 = 256x256, 128x256, 256x128, 192x256, 256x192, 192x192, 192x128 (these
+ *         three: no SwiGLU), 64x256 (a few dozen rows: the launch is a W stream)); bits 4-5 = schedule (0 hybrid: whole-tile rounds + stream-K remainder, 1 data-parallel only,
  *         2 stream-K only).  Every choice writes the same result up to the fp32 summation order of a K-split tile. */
 #define VDD_GEMM_NONE 0
 #define VDD_GEMM_BIAS 1

@@ -517,6 +517,8 @@ int vdd_gemm(const void* X, const void* W, void* Y, const void* bias, const void
         case 5: return launch_cfg<256, 192, 4, 2>(a, epilogue, sched, workspace, workspace_bytes, st);
         case 6: return launch_cfg<192, 192, 2, 3>(a, epilogue, sched, workspace, workspace_bytes, st);      // 6 waves of 96 x 64
         case 7: return launch_cfg<192, 128, 2, 4>(a, epilogue, sched, workspace, workspace_bytes, st);      // 8 waves of 96 x 32
+        case 8: return launch_cfg<64, 256, 2, 4>(a, epilogue, sched, workspace, workspace_bytes, st);       // a few dozen rows: W streaming,
+                                                                                                            // 64-KiB partial slabs
         default: return VDD_ERR_INVALID_ARG;
     }
 }

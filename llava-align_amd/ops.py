@@ -142,7 +142,7 @@ def linear_to_norm(x, w):
     regime N = d gives only d/16 column blocks: the kernel then splits K eight ways inside a block (K % 256 == 0), or, failing
     that, across blocks into fp32 slabs that the norm sums."""
     M, K = x.shape
-    if M <= SKINNY_MAX_M and K % 128 == 0 and w.shape[0] <= 8192 and K % 256 != 0:
+    if M <= skinny_rows(w.shape[0], K) and K % 128 == 0 and w.shape[0] <= 8192 and K % 256 != 0:
         for ns in (4, 2):
             if K % (128 * ns) == 0:
                 return skinny_gemm(x, w, n_split=ns, slabs=True)
@@ -181,13 +181,26 @@ def norm_swiglu_linear(resid, delta, norm_w, eps, w_gate_up, resid_out=None, out
     return out
 
 
-SKINNY_MAX_M = 8      # measured on MI355X (tools/e2e_probe.py): the weight-streaming GEMV wins up to ~8 rows
+SKINNY_MAX_M = 8      # up to here every projection is a weight-streaming kernel and the RMSNorms run as their prologues
+
+
+def skinny_rows(N, K):
+    """Up to how many rows the weight-streaming kernel beats the row-batched MFMA GEMM for an [N, K] weight
+    (tools/skinny_crossover_probe.py, LLaVA-1.5-7B shapes, MI355X): the GEMM's time is flat in M below one macro tile (qkv 31, o 28,
+    gate/up 46, down 41 us with the 64-row tile), the streaming kernel's grows with its 16-row MFMA tiles - wide outputs (qkv,
+    gate/up) win up to 16 rows (26 vs 31, 46 vs 46 us), the d-wide ones (eight waves per block) up to 32 (down: 36 vs 41 us) and,
+    with K <= 5120, up to 64 (o: 23 vs 29 us).  Under GEMM_BATCH_INVARIANT the switch stays at SKINNY_MAX_M rows."""
+    if GEMM_BATCH_INVARIANT:
+        return SKINNY_MAX_M
+    if N > 8192:
+        return 16
+    return 64 if K <= 5120 else 32
 
 # ---- row-batched MFMA GEMM (csrc/vdd_gemm.hip): every projection above SKINNY_MAX_M rows
 EPI_NONE, EPI_BIAS, EPI_BIAS_QUICK_GELU, EPI_BIAS_GELU, EPI_SWIGLU, EPI_BIAS_RESID = range(6)
 GEMM_TUNE_MAX_M = 4096          # shapes up to here (the decode batch, single images) pick their tile shape / schedule by a
                                 # one-off timing run; above, 256 x 256 tiles + the hybrid schedule (tools/gemm_sched.py)
-GEMM_CANDIDATES = [(c, s_) for c in (1, 2, 3, 4, 5, 6, 7) for s_ in (0, 1, 2)]     # (macro tile id, schedule) -> config = c + 16 * s
+GEMM_CANDIDATES = [(c, s_) for c in (1, 2, 3, 4, 5, 6, 7, 8) for s_ in (0, 1, 2)]     # (macro tile id, schedule) -> config = c + 16 * s
 GEMM_BATCH_INVARIANT = False    # True: data-parallel schedule only.  Every output element is then accumulated over K in one fixed
                                 # order whatever the macro tile, i.e. a row's result does not depend on which other rows are in the
                                 # batch (stream-K cuts K where the batch shape puts the cut); costs the load balance at decode size
@@ -254,7 +267,7 @@ def _gemm_tune(x, w, out, bias, resid, M, N, K, epi, ws, iters=8):
     e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
     turn = 0
     for c, sch in GEMM_CANDIDATES:
-        if (epi == EPI_SWIGLU and c in (5, 6, 7)) or (GEMM_BATCH_INVARIANT and sch != 1):
+        if (epi == EPI_SWIGLU and c in (5, 6, 7)) or (GEMM_BATCH_INVARIANT and sch != 1) or (c == 8 and M > 256):
             continue
         cfg = c + 16 * sch
         _gemm_call(x, copies[turn % len(copies)], out, bias, resid, M, N, K, epi, cfg, ws); turn += 1
@@ -271,8 +284,8 @@ def _gemm_tune(x, w, out, bias, resid, M, N, K, epi, ws, iters=8):
 
 
 def linear(x, w, out=None, bias=None):
-    """Row-batched projection: weight-streaming GEMV kernel up to SKINNY_MAX_M rows, the MFMA GEMM above."""
-    if x.shape[0] <= SKINNY_MAX_M and x.shape[1] % 128 == 0:
+    """Row-batched projection: weight-streaming GEMV kernel up to skinny_rows(N, K) rows, the MFMA GEMM above."""
+    if x.shape[0] <= skinny_rows(w.shape[0], x.shape[1]) and x.shape[1] % 128 == 0:
         y = skinny_gemm(x, w, out=out)
         return bias_act(y, bias, out=y) if bias is not None else y
     return gemm(x, w, bias=bias, epi=EPI_BIAS if bias is not None else EPI_NONE, out=out)
@@ -283,7 +296,7 @@ def swiglu_linear(x, w_gate_up, out=None):
     handful of rows, the MFMA GEMM with the SwiGLU epilogue above (no [M, 2F] round trip, no silu_mul launch)."""
     M, K = x.shape
     F = w_gate_up.shape[0] // 2
-    if M <= SKINNY_MAX_M and K % 128 == 0:
+    if M <= min(16, skinny_rows(2 * F, K)) and K % 128 == 0:          # the fused kernel holds one 16-row MFMA tile
         _bf16(x, w_gate_up)
         out = torch.empty(M, F, dtype=x.dtype, device=x.device) if out is None else out
         _lib.check(_lib_ready().vdd_skinny_swiglu(x.data_ptr(), w_gate_up.data_ptr(), out.data_ptr(), M, F, K, x.stride(0), _st(x)))
