@@ -86,6 +86,7 @@ __global__ void __launch_bounds__(WM * WN * 64) gemm_kernel(const GemmArgs a) {
     constexpr int XIMG = BM / 8, WIMG = BN / 8;            // 1-KiB LDS-DMA images (8 rows x 128 B) per K-tile
     constexpr int XJ = XIMG / NW, WJ = WIMG / NW;          // images per wave
     constexpr int BUF = (BM + BN) * 128;                   // bytes of one K-tile buffer
+    constexpr int NSTG = (BM == 64) ? 3 : 2;                // K-tile buffers (the 64-row tile is a W stream: see the K pipeline below)
     constexpr int NMMA = NI * MI, NRD = NI + MI, NLD = XJ + WJ;
     static_assert(XIMG % NW == 0 && WIMG % NW == 0 && TM % 32 == 0 && TN % 32 == 0, "tile / wave shape");
     static_assert(EPI != EPI_SWIGLU || NI % 2 == 0, "SwiGLU pairs gate/up 32-column blocks inside a wave");
@@ -187,7 +188,11 @@ __global__ void __launch_bounds__(WM * WN * 64) gemm_kernel(const GemmArgs a) {
     };
 
     bool more = advance();
-    if (more) { setup(); stage(0, 0); stage(1, 1); }
+    auto stage_first = [&]() {
+        stage(0, 0); stage(1, 1);
+        if constexpr (NSTG == 3) { if (nk > 2) stage(2, 2); }
+    };
+    if (more) { setup(); stage_first(); }
     while (more) {
         const int cL = L, cku0 = ku0, cku1 = ku1, ctn = tn, cm0 = m0, cn0 = n0;      // this segment (the state moves on to the next one below)
         f32x16_t acc[NI][MI];
@@ -201,8 +206,10 @@ __global__ void __launch_bounds__(WM * WN * 64) gemm_kernel(const GemmArgs a) {
         // ---- K pipeline.  Fragments are read TWO 16-deep k-steps ahead of their MFMAs (sets kk = 0..3, three live at a
         // time), one LDS read (and, behind the barrier, one LDS-DMA of tile t+2) issued behind each MFMA.
         // (the first two K-tiles of this segment were staged before the previous segment's epilogue)
-        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-        __builtin_amdgcn_s_barrier();
+        if constexpr (NSTG == 2) {
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+            __builtin_amdgcn_s_barrier();
+        }
         auto interleave = [&](bool with_dma, bool with_reads) {             // MFMA, [DMA], [read], MFMA, ...
 #pragma unroll
             for (int i = 0; i < NMMA; ++i) {
@@ -224,6 +231,26 @@ __global__ void __launch_bounds__(WM * WN * 64) gemm_kernel(const GemmArgs a) {
 #pragma unroll
                 for (int j = 0; j < MI; ++j) acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(wg[kk][i], xg[kk][j], acc[i][j], 0, 0, 0);
         };
+        if constexpr (NSTG == 3) {
+            // The 64-row tile (a few dozen rows of activations): the launch is a stream of W through the CUs, 2 MFMAs per wave and
+            // k-step, and what bounds it is the bytes in flight - with two buffers one K-tile (40 KiB) per CU, 2.6 TB/s.  Three
+            // buffers, two tiles in flight behind the one being multiplied; nothing to interleave, two barriers per K-tile.
+            const int cnk = nk;
+            for (int t = 0; t < cnk; ++t) {
+                const int ahead = min(2, cnk - 1 - t);                // tiles staged beyond t
+                // (t = 0: the previous segment's epilogue stores are counted by vmcnt too and retire out of order with the loads)
+                if (ahead == 2 && t > 0) asm volatile("s_waitcnt vmcnt(%0)" :: "n"(2 * NLD) : "memory");
+                else if (ahead == 1 && t > 0) asm volatile("s_waitcnt vmcnt(%0)" :: "n"(NLD) : "memory");
+                else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+                __builtin_amdgcn_s_barrier();
+                const int buf = t % 3;
+                rd(buf, 0); rd(buf, 1); rd(buf, 2); rd(buf, 3);
+                asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+                __builtin_amdgcn_s_barrier();                         // every wave holds its fragments of tile t: the buffer is free
+                if (t + 3 < cnk) stage(t + 3, buf);
+                mm(0); mm(1); mm(2); mm(3);
+            }
+        } else {
         rd(0, 0); rd(0, 1);
         __builtin_amdgcn_sched_barrier(0);
         auto tile = [&](int t, int buf, auto do_stage, auto do_next) {           // buf is a literal at every call site
@@ -244,10 +271,11 @@ __global__ void __launch_bounds__(WM * WN * 64) gemm_kernel(const GemmArgs a) {
         for (; t + 2 < nk; t += 2) { tile(t, 0, T_{}, T_{}); tile(t + 1, 1, T_{}, T_{}); }
         tile(t, 0, F_{}, T_{});
         tile(t + 1, 1, F_{}, F_{});
+        }
         // nobody reads LDS behind the last barrier of a segment: stage the next segment's first two K-tiles now, so that
         // they land under this segment's epilogue
         more = advance();
-        if (more) { setup(); stage(0, 0); stage(1, 1); }
+        if (more) { setup(); stage_first(); }
 
         // ---- a tile cut across workgroups
         const bool whole = (cku0 == 0 && cku1 == a.UP);
@@ -306,7 +334,7 @@ __global__ void __launch_bounds__(WM * WN * 64) gemm_kernel(const GemmArgs a) {
                 }
             };
             if ((TN == 64) && a.stage_out) {       // 32 feature columns per wave: 64-byte rows through LDS, 16 rows per store instruction
-                char* st = lds + 2 * BUF + wave * 4096;
+                char* st = lds + NSTG * BUF + wave * 4096;
                 const int r = lane & 31, hi = lane >> 5;
 #pragma unroll
                 for (int j = 0; j < MI; ++j) {
@@ -366,7 +394,7 @@ __global__ void __launch_bounds__(WM * WN * 64) gemm_kernel(const GemmArgs a) {
             // whole 128-byte rows, 16 B per lane, 8 rows per instruction (chunks XOR-swizzled with the row: conflict-free reads).
             const bool staged = (TN == 64) && a.stage_out;
             if (staged) {
-                char* st = lds + 2 * BUF + wave * 4096;
+                char* st = lds + NSTG * BUF + wave * 4096;
                 const int r = lane & 31, hi = lane >> 5;
 #pragma unroll
                 for (int j = 0; j < MI; ++j) {
@@ -451,7 +479,7 @@ int launch_cfg(const GemmArgs& a0, int epi, int sched, void* workspace, int64_t 
     a.counter = (int*)workspace;
     a.partial = (float*)((char*)workspace + (((size_t)a.Mt * a.Nt * sizeof(int) + 255) & ~(size_t)255));
     const dim3 grid(P), block(WM * WN * 64);
-    const size_t smem = 2 * (BM + BN) * 128 + ((BN / WN == 64) ? WM * WN * 4096 : 0);      // + the epilogue's staging blocks
+    const size_t smem = (BM == 64 ? 3 : 2) * (BM + BN) * 128 + ((BN / WN == 64) ? WM * WN * 4096 : 0);      // + the epilogue's staging blocks
     a.stage_out = ((a.ldy % 8) == 0 && (((uintptr_t)a.Y) & 15) == 0) ? 1 : 0;
 #define VDD_GEMM_LAUNCH(E)                                                                                            \
     case E: {                                                                                                         \
