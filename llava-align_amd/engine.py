@@ -843,8 +843,9 @@ class VddLlavaEngine:
         sel = [b * Q + q for b in keep for q in range(Q)]
         dec_rows = [[seg[i]["slot"], seg[i]["pos0"] + seg[i]["T"] + 1, seg[i]["pslot"], seg[i]["plen"]] for i in sel]
         grp, _members = group_rows_by_prefix(dec_rows) if self.group_attention else ([], [])
-        if grp and not grouping_pays(grp, dec_rows):
-            grp = []
+        if grp and (not grouping_pays(grp, dec_rows) or (len(dec_rows) <= ops.FUSED_ATTN_MAX_M and lm.head_dim == 128)):
+            grp = []      # (up to 16 rows the one-launch RoPE + KV write + attention kernel beats the three launches of the grouped
+                          #  path although it reads a shared prefix once per row: tools/small_batch_attn_probe.py, +4 ... 9 %)
         cpi = ops.prefix_chunks_per_item(grp, lm.n_heads)
         n_groups, n_items = len(grp), len(ops.prefix_work_items(grp, cpi))
         cfgkey = cfgkey + (n_groups, n_items, cpi)
@@ -894,6 +895,7 @@ class VddLlavaEngine:
         seqs_out = [torch.cat([flat[offs[q]:offs[q + 1]], gen[q]]) for q in range(Q)]
         stats["steps"] = int(gen.shape[1])
         stats["graph"] = run.graph is not None
+        stats["n_groups"] = n_groups          # > 0: the decode steps ran the grouped (shared-prefix) attention
         return GenerateOutput(seqs_out, gen, scores, top_prob, top_tok, stats)
 
     def _runner(self, key, Q, nb, max_new, tail):

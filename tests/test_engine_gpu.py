@@ -213,11 +213,17 @@ def test_grouped_prefix_attention_is_transparent(eng):
     ids, imgs = prompts(seed=17)
     kw = dict(images=imgs, cd_alpha=1.0, cd_beta=0.1, temperature=0.5, max_new_tokens=6, cd_greedy=True, output_scores=True,
               use_dd=True, use_dd_unk=True)
-    eng.group_attention = True
-    a = eng.generate(ids, **kw)
-    eng.group_attention = False
-    b = eng.generate(ids, **kw)
-    eng.group_attention = True
+    from llava_align_amd import ops
+    fmax, ops.FUSED_ATTN_MAX_M = ops.FUSED_ATTN_MAX_M, 0        # (up to FUSED_ATTN_MAX_M rows the engine would not group at all)
+    try:
+        eng.group_attention = True
+        a = eng.generate(ids, **kw)
+        assert a.stats["n_groups"] > 0
+        eng.group_attention = False
+        b = eng.generate(ids, **kw)
+    finally:
+        eng.group_attention = True
+        ops.FUSED_ATTN_MAX_M = fmax
     checked = 0
     for q in range(len(ids)):
         for step in range(6):
