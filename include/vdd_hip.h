@@ -151,18 +151,6 @@ int vdd_skinny_gemm(const void* X, const void* W, const void* R, void* Y, float*
  * launch; replaces vdd_skinny_gemm(N = 2F) + vdd_silu_mul with the same bf16 rounding points. */
 int vdd_skinny_swiglu(const void* X, const void* W_gate_up, void* act, int M, int F, int K, int64_t ldx, void* hip_stream);
 
-/* The same two weight-streaming kernels with the RMSNorm that feeds them as their PROLOGUE (one question in flight = 2 - 3 rows:
- * HF LlamaDecoderLayer.forward [ext] under llava_llama.py:88-103 is then a chain of launches that each cost a kernel boundary,
- * and a two-block RMSNorm launch runs 6.8 us for 16 KB):  h = resid (+ delta);  resid_out <- h (written by one block; may be
- * NULL; must NOT alias resid);  x = bf16(bf16(h * rsqrt(mean h^2 + eps)) * norm_w);  then Y = x W^T  /  act = silu(x Wg^T) *
- * (x Wu^T).  Every block normalises the M rows itself in LDS, in vdd_rmsnorm's element order: bit-identical to
- * vdd_rmsnorm + vdd_skinny_gemm / vdd_skinny_swiglu.  M <= 8, K % 128 == 0, M * K * 2 <= 65536 bytes of LDS;
- * resid / delta / resid_out are contiguous [M, K]. */
-int vdd_skinny_norm_gemm(const void* resid, const void* delta, const void* norm_w, float eps, void* resid_out, const void* W, void* Y,
-                         int M, int N, int K, int64_t ldy, void* hip_stream);
-int vdd_skinny_norm_swiglu(const void* resid, const void* delta, const void* norm_w, float eps, void* resid_out, const void* W_gate_up,
-                           void* act, int M, int F, int K, void* hip_stream);
-
 /* Row-batched projection GEMM, any M above the skinny regime (csrc/vdd_gemm.hip): Y[M,N] = epilogue(X[M,K] W[N,K]^T), bf16 in,
  * fp32 accumulate (32x32x16 MFMA, both operands LDS-DMA'd into swizzled LDS tiles, persistent stream-K over one workgroup
  * per CU), bf16 out.  K % 128 == 0, N % 4 == 0, ldx/ldw % 8 == 0 (elements).  Replaces the eager nn.Linear calls of HF

@@ -223,71 +223,6 @@ __global__ void __launch_bounds__(256) embed_scatter_kernel(const int* __restric
         *reinterpret_cast<uint4*>(out + row * d + e) = *reinterpret_cast<const uint4*>(table + (size_t)id * d + e);
 }
 
-// ------------------------------------------------------------------ RMSNorm as the PROLOGUE of a weight-streaming kernel
-// One question in flight (2 - 3 rows) is a chain of launches that each cost a kernel boundary: a two-block RMSNorm runs 6.8 us
-// for 16 KB of data.  The GEMV that consumes the normalised rows can make them itself: every block (256 threads, the thread ->
-// element map and the summation order of rmsnorm_kernel, so the rows are bit-identical) forms h = resid + delta and
-// y = bf16(bf16(h * rstd) * w) for all M rows in LDS, after its first batch of W loads has gone out.  Block 0 stores h to
-// `resid_out` (which must not alias `resid`: the other blocks are still reading it).
-struct NormIn {
-    const uint16_t* resid; const uint16_t* delta; const uint16_t* w; uint16_t* resid_out; float eps;
-};
-
-__device__ __forceinline__ void norm_rows_to_lds(const NormIn& n, int M, int d, uint16_t* ylds, float (*red)[8]) {
-    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-    const int vpt = (d / 8 + 255) / 256, nslots = M * vpt;
-    const bool writer = blockIdx.x == 0 && blockIdx.y == 0 && n.resid_out != nullptr;
-    float s_run = 0.f; int r_run = 0;
-    auto flush = [&]() { const float t = wave_sum(s_run); if (lane == 0) red[wave][r_run] = t; };
-    constexpr int G = 4;
-    for (int s0 = 0; s0 < nslots; s0 += G) {
-        uint4 a[G], b[G];
-#pragma unroll
-        for (int u = 0; u < G; ++u) {
-            const int sl = s0 + u, r = sl / vpt, e = ((sl - r * vpt) * 256 + tid) * 8;
-            const bool ok = sl < nslots && e < d;
-            a[u] = ok ? *reinterpret_cast<const uint4*>(n.resid + (size_t)r * d + e) : make_uint4(0, 0, 0, 0);
-            b[u] = (ok && n.delta != nullptr) ? *reinterpret_cast<const uint4*>(n.delta + (size_t)r * d + e) : make_uint4(0, 0, 0, 0);
-        }
-#pragma unroll
-        for (int u = 0; u < G; ++u) {
-            const int sl = s0 + u;
-            if (sl >= nslots) break;
-            const int r = sl / vpt, e = ((sl - r * vpt) * 256 + tid) * 8;
-            if (r != r_run) { flush(); s_run = 0.f; r_run = r; }
-            if (e < d) {
-                uint4 h = a[u];
-                if (n.delta != nullptr) {
-                    h.x = pack(lo(h.x) + lo(b[u].x), hi(h.x) + hi(b[u].x)); h.y = pack(lo(h.y) + lo(b[u].y), hi(h.y) + hi(b[u].y));
-                    h.z = pack(lo(h.z) + lo(b[u].z), hi(h.z) + hi(b[u].z)); h.w = pack(lo(h.w) + lo(b[u].w), hi(h.w) + hi(b[u].w));
-                }
-                if (writer) *reinterpret_cast<uint4*>(n.resid_out + (size_t)r * d + e) = h;
-                *reinterpret_cast<uint4*>(ylds + (size_t)r * d + e) = h;
-                float f;
-                f = lo(h.x); s_run += f * f; f = hi(h.x); s_run += f * f; f = lo(h.y); s_run += f * f; f = hi(h.y); s_run += f * f;
-                f = lo(h.z); s_run += f * f; f = hi(h.z); s_run += f * f; f = lo(h.w); s_run += f * f; f = hi(h.w); s_run += f * f;
-            }
-        }
-    }
-    flush();
-    __syncthreads();
-    for (int sl = 0; sl < nslots; ++sl) {
-        const int r = sl / vpt, e = ((sl - r * vpt) * 256 + tid) * 8;
-        if (e < d) {
-            const float rstd = rsqrtf((red[0][r] + red[1][r] + red[2][r] + red[3][r]) / (float)d + n.eps);
-            const uint4 h = *reinterpret_cast<const uint4*>(ylds + (size_t)r * d + e), g = *reinterpret_cast<const uint4*>(n.w + e);
-            auto nrm = [&](uint32_t hv, uint32_t gv) {
-                float n0 = bf2f(f2bf(lo(hv) * rstd)), n1 = bf2f(f2bf(hi(hv) * rstd));
-                return pack(n0 * lo(gv), n1 * hi(gv));
-            };
-            uint4 o;
-            o.x = nrm(h.x, g.x); o.y = nrm(h.y, g.y); o.z = nrm(h.z, g.z); o.w = nrm(h.w, g.w);
-            *reinterpret_cast<uint4*>(ylds + (size_t)r * d + e) = o;
-        }
-    }
-    __syncthreads();
-}
-
 // ------------------------------------------------------------------ skinny GEMM (weight streaming)
 // Y[M,N] = X[M,K] * W[N,K]^T (+ R[M,N]).  One 256-thread block owns 16 output columns; its 4
 // waves split K four ways and each streams its quarter of the 16 W rows straight into MFMA B
@@ -296,16 +231,13 @@ __device__ __forceinline__ void norm_rows_to_lds(const NormIn& n, int M, int d, 
 // rows) are L2-resident re-reads.  MT = number of 16-row M tiles (M <= 16*MT); the four wave
 // partials are summed through LDS.
 // NW = 4 or 8 waves per block (8: the N <= 8192 projections, whose d/16 column blocks alone would leave one 4-wave block per CU -
-// eight-way K split inside the block, no fp32 slabs for the consumer to sum).  NORM: X = RMSNorm(resid + delta) made in the
-// block's LDS by norm_rows_to_lds (MT = 1, NW = 4 only).
-template <int MT, int NW, bool NORM>
+// eight-way K split inside the block, no fp32 slabs for the consumer to sum).
+template <int MT, int NW>
 __global__ void __launch_bounds__(NW * 64) skinny_gemm_kernel(const uint16_t* __restrict__ X, const uint16_t* __restrict__ W,
                                                              const uint16_t* __restrict__ R, uint16_t* __restrict__ Y,
                                                              float* __restrict__ Yslab, int M, int N, int K, long long ldx,
-                                                             long long ldr, long long ldy, NormIn nin) {
+                                                             long long ldr, long long ldy) {
     __shared__ float part[NW][MT][64][4];
-    __shared__ float red[4][8];
-    extern __shared__ __attribute__((aligned(16))) uint16_t ylds[];
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int n0 = blockIdx.x * 16;
     const int ln = lane & 15, g = lane >> 4;
@@ -316,10 +248,8 @@ __global__ void __launch_bounds__(NW * 64) skinny_gemm_kernel(const uint16_t* __
     const uint16_t* wp = W + (size_t)nrow * K + kbeg + g * 8;
     constexpr int WS = 1;
     const uint16_t* xp[MT];
-    const uint16_t* xl = nullptr;             // NORM: this lane's row in the LDS copy
 #pragma unroll
-    for (int t = 0; t < MT; ++t) { int r = t * 16 + ln; if (r >= M) r = M - 1; xp[t] = NORM ? nullptr : X + (size_t)r * ldx + kbeg + g * 8; }
-    if constexpr (NORM) { int r = ln; if (r >= M) r = M - 1; xl = ylds + (size_t)r * K + kbeg + g * 8; }
+    for (int t = 0; t < MT; ++t) { int r = t * 16 + ln; if (r >= M) r = M - 1; xp[t] = X + (size_t)r * ldx + kbeg + g * 8; }
     f32x4_t acc[MT];
 #pragma unroll
     for (int t = 0; t < MT; ++t) acc[t] = f32x4_t{0.f, 0.f, 0.f, 0.f};
@@ -329,21 +259,15 @@ __global__ void __launch_bounds__(NW * 64) skinny_gemm_kernel(const uint16_t* __
     constexpr int U = 8;
     const int nit = kq / (32 * U);
     bf16x8_t b0[U], a0[U][MT], b1[U], a1[U][MT];
-    auto ldw = [&](bf16x8_t (&b)[U], int kk) {
+    auto ld = [&](bf16x8_t (&b)[U], bf16x8_t (&a)[U][MT], int kk) {
 #pragma unroll
         for (int u = 0; u < U; ++u) b[u] = *reinterpret_cast<const bf16x8_t*>(wp + (size_t)(kk + 32 * u) * WS);
-    };
-    auto ldx_ = [&](bf16x8_t (&a)[U][MT], int kk) {
 #pragma unroll
         for (int u = 0; u < U; ++u)
 #pragma unroll
-            for (int t = 0; t < MT; ++t) {
-                if constexpr (NORM) a[u][t] = *reinterpret_cast<const bf16x8_t*>(xl + kk + 32 * u);
-                else a[u][t] = *reinterpret_cast<const bf16x8_t*>(xp[t] + kk + 32 * u);
-            }
+            for (int t = 0; t < MT; ++t) a[u][t] = *reinterpret_cast<const bf16x8_t*>(xp[t] + kk + 32 * u);
         __builtin_amdgcn_sched_barrier(0);
     };
-    auto ld = [&](bf16x8_t (&b)[U], bf16x8_t (&a)[U][MT], int kk) { ldw(b, kk); ldx_(a, kk); };
     auto mm = [&](const bf16x8_t (&b)[U], const bf16x8_t (&a)[U][MT]) {
 #pragma unroll
         for (int u = 0; u < U; ++u)
@@ -352,11 +276,7 @@ __global__ void __launch_bounds__(NW * 64) skinny_gemm_kernel(const uint16_t* __
         __builtin_amdgcn_sched_barrier(0);
     };
     if constexpr (MT == 1) {
-        if constexpr (NORM) {               // W first: the norm's loads and its two barriers sit inside that round trip
-            if (nit > 0) ldw(b0, 0);
-            norm_rows_to_lds(nin, M, K, ylds, red);
-            if (nit > 0) ldx_(a0, 0);
-        } else if (nit > 0) ld(b0, a0, 0);
+        if (nit > 0) ld(b0, a0, 0);
         int it = 0;
         for (; it + 2 <= nit; it += 2) {
             ld(b1, a1, (it + 1) * 32 * U);
@@ -373,8 +293,7 @@ __global__ void __launch_bounds__(NW * 64) skinny_gemm_kernel(const uint16_t* __
         bf16x8_t b = *reinterpret_cast<const bf16x8_t*>(wp + (size_t)k * WS);
 #pragma unroll
         for (int t = 0; t < MT; ++t) {
-            bf16x8_t a;
-            if constexpr (NORM) a = *reinterpret_cast<const bf16x8_t*>(xl + k); else a = *reinterpret_cast<const bf16x8_t*>(xp[t] + k);
+            bf16x8_t a = *reinterpret_cast<const bf16x8_t*>(xp[t] + k);
             acc[t] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a, b, acc[t], 0, 0, 0);
         }
     }
@@ -405,12 +324,9 @@ __global__ void __launch_bounds__(NW * 64) skinny_gemm_kernel(const uint16_t* __
 // (B-fragment lanes ln < 8 -> row f0 + ln) and the 8 matching up columns (ln >= 8 -> row F + f0 + ln - 8), so the
 // epilogue finds gate and up of one feature in the same LDS tile: no [M, 2F] round trip and no silu_mul launch.
 // Rounding as the unfused pair: gate, up -> bf16; silu(gate) -> bf16; product -> bf16.
-template <bool NORM>
 __global__ void __launch_bounds__(256) skinny_swiglu_kernel(const uint16_t* __restrict__ X, const uint16_t* __restrict__ W,
-                                                            uint16_t* __restrict__ A, int M, int F, int K, long long ldx, NormIn nin) {
+                                                            uint16_t* __restrict__ A, int M, int F, int K, long long ldx) {
     __shared__ float part[4][64][4];
-    __shared__ float red[4][8];
-    extern __shared__ __attribute__((aligned(16))) uint16_t ylds[];
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int f0 = blockIdx.x * 8;
     const int ln = lane & 15, g = lane >> 4;
@@ -419,35 +335,24 @@ __global__ void __launch_bounds__(256) skinny_swiglu_kernel(const uint16_t* __re
     const uint16_t* wp = W + ((size_t)(ln < 8 ? 0 : F) + f) * K + kbeg + g * 8;
     constexpr int WS = 1;
     int r = ln; if (r >= M) r = M - 1;
-    const uint16_t* xp = NORM ? nullptr : X + (size_t)r * ldx + kbeg + g * 8;
-    const uint16_t* xl = NORM ? ylds + (size_t)r * K + kbeg + g * 8 : nullptr;
+    const uint16_t* xp = X + (size_t)r * ldx + kbeg + g * 8;
     f32x4_t acc = f32x4_t{0.f, 0.f, 0.f, 0.f};
     constexpr int U = 8;             // two register stages, as in skinny_gemm_kernel
     const int nit = kq / (32 * U);
     bf16x8_t b0[U], a0[U], b1[U], a1[U];
-    auto ldw = [&](bf16x8_t (&b)[U], int kk) {
+    auto ld = [&](bf16x8_t (&b)[U], bf16x8_t (&a)[U], int kk) {
 #pragma unroll
         for (int u = 0; u < U; ++u) b[u] = *reinterpret_cast<const bf16x8_t*>(wp + (size_t)(kk + 32 * u) * WS);
-    };
-    auto ldx_ = [&](bf16x8_t (&a)[U], int kk) {
 #pragma unroll
-        for (int u = 0; u < U; ++u) {
-            if constexpr (NORM) a[u] = *reinterpret_cast<const bf16x8_t*>(xl + kk + 32 * u);
-            else a[u] = *reinterpret_cast<const bf16x8_t*>(xp + kk + 32 * u);
-        }
+        for (int u = 0; u < U; ++u) a[u] = *reinterpret_cast<const bf16x8_t*>(xp + kk + 32 * u);
         __builtin_amdgcn_sched_barrier(0);
     };
-    auto ld = [&](bf16x8_t (&b)[U], bf16x8_t (&a)[U], int kk) { ldw(b, kk); ldx_(a, kk); };
     auto mm = [&](const bf16x8_t (&b)[U], const bf16x8_t (&a)[U]) {
 #pragma unroll
         for (int u = 0; u < U; ++u) acc = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a[u], b[u], acc, 0, 0, 0);
         __builtin_amdgcn_sched_barrier(0);
     };
-    if constexpr (NORM) {
-        if (nit > 0) ldw(b0, 0);
-        norm_rows_to_lds(nin, M, K, ylds, red);
-        if (nit > 0) ldx_(a0, 0);
-    } else if (nit > 0) ld(b0, a0, 0);
+    if (nit > 0) ld(b0, a0, 0);
     int it = 0;
     for (; it + 2 <= nit; it += 2) {
         ld(b1, a1, (it + 1) * 32 * U);
@@ -457,11 +362,9 @@ __global__ void __launch_bounds__(256) skinny_swiglu_kernel(const uint16_t* __re
     }
     if (it < nit) mm(b0, a0);
     int k = nit * 32 * U;
-    for (; k < kq; k += 32) {
-        bf16x8_t a;
-        if constexpr (NORM) a = *reinterpret_cast<const bf16x8_t*>(xl + k); else a = *reinterpret_cast<const bf16x8_t*>(xp + k);
-        acc = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a, *reinterpret_cast<const bf16x8_t*>(wp + (size_t)k * WS), acc, 0, 0, 0);
-    }
+    for (; k < kq; k += 32)
+        acc = __builtin_amdgcn_mfma_f32_16x16x32_bf16(*reinterpret_cast<const bf16x8_t*>(xp + k),
+                                                      *reinterpret_cast<const bf16x8_t*>(wp + (size_t)k * WS), acc, 0, 0, 0);
 #pragma unroll
     for (int rr = 0; rr < 4; ++rr) part[wave][lane][rr] = acc[rr];
     __syncthreads();
@@ -1030,8 +933,7 @@ static int skinny_gemm_launch(const void* X, const void* W, const void* R, void*
     hipStream_t st = (hipStream_t)stream;
     dim3 grid((N + 15) / 16, n_split);
     auto x = (const uint16_t*)X; auto w = (const uint16_t*)W; auto r = (const uint16_t*)R; auto y = (uint16_t*)Y;
-    const NormIn none{nullptr, nullptr, nullptr, nullptr, 0.f};
-#define VDD_SKINNY(MT, NW) hipLaunchKernelGGL((skinny_gemm_kernel<MT, NW, false>), grid, dim3(NW * 64), 0, st, x, w, r, y, Y_slabs, M, N, K, (long long)ldx, (long long)ldr, (long long)ldy, none)
+#define VDD_SKINNY(MT, NW) hipLaunchKernelGGL((skinny_gemm_kernel<MT, NW>), grid, dim3(NW * 64), 0, st, x, w, r, y, Y_slabs, M, N, K, (long long)ldx, (long long)ldr, (long long)ldy)
     // few column blocks (N = d projections): eight waves per block split K eight ways instead of fp32 slabs across blocks
     if (M <= 16 && n_split == 1 && N <= 8192 && K % 256 == 0) VDD_SKINNY(1, 8);
     else if (M <= 16) VDD_SKINNY(1, 4); else if (M <= 32) VDD_SKINNY(2, 4); else VDD_SKINNY(4, 4);
@@ -1047,39 +949,13 @@ int vdd_skinny_gemm(const void* X, const void* W, const void* R, void* Y, float*
 static int skinny_swiglu_launch(const void* X, const void* W, void* act, int M, int F, int K, int64_t ldx, void* stream) {
     if (M <= 0 || F <= 0) return VDD_OK;
     if (!X || !W || !act || M > 16 || K % 128 != 0 || (ldx % 8) != 0) return VDD_ERR_INVALID_ARG;
-    const NormIn none{nullptr, nullptr, nullptr, nullptr, 0.f};
-    hipLaunchKernelGGL(skinny_swiglu_kernel<false>, dim3((F + 7) / 8), dim3(256), 0, (hipStream_t)stream, (const uint16_t*)X,
-                            (const uint16_t*)W, (uint16_t*)act, M, F, K, (long long)ldx, none);
+    hipLaunchKernelGGL(skinny_swiglu_kernel, dim3((F + 7) / 8), dim3(256), 0, (hipStream_t)stream, (const uint16_t*)X,
+                            (const uint16_t*)W, (uint16_t*)act, M, F, K, (long long)ldx);
     return ok(hipSuccess);
 }
 
 int vdd_skinny_swiglu(const void* X, const void* W_gate_up, void* act, int M, int F, int K, int64_t ldx, void* stream) {
     return skinny_swiglu_launch(X, W_gate_up, act, M, F, K, ldx, stream);
-}
-
-static bool norm_args_ok(const void* resid, const void* norm_w, const void* resid_out, int M, int K) {
-    return resid && norm_w && resid_out != resid && M >= 1 && M <= 8 && K % 128 == 0 && K <= 8192 && (size_t)M * K * 2 <= 65536;
-}
-
-int vdd_skinny_norm_gemm(const void* resid, const void* delta, const void* norm_w, float eps, void* resid_out, const void* W, void* Y,
-                         int M, int N, int K, int64_t ldy, void* stream) {
-    if (M <= 0 || N <= 0) return VDD_OK;
-    if (!W || !Y || !norm_args_ok(resid, norm_w, resid_out, M, K)) return VDD_ERR_INVALID_ARG;
-    const NormIn nin{(const uint16_t*)resid, (const uint16_t*)delta, (const uint16_t*)norm_w, (uint16_t*)resid_out, eps};
-    hipLaunchKernelGGL((skinny_gemm_kernel<1, 4, true>), dim3((N + 15) / 16, 1), dim3(256), (size_t)M * K * 2, (hipStream_t)stream,
-                       (const uint16_t*)nullptr, (const uint16_t*)W, (const uint16_t*)nullptr, (uint16_t*)Y, (float*)nullptr, M, N, K,
-                       (long long)K, 0ll, (long long)ldy, nin);
-    return ok(hipSuccess);
-}
-
-int vdd_skinny_norm_swiglu(const void* resid, const void* delta, const void* norm_w, float eps, void* resid_out, const void* W_gate_up,
-                           void* act, int M, int F, int K, void* stream) {
-    if (M <= 0 || F <= 0) return VDD_OK;
-    if (!W_gate_up || !act || !norm_args_ok(resid, norm_w, resid_out, M, K)) return VDD_ERR_INVALID_ARG;
-    const NormIn nin{(const uint16_t*)resid, (const uint16_t*)delta, (const uint16_t*)norm_w, (uint16_t*)resid_out, eps};
-    hipLaunchKernelGGL(skinny_swiglu_kernel<true>, dim3((F + 7) / 8), dim3(256), (size_t)M * K * 2, (hipStream_t)stream,
-                       (const uint16_t*)nullptr, (const uint16_t*)W_gate_up, (uint16_t*)act, M, F, K, (long long)K, nin);
-    return ok(hipSuccess);
 }
 
 int vdd_decode_attention(const void* q, const void* k_cache, const void* v_cache, const void* k_prefix, const void* v_prefix,

@@ -437,25 +437,13 @@ class LanguageModel:
         H, Hkv, D = c.n_heads, c.n_kv_heads, c.head_dim
         resid = ops.embed(tokens, t["embed"])
         delta = None
-        # a few rows (one question in flight): both RMSNorms of a layer run as the prologue of the weight-streaming kernel they
-        # feed - 5 launches per layer instead of 7; the residual stream ping-pongs between two buffers (the blocks of a fused
-        # launch read the old one while one of them writes the new one)
-        fuse_norm = ops.norm_fusable(tokens.shape[0], c.d)
-        spare = torch.empty_like(resid) if fuse_norm else None
         for i in range(c.n_layers):
             p = f"l{i}."
-            if fuse_norm:
-                qkv = ops.norm_linear(resid, delta, t[p + "ln1"], c.eps, t[p + "wqkv"], resid_out=spare if delta is not None else None)
-                if delta is not None:
-                    resid, spare = spare, resid
-                if c.qkv_bias:
-                    qkv = ops.bias_act(qkv, t[p + "bqkv_lm"], out=qkv)
+            if delta is None:
+                a = ops.rmsnorm(resid, t[p + "ln1"], c.eps)
             else:
-                if delta is None:
-                    a = ops.rmsnorm(resid, t[p + "ln1"], c.eps)
-                else:
-                    a = ops.rmsnorm(resid, t[p + "ln1"], c.eps, delta=delta, resid_out=resid)
-                qkv = ops.linear(a, t[p + "wqkv"], bias=t[p + "bqkv_lm"] if c.qkv_bias else None)
+                a = ops.rmsnorm(resid, t[p + "ln1"], c.eps, delta=delta, resid_out=resid)
+            qkv = ops.linear(a, t[p + "wqkv"], bias=t[p + "bqkv_lm"] if c.qkv_bias else None)
             if grouping is None and tokens.shape[0] <= ops.FUSED_ATTN_MAX_M and D == 128:
                 # a few rows (one question in flight): RoPE + KV write + attention + merge in one launch
                 att = ops.decode_attention_fused(qkv, pos, cpos, slot, self.cs, kv.ko[i], kv.vo[i], attn_rows, H, Hkv, D,
@@ -471,13 +459,8 @@ class LanguageModel:
                 att = ops.decode_attention(q, kv.ko[i], kv.vo[i], attn_rows, H, Hkv, D, k_prefix=kv.kp[i], v_prefix=kv.vp[i],
                                            max_len=kv.t_pre + kv.t_own, workspace=workspace)
             o = ops.linear_to_norm(att, t[p + "wo"])
-            if fuse_norm and o.dtype == torch.bfloat16:
-                act = ops.norm_swiglu_linear(resid, o, t[p + "ln2"], c.eps, t[p + "wgu"], resid_out=spare)
-                resid, spare = spare, resid
-            else:
-                a = ops.rmsnorm(resid, t[p + "ln2"], c.eps, delta=o, resid_out=resid)
-                act = ops.swiglu_linear(a, t[p + "wgu"])
-            delta = ops.linear_to_norm(act, t[p + "wd"])
+            a = ops.rmsnorm(resid, t[p + "ln2"], c.eps, delta=o, resid_out=resid)
+            delta = ops.linear_to_norm(ops.swiglu_linear(a, t[p + "wgu"]), t[p + "wd"])
         a = ops.rmsnorm(resid, t["norm"], c.eps, delta=delta)
         return ops.linear(a, t["lm_head"])
 

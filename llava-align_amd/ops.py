@@ -14,8 +14,6 @@ _P, _I, _L, _F = C.c_void_p, C.c_int, C.c_int64, C.c_float
 _SIGS = {
     "vdd_embed_scatter": [_P, _P, _P, _P, _I, _I, _I, _P],
     "vdd_skinny_swiglu": [_P, _P, _P, _I, _I, _I, _L, _P],
-    "vdd_skinny_norm_gemm": [_P, _P, _P, _F, _P, _P, _P, _I, _I, _I, _L, _P],
-    "vdd_skinny_norm_swiglu": [_P, _P, _P, _F, _P, _P, _P, _I, _I, _I, _P],
     "vdd_decode_attention_fused": [_P] * 11 + [_I, _I, _I, _I, _L, _I, _L, _I, _F, _P],
     "vdd_rmsnorm": [_P, _P, _P, _I, _P, _P, _P, _I, _I, _F, _P],
     "vdd_gemm": [_P, _P, _P, _P, _P, _I, _I, _I, _L, _L, _L, _L, _I, _I, _P, _L, _P],
@@ -149,39 +147,7 @@ def linear_to_norm(x, w):
     return linear(x, w)
 
 
-def norm_fusable(M, d):
-    """Can the RMSNorm run as the prologue of the weight-streaming kernel that consumes it?  (vdd_skinny_norm_gemm)"""
-    return M <= SKINNY_MAX_M and d % 128 == 0 and d <= 8192 and M * d * 2 <= 65536
-
-
-def norm_linear(resid, delta, norm_w, eps, w, resid_out=None, out=None):
-    """rmsnorm(resid + delta) @ w^T in one launch (a few rows); resid_out <- resid + delta, must be another buffer than resid."""
-    _bf16(resid, delta, norm_w, w, resid_out)
-    M, d = resid.shape
-    if not norm_fusable(M, d) or w.shape[1] != d or (resid_out is not None and resid_out.data_ptr() == resid.data_ptr()):
-        raise ValueError("norm_linear: up to 8 contiguous rows of d <= 8192, resid_out distinct from resid")
-    out = torch.empty(M, w.shape[0], dtype=resid.dtype, device=resid.device) if out is None else out
-    _lib.check(_lib_ready().vdd_skinny_norm_gemm(resid.data_ptr(), delta.data_ptr() if delta is not None else None, norm_w.data_ptr(),
-                                                 eps, resid_out.data_ptr() if resid_out is not None else None,
-                                                 w.data_ptr(), out.data_ptr(), M, w.shape[0], d, out.stride(0), _st(resid)))
-    return out
-
-
-def norm_swiglu_linear(resid, delta, norm_w, eps, w_gate_up, resid_out=None, out=None):
-    """silu(x Wg^T) * (x Wu^T) for x = rmsnorm(resid + delta), one launch (a few rows); resid_out as in norm_linear."""
-    _bf16(resid, delta, norm_w, w_gate_up, resid_out)
-    M, d = resid.shape
-    F = w_gate_up.shape[0] // 2
-    if not norm_fusable(M, d) or w_gate_up.shape[1] != d or (resid_out is not None and resid_out.data_ptr() == resid.data_ptr()):
-        raise ValueError("norm_swiglu_linear: up to 8 contiguous rows of d <= 8192, resid_out distinct from resid")
-    out = torch.empty(M, F, dtype=resid.dtype, device=resid.device) if out is None else out
-    _lib.check(_lib_ready().vdd_skinny_norm_swiglu(resid.data_ptr(), delta.data_ptr() if delta is not None else None, norm_w.data_ptr(),
-                                                   eps, resid_out.data_ptr() if resid_out is not None else None,
-                                                   w_gate_up.data_ptr(), out.data_ptr(), M, F, d, _st(resid)))
-    return out
-
-
-SKINNY_MAX_M = 8      # up to here every projection is a weight-streaming kernel and the RMSNorms run as their prologues
+SKINNY_MAX_M = 8      # up to here every projection is a weight-streaming kernel
 
 
 def skinny_rows(N, K):

@@ -112,30 +112,6 @@ def test_skinny_gemm(M, N, K):
     assert (y3.float() - big[:, :K].float() @ w.float().t()).abs().max().item() <= tol
 
 
-@pytest.mark.parametrize("M,d,N,F", [(2, 4096, 12288, 11008), (3, 5120, 15360, 13824), (1, 4096, 4096, 11008), (8, 4096, 12288, 1376),
-                                     (2, 256, 768, 688), (5, 1280, 384, 3424)])
-def test_rmsnorm_as_the_prologue_of_the_weight_streaming_kernels(M, d, N, F):
-    """vdd_skinny_norm_gemm / vdd_skinny_norm_swiglu against vdd_rmsnorm + vdd_skinny_gemm / vdd_skinny_swiglu: the same bits,
-    for the projection, for the activation and for the updated residual stream; with and without a delta; d = 5120 has a ragged
-    last element chunk per row (640 = 2.5 x 256 threads)."""
-    O = ops()
-    resid, delta, nw = bf(M, d, seed=21), bf(M, d, scale=0.3, seed=22), bf(d, seed=23)
-    w, wgu = bf(N, d, scale=0.02, seed=24), bf(2 * F, d, scale=0.02, seed=25)
-    for dl in (delta, None):
-        r_ref = torch.empty_like(resid)
-        a = O.rmsnorm(resid, nw, 1e-5, delta=dl, resid_out=r_ref if dl is not None else None)
-        want, want_act = O.skinny_gemm(a, w), O.swiglu_linear(a, wgu)
-        r1, r2 = torch.full_like(resid, 7.0), torch.full_like(resid, 7.0)
-        got = O.norm_linear(resid, dl, nw, 1e-5, w, resid_out=r1 if dl is not None else None)
-        got_act = O.norm_swiglu_linear(resid, dl, nw, 1e-5, wgu, resid_out=r2 if dl is not None else None)
-        assert torch.equal(got.view(torch.int16), want.view(torch.int16))
-        assert torch.equal(got_act.view(torch.int16), want_act.view(torch.int16))
-        if dl is not None:
-            assert torch.equal(r1.view(torch.int16), r_ref.view(torch.int16)) and torch.equal(r2.view(torch.int16), r_ref.view(torch.int16))
-    with pytest.raises(ValueError):
-        O.norm_linear(resid, delta, nw, 1e-5, w, resid_out=resid)          # in place: the other blocks still read resid
-
-
 def test_skinny_gemm_eight_wave_blocks_for_narrow_outputs():
     """N <= 8192 without slabs: eight waves per block split K eight ways (o / down projections of one question in flight);
     same result up to the summation order as the four-wave kernel on a wider N made of the same rows."""
