@@ -1,4 +1,5 @@
-"""Plain-PyTorch fp32 restatement of the InstructBLIP front-end as LAVIS computes it (test infrastructure only):
+"""Plain-PyTorch fp32 restatement of the InstructBLIP front-end as LAVIS computes it (test infrastructure only; PINNED to outputs
+of the reference's own LAVIS modules by tests/test_blip_golden.py / tests/golden/make_blip_golden.py):
 EVA-ViT (lavis/models/eva_vit.py:64-342: pre-LN blocks, qkv bias = (q_bias, 0, v_bias), absolute position embedding, no final norm)
 -> ln_vision -> Q-Former BertModel with query_embeds + text (blip2_models/Qformer.py:51-108 embeddings, :378-484 layers: joint
 self-attention over [queries ; text] under the padding mask, cross-attention of the queries to the image every cross_freq
@@ -47,13 +48,15 @@ def qformer(sd, cfg, image_embeds, text_ids):
     q = cfg.qf
     w = lambda k: sd[k].float()
     n = image_embeds.shape[0]
+    if text_ids is None:                                  # qformer_text_input=False (blip2_vicuna_instruct.py:358-363): queries only
+        text_ids = [[] for _ in range(n)]
     lens = [len(r) for r in text_ids]
     L = max(lens)
     ids = torch.zeros(n, L, dtype=torch.long, device=image_embeds.device)
     mask = torch.zeros(n, q.n_query + L, device=image_embeds.device)
     mask[:, : q.n_query] = 1
     for i, r in enumerate(text_ids):
-        ids[i, : len(r)] = torch.tensor(list(r))
+        ids[i, : len(r)] = torch.tensor(list(r), dtype=torch.long)
         mask[i, q.n_query: q.n_query + len(r)] = 1
     e = "Qformer.bert.embeddings."
     emb = w(e + "word_embeddings.weight")[ids] + w(e + "position_embeddings.weight")[torch.arange(L, device=ids.device)][None]

@@ -59,3 +59,44 @@ def test_front_end_feeds_vcd_decoding_of_the_engine(front):
     assert out.tokens.shape == (3, 5) and all(torch.isfinite(s).any(-1).all() for s in out.scores)
     # step 0 is contrasted against the noisy-image branch (masked entries appear), later steps have c == v
     assert torch.isinf(out.scores[0]).any() and not torch.isinf(plain.scores[0]).any()
+
+
+# ---- against OUTPUTS OF THE REFERENCE'S LAVIS MODULES (tests/golden/blip_vectors.npz, see tests/test_blip_golden.py), at the tiny
+# size and at the published EVA-ViT-g / Q-Former widths (1408 = 16 x 88 padded to 128-wide heads, MLP 6144, 257 tokens; 768 = 12 x 64,
+# FFN 3072, 32 queries, vocabulary 30523; 2 + 3 layers)
+import os
+
+import numpy as np
+
+from blip_weights import blip_inputs, blip_state_dict, cases
+
+GOLD = np.load(os.path.join(os.path.dirname(__file__), "golden", "blip_vectors.npz"))
+
+
+@pytest.mark.parametrize("name", list(cases()))
+def test_front_end_matches_the_lavis_fixture(name):
+    from llava_align_amd.blip_frontend import BlipWeights, InstructBlipFrontEnd
+    mk, wseed, iseed, n = cases()[name]
+    cfg = mk()
+    sd = blip_state_dict(cfg, wseed)
+    imgs, text = blip_inputs(cfg, iseed, n)
+    fe = InstructBlipFrontEnd(BlipWeights.from_state_dict(cfg, sd, DEV))
+
+    def check(got, want, what, rel=0.04):
+        want = torch.from_numpy(np.asarray(want)).to(got.device)
+        err, scale = (got.float() - want).abs().max().item(), want.abs().max().item()
+        assert cos(got, want) > 0.9995 and err <= rel * scale, (what, cos(got, want), err, scale)
+
+    ie = fe.image_embeds(imgs.to(DEV))
+    assert tuple(ie.shape) == (n, cfg.vit.n_tokens, cfg.vit.width)
+    check(ie[:, [0, 1, -1]], GOLD[f"{name}.image_embeds_rows"], "image_embeds rows")
+    want_abs = torch.from_numpy(GOLD[f"{name}.image_embeds_rowabs"]).to(DEV)
+    assert ((ie.float().abs().sum(-1) - want_abs).abs() <= 0.01 * want_abs).all()              # every token row, via its L1 norm
+    hq = fe.qformer(ie, text)
+    check(hq, GOLD[f"{name}.query_out"], "query_out")
+    check(fe.qformer(ie, None), GOLD[f"{name}.query_out_notext"], "query_out_notext")
+    il = fe.inputs_llm(imgs.to(DEV), text)
+    assert tuple(il.shape) == (n, cfg.qf.n_query, cfg.d_llm)
+    check(il[:, :, :64], GOLD[f"{name}.inputs_llm_head"], "inputs_llm head")
+    want_abs = torch.from_numpy(GOLD[f"{name}.inputs_llm_rowabs"]).to(DEV)
+    assert ((il.float().abs().sum(-1) - want_abs).abs() <= 0.02 * want_abs).all()
