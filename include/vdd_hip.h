@@ -28,7 +28,7 @@
 extern "C" {
 #endif
 
-#define VDD_ABI_VERSION 1
+#define VDD_ABI_VERSION 2
 
 typedef enum vdd_status {
     VDD_OK = 0,
@@ -96,10 +96,39 @@ typedef struct vdd_sample_params {
     int64_t stride_workspace;
     const uint64_t* philox_offset_ptr;   /* optional device counter ADDED to philox_offset at run time, so a launch
                                             captured in a HIP graph draws fresh numbers on every replay */
+    /* ---- logits-processor stage: runs where vcd_sample.py:197 calls `logits_processor(input_ids, scores)`, i.e. after the
+     *      contrast + plausibility mask (or on the raw logits of the plain path, :204) and BEFORE the warpers ---- */
+    const int32_t* eos_min_step; /* optional [B]: while (step + *step_ptr) < eos_min_step[row] every id of eos_ids scores -inf:
+                                    HF MinNewTokensLengthLogitsProcessor (min_new_tokens, run_qwen.py:194) and
+                                    MinLengthLogitsProcessor (min_length - prompt_length, blip2_vicuna_instruct.py:397) */
+    int64_t step;                /* new tokens this row set has produced so far (0 at the prefill step) */
+    const int64_t* step_ptr;     /* optional device counter ADDED to step at run time (graph replay) */
+    const int32_t* force_eos;    /* optional [B] flags: where non-zero, scores[row, force_eos_id] = force_eos_value - the Qwen
+                                    StopWordsLogitsProcessor (qwen_generation_utils.py:352-359; flags from vdd_stop_words_match);
+                                    applied after eos_min_step, as HF orders custom processors behind its own */
+    int64_t force_eos_id;
+    double force_eos_value;      /* the reference uses float(2**15) */
 } vdd_sample_params;
 
 /* Fused per-step contrastive sampling tail; one launch for all B rows. */
 int vdd_contrast_sample(const vdd_sample_params* p, void* hip_stream);
+
+/* Stop-sequence matcher of the Qwen StopWordsLogitsProcessor (qwen_generation_utils.py:361-385): force_out[row] = 1 iff the ids of
+ * the row so far END with one of the stop sequences.  The ids of a row are its prompt tail (prompt_tail [B, tail_len] int64, the
+ * LAST tail_len prompt tokens, left-padded with -1) followed by its (step + *step_ptr) generated tokens gen[row * ld_gen + 0..].
+ * stop_flat / stop_off: the n_stop sequences back to back and their offsets (n_stop + 1 entries).  One thread per row. */
+int vdd_stop_words_match(const int64_t* gen, int64_t ld_gen, int64_t step, const int64_t* step_ptr, const int64_t* prompt_tail,
+                         int tail_len, const int64_t* stop_flat, const int32_t* stop_off, int n_stop, int32_t* force_out, int B,
+                         void* hip_stream);
+
+/* HF RepetitionPenaltyLogitsProcessor on a [B, V] scores matrix in place (blip2_vicuna_instruct.py:400 passes repetition_penalty):
+ * for every DISTINCT id in the row's history (prompt_ids [B, prompt_len] int64, -1 = padding, then (step + *step_ptr) generated
+ * tokens of gen) score = score < 0 ? score * penalty : score / penalty, computed from the un-penalised value and rounded in
+ * `dtype`.  flags & VDD_TEMP_RECIPROCAL: the division as a multiply by fl32(1 / penalty) (torch-GPU), else a true division
+ * (torch-CPU).  History length (prompt_len + step) <= 8192. */
+int vdd_repetition_penalty(void* scores, int64_t stride, int dtype, int B, int V, const int64_t* prompt_ids, int prompt_len,
+                           const int64_t* gen, int64_t ld_gen, int64_t step, const int64_t* step_ptr, float penalty,
+                           uint32_t flags, void* hip_stream);
 
 /* VCD branch input: x_t = sqrt(abar_t) x_0 + sqrt(1-abar_t) eps   (vcd_utils/vcd_add_noise.py:18-22).
  * x, y: n elements of `dtype` (may alias).  eps: optional explicit fp32 noise [n]; NULL draws

@@ -6,7 +6,7 @@ import ctypes as C
 import os
 
 PKG = os.path.dirname(os.path.abspath(__file__))
-ABI_VERSION = 1
+ABI_VERSION = 2
 
 VDD_F32, VDD_F16, VDD_BF16 = 0, 1, 2
 PICK_ARGMAX, CUTOFF_F32_SCALAR, TEMP_RECIPROCAL, NO_SAMPLE, TOPP_FP32_MASS = 1, 2, 4, 8, 16
@@ -35,6 +35,8 @@ class VddSampleParams(C.Structure):
         ("row_status", C.c_void_p),
         ("workspace", C.c_void_p), ("stride_workspace", C.c_int64),
         ("philox_offset_ptr", C.c_void_p),
+        ("eos_min_step", C.c_void_p), ("step", C.c_int64), ("step_ptr", C.c_void_p),
+        ("force_eos", C.c_void_p), ("force_eos_id", C.c_int64), ("force_eos_value", C.c_double),
     ]
 
 

@@ -114,6 +114,11 @@ struct KP {
     float* top_prob; long long* top_tok;
     int* status;
     int vec_in, vec_out, vec_work;   // 16-B aligned fast paths usable
+    // logits-processor stage between contrast and warp (vcd_sample.py:197)
+    const int* eos_min;              // [B] or null: eos ids -> -inf while step < eos_min[row]
+    long long step; const long long* step_ptr;
+    const int* force;                // [B] or null: scores[row, force_id] = force_val where force[row] != 0
+    long long force_id; float force_val;
 };
 
 // ------------------------------------------------------------------ block collectives
@@ -445,6 +450,18 @@ __global__ void __launch_bounds__(BLOCK, 6) vdd_contrast_sample_kernel(KP p) {
     // (measured: 2.7 us per row for the mass pass alone, the passes after the scores store were 1/3 of the kernel), so
     // the passes of the sampling tail walk only the flagged chunks.  Chunks past bit 63 (V > 2^19) count as flagged.
     unsigned long long livemask = 0ull;
+    // Logits-processor stage (vcd_sample.py:197, between contrast and warp), block-uniform per row:
+    //   bit 0  every eos id -> -inf  (HF MinLength / MinNewTokensLength processors: the row has not produced enough tokens yet)
+    //   bit 1  scores[force_id] = force_val (Qwen StopWordsLogitsProcessor, qwen_generation_utils.py:352-359: a stop sequence
+    //          matched; applied AFTER bit 0 as in HF's processor order: defaults first, custom processors last)
+    int proc = 0;
+    if (p.eos_min != nullptr && p.n_eos > 0) {
+        const long long s_now = p.step + (p.step_ptr ? *p.step_ptr : 0ll);
+        proc |= (s_now < (long long)p.eos_min[row]) ? 1 : 0;
+    }
+    if (p.force != nullptr && p.force[row] != 0) proc |= 2;
+    const int force_ch = (proc & 2) ? (int)(p.force_id / EPC) : -1;
+    auto is_eos = [&](int idx) { bool e = false; for (int q = 0; q < p.n_eos; ++q) e |= (long long)idx == p.eos[q]; return e; };
 
     if (p.c != nullptr) {
         // ---- pass A: v -> working row, row max (vcd_sample.py:191) --------------------
@@ -494,8 +511,12 @@ __global__ void __launch_bounds__(BLOCK, 6) vdd_contrast_sample_kernel(KP p) {
                 float a = rnd<DT>(__fmul_rn(vf, p.s1));
                 float b = rnd<DT>(__fmul_rn(cf, p.s2));
                 float x = rnd<DT>(__fsub_rn(a, b));                                           // :193
+                bool masked = (vf < cutoff) || (idx >= V);                                    // :194
+                if (proc) {                                                                   // :197 logits_processor
+                    if ((proc & 1) && is_eos(idx)) masked = true;
+                    if ((proc & 2) && (long long)idx == p.force_id) { x = rnd<DT>(p.force_val); masked = false; }
+                }
                 if (p.use_temp) x = rnd<DT>(recip ? __fmul_rn(x, p.inv_temp) : __fdiv_rn(x, p.temp));   // HF temperature
-                const bool masked = (vf < cutoff) || (idx >= V);                              // :194
                 if (!masked) {
                     setb<DT>(x4, j, Tr<DT>::from_f(x));
                     nfin += 1; m = fmaxf(m, x); t_nan |= (x != x) ? 1 : 0; t_pinf |= (x == INFINITY) ? 1 : 0;
@@ -531,6 +552,7 @@ __global__ void __launch_bounds__(BLOCK, 6) vdd_contrast_sample_kernel(KP p) {
                         float vf = Tr<DT>::to_f(getb<DT>(qv[u], j));
                         live |= !(vf < cutoff) && (ch * EPC + j < V);
                     }
+                    live |= ch == force_ch;
                     if (!live) { if (!sparse) R.put(ch, ninf4); continue; }
                     if (kb + u < 64) livemask |= 1ull << (kb + u);
                     const unsigned slot = atomicAdd(&sm.live_n, 1u);
@@ -593,6 +615,10 @@ __global__ void __launch_bounds__(BLOCK, 6) vdd_contrast_sample_kernel(KP p) {
                         const int idx = ch * EPC + j;
                         uint32_t b = getb<DT>(q[u], j);
                         float x = Tr<DT>::to_f(b);
+                        if (proc) {                                                           // :204 logits_processor
+                            if ((proc & 1) && is_eos(idx)) { x = -INFINITY; b = NINF; }
+                            if ((proc & 2) && (long long)idx == p.force_id) { x = rnd<DT>(p.force_val); b = Tr<DT>::from_f(x); }
+                        }
                         if (p.use_temp) { x = rnd<DT>(recip ? __fmul_rn(x, p.inv_temp) : __fdiv_rn(x, p.temp)); b = Tr<DT>::from_f(x); }
                         if (idx >= V) b = NINF;
                         setb<DT>(q[u], j, b);
@@ -1228,6 +1254,8 @@ int vdd_contrast_sample(const vdd_sample_params* p, void* hip_stream) {
     if ((p->top_prob == nullptr) != (p->top_tok == nullptr)) return fail(VDD_ERR_INVALID_ARG, "top_prob/top_tok must be given together");
     if (p->n_eos < 0 || (p->n_eos > 0 && !p->eos_ids)) return fail(VDD_ERR_INVALID_ARG, "eos_ids missing");
     if (p->temperature != p->temperature) return fail(VDD_ERR_INVALID_ARG, "temperature is NaN");
+    if (p->eos_min_step && p->n_eos <= 0) return fail(VDD_ERR_INVALID_ARG, "eos_min_step given without eos_ids");
+    if (p->force_eos && (p->force_eos_id < 0 || p->force_eos_id >= p->V)) return fail(VDD_ERR_INVALID_ARG, "force_eos_id outside [0, V)");
 
     const size_t es = esize(p->dtype);
     const int epc = (int)(16 / es);
@@ -1258,6 +1286,8 @@ int vdd_contrast_sample(const vdd_sample_params* p, void* hip_stream) {
     kp.st = p->stride_tokens > 0 ? p->stride_tokens : 1;
     kp.scores = p->scores_out; kp.top_prob = p->top_prob; kp.top_tok = (long long*)p->top_tok;
     kp.status = p->row_status;
+    kp.eos_min = p->eos_min_step; kp.step = p->step; kp.step_ptr = (const long long*)p->step_ptr;
+    kp.force = p->force_eos; kp.force_id = p->force_eos_id; kp.force_val = (float)p->force_eos_value;
     kp.vec_in = al(p->logit_v, p->stride_v) && al(p->logit_cd, p->stride_cd) && al(p->logit_dd, p->stride_dd);
     kp.vec_out = al(p->scores_out, p->stride_scores);
     if (!ldsrow) {

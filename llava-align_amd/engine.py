@@ -515,6 +515,14 @@ class _DecodeRunner:
         self.graph = None
         self._tried = False
         self.grouping = None
+        # logits-processor stage (vcd_sample.py:197): per-row EOS floor, stop-word flags, repetition-penalty history
+        pr = tail.get("proc") or {}
+        self.proc = pr
+        self.eos_min = torch.zeros(Q, **i32) if pr.get("eos_min") else None
+        self.force = torch.zeros(Q, **i32) if pr.get("stop") is not None else None
+        self.prompt_tail = torch.full((Q, pr["stop"].max_len), -1, dtype=torch.long, device=dev) if pr.get("stop") is not None else None
+        self.prompt_ids = (torch.full((Q, max(1, pr["hist_len"])), -1, dtype=torch.long, device=dev)
+                           if (pr.get("rep") is not None or pr.get("python")) else None)
         lm = eng.cfg.lm
         # the step's own partials buffer (also for the ungrouped split-KV pass): a captured graph must not point into a
         # shared buffer that a later, larger call re-allocates
@@ -524,6 +532,48 @@ class _DecodeRunner:
                                  n_groups=tail["n_groups"], items=torch.zeros(max(1, tail["n_items"]), 4, **i32), n_items=tail["n_items"],
                                  cpi=tail.get("cpi", 1),
                                  workspace=self.workspace)
+
+    def set_processor_inputs(self, eos_min=None, prompt_tail=None, prompt_ids=None):
+        """Per-call data of the processor stage into the runner's static buffers (a captured step points at them)."""
+        if self.eos_min is not None:
+            self.eos_min.copy_(eos_min)
+        if self.prompt_tail is not None:
+            self.prompt_tail.copy_(prompt_tail)
+        if self.prompt_ids is not None:
+            self.prompt_ids.fill_(-1)                                   # LEFT-padded with -1, like an HF batch
+            if prompt_ids.shape[1]:
+                self.prompt_ids[:, -prompt_ids.shape[1]:].copy_(prompt_ids)
+
+    def sample_tail(self, v, c, d, out_scores, return_scores, n_top=0, status_out=None, step=0, step_ptr=None):
+        """The reference's per-step tail (vcd_sample.py:185-207) with its `logits_processor` stage: EOS floor and stop-word forcing
+        inside the fused kernel; a repetition penalty or Python processors through the contrast-only / plain split (the scores
+        row is materialised between the two launches, as in the generic loop)."""
+        t, pr = self.tail, self.proc
+        kw = {}
+        if self.eos_min is not None:
+            kw.update(eos_min_step=self.eos_min, step=step, step_ptr=step_ptr)
+        if self.force is not None:
+            ops.stop_words_match(pr["stop"], self.prompt_tail, self.gen, step=step, step_ptr=step_ptr, out=self.force)
+            kw.update(force_eos=self.force, force_eos_id=pr["stop"].eos_token_id)
+        eos_kw = dict(eos_ids=t["eos_t"], pad_id=t["pad"], unfinished=self.unfinished) if t["eos_t"] is not None else {}
+        if pr.get("rep") is not None or pr.get("python"):
+            if c is not None:
+                x = contrast_sample(v, c, d, alpha=t["alpha"], beta=t["beta"], no_sample=True, return_scores=True).scores
+            else:
+                x = v.clone()
+            if pr.get("rep") is not None:
+                from .sampling import GPU_SCALAR_SEMANTICS
+                ops.repetition_penalty_(x, pr["rep"], self.prompt_ids, self.gen, step=step, step_ptr=step_ptr,
+                                        reciprocal=GPU_SCALAR_SEMANTICS)
+            if pr.get("python"):                 # eager only (step is a host integer here): HF-style callables on left-padded ids
+                pad = t["pad"] if t["pad"] is not None else 0
+                ids = torch.cat([torch.where(self.prompt_ids < 0, pad, self.prompt_ids), self.gen[:, :step]], 1)
+                for f in pr["python"]:
+                    x = f(ids, x)
+            v, c, d = x, None, None
+        return contrast_sample(v, c, d, alpha=t["alpha"], beta=t["beta"], warp=t["warp"], out_tokens=self.tok, out_scores=out_scores,
+                               return_scores=return_scores, pick_argmax=t["greedy"], seed=0, offset=0, offset_ptr=self.ctr, n_top=n_top,
+                               status_out=status_out, **eos_kw, **kw)
 
     def reset(self, ctr0):
         self.unfinished.fill_(1)
@@ -561,9 +611,10 @@ class _DecodeRunner:
             else:
                 c = logits[Q:2 * Q]
                 d = logits[2 * Q:3 * Q] if nb == 3 else None
-        eos_kw = dict(eos_ids=t["eos_t"], pad_id=t["pad"], unfinished=self.unfinished) if t["eos_t"] is not None else {}
-        contrast_sample(v, c, d, alpha=t["alpha"], beta=t["beta"], warp=t["warp"], out_tokens=self.tok, out_scores=self.scores_buf,
-                        pick_argmax=t["greedy"], seed=0, offset=0, offset_ptr=self.ctr, status_out=self._st, **eos_kw)
+        if self.proc.get("python"):
+            self.sample_tail(v, c, d, self.scores_buf, False, status_out=self._st, step=int(self.step_idx.item()))
+        else:
+            self.sample_tail(v, c, d, self.scores_buf, False, status_out=self._st, step_ptr=self.step_idx)
         self.status |= self._st
         self.gen.index_copy_(1, self.step_idx, self.tok[:, None])
         self.pos += 1
@@ -577,7 +628,7 @@ class _DecodeRunner:
                 self.status, self._st]
 
     def step(self, kv):
-        if self.graph is None and self.eng.use_graph and not self._tried:
+        if self.graph is None and self.eng.use_graph and not self._tried and not self.proc.get("python"):
             self._tried = True
             saved = [x.clone() for x in self._state()]
             side = torch.cuda.Stream(device=self.eng.device)
@@ -609,6 +660,11 @@ class _DecodeRunner:
 
 class VddLlavaEngine:
     """model.generate()-compatible surface (llava_calibrate.py:161-177) over the native kernels."""
+
+    # generate() kwargs of the reference's drivers that have no effect on this path: KV caching is always on, attention maps /
+    # hidden states are never materialised, masks are implied by the ragged prompts, length_penalty only acts on beam search
+    IGNORED_GENERATE_KWARGS = frozenset({"use_cache", "output_attentions", "output_hidden_states", "attention_mask", "length_penalty",
+                                         "synced_gpus", "streamer", "use_image"})
 
     def __init__(self, cfg: LlavaConfig | str = "llava-1.5-7b", weights: Optional[LlavaWeights] = None, device="cuda:0",
                  seed: int = 0, max_questions: int = 64, t_max: int = 0, use_graph: bool = True, lm_head_gain: float = 1.0):
@@ -707,13 +763,31 @@ class VddLlavaEngine:
                  top_p: Optional[float] = None, top_k: Optional[int] = None, max_new_tokens: int = 64,
                  eos_token_id=None, pad_token_id: Optional[int] = None, output_scores: bool = False,
                  return_dict_in_generate: bool = True, cd_greedy: bool = False, n_top: int = 0, seed: Optional[int] = None,
-                 share_prefix: bool = True, sync_every: int = 8, inputs_embeds=None, **_ignored) -> GenerateOutput:
+                 share_prefix: bool = True, sync_every: int = 8, inputs_embeds=None, min_new_tokens: Optional[int] = None,
+                 min_length: Optional[int] = None, stop_words_ids=None, repetition_penalty: Optional[float] = None,
+                 logits_processor=None, max_length: Optional[int] = None, num_beams: Optional[int] = None,
+                 num_return_sequences: Optional[int] = None, **other) -> GenerateOutput:
         """Same kwargs as the reference's model.generate(...) call (llava_calibrate.py:161-177); `input_ids` is a
         list of 1-D id tensors (one per question, each with one -200 image slot) or a [Q, L] tensor; `images` one
         image per question (repeat the SAME tensor for questions about the same image to share its features and
         prompt-prefix KV).  use_cache / output_attentions are accepted and ignored (attention maps are never
-        materialised: flash-style kernels; the reference only reads them for a commented-out plot, :180-183)."""
+        materialised: flash-style kernels; the reference only reads them for a commented-out plot, :180-183).
+
+        Logits processors (what HF's generate() builds into `logits_processor` for vcd_sample.py:197 / :204, in HF's order):
+        repetition_penalty (blip2_vicuna_instruct.py:400), min_length (:397; counts the prompt, which is EMPTY for inputs_embeds
+        prompts as in HF), min_new_tokens (MME/run_qwen.py:194), stop_words_ids (Qwen, modeling_qwen.py:1061-1075: forces
+        eos_token_id[0] once a stop sequence ends the row), then `logits_processor`: a list of HF-style callables
+        `f(input_ids, scores)` run in eager mode on left-padded ids.  max_length (LAVIS passes it instead of max_new_tokens) =
+        prompt length + new tokens; the prompt length of inputs_embeds prompts is 0.  Beam search / several return sequences are
+        not part of the patched sample() path: refused.  Any other keyword raises TypeError instead of being dropped."""
         dev, lm = self.device, self.cfg.lm
+        unknown = sorted(k for k in other if k not in self.IGNORED_GENERATE_KWARGS)
+        if unknown:
+            raise TypeError(f"generate() got unexpected keyword argument(s) {unknown}: not implemented by VddLlavaEngine "
+                            f"(accepted without effect: {sorted(self.IGNORED_GENERATE_KWARGS)})")
+        if num_beams not in (None, 1) or num_return_sequences not in (None, 1):
+            raise ValueError("num_beams / num_return_sequences > 1: the reference patches sample() only (vcd_sample.py:325-326); "
+                             "beam search never reaches contrastive decoding")
         if inputs_embeds is not None:
             # LAVIS / InstructBLIP call shape (blip2_vicuna_instruct.py:380-410): the prompt arrives as embeddings
             # [T, d] per question (Q-Former output ++ text embeddings) and `images_cd` holds the noisy-image EMBEDDINGS,
@@ -730,6 +804,13 @@ class VddLlavaEngine:
         ids_list = [r for r in input_ids] if torch.is_tensor(input_ids) else list(input_ids)
         ids_list = [r.reshape(-1).tolist() for r in ids_list]
         Q = len(ids_list)
+        prompt_lens = [0] * Q if inputs_embeds is not None else [len(r) for r in ids_list]     # HF's input_ids length per row
+        if max_length is not None:
+            if len(set(prompt_lens)) != 1:
+                raise ValueError("max_length with prompts of different lengths: pass max_new_tokens")
+            max_new_tokens = int(max_length) - prompt_lens[0]
+            if max_new_tokens < 1:
+                raise ValueError(f"max_length {max_length} leaves no room behind a prompt of {prompt_lens[0]} tokens")
         # the vision tower needs nothing of the planning below: its launches go out first, so the host-side validation / planning
         # of ~800 prompts (20-30 ms of Python) runs under its GPU time instead of in front of it
         feats = None
@@ -757,6 +838,8 @@ class VddLlavaEngine:
         if eos_token_id is not None and pad_token_id is None:
             raise ValueError("If `eos_token_id` is defined, make sure that `pad_token_id` is defined.")   # :258-259
         warp = WarpSpec(temperature=temperature, top_k=top_k, top_p=top_p)
+        proc, proc_key = self._processor_config(prompt_lens, ids_list, eos_token_id, min_new_tokens, min_length, stop_words_ids,
+                                                repetition_penalty, logits_processor, max_new_tokens)
 
         # ---- branches: (name, per-question token lists with image slot handling) ------------
         feats_cd = None
@@ -831,18 +914,18 @@ class VddLlavaEngine:
                           #  path although it reads a shared prefix once per row: tools/small_batch_attn_probe.py, +4 ... 9 %)
         cpi = ops.prefix_chunks_per_item(grp, lm.n_heads)
         n_groups, n_items = len(grp), len(ops.prefix_work_items(grp, cpi))
-        cfgkey = cfgkey + (n_groups, n_items, cpi)
+        cfgkey = cfgkey + (n_groups, n_items, cpi, proc_key)
         run = self._runner(cfgkey, Q, len(keep), max_new_tokens, dict(alpha=alpha, beta=beta, warp=warp, contrast=contrast,
                            is_vcd=use_cd, both=(use_dd and use_dd_unk), greedy=cd_greedy, eos_t=eos_t, pad=pad_token_id,
-                           output_scores=output_scores, n_groups=n_groups, n_items=n_items, cpi=cpi))
+                           output_scores=output_scores, n_groups=n_groups, n_items=n_items, cpi=cpi, proc=proc))
         run.reset(ctr0)
+        if proc:
+            run.set_processor_inputs(**self._processor_inputs(proc, prompt_lens, ids_list, min_new_tokens, min_length))
         scores = [] if output_scores else None
         v0 = logits0[:Q]
         c0 = logits0[Q:2 * Q] if contrast else None
         d0 = logits0[2 * Q:3 * Q] if (contrast and nb == 3) else None
-        eos_kw = dict(eos_ids=eos_t, pad_id=pad_token_id, unfinished=run.unfinished) if eos_t is not None else {}
-        r0 = contrast_sample(v0, c0, d0, alpha=alpha, beta=beta, warp=warp, out_tokens=run.tok, return_scores=output_scores,
-                             pick_argmax=cd_greedy, seed=0, offset=0, offset_ptr=run.ctr, n_top=n_top, status_out=run.status0, **eos_kw)
+        r0 = run.sample_tail(v0, c0, d0, None, output_scores, n_top=n_top, status_out=run.status0, step=0)
         if output_scores:
             scores.append(r0.scores)
         top_prob, top_tok = r0.top_prob, r0.top_tok
@@ -880,6 +963,53 @@ class VddLlavaEngine:
         stats["graph"] = run.graph is not None
         stats["n_groups"] = n_groups          # > 0: the decode steps ran the grouped (shared-prefix) attention
         return GenerateOutput(seqs_out, gen, scores, top_prob, top_tok, stats)
+
+    def _processor_config(self, prompt_lens, ids_list, eos_token_id, min_new_tokens, min_length, stop_words_ids, repetition_penalty,
+                          logits_processor, max_new_tokens):
+        """-> (proc dict for the runner (empty: no processor stage), hashable key).  Activation rules are HF's
+        `_get_logits_processor` [ext]: repetition_penalty iff not None and != 1.0; min_length iff > 0 and an EOS id is defined;
+        min_new_tokens iff > 0 and an EOS id is defined."""
+        proc, key = {}, []
+        eos_defined = eos_token_id is not None and len(eos_token_id) > 0
+        floor_on = eos_defined and ((min_new_tokens or 0) > 0 or ((min_length or 0) > 0 and any((min_length - n) > 0 for n in prompt_lens)))
+        if floor_on:
+            proc["eos_min"] = True
+            key.append("eos_min")
+        if stop_words_ids is not None:
+            if not eos_defined:
+                raise ValueError("stop_words_ids needs eos_token_id (the id the stop words force)")
+            proc["stop"] = ops.StopWords(stop_words_ids, eos_token_id[0], self.device)
+            key.append(("stop", tuple(tuple(w) for w in proc["stop"].seqs), proc["stop"].eos_token_id))
+        if repetition_penalty is not None and float(repetition_penalty) != 1.0:
+            if not float(repetition_penalty) > 0:
+                raise ValueError(f"`penalty` has to be a strictly positive float, but is {repetition_penalty}")
+            if any(t == IMAGE_TOKEN_INDEX for r in ids_list for t in r):
+                raise ValueError("repetition_penalty with an image placeholder (-200) in input_ids: HF's processor gathers "
+                                 "scores[input_ids] and fails on it; the reference only combines it with slot-free prompts")
+            proc["rep"] = float(repetition_penalty)
+            key.append(("rep", proc["rep"]))
+        if logits_processor:
+            proc["python"] = list(logits_processor)
+            key.append(("python", tuple(id(f) for f in proc["python"])))
+        if "rep" in proc or "python" in proc:
+            proc["hist_len"] = (max(prompt_lens + [1]) + 63) // 64 * 64
+            key.append(proc["hist_len"])
+            if proc["hist_len"] + max_new_tokens + 1 > 8192:
+                raise ValueError("repetition_penalty / logits_processor: prompt + new tokens exceed the 8192-id history bound")
+        return proc, tuple(key)
+
+    def _processor_inputs(self, proc, prompt_lens, ids_list, min_new_tokens, min_length):
+        dev, out = self.device, {}
+        if proc.get("eos_min"):
+            floor = [max(int(min_new_tokens or 0), int(min_length or 0) - n) for n in prompt_lens]
+            (out["eos_min"],) = h2d_int32(dev, floor)
+        if proc.get("stop") is not None:
+            out["prompt_tail"] = proc["stop"].prompt_tail(ids_list, dev)
+        if "hist_len" in proc:
+            L = max(prompt_lens + [0])
+            out["prompt_ids"] = torch.tensor([[-1] * (L - len(r)) + [(-1 if t == IMAGE_TOKEN_INDEX else t) for t in r] for r in ids_list],
+                                             dtype=torch.long, device=dev).reshape(len(ids_list), L)
+        return out
 
     def _runner(self, key, Q, nb, max_new, tail):
         r = self._graphs.get(key)

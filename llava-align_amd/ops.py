@@ -32,6 +32,8 @@ _SIGS = {
     "vdd_vit_im2col": [_P, _I, _P, _I, _I, _I, _I, _P],
     "vdd_vit_assemble": [_P, _P, _P, _P, _I, _I, _I, _P],
     "vdd_vit_qkv_split": [_P, _P, _P, _P, _I, _I, _I, _I, _L, _I, _I, _P],
+    "vdd_stop_words_match": [_P, _L, _L, _P, _P, _I, _P, _P, _I, _P, _I, _P],
+    "vdd_repetition_penalty": [_P, _L, _I, _I, _I, _P, _I, _P, _L, _L, _P, _F, C.c_uint32, _P],
 }
 _bound = False
 
@@ -490,3 +492,60 @@ def add(a, b, out=None):
     out = torch.empty_like(a) if out is None else out
     _lib.check(_lib_ready().vdd_add(a.data_ptr(), b.data_ptr(), out.data_ptr(), a.numel(), _st(a)))
     return out
+
+
+# ---- logits processors that need the token history (csrc/vdd_logits_process.hip) ------------------------------------------------
+class StopWords:
+    """Device-side form of a `stop_words_ids` list (qwen_generation_utils.py:318-345: sequences equal to [eos] are dropped)."""
+
+    def __init__(self, stop_words_ids, eos_token_id: int, device):
+        if not isinstance(stop_words_ids, list) or len(stop_words_ids) == 0:
+            raise ValueError(f"`stop_words_ids` has to be a non-emtpy list, but is {stop_words_ids}.")
+        if any(not isinstance(w, list) for w in stop_words_ids):
+            raise ValueError(f"`stop_words_ids` has to be a list of lists, but is {stop_words_ids}.")
+        if any(any((not isinstance(t, int) or isinstance(t, bool) or t < 0) for t in w) for w in stop_words_ids):
+            raise ValueError(f"Each list in `stop_words_ids` has to be a list of positive integers, but is {stop_words_ids}.")
+        self.seqs = [list(w) for w in stop_words_ids if list(w) != [eos_token_id]]
+        assert all(len(w) > 0 for w in self.seqs), f"Stop words token sequences {stop_words_ids} cannot have an empty list"
+        self.eos_token_id = int(eos_token_id)
+        self.max_len = max([len(w) for w in self.seqs] + [1])
+        off = [0]
+        for w in self.seqs:
+            off.append(off[-1] + len(w))
+        self.flat = torch.tensor([t for w in self.seqs for t in w] or [0], dtype=torch.long, device=device)
+        self.off = torch.tensor(off, dtype=torch.int32, device=device)
+
+    def prompt_tail(self, prompts, device):
+        """[Q, max_len] int64: the last max_len ids of every prompt, left-padded with -1."""
+        L = self.max_len
+        rows = [([-1] * L + [int(t) for t in r])[-L:] for r in prompts]
+        return torch.tensor(rows, dtype=torch.long, device=device).reshape(len(prompts), L)
+
+
+def stop_words_match(sw: StopWords, prompt_tail, gen, step=0, step_ptr=None, out=None):
+    """out[q] = 1 iff (prompt q ++ its first `step (+ *step_ptr)` columns of gen) ends with one of sw's sequences."""
+    Q = prompt_tail.shape[0]
+    out = torch.empty(Q, dtype=torch.int32, device=prompt_tail.device) if out is None else out
+    _lib.check(_lib_ready().vdd_stop_words_match(gen.data_ptr() if gen is not None else None, gen.stride(0) if gen is not None else 0,
+                                                 int(step), step_ptr.data_ptr() if step_ptr is not None else None,
+                                                 prompt_tail.data_ptr(), prompt_tail.shape[1], sw.flat.data_ptr(), sw.off.data_ptr(),
+                                                 len(sw.seqs), out.data_ptr(), Q, _st(prompt_tail)))
+    return out
+
+
+_SCORE_DT = {torch.float32: _lib.VDD_F32, torch.float16: _lib.VDD_F16, torch.bfloat16: _lib.VDD_BF16}
+
+
+def repetition_penalty_(scores, penalty, prompt_ids, gen, step=0, step_ptr=None, reciprocal=False):
+    """HF RepetitionPenaltyLogitsProcessor in place on scores [Q, V]: history = prompt_ids [Q, Lp] (int64, -1 = padding) ++ the
+    first `step (+ *step_ptr)` columns of gen."""
+    if not scores.is_cuda or scores.dtype not in _SCORE_DT or scores.stride(1) != 1:
+        raise ValueError("repetition_penalty_ takes a device [Q, V] tensor with contiguous rows")
+    Q, V = scores.shape
+    Lp = prompt_ids.shape[1] if prompt_ids is not None else 0
+    _lib.check(_lib_ready().vdd_repetition_penalty(scores.data_ptr(), scores.stride(0), _SCORE_DT[scores.dtype], Q, V,
+                                                   prompt_ids.data_ptr() if Lp else None, Lp,
+                                                   gen.data_ptr() if gen is not None else None, gen.stride(0) if gen is not None else 0,
+                                                   int(step), step_ptr.data_ptr() if step_ptr is not None else None, float(penalty),
+                                                   _lib.TEMP_RECIPROCAL if reciprocal else 0, _st(scores)))
+    return scores

@@ -92,11 +92,19 @@ def contrast_sample(logits_v: torch.Tensor, logits_cd: Optional[torch.Tensor] = 
                     no_sample: bool = False, cutoff_f32_scalar: Optional[bool] = None, temp_reciprocal: Optional[bool] = None,
                     topp_fp32_mass: bool = False,
                     workspace: Optional[torch.Tensor] = None, stream: Optional[int] = None,
-                    offset_ptr: Optional[torch.Tensor] = None, status_out: Optional[torch.Tensor] = None) -> SampleOutput:
+                    offset_ptr: Optional[torch.Tensor] = None, status_out: Optional[torch.Tensor] = None,
+                    eos_min_step: Optional[torch.Tensor] = None, step: int = 0, step_ptr: Optional[torch.Tensor] = None,
+                    force_eos: Optional[torch.Tensor] = None, force_eos_id: Optional[int] = None,
+                    force_eos_value: float = float(2 ** 15)) -> SampleOutput:
     """Fused contrastive sampling tail on [B, V] last-position logits (any row stride).
 
     logits_cd=None is the reference's plain path (:204-207); logits_dd selects the
     both-branches average (:185).  Asynchronous on the current stream.
+
+    Logits-processor stage (where vcd_sample.py:197 / :204 call `logits_processor`, before the warpers): eos_min_step int32 [B] -
+    every id of eos_ids scores -inf while step (+ the int64 device scalar step_ptr) < eos_min_step[row] (HF MinNewTokensLength /
+    MinLength processors; needs eos_ids); force_eos int32 [B] flags + force_eos_id - scores[row, force_eos_id] = force_eos_value
+    where set (Qwen StopWordsLogitsProcessor, qwen_generation_utils.py:352-359; flags from ops.stop_words_match).
 
     cutoff_f32_scalar / temp_reciprocal select torch-GPU's scalar arithmetic (log(beta) added in fp32 before the rounding, the
     temperature division as a multiply by the reciprocal) instead of torch-CPU's, which the golden vectors were made with; None =
@@ -149,13 +157,29 @@ def contrast_sample(logits_v: torch.Tensor, logits_cd: Optional[torch.Tensor] = 
         if uniforms.dtype != torch.float32 or uniforms.numel() != B or not uniforms.is_contiguous():
             raise ValueError("uniforms must be contiguous fp32 [B]")
         prm.uniforms = uniforms.data_ptr()
-    if eos_ids is not None and eos_ids.numel() > 0:
+    if eos_ids is not None and eos_ids.numel() > 0 and not (unfinished is None and eos_min_step is not None):
         if unfinished is None:
             raise ValueError("eos_ids given without an `unfinished` state tensor")
         if pad_id is None:
             raise ValueError("If `eos_token_id` is defined, make sure that `pad_token_id` is defined.")  # :258-259
         prm.eos_ids, prm.n_eos, prm.pad_id = eos_ids.data_ptr(), eos_ids.numel(), int(pad_id)
         prm.unfinished = unfinished.data_ptr()
+    if eos_min_step is not None:
+        if eos_ids is None or eos_ids.numel() == 0:
+            raise ValueError("eos_min_step given without eos_ids")
+        if eos_min_step.dtype != torch.int32 or eos_min_step.numel() != B or not eos_min_step.is_contiguous():
+            raise ValueError("eos_min_step must be contiguous int32 [B]")
+        if unfinished is None:                     # the processor stage only needs the id list, not the pad / unfinished bookkeeping
+            prm.eos_ids, prm.n_eos = eos_ids.data_ptr(), eos_ids.numel()
+        prm.eos_min_step, prm.step = eos_min_step.data_ptr(), int(step)
+        if step_ptr is not None:
+            prm.step_ptr = step_ptr.data_ptr()
+        keep.append(eos_min_step)
+    if force_eos is not None:
+        if force_eos.dtype != torch.int32 or force_eos.numel() != B or not force_eos.is_contiguous() or force_eos_id is None:
+            raise ValueError("force_eos must be contiguous int32 [B] and comes with force_eos_id")
+        prm.force_eos, prm.force_eos_id, prm.force_eos_value = force_eos.data_ptr(), int(force_eos_id), float(force_eos_value)
+        keep.append(force_eos)
     tokens = None
     if not no_sample:
         tokens = out_tokens if out_tokens is not None else torch.empty(B, dtype=torch.long, device=dev)

@@ -95,11 +95,85 @@ class WarpConfig:
         return x
 
 
+# --------------------------------------------------------------------------------------
+# Logits processors the reference's drivers put between contrast and warp (vcd_sample.py:197 / :204):
+# `logits_processor(input_ids, scores)`.  HF builds the list in this order [ext, transformers
+# `_get_logits_processor`]: repetition penalty, min_length, min_new_tokens, ..., then the caller's
+# own (Qwen appends its stop-words processor, modeling_qwen.py:1061-1075).
+# --------------------------------------------------------------------------------------
+class RepetitionPenalty:
+    """HF RepetitionPenaltyLogitsProcessor [ext] (InstructBLIP passes repetition_penalty, blip2_vicuna_instruct.py:400):
+    gather the scores of every id in input_ids, `score < 0 ? score * p : score / p`, scatter back."""
+
+    def __init__(self, penalty: float):
+        self.penalty = float(penalty)
+
+    def __call__(self, input_ids, scores):
+        if input_ids.shape[1] == 0:
+            return scores
+        score = torch.gather(scores, 1, input_ids)
+        score = torch.where(score < 0, score * self.penalty, score / self.penalty)
+        return scores.scatter(1, input_ids, score)
+
+
+class MinLength:
+    """HF MinLengthLogitsProcessor [ext] (min_length, blip2_vicuna_instruct.py:397): eos ids score -inf while the row is shorter
+    than min_length (prompt included)."""
+
+    def __init__(self, min_length: int, eos_token_id):
+        self.min_length, self.eos = int(min_length), [eos_token_id] if isinstance(eos_token_id, int) else list(eos_token_id)
+
+    def __call__(self, input_ids, scores):
+        if input_ids.shape[-1] < self.min_length:
+            scores = scores.clone()
+            scores[:, self.eos] = NEG_INF
+        return scores
+
+
+class MinNewTokens:
+    """HF MinNewTokensLengthLogitsProcessor [ext] (min_new_tokens=1, MME/run_qwen.py:194): eos ids score -inf until
+    min_new_tokens ids have been generated behind the prompt."""
+
+    def __init__(self, prompt_length: int, min_new_tokens: int, eos_token_id):
+        self.prompt_length, self.min_new = int(prompt_length), int(min_new_tokens)
+        self.eos = [eos_token_id] if isinstance(eos_token_id, int) else list(eos_token_id)
+
+    def __call__(self, input_ids, scores):
+        if input_ids.shape[-1] - self.prompt_length < self.min_new:
+            scores = scores.clone()
+            scores[:, self.eos] = NEG_INF
+        return scores
+
+
+class StopWords:
+    """experiments/Qwen_VL/qwen_generation_utils.py:305-385: a row whose ids END with one of the stop sequences gets
+    scores[row, eos] = 2**15 (:352-359); sequences equal to [eos] are dropped at construction (:340-344)."""
+
+    def __init__(self, stop_words_ids, eos_token_id: int):
+        self.stop = [list(w) for w in stop_words_ids if list(w) != [eos_token_id]]
+        self.eos = int(eos_token_id)
+
+    def __call__(self, input_ids, scores):
+        for i, row in enumerate(input_ids.tolist()):
+            if any(len(w) <= len(row) and row[len(row) - len(w):] == w for w in self.stop):      # _tokens_match, :361-372
+                scores[i, self.eos] = float(2 ** 15)
+        return scores
+
+
+class ProcessorList(list):
+    def __call__(self, input_ids, scores):
+        for p in self:
+            scores = p(input_ids, scores)
+        return scores
+
+
 def step_scores(v: torch.Tensor, c: Optional[torch.Tensor], d: Optional[torch.Tensor],
                 alpha: float, beta: float, warp: WarpConfig,
-                processors: Optional[Callable[[torch.Tensor], torch.Tensor]] = None) -> torch.Tensor:
+                processors: Optional[Callable[[torch.Tensor, torch.Tensor], torch.Tensor]] = None,
+                input_ids: Optional[torch.Tensor] = None) -> torch.Tensor:
     """One decode step's post-warp `next_token_scores` row(s) — what `output_scores`
-    returns (vcd_sample.py:200,240).  `c is None` is the plain path (:204-205)."""
+    returns (vcd_sample.py:200,240).  `c is None` is the plain path (:204-205).
+    `processors(input_ids, scores)` is the reference's `logits_processor` (:197 / :204)."""
     if c is not None:
         if d is not None:
             c = average_branches(c, d)
@@ -107,7 +181,7 @@ def step_scores(v: torch.Tensor, c: Optional[torch.Tensor], d: Optional[torch.Te
     else:
         x = v
     if processors is not None:
-        x = processors(x)
+        x = processors(input_ids, x)
     return warp(x)
 
 
@@ -200,9 +274,9 @@ def reference_loop(model, input_ids: torch.Tensor, *, warp: WarpConfig, max_leng
                 d = o_dd.logits[:, -1, :]                                                   # :184
             alpha = model_kwargs.get("cd_alpha") if model_kwargs.get("cd_alpha") is not None else 0.5   # :188
             beta = model_kwargs.get("cd_beta") if model_kwargs.get("cd_beta") is not None else 0.1      # :189
-            scores = step_scores(v, c, d, alpha, beta, warp, processors)                    # :185-198
+            scores = step_scores(v, c, d, alpha, beta, warp, processors, input_ids)                  # :185-198
         else:
-            scores = step_scores(v, None, None, 0.0, 0.0, warp, processors)                 # :204-205
+            scores = step_scores(v, None, None, 0.0, 0.0, warp, processors, input_ids)               # :204-205
         probs = torch.nn.functional.softmax(scores, dim=-1)                                 # :201 / :206
         tokens = pick(probs)                                                                # :202 / :207
         out.scores.append(scores)                                                           # :240

@@ -287,7 +287,88 @@ def gen_scorers():
     print("scorers:", out["eval_pope"], list(out["eval_pope_calibrate"]))
 
 
+PROC_SPECS = [
+    # (name, spec); spec keys: min_new (n, eos list), min_len (n, eos list), rep (penalty), stop (True: sequences taken from a
+    # processor-free run of the same case so that they really occur)
+    ("min_new", {"min_new": 2}),
+    ("min_len", {"min_len": 6}),
+    ("rep", {"rep": 1.3}),
+    ("stop", {"stop": True}),
+    ("qwen_mme", {"min_new": 1, "stop": True}),
+    ("all", {"rep": 1.5, "min_len": 5, "min_new": 3, "stop": True}),
+]
+
+
+def build_hf_processors(spec, prompt_len, eos, stop_words):
+    """The list HF's generate() would hand to sample() for these kwargs, in HF's order (repetition penalty, min_length,
+    min_new_tokens, then the caller's own = Qwen's stop-words processor, modeling_qwen.py:1061-1075), made of HF's classes and the
+    reference's own StopWordsLogitsProcessor."""
+    from transformers.generation.logits_process import (LogitsProcessorList, MinLengthLogitsProcessor,
+                                                        MinNewTokensLengthLogitsProcessor, RepetitionPenaltyLogitsProcessor)
+    from ref_shim import load_qwen_stop_words
+    lst = LogitsProcessorList()
+    if "rep" in spec:
+        lst.append(RepetitionPenaltyLogitsProcessor(penalty=spec["rep"]))
+    if "min_len" in spec:
+        lst.append(MinLengthLogitsProcessor(spec["min_len"], eos))
+    if "min_new" in spec:
+        lst.append(MinNewTokensLengthLogitsProcessor(prompt_len, spec["min_new"], eos))
+    if spec.get("stop"):
+        lst.append(load_qwen_stop_words()(stop_words_ids=stop_words, eos_token_id=eos[0]))
+    return lst
+
+
+def gen_processors():
+    """Real reference sample() with a `logits_processor` list between contrast and warp (vcd_sample.py:197 / :204)."""
+    cases = []
+    arrays = {}
+    steps, B, L0 = 5, 3, 4
+    for V in (97, 1003):
+        for dt in ("fp32", "fp16", "bf16"):
+            for n_in in (1, 2, 3):
+                if V == 1003 and n_in == 3:
+                    continue
+                for name, spec in PROC_SPECS:
+                    for warp in ({"top_k": 1}, {"temperature": 0.7, "top_k": 1}):
+                        if warp.get("temperature") and name not in ("qwen_mme", "all"):
+                            continue
+                        seed = 5000 + len(cases)
+                        rows = logit_rows(seed, B, V, DTYPES[dt], n_in, "normal", steps)
+                        bank = [r for step in rows for r in step]
+                        ids = torch.ones(B, L0, dtype=torch.long)
+                        if "rep" not in spec:           # HF's repetition penalty gathers scores[input_ids]: an image slot (-200) is out of
+                            ids[:, 2] = -200            # range, so only Qwen / InstructBLIP-style prompts (no slot) ever combine with it
+                        ids[:, 3] = torch.tensor([5, 6, 7])
+                        kw = dict(attention_mask=torch.ones_like(ids), cd_alpha=1.0, cd_beta=0.1, **MODE_KW[n_in])
+                        free = run_reference(BankModel([b.clone() for b in bank]), ids.clone(), max_length=L0 + steps, warp=warp,
+                                             multinomial=ARGMAX_MN, **kw)
+                        toks = free.sequences[:, L0:].tolist()
+                        eos = [toks[0][0], toks[2][1]]         # ids the free run really emits early: the EOS masks bite
+                        # stop sequences that occur: row 0's first two tokens, row 1's token at step 2, one ending in the prompt's
+                        # last id (matches at step 0 from the PROMPT tail), and [eos] itself (dropped by the constructor)
+                        stop_words = [toks[0][:2], [toks[1][2]], [6], [eos[0]]]
+                        procs = build_hf_processors(spec, L0, eos, stop_words)
+                        out = run_reference(BankModel([b.clone() for b in bank]), ids.clone(), max_length=L0 + steps, warp=warp,
+                                            pad=0, eos=eos, multinomial=ARGMAX_MN, logits_processor=procs, **kw)
+                        ci = len(cases)
+                        for s_, sc in enumerate(out.scores):
+                            arrays[f"p{ci}_s{s_}"] = to_bits(sc)
+                        cases.append({"id": ci, "V": V, "dtype": dt, "n_in": n_in, "proc": name, "spec": spec, "warp": warp, "seed": seed,
+                                      "steps": steps, "B": B, "ids": ids.tolist(), "eos": eos, "pad": 0, "stop_words": stop_words,
+                                      "free_tokens": toks, "sequences": out.sequences.tolist(), "n_scores": len(out.scores)})
+    np.savez_compressed(os.path.join(HERE, "processors.npz"), **arrays)
+    with open(os.path.join(HERE, "processors.json"), "w") as f:
+        json.dump(cases, f)
+    changed = sum(c["sequences"] != [r[:len(c["sequences"][0])] for r in [i + t for i, t in zip(c["ids"], c["free_tokens"])]] for c in cases)
+    print("processors:", len(cases), "cases;", changed, "differ from the processor-free run")
+
+
 if __name__ == "__main__":
+    if len(sys.argv) > 1:                       # python make_golden.py processors ...: regenerate only the named sets
+        torch.set_num_threads(8)
+        for name in sys.argv[1:]:
+            globals()["gen_" + name]()
+        sys.exit(0)
     torch.set_num_threads(8)
     gen_kernel_vectors()
     gen_loop_traces()
@@ -295,3 +376,4 @@ if __name__ == "__main__":
     gen_noise()
     gen_calibration()
     gen_scorers()
+    gen_processors()

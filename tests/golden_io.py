@@ -51,3 +51,20 @@ def check_scores(case, arrays, step, got: torch.Tensor):
 def load_json(name):
     with open(os.path.join(GOLD, name)) as f:
         return json.load(f)
+
+
+def processor_cases():
+    """tests/golden/processors.{json,npz}: the real reference sample() run with HF's MinLength / MinNewTokensLength /
+    RepetitionPenalty processors and the reference's own Qwen StopWordsLogitsProcessor between contrast and warp."""
+    if "p" not in _cache:
+        _cache["p"] = (load_json("processors.json"), np.load(os.path.join(GOLD, "processors.npz")))
+    return _cache["p"]
+
+
+def processor_case_rows(case):
+    """-> per step the [v, c, d][:n_in] rows (each [B, V]) of a processors.json case."""
+    return logit_rows(case["seed"], case["B"], case["V"], DTYPES[case["dtype"]], case["n_in"], "normal", case["steps"])
+
+
+def processor_case_scores(case, arrays, step):
+    return from_bits(arrays[f"p{case['id']}_s{step}"], DTYPES[case["dtype"]])

@@ -72,8 +72,16 @@ def hf_warpers(temperature=None, top_k=None, top_p=None, min_keep=1):
     return lst
 
 
+def load_qwen_stop_words():
+    """The reference's own StopWordsLogitsProcessor class (experiments/Qwen_VL/qwen_generation_utils.py:305-385), loaded by path."""
+    if "qgu" not in _cache:
+        sys.dont_write_bytecode = True
+        _cache["qgu"] = _load("ref_qwen_generation_utils", os.path.join(REF_ROOT, "experiments/Qwen_VL/qwen_generation_utils.py"))
+    return _cache["qgu"].StopWordsLogitsProcessor
+
+
 def run_reference(model, input_ids, *, max_length, warp=None, pad=None, eos=None, output_scores=True,
-                  multinomial=None, **model_kwargs):
+                  multinomial=None, logits_processor=None, **model_kwargs):
     """Drive the reference sample() once.  `multinomial`, if given, temporarily replaces
     torch.multinomial (the reference's only RNG consumer on this path, vcd_sample.py:202)."""
     import torch
@@ -92,7 +100,7 @@ def run_reference(model, input_ids, *, max_length, warp=None, pad=None, eos=None
     if multinomial is not None:
         torch.multinomial = multinomial
     try:
-        out = ref.sample(model, input_ids,
+        out = ref.sample(model, input_ids, logits_processor=logits_processor,
                          logits_warper=hf_warpers(**warp),
                          stopping_criteria=MaxLen431(),
                          pad_token_id=pad, eos_token_id=eos, output_scores=output_scores,

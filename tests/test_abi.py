@@ -36,7 +36,8 @@ def test_exports_every_declared_symbol(lib):
 
 
 def test_abi_version(lib):
-    assert lib.vdd_abi_version() == 1
+    from llava_align_amd._lib import ABI_VERSION
+    assert lib.vdd_abi_version() == ABI_VERSION == 2
     assert lib.vdd_lds_row_capacity(1) >= 32000 and lib.vdd_lds_row_capacity(0) >= 32000
     assert lib.vdd_kernel_name(2, 32000).decode() == "vdd_contrast_sample_kernel"
 
@@ -65,7 +66,8 @@ def test_invalid_arguments_return_status_not_crash(lib):
     p.abi_version = 99
     assert lib.vdd_contrast_sample(C.byref(p), None) == -1
     assert b"abi_version" in lib.vdd_last_error()
-    p.abi_version = 1
+    from llava_align_amd._lib import ABI_VERSION
+    p.abi_version = ABI_VERSION
     p.B, p.V = 1, 0
     assert lib.vdd_contrast_sample(C.byref(p), None) == -1
     p.B, p.V = 0, 10

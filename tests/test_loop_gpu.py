@@ -101,7 +101,7 @@ def test_python_processor_between_contrast_and_warp():
     assert out[0, 4:].cpu().tolist() == [3, 3]
     r = O.reference_loop(BankModel([b.clone() for b in bank]), ids.cpu(), warp=O.WarpConfig(top_k=1), max_length=6,
                          pad_token_id=None, eos_token_id=None, pick=O.pick_argmax,
-                         processors=lambda x: ForceTok()(None, x), attention_mask=torch.ones_like(ids).cpu(),
+                         processors=lambda ids_, x: ForceTok()(ids_, x), attention_mask=torch.ones_like(ids).cpu(),
                          use_dd_unk=True, cd_alpha=1.0, cd_beta=0.1)
     assert out.cpu().tolist() == r.sequences.tolist()
 

@@ -115,3 +115,53 @@ def test_calibration_matches_reference():
             assert np.array_equal(q.reshape(-1), np.array(want))
             hits.append(int(ans == lab))
         assert float(np.mean(hits)) == e["acc"]
+
+
+# ---- logits processors between contrast and warp (vcd_sample.py:197 / :204) ---------------------------------------------------
+from golden_io import processor_case_rows, processor_case_scores, processor_cases  # noqa: E402
+
+PCASES, PARR = processor_cases()
+
+
+def oracle_processors(case):
+    """The oracle's restatements in HF's order (repetition penalty, min_length, min_new_tokens, caller's stop words)."""
+    spec, eos, L0 = case["spec"], case["eos"], len(case["ids"][0])
+    lst = O.ProcessorList()
+    if "rep" in spec:
+        lst.append(O.RepetitionPenalty(spec["rep"]))
+    if "min_len" in spec:
+        lst.append(O.MinLength(spec["min_len"], eos))
+    if "min_new" in spec:
+        lst.append(O.MinNewTokens(L0, spec["min_new"], eos))
+    if spec.get("stop"):
+        lst.append(O.StopWords(case["stop_words"], eos[0]))
+    return lst
+
+
+@pytest.mark.parametrize("case", PCASES, ids=[f"p{c['id']}-{c['dtype']}-V{c['V']}-n{c['n_in']}-{c['proc']}" for c in PCASES])
+def test_loop_with_logits_processors_matches_reference(case):
+    rows = processor_case_rows(case)
+    bank = [r for step in rows for r in step]
+    ids = torch.tensor(case["ids"])
+    mode = {1: {}, 2: {"use_dd_unk": True}, 3: {"use_dd": True, "use_dd_unk": True}}[case["n_in"]]
+    r = O.reference_loop(BankModel(bank), ids.clone(), warp=O.WarpConfig(**case["warp"]), max_length=ids.shape[1] + case["steps"],
+                         pad_token_id=case["pad"], eos_token_id=case["eos"], pick=O.pick_argmax, processors=oracle_processors(case),
+                         attention_mask=torch.ones_like(ids), cd_alpha=1.0, cd_beta=0.1, **mode)
+    assert r.sequences.tolist() == case["sequences"]
+    assert len(r.scores) == case["n_scores"]
+    for s, got in enumerate(r.scores):
+        want = processor_case_scores(case, PARR, s)
+        assert torch.equal(torch.from_numpy(to_bits(got)), torch.from_numpy(to_bits(want))), (s, int((got != want).sum()))
+
+
+def test_processor_fixture_bites():
+    """The processors really change the reference's output in the fixture: some EOS that the free run emits is masked, some stop
+    sequence forces EOS (a 2**15 score appears, also from the prompt tail at step 0), the penalty changes scores."""
+    forced = masked_first = 0
+    for c in PCASES:
+        s0 = processor_case_scores(c, PARR, 0)
+        if c["spec"].get("stop"):
+            forced += int((s0[1] == (2.0 ** 15) / c["warp"].get("temperature", 1.0)).any())      # row 1's prompt ends with 6 = a stop word
+        if "min_new" in c["spec"] or "min_len" in c["spec"]:
+            masked_first += int(c["sequences"][0][len(c["ids"][0])] != c["free_tokens"][0][0])
+    assert forced >= 20 and masked_first >= 20
