@@ -56,7 +56,15 @@ def test_processor_stage_matches_reference_fixture(case):
                               pad_id=case["pad"], unfinished=unfinished, **kw)
         want = processor_case_scores(case, PARR, s).to(DEV)
         assert torch.equal(_bits(out.scores), _bits(want)), (s, int((_bits(out.scores) != _bits(want)).sum()))
-        assert out.tokens.tolist() == seqs[:, L0 + s].tolist(), s
+        # a row whose only plausible token was the masked EOS is all -inf: the reference's multinomial raises there (the fixture's
+        # arg-max stand-in wrote 0); the kernel reports it through row_status instead of inventing a token
+        dead = torch.isneginf(want).all(-1)
+        assert out.status.ne(0).tolist() == dead.tolist(), s
+        live = (~dead).nonzero().reshape(-1).tolist()
+        assert [out.tokens[i].item() for i in live] == [seqs[i, L0 + s].item() for i in live], s
+        for i in dead.nonzero().reshape(-1).tolist():                # keep following the fixture's run behind its stand-in token
+            if seqs[i, L0 + s].item() in eos:
+                unfinished[i] = 0
 
 
 def test_stop_words_match_semantics():
