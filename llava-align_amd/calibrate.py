@@ -9,6 +9,8 @@ sampling kernel (`top_prob`, `top_tok`).
   pope_scores              experiments/eval/eval_pope.py:27-67
   pope_scores_calibrated   experiments/eval/eval_pope_calibrate.py:84-180 ('individual' mode)
   AnswerWriter             experiments/eval/calibrate/llava_calibrate.py:209-219 (JSONL schema, flush per question)
+  mme_convert / write_mme_results   experiments/eval/MME/convert_answer_to_mme_calibrate.py:59-139 (and convert_answer_to_mme.py:52-70)
+  mme_scores               experiments/eval/MME/eval_tool/calculation.py
 """
 from __future__ import annotations
 
@@ -192,3 +194,95 @@ def mme_scores(results_dir: str) -> dict:
         per = {t: mme_task_score(open(os.path.join(results_dir, t + ".txt")).readlines()) for t in tasks}
         out[group] = {"total": sum(v["score"] for v in per.values()), "tasks": {t: v["score"] for t, v in per.items()}}
     return out
+
+
+# ------------------------------------------------------------------ MME answers -> per-task result files
+MME_CALIBRATE_NAMES = ("naive", "none", "unk", "none_unk")
+
+
+def mme_gt_key_prompt(category: str, file: str, prompt: str, gt: Dict[tuple, str]) -> str:
+    """The question string under which the benchmark's ground truth lists this answer (convert_answer_to_mme_calibrate.py:128-133):
+    the eval prompt's 'Answer the question using a single word or phrase.' is dropped, ' Please answer yes or no.' appended, with a
+    DOUBLE space where the single-space form is not a ground-truth key."""
+    if "Answer the question using a single word or phrase." in prompt:
+        prompt = prompt.replace("Answer the question using a single word or phrase.", "").strip()
+    if "Please answer yes or no." not in prompt:
+        prompt = prompt + " Please answer yes or no."
+        if (category, file, prompt) not in gt:
+            prompt = prompt.replace(" Please answer yes or no.", "  Please answer yes or no.")
+    return prompt
+
+
+def mme_convert(answers: Sequence[dict], gt: Dict[tuple, str], names: Sequence[str] = MME_CALIBRATE_NAMES,
+                calibrate_mode: str = "individual", mode: str = "diagonal_W") -> Dict[str, Dict[str, List[str]]]:
+    """MME answers (JSONL records with question_id 'category/image.ext', prompt, text, naive / none / unk label dicts) ->
+    {name: {category: ['file<TAB>question<TAB>gt<TAB>answer', ...]}}: what the reference writes to
+    eval_tool/answers/<experiment>-<name>/<category>.txt.  'naive' keeps the generated text; the other names answer 'Yes' / 'No'
+    by the arg-max of the affine-calibrated label probabilities, the prior taken per question ('individual': p_cf = prior + 1e-4,
+    NOT renormalised, :113-114) or as the mean over the whole file ('all', :79-96).  gt: {(category, file, question): answer}
+    (get_gt, :22-41)."""
+    label = {0: "yes", 1: "no"}
+    prob = {n: [get_prob_from_logits(a[n]) for a in answers] for n in ("naive", "none", "unk")}
+    out: Dict[str, Dict[str, List[str]]] = {}
+    for name in names:
+        res: Dict[str, List[tuple]] = {}
+        W, b = np.identity(2), np.zeros([2, 1])
+        if calibrate_mode == "all" and name != "naive":
+            all_p = np.array(prob["unk"]) + np.array(prob["none"]) if name == "none_unk" else np.array(prob[name])
+            p_cf = np.mean(all_p, axis=0)
+            W, b = calibrate_weight(p_cf / np.sum(p_cf), mode)
+        for i, a in enumerate(answers):
+            category = a["question_id"].split("/")[0]
+            file = a["question_id"].split("/")[-1].split(".")[0] + ".txt"
+            if name == "naive":
+                res.setdefault(category, []).append((file, a["prompt"], a["text"]))
+                continue
+            if calibrate_mode == "individual":
+                if name == "none_unk":
+                    s_ = np.array(prob["unk"][i]) + np.array(prob["none"][i])
+                    p_cf = s_ / np.sum(s_)
+                else:
+                    p_cf = prob[name][i]
+                W, b = calibrate_weight([x + 1e-4 for x in p_cf], mode)
+            q = np.matmul(W, np.expand_dims(prob["naive"][i], axis=-1)) + b
+            q /= np.sum(q)
+            res.setdefault(category, []).append((file, a["prompt"], label[int(np.argmax(q))].capitalize()))
+        out[name] = {}
+        for category, tups in res.items():
+            lines = []
+            for file, prompt, ans in tups:
+                prompt = mme_gt_key_prompt(category, file, prompt, gt)
+                lines.append("\t".join((file, prompt, gt[category, file, prompt], ans)))
+            out[name][category] = lines
+    return out
+
+
+def write_mme_results(converted: Dict[str, Dict[str, List[str]]], root: str, experiment: str) -> Dict[str, str]:
+    """-> {name: directory}; one <category>.txt per task under <root>/<experiment>-<name>/ (the layout calculation.py reads)."""
+    import os
+    dirs = {}
+    for name, cats in converted.items():
+        d = os.path.join(root, f"{experiment}-{name}")
+        os.makedirs(d, exist_ok=True)
+        for category, lines in cats.items():
+            with open(os.path.join(d, f"{category}.txt"), "w") as fp:
+                fp.write("".join(line + "\n" for line in lines))
+        dirs[name] = d
+    return dirs
+
+
+def mme_load_gt(data_path: str) -> Dict[tuple, str]:
+    """get_gt (convert_answer_to_mme_calibrate.py:22-41): {(category, file, question): answer} from the MME benchmark tree."""
+    import os
+    gt = {}
+    for category in os.listdir(data_path):
+        cdir = os.path.join(data_path, category)
+        if not os.path.isdir(cdir):
+            continue
+        qa = os.path.join(cdir, "questions_answers_YN") if os.path.exists(os.path.join(cdir, "images")) else cdir
+        for file in os.listdir(qa):
+            if file.endswith(".txt"):
+                for line in open(os.path.join(qa, file)):
+                    question, answer = line.strip().split("\t")
+                    gt[(category, file, question)] = answer
+    return gt

@@ -792,9 +792,10 @@ class VddLlavaEngine:
             # LAVIS / InstructBLIP call shape (blip2_vicuna_instruct.py:380-410): the prompt arrives as embeddings
             # [T, d] per question (Q-Former output ++ text embeddings) and `images_cd` holds the noisy-image EMBEDDINGS,
             # which modeling_llama.py:778-782 feeds as inputs_embeds of the cd branch at step 0.
-            if use_dd or use_dd_unk:
-                raise ValueError("use_dd / use_dd_unk act on the image placeholder of input_ids; with inputs_embeds only "
-                                 "plain and VCD (images_cd = embeddings) decoding are defined")
+            # use_dd / use_dd_unk with a prompt that carries NO -200 placeholder is the reference's Qwen-VL case (SURVEY A.3 #4:
+            # its ids never contain IMAGE_TOKEN_INDEX, vcd_sample.py:154-160 change nothing): the image-free branches re-run the
+            # SAME inputs on their own KV caches, c ~ v, and the contrast reduces to the beta-mask.  Reproduced as such: the extra
+            # branches get the main branch's embeddings (the dual / triple forward pass is really executed).
             emb_main = [e.reshape(-1, lm.d) for e in (inputs_embeds if not torch.is_tensor(inputs_embeds) else list(inputs_embeds))]
             emb_cd = None
             if images_cd is not None:
@@ -847,18 +848,27 @@ class VddLlavaEngine:
             imgs_cd = [images_cd[i] for i in range(Q)] if torch.is_tensor(images_cd) else list(images_cd)
             feats_cd = [self.vit(im.reshape(1, *im.shape[-3:]))[0] for im in imgs_cd]
         if inputs_embeds is not None:
-            branches = [("main", ids_list, [e.to(dev, torch.bfloat16) for e in emb_main])]
+            main_dev = [e.to(dev, torch.bfloat16) for e in emb_main]
+            branches = [("main", ids_list, main_dev)]
             if use_cd:
                 branches.append(("cd", ids_list, [e.to(dev, torch.bfloat16) for e in emb_cd]))
+            elif use_dd_unk:
+                branches.append(("unk", ids_list, main_dev))
+            elif use_dd:
+                branches.append(("none", ids_list, main_dev))
+            if use_dd and use_dd_unk:
+                branches.append(("none", ids_list, main_dev))
         else:
             branches = [("main", ids_list, feats)]
         if use_cd and inputs_embeds is None:
             branches.append(("cd", ids_list, feats_cd))                                       # :148-150, takes precedence
+        elif inputs_embeds is not None:
+            pass
         elif use_dd_unk:
             branches.append(("unk", [[0 if t == IMAGE_TOKEN_INDEX else t for t in r] for r in ids_list], None))   # :154-155
         elif use_dd:
             branches.append(("none", [[t for t in r if t != IMAGE_TOKEN_INDEX] for r in ids_list], None))         # :157-160
-        if use_dd and use_dd_unk:
+        if use_dd and use_dd_unk and inputs_embeds is None:
             branches.append(("none", [[t for t in r if t != IMAGE_TOKEN_INDEX] for r in ids_list], None))         # :171-177
         nb = len(branches)
 

@@ -1,0 +1,157 @@
+"""MME evaluation driver over the native engine (BASELINE config #4): the batched replacement of the reference's per-question loops
+experiments/eval/MME/run_qwen.py:143-238 (Qwen-VL) and experiments/eval/MME/run_llava.py:130-237 (LLaVA), followed by the
+calibrate converter (convert_answer_to_mme_calibrate.py -> calibrate.mme_convert) and the MME scorer (eval_tool/calculation.py ->
+calibrate.mme_scores).
+
+Per question the reference runs THREE generate() calls at B = 1:
+  main   image + question with the VDD / VCD kwargs                                   -> `text`, `naive` (step-0 top-10 label dict)
+  none   the question as TEXT only, plain sampling                                    -> `none`   (run_qwen.py:100-137, run_llava.py:95-128)
+  unk    the image replaced by a placeholder ('None ' text / the <unk> token), plain  -> `unk`
+Only the step-0 scores of `none` / `unk` are ever used (:135-137), so here they decode ONE token.  Each of the three is one engine
+call over a whole batch of questions.
+
+Model-specific prompt construction stays with the caller through `build_inputs(line, kind)`, kind in {"main", "none", "unk"}, which
+returns either {"input_ids": 1-D ids with one -200 image slot, "image": [3,S,S] tensor or None} (LLaVA: llava_mme_inputs) or
+{"inputs_embeds": [T, d] embeddings} (Qwen-VL, whose ViT + resampler are outside the north-star path and fill the 256 image slots
+upstream: qwen_mme_inputs).
+"""
+from __future__ import annotations
+
+import uuid
+from typing import Callable, Dict, List, Optional, Sequence
+
+import torch
+
+from . import calibrate as C
+from .engine import IMAGE_TOKEN_INDEX, VddLlavaEngine
+
+MME_SUBSETS = ("existence", "count", "position", "color", "commonsense_reasoning", "numerical_calculation", "text_translation",
+               "code_reasoning")                                                   # run_qwen.py:146, run_llava.py:133
+ONE_WORD = " Please answer this question with one word."                          # run_llava.py:106
+
+
+def vicuna_v1_prompt(user_text: str) -> str:
+    """conv_templates['vicuna_v1'] with one user turn (experiments/llava/conversation.py:252-262, SeparatorStyle.TWO)."""
+    system = ("A chat between a curious user and an artificial intelligence assistant. "
+              "The assistant gives helpful, detailed, and polite answers to the user's questions.")
+    return f"{system} USER: {user_text} ASSISTANT:"
+
+
+def llava_mme_inputs(encode: Callable[[str], List[int]], load_image: Callable[[str], torch.Tensor], unk_token_id: int = 0):
+    """run_llava.py: main = '<image>\\n' + question in the vicuna_v1 template (:52-62, no one-word suffix); none = question + suffix
+    without an image token (:101-109 with images=None); unk = '<image>\\n' + question + suffix with the slot replaced by the
+    tokenizer's <unk> (:102-115).  `encode(prompt)` tokenises with -200 where '<image>' stands (tokenizer_image_token)."""
+    def build(line, kind):
+        q = line["text"]
+        if kind == "main":
+            return {"input_ids": torch.tensor(encode(vicuna_v1_prompt("<image>\n" + q))), "image": load_image(line["image"])}
+        if kind == "none":
+            return {"input_ids": torch.tensor(encode(vicuna_v1_prompt(q + ONE_WORD))), "image": None}
+        ids = encode(vicuna_v1_prompt("<image>\n" + q + ONE_WORD))
+        return {"input_ids": torch.tensor([unk_token_id if t == IMAGE_TOKEN_INDEX else t for t in ids]), "image": None}
+    return build
+
+
+def qwen_mme_inputs(embed_prompt: Callable[[str, Optional[str]], torch.Tensor], image_path: Callable[[str], str] = lambda f: f):
+    """run_qwen.py: main = '<img>{path}</img>{q} Answer:' (:176-177), none = '{q} Answer:' (:101-102), unk = 'None {q} Answer:'
+    (:103-104).  `embed_prompt(text, image_path_or_None) -> [T, d]` is the caller's Qwen front-end: token embeddings with the 256
+    image slots between <img> and </img> filled by its ViT + resampler."""
+    def build(line, kind):
+        q = line["text"]
+        if kind == "main":
+            p = image_path(line["image"])
+            return {"inputs_embeds": embed_prompt("<img>{}</img>{} Answer:".format(p, q), p)}
+        if kind == "none":
+            return {"inputs_embeds": embed_prompt("{} Answer:".format(q), None)}
+        return {"inputs_embeds": embed_prompt("{} {} Answer:".format("None", q), None)}
+    return build
+
+
+def _generate(engine, batch, **kw):
+    if "inputs_embeds" in batch[0]:
+        return engine.generate(None, inputs_embeds=[b["inputs_embeds"] for b in batch], **kw)
+    imgs = [b["image"] for b in batch]
+    has_img = imgs[0] is not None
+    return engine.generate([b["input_ids"] for b in batch], images=imgs if has_img else None, **kw)
+
+
+def run_mme(engine: VddLlavaEngine, questions: Sequence[dict], build_inputs: Callable[[dict, str], dict],
+            decode: Callable[[List[int]], str], answers_path: Optional[str] = None, model_id: str = "llava-align_amd",
+            batch_questions: int = 256, eos_token_id=None, pad_token_id: Optional[int] = None, stop_str: Optional[str] = None,
+            max_new_tokens: int = 20, min_new_tokens: Optional[int] = None, noise_step: Optional[int] = None,
+            gt: Optional[Dict[tuple, str]] = None, results_root: Optional[str] = None, experiment: str = "exp",
+            subsets: Optional[Sequence[str]] = MME_SUBSETS, chunk: Optional[tuple] = None, **generate_kw) -> dict:
+    """questions: the llava_mme.jsonl lines (question_id 'category/image.ext', image, text, category); subsets filters them as the
+    reference does; chunk=(n, k) takes the reference's k-th of n contiguous ceil-chunks (get_chunk, run_llava.py:32-40).
+    generate_kw: cd_alpha, cd_beta, use_dd, use_dd_unk, temperature, top_p, top_k, seed - the reference's generate kwargs; the Qwen
+    call shape adds min_new_tokens=1 and pad = eos = eod id (run_qwen.py:190-213); noise_step adds the VCD branch for LLaVA inputs.
+    gt + results_root: also convert ('naive', 'none', 'unk', 'none_unk') and score.
+    Returns {"answers": [...], "results": {name: dir}, "scores": {name: mme_scores}}."""
+    from .shard import get_chunk
+    qs_all = [q for q in questions if subsets is None or q.get("category") in subsets]
+    if chunk is not None:
+        qs_all = [qs_all[i] for i in get_chunk(len(qs_all), chunk[0], chunk[1], group=1)]
+    order = sorted(range(len(qs_all)), key=lambda i: (qs_all[i]["image"], i))          # an image's two questions adjacent: shared features
+    decode_token = lambda t: decode([t])
+    eos_set = set([eos_token_id] if isinstance(eos_token_id, int) else (eos_token_id or []))
+    records: Dict[int, dict] = {}
+    plain_kw = {k: v for k, v in generate_kw.items() if k in ("temperature", "top_p", "top_k", "seed", "cd_alpha", "cd_beta")}
+    for b0 in range(0, len(order), batch_questions):
+        idx = order[b0:b0 + batch_questions]
+        lines = [qs_all[i] for i in idx]
+        img_cache: Dict[str, dict] = {}
+
+        def main_inputs(line):
+            # one tensor object per distinct image, so that the engine shares its features and prompt-prefix KV
+            b = build_inputs(line, "main")
+            if b.get("image") is not None:
+                b["image"] = img_cache.setdefault(line["image"], b)["image"]
+            return b
+        mains = [main_inputs(l) for l in lines]
+        kw = dict(generate_kw)
+        if noise_step is not None and "image" in mains[0]:
+            from .vcd_add_noise import add_diffusion_noise
+            kw["images_cd"] = [add_diffusion_noise(img_cache[l["image"]]["image"].to(engine.device), noise_step) for l in lines]   # run_llava.py:187-190
+        main = _generate(engine, mains, max_new_tokens=max_new_tokens, n_top=10, eos_token_id=eos_token_id, pad_token_id=pad_token_id,
+                         min_new_tokens=min_new_tokens, **kw)
+        # content-free priors: plain sampling, only the step-0 distribution is used; min_new_tokens = 1 keeps EOS out of it as in
+        # the reference's calibration calls (run_qwen.py:111-131)
+        prior_kw = dict(max_new_tokens=1, n_top=10, **plain_kw)
+        if min_new_tokens:
+            prior_kw.update(min_new_tokens=min_new_tokens, eos_token_id=eos_token_id, pad_token_id=pad_token_id)
+        none = _generate(engine, [build_inputs(l, "none") for l in lines], **prior_kw)
+        unk = _generate(engine, [build_inputs(l, "unk") for l in lines], **prior_kw)
+        dicts = [[C.label_dict_from_top(t, p, decode_token) for t, p in zip(o.top_tok.cpu().tolist(), o.top_prob.cpu().tolist())]
+                 for o in (main, none, unk)]
+        for j, i in enumerate(idx):
+            toks = main.tokens[j].tolist()
+            for k, t in enumerate(toks):                       # cut at the first EOS (the rest is padding)
+                if t in eos_set:
+                    toks = toks[:k + 1]
+                    break
+            text = decode(toks).strip()
+            if stop_str and text.endswith(stop_str):
+                text = text[:-len(stop_str)]
+            records[i] = {"question_id": lines[j]["question_id"], "prompt": lines[j]["text"], "text": text.strip(), "naive": dicts[0][j],
+                          "none": dicts[1][j], "unk": dicts[2][j], "answer_id": uuid.uuid4().hex[:22], "model_id": model_id, "metadata": {}}
+        engine.clear_image_cache()
+    answers = [records[i] for i in range(len(qs_all))]
+    if answers_path is not None:
+        import json
+        import os
+        os.makedirs(os.path.dirname(os.path.abspath(answers_path)), exist_ok=True)
+        with open(answers_path, "w") as f:
+            for a in answers:
+                f.write(json.dumps(a) + "\n")
+    out = {"answers": answers, "results": {}, "scores": {}}
+    if gt is not None:
+        conv = C.mme_convert(answers, gt)
+        out["converted"] = conv
+        if results_root is not None:
+            out["results"] = C.write_mme_results(conv, results_root, experiment)
+            for name, d in out["results"].items():
+                try:
+                    out["scores"][name] = C.mme_scores(d)
+                except (FileNotFoundError, AssertionError):        # a chunk / subset without all 8 task files or with odd line counts
+                    out["scores"][name] = None
+    return out

@@ -65,8 +65,8 @@ def run_pope(engine: VddLlavaEngine, questions: Sequence[dict], encode: Callable
         kw = dict(generate_kw)
         if noise_step is not None:
             from .vcd_add_noise import add_diffusion_noise
-            noisy = {k: add_diffusion_noise(v, noise_step) for k, v in img_cache.items() if any(q["image"] == k for q in qs)}
-            kw["images_cd"] = [noisy[q["image"]] for q in qs]
+            # fresh noise per QUESTION, as the reference draws it inside its per-question loop (llava_calibrate.py:152-155)
+            kw["images_cd"] = [add_diffusion_noise(img_cache[q["image"]], noise_step) for q in qs]
         main = engine.generate(ids_main, images=imgs, max_new_tokens=max_new_tokens, n_top=10, eos_token_id=eos_token_id,
                                pad_token_id=pad_token_id, **kw)
         # content-free priors: plain sampling (no image -> no contrast branch), step-0 distribution only

@@ -20,6 +20,22 @@ _schedule = None
 _DT = {torch.float32: _lib.VDD_F32, torch.float16: _lib.VDD_F16, torch.bfloat16: _lib.VDD_BF16}
 
 
+_calls: dict = {}
+
+
+def reset_noise_calls(seed: Optional[int] = None):
+    """Restart the per-seed call counter (all seeds when None): the next add_diffusion_noise(..., seed=s) draws call 0 again."""
+    if seed is None:
+        _calls.clear()
+    else:
+        _calls.pop(int(seed) & 0xFFFFFFFFFFFFFFFF, None)
+
+
+def _rank() -> int:
+    import torch.distributed as dist
+    return dist.get_rank() if (dist.is_available() and dist.is_initialized()) else 0
+
+
 def schedule(num_steps: int = 1000):
     """(sqrt(abar), sqrt(1-abar)) as python floats per step — vcd_add_noise.py:7-16."""
     global _schedule
@@ -52,10 +68,21 @@ def add_diffusion_noise(image_tensor: torch.Tensor, noise_step: int, noise: Opti
                                             C.c_void_p, C.c_uint64, C.c_uint64, C.c_void_p]
     lib.vdd_add_diffusion_noise.restype = C.c_int
     sd = (torch.initial_seed() if seed is None else int(seed)) & 0xFFFFFFFFFFFFFFFF
-    # counter range of this call: drawn from torch's generator when no seed is given (each call advances it, manual_seed
-    # reproduces a run); an explicit seed is a pure function of (seed, image shape)
+    # Philox counter of element i = off + i / 4: the low 24 bits index inside the call (images up to 2^26 elements), the upper 40
+    # the CALL.  No seed: the call id is drawn from torch's generator (each call advances it like the reference's randn_like,
+    # vcd_add_noise.py:24; torch.manual_seed reproduces a run; 40 bits: two of ~10^3 images collide with probability ~5e-7).
+    # Explicit seed: the call id counts the calls made under that seed, so consecutive images get different epsilon while the
+    # sequence as a whole is a pure function of the seed (reset_noise_calls() restarts it).  The data-parallel rank is folded into
+    # the key so that ranks seeded alike do not noise their shards with one stream.
     from .sampling import fresh_offset
-    off = ((fresh_offset() if seed is None else 0) & ((1 << 23) - 1)) << 40
+    if x.numel() > (1 << 26):
+        raise ValueError("add_diffusion_noise: more than 2^26 elements in one call")
+    if seed is None:
+        call = fresh_offset() & ((1 << 40) - 1)
+    else:
+        call = _calls[sd] = _calls.get(sd, -1) + 1
+    off = (call & ((1 << 40) - 1)) << 24
+    sd = (sd ^ (_rank() * 0x9E3779B97F4A7C15)) & 0xFFFFFFFFFFFFFFFF
     with torch.cuda.device(x.device):
         _lib.check(lib.vdd_add_diffusion_noise(x.data_ptr(), y.data_ptr(), x.numel(), _DT[x.dtype], a[t], b[t],
                                                eps_ptr, sd, off, torch.cuda.current_stream(x.device).cuda_stream))

@@ -287,6 +287,68 @@ def gen_scorers():
     print("scorers:", out["eval_pope"], list(out["eval_pope_calibrate"]))
 
 
+def gen_mme_convert():
+    """Runs the reference's MME converter SCRIPT (experiments/eval/MME/convert_answer_to_mme_calibrate.py) unmodified on a synthetic
+    benchmark tree + answers file and records what it writes.  The script hard-codes an absolute ground-truth path
+    (/mnt/data/xue.w/yf/data/MME_Benchmark) and cwd-relative answer paths, so it runs in a scratch cwd inside a wrapper process
+    that only remaps that path prefix to the scratch tree for os.listdir / os.path.isdir / os.path.exists / open."""
+    import subprocess
+    import tempfile
+    from ref_shim import REF_ROOT
+    rng = np.random.default_rng(23)
+    cats = ["existence", "count", "position", "color", "commonsense_reasoning", "numerical_calculation", "text_translation", "code_reasoning"]
+    gt_rows, answers = [], []
+    words = ["Yes", "No", "yes", "no.", "Maybe", "Yes, it is"]
+    for ci, cat in enumerate(cats):
+        for img in range(3):
+            ext = "png" if ci % 2 else "jpg"
+            for qi in range(2):
+                base_q = f"Is there item {img}-{qi} in the {cat} picture?"
+                double = (img + qi + ci) % 3 == 0                      # some ground-truth questions carry the double space
+                gt_q = base_q + ("  " if double else " ") + "Please answer yes or no."
+                gt_rows.append((cat, f"{img:04d}.txt", gt_q, "Yes" if rng.random() < 0.5 else "No", ci % 2 == 0))
+
+                def td():
+                    d = {"yes": float(rng.random()), "no": float(rng.random()), "maybe": 0.01}
+                    if rng.random() < 0.15:
+                        d.pop("no")
+                    return d
+                prompt = base_q + "\nAnswer the question using a single word or phrase." if (img + qi) % 2 == 0 else gt_q
+                answers.append({"question_id": f"{cat}/{img:04d}.{ext}", "prompt": prompt, "text": words[int(rng.integers(len(words)))],
+                                "naive": td(), "none": td(), "unk": td()})
+    out = {"gt": [list(r[:4]) for r in gt_rows], "answers": answers, "results": {}}
+    with tempfile.TemporaryDirectory() as d:
+        bench = os.path.join(d, "MME_Benchmark")
+        for cat, file, q, a, nested in gt_rows:
+            qa = os.path.join(bench, cat, "questions_answers_YN") if nested else os.path.join(bench, cat)
+            os.makedirs(qa, exist_ok=True)
+            if nested:
+                os.makedirs(os.path.join(bench, cat, "images"), exist_ok=True)
+            with open(os.path.join(qa, file), "a") as f:
+                f.write(q + "\t" + a + "\n")
+        os.makedirs(os.path.join(d, "eval/MME/answers/MME_sft_dd"))
+        open(os.path.join(d, "eval/MME/answers/MME_sft_dd/exp.jsonl"), "w").write("\n".join(json.dumps(x) for x in answers))
+        script = os.path.join(REF_ROOT, "experiments/eval/MME/convert_answer_to_mme_calibrate.py")
+        wrapper = (
+            "import os, sys, builtins, runpy\n"
+            "PRE, REAL = '/mnt/data/xue.w/yf/data/MME_Benchmark', sys.argv[1]\n"
+            "m = lambda p: REAL + p[len(PRE):] if isinstance(p, str) and p.startswith(PRE) else p\n"
+            "for mod, name in ((os, 'listdir'), (os.path, 'isdir'), (os.path, 'exists'), (builtins, 'open')):\n"
+            "    f = getattr(mod, name)\n"
+            "    setattr(mod, name, (lambda f: lambda p, *a, **k: f(m(p), *a, **k))(f))\n"
+            "sys.dont_write_bytecode = True\n"
+            "sys.argv = [sys.argv[2], '--experiment', 'exp']\n"
+            "runpy.run_path(sys.argv[0], run_name='__main__')\n")
+        subprocess.run([sys.executable, "-c", wrapper, bench, script], cwd=d, check=True, capture_output=True, text=True,
+                       env={**os.environ, "PYTHONDONTWRITEBYTECODE": "1"})
+        for name in ("naive", "none", "unk", "none_unk"):
+            rd = os.path.join(d, "eval/MME/eval_tool/answers", f"exp-{name}")
+            out["results"][name] = {f[:-4]: open(os.path.join(rd, f)).read().splitlines() for f in sorted(os.listdir(rd))}
+    with open(os.path.join(HERE, "mme_convert.json"), "w") as f:
+        json.dump(out, f)
+    print("mme_convert:", {k: sum(len(v) for v in r.values()) for k, r in out["results"].items()})
+
+
 PROC_SPECS = [
     # (name, spec); spec keys: min_new (n, eos list), min_len (n, eos list), rep (penalty), stop (True: sequences taken from a
     # processor-free run of the same case so that they really occur)
@@ -377,3 +439,4 @@ if __name__ == "__main__":
     gen_calibration()
     gen_scorers()
     gen_processors()
+    gen_mme_convert()

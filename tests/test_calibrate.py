@@ -79,3 +79,46 @@ def test_mme_scorer_matches_reference_on_its_own_answer_set(golden_dir):
         assert got[k] == pytest.approx(v, abs=1e-9), k
     assert C.mme_parse_pred("yes") == "yes" and C.mme_parse_pred("no, it") == "no" and C.mme_parse_pred("maybe") == "other"
     assert C.mme_parse_pred("the yes") == "other"          # only the first 4 characters are searched
+
+
+def test_mme_convert_matches_the_reference_converter_script():
+    """tests/golden/mme_convert.json: what experiments/eval/MME/convert_answer_to_mme_calibrate.py (run unmodified, make_golden.py
+    gen_mme_convert) wrote for a synthetic benchmark tree + answers file: 'naive' keeps the text, none / unk / none_unk answer by the
+    individually calibrated arg-max; the ground-truth key quirks (single-word suffix dropped, double-space variant) included."""
+    import json
+    import os
+    from llava_align_amd import calibrate as C
+    g = json.load(open(os.path.join(os.path.dirname(__file__), "golden", "mme_convert.json")))
+    gt = {(c, f, q): a for c, f, q, a in g["gt"]}
+    got = C.mme_convert(g["answers"], gt)
+    assert set(got) == set(g["results"]) == {"naive", "none", "unk", "none_unk"}
+    for name, cats in g["results"].items():
+        assert got[name] == cats, name
+    # the calibrated variants really differ from each other and from the generated text somewhere
+    flat = lambda n: [l.split("\t")[3] for c in sorted(got[n]) for l in got[n][c]]
+    assert flat("none") != flat("unk") and flat("none_unk") != flat("none") and set(flat("none")) <= {"Yes", "No"}
+    assert any("  Please answer yes or no." in l for c in got["naive"].values() for l in c)
+
+
+def test_mme_results_files_feed_the_scorer(tmp_path):
+    import json
+    import os
+    from llava_align_amd import calibrate as C
+    g = json.load(open(os.path.join(os.path.dirname(__file__), "golden", "mme_convert.json")))
+    gt = {(c, f, q): a for c, f, q, a in g["gt"]}
+    dirs = C.write_mme_results(C.mme_convert(g["answers"], gt), str(tmp_path), "exp")
+    for name, d in dirs.items():
+        assert sorted(os.listdir(d)) == sorted(f"{c}.txt" for c in g["results"][name])
+        assert open(os.path.join(d, "color.txt")).read().splitlines() == g["results"][name]["color"]
+        s = C.mme_scores(d)
+        assert set(s) == {"Perception", "Cognition"} and 0 <= s["Perception"]["total"] <= 800
+    # mme_load_gt reads the benchmark tree back (both layouts: <cat>/*.txt and <cat>/questions_answers_YN/*.txt next to images/)
+    bench = tmp_path / "bench"
+    for c, f, q, a in g["gt"]:
+        d = bench / c / "questions_answers_YN" if c in ("existence", "position") else bench / c
+        d.mkdir(parents=True, exist_ok=True)
+        if c in ("existence", "position"):
+            (bench / c / "images").mkdir(exist_ok=True)
+        with open(d / f, "a") as fp:
+            fp.write(q + "\t" + a + "\n")
+    assert C.mme_load_gt(str(bench)) == gt

@@ -1,0 +1,167 @@
+"""Config #4 / #5 drivers over the engine: mme_driver.run_mme (LLaVA and Qwen call shapes, run_llava.py / run_qwen.py +
+convert_answer_to_mme_calibrate.py + calculation.py) and blip_driver.run_blip_pope (blip_calibrate.py), against the reference's
+per-question procedure restated with the oracle loop over the fp32 reference model."""
+import json
+import os
+
+import numpy as np
+import pytest
+import torch
+
+from oracle import vdd_oracle as O
+from ref_llava import RefLlava
+
+pytestmark = pytest.mark.gpu
+DEV = "cuda:0"
+CATS = ["existence", "count", "position", "color", "commonsense_reasoning", "numerical_calculation", "text_translation", "code_reasoning"]
+
+
+def decode_token(t):
+    return {0: "yes", 1: " Yes", 2: "no", 3: "No "}.get(t % 11, f"w{t}")
+
+
+def decode(ids):
+    return " ".join(decode_token(t).strip() for t in ids)
+
+
+def toy_encode(prompt):
+    """'<image>' -> -200; every other word -> a stable id in [3, 1000)."""
+    out = []
+    for w in prompt.replace("<image>", " <image> ").split():
+        out.append(-200 if w == "<image>" else (sum(ord(c) * (i + 1) for i, c in enumerate(w)) % 997) + 3)
+    return [1] + out
+
+
+def mme_questions(n_img=2):
+    qs, gt = [], {}
+    for ci, cat in enumerate(CATS):
+        for im in range(n_img):
+            for k in range(2):
+                text = f"Is thing {ci}{im}{k} here?"
+                qs.append({"question_id": f"{cat}/{im:04d}.png", "image": f"{cat}/{im:04d}.png", "category": cat,
+                           "text": text + "\nAnswer the question using a single word or phrase."})
+                gt[(cat, f"{im:04d}.txt", text + " Please answer yes or no.")] = ("Yes", "No")[(ci + im + k) % 2]
+    qs.append({"question_id": "artwork/0001.png", "image": "artwork/0001.png", "category": "artwork", "text": "filtered out"})
+    return qs, gt
+
+
+@pytest.fixture(scope="module")
+def eng():
+    from llava_align_amd.engine import LlavaWeights, VddLlavaEngine, preset
+    cfg = preset("tiny")
+    return VddLlavaEngine(cfg, weights=LlavaWeights.random(cfg, DEV, seed=3, std=0.06), device=DEV, use_graph=False)
+
+
+def test_run_mme_llava_call_shape_against_the_per_question_procedure(eng, tmp_path):
+    from llava_align_amd import calibrate as C
+    from llava_align_amd.mme_driver import ONE_WORD, llava_mme_inputs, run_mme, vicuna_v1_prompt
+    ref = RefLlava(eng.w, device=DEV)
+    qs, gt = mme_questions()
+    images = {}
+
+    def load_image(name):
+        if name not in images:
+            images[name] = torch.randn(3, 56, 56, generator=torch.Generator().manual_seed(len(images)))
+        return images[name]
+    build = llava_mme_inputs(toy_encode, load_image, unk_token_id=0)
+    res = run_mme(eng, qs, build, decode, answers_path=str(tmp_path / "a" / "ans.jsonl"), batch_questions=12, max_new_tokens=3,
+                  gt=gt, results_root=str(tmp_path / "res"), experiment="tiny", use_dd_unk=True, cd_alpha=1.0, cd_beta=0.1,
+                  temperature=0.5, cd_greedy=True)
+    lines = [json.loads(l) for l in open(tmp_path / "a" / "ans.jsonl")]
+    assert len(lines) == 32 and [l["question_id"] for l in lines] == [q["question_id"] for q in qs[:-1]]       # 'artwork' is filtered
+    assert set(lines[0]) == {"question_id", "prompt", "text", "naive", "none", "unk", "answer_id", "model_id", "metadata"}
+    assert set(res["results"]) == {"naive", "none", "unk", "none_unk"}
+    for name, d in res["results"].items():
+        assert sorted(os.listdir(d)) == sorted(c + ".txt" for c in CATS)
+        assert res["scores"][name] is not None and 0 <= res["scores"][name]["Perception"]["total"] <= 800
+    assert res["converted"] == C.mme_convert(lines, gt)
+
+    def step0(ids, img, **kw):
+        kw = dict(images=img[None] if img is not None else None, attention_mask=torch.ones(1, len(ids), dtype=torch.long), use_cache=True,
+                  cd_alpha=1.0, cd_beta=0.1, **kw)
+        r = O.reference_loop(ref, torch.tensor([ids]), warp=O.WarpConfig(temperature=0.5), max_length=len(ids) + 1, pad_token_id=None,
+                             eos_token_id=None, pick=O.pick_argmax, **kw)
+        tp, tt = torch.topk(torch.softmax(r.scores[0][0].float(), -1), 10)
+        return C.label_dict_from_top(tt.tolist(), tp.tolist(), decode_token)
+    for q, a in list(zip(qs, lines))[::5]:
+        text = q["text"]
+        ids_main = toy_encode(vicuna_v1_prompt("<image>\n" + text))
+        ids_unk = [0 if t == -200 else t for t in toy_encode(vicuna_v1_prompt("<image>\n" + text + ONE_WORD))]
+        want = (step0(ids_main, images[q["image"]], use_dd_unk=True), step0(toy_encode(vicuna_v1_prompt(text + ONE_WORD)), None),
+                step0(ids_unk, None))
+        for got, w in zip((a["naive"], a["none"], a["unk"]), want):
+            pg, pw = np.array(C.get_prob_from_logits(got)), np.array(C.get_prob_from_logits(w))
+            assert np.abs(pg - pw).max() <= 0.05 + 0.15 * pw.max(), (q["question_id"], pg, pw)
+
+
+def test_run_mme_qwen_call_shape_dual_pass_and_calibrate():
+    """run_qwen.py:190-221: prompts as embeddings (256 image slots + text), min_new_tokens=1, pad = eos = eod id, use_dd_unk whose
+    image-free branch re-runs the SAME inputs, then the two text-only prior passes and the affine calibration."""
+    from llava_align_amd import calibrate as C
+    from llava_align_amd.engine import LlavaWeights, VddLlavaEngine, preset
+    from llava_align_amd.mme_driver import qwen_mme_inputs, run_mme
+    cfg = preset("tiny-qwen")
+    eng = VddLlavaEngine(cfg, weights=LlavaWeights.random(cfg, DEV, seed=5, std=0.06), device=DEV, use_graph=True)
+    qs, gt = mme_questions(n_img=1)
+    table = eng.w.t["embed"]
+    g = torch.Generator(device=DEV).manual_seed(1)
+    feats = {}
+
+    def embed_prompt(text, path):
+        ids = torch.tensor([t for t in toy_encode(text) if t >= 0], device=DEV)
+        e = table[ids]
+        if path is not None:                                          # 16 "resampler" slots stand in for Qwen's 256
+            if path not in feats:
+                feats[path] = (torch.randn(16, cfg.lm.d, device=DEV, generator=g) * 0.06).to(torch.bfloat16)
+            e = torch.cat([e[:1], feats[path], e[1:]], 0)
+        return e
+    eod = 151643
+    res = run_mme(eng, qs, qwen_mme_inputs(embed_prompt), decode, batch_questions=8, max_new_tokens=4, min_new_tokens=1, eos_token_id=eod,
+                  pad_token_id=eod, gt=gt, use_dd_unk=True, cd_alpha=1.0, cd_beta=0.1, temperature=0.5, cd_greedy=True, output_scores=True)
+    assert len(res["answers"]) == 16 and set(res["converted"]) == {"naive", "none", "unk", "none_unk"}
+    # the dual pass really ran two rows per question with identical inputs; their contrast keeps exactly the beta-plausible set of v
+    emb = [embed_prompt("<img>{}</img>{} Answer:".format(q["image"], q["text"]), q["image"]) for q in qs[:4]]
+    dd = eng.generate(None, inputs_embeds=emb, use_dd_unk=True, cd_alpha=1.0, cd_beta=0.1, temperature=0.5, cd_greedy=True, max_new_tokens=2,
+                      output_scores=True, min_new_tokens=1, eos_token_id=eod, pad_token_id=eod)
+    plain = eng.generate(None, inputs_embeds=emb, temperature=0.5, cd_greedy=True, max_new_tokens=2, output_scores=True)
+    assert dd.stats["n_rows"] == 8 and plain.stats["n_rows"] == 4
+    s_dd, s_pl = dd.scores[0].float(), plain.scores[0].float()
+    assert torch.isneginf(s_dd[:, eod]).all()                         # min_new_tokens=1 at step 0
+    keep = torch.isfinite(s_dd)
+    cut = s_pl.max(-1, keepdim=True).values + np.log(0.1) / 0.5
+    assert ((s_pl >= cut + 0.3) & ~keep).sum() <= 4 and ((s_pl < cut - 0.3) & keep).sum() == 0     # beta mask of v (eos aside)
+    assert (s_dd[keep] - s_pl[keep]).abs().max() <= 0.3               # (1+a) v - a c with c ~ v  ->  v
+
+
+def test_run_blip_pope_vcd_against_direct_front_end_and_engine_calls(tmp_path):
+    from llava_align_amd import calibrate as C
+    from llava_align_amd.blip_driver import QUESTION_SUFFIX, map_pad_to_eos, run_blip_pope
+    from llava_align_amd.blip_frontend import BlipWeights, InstructBlipFrontEnd, tiny_blip_config
+    from llava_align_amd.engine import LlavaWeights, VddLlavaEngine, preset
+    cfg = preset("tiny")
+    eng = VddLlavaEngine(cfg, weights=LlavaWeights.random(cfg, DEV, seed=3, std=0.06), device=DEV, use_graph=False)
+    front = InstructBlipFrontEnd(BlipWeights.random(tiny_blip_config(), DEV, seed=4, std=0.05))
+    images = {f"im{i}.jpg": torch.randn(3, 56, 56, generator=torch.Generator().manual_seed(70 + i)) for i in range(2)}
+    qs = [{"question_id": i, "image": f"im{i % 2}.jpg", "text": f"Is there a thing{i}?", "label": ("yes", "no")[i % 2]} for i in range(5)]
+    tok_llm = lambda p: [t % 997 + 3 for t in toy_encode(p)]
+    tok_qf = lambda p: [101] + [t % 400 + 5 for t in toy_encode(p)[1:9]] + [102]
+    torch.manual_seed(11)
+    res = run_blip_pope(eng, front, qs, tok_llm, tok_qf, decode, lambda n: images[n], answers_path=str(tmp_path / "blip.jsonl"),
+                        use_cd=True, noise_step=500, cd_beta=0.1, max_length=4, cd_greedy=True, output_scores=True)
+    lines = [json.loads(l) for l in open(tmp_path / "blip.jsonl")]
+    assert [l["question_id"] for l in lines] == list(range(5))
+    assert set(lines[0]) == {"question_id", "prompt", "text", "model_id", "image", "naive", "noise", "zeros", "metadata"}
+    assert lines[0]["prompt"].endswith(QUESTION_SUFFIX) and lines[0]["model_id"] == "instruct_blip"
+    assert set(res["scores"]) == {"string_match", "naive", "noise", "zeros"}
+    # the zeros prior is deterministic: recompute it directly (front end on a zero image -> plain step-0 top-10)
+    for q, a in zip(qs, lines):
+        p = q["text"] + QUESTION_SUFFIX
+        emb, _ = front.build(torch.zeros(1, 3, 56, 56, device=DEV), [tok_llm(p)], eng.w.t["embed"], qformer_text_ids=[tok_qf(p)])
+        o = eng.generate(None, inputs_embeds=emb, max_length=1, min_length=1, eos_token_id=2, pad_token_id=2, n_top=10, temperature=1.0)
+        want = C.label_dict_from_top(o.top_tok[0].tolist(), o.top_prob[0].tolist(), decode_token)
+        pg, pw = np.array(C.get_prob_from_logits(a["zeros"])), np.array(C.get_prob_from_logits(want))
+        assert np.abs(pg - pw).max() <= 0.02 + 0.05 * pw.max()
+        assert a["noise"] != a["zeros"]
+    assert map_pad_to_eos(torch.tensor([[5, 0, 0], [0, 7, 2]])).tolist() == [[5, 2, 2], [2, 7, 2]]
+    # VCD at step 0 only (alpha 0.5 = the sampler default the reference driver leaves in place): masked entries appear in the
+    # main pass's scores
