@@ -273,8 +273,9 @@ def test_lavis_call_shape_inputs_embeds_with_vcd_embeddings(eng):
                 if o.tokens[q, step].item() != r.sequences[0, step].item():
                     break
     assert checked >= 4
-    with pytest.raises(ValueError, match="use_dd"):
-        eng.generate(None, inputs_embeds=embs, use_dd_unk=True, max_new_tokens=2)
+    # use_dd_unk on slot-free embeddings = the reference's Qwen case: the image-free branch re-runs the same inputs
+    dd = eng.generate(None, inputs_embeds=embs, use_dd_unk=True, max_new_tokens=2, cd_greedy=True)
+    assert dd.stats["n_rows"] == 6 and dd.tokens.shape == (3, 2)
 
 
 def test_qwen_shaped_lm_bias_and_large_vocab():
