@@ -188,9 +188,11 @@ int vdd_skinny_swiglu(const void* X, const void* W_gate_up, void* act, int M, in
  * epilogue: VDD_GEMM_NONE; _BIAS y = bf16(acc + bias[n]); _BIAS_QUICK_GELU / _BIAS_GELU act(bf16(acc + bias));
  *   _SWIGLU  W = [Wgate; Wup] (2N rows), Y[M, N] = bf16(bf16(silu(bf16 gate)) * bf16 up), N % 128 == 0;
  *   _BIAS_RESID y = bf16(bf16(acc + bias) + resid[m, n]).
- * workspace: caller-owned device scratch of >= vdd_gemm_workspace_bytes(M, N) bytes whose first (tile-count) int32 words are
- *   ZERO before the first call (arrival counters of tiles cut across workgroups; every call leaves them zero again) - one
- *   buffer per stream, launches on a stream may share it.
+ * workspace: caller-owned device scratch of >= vdd_gemm_workspace_bytes(M, N) bytes (the same for every shape: a 4-MiB arrival-
+ *   counter region, one int32 per output tile - at most 2^20 tiles per launch - followed by one fp32 partial tile per workgroup)
+ *   whose counter region is ZERO before the first call (counters of tiles cut across workgroups; every completed call leaves
+ *   them zero again; after a launch that did NOT complete - device fault, abort - zero the region before the next call).  One
+ *   buffer per stream: launches on one stream may share it, launches that can run concurrently must not.
  * config: low 4 bits = macro tile (0 = 256x256; 1..8 = 256x256, 128x256, 256x128, 192x256, 256x192, 192x192, 192x128 (these
  *         three: no SwiGLU), 64x256 (a few dozen rows: the launch is a W stream)); bits 4-5 = schedule (0 hybrid: whole-tile rounds + stream-K remainder, 1 data-parallel only,
  *         2 stream-K only).  Every choice writes the same result up to the fp32 summation order of a K-split tile. */

@@ -443,6 +443,7 @@ __global__ void __launch_bounds__(WM * WN * 64) gemm_kernel(const GemmArgs a) {
 }
 
 int g_num_cu = 0;
+constexpr size_t COUNTER_BYTES = (size_t)4 << 20;      // arrival counters: one int32 per output tile of a launch
 
 int num_workgroups() {
     if (g_num_cu == 0) {
@@ -474,10 +475,15 @@ int launch_cfg(const GemmArgs& a0, int epi, int sched, void* workspace, int64_t 
         else if (sched == 2) a.dp_rounds = 0;                     // stream-K only
         else a.dp_rounds = rem == 0 ? full : (full > 0 ? full - 1 : 0);
     }
-    const size_t need = (size_t)a.Mt * a.Nt * sizeof(int) + 256 + (size_t)P * BM * BN * sizeof(float);
+    // Workspace layout: [COUNTER_BYTES of arrival counters | one fp32 partial tile per workgroup].  The counter region has a FIXED
+    // size: with the partials placed right behind the Mt x Nt counters of the CURRENT launch, the slabs of a launch with few tiles
+    // lay where a later launch with many tiles reads its counters (float bit patterns as arrival counts: a finisher that spins
+    // forever on a negative one, or adds partial sums that were never written on a large one).
+    if ((size_t)a.Mt * a.Nt * sizeof(int) > COUNTER_BYTES) return VDD_ERR_INVALID_ARG;
+    const size_t need = COUNTER_BYTES + (size_t)P * BM * BN * sizeof(float);
     if (!workspace || (size_t)workspace_bytes < need) return VDD_ERR_INVALID_ARG;
     a.counter = (int*)workspace;
-    a.partial = (float*)((char*)workspace + (((size_t)a.Mt * a.Nt * sizeof(int) + 255) & ~(size_t)255));
+    a.partial = (float*)((char*)workspace + COUNTER_BYTES);
     const dim3 grid(P), block(WM * WN * 64);
     const size_t smem = (BM == 64 ? 3 : 2) * (BM + BN) * 128 + ((BN / WN == 64) ? WM * WN * 4096 : 0);      // + the epilogue's staging blocks
     a.stage_out = ((a.ldy % 8) == 0 && (((uintptr_t)a.Y) & 15) == 0) ? 1 : 0;
@@ -513,9 +519,9 @@ int launch_cfg(const GemmArgs& a0, int epi, int sched, void* workspace, int64_t 
 extern "C" {
 
 int64_t vdd_gemm_workspace_bytes(int M, int N) {
-    // arrival counters of the smallest tile shape + one 256 x 256 fp32 partial per workgroup
-    const int64_t tiles = ((int64_t)(M + 127) / 128) * ((2 * (int64_t)N + 127) / 128);
-    return tiles * 4 + 512 + (int64_t)num_workgroups() * 256 * 256 * 4;
+    // fixed counter region (up to 2^20 tiles per launch) + one 256 x 256 fp32 partial per workgroup; the same for every shape
+    (void)M; (void)N;
+    return (int64_t)COUNTER_BYTES + (int64_t)num_workgroups() * 256 * 256 * 4;
 }
 
 int vdd_gemm(const void* X, const void* W, void* Y, const void* bias, const void* resid, int M, int N, int K,

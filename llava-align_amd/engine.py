@@ -908,7 +908,8 @@ class VddLlavaEngine:
         seg = plan["suffix"]
         # device-side Philox counter = (stream, step): graphs are seed-agnostic.  seed=None: the stream id is drawn from torch's
         # default generator, so every generate() call samples fresh numbers (the reference's torch.multinomial advances the
-        # generator too) and torch.manual_seed() reproduces a run; an explicit seed is a pure function of the seed
+        # generator too) and torch.manual_seed() reproduces a run's random numbers; an explicit seed is a pure function of the seed.
+        # (The bf16 logits they are applied to depend, in their last bits, on the GEMM schedule the tuner picked: ops.gemm_choices_export.)
         from .sampling import fresh_offset
         sd = (fresh_offset() if seed is None else int(seed)) & 0x3FFFFFFFFF
         ctr0 = sd << 24

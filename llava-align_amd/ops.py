@@ -139,13 +139,9 @@ def skinny_gemm(x, w, resid=None, out=None, n_split=1, slabs=False):
 
 def linear_to_norm(x, w):
     """Projection whose only consumer is the next RMSNorm's residual add (attention output / MLP down projection).  In the skinny
-    regime N = d gives only d/16 column blocks: the kernel then splits K eight ways inside a block (K % 256 == 0), or, failing
-    that, across blocks into fp32 slabs that the norm sums."""
-    M, K = x.shape
-    if M <= skinny_rows(w.shape[0], K) and K % 128 == 0 and w.shape[0] <= 8192 and K % 256 != 0:
-        for ns in (4, 2):
-            if K % (128 * ns) == 0:
-                return skinny_gemm(x, w, n_split=ns, slabs=True)
+    regime N = d gives only d/16 column blocks: the kernel then splits K eight ways INSIDE a block (eight waves, K % 256 == 0 for
+    every LLaVA / Qwen width).  (A second form - fp32 split-K slabs across blocks, summed by the norm - never fired for any K the
+    8-wave form does not cover and was removed; skinny_gemm(..., slabs=True) + rmsnorm(delta=slabs) remain as kernels.)"""
     return linear(x, w)
 
 
@@ -177,18 +173,28 @@ _gemm_choice = {}
 
 
 def _gemm_workspace(device, M, N):
-    """Per-device scratch of the persistent GEMM (arrival counters + one fp32 partial tile per workgroup).  The counters
-    must start at zero and every launch leaves them zero, so the buffer is only ever replaced by a larger zeroed one."""
+    """Scratch of the persistent GEMM (arrival counters + one fp32 partial tile per workgroup), one per (device, STREAM): two
+    GEMMs that may run at the same time (different streams) must not share counters or slabs; launches on one stream are ordered.
+    The counters must start at zero and every completed launch leaves them zero.  A graph captured on a stream keeps using that
+    stream's buffer on replay."""
     lib = _lib_ready()
     lib.vdd_gemm_workspace_bytes.restype = C.c_int64
     lib.vdd_gemm_workspace_bytes.argtypes = [_I, _I]
     need = lib.vdd_gemm_workspace_bytes(int(M), int(N))
-    ws = _gemm_ws.get(device)
+    key = (device, torch.cuda.current_stream(device).cuda_stream)
+    ws = _gemm_ws.get(key)
     if ws is None or ws.numel() < need:
         if torch.cuda.is_current_stream_capturing():
-            raise RuntimeError("the GEMM workspace must exist before a graph capture (run the step once eagerly)")
-        ws = _gemm_ws[device] = torch.zeros(max(need, 1 << 27), dtype=torch.uint8, device=device)
+            raise RuntimeError("the GEMM workspace must exist before a graph capture (run the step once eagerly on this stream)")
+        ws = _gemm_ws[key] = torch.zeros(need, dtype=torch.uint8, device=device)
     return ws
+
+
+def gemm_workspace_reset(device=None):
+    """Zero the arrival counters of every GEMM workspace (of `device`): needed only after a launch that did not complete."""
+    for (dev, _), ws in _gemm_ws.items():
+        if device is None or dev == torch.device(device):
+            ws[: 4 << 20].zero_()
 
 
 def _gemm_call(x, w, out, bias, resid, M, N, K, epi, config, ws):
@@ -210,15 +216,42 @@ def gemm(x, w, bias=None, resid=None, epi=EPI_NONE, out=None, config=None):
         return out
     ws = _gemm_workspace(x.device, M, N)
     if config is None:
-        key = (M if M <= GEMM_TUNE_MAX_M else 0, N, K, epi, GEMM_BATCH_INVARIANT)
+        key = _gemm_key(M, N, K, epi)
         config = _gemm_choice.get(key)
         if config is None:
             config = 1 + 16 if GEMM_BATCH_INVARIANT else 1
-            if M <= GEMM_TUNE_MAX_M and not torch.cuda.is_current_stream_capturing():
-                config = _gemm_tune(x, w, out, bias, resid, M, N, K, epi, ws)
-            _gemm_choice[key] = config
+            if M <= GEMM_TUNE_MAX_M and GEMM_AUTOTUNE:
+                if not torch.cuda.is_current_stream_capturing():
+                    config = _gemm_choice[key] = _gemm_tune(x, w, out, bias, resid, M, N, K, epi, ws)
+                # (under capture: the default for this launch only - caching it would pin an untuned choice for the process)
+            else:
+                _gemm_choice[key] = config
     _gemm_call(x, w, out, bias, resid, M, N, K, epi, config, ws)
     return out
+
+
+GEMM_AUTOTUNE = True            # False: 256 x 256 tiles + the hybrid schedule for every shape (no timing runs at all)
+
+
+def _gemm_key(M, N, K, epi):
+    """Tuning granularity: shapes up to GEMM_TUNE_MAX_M rows are bucketed by their number of 64-row units (the decode batch and
+    the per-image ViT calls repeat a handful of sizes; a prefill length that differs by a few tokens must not re-run 24 candidates
+    and clone 640 MiB of weights); everything above shares one entry."""
+    return (-(-M // 64) if M <= GEMM_TUNE_MAX_M else 0, N, K, epi, GEMM_BATCH_INVARIANT)
+
+
+def gemm_choices_export() -> dict:
+    """The tuner's choices so far as a JSON-able dict.  The winner among schedules is picked by wall-clock timing and stream-K cuts
+    change the fp32 summation order of a tile, so two processes may settle on different (equally valid) low-order bits for the same
+    seed; a deployment that needs run-to-run identical logits exports the choices once and imports them at start-up (or sets
+    GEMM_BATCH_INVARIANT, which pins the data-parallel schedule)."""
+    return {",".join(map(str, k)): v for k, v in _gemm_choice.items()}
+
+
+def gemm_choices_import(d: dict):
+    for k, v in d.items():
+        b, N, K, epi, inv = k.split(",")
+        _gemm_choice[(int(b), int(N), int(K), int(epi), inv == "True")] = int(v)
 
 
 def _gemm_tune(x, w, out, bias, resid, M, N, K, epi, ws, iters=8):

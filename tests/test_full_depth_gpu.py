@@ -1,0 +1,135 @@
+"""The engine at FULL depth (32 decoder layers of LLaVA-1.5-7B shapes) against the fp32 torch LLaVA (tests/ref_llava.py) driven by the
+oracle loop.  A bf16 engine cannot be bit-exact with an fp32 (or any other) GEMM implementation, so what is asserted is what IS
+guaranteed, with the measured numbers recorded in DESIGN.md section 2:
+  * step-0 logit error against depth (1 / 8 / 16 / 32 layers of the same weights) grows like sqrt(depth) - accumulated bf16
+    rounding of the residual stream, not a systematic error - and stays below the error of the reference's own eager bf16 stack;
+  * over a 16-token decode (KV growth, the captured graph) the engine's token equals the fp32 reference's wherever the fp32 top-1
+    margin exceeds twice the measured score noise, and the scores agree within that noise;
+  * the same for a sample of questions inside a 768-question batch (1,536 decode rows: stream-K GEMM schedules, grouped prefix pass).
+The bounds below are ~1.3x the values measured on MI355X (tools/depth_probe.py prints them)."""
+import copy
+
+import numpy as np
+import pytest
+import torch
+
+from oracle import vdd_oracle as O
+from ref_llava import RefLlava
+
+pytestmark = pytest.mark.gpu
+DEV = "cuda:0"
+
+
+def _prompts(n_img, per_img, seed, vocab=32000):
+    rng = np.random.default_rng(seed)
+    sys_tok = [1] + rng.integers(3, vocab, size=34).tolist()
+    ids, imgs = [], []
+    for i in range(n_img):
+        im = torch.randn(3, 336, 336, generator=torch.Generator().manual_seed(900 + i))
+        for _ in range(per_img):
+            ids.append(torch.tensor(sys_tok + [-200] + rng.integers(3, vocab, size=int(rng.integers(19, 29))).tolist()))
+            imgs.append(im)
+    return ids, imgs
+
+
+@pytest.fixture(scope="module")
+def model():
+    from llava_align_amd.engine import LlavaConfig, LlavaWeights, LMConfig, VisionConfig
+    cfg = LlavaConfig(LMConfig(n_layers=32, max_pos=1024), VisionConfig(layers=3), "full-depth")
+    w = LlavaWeights.random(cfg, DEV, seed=5, std=0.02, lm_head_gain=2.0)
+    return cfg, w, RefLlava(w, device=DEV)
+
+
+def _engine(w, n_layers, use_graph):
+    from llava_align_amd.engine import LlavaConfig, LMConfig, VddLlavaEngine, VisionConfig
+    cfg = LlavaConfig(LMConfig(n_layers=n_layers, max_pos=1024), VisionConfig(layers=3), f"depth-{n_layers}")
+    wl = copy.copy(w)
+    wl.cfg = cfg
+    return cfg, VddLlavaEngine(cfg, weights=wl, device=DEV, use_graph=use_graph)
+
+
+def test_logit_error_grows_like_sqrt_depth_and_stays_below_eager_bf16(model):
+    full, w, ref = model
+    ref16 = RefLlava(w, device=DEV, dtype=torch.bfloat16)             # what the reference's eager HF stack computes in (bf16 weights / matmuls)
+    ids, imgs = _prompts(1, 6, seed=31)
+    rows = []
+    for L in (1, 8, 16, 32):
+        cfg, eng = _engine(w, L, use_graph=False)
+        eng.generate(ids, images=imgs, use_dd_unk=True, cd_alpha=1.0, cd_beta=0.1, max_new_tokens=1, cd_greedy=True)
+        got = eng.debug_logits0.float().cpu()
+        ref.cfg = ref16.cfg = cfg
+        e_eng, e_16 = [], []
+        for q in range(len(ids)):
+            unk = ids[q].clone(); unk[unk == -200] = 0
+            for b, (i_, im) in enumerate(((ids[q], imgs[q][None]), (unk, None))):
+                want = ref(input_ids=i_[None], images=im).logits[0, -1].float()
+                e_eng.append((got[b * len(ids) + q] - want).abs().max().item())
+                e_16.append((ref16(input_ids=i_[None], images=im).logits[0, -1].float() - want).abs().max().item())
+        rows.append((L, max(e_eng), float(np.mean(e_eng)), max(e_16), float(np.mean(e_16))))
+        print(f"depth {L:2d}: engine max |dlogit| {max(e_eng):.3f} (mean of row maxima {np.mean(e_eng):.3f}); eager bf16 {max(e_16):.3f} ({np.mean(e_16):.3f})")
+        del eng
+        torch.cuda.empty_cache()
+    ref.cfg = full
+    for L, emax, emean, bmax, bmean in rows:
+        assert emax <= 0.10 + 0.17 * L ** 0.5, (L, emax)              # measured 0.16 / 0.45 / 0.56 / 0.81 at logit sigma 2.56
+        assert emean <= 1.25 * bmean + 0.05, (L, emean, bmean)        # no worse than the reference's own bf16 arithmetic
+    assert rows[-1][2] <= 8.0 * rows[0][2]                             # sqrt(32) = 5.7x: random-walk growth, not linear (32x)
+
+
+def _agreement(out, ref, ids, imgs, questions, n_new, mode_kw, warp_kw):
+    """-> (checked tokens, agreeing tokens among the checked, max score error on entries finite on both sides)."""
+    checked = agree = 0
+    noise = 0.0
+    per_q = []
+    for q in questions:
+        kw = dict(images=imgs[q][None], attention_mask=torch.ones(1, ids[q].numel(), dtype=torch.long), use_cache=True, cd_alpha=1.0,
+                  cd_beta=0.1, **mode_kw)
+        r = O.reference_loop(ref, ids[q][None].clone(), warp=O.WarpConfig(**warp_kw), max_length=ids[q].numel() + n_new, pad_token_id=None,
+                             eos_token_id=None, pick=O.pick_argmax, **kw)
+        per_q.append((q, r))
+        want, got = r.sequences[0, ids[q].numel():].tolist(), out.tokens[q].tolist()
+        for step in range(n_new):
+            s_got, s_want = out.scores[step][q].float().cpu(), r.scores[step][0].float().cpu()
+            fin = torch.isfinite(s_got) & torch.isfinite(s_want)
+            assert fin.sum() >= 1, (q, step)
+            noise = max(noise, (s_got[fin] - s_want[fin]).abs().max().item())
+            if got[step] != want[step]:
+                break                                               # a near-tie flipped: different sequences from here on
+    for q, r in per_q:
+        want, got = r.sequences[0, ids[q].numel():].tolist(), out.tokens[q].tolist()
+        for step in range(n_new):
+            top2 = torch.topk(r.scores[step][0].float(), 2).values
+            if (top2[0] - top2[1]).item() > 2 * noise:
+                checked += 1
+                agree += int(got[step] == want[step])
+            if got[step] != want[step]:
+                break
+    return checked, agree, noise
+
+
+def test_full_depth_decode_matches_fp32_where_the_margin_clears_the_noise(model):
+    full, w, ref = model
+    _, eng = _engine(w, 32, use_graph=True)
+    ids, imgs = _prompts(1, 6, seed=32)
+    n_new = 16
+    out = eng.generate(ids, images=imgs, use_dd_unk=True, cd_alpha=1.0, cd_beta=0.1, temperature=1.0, max_new_tokens=n_new, cd_greedy=True,
+                       output_scores=True)
+    assert out.stats["graph"] and out.stats["n_rows"] == 12
+    checked, agree, noise = _agreement(out, ref, ids, imgs, range(6), n_new, dict(use_dd_unk=True), dict(temperature=1.0))
+    print(f"32 layers, 6 questions x 2 branches, {n_new} tokens: score noise {noise:.3f}; {agree}/{checked} tokens agree where margin > 2 x noise")
+    assert noise <= 3.0                                               # (1+a) e_v + a e_c with |e| <= 0.8: measured ~1.5
+    assert checked >= 12 and agree == checked
+
+
+def test_full_depth_at_1536_rows_sampled_questions_match_fp32(model):
+    full, w, ref = model
+    _, eng = _engine(w, 32, use_graph=True)
+    ids, imgs = _prompts(128, 6, seed=33)
+    n_new = 6
+    out = eng.generate(ids, images=imgs, use_dd_unk=True, cd_alpha=1.0, cd_beta=0.1, temperature=1.0, max_new_tokens=n_new, cd_greedy=True,
+                       output_scores=True)
+    assert out.stats["n_rows"] == 1536 and out.stats["n_groups"] > 0
+    sample = list(range(0, 768, 97))                                  # 8 questions from different images
+    checked, agree, noise = _agreement(out, ref, ids, imgs, sample, n_new, dict(use_dd_unk=True), dict(temperature=1.0))
+    print(f"32 layers, 1,536 rows: score noise {noise:.3f}; {agree}/{checked} tokens agree where margin > 2 x noise")
+    assert noise <= 3.0 and checked >= 6 and agree == checked

@@ -404,6 +404,29 @@ def test_gemm_repeated_launches_leave_the_arrival_counters_clean():
     assert torch.equal(O.gemm(x, w, config=1 + 32), first)
 
 
+def test_gemm_small_launch_slabs_do_not_poison_a_large_launch_counters():
+    """Round-3 regression (a hang found by tests/test_full_depth_gpu.py): the partial slabs used to start right behind the Mt x Nt
+    counters of the CURRENT launch, so the fp32 slabs of a launch with few tiles lay where a later launch with many tiles reads
+    its arrival counters (a negative float pattern = a finisher that spins forever; a positive one = partial sums added before
+    they were written).  The counter region is fixed now: a stream-K launch with ONE tile row, then launches with thousands of
+    tiles in every schedule, on one workspace."""
+    O = ops()
+    xs, w = bf(96, 4096, seed=60) * 50, bf(4096, 4096, scale=0.5, seed=61)             # large-magnitude slabs, both signs
+    for cfg in (8, 2, 1):
+        O.gemm(xs, w, config=cfg + 32)                                                     # stream-K only: every workgroup publishes a slab
+    xb = bf(40000, 4096, seed=62)
+    ref = _gemm_ref(xb, w, O.EPI_NONE, None, None)
+    tol = 2 ** -7 * ref.abs().max().item() + 1e-3
+    for cfg, sched in ((2, 0), (2, 2), (7, 0), (1, 2), (3, 0)):                          # up to 313 x 32 = 10,016 tiles
+        y = O.gemm(xb, w, config=cfg + 16 * sched)
+        assert (y.float() - ref).abs().max().item() <= tol, (cfg, sched)
+    import ctypes
+    from llava_align_amd import _lib
+    lib = _lib.load_lib()
+    lib.vdd_gemm_workspace_bytes.restype = ctypes.c_int64
+    assert lib.vdd_gemm_workspace_bytes(96, 4096) == lib.vdd_gemm_workspace_bytes(40000, 4096)     # one layout for every shape
+
+
 def test_gemm_rejects_what_it_cannot_do():
     O = ops()
     with pytest.raises(ValueError):
