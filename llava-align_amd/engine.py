@@ -277,7 +277,7 @@ class VisionTower:
                 gc_on = gc.isenabled()
                 gc.disable()
                 try:
-                    with torch.cuda.graph(g):
+                    with torch.cuda.graph(g, stream=side):          # the warm-up stream: its GEMM workspace exists (ops._gemm_workspace)
                         g_out = self._forward(g_in)
                 finally:
                     if gc_on:
@@ -646,7 +646,7 @@ class _DecodeRunner:
             gc_was_on = gc.isenabled()
             gc.disable()
             try:
-                with torch.cuda.graph(g):
+                with torch.cuda.graph(g, stream=side):              # the warm-up stream: its GEMM workspace exists (ops._gemm_workspace)
                     self.body(kv)
             finally:
                 if gc_was_on:
