@@ -89,3 +89,42 @@ def test_llava_13b_widths_three_branches_top_p_match_reference():
     ids, imgs = _prompts(6, 1, 32000, seed=22)                       # BASELINE config #3: one image per question, nothing to group
     out, checked = _compare(eng, ref, ids, imgs, dict(use_dd=True, use_dd_unk=True), dict(top_p=0.9), n_new=4, questions=range(6), tol=0.25)
     assert out.stats["n_rows"] == 18 and checked >= 6
+
+
+def test_qwen_7b_widths_bias_epilogue_and_151936_vocab_match_reference():
+    """BASELINE config #4 at Qwen-7B LM widths (d 4096, 32 heads, qkv bias, V = 151,936: the 151936 x 4096 lm_head through the MFMA
+    GEMM with 594 column tiles, the bias epilogue at N = 12,288, the sampling kernel's global-row path), 2 layers, 24 questions x 2
+    branches = 48 rows.  Prompts arrive as embeddings (256 image slots + text, run_qwen.py:176-177); use_dd_unk re-runs the same
+    inputs in the second branch (SURVEY A.3 #4, modeling_qwen.py:1089-1118); min_new_tokens = 1 and pad = eos = eod (run_qwen.py:190-213)."""
+    from ref_llava import RefLavisLM
+    eng = _engine(dict(d=4096, n_heads=32, n_kv_heads=32, head_dim=128, ffn=11008, vocab=151936, qkv_bias=True, eps=1e-6))
+
+    class RefQwenLM(RefLavisLM):
+        def prepare_inputs_for_generation_cd(self, input_ids, **kw):        # Qwen: the cd branch gets the SAME inputs
+            return self.prepare_inputs_for_generation(input_ids, **kw)
+    ref = RefQwenLM(eng.w, device=DEV)
+    g = torch.Generator().manual_seed(77)
+    embs = [torch.randn(256 + int(n), 4096, generator=g) * 0.02 for n in torch.randint(30, 50, (24,), generator=g)]
+    eod, n_new = 151643, 3
+    out = eng.generate(None, inputs_embeds=embs, use_dd_unk=True, cd_alpha=1.0, cd_beta=0.1, temperature=1.0, max_new_tokens=n_new,
+                       min_new_tokens=1, eos_token_id=eod, pad_token_id=eod, cd_greedy=True, output_scores=True, sync_every=1)
+    assert out.stats["n_rows"] == 48 and out.stats["graph"] and torch.isneginf(out.scores[0][:, eod]).all()
+    checked = 0
+    for q in range(0, 24, 4):
+        kw = dict(inputs_embeds=embs[q][None], attention_mask=torch.ones(1, embs[q].shape[0], dtype=torch.long), use_cache=True,
+                  cd_alpha=1.0, cd_beta=0.1, use_dd_unk=True)
+        r = O.reference_loop(ref, torch.zeros(1, 0, dtype=torch.long), warp=O.WarpConfig(temperature=1.0), max_length=n_new, pad_token_id=eod,
+                             eos_token_id=eod, pick=O.pick_argmax, processors=O.ProcessorList([O.MinNewTokens(0, 1, [eod])]), **kw)
+        for step in range(len(r.scores)):
+            s_got, s_want = out.scores[step][q].float().cpu(), r.scores[step][0].float().cpu()
+            fin = torch.isfinite(s_got) & torch.isfinite(s_want)
+            assert fin.sum() >= 1 and (torch.isfinite(s_got) ^ torch.isfinite(s_want)).sum() <= 3 + 0.25 * int(fin.sum()), (q, step)
+            tol_s = 0.25 + 0.02 * s_want[fin].abs().max().item()
+            assert (s_got[fin] - s_want[fin]).abs().max().item() <= tol_s, (q, step)
+            top2 = torch.topk(s_want, 2).values
+            if (top2[0] - top2[1]).item() > 2 * tol_s:
+                assert out.tokens[q, step].item() == r.sequences[0, step].item(), (q, step)
+                checked += 1
+            if out.tokens[q, step].item() != r.sequences[0, step].item():
+                break
+    assert checked >= 4
