@@ -77,9 +77,14 @@ def _row_view(t: torch.Tensor, name: str):
     return t
 
 
-# True: every contrast_sample call that does not say otherwise (the drop-in sample() and the engine included) uses torch-GPU's
-# scalar arithmetic for the plausibility cutoff and the temperature - what the reference computes when its tensors live on a GPU.
-GPU_SCALAR_SEMANTICS = False
+# True (the default since round 3): every contrast_sample call that does not say otherwise (the drop-in sample() and the engine
+# included) uses torch-GPU's scalar arithmetic for the plausibility cutoff and the temperature - what the reference computes when
+# its tensors live on a GPU, as in every one of its drivers (`.cuda()` before generate, llava_calibrate.py:163): log(beta) enters
+# the cutoff add as an fp32 scalar, `scores / T` is a multiplication by fl32(1 / T).  False: torch-CPU's arithmetic (log(beta)
+# demoted to the model dtype first, a true division).  Both forms are pinned bit for bit: tests/golden/kernel_vectors.* (the
+# reference run on a CPU) and tests/golden/kernel_vectors_gpu_scalar.* (the same run with the two GPU scalar paths emulated);
+# they differ by at most 1 ulp of the model dtype, on a handful of elements.
+GPU_SCALAR_SEMANTICS = True
 
 
 def contrast_sample(logits_v: torch.Tensor, logits_cd: Optional[torch.Tensor] = None,
@@ -108,7 +113,7 @@ def contrast_sample(logits_v: torch.Tensor, logits_cd: Optional[torch.Tensor] = 
 
     cutoff_f32_scalar / temp_reciprocal select torch-GPU's scalar arithmetic (log(beta) added in fp32 before the rounding, the
     temperature division as a multiply by the reciprocal) instead of torch-CPU's, which the golden vectors were made with; None =
-    the module default GPU_SCALAR_SEMANTICS (False).  Both forms are bit-exact against their own torch backend
+    the module default GPU_SCALAR_SEMANTICS (True: torch-GPU's).  Both forms are bit-exact against their own torch backend
     (tests/test_kernel_gpu.py::test_torch_gpu_eager_agrees_within_reference_tolerance); they differ by at most 1 ulp.
     """
     if cutoff_f32_scalar is None:

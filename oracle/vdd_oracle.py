@@ -47,13 +47,29 @@ def contrast_and_mask(v: torch.Tensor, c: torch.Tensor, alpha: float, beta: floa
     diffs  = (1+alpha)*v - alpha*c        (:193; three roundings in v's dtype)
     out    = where(v < cutoff, -inf, diffs)  (:194; the mask tests the ORIGINAL v, strict <)
     """
-    cutoff = torch.log(torch.tensor(beta)) + v.max(dim=-1, keepdim=True).values
+    if GPU_SCALAR:
+        # torch on a GPU: the 0-dim CPU tensor log(beta) enters the add as an fp32 SCALAR (not demoted to v's dtype first):
+        # fl_dtype(float(max) + fl32(log beta)), one rounding
+        cutoff = (v.max(dim=-1, keepdim=True).values.float() + torch.log(torch.tensor(beta))).to(v.dtype) if v.dtype != torch.float32 \
+            else torch.log(torch.tensor(beta)) + v.max(dim=-1, keepdim=True).values
+    else:
+        cutoff = torch.log(torch.tensor(beta)) + v.max(dim=-1, keepdim=True).values
     diffs = (1 + alpha) * v - alpha * c
     return diffs.masked_fill(v < cutoff, NEG_INF)
 
 
+# False: torch-CPU scalar arithmetic (what tests/golden/kernel_vectors.* were made with: the reference run on the build container's
+# CPU).  True: torch-GPU's (what the reference computes when its tensors live on a GPU, as in every driver): the plausibility cutoff
+# adds log(beta) as an fp32 scalar, and a division by a Python scalar is a multiplication by its fp32 reciprocal.  The two differ
+# by at most 1 ulp of the model dtype; tests/golden/kernel_vectors_gpu_scalar.* pins this form.
+GPU_SCALAR = False
+
+
 def warp_temperature(x: torch.Tensor, temperature: float) -> torch.Tensor:
     """HF TemperatureLogitsWarper (called at vcd_sample.py:198): scores / T."""
+    if GPU_SCALAR:
+        inv = torch.tensor(1.0, dtype=torch.float32) / torch.tensor(float(temperature), dtype=torch.float32)     # fl32(1 / T)
+        return (x.float() * inv).to(x.dtype)
     return x / temperature
 
 

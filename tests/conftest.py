@@ -11,8 +11,23 @@ for p in (ROOT, os.path.join(ROOT, "tests")):
 
 def pytest_configure(config):
     config.addinivalue_line("markers", "gpu: needs a real MI355X (run with `-m gpu` on the GPU box)")
+    config.addinivalue_line("markers", "gpu_scalar: run with torch-GPU scalar arithmetic (the package default) instead of torch-CPU's")
 
 
 @pytest.fixture(scope="session")
 def golden_dir():
     return os.path.join(ROOT, "tests", "golden")
+
+
+@pytest.fixture(autouse=True)
+def _cpu_scalar_semantics_for_cpu_made_goldens(request):
+    """The package default is torch-GPU scalar arithmetic (sampling.GPU_SCALAR_SEMANTICS = True).  Most fixtures and the oracle's
+    default follow the reference run on the build container's CPU, so tests run the kernels in the torch-CPU form unless they are
+    marked `gpu_scalar` (those check the default / the second golden set)."""
+    import llava_align_amd.sampling as S
+    from oracle import vdd_oracle as O
+    want = request.node.get_closest_marker("gpu_scalar") is not None
+    old = (S.GPU_SCALAR_SEMANTICS, O.GPU_SCALAR)
+    S.GPU_SCALAR_SEMANTICS = O.GPU_SCALAR = want
+    yield
+    S.GPU_SCALAR_SEMANTICS, O.GPU_SCALAR = old

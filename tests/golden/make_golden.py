@@ -80,9 +80,71 @@ def sparse_pack(t: torch.Tensor):
         int(torch.isnan(flat).sum()), int((flat == float("inf")).sum())
 
 
-def gen_kernel_vectors():
+class _GpuScalarEmulation:
+    """Runs the REAL reference sample() on the CPU with torch-GPU's scalar arithmetic at the two places where the backends differ
+    (found by probing torch-ROCm eager, tests/test_kernel_gpu.py::test_torch_gpu_eager_agrees_within_reference_tolerance):
+      * vcd_sample.py:191 `torch.log(torch.tensor(cd_beta)) + max`: on a GPU the 0-dim CPU tensor is an fp32 scalar operand,
+        fl_dtype(float(max) + fl32(log beta)); on the CPU it is demoted to the model dtype first.  Emulated by a Tensor subclass
+        returned from torch.log for 0-dim inputs whose `+` does the fp32 add;
+      * HF TemperatureLogitsWarper `scores / T`: on a GPU a multiplication by fl32(1 / T).  Emulated by a warper class that
+        replaces it in the warper list.
+    Everything else (the loop, contrast arithmetic, top-k / top-p warpers, softmax) is the unmodified reference / HF code."""
+
+    class F32Scalar(torch.Tensor):
+        @classmethod
+        def __torch_function__(cls, func, types, args=(), kwargs=None):
+            kwargs = kwargs or {}
+            if func in (torch.Tensor.__add__, torch.Tensor.add, torch.add, torch.Tensor.__radd__):
+                a, b = args[0], args[1]
+                s_, t = (a, b) if isinstance(a, cls) else (b, a)
+                with torch._C.DisableTorchFunctionSubclass():
+                    s32 = s_.as_subclass(torch.Tensor).float()
+                    return (t.float() + s32).to(t.dtype)
+            with torch._C.DisableTorchFunctionSubclass():
+                return func(*[x.as_subclass(torch.Tensor) if isinstance(x, cls) else x for x in args], **kwargs)
+
+    class RecipTemperature:
+        def __init__(self, t):
+            self.inv = torch.tensor(1.0, dtype=torch.float32) / torch.tensor(float(t), dtype=torch.float32)
+
+        def __call__(self, input_ids, scores):
+            return (scores.float() * self.inv).to(scores.dtype)
+
+    def __enter__(self):
+        import ref_shim
+        self._log, self._hw = torch.log, ref_shim.hf_warpers
+        real_log, F32 = torch.log, self.F32Scalar
+
+        def log(x, *a, **k):
+            y = real_log(x, *a, **k)
+            return y.as_subclass(F32) if (torch.is_tensor(x) and x.dim() == 0) else y
+        torch.log = log
+        real_hw, Recip = ref_shim.hf_warpers, self.RecipTemperature
+
+        def hf_warpers(temperature=None, **kw):
+            lst = real_hw(temperature=None, **kw)
+            if temperature is not None and temperature != 1.0:
+                lst.insert(0, Recip(temperature))
+            return lst
+        ref_shim.hf_warpers = hf_warpers
+        return self
+
+    def __exit__(self, *a):
+        import ref_shim
+        torch.log, ref_shim.hf_warpers = self._log, self._hw
+
+
+def gen_kernel_vectors_gpu_scalar():
+    """Second golden set: the same cases (V <= 32000; fp16 / bf16 - for fp32 the two backends agree) under torch-GPU scalar arithmetic."""
+    with _GpuScalarEmulation():
+        gen_kernel_vectors(out_name="kernel_vectors_gpu_scalar", keep=lambda c: c["dtype"] != "fp32" and c["V"] <= 32000)
+
+
+def gen_kernel_vectors(out_name="kernel_vectors", keep=lambda c: True):
     arrays, manifest = {}, []
     for ci, case in enumerate(kernel_cases()):
+        if not keep(case):
+            continue
         dt = DTYPES[case["dtype"]]
         rows = logit_rows(case["seed"], case["B"], case["V"], dt, case["n_in"], case["kind"], case["steps"])
         bank = [r for step in rows for r in step]
@@ -125,10 +187,10 @@ def gen_kernel_vectors():
     import transformers
     meta = {"torch": torch.__version__, "transformers": transformers.__version__, "numpy": np.__version__,
             "all_masked_row_raises": raised, "cases": manifest}
-    np.savez_compressed(os.path.join(HERE, "kernel_vectors.npz"), **arrays)
-    with open(os.path.join(HERE, "kernel_vectors.json"), "w") as f:
+    np.savez_compressed(os.path.join(HERE, out_name + ".npz"), **arrays)
+    with open(os.path.join(HERE, out_name + ".json"), "w") as f:
         json.dump(meta, f, indent=0)
-    print("kernel vectors:", len(manifest), "cases")
+    print(out_name + ":", len(manifest), "cases")
 
 
 def loop_kwargs(mode, ids, img, img_cd):
@@ -440,3 +502,4 @@ if __name__ == "__main__":
     gen_scorers()
     gen_processors()
     gen_mme_convert()
+    gen_kernel_vectors_gpu_scalar()

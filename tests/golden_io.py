@@ -68,3 +68,13 @@ def processor_case_rows(case):
 
 def processor_case_scores(case, arrays, step):
     return from_bits(arrays[f"p{case['id']}_s{step}"], DTYPES[case["dtype"]])
+
+
+def gpu_scalar_cases():
+    """tests/golden/kernel_vectors_gpu_scalar.*: the kernel-vector cases (fp16 / bf16, V <= 32000) from the reference run with
+    torch-GPU's scalar arithmetic emulated at the two places the backends differ (make_golden.py::_GpuScalarEmulation)."""
+    if "k2" not in _cache:
+        with open(os.path.join(GOLD, "kernel_vectors_gpu_scalar.json")) as f:
+            meta = json.load(f)
+        _cache["k2"] = (meta, np.load(os.path.join(GOLD, "kernel_vectors_gpu_scalar.npz")))
+    return _cache["k2"]

@@ -463,11 +463,12 @@ def test_torch_gpu_eager_agrees_within_reference_tolerance():
           "| default flags:", int((_bits(out.scores) != _bits(eager)).sum()))
     assert n_diff == 0
     import llava_align_amd.sampling as S                       # the process-wide switch reaches calls that do not pass the flags
+    old = S.GPU_SCALAR_SEMANTICS
     try:
         S.GPU_SCALAR_SEMANTICS = True
         out3 = L.contrast_sample(v, c, alpha=alpha, beta=beta, warp=L.WarpSpec(temperature=T), return_scores=True)
     finally:
-        S.GPU_SCALAR_SEMANTICS = False
+        S.GPU_SCALAR_SEMANTICS = old
     assert torch.equal(_bits(out3.scores), _bits(out2.scores))
 
 
@@ -489,3 +490,33 @@ def test_add_diffusion_noise_matches_oracle_with_explicit_noise(golden_dir):
     assert abs(n.mean().item()) < 0.01 and abs(n.std().item() - b[999].item()) < 0.01
     kurt = ((n / n.std()) ** 4).mean().item()
     assert abs(kurt - 3.0) < 0.1
+
+
+# ---- second golden set: the reference run with torch-GPU's scalar arithmetic (the package default) ---------------------------
+from golden_io import gpu_scalar_cases  # noqa: E402
+
+META2, ARR2 = gpu_scalar_cases()
+
+
+@pytest.mark.gpu_scalar
+@pytest.mark.parametrize("case", [c for c in META2["cases"] if not c["warp"].get("top_p")], ids=_ids([c for c in META2["cases"] if not c["warp"].get("top_p")]))
+def test_default_gpu_scalar_semantics_match_the_second_golden_set(case):
+    """No flags passed: the package default must be the torch-GPU form and reproduce kernel_vectors_gpu_scalar.* bit for bit."""
+    import llava_align_amd.sampling as S
+    L = _L()
+    assert S.GPU_SCALAR_SEMANTICS is True
+    rows = case_inputs(case)
+    warp = L.WarpSpec(**case["warp"])
+    for s, step_rows in enumerate(rows):
+        r = [t.to(DEV) for t in step_rows]
+        out = L.contrast_sample(r[0], r[1] if case["n_in"] >= 2 else None, r[2] if case["n_in"] == 3 else None, alpha=case["alpha"],
+                                beta=case["beta"], warp=warp, return_scores=True, pick_argmax=True)
+        ok, bad = check_scores(case, ARR2, s, out.scores.cpu())
+        assert ok, f"{bad} mismatching elements at step {s}"
+
+
+def test_package_default_is_the_gpu_form():
+    """(Outside the conftest fixture's reach: read the module source default.)"""
+    import inspect
+    import llava_align_amd.sampling as S
+    assert "\nGPU_SCALAR_SEMANTICS = True\n" in inspect.getsource(S)

@@ -165,3 +165,28 @@ def test_processor_fixture_bites():
         if "min_new" in c["spec"] or "min_len" in c["spec"]:
             masked_first += int(c["sequences"][0][len(c["ids"][0])] != c["free_tokens"][0][0])
     assert forced >= 20 and masked_first >= 20
+
+
+# ---- second golden set: torch-GPU scalar arithmetic ------------------------------------------------------------------------
+from golden_io import gpu_scalar_cases  # noqa: E402
+
+META2, ARR2 = gpu_scalar_cases()
+
+
+@pytest.mark.gpu_scalar
+@pytest.mark.parametrize("case", META2["cases"], ids=_ids(META2["cases"]))
+def test_step_scores_gpu_scalar_form_matches_second_golden_set(case):
+    assert O.GPU_SCALAR is True
+    rows = case_inputs(case)
+    warp = O.WarpConfig(**case["warp"])
+    for s, step_rows in enumerate(rows):
+        got = O.step_scores(step_rows[0], step_rows[1] if case["n_in"] >= 2 else None, step_rows[2] if case["n_in"] == 3 else None,
+                            case["alpha"], case["beta"], warp)
+        ok, bad = check_scores(case, ARR2, s, got)
+        assert ok, f"{bad} mismatching elements at step {s}"
+
+
+def test_the_two_golden_sets_differ_only_by_an_ulp_somewhere():
+    cpu = {c["id"]: c for c in META["cases"]}
+    differing = [c["id"] for c in META2["cases"] if c["sha256"] != cpu[c["id"]]["sha256"]]
+    assert 1 <= len(differing) <= len(META2["cases"]) // 4
