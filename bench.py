@@ -53,6 +53,9 @@ def parse_args():
     ap.add_argument("--questions", type=int, default=768, help="questions per generate() batch per GPU (6 per image); 768 = 1,536 decode rows, ~190 GB of KV pools + weights")
     ap.add_argument("--model", default="llava-1.5-7b")
     ap.add_argument("--no-baselines", action="store_true")
+    ap.add_argument("--strong", type=int, default=0, metavar="N_QUESTIONS",
+                    help="strong-scaling mode: ONE seeded list of N questions (6 per image) split over the ranks by shard.get_chunk "
+                         "(the reference's contiguous ceil-chunks, whole image groups), EOS on, ragged results gathered once")
     return ap.parse_args()
 
 
@@ -265,6 +268,75 @@ def bench_cpu(eng):
                                           f"{full} layers -> {t_full:.1f}s"}}
 
 
+# ------------------------------------------------------------------ strong scaling: one question list split over the ranks
+def run_strong(a, eng, dev, rank, world):
+    """`--strong N`: what the eval drivers do on a node (MME/run_llava.py:32-40): ONE seeded POPE-like list of N questions,
+    rank k takes get_chunk(N, world, k, group=6) (contiguous ceil-chunks of whole image groups), decodes it in batches of
+    --questions with EOS on (answers of 1-2 tokens: the EOS ids are the second tokens a 2-token probe of the shard emits), and
+    the per-question payload is gathered ONCE; rank 0 checks that the gathered question ids are 0..N-1 exactly once.
+    value = answer tokens of the whole list / max-over-ranks wall time, per timed step = one pass over the whole list."""
+    import torch
+    import torch.distributed as dist
+    from llava_align_amd.shard import gather_results, get_chunk
+    N = a.strong - a.strong % 6
+    ids_all, imgs_all = pope_prompts(N // 6, seed=4321, vocab=eng.cfg.lm.vocab, image=eng.cfg.vision.image)      # same list on every rank
+    mine = get_chunk(N, world, rank, group=6)
+    on_dev = {}
+    ids = [ids_all[i] for i in mine]
+    imgs = [on_dev.setdefault(id(imgs_all[i]), imgs_all[i].to(dev).to(torch.bfloat16)) for i in mine]
+    n_new = N_NEW if not a.model.startswith("tiny") else 16
+    kw = dict(use_dd_unk=True, cd_alpha=1.0, cd_beta=0.1, temperature=0.2, seed=1 + rank, n_top=10)
+    batches = [range(b, min(b + a.questions, len(ids))) for b in range(0, len(ids), a.questions)]
+    probe = [eng.generate([ids[i] for i in b], images=[imgs[i] for i in b], max_new_tokens=2, **kw).tokens[:, 1] for b in batches]
+    eos = sorted(set(torch.cat(probe).tolist())) if probe else [0]
+
+    def one_pass():
+        outs = [eng.generate([ids[i] for i in b], images=[imgs[i] for i in b], max_new_tokens=n_new, eos_token_id=eos, pad_token_id=0,
+                             sync_every=2, **kw) for b in batches]
+        T = max([o.tokens.shape[1] for o in outs] + [1])
+        pad = lambda t: torch.nn.functional.pad(t, (0, T - t.shape[1]))
+        toks = torch.cat([pad(o.tokens) for o in outs]) if outs else torch.zeros(0, T, dtype=torch.long, device=dev)
+        tt = torch.cat([o.top_tok for o in outs]) if outs else torch.zeros(0, 10, dtype=torch.long, device=dev)
+        tp = torch.cat([o.top_prob for o in outs]) if outs else torch.zeros(0, 10, device=dev)
+        return toks, tt, tp
+    for _ in range(a.warmup):
+        one_pass()
+    torch.cuda.synchronize(dev)
+    if world > 1:
+        dist.barrier()
+    torch.cuda.synchronize(dev)
+    t0 = time.perf_counter()
+    for _ in range(a.steps):
+        toks, tt, tp = one_pass()
+    eos_t = torch.tensor(eos, device=dev)
+    hit = (toks[:, :, None] == eos_t[None, None, :]).any(-1)
+    n_tok = torch.where(hit.any(1), hit.float().argmax(1) + 1, torch.full((toks.shape[0],), toks.shape[1], device=dev))
+    res = gather_results(torch.tensor(list(mine), dtype=torch.long, device=dev), toks, n_tok, tt, tp, N)      # ragged T across ranks
+    torch.cuda.synchronize(dev)
+    if world > 1:
+        dist.barrier()
+    torch.cuda.synchronize(dev)
+    dt = time.perf_counter() - t0
+    if world > 1:
+        t = torch.tensor([dt], device=dev, dtype=torch.float64)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        dt = t.item()
+    if rank == 0:
+        assert res["count"].tolist() == [1] * N, "the shards do not partition the question list"
+        total_tokens = int(res["n_tokens"].sum().item())
+        print(json.dumps({"metric": "decode tokens/sec (VDD dual-pass) LLaVA-1.5-7B POPE", "value": round(total_tokens * a.steps / dt, 1), "unit": "tokens/s",
+                          "n_gpus": world, "steps": a.steps, "warmup": a.warmup, "ms_per_step": round(dt / a.steps * 1e3, 2), "higher_is_better": True,
+                          "scaling": "strong", "vs_baseline": None, "dtype": "bf16", "data": "synthetic",
+                          "config": {"workload": f"ONE list of {N} POPE-like questions ({N // 6} images x 6) split over the ranks by get_chunk(group=6), "
+                                                 f"use_dd_unk, cd_alpha=1, cd_beta=0.1, T=0.2, EOS after 1-2 tokens, batches of {a.questions}",
+                                     "questions_total": N, "questions_rank0": len(ids), "parallelism": f"dp{world}"},
+                          "questions_per_s": round(N * a.steps / dt, 1), "mean_answer_tokens": round(total_tokens / N, 2),
+                          "gathered_question_ids_cover_the_list_once": True, "roofline": None, "cpu_baseline": None}))
+    if world > 1:
+        dist.barrier()
+        dist.destroy_process_group()
+
+
 # ------------------------------------------------------------------ main
 def main():
     a = parse_args()
@@ -289,11 +361,13 @@ def main():
 
     tiny = a.model.startswith("tiny")
     roof = roof_extra = None
-    if rank == 0 and not tiny:
+    if rank == 0 and not tiny and not a.strong:
         roof = kernel_point(dev, 4096, 32000)
         roof_extra = [kernel_point(dev, 4096, 32000, beta=1e-6, iters=50), kernel_point(dev, 1024, 151936, iters=50),
                       kernel_point(dev, 1024, 151936, scores=False, iters=50)]
     eng = VddLlavaEngine(a.model, device=dev, seed=0, use_graph=True, lm_head_gain=4.0)
+    if a.strong:
+        return run_strong(a, eng, dev, rank, world)
     n_img = max(1, a.questions // 6)
     # every rank: its own shard of the question list (weak scaling)
     ids, imgs = pope_prompts(n_img, seed=1234 + rank, vocab=eng.cfg.lm.vocab, image=eng.cfg.vision.image)

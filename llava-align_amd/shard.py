@@ -86,9 +86,11 @@ def gather_results(local_ids: torch.Tensor, tokens: torch.Tensor, n_tokens: torc
     if k:
         out["top_tok"] = torch.full((n_total, k), -1, dtype=torch.long, device=dev)
         out["top_prob"] = torch.zeros(n_total, k, dtype=torch.float32, device=dev)
+    out["count"] = torch.zeros(n_total, dtype=torch.long, device=dev)       # how many ranks delivered each question (a partition: all 1)
     for b in blocks:
         ok = b[:, 0] >= 0
         q = b[ok, 0]
+        out["count"].index_add_(0, q, torch.ones_like(q))
         out["n_tokens"][q] = b[ok, 1]
         out["tokens"][q] = b[ok, 2: 2 + T]
         if k:

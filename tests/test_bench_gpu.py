@@ -34,3 +34,15 @@ def test_bench_single_rank_line_has_the_contract_fields():
               "data", "config", "roofline", "cpu_baseline"):
         assert k in line
     assert line["n_gpus"] == 1 and "workload" in line["config"]
+
+
+def test_bench_strong_scaling_mode_splits_one_list_over_two_ranks():
+    """`--strong N`: one seeded question list, rank k takes shard.get_chunk(N, world, k, group=6) - the code path the eval drivers use on
+    a node - EOS on, ragged results gathered once; rank 0 asserts that the gathered question ids cover 0..N-1 exactly once."""
+    line = _run(["--gpus", "2", "--model", "tiny", "--strong", "42", "--questions", "12", "--steps", "1", "--warmup", "1", "--no-baselines"],
+                {"VDD_FORCE_DEVICE": "0", "VDD_DIST_BACKEND": "gloo"})
+    assert line["scaling"] == "strong" and line["n_gpus"] == 2 and line["config"]["questions_total"] == 42
+    assert line["config"]["questions_rank0"] == 24                       # ceil(7 image groups / 2) = 4 groups of 6
+    assert line["gathered_question_ids_cover_the_list_once"] and 1.0 <= line["mean_answer_tokens"] <= 2.0
+    one = _run(["--model", "tiny", "--strong", "42", "--questions", "12", "--steps", "1", "--warmup", "0", "--no-baselines"], {})
+    assert one["n_gpus"] == 1 and one["config"]["questions_rank0"] == 42
