@@ -110,7 +110,7 @@ def test_qwen_7b_widths_bias_epilogue_and_151936_vocab_match_reference():
                        min_new_tokens=1, eos_token_id=eod, pad_token_id=eod, cd_greedy=True, output_scores=True, sync_every=1)
     assert out.stats["n_rows"] == 48 and out.stats["graph"] and torch.isneginf(out.scores[0][:, eod]).all()
     checked = 0
-    for q in range(0, 24, 4):
+    for q in range(0, 24, 2):
         kw = dict(inputs_embeds=embs[q][None], attention_mask=torch.ones(1, embs[q].shape[0], dtype=torch.long), use_cache=True,
                   cd_alpha=1.0, cd_beta=0.1, use_dd_unk=True)
         r = O.reference_loop(ref, torch.zeros(1, 0, dtype=torch.long), warp=O.WarpConfig(temperature=1.0), max_length=n_new, pad_token_id=eod,
