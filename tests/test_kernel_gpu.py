@@ -499,7 +499,7 @@ META2, ARR2 = gpu_scalar_cases()
 
 
 @pytest.mark.gpu_scalar
-@pytest.mark.parametrize("case", [c for c in META2["cases"] if not c["warp"].get("top_p")], ids=_ids([c for c in META2["cases"] if not c["warp"].get("top_p")]))
+@pytest.mark.parametrize("case", [c for c in META2["cases"] if "top_p" not in c["warp"]], ids=_ids([c for c in META2["cases"] if "top_p" not in c["warp"]]))
 def test_default_gpu_scalar_semantics_match_the_second_golden_set(case):
     """No flags passed: the package default must be the torch-GPU form and reproduce kernel_vectors_gpu_scalar.* bit for bit."""
     import llava_align_amd.sampling as S
