@@ -180,6 +180,21 @@ int vdd_skinny_gemm(const void* X, const void* W, const void* R, void* Y, float*
  * launch; replaces vdd_skinny_gemm(N = 2F) + vdd_silu_mul with the same bf16 rounding points. */
 int vdd_skinny_swiglu(const void* X, const void* W_gate_up, void* act, int M, int F, int K, int64_t ldx, void* hip_stream);
 
+/* Small-M (M <= 16: one or a few questions in flight, the reference's own B = 1 regime) fusion of the decoder layer's two RMSNorm
+ * launches into the weight-streaming projections around them (HF LlamaDecoderLayer [ext] under llava_llama.py:88-103):
+ *   vdd_skinny_gemm_resid_ss   Y = bf16(bf16(X W^T) + R): the d-wide projection (attention output / MLP down) writes the NEW residual
+ *                              stream and ss_out[row * ceil(N/16) + block] = the sum of squares of the block's 16 columns of that row;
+ *   vdd_skinny_gemm_normed     Y = rmsnorm(H) W^T with rmsnorm(H)[k] = bf16(bf16(H[k] * rstd) * ln_w[k]), rstd = rsqrt(sum(ss[row][0..nss))
+ *                              / K + eps): H is the un-normalised residual stream (row length K), normalised as its fragments load;
+ *   vdd_skinny_swiglu_normed   the same input form for the gate/up projection + SiLU*mul (vdd_skinny_swiglu).
+ * The partial sums are added in a fixed order (deterministic); same bf16 rounding points as vdd_rmsnorm + the plain projections. */
+int vdd_skinny_gemm_resid_ss(const void* X, const void* W, const void* R, void* Y, float* ss_out, int M, int N, int K, int64_t ldx,
+                             int64_t ldr, int64_t ldy, void* hip_stream);
+int vdd_skinny_gemm_normed(const void* H, const float* ss, int nss, const void* ln_w, float eps, const void* W, void* Y, int M, int N,
+                           int K, int64_t ldh, int64_t ldy, void* hip_stream);
+int vdd_skinny_swiglu_normed(const void* H, const float* ss, int nss, const void* ln_w, float eps, const void* W_gate_up, void* act,
+                             int M, int F, int K, int64_t ldh, void* hip_stream);
+
 /* Row-batched projection GEMM, any M above the skinny regime (csrc/vdd_gemm.hip): Y[M,N] = epilogue(X[M,K] W[N,K]^T), bf16 in,
  * fp32 accumulate (32x32x16 MFMA, both operands LDS-DMA'd into swizzled LDS tiles, persistent stream-K over one workgroup
  * per CU), bf16 out.  K % 128 == 0, N % 4 == 0, ldx/ldw % 8 == 0 (elements).  Replaces the eager nn.Linear calls of HF

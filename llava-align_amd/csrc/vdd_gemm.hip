@@ -392,7 +392,7 @@ __global__ void __launch_bounds__(WM * WN * 64) gemm_kernel(const GemmArgs a) {
             // is written by 8 instructions (5-12 % of a prefill-size GEMM, measured with the stores switched off).  With 64-column
             // wave tiles a 32-row block of the wave goes through 4 KiB of LDS behind the two K-tile buffers instead and leaves as
             // whole 128-byte rows, 16 B per lane, 8 rows per instruction (chunks XOR-swizzled with the row: conflict-free reads).
-            const bool staged = (TN == 64) && a.stage_out;
+            const bool staged = (TN % 64 == 0) && a.stage_out;
             if (staged) {
                 char* st = lds + NSTG * BUF + wave * 4096;
                 const int r = lane & 31, hi = lane >> 5;
@@ -400,23 +400,27 @@ __global__ void __launch_bounds__(WM * WN * 64) gemm_kernel(const GemmArgs a) {
                 for (int j = 0; j < MI; ++j) {
                     const int m = mrow + j * 32;
 #pragma unroll
-                    for (int i = 0; i < NI; ++i)
+                    for (int h = 0; h < TN / 64; ++h) {                  // 64-column halves of a 128-column wave tile, one after the other
 #pragma unroll
-                        for (int q = 0; q < 4; ++q) {
-                            const int n = cn0 + wc * TN + i * 32 + q * 8 + 4 * hi;
-                            float v[4] = {0.f, 0.f, 0.f, 0.f};
-                            if (m < a.M && n < a.N) quad(i, j, q, m, n, v);
-                            *reinterpret_cast<uint2*>(st + r * 128 + (((i * 4 + q) ^ (r & 7)) * 16) + hi * 8) = pack4(v[0], v[1], v[2], v[3]);
-                        }
+                        for (int ii = 0; ii < 2; ++ii)
 #pragma unroll
-                    for (int t = 0; t < 4; ++t) {
-                        const int row = t * 8 + (lane >> 3), c = lane & 7;
-                        const int mm = cm0 + wr * TM + j * 32 + row, nn = cn0 + wc * TN + c * 8;
-                        const uint4 val = *reinterpret_cast<const uint4*>(st + row * 128 + ((c ^ (row & 7)) * 16));
-                        if (mm < a.M) {
-                            uint16_t* yp = a.Y + (size_t)mm * a.ldy + nn;
-                            if (nn + 8 <= a.N) __builtin_nontemporal_store(__builtin_bit_cast(u32x4_t, val), reinterpret_cast<u32x4_t*>(yp));
-                            else if (nn + 4 <= a.N) *reinterpret_cast<uint2*>(yp) = make_uint2(val.x, val.y);
+                            for (int q = 0; q < 4; ++q) {
+                                const int i = h * 2 + ii;
+                                const int n = cn0 + wc * TN + i * 32 + q * 8 + 4 * hi;
+                                float v[4] = {0.f, 0.f, 0.f, 0.f};
+                                if (m < a.M && n < a.N) quad(i, j, q, m, n, v);
+                                *reinterpret_cast<uint2*>(st + r * 128 + (((ii * 4 + q) ^ (r & 7)) * 16) + hi * 8) = pack4(v[0], v[1], v[2], v[3]);
+                            }
+#pragma unroll
+                        for (int t = 0; t < 4; ++t) {
+                            const int row = t * 8 + (lane >> 3), c = lane & 7;
+                            const int mm = cm0 + wr * TM + j * 32 + row, nn = cn0 + wc * TN + h * 64 + c * 8;
+                            const uint4 val = *reinterpret_cast<const uint4*>(st + row * 128 + ((c ^ (row & 7)) * 16));
+                            if (mm < a.M) {
+                                uint16_t* yp = a.Y + (size_t)mm * a.ldy + nn;
+                                if (nn + 8 <= a.N) __builtin_nontemporal_store(__builtin_bit_cast(u32x4_t, val), reinterpret_cast<u32x4_t*>(yp));
+                                else if (nn + 4 <= a.N) *reinterpret_cast<uint2*>(yp) = make_uint2(val.x, val.y);
+                            }
                         }
                     }
                 }
@@ -485,7 +489,7 @@ int launch_cfg(const GemmArgs& a0, int epi, int sched, void* workspace, int64_t 
     a.counter = (int*)workspace;
     a.partial = (float*)((char*)workspace + COUNTER_BYTES);
     const dim3 grid(P), block(WM * WN * 64);
-    const size_t smem = (BM == 64 ? 3 : 2) * (BM + BN) * 128 + ((BN / WN == 64) ? WM * WN * 4096 : 0);      // + the epilogue's staging blocks
+    const size_t smem = (BM == 64 ? 3 : 2) * (BM + BN) * 128 + (((BN / WN) % 64 == 0) ? WM * WN * 4096 : 0);      // + the epilogue's staging blocks
     a.stage_out = ((a.ldy % 8) == 0 && (((uintptr_t)a.Y) & 15) == 0) ? 1 : 0;
 #define VDD_GEMM_LAUNCH(E)                                                                                            \
     case E: {                                                                                                         \

@@ -232,11 +232,44 @@ __global__ void __launch_bounds__(256) embed_scatter_kernel(const int* __restric
 // partials are summed through LDS.
 // NW = 4 or 8 waves per block (8: the N <= 8192 projections, whose d/16 column blocks alone would leave one 4-wave block per CU -
 // eight-way K split inside the block, no fp32 slabs for the consumer to sum).
-template <int MT, int NW>
+// Small-M decoder-layer fusion of the two RMSNorm launches (a one-question step is a chain of ~7 launches per layer of which the
+// two norms are 6.8 us each for 16 KB of data):
+//   SSOUT  the d-wide projections (attention output / MLP down): Y = bf16(bf16(X W^T) + R) IS the new residual stream, and the block
+//          also leaves the sum of squares of its 16 columns per row in ss_out[row][blockIdx.x] (summed by the consumer in a fixed
+//          order: deterministic);
+//   NORM   the projections that read a normalised input (qkv, lm_head; gate/up in skinny_swiglu_kernel): X is the un-normalised
+//          residual stream H; every lane sums its row's partials (issued behind the first W loads: off the weight stream's
+//          critical path), rstd = rsqrt(sum / K + eps), and the X fragments are normalised as they are loaded,
+//          bf16(bf16(h * rstd) * ln_w[k]) - the roundings of rmsnorm_kernel.
+struct NormIn { const float* ss; int nss; const uint16_t* lnw; float eps; };
+
+__device__ __forceinline__ bf16x8_t norm_frag(bf16x8_t h, bf16x8_t g, float rstd) {
+    const uint4 a = __builtin_bit_cast(uint4, h), w = __builtin_bit_cast(uint4, g);
+    auto nrm = [&](uint32_t hv, uint32_t gv) {
+        const float n0 = bf2f(f2bf(lo(hv) * rstd)), n1 = bf2f(f2bf(hi(hv) * rstd));
+        return pack(n0 * lo(gv), n1 * hi(gv));
+    };
+    const uint4 o = make_uint4(nrm(a.x, w.x), nrm(a.y, w.y), nrm(a.z, w.z), nrm(a.w, w.w));
+    return __builtin_bit_cast(bf16x8_t, o);
+}
+
+// rstd of row `r` from the producer's per-block partial sums ss[r][0 .. nss): the four lanes g = 0..3 that share a row take every
+// fourth partial each (in index order), then g0 + g1 and g2 + g3 are exchanged - a fixed summation tree
+__device__ __forceinline__ float row_rstd(const NormIn& ni, int r, int g, int K) {
+    const float* p = ni.ss + (size_t)r * ni.nss;
+    float s = 0.f;
+    for (int i = g; i < ni.nss; i += 4) s += p[i];
+    s += __shfl_xor(s, 16);
+    s += __shfl_xor(s, 32);
+    return rsqrtf(s / (float)K + ni.eps);
+}
+
+template <int MT, int NW, bool NORM = false, bool SSOUT = false>
 __global__ void __launch_bounds__(NW * 64) skinny_gemm_kernel(const uint16_t* __restrict__ X, const uint16_t* __restrict__ W,
                                                              const uint16_t* __restrict__ R, uint16_t* __restrict__ Y,
                                                              float* __restrict__ Yslab, int M, int N, int K, long long ldx,
-                                                             long long ldr, long long ldy) {
+                                                             long long ldr, long long ldy, NormIn ni, float* __restrict__ ss_out) {
+    static_assert(!NORM || MT == 1, "normalise-on-load is the <= 16-row path");
     __shared__ float part[NW][MT][64][4];
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int n0 = blockIdx.x * 16;
@@ -259,34 +292,47 @@ __global__ void __launch_bounds__(NW * 64) skinny_gemm_kernel(const uint16_t* __
     constexpr int U = 8;
     const int nit = kq / (32 * U);
     bf16x8_t b0[U], a0[U][MT], b1[U], a1[U][MT];
-    auto ld = [&](bf16x8_t (&b)[U], bf16x8_t (&a)[U][MT], int kk) {
+    constexpr int UG = NORM ? U : 1;
+    bf16x8_t g0[UG], g1[UG];                             // NORM: the ln weights of a batch's k positions
+    const uint16_t* gp = NORM ? ni.lnw + kbeg + g * 8 : nullptr;
+    float rstd = 1.f;
+    auto ld = [&](bf16x8_t (&b)[U], bf16x8_t (&a)[U][MT], bf16x8_t (&gw)[UG], int kk) {
 #pragma unroll
         for (int u = 0; u < U; ++u) b[u] = *reinterpret_cast<const bf16x8_t*>(wp + (size_t)(kk + 32 * u) * WS);
 #pragma unroll
         for (int u = 0; u < U; ++u)
 #pragma unroll
             for (int t = 0; t < MT; ++t) a[u][t] = *reinterpret_cast<const bf16x8_t*>(xp[t] + kk + 32 * u);
+        if constexpr (NORM) {
+#pragma unroll
+            for (int u = 0; u < U; ++u) gw[u] = *reinterpret_cast<const bf16x8_t*>(gp + kk + 32 * u);
+        }
         __builtin_amdgcn_sched_barrier(0);
     };
-    auto mm = [&](const bf16x8_t (&b)[U], const bf16x8_t (&a)[U][MT]) {
+    auto mm = [&](const bf16x8_t (&b)[U], const bf16x8_t (&a)[U][MT], const bf16x8_t (&gw)[UG]) {
 #pragma unroll
         for (int u = 0; u < U; ++u)
 #pragma unroll
-            for (int t = 0; t < MT; ++t) acc[t] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a[u][t], b[u], acc[t], 0, 0, 0);
+            for (int t = 0; t < MT; ++t) {
+                bf16x8_t av = a[u][t];
+                if constexpr (NORM) av = norm_frag(av, gw[u], rstd);
+                acc[t] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(av, b[u], acc[t], 0, 0, 0);
+            }
         __builtin_amdgcn_sched_barrier(0);
     };
     if constexpr (MT == 1) {
-        if (nit > 0) ld(b0, a0, 0);
+        if (nit > 0) ld(b0, a0, g0, 0);
+        if constexpr (NORM) { int r = ln; if (r >= M) r = M - 1; rstd = row_rstd(ni, r, g, K); }     // behind the first W batch
         int it = 0;
         for (; it + 2 <= nit; it += 2) {
-            ld(b1, a1, (it + 1) * 32 * U);
-            mm(b0, a0);
-            if (it + 2 < nit) ld(b0, a0, (it + 2) * 32 * U);
-            mm(b1, a1);
+            ld(b1, a1, g1, (it + 1) * 32 * U);
+            mm(b0, a0, g0);
+            if (it + 2 < nit) ld(b0, a0, g0, (it + 2) * 32 * U);
+            mm(b1, a1, g1);
         }
-        if (it < nit) mm(b0, a0);
+        if (it < nit) mm(b0, a0, g0);
     } else {            // 32 - 64 rows: the X fragments alone are 64 - 128 registers per batch; one stage
-        for (int it = 0; it < nit; ++it) { ld(b0, a0, it * 32 * U); mm(b0, a0); }
+        for (int it = 0; it < nit; ++it) { ld(b0, a0, g0, it * 32 * U); mm(b0, a0, g0); }
     }
     int k = nit * 32 * U;
     for (; k < kq; k += 32) {
@@ -294,6 +340,7 @@ __global__ void __launch_bounds__(NW * 64) skinny_gemm_kernel(const uint16_t* __
 #pragma unroll
         for (int t = 0; t < MT; ++t) {
             bf16x8_t a = *reinterpret_cast<const bf16x8_t*>(xp[t] + k);
+            if constexpr (NORM) a = norm_frag(a, *reinterpret_cast<const bf16x8_t*>(gp + k), rstd);
             acc[t] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a, b, acc[t], 0, 0, 0);
         }
     }
@@ -309,11 +356,18 @@ __global__ void __launch_bounds__(NW * 64) skinny_gemm_kernel(const uint16_t* __
             const int row = t * 16 + g * 4 + r, col = n0 + ln;
             float s = (part[0][t][lane][r] + part[1][t][lane][r]) + (part[2][t][lane][r] + part[3][t][lane][r]);
             if constexpr (NW == 8) s += (part[4][t][lane][r] + part[5][t][lane][r]) + (part[6][t][lane][r] + part[7][t][lane][r]);
+            float sq = 0.f;
             if (row < M && col < N) {
                 if (Yslab != nullptr) { Yslab[((size_t)blockIdx.y * M + row) * N + col] = s; continue; }
                 float o = bf2f(f2bf(s));
                 if (R != nullptr) o = o + bf2f(R[(size_t)row * ldr + col]);
-                Y[(size_t)row * ldy + col] = (uint16_t)f2bf(o);
+                const uint32_t ob = f2bf(o);
+                Y[(size_t)row * ldy + col] = (uint16_t)ob;
+                if constexpr (SSOUT) { const float h = bf2f(ob); sq = h * h; }
+            }
+            if constexpr (SSOUT) {      // the 16 lanes ln = 0..15 of a lane group hold the block's 16 columns of one row
+                sq += __shfl_xor(sq, 1); sq += __shfl_xor(sq, 2); sq += __shfl_xor(sq, 4); sq += __shfl_xor(sq, 8);
+                if (ln == 0 && row < M) ss_out[(size_t)row * gridDim.x + blockIdx.x] = sq;
             }
         }
     }
@@ -324,8 +378,9 @@ __global__ void __launch_bounds__(NW * 64) skinny_gemm_kernel(const uint16_t* __
 // (B-fragment lanes ln < 8 -> row f0 + ln) and the 8 matching up columns (ln >= 8 -> row F + f0 + ln - 8), so the
 // epilogue finds gate and up of one feature in the same LDS tile: no [M, 2F] round trip and no silu_mul launch.
 // Rounding as the unfused pair: gate, up -> bf16; silu(gate) -> bf16; product -> bf16.
+template <bool NORM>
 __global__ void __launch_bounds__(256) skinny_swiglu_kernel(const uint16_t* __restrict__ X, const uint16_t* __restrict__ W,
-                                                            uint16_t* __restrict__ A, int M, int F, int K, long long ldx) {
+                                                            uint16_t* __restrict__ A, int M, int F, int K, long long ldx, NormIn ni) {
     __shared__ float part[4][64][4];
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int f0 = blockIdx.x * 8;
@@ -340,31 +395,46 @@ __global__ void __launch_bounds__(256) skinny_swiglu_kernel(const uint16_t* __re
     constexpr int U = 8;             // two register stages, as in skinny_gemm_kernel
     const int nit = kq / (32 * U);
     bf16x8_t b0[U], a0[U], b1[U], a1[U];
-    auto ld = [&](bf16x8_t (&b)[U], bf16x8_t (&a)[U], int kk) {
+    constexpr int UG = NORM ? U : 1;
+    bf16x8_t g0[UG], g1[UG];
+    const uint16_t* gp = NORM ? ni.lnw + kbeg + g * 8 : nullptr;
+    float rstd = 1.f;
+    auto ld = [&](bf16x8_t (&b)[U], bf16x8_t (&a)[U], bf16x8_t (&gw)[UG], int kk) {
 #pragma unroll
         for (int u = 0; u < U; ++u) b[u] = *reinterpret_cast<const bf16x8_t*>(wp + (size_t)(kk + 32 * u) * WS);
 #pragma unroll
         for (int u = 0; u < U; ++u) a[u] = *reinterpret_cast<const bf16x8_t*>(xp + kk + 32 * u);
-        __builtin_amdgcn_sched_barrier(0);
-    };
-    auto mm = [&](const bf16x8_t (&b)[U], const bf16x8_t (&a)[U]) {
+        if constexpr (NORM) {
 #pragma unroll
-        for (int u = 0; u < U; ++u) acc = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a[u], b[u], acc, 0, 0, 0);
+            for (int u = 0; u < U; ++u) gw[u] = *reinterpret_cast<const bf16x8_t*>(gp + kk + 32 * u);
+        }
         __builtin_amdgcn_sched_barrier(0);
     };
-    if (nit > 0) ld(b0, a0, 0);
+    auto mm = [&](const bf16x8_t (&b)[U], const bf16x8_t (&a)[U], const bf16x8_t (&gw)[UG]) {
+#pragma unroll
+        for (int u = 0; u < U; ++u) {
+            bf16x8_t av = a[u];
+            if constexpr (NORM) av = norm_frag(av, gw[u], rstd);
+            acc = __builtin_amdgcn_mfma_f32_16x16x32_bf16(av, b[u], acc, 0, 0, 0);
+        }
+        __builtin_amdgcn_sched_barrier(0);
+    };
+    if (nit > 0) ld(b0, a0, g0, 0);
+    if constexpr (NORM) rstd = row_rstd(ni, r, g, K);            // behind the first W batch
     int it = 0;
     for (; it + 2 <= nit; it += 2) {
-        ld(b1, a1, (it + 1) * 32 * U);
-        mm(b0, a0);
-        if (it + 2 < nit) ld(b0, a0, (it + 2) * 32 * U);
-        mm(b1, a1);
+        ld(b1, a1, g1, (it + 1) * 32 * U);
+        mm(b0, a0, g0);
+        if (it + 2 < nit) ld(b0, a0, g0, (it + 2) * 32 * U);
+        mm(b1, a1, g1);
     }
-    if (it < nit) mm(b0, a0);
+    if (it < nit) mm(b0, a0, g0);
     int k = nit * 32 * U;
-    for (; k < kq; k += 32)
-        acc = __builtin_amdgcn_mfma_f32_16x16x32_bf16(*reinterpret_cast<const bf16x8_t*>(xp + k),
-                                                      *reinterpret_cast<const bf16x8_t*>(wp + (size_t)k * WS), acc, 0, 0, 0);
+    for (; k < kq; k += 32) {
+        bf16x8_t a = *reinterpret_cast<const bf16x8_t*>(xp + k);
+        if constexpr (NORM) a = norm_frag(a, *reinterpret_cast<const bf16x8_t*>(gp + k), rstd);
+        acc = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a, *reinterpret_cast<const bf16x8_t*>(wp + (size_t)k * WS), acc, 0, 0, 0);
+    }
 #pragma unroll
     for (int rr = 0; rr < 4; ++rr) part[wave][lane][rr] = acc[rr];
     __syncthreads();
@@ -933,7 +1003,7 @@ static int skinny_gemm_launch(const void* X, const void* W, const void* R, void*
     hipStream_t st = (hipStream_t)stream;
     dim3 grid((N + 15) / 16, n_split);
     auto x = (const uint16_t*)X; auto w = (const uint16_t*)W; auto r = (const uint16_t*)R; auto y = (uint16_t*)Y;
-#define VDD_SKINNY(MT, NW) hipLaunchKernelGGL((skinny_gemm_kernel<MT, NW>), grid, dim3(NW * 64), 0, st, x, w, r, y, Y_slabs, M, N, K, (long long)ldx, (long long)ldr, (long long)ldy)
+#define VDD_SKINNY(MT, NW) hipLaunchKernelGGL((skinny_gemm_kernel<MT, NW>), grid, dim3(NW * 64), 0, st, x, w, r, y, Y_slabs, M, N, K, (long long)ldx, (long long)ldr, (long long)ldy, NormIn{}, (float*)nullptr)
     // few column blocks (N = d projections): eight waves per block split K eight ways instead of fp32 slabs across blocks
     if (M <= 16 && n_split == 1 && N <= 8192 && K % 256 == 0) VDD_SKINNY(1, 8);
     else if (M <= 16) VDD_SKINNY(1, 4); else if (M <= 32) VDD_SKINNY(2, 4); else VDD_SKINNY(4, 4);
@@ -949,8 +1019,49 @@ int vdd_skinny_gemm(const void* X, const void* W, const void* R, void* Y, float*
 static int skinny_swiglu_launch(const void* X, const void* W, void* act, int M, int F, int K, int64_t ldx, void* stream) {
     if (M <= 0 || F <= 0) return VDD_OK;
     if (!X || !W || !act || M > 16 || K % 128 != 0 || (ldx % 8) != 0) return VDD_ERR_INVALID_ARG;
-    hipLaunchKernelGGL(skinny_swiglu_kernel, dim3((F + 7) / 8), dim3(256), 0, (hipStream_t)stream, (const uint16_t*)X,
-                            (const uint16_t*)W, (uint16_t*)act, M, F, K, (long long)ldx);
+    hipLaunchKernelGGL(skinny_swiglu_kernel<false>, dim3((F + 7) / 8), dim3(256), 0, (hipStream_t)stream, (const uint16_t*)X,
+                            (const uint16_t*)W, (uint16_t*)act, M, F, K, (long long)ldx, NormIn{});
+    return ok(hipSuccess);
+}
+
+// ---- small-M decoder-layer fusions of the RMSNorm launches (see skinny_gemm_kernel)
+int vdd_skinny_gemm_resid_ss(const void* X, const void* W, const void* R, void* Y, float* ss_out, int M, int N, int K, int64_t ldx,
+                             int64_t ldr, int64_t ldy, void* stream) {
+    if (M <= 0 || N <= 0) return VDD_OK;
+    if (!X || !W || !R || !Y || !ss_out || M > 16 || K % 128 != 0 || (ldx % 8) != 0) return VDD_ERR_INVALID_ARG;
+    dim3 grid((N + 15) / 16, 1);
+    hipStream_t st = (hipStream_t)stream;
+    if (N <= 8192 && K % 256 == 0)
+        hipLaunchKernelGGL((skinny_gemm_kernel<1, 8, false, true>), grid, dim3(512), 0, st, (const uint16_t*)X, (const uint16_t*)W, (const uint16_t*)R,
+                           (uint16_t*)Y, (float*)nullptr, M, N, K, (long long)ldx, (long long)ldr, (long long)ldy, NormIn{}, ss_out);
+    else
+        hipLaunchKernelGGL((skinny_gemm_kernel<1, 4, false, true>), grid, dim3(256), 0, st, (const uint16_t*)X, (const uint16_t*)W, (const uint16_t*)R,
+                           (uint16_t*)Y, (float*)nullptr, M, N, K, (long long)ldx, (long long)ldr, (long long)ldy, NormIn{}, ss_out);
+    return ok(hipSuccess);
+}
+
+int vdd_skinny_gemm_normed(const void* H, const float* ss, int nss, const void* ln_w, float eps, const void* W, void* Y, int M, int N,
+                           int K, int64_t ldh, int64_t ldy, void* stream) {
+    if (M <= 0 || N <= 0) return VDD_OK;
+    if (!H || !ss || nss <= 0 || !ln_w || !W || !Y || M > 16 || K % 128 != 0 || (ldh % 8) != 0) return VDD_ERR_INVALID_ARG;
+    dim3 grid((N + 15) / 16, 1);
+    const NormIn ni{ss, nss, (const uint16_t*)ln_w, eps};
+    hipStream_t st = (hipStream_t)stream;
+    if (N <= 8192 && K % 256 == 0)
+        hipLaunchKernelGGL((skinny_gemm_kernel<1, 8, true, false>), grid, dim3(512), 0, st, (const uint16_t*)H, (const uint16_t*)W, (const uint16_t*)nullptr,
+                           (uint16_t*)Y, (float*)nullptr, M, N, K, (long long)ldh, 0ll, (long long)ldy, ni, (float*)nullptr);
+    else
+        hipLaunchKernelGGL((skinny_gemm_kernel<1, 4, true, false>), grid, dim3(256), 0, st, (const uint16_t*)H, (const uint16_t*)W, (const uint16_t*)nullptr,
+                           (uint16_t*)Y, (float*)nullptr, M, N, K, (long long)ldh, 0ll, (long long)ldy, ni, (float*)nullptr);
+    return ok(hipSuccess);
+}
+
+int vdd_skinny_swiglu_normed(const void* H, const float* ss, int nss, const void* ln_w, float eps, const void* W_gate_up, void* act,
+                             int M, int F, int K, int64_t ldh, void* stream) {
+    if (M <= 0 || F <= 0) return VDD_OK;
+    if (!H || !ss || nss <= 0 || !ln_w || !W_gate_up || !act || M > 16 || K % 128 != 0 || (ldh % 8) != 0) return VDD_ERR_INVALID_ARG;
+    hipLaunchKernelGGL(skinny_swiglu_kernel<true>, dim3((F + 7) / 8), dim3(256), 0, (hipStream_t)stream, (const uint16_t*)H,
+                       (const uint16_t*)W_gate_up, (uint16_t*)act, M, F, K, (long long)ldh, NormIn{ss, nss, (const uint16_t*)ln_w, eps});
     return ok(hipSuccess);
 }
 

@@ -427,6 +427,32 @@ class LanguageModel:
         a = ops.rmsnorm(resid, t["norm"], c.eps, delta=delta)
         return ops.linear(a, t["lm_head"])
 
+    fuse_norms = True         # few rows in flight: the RMSNorm launches ride inside the projections around them
+
+    @torch.no_grad()
+    def _decode_step_few_rows(self, resid, pos, cpos, slot, attn_rows, kv):
+        """One question (2-3 branch rows) up to 16 rows: 5 launches per layer instead of 7.  The attention-output and MLP-down
+        projections write the residual stream themselves (+ per-block sums of squares of its rows), and the projections that read a
+        normalised input (qkv, gate/up, lm_head) normalise it as it loads (ops.linear_resid_ss / linear_normed): the two 6.8-us
+        RMSNorm launches of a layer - a tenth of a one-question step - are gone; only layer 0 normalises the embeddings with the
+        stand-alone kernel."""
+        c, t = self.cfg, self.w.t
+        H, Hkv, D = c.n_heads, c.n_kv_heads, c.head_dim
+        ss = None
+        for i in range(c.n_layers):
+            p = f"l{i}."
+            bias = t[p + "bqkv_lm"] if c.qkv_bias else None
+            if ss is None:
+                qkv = ops.linear(ops.rmsnorm(resid, t[p + "ln1"], c.eps), t[p + "wqkv"], bias=bias)
+            else:
+                qkv = ops.linear_normed(resid, ss, t[p + "ln1"], c.eps, t[p + "wqkv"], bias=bias)
+            att = ops.decode_attention_fused(qkv, pos, cpos, slot, self.cs, kv.ko[i], kv.vo[i], attn_rows, H, Hkv, D,
+                                             k_prefix=kv.kp[i], v_prefix=kv.vp[i])
+            resid, ss = ops.linear_resid_ss(att, t[p + "wo"], resid)
+            act = ops.swiglu_linear_normed(resid, ss, t[p + "ln2"], c.eps, t[p + "wgu"])
+            resid, ss = ops.linear_resid_ss(act, t[p + "wd"], resid)
+        return ops.linear_normed(resid, ss, t["norm"], c.eps, t["lm_head"])
+
     @torch.no_grad()
     def decode_step(self, tokens: torch.Tensor, pos: torch.Tensor, cpos: torch.Tensor, slot: torch.Tensor, attn_rows: torch.Tensor,
                     kv: KVCache, grouping: Optional[dict] = None, workspace: Optional[torch.Tensor] = None) -> torch.Tensor:
@@ -436,6 +462,9 @@ class LanguageModel:
         c, t = self.cfg, self.w.t
         H, Hkv, D = c.n_heads, c.n_kv_heads, c.head_dim
         resid = ops.embed(tokens, t["embed"])
+        if (self.fuse_norms and grouping is None and tokens.shape[0] <= min(ops.FUSED_ATTN_MAX_M, ops.NORM_FUSED_MAX_M) and D == 128
+                and c.d % 256 == 0 and c.ffn % 128 == 0 and c.n_layers > 0):
+            return self._decode_step_few_rows(resid, pos, cpos, slot, attn_rows, kv)
         delta = None
         for i in range(c.n_layers):
             p = f"l{i}."

@@ -32,6 +32,9 @@ _SIGS = {
     "vdd_vit_im2col": [_P, _I, _P, _I, _I, _I, _I, _P],
     "vdd_vit_assemble": [_P, _P, _P, _P, _I, _I, _I, _P],
     "vdd_vit_qkv_split": [_P, _P, _P, _P, _I, _I, _I, _I, _L, _I, _I, _P],
+    "vdd_skinny_gemm_resid_ss": [_P, _P, _P, _P, _P, _I, _I, _I, _L, _L, _L, _P],
+    "vdd_skinny_gemm_normed": [_P, _P, _I, _P, _F, _P, _P, _I, _I, _I, _L, _L, _P],
+    "vdd_skinny_swiglu_normed": [_P, _P, _I, _P, _F, _P, _P, _I, _I, _I, _L, _P],
     "vdd_stop_words_match": [_P, _L, _L, _P, _P, _I, _P, _P, _I, _P, _I, _P],
     "vdd_repetition_penalty": [_P, _L, _I, _I, _I, _P, _I, _P, _L, _L, _P, _F, C.c_uint32, _P],
 }
@@ -143,6 +146,43 @@ def linear_to_norm(x, w):
     every LLaVA / Qwen width).  (A second form - fp32 split-K slabs across blocks, summed by the norm - never fired for any K the
     8-wave form does not cover and was removed; skinny_gemm(..., slabs=True) + rmsnorm(delta=slabs) remain as kernels.)"""
     return linear(x, w)
+
+
+NORM_FUSED_MAX_M = 16   # rows up to which the decoder layer's RMSNorms ride inside the projections around them
+
+
+def linear_resid_ss(x, w, resid, out=None, ss=None):
+    """h = bf16(bf16(x w^T) + resid) (the new residual stream) and ss [M, N/16] fp32: per-block partial sums of squares of h's rows,
+    for linear_normed / swiglu_linear_normed.  M <= NORM_FUSED_MAX_M."""
+    _bf16(x, w, resid)
+    M, K = x.shape
+    N = w.shape[0]
+    out = torch.empty(M, N, dtype=x.dtype, device=x.device) if out is None else out
+    ss = torch.empty(M, (N + 15) // 16, dtype=torch.float32, device=x.device) if ss is None else ss
+    _lib.check(_lib_ready().vdd_skinny_gemm_resid_ss(x.data_ptr(), w.data_ptr(), resid.data_ptr(), out.data_ptr(), ss.data_ptr(), M, N, K,
+                                                     x.stride(0), resid.stride(0), out.stride(0), _st(x)))
+    return out, ss
+
+
+def linear_normed(h, ss, ln_w, eps, w, out=None, bias=None):
+    """rmsnorm(h; ln_w, eps) @ w^T with the normalisation done as h's fragments load (h, ss from linear_resid_ss)."""
+    _bf16(h, w, ln_w)
+    M, K = h.shape
+    N = w.shape[0]
+    out = torch.empty(M, N, dtype=h.dtype, device=h.device) if out is None else out
+    _lib.check(_lib_ready().vdd_skinny_gemm_normed(h.data_ptr(), ss.data_ptr(), ss.shape[1], ln_w.data_ptr(), eps, w.data_ptr(), out.data_ptr(),
+                                                   M, N, K, h.stride(0), out.stride(0), _st(h)))
+    return bias_act(out, bias, out=out) if bias is not None else out
+
+
+def swiglu_linear_normed(h, ss, ln_w, eps, w_gate_up, out=None):
+    _bf16(h, w_gate_up, ln_w)
+    M, K = h.shape
+    F = w_gate_up.shape[0] // 2
+    out = torch.empty(M, F, dtype=h.dtype, device=h.device) if out is None else out
+    _lib.check(_lib_ready().vdd_skinny_swiglu_normed(h.data_ptr(), ss.data_ptr(), ss.shape[1], ln_w.data_ptr(), eps, w_gate_up.data_ptr(),
+                                                     out.data_ptr(), M, F, K, h.stride(0), _st(h)))
+    return out
 
 
 SKINNY_MAX_M = 8      # up to here every projection is a weight-streaming kernel

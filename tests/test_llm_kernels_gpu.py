@@ -427,6 +427,32 @@ def test_gemm_small_launch_slabs_do_not_poison_a_large_launch_counters():
     assert lib.vdd_gemm_workspace_bytes(96, 4096) == lib.vdd_gemm_workspace_bytes(40000, 4096)     # one layout for every shape
 
 
+@pytest.mark.parametrize("M,d,F", [(2, 4096, 11008), (3, 5120, 13824), (16, 4096, 11008), (5, 256, 512)])
+def test_norm_fused_small_m_projections(M, d, F):
+    """The one-question decoder layer without RMSNorm launches: linear_resid_ss (projection + residual add + per-block sums of
+    squares), linear_normed / swiglu_linear_normed (normalise-on-load) against rmsnorm + the plain projections.  Same bf16 rounding
+    points; the only licence is the summation order of the fp32 sum of squares (one ulp of rstd)."""
+    O = ops()
+    x, resid = bf(M, d, seed=70), bf(M, d, seed=71)
+    wo, ln = bf(d, d, scale=0.02, seed=72), (1 + 0.1 * bf(d, seed=73).float()).to(torch.bfloat16)
+    h, ss = O.linear_resid_ss(x, wo, resid)
+    want_h = O.skinny_gemm(x, wo, resid=resid)
+    assert torch.equal(h, want_h)                                            # same kernel arithmetic as the unfused projection
+    want_ss = (h.float() ** 2).view(M, d // 16, 16).sum(-1)
+    assert torch.allclose(ss, want_ss, rtol=1e-5, atol=1e-6) and ss.shape == (M, d // 16)
+    a = O.rmsnorm(h, ln, 1e-5)                                                # reference path: stand-alone norm, then the projections
+    for w_next, bias in ((bf(3 * d, d, scale=0.02, seed=74), None), (bf(1000, d, scale=0.02, seed=75), bf(1000, seed=76))):
+        got = O.linear_normed(h, ss, ln, 1e-5, w_next, bias=bias)
+        want = O.linear(a, w_next, bias=bias)
+        assert (got.float() - want.float()).abs().max().item() <= 2 ** -6 * want.float().abs().max().item()
+        assert (got != want).float().mean().item() <= 0.02                   # bit-identical but for the odd rstd ulp
+    wgu = bf(2 * F, d, scale=0.02, seed=77)
+    got = O.swiglu_linear_normed(h, ss, ln, 1e-5, wgu)
+    want = O.swiglu_linear(a, wgu)
+    assert got.shape == (M, F) and (got.float() - want.float()).abs().max().item() <= 2 ** -6 * want.float().abs().max().item() + 1e-3
+    assert (got != want).float().mean().item() <= 0.02
+
+
 def test_gemm_rejects_what_it_cannot_do():
     O = ops()
     with pytest.raises(ValueError):

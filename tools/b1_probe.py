@@ -17,6 +17,8 @@ def timed(n_new):
     for _ in range(5):
         t0 = time.perf_counter(); eng.generate(ids, **k2); torch.cuda.synchronize(); ts.append(time.perf_counter() - t0)
     return sorted(ts)[2]
+if len(sys.argv) > 1 and sys.argv[1] == "--unfused":
+    eng.lm.fuse_norms = False
 t64, t32, t1 = timed(64), timed(32), timed(1)
 print(json.dumps({"total_s_64": round(t64, 4), "prefill_plus_1_token_s": round(t1, 4), "ms_per_decode_step": round((t64 - t32) / 32 * 1e3, 3),
                   "tok_per_s": round(64 / t64, 1)}))
