@@ -243,25 +243,151 @@ __global__ void __launch_bounds__(256) embed_scatter_kernel(const int* __restric
 //          bf16(bf16(h * rstd) * ln_w[k]) - the roundings of rmsnorm_kernel.
 struct NormIn { const float* ss; int nss; const uint16_t* lnw; float eps; };
 
-__device__ __forceinline__ bf16x8_t norm_frag(bf16x8_t h, bf16x8_t g, float rstd) {
-    const uint4 a = __builtin_bit_cast(uint4, h), w = __builtin_bit_cast(uint4, g);
-    auto nrm = [&](uint32_t hv, uint32_t gv) {
-        const float n0 = bf2f(f2bf(lo(hv) * rstd)), n1 = bf2f(f2bf(hi(hv) * rstd));
-        return pack(n0 * lo(gv), n1 * hi(gv));
-    };
-    const uint4 o = make_uint4(nrm(a.x, w.x), nrm(a.y, w.y), nrm(a.z, w.z), nrm(a.w, w.w));
-    return __builtin_bit_cast(bf16x8_t, o);
+typedef __attribute__((ext_vector_type(2))) __bf16 bf16x2_hw;
+typedef __attribute__((ext_vector_type(2))) float f32x2_hw;
+// two bf16 (packed in a dword) -> bf16(bf16(h * rstd) * g) with the hardware's RNE pack conversion (v_cvt_pk_bf16_f32)
+__device__ __forceinline__ uint32_t norm_pair(uint32_t hv, uint32_t gv, float rstd) {
+    const f32x2_hw n = {lo(hv) * rstd, hi(hv) * rstd};
+    const uint32_t nb = __builtin_bit_cast(uint32_t, __builtin_convertvector(n, bf16x2_hw));
+    const f32x2_hw o = {lo(nb) * lo(gv), hi(nb) * hi(gv)};
+    return __builtin_bit_cast(uint32_t, __builtin_convertvector(o, bf16x2_hw));
+}
+__device__ __forceinline__ uint4 norm_chunk(uint4 a, uint4 w, float rstd) {
+    return make_uint4(norm_pair(a.x, w.x, rstd), norm_pair(a.y, w.y, rstd), norm_pair(a.z, w.z, rstd), norm_pair(a.w, w.w, rstd));
 }
 
-// rstd of row `r` from the producer's per-block partial sums ss[r][0 .. nss): the four lanes g = 0..3 that share a row take every
-// fourth partial each (in index order), then g0 + g1 and g2 + g3 are exchanged - a fixed summation tree
-__device__ __forceinline__ float row_rstd(const NormIn& ni, int r, int g, int K) {
-    const float* p = ni.ss + (size_t)r * ni.nss;
+// rstd of row `r` from the producer's per-block partial sums ss[r][0 .. nss) (nss % 4 == 0): thread-local, fixed order - 16-byte
+// loads issued in batches of eight (one memory round trip per 32 partials), then added in index order
+__device__ __forceinline__ float row_rstd(const NormIn& ni, int r, int K) {
+    const float4* p = reinterpret_cast<const float4*>(ni.ss + (size_t)r * ni.nss);
+    const int n4 = ni.nss >> 2;
     float s = 0.f;
-    for (int i = g; i < ni.nss; i += 4) s += p[i];
-    s += __shfl_xor(s, 16);
-    s += __shfl_xor(s, 32);
+    for (int base = 0; base < n4; base += 8) {
+        float4 v[8];
+#pragma unroll
+        for (int j = 0; j < 8; ++j) v[j] = base + j < n4 ? p[base + j] : make_float4(0.f, 0.f, 0.f, 0.f);
+#pragma unroll
+        for (int j = 0; j < 8; ++j) s += (v[j].x + v[j].y) + (v[j].z + v[j].w);
+    }
     return rsqrtf(s / (float)K + ni.eps);
+}
+
+// Persistent form of the weight-streaming projections for a NORMALISED input: a block normalises the (<= 16) rows of H ONCE into LDS
+// - bf16(bf16(h * rstd) * ln_w[k]), the roundings of rmsnorm_kernel - behind its first batch of W loads, then walks its column
+// blocks (blockIdx.x, + gridDim.x, ...) with the A fragments read from LDS.  (Normalising per column block - in every one of the
+// 768 - 2000 blocks of the plain kernels - costs more VALU time than the two RMSNorm launches it replaces: 6.2 vs 3.4 ms per
+// one-question step.)  LDS row stride = 2 K + 64 B: the 16 x 4 (row, k-group) lanes of a fragment read hit distinct 16-byte slots.
+// SWIGLU: a column block is 8 features (gate rows | up rows of W = [Wg; Wu]) with the SiLU * mul epilogue of skinny_swiglu_kernel.
+template <int NW, bool SWIGLU>
+__global__ void __launch_bounds__(NW * 64) skinny_normed_kernel(const uint16_t* __restrict__ Hs, const uint16_t* __restrict__ W,
+                                                               uint16_t* __restrict__ Y, int M, int N, int K, long long ldh,
+                                                               long long ldy, NormIn ni, int n_cb) {
+    extern __shared__ __attribute__((aligned(16))) unsigned char xs[];           // [M][2 K + 64] bytes
+    __shared__ float part[NW][64][4];
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int ln = lane & 15, g = lane >> 4;
+    const int kq = K / NW, kbeg = wave * kq;
+    const int rstride = 2 * K + 64;
+    constexpr int U = 8;
+    const int nit = kq / (32 * U);
+    auto wptr = [&](int cb) {
+        if constexpr (SWIGLU) { int f = cb * 8 + (ln & 7); if (f >= N) f = N - 1; return W + ((size_t)(ln < 8 ? 0 : N) + f) * K + kbeg + g * 8; }
+        else { int nrow = cb * 16 + ln; if (nrow >= N) nrow = N - 1; return W + (size_t)nrow * K + kbeg + g * 8; }
+    };
+    bf16x8_t b0[U], b1[U];
+    auto ldw = [&](bf16x8_t (&b)[U], const uint16_t* wp, int kk) {
+#pragma unroll
+        for (int u = 0; u < U; ++u) b[u] = *reinterpret_cast<const bf16x8_t*>(wp + kk + 32 * u);
+        __builtin_amdgcn_sched_barrier(0);
+    };
+    int cb = blockIdx.x;
+    const uint16_t* wp = wptr(cb < n_cb ? cb : 0);
+    if (nit > 0) ldw(b0, wp, 0);                                               // the weight stream starts before anything else:
+    bool b1_ahead = false;                                                     // BOTH register stages of the first column block are
+    if (nit > 1) { ldw(b1, wp, 32 * U); b1_ahead = true; }                     // in flight under the normalisation prologue
+    // ---- normalise the rows into LDS (once per block).  Sum of squares of a row = its nss per-block partials: thread t takes
+    // partials t, t + NT, ... (one load per row for d <= 4096), butterfly over the wave, the NW wave sums in a fixed tree: one
+    // memory round trip for all rows together and deterministic.  (A per-thread loop over the partials of a row is a chain of
+    // dependent round trips: 10 us per launch.)
+    __shared__ float red[NW][16];
+    {
+        float pv[16];
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+            pv[r] = 0.f;
+            if (r < M) for (int i = tid; i < ni.nss; i += NW * 64) pv[r] += ni.ss[(size_t)r * ni.nss + i];
+        }
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+            if (r < M) { const float sw = wave_sum(pv[r]); if (lane == 0) red[wave][r] = sw; }
+        }
+    }
+    __syncthreads();
+    for (int r = 0; r < M; ++r) {
+        float tot = (red[0][r] + red[1][r]) + (red[2][r] + red[3][r]);
+        if constexpr (NW == 8) tot += (red[4][r] + red[5][r]) + (red[6][r] + red[7][r]);
+        const float rstd = rsqrtf(tot / (float)K + ni.eps);
+        for (int e = tid * 8; e < K; e += NW * 64 * 8) {
+            const uint4 h = *reinterpret_cast<const uint4*>(Hs + (size_t)r * ldh + e), gw = *reinterpret_cast<const uint4*>(ni.lnw + e);
+            *reinterpret_cast<uint4*>(xs + (size_t)r * rstride + e * 2) = norm_chunk(h, gw, rstd);
+        }
+    }
+    __syncthreads();
+    int rr = ln; if (rr >= M) rr = M - 1;
+    const unsigned char* xrow = xs + (size_t)rr * rstride + (kbeg + g * 8) * 2;
+    auto mm = [&](const bf16x8_t (&b)[U], int kk, f32x4_t& acc) {
+#pragma unroll
+        for (int u = 0; u < U; ++u)
+            acc = __builtin_amdgcn_mfma_f32_16x16x32_bf16(*reinterpret_cast<const bf16x8_t*>(xrow + (kk + 32 * u) * 2), b[u], acc, 0, 0, 0);
+        __builtin_amdgcn_sched_barrier(0);
+    };
+    for (; cb < n_cb; cb += gridDim.x) {
+        f32x4_t acc = f32x4_t{0.f, 0.f, 0.f, 0.f};
+        int it = 0;
+        for (; it + 2 <= nit; it += 2) {
+            if (!b1_ahead) ldw(b1, wp, (it + 1) * 32 * U);
+            b1_ahead = false;
+            mm(b0, it * 32 * U, acc);
+            if (it + 2 < nit) ldw(b0, wp, (it + 2) * 32 * U);
+            mm(b1, (it + 1) * 32 * U, acc);
+        }
+        if (it < nit) mm(b0, it * 32 * U, acc);
+        for (int k = nit * 32 * U; k < kq; k += 32)
+            acc = __builtin_amdgcn_mfma_f32_16x16x32_bf16(*reinterpret_cast<const bf16x8_t*>(xrow + k * 2),
+                                                          *reinterpret_cast<const bf16x8_t*>(wp + k), acc, 0, 0, 0);
+        const int cb_next = cb + gridDim.x;
+        const uint16_t* wp_next = wptr(cb_next < n_cb ? cb_next : cb);
+        if (cb_next < n_cb && nit > 0) ldw(b0, wp_next, 0);                     // next column block's first batch under this epilogue
+#pragma unroll
+        for (int r = 0; r < 4; ++r) part[wave][lane][r] = acc[r];
+        __syncthreads();
+        if constexpr (SWIGLU) {
+            if (tid < 128) {           // C map: col = lane & 15, row = (lane >> 4) * 4 + r.  (row = tid / 8, feature = tid % 8)
+                const int row = tid >> 3, c = tid & 7;
+                if (row < M && cb * 8 + c < N) {
+                    const int lg = (row >> 2) * 16 + c, lu = lg + 8, q = row & 3;
+                    float gs = 0.f, us = 0.f;
+                    if constexpr (NW == 4) { gs = (part[0][lg][q] + part[1][lg][q]) + (part[2][lg][q] + part[3][lg][q]);
+                                             us = (part[0][lu][q] + part[1][lu][q]) + (part[2][lu][q] + part[3][lu][q]); }
+                    const float gb = bf2f(f2bf(gs)), ub = bf2f(f2bf(us));
+                    const float sl = bf2f(f2bf(gb / (1.f + __expf(-gb))));
+                    Y[(size_t)row * ldy + cb * 8 + c] = (uint16_t)f2bf(sl * ub);
+                }
+            }
+        } else {
+            if (wave == 0) {
+#pragma unroll
+                for (int r = 0; r < 4; ++r) {
+                    const int row = g * 4 + r, col = cb * 16 + ln;
+                    float sacc = (part[0][lane][r] + part[1][lane][r]) + (part[2][lane][r] + part[3][lane][r]);
+                    if constexpr (NW == 8) sacc += (part[4][lane][r] + part[5][lane][r]) + (part[6][lane][r] + part[7][lane][r]);
+                    if (row < M && col < N) Y[(size_t)row * ldy + col] = (uint16_t)f2bf(sacc);
+                }
+            }
+        }
+        __syncthreads();                                                       // `part` is free for the next column block
+        wp = wp_next;
+    }
 }
 
 template <int MT, int NW, bool NORM = false, bool SSOUT = false>
@@ -315,14 +441,14 @@ __global__ void __launch_bounds__(NW * 64) skinny_gemm_kernel(const uint16_t* __
 #pragma unroll
             for (int t = 0; t < MT; ++t) {
                 bf16x8_t av = a[u][t];
-                if constexpr (NORM) av = norm_frag(av, gw[u], rstd);
+                if constexpr (NORM) av = __builtin_bit_cast(bf16x8_t, norm_chunk(__builtin_bit_cast(uint4, av), __builtin_bit_cast(uint4, gw[u]), rstd));
                 acc[t] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(av, b[u], acc[t], 0, 0, 0);
             }
         __builtin_amdgcn_sched_barrier(0);
     };
     if constexpr (MT == 1) {
         if (nit > 0) ld(b0, a0, g0, 0);
-        if constexpr (NORM) { int r = ln; if (r >= M) r = M - 1; rstd = row_rstd(ni, r, g, K); }     // behind the first W batch
+        if constexpr (NORM) { int r = ln; if (r >= M) r = M - 1; rstd = row_rstd(ni, r, K); }
         int it = 0;
         for (; it + 2 <= nit; it += 2) {
             ld(b1, a1, g1, (it + 1) * 32 * U);
@@ -340,7 +466,7 @@ __global__ void __launch_bounds__(NW * 64) skinny_gemm_kernel(const uint16_t* __
 #pragma unroll
         for (int t = 0; t < MT; ++t) {
             bf16x8_t a = *reinterpret_cast<const bf16x8_t*>(xp[t] + k);
-            if constexpr (NORM) a = norm_frag(a, *reinterpret_cast<const bf16x8_t*>(gp + k), rstd);
+            if constexpr (NORM) a = __builtin_bit_cast(bf16x8_t, norm_chunk(__builtin_bit_cast(uint4, a), *reinterpret_cast<const uint4*>(gp + k), rstd));
             acc[t] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a, b, acc[t], 0, 0, 0);
         }
     }
@@ -414,13 +540,13 @@ __global__ void __launch_bounds__(256) skinny_swiglu_kernel(const uint16_t* __re
 #pragma unroll
         for (int u = 0; u < U; ++u) {
             bf16x8_t av = a[u];
-            if constexpr (NORM) av = norm_frag(av, gw[u], rstd);
+            if constexpr (NORM) av = __builtin_bit_cast(bf16x8_t, norm_chunk(__builtin_bit_cast(uint4, av), __builtin_bit_cast(uint4, gw[u]), rstd));
             acc = __builtin_amdgcn_mfma_f32_16x16x32_bf16(av, b[u], acc, 0, 0, 0);
         }
         __builtin_amdgcn_sched_barrier(0);
     };
     if (nit > 0) ld(b0, a0, g0, 0);
-    if constexpr (NORM) rstd = row_rstd(ni, r, g, K);            // behind the first W batch
+    if constexpr (NORM) rstd = row_rstd(ni, r, K);
     int it = 0;
     for (; it + 2 <= nit; it += 2) {
         ld(b1, a1, g1, (it + 1) * 32 * U);
@@ -432,7 +558,7 @@ __global__ void __launch_bounds__(256) skinny_swiglu_kernel(const uint16_t* __re
     int k = nit * 32 * U;
     for (; k < kq; k += 32) {
         bf16x8_t a = *reinterpret_cast<const bf16x8_t*>(xp + k);
-        if constexpr (NORM) a = norm_frag(a, *reinterpret_cast<const bf16x8_t*>(gp + k), rstd);
+        if constexpr (NORM) a = __builtin_bit_cast(bf16x8_t, norm_chunk(__builtin_bit_cast(uint4, a), *reinterpret_cast<const uint4*>(gp + k), rstd));
         acc = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a, *reinterpret_cast<const bf16x8_t*>(wp + (size_t)k * WS), acc, 0, 0, 0);
     }
 #pragma unroll
@@ -1040,31 +1166,45 @@ int vdd_skinny_gemm_resid_ss(const void* X, const void* W, const void* R, void* 
     return ok(hipSuccess);
 }
 
+static int normed_grid(int n_cb) {
+    int dev = 0, n = 0;
+    if (hipGetDevice(&dev) != hipSuccess || hipDeviceGetAttribute(&n, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess || n <= 0) n = 256;
+    const int g = 2 * n;                                   // two persistent blocks per CU
+    return n_cb < g ? n_cb : g;
+}
+
 int vdd_skinny_gemm_normed(const void* H, const float* ss, int nss, const void* ln_w, float eps, const void* W, void* Y, int M, int N,
                            int K, int64_t ldh, int64_t ldy, void* stream) {
     if (M <= 0 || N <= 0) return VDD_OK;
-    if (!H || !ss || nss <= 0 || !ln_w || !W || !Y || M > 16 || K % 128 != 0 || (ldh % 8) != 0) return VDD_ERR_INVALID_ARG;
-    dim3 grid((N + 15) / 16, 1);
+    if (!H || !ss || nss <= 0 || (nss % 4) != 0 || !ln_w || !W || !Y || M > 16 || K % 256 != 0 || (ldh % 8) != 0) return VDD_ERR_INVALID_ARG;
+    const size_t lds = (size_t)M * (2 * (size_t)K + 64);
+    if (lds > 152 * 1024) return VDD_ERR_UNSUPPORTED;
+    const int n_cb = (N + 15) / 16;
     const NormIn ni{ss, nss, (const uint16_t*)ln_w, eps};
-    hipStream_t st = (hipStream_t)stream;
-    if (N <= 8192 && K % 256 == 0)
-        hipLaunchKernelGGL((skinny_gemm_kernel<1, 8, true, false>), grid, dim3(512), 0, st, (const uint16_t*)H, (const uint16_t*)W, (const uint16_t*)nullptr,
-                           (uint16_t*)Y, (float*)nullptr, M, N, K, (long long)ldh, 0ll, (long long)ldy, ni, (float*)nullptr);
-    else
-        hipLaunchKernelGGL((skinny_gemm_kernel<1, 4, true, false>), grid, dim3(256), 0, st, (const uint16_t*)H, (const uint16_t*)W, (const uint16_t*)nullptr,
-                           (uint16_t*)Y, (float*)nullptr, M, N, K, (long long)ldh, 0ll, (long long)ldy, ni, (float*)nullptr);
+    static bool attr = false;
+    if (!attr) {
+        (void)hipFuncSetAttribute((const void*)skinny_normed_kernel<4, false>, hipFuncAttributeMaxDynamicSharedMemorySize, 152 * 1024);
+        (void)hipFuncSetAttribute((const void*)skinny_normed_kernel<4, true>, hipFuncAttributeMaxDynamicSharedMemorySize, 152 * 1024);
+        attr = true;
+    }
+    hipLaunchKernelGGL((skinny_normed_kernel<4, false>), dim3(normed_grid(n_cb)), dim3(256), lds, (hipStream_t)stream, (const uint16_t*)H,
+                       (const uint16_t*)W, (uint16_t*)Y, M, N, K, (long long)ldh, (long long)ldy, ni, n_cb);
     return ok(hipSuccess);
 }
 
 int vdd_skinny_swiglu_normed(const void* H, const float* ss, int nss, const void* ln_w, float eps, const void* W_gate_up, void* act,
                              int M, int F, int K, int64_t ldh, void* stream) {
     if (M <= 0 || F <= 0) return VDD_OK;
-    if (!H || !ss || nss <= 0 || !ln_w || !W_gate_up || !act || M > 16 || K % 128 != 0 || (ldh % 8) != 0) return VDD_ERR_INVALID_ARG;
-    hipLaunchKernelGGL(skinny_swiglu_kernel<true>, dim3((F + 7) / 8), dim3(256), 0, (hipStream_t)stream, (const uint16_t*)H,
-                       (const uint16_t*)W_gate_up, (uint16_t*)act, M, F, K, (long long)ldh, NormIn{ss, nss, (const uint16_t*)ln_w, eps});
+    if (!H || !ss || nss <= 0 || (nss % 4) != 0 || !ln_w || !W_gate_up || !act || M > 16 || K % 256 != 0 || (ldh % 8) != 0) return VDD_ERR_INVALID_ARG;
+    const size_t lds = (size_t)M * (2 * (size_t)K + 64);
+    if (lds > 152 * 1024) return VDD_ERR_UNSUPPORTED;
+    const int n_cb = (F + 7) / 8;
+    static bool attr = false;
+    if (!attr) { (void)hipFuncSetAttribute((const void*)skinny_normed_kernel<4, true>, hipFuncAttributeMaxDynamicSharedMemorySize, 152 * 1024); attr = true; }
+    hipLaunchKernelGGL((skinny_normed_kernel<4, true>), dim3(normed_grid(n_cb)), dim3(256), lds, (hipStream_t)stream, (const uint16_t*)H,
+                       (const uint16_t*)W_gate_up, (uint16_t*)act, M, F, K, (long long)ldh, (long long)F, NormIn{ss, nss, (const uint16_t*)ln_w, eps}, n_cb);
     return ok(hipSuccess);
 }
-
 int vdd_skinny_swiglu(const void* X, const void* W_gate_up, void* act, int M, int F, int K, int64_t ldx, void* stream) {
     return skinny_swiglu_launch(X, W_gate_up, act, M, F, K, ldx, stream);
 }

@@ -462,8 +462,8 @@ class LanguageModel:
         c, t = self.cfg, self.w.t
         H, Hkv, D = c.n_heads, c.n_kv_heads, c.head_dim
         resid = ops.embed(tokens, t["embed"])
-        if (self.fuse_norms and grouping is None and tokens.shape[0] <= min(ops.FUSED_ATTN_MAX_M, ops.NORM_FUSED_MAX_M) and D == 128
-                and c.d % 256 == 0 and c.ffn % 128 == 0 and c.n_layers > 0):
+        if (self.fuse_norms and grouping is None and tokens.shape[0] <= min(ops.FUSED_ATTN_MAX_M, ops.norm_fused_rows(c.d)) and D == 128
+                and c.ffn % 128 == 0 and c.n_layers > 0):
             return self._decode_step_few_rows(resid, pos, cpos, slot, attn_rows, kv)
         delta = None
         for i in range(c.n_layers):

@@ -151,6 +151,12 @@ def linear_to_norm(x, w):
 NORM_FUSED_MAX_M = 16   # rows up to which the decoder layer's RMSNorms ride inside the projections around them
 
 
+def norm_fused_rows(d: int) -> int:
+    """How many rows the normalise-once projections take for a residual stream of width d: the normalised rows live in LDS
+    (M x (2 d + 64) bytes of the 152 KiB the kernel may use)."""
+    return min(NORM_FUSED_MAX_M, (152 * 1024) // (2 * d + 64)) if d % 256 == 0 else 0
+
+
 def linear_resid_ss(x, w, resid, out=None, ss=None):
     """h = bf16(bf16(x w^T) + resid) (the new residual stream) and ss [M, N/16] fp32: per-block partial sums of squares of h's rows,
     for linear_normed / swiglu_linear_normed.  M <= NORM_FUSED_MAX_M."""
