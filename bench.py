@@ -139,6 +139,23 @@ def kernel_point(dev, B, V, beta=0.1, n_in=2, scores=True, iters=100, warmup=10)
             "shape": {"B": B, "V": V, "dtype": "bf16", "n_in": n_in, "scores_out": scores, "beta": beta, "note": "use_dd_unk, T=0.2"}}
 
 
+def pmc_traffic():
+    """HBM bytes per launch of the fused kernel at the roofline shape from the latest committed rocprofv3 PMC passes
+    (profiles/r*_pmc_fused_kernel.txt: FETCH_SIZE and WRITE_SIZE in KB, separate passes; gfx950 reads are counted at half: x 2) -
+    the measured cross-check of the computed `traffic`; None when no profile file travels with the tree."""
+    import glob
+    import re
+    files = sorted(glob.glob(os.path.join(ROOT, "profiles", "r*pmc_fused_kernel.txt")))
+    if not files:
+        return None
+    txt = open(files[-1]).read()
+    f, w = re.search(r"FETCH_SIZE\s+n=\d+ mean ([0-9.]+) KB", txt), re.search(r"WRITE_SIZE\s+n=\d+ mean ([0-9.]+) KB", txt)
+    if not (f and w):
+        return None
+    return {"bytes": int((2 * float(f.group(1)) + float(w.group(1))) * 1000), "source": os.path.relpath(files[-1], ROOT),
+            "formula": "2 x FETCH_SIZE + WRITE_SIZE (KB -> bytes)"}
+
+
 # ------------------------------------------------------------------ reference-path baselines (oracle loop + eager torch model)
 def reference_path(weights, device, ids, img, n_new, dtype=None, layers=None):
     """Runs the reference's decoding path for ONE question: oracle restatement of sample() (B=1, one forward per
@@ -257,6 +274,10 @@ def bench_cpu(eng):
     t_fixed = reference_path(w0, "cpu", pids[0], pimgs[0], n7)
     t_full = t_fixed + max(0.0, (t_small - t_fixed) / layers) * full
     return {"value": round(cfg1, 2), "unit": "tokens/s", "cores": threads, "host_cpus": os.cpu_count(), "kind": "port",
+            "comparable_with_headline": False,
+            "note": "value = BASELINE config #1 (the reference's CPU-runnable plumbing case: toy LM, d = 64) - a DIFFERENT model from the "
+                    "LLaVA-7B GPU headline, so value / cpu_baseline.value is not a speed-up; the same-model CPU figure is "
+                    "llava7b_bounded.tokens_per_s (2 of 32 layers timed, extrapolated)",
             "sample": f"BASELINE config #1, fully measured: {n_q} POPE-like questions (35 sys + image slot + 24 text tokens), B=1, use_dd, "
                       f"top-k 1, {n_new} new tokens each, toy KV-cache LM (V=32000, d=64) on torch-CPU through the oracle restatement of "
                       f"the reference loop: {tot:.1f}s",
@@ -416,6 +437,8 @@ def main():
         ms_step = dt / a.steps * 1e3
         ms_decode = (dt / a.steps - t_pre) / (n_new - 2) * 1e3
         wbytes = eng.w.lm_stream_bytes()
+        if roof is not None:
+            roof["traffic_pmc"] = pmc_traffic()
         line = {"metric": "decode tokens/sec (VDD dual-pass) LLaVA-1.5-7B POPE", "value": round(world * Q * n_new * a.steps / dt, 1),
                 "unit": "tokens/s", "n_gpus": world, "steps": a.steps, "warmup": a.warmup, "ms_per_step": round(ms_step, 2),
                 "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "bf16", "data": "synthetic",

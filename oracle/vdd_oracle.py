@@ -12,7 +12,8 @@ Parity status: PINNED against the reference itself.  tests/golden/make_golden.py
 drives the unmodified reference `sample()` (vcd_utils/vcd_sample.py:25-323, loaded
 through the two runtime shims of SURVEY.md Appendix B) in the build container and
 commits its inputs/outputs under tests/golden/*.npz; tests/test_oracle_golden.py
-checks this restatement against those vectors bit-for-bit.  Version caveat: the
+checks this restatement against those vectors bit-for-bit (per-step rows in both torch-CPU and torch-GPU
+scalar arithmetic, loop traces, EOS/pad, logits-processor runs, noise, calibration).  Version caveat: the
 fixtures were produced with torch 2.10 / transformers 5.15 warpers, not the
 reference's (unpinned, ~4.31-era) versions.
 
