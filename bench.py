@@ -370,9 +370,14 @@ def main():
         local = int(os.environ["VDD_FORCE_DEVICE"])
     dev = torch.device(f"cuda:{local}")
     torch.cuda.set_device(dev)
-    if world > 1:
+    # VDD_FORCE_DIST=1: initialise the process group (and run barrier / all_reduce / the result all_gather through it) even at world
+    # size 1 - the only way to execute the RCCL code path on a single-GPU box (tests/test_bench_gpu.py)
+    use_dist = world > 1 or os.environ.get("VDD_FORCE_DIST") == "1"
+    if use_dist:
         import torch.distributed as dist
         backend = os.environ.get("VDD_DIST_BACKEND", "nccl")            # "nccl" is RCCL on ROCm
+        if "RANK" not in os.environ:
+            os.environ.update(RANK="0", WORLD_SIZE="1", MASTER_ADDR="127.0.0.1", MASTER_PORT=os.environ.get("MASTER_PORT", "29533"))
         dist.init_process_group(backend, **({"device_id": dev} if backend == "nccl" else {}))
         assert dist.get_world_size() == world
 
@@ -408,7 +413,7 @@ def main():
     for _ in range(a.warmup):
         out = step()
     torch.cuda.synchronize(dev)
-    if world > 1:
+    if use_dist:
         import torch.distributed as dist
         dist.barrier()
     torch.cuda.synchronize(dev)
@@ -418,11 +423,11 @@ def main():
     res = gather_results(torch.arange(rank * Q, (rank + 1) * Q, device=dev), out.tokens, torch.full((Q,), out.tokens.shape[1], device=dev),
                          out.top_tok, out.top_prob, world * Q)                       # the one result gather
     torch.cuda.synchronize(dev)
-    if world > 1:
+    if use_dist:
         dist.barrier()
     torch.cuda.synchronize(dev)
     dt = time.perf_counter() - t0
-    if world > 1:
+    if use_dist:
         t = torch.tensor([dt], device=dev, dtype=torch.float64)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         dt = t.item()
@@ -494,8 +499,9 @@ def main():
             line["cpu_baseline"] = bench_cpu(eng)
         else:
             line["cpu_baseline"] = None
+        line["collective_backend"] = (os.environ.get("VDD_DIST_BACKEND", "nccl") if use_dist else None)
         print(json.dumps(line))
-    if world > 1:
+    if use_dist:
         dist.barrier()
         dist.destroy_process_group()
 

@@ -46,3 +46,11 @@ def test_bench_strong_scaling_mode_splits_one_list_over_two_ranks():
     assert line["gathered_question_ids_cover_the_list_once"] and 1.0 <= line["mean_answer_tokens"] <= 2.0
     one = _run(["--model", "tiny", "--strong", "42", "--questions", "12", "--steps", "1", "--warmup", "0", "--no-baselines"], {})
     assert one["n_gpus"] == 1 and one["config"]["questions_rank0"] == 42
+
+
+def test_bench_result_gather_through_rccl_at_world_size_one():
+    """The one thing a single-GPU box can do for the N > 1 path: run the SAME process-group code through RCCL (backend "nccl" with
+    device_id, barrier, all_reduce of the timing, the all_gather of the section-8(e) payload on device tensors) at world size 1."""
+    line = _run(["--model", "tiny", "--questions", "12", "--steps", "1", "--warmup", "1", "--no-baselines"],
+                {"VDD_FORCE_DIST": "1", "VDD_DIST_BACKEND": "nccl", "MASTER_PORT": "29541", "HSA_ENABLE_IPC_MODE_LEGACY": "0"})
+    assert line["collective_backend"] == "nccl" and line["n_gpus"] == 1 and line["value"] > 0
