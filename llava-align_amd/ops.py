@@ -582,9 +582,10 @@ class StopWords:
             raise ValueError(f"`stop_words_ids` has to be a non-emtpy list, but is {stop_words_ids}.")
         if any(not isinstance(w, list) for w in stop_words_ids):
             raise ValueError(f"`stop_words_ids` has to be a list of lists, but is {stop_words_ids}.")
-        if any(any((not isinstance(t, int) or isinstance(t, bool) or t < 0) for t in w) for w in stop_words_ids):
+        import numpy as np
+        if any(any((not isinstance(t, (int, np.integer)) or isinstance(t, bool) or t < 0) for t in w) for w in stop_words_ids):
             raise ValueError(f"Each list in `stop_words_ids` has to be a list of positive integers, but is {stop_words_ids}.")
-        self.seqs = [list(w) for w in stop_words_ids if list(w) != [eos_token_id]]
+        self.seqs = [[int(t) for t in w] for w in stop_words_ids if [int(t) for t in w] != [int(eos_token_id)]]
         assert all(len(w) > 0 for w in self.seqs), f"Stop words token sequences {stop_words_ids} cannot have an empty list"
         self.eos_token_id = int(eos_token_id)
         self.max_len = max([len(w) for w in self.seqs] + [1])

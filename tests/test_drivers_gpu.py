@@ -165,3 +165,32 @@ def test_run_blip_pope_vcd_against_direct_front_end_and_engine_calls(tmp_path):
     assert map_pad_to_eos(torch.tensor([[5, 0, 0], [0, 7, 2]])).tolist() == [[5, 2, 2], [2, 7, 2]]
     # VCD at step 0 only (alpha 0.5 = the sampler default the reference driver leaves in place): masked entries appear in the
     # main pass's scores
+
+
+def test_drivers_at_7b_widths_with_shared_image_prefixes(tmp_path):
+    """run_pope and run_mme over an engine with LLaVA-1.5-7B widths (2 decoder layers): 48 POPE questions (8 images x 6: grouped prefix
+    attention, captured graph, EOS) and 32 MME questions (2 per image), answers files + scorers + converter end to end."""
+    from llava_align_amd import calibrate as C
+    from llava_align_amd.engine import LlavaConfig, LlavaWeights, LMConfig, VddLlavaEngine, VisionConfig
+    from llava_align_amd.mme_driver import llava_mme_inputs, run_mme
+    from llava_align_amd.pope_driver import run_pope
+    cfg = LlavaConfig(LMConfig(n_layers=2, max_pos=1024), VisionConfig(layers=3), "drivers-7b-widths")
+    eng = VddLlavaEngine(cfg, weights=LlavaWeights.random(cfg, DEV, seed=5, std=0.02, lm_head_gain=2.0), device=DEV, use_graph=True)
+    images = {}
+
+    def load_image(name):
+        if name not in images:
+            images[name] = torch.randn(3, 336, 336, generator=torch.Generator().manual_seed(len(images)))
+        return images[name]
+    pope_q = [{"question_id": i, "image": f"im{i // 6}.jpg", "text": f"Is there a thing{i} in the image?", "label": ("yes", "no")[i % 2]} for i in range(48)]
+    enc = lambda text, with_image: [t % 31990 + 3 if t >= 0 else t for t in toy_encode(("<image> " if with_image else "") + "system prompt of some length here . " + text)]
+    res = run_pope(eng, pope_q, enc, decode, load_image, answers_path=str(tmp_path / "pope.jsonl"), batch_questions=48, unk_token_id=0, eos_token_id=2,
+                   pad_token_id=0, max_new_tokens=6, use_dd_unk=True, cd_alpha=1.0, cd_beta=0.1, temperature=0.2, seed=1)
+    lines = [json.loads(l) for l in open(tmp_path / "pope.jsonl")]
+    assert len(lines) == 48 and all(set(l["naive"]) and l["logits_score"] == C.get_prob_from_logits(l["naive"]) for l in lines)
+    assert set(res["scores"]) == {"string_match", "naive", "none", "unk", "none_unk"}
+    qs, gt = mme_questions(n_img=2)
+    build = llava_mme_inputs(lambda p: [t % 31990 + 3 if t >= 0 else t for t in toy_encode(p)], load_image, unk_token_id=0)
+    out = run_mme(eng, qs, build, decode, answers_path=str(tmp_path / "mme.jsonl"), batch_questions=32, max_new_tokens=4, eos_token_id=2, pad_token_id=0,
+                  gt=gt, results_root=str(tmp_path / "res"), experiment="w7b", use_dd=True, use_dd_unk=True, cd_alpha=1.0, cd_beta=0.1, temperature=0.2, seed=2)
+    assert len(out["answers"]) == 32 and all(out["scores"][n] is not None for n in ("naive", "none", "unk", "none_unk"))
