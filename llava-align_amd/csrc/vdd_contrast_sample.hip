@@ -470,21 +470,71 @@ __global__ void __launch_bounds__(BLOCK, 6) vdd_contrast_sample_kernel(KP p) {
     if (p.c != nullptr) {
         // ---- pass A: v -> working row, row max (vcd_sample.py:191) --------------------
         float vmax = -INFINITY; int vnan = 0, zero = 0;
-        for (int base = tid; base < nch; base += UNR * BLOCK) {
+        LiveList& LL = *reinterpret_cast<LiveList*>(reinterpret_cast<unsigned char*>(&sm) + ((sizeof(Smem) + 15) & ~(size_t)15));
+        // Rows too large for the chip (!LDSROW: V = 151,936) used to read v TWICE - once for the row maximum, once more (from L2 / the
+        // Infinity Cache) to contrast and mask.  Now pass A reads v ONCE, nontemporally, and stashes every chunk that CAN hold a
+        // survivor in the LDS work list of pass B: a chunk is kept when one of its elements reaches fl(bm + log beta), bm = the
+        // block-wide maximum of all batches read so far (of this very batch for the first one).  bm <= the final maximum and the
+        // rounding is monotone, so that cutoff is <= the final one: the list is a superset of the live chunks, and pass B contrasts
+        // list entries only (chunks that fail the final cutoff come out all -inf).  A list overflow (a flat row, or a maximum that
+        // shows up late in a row of large values) falls back to the two-read form.
+        [[maybe_unused]] unsigned long long stash = 0ull;     // this thread's stashed chunks (bit k: ch = tid + k * BLOCK)
+        [[maybe_unused]] bool stash_ok = !LDSROW && nch <= 64 * BLOCK;
+        [[maybe_unused]] const float lb_a = (p.flags & VDD_CUTOFF_F32_SCALAR) ? p.log_beta : rnd<DT>(p.log_beta);
+        float bm = -INFINITY;
+        int kb_a = 0;
+        for (int base = tid; LDSROW ? base < nch : base - tid < nch; base += UNR * BLOCK, kb_a += UNR) {   // (!LDSROW: uniform trip count, block-wide exchanges inside)
             uint32_t q[UNR][4];
 #pragma unroll
-            for (int u = 0; u < UNR; ++u) { const int ch = base + u * BLOCK; if (ch < nch) gload<DT, LDSROW>(p.v, ov, ch, V, p.vec_in, q[u]); }
+            for (int u = 0; u < UNR; ++u) { const int ch = base + u * BLOCK; if (ch < nch) gload<DT, true>(p.v, ov, ch, V, p.vec_in, q[u]); }
+            [[maybe_unused]] float cmax[UNR];
 #pragma unroll
             for (int u = 0; u < UNR; ++u) {
                 const int ch = base + u * BLOCK;
+                if constexpr (!LDSROW) cmax[u] = -INFINITY;
                 if (ch < nch) {
                     if constexpr (LDSROW) R.put(ch, q[u]);
 #pragma unroll
-                    for (int j = 0; j < EPC; ++j) { float f = Tr<DT>::to_f(getb<DT>(q[u], j)); vnan |= (f != f) ? 1 : 0; vmax = fmaxf(vmax, f); }
+                    for (int j = 0; j < EPC; ++j) {
+                        float f = Tr<DT>::to_f(getb<DT>(q[u], j)); vnan |= (f != f) ? 1 : 0; vmax = fmaxf(vmax, f);
+                        if constexpr (!LDSROW) { if (ch * EPC + j < V) cmax[u] = fmaxf(cmax[u], f); }
+                    }
+                }
+            }
+            if constexpr (!LDSROW) {
+                if (stash_ok) {
+                    // block-wide maximum up to and including this batch (one exchange per batch of UNR * BLOCK chunks)
+                    float t = wave_max(vmax);
+                    if (lane == 0) sm.f[1][wave] = t;
+                    __syncthreads();
+                    float nb = sm.f[1][0];
+#pragma unroll
+                    for (int w = 1; w < NWAVE; ++w) nb = fmaxf(nb, sm.f[1][w]);
+                    __syncthreads();
+                    bm = fmaxf(bm, nb);
+                    const float cut_lag = rnd<DT>(__fadd_rn(bm, lb_a));
+#pragma unroll
+                    for (int u = 0; u < UNR; ++u) {
+                        const int ch = base + u * BLOCK;
+                        if (ch < nch && (!(cmax[u] < cut_lag) || (PROC && ch == force_ch))) {
+                            const unsigned slot = atomicAdd(&sm.live_n, 1u);
+                            if (slot < (unsigned)LIVE_CAP) {
+                                LL.ch[slot] = ch;
+                                LL.data[slot] = make_uint4(q[u][0], q[u][1], q[u][2], q[u][3]);
+                                stash |= 1ull << (kb_a + u);
+                            }
+                        }
+                    }
                 }
             }
         }
         block_max_count2(vmax, vnan, zero, sm, lane, wave);
+        if constexpr (!LDSROW) {
+            if (stash_ok && sm.live_n > (unsigned)LIVE_CAP) stash_ok = false;       // (uniform: read behind the barriers of the exchange above)
+            __syncthreads();
+            if (!stash_ok && tid == 0) sm.live_n = 0u;
+            __syncthreads();
+        }
         t_nan = vnan ? 1 : 0;
         const float lb = (p.flags & VDD_CUTOFF_F32_SCALAR) ? p.log_beta : rnd<DT>(p.log_beta);
         const float cutoff = rnd<DT>(__fadd_rn(vmax, lb));                                   // :191
@@ -499,7 +549,6 @@ __global__ void __launch_bounds__(BLOCK, 6) vdd_contrast_sample_kernel(KP p) {
         // live chunks (index + the v chunk) to an LDS list, then the list is processed one entry per thread with all lanes busy
         // (the c / d loads of a pass go out together), and the results are copied back into the row: by any thread for the LDS
         // (or global) part, by the owner for its register-resident chunks.  Past LIVE_CAP entries a chunk is done in place.
-        LiveList& LL = *reinterpret_cast<LiveList*>(reinterpret_cast<unsigned char*>(&sm) + ((sizeof(Smem) + 15) & ~(size_t)15));
         auto contrast_chunk = [&](auto both_c, int ch, const uint32_t* qv, const uint32_t* qc, const uint32_t* qd, uint32_t* x4) {
             constexpr bool BOTH = decltype(both_c)::value;
             if constexpr (Tr<DT>::KEYBITS == 16) { x4[0] = x4[1] = x4[2] = x4[3] = NINF | (NINF << 16); }
@@ -539,7 +588,19 @@ __global__ void __launch_bounds__(BLOCK, 6) vdd_contrast_sample_kernel(KP p) {
 #pragma unroll
             for (int r = 0; r < NREG; ++r) rslot[r] = -1;
             int kb = 0;
-            for (int base = tid; base < nch; base += UNR * BLOCK, kb += UNR) {
+            bool walk = true;
+            if constexpr (!LDSROW) {
+                if (stash_ok) {                // single-read form: the list already holds every chunk that can be live
+                    walk = false;
+                    livemask = stash;
+                    if (!sparse) {             // the scores / working row: -inf everywhere the list does not cover (written by the owner)
+                        int k2 = 0;
+                        for (int ch = tid; ch < nch; ch += BLOCK, ++k2)
+                            if (!((stash >> k2) & 1ull)) R.put(ch, ninf4);
+                    }
+                }
+            }
+            for (int base = tid; walk && base < nch; base += UNR * BLOCK, kb += UNR) {
                 uint32_t qv[UNR][4];
                 if constexpr (!LDSROW) {       // global working row: batch the v re-reads (L2 / Infinity-Cache hits)
 #pragma unroll
