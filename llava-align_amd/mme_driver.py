@@ -41,10 +41,19 @@ def llava_mme_inputs(encode: Callable[[str], List[int]], load_image: Callable[[s
     """run_llava.py: main = '<image>\\n' + question in the vicuna_v1 template (:52-62, no one-word suffix); none = question + suffix
     without an image token (:101-109 with images=None); unk = '<image>\\n' + question + suffix with the slot replaced by the
     tokenizer's <unk> (:102-115).  `encode(prompt)` tokenises with -200 where '<image>' stands (tokenizer_image_token)."""
+    cache: Dict[str, torch.Tensor] = {}         # MME asks two questions per image, adjacent after the driver's sort: decode each image once
+
+    def image(name):
+        if name not in cache:
+            if len(cache) >= 64:
+                cache.pop(next(iter(cache)))
+            cache[name] = load_image(name)
+        return cache[name]
+
     def build(line, kind):
         q = line["text"]
         if kind == "main":
-            return {"input_ids": torch.tensor(encode(vicuna_v1_prompt("<image>\n" + q))), "image": load_image(line["image"])}
+            return {"input_ids": torch.tensor(encode(vicuna_v1_prompt("<image>\n" + q))), "image": image(line["image"])}
         if kind == "none":
             return {"input_ids": torch.tensor(encode(vicuna_v1_prompt(q + ONE_WORD))), "image": None}
         ids = encode(vicuna_v1_prompt("<image>\n" + q + ONE_WORD))
