@@ -115,3 +115,39 @@ def test_eos_without_pad_raises_like_the_reference():
     ids = torch.ones(1, 4, dtype=torch.long)
     with pytest.raises(ValueError, match="make sure that `pad_token_id` is defined"):
         VS.sample(M(), ids, eos_token_id=2, pad_token_id=None)
+
+
+def test_driver_prompt_builders_follow_the_reference_format_strings():
+    """CPU-only host logic of the MME / InstructBLIP drivers: the prompt strings the reference builds (run_llava.py:52-62,101-115,
+    run_qwen.py:101-104,176-177, blip_calibrate.py:42,74; conversation.py:252-262) and the token 0 -> 2 post-map
+    (blip2_vicuna_instruct.py:414)."""
+    import torch
+    from llava_align_amd.blip_driver import QUESTION_SUFFIX, map_pad_to_eos
+    from llava_align_amd.mme_driver import MME_SUBSETS, ONE_WORD, llava_mme_inputs, qwen_mme_inputs, vicuna_v1_prompt
+    assert vicuna_v1_prompt("hi") == ("A chat between a curious user and an artificial intelligence assistant. The assistant gives helpful, "
+                                      "detailed, and polite answers to the user's questions. USER: hi ASSISTANT:")
+    assert ONE_WORD == QUESTION_SUFFIX == " Please answer this question with one word."
+    assert len(MME_SUBSETS) == 8 and "existence" in MME_SUBSETS and "artwork" not in MME_SUBSETS
+    seen = []
+
+    def encode(prompt):
+        seen.append(prompt)
+        return [1] + [(-200 if w == "<image>" else 7) for w in prompt.replace("<image>", " <image> ").split()]
+    loads = []
+    build = llava_mme_inputs(encode, lambda name: loads.append(name) or torch.zeros(3, 2, 2), unk_token_id=0)
+    line = {"image": "a.png", "text": "Is it red?"}
+    main, none, unk = build(line, "main"), build(line, "none"), build(line, "unk")
+    assert seen[0].endswith("USER: <image>\nIs it red? ASSISTANT:")                                   # main: no one-word suffix
+    assert seen[1].endswith("USER: Is it red? Please answer this question with one word. ASSISTANT:")    # none: no image token
+    assert seen[2].endswith("USER: <image>\nIs it red? Please answer this question with one word. ASSISTANT:")
+    assert (main["input_ids"] == -200).sum() == 1 and main["image"] is not None
+    assert (none["input_ids"] == -200).sum() == 0 and none["image"] is None
+    assert (unk["input_ids"] == -200).sum() == 0 and (unk["input_ids"] == 0).sum() == 1 and unk["image"] is None
+    build(line, "main")
+    assert loads == ["a.png"]                                                                          # decoded once, cached
+    texts = []
+    qb = qwen_mme_inputs(lambda text, path: texts.append((text, path)) or torch.zeros(1, 4), image_path=lambda f: "/imgs/" + f)
+    for kind in ("main", "none", "unk"):
+        qb(line, kind)
+    assert texts == [("<img>/imgs/a.png</img>Is it red? Answer:", "/imgs/a.png"), ("Is it red? Answer:", None), ("None Is it red? Answer:", None)]
+    assert map_pad_to_eos(torch.tensor([[5, 0, 0], [0, 7, 2]])).tolist() == [[5, 2, 2], [2, 7, 2]]
