@@ -1077,12 +1077,29 @@ class VddLlavaEngine:
         prefix, suffix = [], []
         n_slots, max_len, unshared = 0, 0, 0
         main_rows = branches[0][1]
+        # Prompts given as embeddings: rows fed by the SAME tensor - the Qwen-style degenerate image-free branches, which re-run
+        # the main branch's inputs - share everything but the last position as a prefix slot: their prefill K/V
+        # are identical by construction, so they are computed once (config #4: half the prefill tokens and KV memory).
+        emb_uses: Dict[tuple, int] = {}
+        if embeds_only and share_prefix:
+            for _, rows_, feats_ in branches:
+                for qi in range(len(rows_)):
+                    k_ = (feats_[qi].data_ptr(), int(feats_[qi].shape[0]))
+                    emb_uses[k_] = emb_uses.get(k_, 0) + 1
         for name, rows, feats in branches:
-            if embeds_only:                                  # whole prompt given as embeddings: one own slot each, nothing shared
+            if embeds_only:                                  # whole prompt given as embeddings
                 for qi in range(len(rows)):
                     T = int(feats[qi].shape[0])
-                    suffix.append(dict(slot=len(suffix), tokens=None, pre=[], img=feats[qi], suf=[], T=T, pos0=0, pslot=0, plen=0))
+                    key = (feats[qi].data_ptr(), T)
                     unshared += T; max_len = max(max_len, T); n_slots += 1
+                    if emb_uses.get(key, 0) >= 2 and T > 1:
+                        if key not in prefix_slots:
+                            prefix_slots[key] = dict(slot=len(prefix), tokens=[], img=feats[qi][: T - 1], T=T - 1, pos0=0, pslot=0, plen=0)
+                            prefix.append(prefix_slots[key])
+                        ps = prefix_slots[key]["slot"]
+                        suffix.append(dict(slot=len(suffix), tokens=None, pre=[], img=feats[qi][T - 1:], suf=[], T=1, pos0=T - 1, pslot=ps, plen=T - 1))
+                    else:
+                        suffix.append(dict(slot=len(suffix), tokens=None, pre=[], img=feats[qi], suf=[], T=T, pos0=0, pslot=0, plen=0))
                 continue
             for qi, ids in enumerate(rows):
                 src = main_rows[qi]

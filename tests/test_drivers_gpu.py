@@ -125,6 +125,8 @@ def test_run_mme_qwen_call_shape_dual_pass_and_calibrate():
                       output_scores=True, min_new_tokens=1, eos_token_id=eod, pad_token_id=eod)
     plain = eng.generate(None, inputs_embeds=emb, temperature=0.5, cd_greedy=True, max_new_tokens=2, output_scores=True)
     assert dd.stats["n_rows"] == 8 and plain.stats["n_rows"] == 4
+    # both branches are fed by the same embeddings: their prompt K/V are computed once (everything but the last position is a shared prefix)
+    assert dd.stats["prefill_tokens"] == plain.stats["prefill_tokens"] + 4 and dd.stats["unshared_prefill_tokens"] == 2 * plain.stats["prefill_tokens"]
     s_dd, s_pl = dd.scores[0].float(), plain.scores[0].float()
     assert torch.isneginf(s_dd[:, eod]).all()                         # min_new_tokens=1 at step 0
     keep = torch.isfinite(s_dd)
