@@ -795,12 +795,16 @@ class VddLlavaEngine:
                  share_prefix: bool = True, sync_every: int = 8, inputs_embeds=None, min_new_tokens: Optional[int] = None,
                  min_length: Optional[int] = None, stop_words_ids=None, repetition_penalty: Optional[float] = None,
                  logits_processor=None, max_length: Optional[int] = None, num_beams: Optional[int] = None,
-                 num_return_sequences: Optional[int] = None, **other) -> GenerateOutput:
+                 num_return_sequences: Optional[int] = None, embeds_prefix=None, **other) -> GenerateOutput:
         """Same kwargs as the reference's model.generate(...) call (llava_calibrate.py:161-177); `input_ids` is a
         list of 1-D id tensors (one per question, each with one -200 image slot) or a [Q, L] tensor; `images` one
         image per question (repeat the SAME tensor for questions about the same image to share its features and
         prompt-prefix KV).  use_cache / output_attentions are accepted and ignored (attention maps are never
         materialised: flash-style kernels; the reference only reads them for a commented-out plot, :180-183).
+
+        embeds_prefix (with inputs_embeds): per prompt `(key, n)` - the caller's promise that prompts with the same key start with the
+        same n embedding rows (Qwen-VL: '<img>' + the 256 image slots of one image, shared by its questions): they are prefilled once
+        into a shared prefix slot, like [system prompt + image] of the LLaVA path.
 
         Logits processors (what HF's generate() builds into `logits_processor` for vcd_sample.py:197 / :204, in HF's order):
         repetition_penalty (blip2_vicuna_instruct.py:400), min_length (:397; counts the prompt, which is EMPTY for inputs_embeds
@@ -903,7 +907,9 @@ class VddLlavaEngine:
 
         # ---- plan prefill: split every (branch, question) sequence into shared prefix + own suffix -----
         n_img_tok = self.cfg.vision.n_patches
-        plan = self._plan(branches, n_img_tok, share_prefix, embeds_only=inputs_embeds is not None)
+        if embeds_prefix is not None and (inputs_embeds is None or len(embeds_prefix) != Q):
+            raise ValueError("embeds_prefix goes with inputs_embeds: one (key, n_rows) per prompt")
+        plan = self._plan(branches, n_img_tok, share_prefix, embeds_only=inputs_embeds is not None, embeds_prefix=embeds_prefix)
         kv = self.kv(len(plan["prefix"]), max([s_["T"] for s_ in plan["prefix"]] + [0]), len(plan["suffix"]),
                      max(s_["T"] for s_ in plan["suffix"]) + max_new_tokens)
         assert plan["max_len"] + max_new_tokens <= self.cfg.lm.max_pos, "prompt + new tokens exceed the rotary table"
@@ -1069,7 +1075,7 @@ class VddLlavaEngine:
         return gen[:, : int(done_at.max().item()) + 1]
 
     # -- prefill planning ---------------------------------------------------------------------------------
-    def _plan(self, branches, n_img_tok, share_prefix, embeds_only=False):
+    def _plan(self, branches, n_img_tok, share_prefix, embeds_only=False, embeds_prefix=None):
         """Every (branch, question) sequence = [prefix | suffix].  Prefix = everything up to and including the
         image slot (main/cd: system prompt + 576 patch embeddings; unk: system prompt + <unk>; none: system prompt);
         identical prefixes (same tokens, same image features) are prefilled ONCE into a prefix slot."""
@@ -1092,7 +1098,17 @@ class VddLlavaEngine:
                     T = int(feats[qi].shape[0])
                     key = (feats[qi].data_ptr(), T)
                     unshared += T; max_len = max(max_len, T); n_slots += 1
-                    if emb_uses.get(key, 0) >= 2 and T > 1:
+                    if share_prefix and embeds_prefix is not None and embeds_prefix[qi] is not None and 0 < int(embeds_prefix[qi][1]) < T:
+                        # caller-declared common leading rows (same image): one prefix slot per (embedding source, key, length) - the
+                        # degenerate branches read the main branch's list, so they land in the same slot
+                        n_pre = int(embeds_prefix[qi][1])
+                        pkey = ("emb", id(feats), embeds_prefix[qi][0], n_pre)
+                        if pkey not in prefix_slots:
+                            prefix_slots[pkey] = dict(slot=len(prefix), tokens=[], img=feats[qi][:n_pre], T=n_pre, pos0=0, pslot=0, plen=0)
+                            prefix.append(prefix_slots[pkey])
+                        suffix.append(dict(slot=len(suffix), tokens=None, pre=[], img=feats[qi][n_pre:], suf=[], T=T - n_pre, pos0=n_pre,
+                                           pslot=prefix_slots[pkey]["slot"], plen=n_pre))
+                    elif emb_uses.get(key, 0) >= 2 and T > 1:
                         if key not in prefix_slots:
                             prefix_slots[key] = dict(slot=len(prefix), tokens=[], img=feats[qi][: T - 1], T=T - 1, pos0=0, pslot=0, plen=0)
                             prefix.append(prefix_slots[key])

@@ -64,12 +64,17 @@ def llava_mme_inputs(encode: Callable[[str], List[int]], load_image: Callable[[s
 def qwen_mme_inputs(embed_prompt: Callable[[str, Optional[str]], torch.Tensor], image_path: Callable[[str], str] = lambda f: f):
     """run_qwen.py: main = '<img>{path}</img>{q} Answer:' (:176-177), none = '{q} Answer:' (:101-102), unk = 'None {q} Answer:'
     (:103-104).  `embed_prompt(text, image_path_or_None) -> [T, d]` is the caller's Qwen front-end: token embeddings with the 256
-    image slots between <img> and </img> filled by its ViT + resampler."""
+    image slots between <img> and </img> filled by its ViT + resampler; it may return `(embeddings, n_shared)` instead, n_shared =
+    the leading rows every prompt about that image starts with ('<img>' + the image slots): the engine then prefills them once per
+    image (`embeds_prefix`)."""
     def build(line, kind):
         q = line["text"]
         if kind == "main":
             p = image_path(line["image"])
-            return {"inputs_embeds": embed_prompt("<img>{}</img>{} Answer:".format(p, q), p)}
+            e = embed_prompt("<img>{}</img>{} Answer:".format(p, q), p)
+            if isinstance(e, tuple):
+                return {"inputs_embeds": e[0], "embeds_prefix": (p, int(e[1]))}
+            return {"inputs_embeds": e}
         if kind == "none":
             return {"inputs_embeds": embed_prompt("{} Answer:".format(q), None)}
         return {"inputs_embeds": embed_prompt("{} {} Answer:".format("None", q), None)}
@@ -78,7 +83,10 @@ def qwen_mme_inputs(embed_prompt: Callable[[str, Optional[str]], torch.Tensor], 
 
 def _generate(engine, batch, **kw):
     if "inputs_embeds" in batch[0]:
-        return engine.generate(None, inputs_embeds=[b["inputs_embeds"] for b in batch], **kw)
+        unwrap = lambda e: e[0] if isinstance(e, tuple) else e
+        if all("embeds_prefix" in b for b in batch):
+            kw = dict(kw, embeds_prefix=[b["embeds_prefix"] for b in batch])
+        return engine.generate(None, inputs_embeds=[unwrap(b["inputs_embeds"]) for b in batch], **kw)
     imgs = [b["image"] for b in batch]
     has_img = imgs[0] is not None
     return engine.generate([b["input_ids"] for b in batch], images=imgs if has_img else None, **kw)

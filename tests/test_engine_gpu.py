@@ -491,3 +491,29 @@ def test_norm_fused_few_row_step_equals_the_unfused_step(eng):
         fin = torch.isfinite(sa) & torch.isfinite(sb)
         assert (torch.isfinite(sa) ^ torch.isfinite(sb)).sum() <= 2 and (sa[fin].float() - sb[fin].float()).abs().max().item() <= 0.25
     assert (a.tokens == b.tokens).float().mean().item() >= 0.75
+
+
+def test_embedding_prompts_share_declared_prefixes_transparently(eng, batch_invariant):
+    """inputs_embeds prompts (Qwen-VL / LAVIS call shape): `embeds_prefix=(key, n)` - prompts about one image start with the same n
+    rows - and the degenerate image-free branch (same tensor) share prompt K/V; results equal the unshared run."""
+    d = eng.cfg.lm.d
+    g = torch.Generator(device=DEV).manual_seed(8)
+    img = [(torch.randn(20, d, device=DEV, generator=g) * 0.3).bfloat16() for _ in range(2)]
+    embs, keys = [], []
+    for q in range(5):
+        txt = (torch.randn(4 + q, d, device=DEV, generator=g) * 0.3).bfloat16()
+        embs.append(torch.cat([img[q % 2], txt], 0))
+        keys.append((f"image{q % 2}", 20))
+    kw = dict(inputs_embeds=embs, use_dd_unk=True, cd_alpha=1.0, cd_beta=0.1, temperature=0.5, max_new_tokens=5, cd_greedy=True, output_scores=True)
+    a = eng.generate(None, embeds_prefix=keys, **kw)
+    b = eng.generate(None, share_prefix=False, **kw)
+    c = eng.generate(None, **kw)                                   # same-tensor sharing only (main / image-free branch)
+    assert a.stats["prefill_tokens"] == 2 * 20 + 2 * sum(4 + q for q in range(5))        # 2 image prefixes + both branches' text rows
+    assert c.stats["prefill_tokens"] == sum(24 + q for q in range(5)) + 5 and b.stats["prefill_tokens"] == 2 * sum(24 + q for q in range(5))
+    for x in (a, c):
+        for sx, sb in zip(x.scores, b.scores):
+            fin = torch.isfinite(sx) & torch.isfinite(sb)
+            assert (torch.isfinite(sx) ^ torch.isfinite(sb)).sum() <= 2 and (sx[fin].float() - sb[fin].float()).abs().max().item() <= 0.3
+        assert (x.tokens == b.tokens).float().mean().item() >= 0.8
+    with pytest.raises(ValueError, match="embeds_prefix"):
+        eng.generate(None, inputs_embeds=embs, embeds_prefix=keys[:2], max_new_tokens=1)

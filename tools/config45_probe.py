@@ -37,13 +37,16 @@ def config4():
     g = torch.Generator(device=dev).manual_seed(2)
     feats = {}
 
+    lead = table[torch.tensor([151857, 151857], device=dev)]
+
     def embed_prompt(text, path):                       # 256 resampler slots + ~40 text tokens (the Qwen ViT / resampler are upstream of this path)
         n = 40 + (len(text) % 9)
         e = table[torch.from_numpy(rng.integers(3, 151000, size=n)).to(dev)]
         if path is not None:
             if path not in feats:
                 feats[path] = (torch.randn(256, cfg.lm.d, device=dev, generator=g) * 0.02).to(torch.bfloat16)
-            e = torch.cat([e[:2], feats[path], e[2:]], 0)
+            e = torch.cat([lead, feats[path], e[2:]], 0)
+            return e, 258                                # '<img>' tokens + the 256 slots: the same for both questions about this image
         return e
     kw = dict(batch_questions=504, max_new_tokens=20, min_new_tokens=1, eos_token_id=151643, pad_token_id=151643, gt=gt,
               results_root="/tmp/mme_res", experiment="qwen", use_dd_unk=True, cd_alpha=1.0, cd_beta=0.1, temperature=1.0, seed=1)
