@@ -67,14 +67,24 @@ def run_blip_pope(engine: VddLlavaEngine, front: InstructBlipFrontEnd, questions
         for q in qs:
             if q["image"] not in cache:
                 cache[q["image"]] = load_image(q["image"]).to(engine.device)
-        imgs = torch.stack([cache[q["image"]] for q in qs])
-        # fresh noise per question, as the reference draws it inside its loop (blip_calibrate.py:80-82, :96)
-        imgs_cd = torch.stack([add_diffusion_noise(im, noise_step) for im in imgs]) if use_cd else None
-        emb, emb_cd = front.build(imgs, llm_ids, embed, qformer_text_ids=qf_ids, images_cd=imgs_cd)
+        # EVA-ViT once per DISTINCT clean image and once for the `zeros` image; the noised copies are drawn per question (fresh noise inside
+        # the reference's loop, blip_calibrate.py:80-82, :96) and so are their ViT passes; the Q-Former reads the instruction: per question
+        names = list(cache)
+        where = [names.index(q["image"]) for q in qs]
+        uniq = torch.stack([cache[n] for n in names])
+        ie_u = front.image_embeds(uniq)
+        ie_main = ie_u[where]
+        imgs = uniq[where]
+        emb = front.assemble(front.embeds_to_llm(ie_main, qf_ids), llm_ids, embed)
+        emb_cd = None
+        if use_cd:
+            imgs_cd = torch.stack([add_diffusion_noise(im, noise_step) for im in imgs])
+            emb_cd = front.assemble(front.embeds_to_llm(front.image_embeds(imgs_cd), qf_ids), llm_ids, embed)
         main = engine.generate(None, inputs_embeds=emb, images_cd=emb_cd, max_length=max_length, **base_kw)
         noise999 = torch.stack([add_diffusion_noise(im, 999) for im in imgs])
-        emb_n, _ = front.build(noise999, llm_ids, embed, qformer_text_ids=qf_ids)
-        emb_z, _ = front.build(torch.zeros_like(imgs), llm_ids, embed, qformer_text_ids=qf_ids)
+        emb_n = front.assemble(front.embeds_to_llm(front.image_embeds(noise999), qf_ids), llm_ids, embed)
+        ie_zero = front.image_embeds(torch.zeros_like(uniq[:1])).expand(len(qs), -1, -1).contiguous()
+        emb_z = front.assemble(front.embeds_to_llm(ie_zero, qf_ids), llm_ids, embed)
         prior_kw = {k: v for k, v in base_kw.items() if k not in ("cd_beta", "cd_alpha")}
         noise = engine.generate(None, inputs_embeds=emb_n, max_length=1, **prior_kw)
         zeros = engine.generate(None, inputs_embeds=emb_z, max_length=1, **prior_kw)

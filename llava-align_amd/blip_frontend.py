@@ -259,11 +259,27 @@ class InstructBlipFrontEnd:
         return hq.view(n, NQ, Hd)
 
     @torch.no_grad()
-    def inputs_llm(self, images: torch.Tensor, text_ids: Optional[Sequence[Sequence[int]]]) -> torch.Tensor:
-        """image -> [n, n_query, d_llm] (blip2_vicuna_instruct.py:333-366)."""
-        hq = self.qformer(self.image_embeds(images), text_ids)
+    def embeds_to_llm(self, image_embeds: torch.Tensor, text_ids: Optional[Sequence[Sequence[int]]]) -> torch.Tensor:
+        """ln_vision(ViT(image)) [n, Ti, width] -> Q-Former -> llm_proj -> [n, n_query, d_llm] (blip2_vicuna_instruct.py:339-366).  Split from
+        image_embeds() so that a driver can run the ViT once per DISTINCT image (POPE asks 6 questions per image; the `zeros` prior image is
+        the same for every question) while the Q-Former, which also reads the instruction, runs per question."""
+        hq = self.qformer(image_embeds, text_ids)
         n, NQ, Hd = hq.shape
         return ops.gemm(hq.reshape(n * NQ, Hd), self.w.t["llm_proj.weight"], bias=self.w.t["llm_proj.bias"], epi=ops.EPI_BIAS).view(n, NQ, -1)
+
+    @torch.no_grad()
+    def inputs_llm(self, images: torch.Tensor, text_ids: Optional[Sequence[Sequence[int]]]) -> torch.Tensor:
+        """image -> [n, n_query, d_llm] (blip2_vicuna_instruct.py:333-366)."""
+        return self.embeds_to_llm(self.image_embeds(images), text_ids)
+
+    @torch.no_grad()
+    def assemble(self, llm_in: torch.Tensor, prompt_ids: Sequence[Sequence[int]], embed_table: torch.Tensor) -> List[torch.Tensor]:
+        """[n, n_query, d_llm] ++ the LLM's token embeddings of each prompt (:377-388) -> per sample [n_query + len(prompt), d_llm]."""
+        out = []
+        for i in range(llm_in.shape[0]):
+            tok = ops.embed(torch.tensor(list(prompt_ids[i]), dtype=torch.long, device=self.device), embed_table)
+            out.append(torch.cat([llm_in[i], tok], 0))
+        return out
 
     @torch.no_grad()
     def build(self, images: torch.Tensor, prompt_ids: Sequence[Sequence[int]], embed_table: torch.Tensor,
