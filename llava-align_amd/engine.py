@@ -1126,7 +1126,7 @@ class VddLlavaEngine:
                     key = (tuple(pre_tok), img.data_ptr())
                 else:
                     if s_img is None:
-                        cut = self._common_split(name, ids)
+                        cut = self._common_split(rows) if share_prefix else 0
                     else:
                         cut = s_img + 1 if name == "unk" else s_img     # unk keeps the one <unk> token in the prefix (quirk #3)
                     pre_tok, suf_tok, plen = ids[:cut], ids[cut:], cut
@@ -1153,9 +1153,25 @@ class VddLlavaEngine:
         tokens = sum(s["T"] for s in prefix) + sum(s["T"] for s in suffix)
         return dict(prefix=prefix, suffix=suffix, n_slots=n_slots, max_len=max_len, prefill_tokens=tokens, unshared_tokens=unshared)
 
-    def _common_split(self, name, ids):
-        """Text-only prompts (no image slot): nothing marks a shareable prefix, so share nothing."""
-        return 0
+    def _common_split(self, rows):
+        """Text-only prompts (no image slot; the content-free `none` / `unk` prior passes of the calibrate drivers, llava_calibrate.py:46-61):
+        the longest prefix common to EVERY prompt of the branch - the conversation template's system prompt - is prefilled once.  Computed
+        once per branch (cached on the list object); fewer than 8 common tokens or a single prompt: share nothing."""
+        import numpy as np
+        memo = getattr(self, "_lcp_memo", None)
+        if memo is not None and memo[0] is rows:
+            return memo[1]
+        cut = 0
+        if len(rows) >= 2:
+            n = min(len(r) for r in rows)
+            if n >= 8:
+                a = np.array([r[:n] for r in rows])
+                same = (a == a[0]).all(0)
+                cut = int(n if same.all() else np.argmin(same))
+                if cut < 8:
+                    cut = 0
+        self._lcp_memo = (rows, cut)
+        return cut
 
     def _pack(self, segs):
         """Builds the packed embedding matrix and the per-token / per-sequence descriptors of a prefill pass (numpy on the

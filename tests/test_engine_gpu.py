@@ -517,3 +517,20 @@ def test_embedding_prompts_share_declared_prefixes_transparently(eng, batch_inva
         assert (x.tokens == b.tokens).float().mean().item() >= 0.8
     with pytest.raises(ValueError, match="embeds_prefix"):
         eng.generate(None, inputs_embeds=embs, embeds_prefix=keys[:2], max_new_tokens=1)
+
+
+def test_text_only_prompts_share_their_common_system_prompt(eng, batch_invariant):
+    """The content-free prior passes of the calibrate drivers (llava_calibrate.py:46-61): no image slot; the conversation template's system
+    prompt - the longest prefix common to every prompt - is prefilled once, results unchanged."""
+    rng = np.random.default_rng(17)
+    sys_tok = [1] + rng.integers(3, 1000, size=20).tolist()
+    ids = [torch.tensor(sys_tok + rng.integers(3, 1000, size=int(rng.integers(4, 9))).tolist()) for _ in range(6)]
+    kw = dict(temperature=0.5, max_new_tokens=4, cd_greedy=True, output_scores=True, n_top=10)
+    a = eng.generate(ids, **kw)
+    b = eng.generate(ids, share_prefix=False, **kw)
+    assert a.stats["prefill_tokens"] == 21 + sum(i.numel() - 21 for i in ids) < b.stats["prefill_tokens"] == sum(i.numel() for i in ids)
+    for sa, sb in zip(a.scores, b.scores):
+        assert (sa.float() - sb.float()).abs().max().item() <= 0.15
+    assert (a.tokens == b.tokens).float().mean().item() >= 0.8
+    one = eng.generate(ids[:1], **kw)                                  # a single prompt: nothing to share
+    assert one.stats["prefill_tokens"] == ids[0].numel()
