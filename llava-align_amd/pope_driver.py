@@ -71,9 +71,10 @@ def run_pope(engine: VddLlavaEngine, questions: Sequence[dict], encode: Callable
                                pad_token_id=pad_token_id, **kw)
         # content-free priors: plain sampling (no image -> no contrast branch), step-0 distribution only
         plain_kw = {k: v for k, v in generate_kw.items() if k in ("temperature", "top_p", "top_k", "seed", "cd_alpha", "cd_beta")}
-        none = engine.generate(ids_none, images=None, max_new_tokens=1, n_top=10, **plain_kw)
-        unk = engine.generate(ids_unk, images=None, max_new_tokens=1, n_top=10, **plain_kw)
-        naive_d, none_d, unk_d = _top_dicts(main, decode_token), _top_dicts(none, decode_token), _top_dicts(unk, decode_token)
+        # (one call for both priors: 2 x len(qs) text-only prompts that share the conversation template's system prompt as a prefix slot)
+        prior = engine.generate(ids_none + ids_unk, images=None, max_new_tokens=1, n_top=10, **plain_kw)
+        prior_d = _top_dicts(prior, decode_token)
+        naive_d, none_d, unk_d = _top_dicts(main, decode_token), prior_d[:len(qs)], prior_d[len(qs):]
         eos_set = set([eos_token_id] if isinstance(eos_token_id, int) else (eos_token_id or []))
         for j, i in enumerate(idx):
             toks = main.tokens[j].tolist()

@@ -91,6 +91,35 @@ def config5():
                       "hbm_peak_GB": round(torch.cuda.max_memory_allocated() / 1e9, 1), "n_answers": len(res["answers"])}), flush=True)
 
 
+def config2():
+    """POPE proper through pope_driver.run_pope: 768 questions (128 images x 6), use_dd_unk, answers of <= 2 tokens, + the none / unk prior passes,
+    answers file fields and scorers (llava_calibrate.py:130-219)."""
+    from bench import pope_prompts
+    from llava_align_amd.engine import VddLlavaEngine
+    from llava_align_amd.pope_driver import run_pope
+    eng = VddLlavaEngine("llava-1.5-7b", device=dev, seed=0, use_graph=True, lm_head_gain=4.0)
+    ids, imgs = pope_prompts(128, seed=1234)
+    images = {f"im{i}.jpg": imgs[6 * i] for i in range(128)}
+    by_text = {f"q{i}": ids[i].tolist() for i in range(768)}
+    qs = [{"question_id": i, "image": f"im{i // 6}.jpg", "text": f"q{i}", "label": ("yes", "no")[i % 2]} for i in range(768)]
+    enc = lambda text, with_image: by_text[text] if with_image else [t for t in by_text[text] if t != -200]
+    kw = dict(batch_questions=768, unk_token_id=0, eos_token_id=2, pad_token_id=0, max_new_tokens=2, use_dd_unk=True, cd_alpha=1.0, cd_beta=0.1,
+              temperature=0.2, seed=1)
+    for label, patch in (("shared system prompt in the prior passes", False), ("nothing shared in the prior passes", True)):
+        if patch:
+            eng._common_split = lambda rows: 0
+        run_pope(eng, qs, enc, decode, lambda n: images[n], **kw)
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        res = run_pope(eng, qs, enc, decode, lambda n: images[n], **kw)
+        torch.cuda.synchronize()
+        dt = time.perf_counter() - t0
+        print(json.dumps({"config": 2, "what": "run_pope: main (use_dd_unk, 2 new tokens) + none + unk passes + label dicts + scorers, " + label,
+                          "items": 768, "seconds": round(dt, 2), "items_per_s": round(768 / dt, 1), "n_answers": len(res["answers"])}), flush=True)
+
+
+if "2" in which:
+    config2()
 if "4" in which:
     config4()
 if "5" in which:
