@@ -879,7 +879,12 @@ class VddLlavaEngine:
         feats_cd = None
         if use_cd and inputs_embeds is None:
             imgs_cd = [images_cd[i] for i in range(Q)] if torch.is_tensor(images_cd) else list(images_cd)
-            feats_cd = [self.vit(im.reshape(1, *im.shape[-3:]))[0] for im in imgs_cd]
+            # the noised copies differ per question (fresh noise, llava_calibrate.py:152-155): no feature cache, but full tower batches
+            # of 16 (the captured-graph size) instead of one launch chain per question
+            feats_cd = []
+            for i0 in range(0, Q, VisionTower.GRAPH_BATCH):
+                chunk = [im.reshape(im.shape[-3:]).to(dev) for im in imgs_cd[i0:i0 + VisionTower.GRAPH_BATCH]]
+                feats_cd += list(self.vit(torch.stack(chunk)))
         if inputs_embeds is not None:
             main_dev = [e.to(dev, torch.bfloat16) for e in emb_main]
             branches = [("main", ids_list, main_dev)]
