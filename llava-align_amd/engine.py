@@ -989,7 +989,9 @@ class VddLlavaEngine:
             if output_scores:
                 scores.append(run.scores_buf.clone())
             n_new += 1
-            if eos_t is not None and (n_new % sync_every == 0 or n_new == max_new_tokens):
+            # the "everybody finished" test costs a host sync: every sync_every steps, and at steps 2 and 4 on the way there (POPE answers
+            # are 1-2 tokens: waiting for step 8 would run six decode steps for nobody)
+            if eos_t is not None and (n_new % sync_every == 0 or n_new == max_new_tokens or (n_new in (2, 4) and n_new < sync_every)):
                 done_bad = torch.stack([run.unfinished.max() == 0, (run.status | run.status0).ne(0).any()]).tolist()   # ONE sync
                 if done_bad[1]:                                 # a row lost every finite score: stop decoding from token -1
                     break
