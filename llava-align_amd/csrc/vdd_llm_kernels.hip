@@ -28,6 +28,17 @@ typedef __attribute__((ext_vector_type(4))) uint32_t u32x4_nt;
 __device__ __forceinline__ uint4 ld_stream(const uint16_t* p) { return __builtin_bit_cast(uint4, __builtin_nontemporal_load(reinterpret_cast<const u32x4_nt*>(p))); }
 __device__ __forceinline__ void st_stream(uint16_t* p, uint4 v) { __builtin_nontemporal_store(__builtin_bit_cast(u32x4_nt, v), reinterpret_cast<u32x4_nt*>(p)); }
 typedef __attribute__((ext_vector_type(4))) float f32x4_t;    // MFMA C/D fragment
+// a weight fragment of the weight-streaming projections: every byte of W is read by ONE wave, once per launch
+#ifndef VDD_W_NT
+#define VDD_W_NT 0   // measured: nontemporal weight loads are SLOWER here (one-question layer chain 90.2 vs 84.8 us)
+#endif
+__device__ __forceinline__ bf16x8_t ld_w(const uint16_t* p) {
+#if VDD_W_NT
+    return __builtin_nontemporal_load(reinterpret_cast<const bf16x8_t*>(p));
+#else
+    return *reinterpret_cast<const bf16x8_t*>(p);
+#endif
+}
 
 __device__ __forceinline__ float bf2f(uint32_t b) { return __builtin_bit_cast(float, b << 16); }
 __device__ __forceinline__ uint32_t f2bf(float f) {
@@ -276,88 +287,150 @@ __device__ __forceinline__ float row_rstd(const NormIn& ni, int r, int K) {
 // - bf16(bf16(h * rstd) * ln_w[k]), the roundings of rmsnorm_kernel - behind its first batch of W loads, then walks its column
 // blocks (blockIdx.x, + gridDim.x, ...) with the A fragments read from LDS.  (Normalising per column block - in every one of the
 // 768 - 2000 blocks of the plain kernels - costs more VALU time than the two RMSNorm launches it replaces: 6.2 vs 3.4 ms per
-// one-question step.)  LDS row stride = 2 K + 64 B: the 16 x 4 (row, k-group) lanes of a fragment read hit distinct 16-byte slots.
+// one-question step.)  LDS image: row r at byte 2 K r, its 16-byte chunk q at slot q ^ (r & 15): a ds_read_b128 is served in four
+// 16-lane groups ({0-3, 12-15, 20-27}, ...: 16 DISTINCT rows at two adjacent chunks) and the XOR puts those on 16 distinct slots of the
+// 256-byte bank row (a padded stride of 2 K + 64 left them 2-way conflicted: 16 rows cost 33 us where 2 rows - broadcast - cost 21).
 // SWIGLU: a column block is 8 features (gate rows | up rows of W = [Wg; Wu]) with the SiLU * mul epilogue of skinny_swiglu_kernel.
-template <int NW, bool SWIGLU>
+template <int NW, bool SWIGLU, int RMAX>          // RMAX: M rounded up to 2 / 4 / 8 / 16 (the prologue is straight-line code over RMAX rows)
 __global__ void __launch_bounds__(NW * 64) skinny_normed_kernel(const uint16_t* __restrict__ Hs, const uint16_t* __restrict__ W,
                                                                uint16_t* __restrict__ Y, int M, int N, int K, long long ldh,
                                                                long long ldy, NormIn ni, int n_cb) {
-    extern __shared__ __attribute__((aligned(16))) unsigned char xs[];           // [M][2 K + 64] bytes
-    __shared__ float part[NW][64][4];
+    extern __shared__ __attribute__((aligned(16))) unsigned char xs[];           // [M][2 K] bytes, chunk-swizzled
+    __shared__ float part2[2][NW][64][4];                                         // double-buffered: ONE barrier per column block
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int ln = lane & 15, g = lane >> 4;
     const int kq = K / NW, kbeg = wave * kq;
-    const int rstride = 2 * K + 64;
+    const int rstride = 2 * K;
     constexpr int U = 8;
-    const int nit = kq / (32 * U);
+    // a wave's K slice as nb batches of U 32-deep k-steps; a ragged last batch (K = 5120 over 8 waves: 640 = 2 batches + 128) loads
+    // from clamped addresses and multiplies the k-steps beyond the slice by a zero W fragment
+    const int nb = (kq + 32 * U - 1) / (32 * U);
+    const bool ragged = (kq % (32 * U)) != 0;
     auto wptr = [&](int cb) {
         if constexpr (SWIGLU) { int f = cb * 8 + (ln & 7); if (f >= N) f = N - 1; return W + ((size_t)(ln < 8 ? 0 : N) + f) * K + kbeg + g * 8; }
         else { int nrow = cb * 16 + ln; if (nrow >= N) nrow = N - 1; return W + (size_t)nrow * K + kbeg + g * 8; }
     };
     bf16x8_t b0[U], b1[U];
-    auto ldw = [&](bf16x8_t (&b)[U], const uint16_t* wp, int kk) {
+    auto ldw = [&](bf16x8_t (&b)[U], const uint16_t* wp, int i) {
+        const int kk = i * 32 * U;
+        if (ragged && i == nb - 1) {
 #pragma unroll
-        for (int u = 0; u < U; ++u) b[u] = *reinterpret_cast<const bf16x8_t*>(wp + kk + 32 * u);
+            for (int u = 0; u < U; ++u) b[u] = ld_w(wp + (kk + 32 * u < kq ? kk + 32 * u : kk));
+        } else {
+#pragma unroll
+            for (int u = 0; u < U; ++u) b[u] = ld_w(wp + kk + 32 * u);
+        }
         __builtin_amdgcn_sched_barrier(0);
     };
     int cb = blockIdx.x;
     const uint16_t* wp = wptr(cb < n_cb ? cb : 0);
-    if (nit > 0) ldw(b0, wp, 0);                                               // the weight stream starts before anything else:
+    if (nb > 0) ldw(b0, wp, 0);                                                // the weight stream starts before anything else:
     bool b1_ahead = false;                                                     // BOTH register stages of the first column block are
-    if (nit > 1) { ldw(b1, wp, 32 * U); b1_ahead = true; }                     // in flight under the normalisation prologue
+    if (nb > 1) { ldw(b1, wp, 1); b1_ahead = true; }                           // in flight under the normalisation prologue
     // ---- normalise the rows into LDS (once per block).  Sum of squares of a row = its nss per-block partials: thread t takes
     // partials t, t + NT, ... (one load per row for d <= 4096), butterfly over the wave, the NW wave sums in a fixed tree: one
     // memory round trip for all rows together and deterministic.  (A per-thread loop over the partials of a row is a chain of
     // dependent round trips: 10 us per launch.)
     __shared__ float red[NW][16];
     {
-        float pv[16];
+        // everything the normalisation reads goes out in ONE memory round trip, as STRAIGHT-LINE code: the per-block partial sums of
+        // all rows, the ln weights and the first RB rows of H (further row batches: one round trip each).  Loads are never
+        // predicated - a row / chunk / partial that does not exist is read at a clamped, valid address and dropped: a load inside an
+        // `if` or a run-time loop ends in its own s_waitcnt, which made the prologue a chain of M round trips (16 rows: 12 us).
+        constexpr int NT = NW * 64, CMAX = 16 / NW, RB = RMAX < 16 / CMAX ? RMAX : 16 / CMAX, PMAX = 512 / NT;   // K <= 8192, nss <= 512
+        float pv[RMAX][PMAX];
 #pragma unroll
-        for (int r = 0; r < 16; ++r) {
-            pv[r] = 0.f;
-            if (r < M) for (int i = tid; i < ni.nss; i += NW * 64) pv[r] += ni.ss[(size_t)r * ni.nss + i];
-        }
+        for (int r = 0; r < RMAX; ++r) {
+            const int rc = r < M ? r : M - 1;
 #pragma unroll
-        for (int r = 0; r < 16; ++r) {
-            if (r < M) { const float sw = wave_sum(pv[r]); if (lane == 0) red[wave][r] = sw; }
+            for (int q = 0; q < PMAX; ++q) {
+                const int i = tid + q * NT;
+                pv[r][q] = ni.ss[(size_t)rc * ni.nss + (i < ni.nss ? i : 0)];
+            }
         }
-    }
-    __syncthreads();
-    for (int r = 0; r < M; ++r) {
-        float tot = (red[0][r] + red[1][r]) + (red[2][r] + red[3][r]);
-        if constexpr (NW == 8) tot += (red[4][r] + red[5][r]) + (red[6][r] + red[7][r]);
-        const float rstd = rsqrtf(tot / (float)K + ni.eps);
-        for (int e = tid * 8; e < K; e += NW * 64 * 8) {
-            const uint4 h = *reinterpret_cast<const uint4*>(Hs + (size_t)r * ldh + e), gw = *reinterpret_cast<const uint4*>(ni.lnw + e);
-            *reinterpret_cast<uint4*>(xs + (size_t)r * rstride + e * 2) = norm_chunk(h, gw, rstd);
+        uint4 gw[CMAX], hv[RB][CMAX];
+        auto ld_rows = [&](int r0) {
+#pragma unroll
+            for (int j = 0; j < RB; ++j) {
+                const int rc = r0 + j < M ? r0 + j : M - 1;
+#pragma unroll
+                for (int c = 0; c < CMAX; ++c) {
+                    const int e = (c * NT + tid) * 8;
+                    hv[j][c] = *reinterpret_cast<const uint4*>(Hs + (size_t)rc * ldh + (e < K ? e : 0));
+                }
+            }
+        };
+#pragma unroll
+        for (int c = 0; c < CMAX; ++c) { const int e = (c * NT + tid) * 8; gw[c] = *reinterpret_cast<const uint4*>(ni.lnw + (e < K ? e : 0)); }
+        ld_rows(0);
+        __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+        for (int r = 0; r < RMAX; ++r) {
+            float v = 0.f;
+#pragma unroll
+            for (int q = 0; q < PMAX; ++q) v += (tid + q * NT < ni.nss) ? pv[r][q] : 0.f;
+            const float sw = wave_sum(v);
+            if (lane == 0) red[wave][r] = sw;
+        }
+        __syncthreads();
+        for (int r0 = 0; r0 < M; r0 += RB) {
+            if (r0 > 0) { ld_rows(r0); __builtin_amdgcn_sched_barrier(0); }
+#pragma unroll
+            for (int j = 0; j < RB; ++j) {
+                const int r = r0 + j;
+                float tot = (red[0][r & 15] + red[1][r & 15]) + (red[2][r & 15] + red[3][r & 15]);
+                if constexpr (NW == 8) tot += (red[4][r & 15] + red[5][r & 15]) + (red[6][r & 15] + red[7][r & 15]);
+                const float rstd = rsqrtf(tot / (float)K + ni.eps);
+#pragma unroll
+                for (int c = 0; c < CMAX; ++c) {
+                    const int e = (c * NT + tid) * 8;
+                    const uint4 nv = norm_chunk(hv[j][c], gw[c], rstd);
+                    if (r < M && e < K) *reinterpret_cast<uint4*>(xs + (size_t)r * rstride + ((e * 2) ^ ((r & 15) << 4))) = nv;
+                }
+            }
         }
     }
     __syncthreads();
     int rr = ln; if (rr >= M) rr = M - 1;
-    const unsigned char* xrow = xs + (size_t)rr * rstride + (kbeg + g * 8) * 2;
-    auto mm = [&](const bf16x8_t (&b)[U], int kk, f32x4_t& acc) {
+    const unsigned char* xrow = xs + (size_t)rr * rstride;
+    const int xk0 = (kbeg + g * 8) * 2, xsw = (rr & 15) << 4;
+    auto xfrag = [&](int k) { return *reinterpret_cast<const bf16x8_t*>(xrow + ((xk0 + k * 2) ^ xsw)); };
+    auto mm = [&](const bf16x8_t (&b)[U], int i, f32x4_t& acc) {
+        const int kk = i * 32 * U;
+        if (ragged && i == nb - 1) {
+            const bf16x8_t zero = {0, 0, 0, 0, 0, 0, 0, 0};
 #pragma unroll
-        for (int u = 0; u < U; ++u)
-            acc = __builtin_amdgcn_mfma_f32_16x16x32_bf16(*reinterpret_cast<const bf16x8_t*>(xrow + (kk + 32 * u) * 2), b[u], acc, 0, 0, 0);
+            for (int u = 0; u < U; ++u) {
+                const bool in = kk + 32 * u < kq;
+                acc = __builtin_amdgcn_mfma_f32_16x16x32_bf16(xfrag(in ? kk + 32 * u : kk), in ? b[u] : zero, acc, 0, 0, 0);
+            }
+        } else {
+#pragma unroll
+            for (int u = 0; u < U; ++u)
+                acc = __builtin_amdgcn_mfma_f32_16x16x32_bf16(xfrag(kk + 32 * u), b[u], acc, 0, 0, 0);
+        }
         __builtin_amdgcn_sched_barrier(0);
     };
+    int pbuf = 0;
     for (; cb < n_cb; cb += gridDim.x) {
         f32x4_t acc = f32x4_t{0.f, 0.f, 0.f, 0.f};
         int it = 0;
-        for (; it + 2 <= nit; it += 2) {
-            if (!b1_ahead) ldw(b1, wp, (it + 1) * 32 * U);
+        for (; it + 2 <= nb; it += 2) {
+            if (!b1_ahead) ldw(b1, wp, it + 1);
             b1_ahead = false;
-            mm(b0, it * 32 * U, acc);
-            if (it + 2 < nit) ldw(b0, wp, (it + 2) * 32 * U);
-            mm(b1, (it + 1) * 32 * U, acc);
+            mm(b0, it, acc);
+            if (it + 2 < nb) ldw(b0, wp, it + 2);
+            mm(b1, it + 1, acc);
         }
-        if (it < nit) mm(b0, it * 32 * U, acc);
-        for (int k = nit * 32 * U; k < kq; k += 32)
-            acc = __builtin_amdgcn_mfma_f32_16x16x32_bf16(*reinterpret_cast<const bf16x8_t*>(xrow + k * 2),
-                                                          *reinterpret_cast<const bf16x8_t*>(wp + k), acc, 0, 0, 0);
+        if (it < nb) mm(b0, it, acc);
         const int cb_next = cb + gridDim.x;
         const uint16_t* wp_next = wptr(cb_next < n_cb ? cb_next : cb);
-        if (cb_next < n_cb && nit > 0) ldw(b0, wp_next, 0);                     // next column block's first batch under this epilogue
+        // BOTH register stages of the next column block go out before the barrier: the weight stream does not drain while the block
+        // meets.  The partial sums alternate between two LDS buffers: the waves that do not finish the tile go straight on to the
+        // next one (a buffer is rewritten two column blocks later, behind the barrier in between).
+        if (cb_next < n_cb && nb > 0) { ldw(b0, wp_next, 0); if (nb > 1) { ldw(b1, wp_next, 1); b1_ahead = true; } }
+        float (*part)[64][4] = part2[pbuf];
+        pbuf ^= 1;
 #pragma unroll
         for (int r = 0; r < 4; ++r) part[wave][lane][r] = acc[r];
         __syncthreads();
@@ -367,8 +440,10 @@ __global__ void __launch_bounds__(NW * 64) skinny_normed_kernel(const uint16_t* 
                 if (row < M && cb * 8 + c < N) {
                     const int lg = (row >> 2) * 16 + c, lu = lg + 8, q = row & 3;
                     float gs = 0.f, us = 0.f;
-                    if constexpr (NW == 4) { gs = (part[0][lg][q] + part[1][lg][q]) + (part[2][lg][q] + part[3][lg][q]);
-                                             us = (part[0][lu][q] + part[1][lu][q]) + (part[2][lu][q] + part[3][lu][q]); }
+                    gs = (part[0][lg][q] + part[1][lg][q]) + (part[2][lg][q] + part[3][lg][q]);
+                    us = (part[0][lu][q] + part[1][lu][q]) + (part[2][lu][q] + part[3][lu][q]);
+                    if constexpr (NW == 8) { gs += (part[4][lg][q] + part[5][lg][q]) + (part[6][lg][q] + part[7][lg][q]);
+                                             us += (part[4][lu][q] + part[5][lu][q]) + (part[6][lu][q] + part[7][lu][q]); }
                     const float gb = bf2f(f2bf(gs)), ub = bf2f(f2bf(us));
                     const float sl = bf2f(f2bf(gb / (1.f + __expf(-gb))));
                     Y[(size_t)row * ldy + cb * 8 + c] = (uint16_t)f2bf(sl * ub);
@@ -385,7 +460,6 @@ __global__ void __launch_bounds__(NW * 64) skinny_normed_kernel(const uint16_t* 
                 }
             }
         }
-        __syncthreads();                                                       // `part` is free for the next column block
         wp = wp_next;
     }
 }
@@ -424,7 +498,7 @@ __global__ void __launch_bounds__(NW * 64) skinny_gemm_kernel(const uint16_t* __
     float rstd = 1.f;
     auto ld = [&](bf16x8_t (&b)[U], bf16x8_t (&a)[U][MT], bf16x8_t (&gw)[UG], int kk) {
 #pragma unroll
-        for (int u = 0; u < U; ++u) b[u] = *reinterpret_cast<const bf16x8_t*>(wp + (size_t)(kk + 32 * u) * WS);
+        for (int u = 0; u < U; ++u) b[u] = ld_w(wp + (size_t)(kk + 32 * u) * WS);
 #pragma unroll
         for (int u = 0; u < U; ++u)
 #pragma unroll
@@ -446,8 +520,13 @@ __global__ void __launch_bounds__(NW * 64) skinny_gemm_kernel(const uint16_t* __
             }
         __builtin_amdgcn_sched_barrier(0);
     };
+    uint16_t rpre[4] = {0, 0, 0, 0};                    // MT == 1: wave 0's residual entries, fetched under the weight stream
     if constexpr (MT == 1) {
         if (nit > 0) ld(b0, a0, g0, 0);
+        if (R != nullptr && wave == 0 && Yslab == nullptr) {
+#pragma unroll
+            for (int r = 0; r < 4; ++r) { const int row = g * 4 + r, col = n0 + ln; if (row < M && col < N) rpre[r] = R[(size_t)row * ldr + col]; }
+        }
         if constexpr (NORM) { int r = ln; if (r >= M) r = M - 1; rstd = row_rstd(ni, r, K); }
         int it = 0;
         for (; it + 2 <= nit; it += 2) {
@@ -460,15 +539,24 @@ __global__ void __launch_bounds__(NW * 64) skinny_gemm_kernel(const uint16_t* __
     } else {            // 32 - 64 rows: the X fragments alone are 64 - 128 registers per batch; one stage
         for (int it = 0; it < nit; ++it) { ld(b0, a0, g0, it * 32 * U); mm(b0, a0, g0); }
     }
-    int k = nit * 32 * U;
-    for (; k < kq; k += 32) {
-        bf16x8_t b = *reinterpret_cast<const bf16x8_t*>(wp + (size_t)k * WS);
+    // the K slice's remainder (K = 11008 over 8 waves: 1376 = 5 batches + 96): ONE more batch whose loads all go out together, the
+    // k-steps beyond the slice with a zero W fragment (+0 to the accumulators; X is read at a clamped, valid address) - a loop of
+    // load -> MFMA is a chain of memory round trips at the end of every block
+    const int krem = nit * 32 * U;
+    if (krem < kq) {
+        const bf16x8_t zero = {0, 0, 0, 0, 0, 0, 0, 0};
 #pragma unroll
-        for (int t = 0; t < MT; ++t) {
-            bf16x8_t a = *reinterpret_cast<const bf16x8_t*>(xp[t] + k);
-            if constexpr (NORM) a = __builtin_bit_cast(bf16x8_t, norm_chunk(__builtin_bit_cast(uint4, a), *reinterpret_cast<const uint4*>(gp + k), rstd));
-            acc[t] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a, b, acc[t], 0, 0, 0);
+        for (int u = 0; u < U; ++u) {
+            const int kk = krem + 32 * u, kc = kk < kq ? kk : krem;
+            b0[u] = ld_w(wp + (size_t)kc * WS);
+#pragma unroll
+            for (int t = 0; t < MT; ++t) a0[u][t] = *reinterpret_cast<const bf16x8_t*>(xp[t] + kc);
+            if constexpr (NORM) g0[u] = *reinterpret_cast<const bf16x8_t*>(gp + kc);
         }
+        __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+        for (int u = 0; u < U; ++u) if (krem + 32 * u >= kq) b0[u] = zero;
+        mm(b0, a0, g0);
     }
 #pragma unroll
     for (int t = 0; t < MT; ++t)
@@ -486,7 +574,7 @@ __global__ void __launch_bounds__(NW * 64) skinny_gemm_kernel(const uint16_t* __
             if (row < M && col < N) {
                 if (Yslab != nullptr) { Yslab[((size_t)blockIdx.y * M + row) * N + col] = s; continue; }
                 float o = bf2f(f2bf(s));
-                if (R != nullptr) o = o + bf2f(R[(size_t)row * ldr + col]);
+                if (R != nullptr) o = o + bf2f(MT == 1 ? rpre[r] : R[(size_t)row * ldr + col]);
                 const uint32_t ob = f2bf(o);
                 Y[(size_t)row * ldy + col] = (uint16_t)ob;
                 if constexpr (SSOUT) { const float h = bf2f(ob); sq = h * h; }
@@ -527,7 +615,7 @@ __global__ void __launch_bounds__(256) skinny_swiglu_kernel(const uint16_t* __re
     float rstd = 1.f;
     auto ld = [&](bf16x8_t (&b)[U], bf16x8_t (&a)[U], bf16x8_t (&gw)[UG], int kk) {
 #pragma unroll
-        for (int u = 0; u < U; ++u) b[u] = *reinterpret_cast<const bf16x8_t*>(wp + (size_t)(kk + 32 * u) * WS);
+        for (int u = 0; u < U; ++u) b[u] = ld_w(wp + (size_t)(kk + 32 * u) * WS);
 #pragma unroll
         for (int u = 0; u < U; ++u) a[u] = *reinterpret_cast<const bf16x8_t*>(xp + kk + 32 * u);
         if constexpr (NORM) {
@@ -1062,6 +1150,42 @@ __global__ void __launch_bounds__(256, 2) decode_attn_prefix_mfma_kernel(const u
 
 inline int ok(hipError_t) { return hipGetLastError() == hipSuccess ? VDD_OK : VDD_ERR_LAUNCH; }
 
+// Persistent blocks of the normalise-once projections: two 4-wave blocks per CU while two copies of the normalised rows fit in the
+// 160 KiB of LDS; beyond that (>= 10 rows of 4096) ONE 8-wave block per CU, so that as many W bytes are in flight per CU as before
+// (12 rows, gate/up: 48.6 us with one 4-wave block, 64 us with 512 blocks in two rounds - each round repeats the prologue).
+static constexpr size_t NORMED_LDS_CAP = 142 * 1024;                 // + 16.5 KiB static (two partial-sum buffers of 8 waves)
+struct NormedPlan { int grid; bool wide; };
+static NormedPlan normed_plan(int n_cb, size_t lds_bytes) {
+    int dev = 0, n = 0;
+    if (hipGetDevice(&dev) != hipSuccess || hipDeviceGetAttribute(&n, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess || n <= 0) n = 256;
+    const bool two = 2 * (lds_bytes + 9 * 1024) <= 160 * 1024;
+    const int g = (two ? 2 : 1) * n;
+    return NormedPlan{n_cb < g ? n_cb : g, !two};
+}
+template <bool SWIGLU>
+static int normed_launch(const void* H, const float* ss, int nss, const void* ln_w, float eps, const void* W, void* Y, int M, int N, int K,
+                         int64_t ldh, int64_t ldy, int n_cb, void* stream) {
+    const size_t lds = (size_t)M * 2 * (size_t)K;
+    if (lds > NORMED_LDS_CAP || K > 8192 || nss > 512) return VDD_ERR_UNSUPPORTED;
+    const NormIn ni{ss, nss, (const uint16_t*)ln_w, eps};
+    const NormedPlan pl = normed_plan(n_cb, lds);
+#define VDD_NORMED(NW, R)                                                                                                              \
+    do {                                                                                                                               \
+        static bool attr = false;                                                                                                      \
+        if (!attr) { (void)hipFuncSetAttribute((const void*)skinny_normed_kernel<NW, SWIGLU, R>, hipFuncAttributeMaxDynamicSharedMemorySize, \
+                                               (int)NORMED_LDS_CAP); attr = true; }                                                    \
+        hipLaunchKernelGGL((skinny_normed_kernel<NW, SWIGLU, R>), dim3(pl.grid), dim3(NW * 64), lds, (hipStream_t)stream,              \
+                           (const uint16_t*)H, (const uint16_t*)W, (uint16_t*)Y, M, N, K, (long long)ldh, (long long)ldy, ni, n_cb);   \
+    } while (0)
+    if (pl.wide) { if (M <= 8) VDD_NORMED(8, 8); else VDD_NORMED(8, 16); }
+    else if (M <= 2) VDD_NORMED(4, 2);
+    else if (M <= 4) VDD_NORMED(4, 4);
+    else if (M <= 8) VDD_NORMED(4, 8);
+    else VDD_NORMED(4, 16);
+#undef VDD_NORMED
+    return ok(hipSuccess);
+}
+
 }  // namespace
 
 extern "C" {
@@ -1166,44 +1290,18 @@ int vdd_skinny_gemm_resid_ss(const void* X, const void* W, const void* R, void* 
     return ok(hipSuccess);
 }
 
-static int normed_grid(int n_cb) {
-    int dev = 0, n = 0;
-    if (hipGetDevice(&dev) != hipSuccess || hipDeviceGetAttribute(&n, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess || n <= 0) n = 256;
-    const int g = 2 * n;                                   // two persistent blocks per CU
-    return n_cb < g ? n_cb : g;
-}
-
 int vdd_skinny_gemm_normed(const void* H, const float* ss, int nss, const void* ln_w, float eps, const void* W, void* Y, int M, int N,
                            int K, int64_t ldh, int64_t ldy, void* stream) {
     if (M <= 0 || N <= 0) return VDD_OK;
     if (!H || !ss || nss <= 0 || (nss % 4) != 0 || !ln_w || !W || !Y || M > 16 || K % 256 != 0 || (ldh % 8) != 0) return VDD_ERR_INVALID_ARG;
-    const size_t lds = (size_t)M * (2 * (size_t)K + 64);
-    if (lds > 152 * 1024) return VDD_ERR_UNSUPPORTED;
-    const int n_cb = (N + 15) / 16;
-    const NormIn ni{ss, nss, (const uint16_t*)ln_w, eps};
-    static bool attr = false;
-    if (!attr) {
-        (void)hipFuncSetAttribute((const void*)skinny_normed_kernel<4, false>, hipFuncAttributeMaxDynamicSharedMemorySize, 152 * 1024);
-        (void)hipFuncSetAttribute((const void*)skinny_normed_kernel<4, true>, hipFuncAttributeMaxDynamicSharedMemorySize, 152 * 1024);
-        attr = true;
-    }
-    hipLaunchKernelGGL((skinny_normed_kernel<4, false>), dim3(normed_grid(n_cb)), dim3(256), lds, (hipStream_t)stream, (const uint16_t*)H,
-                       (const uint16_t*)W, (uint16_t*)Y, M, N, K, (long long)ldh, (long long)ldy, ni, n_cb);
-    return ok(hipSuccess);
+    return normed_launch<false>(H, ss, nss, ln_w, eps, W, Y, M, N, K, ldh, ldy, (N + 15) / 16, stream);
 }
 
 int vdd_skinny_swiglu_normed(const void* H, const float* ss, int nss, const void* ln_w, float eps, const void* W_gate_up, void* act,
                              int M, int F, int K, int64_t ldh, void* stream) {
     if (M <= 0 || F <= 0) return VDD_OK;
     if (!H || !ss || nss <= 0 || (nss % 4) != 0 || !ln_w || !W_gate_up || !act || M > 16 || K % 256 != 0 || (ldh % 8) != 0) return VDD_ERR_INVALID_ARG;
-    const size_t lds = (size_t)M * (2 * (size_t)K + 64);
-    if (lds > 152 * 1024) return VDD_ERR_UNSUPPORTED;
-    const int n_cb = (F + 7) / 8;
-    static bool attr = false;
-    if (!attr) { (void)hipFuncSetAttribute((const void*)skinny_normed_kernel<4, true>, hipFuncAttributeMaxDynamicSharedMemorySize, 152 * 1024); attr = true; }
-    hipLaunchKernelGGL((skinny_normed_kernel<4, true>), dim3(normed_grid(n_cb)), dim3(256), lds, (hipStream_t)stream, (const uint16_t*)H,
-                       (const uint16_t*)W_gate_up, (uint16_t*)act, M, F, K, (long long)ldh, (long long)F, NormIn{ss, nss, (const uint16_t*)ln_w, eps}, n_cb);
-    return ok(hipSuccess);
+    return normed_launch<true>(H, ss, nss, ln_w, eps, W_gate_up, act, M, F, K, ldh, (int64_t)F, (F + 7) / 8, stream);
 }
 int vdd_skinny_swiglu(const void* X, const void* W_gate_up, void* act, int M, int F, int K, int64_t ldx, void* stream) {
     return skinny_swiglu_launch(X, W_gate_up, act, M, F, K, ldx, stream);

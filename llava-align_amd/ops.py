@@ -153,8 +153,8 @@ NORM_FUSED_MAX_M = 16   # rows up to which the decoder layer's RMSNorms ride ins
 
 def norm_fused_rows(d: int) -> int:
     """How many rows the normalise-once projections take for a residual stream of width d: the normalised rows live in LDS
-    (M x (2 d + 64) bytes of the 152 KiB the kernel may use)."""
-    return min(NORM_FUSED_MAX_M, (152 * 1024) // (2 * d + 64)) if d % 256 == 0 else 0
+    (M x 2 d bytes of the 142 KiB the kernel may use)."""
+    return min(NORM_FUSED_MAX_M, (142 * 1024) // (2 * d)) if d % 256 == 0 and d <= 8192 else 0
 
 
 def linear_resid_ss(x, w, resid, out=None, ss=None):
