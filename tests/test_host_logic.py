@@ -151,3 +151,10 @@ def test_driver_prompt_builders_follow_the_reference_format_strings():
         qb(line, kind)
     assert texts == [("<img>/imgs/a.png</img>Is it red? Answer:", "/imgs/a.png"), ("Is it red? Answer:", None), ("None Is it red? Answer:", None)]
     assert map_pad_to_eos(torch.tensor([[5, 0, 0], [0, 7, 2]])).tolist() == [[5, 2, 2], [2, 7, 2]]
+
+
+def test_norm_fused_row_limit_follows_the_lds_budget():
+    """ops.norm_fused_rows: rows whose normalised copy (2 d bytes each) fits the 142 KiB the normalise-once projections may use; widths the
+    kernel's chunk map does not cover (d % 256, d > 8192) take the unfused layer."""
+    from llava_align_amd import ops
+    assert [ops.norm_fused_rows(d) for d in (4096, 5120, 8192, 2048, 16384, 4000)] == [16, 14, 8, 16, 0, 0]

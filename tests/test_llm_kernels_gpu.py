@@ -427,7 +427,10 @@ def test_gemm_small_launch_slabs_do_not_poison_a_large_launch_counters():
     assert lib.vdd_gemm_workspace_bytes(96, 4096) == lib.vdd_gemm_workspace_bytes(40000, 4096)     # one layout for every shape
 
 
-@pytest.mark.parametrize("M,d,F", [(2, 4096, 11008), (3, 5120, 13824), (16, 4096, 11008), (5, 256, 512)])
+# row buckets of the prologue template (2 / 4 / 8 / 16) x block plan (two 4-wave blocks per CU up to 8 rows of 4096 / 6 of 5120, one 8-wave
+# block beyond) x ragged K batches (5120 over 8 waves: 640 = 2 batches + 128)
+@pytest.mark.parametrize("M,d,F", [(2, 4096, 11008), (3, 5120, 13824), (16, 4096, 11008), (5, 256, 512), (8, 4096, 11008), (9, 4096, 11008),
+                                   (12, 4096, 11008), (7, 5120, 13824), (14, 5120, 13824), (1, 4096, 11008), (4, 8192, 1024)])
 def test_norm_fused_small_m_projections(M, d, F):
     """The one-question decoder layer without RMSNorm launches: linear_resid_ss (projection + residual add + per-block sums of
     squares), linear_normed / swiglu_linear_normed (normalise-on-load) against rmsnorm + the plain projections.  Same bf16 rounding
