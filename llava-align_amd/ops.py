@@ -313,24 +313,28 @@ def _gemm_tune(x, w, out, bias, resid, M, N, K, epi, ws, iters=8):
     best, best_t = 1, float("inf")
     e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
     turn = 0
-    # short launches (a few rows: 30 - 60 us) are timed over more iterations, and every candidate twice (the faster run counts): with 8
-    # launches per candidate the pick among near-equal candidates - and with it the step time at 17 - 64 rows - moved by up to 30 %
-    # from process to process (tools/step_curve.py)
+    # short launches (up to 128 rows: 30 - 60 us) are timed over up to six batches of `iters` launches, twice (the faster run counts):
+    # with 8 launches per candidate the pick among near-equal candidates - and with it the step time at 17 - 64 rows - moved by up to
+    # 30 % from process to process (tools/step_curve.py).  Decode-batch and prefill shapes keep one batch of 8 (100 us and up per launch).
     flops = 2.0 * M * N * K * (2 if epi == EPI_SWIGLU else 1)
-    iters = int(min(48, max(iters, 2.5e-3 / max(flops / 1.0e15, 30e-6))))
+    short = M <= 128
+    chunks, reps = (int(min(6, max(1, 2.5e-3 / max(flops / 1.0e15, 30e-6) / iters))), 2) if short else (1, 1)
     for c, sch in GEMM_CANDIDATES:
         if (epi == EPI_SWIGLU and c in (5, 6, 7)) or (GEMM_BATCH_INVARIANT and sch != 1) or (c == 8 and M > 256):
             continue
         cfg = c + 16 * sch
         _gemm_call(x, copies[turn % len(copies)], out, bias, resid, M, N, K, epi, cfg, ws); turn += 1
         t = float("inf")
-        for _rep in range(2):
-            e0.record()
-            for _ in range(iters):
-                _gemm_call(x, copies[turn % len(copies)], out, bias, resid, M, N, K, epi, cfg, ws); turn += 1
-            e1.record()
-            e1.synchronize()
-            t = min(t, e0.elapsed_time(e1))
+        for _rep in range(reps):
+            tt = 0.0
+            for _chunk in range(chunks):
+                e0.record()
+                for _ in range(iters):
+                    _gemm_call(x, copies[turn % len(copies)], out, bias, resid, M, N, K, epi, cfg, ws); turn += 1
+                e1.record()
+                e1.synchronize()
+                tt += e0.elapsed_time(e1)
+            t = min(t, tt)
         if t < best_t:
             best, best_t = cfg, t
     _gemm_call(x, w, out, bias, resid, M, N, K, epi, best, ws)          # leave the caller's result in `out`

@@ -8,7 +8,9 @@ cd "${GRAFT_REPO_ROOT:-$(pwd)}"
 export TMPDIR=/tmp
 OUT=gpurun_out/prof
 mkdir -p $OUT
-rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/trace -o bench -- python bench.py --no-baselines > $OUT/bench_line.json 2> $OUT/bench.err
+# hard limits on every rocprofv3 run: when the traced process aborts, rocprofv3 keeps waiting for it (one such run cost 36 GPU-minutes)
+timeout -s KILL 600 rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/trace -o bench -- python bench.py --no-baselines > $OUT/bench_line.json 2> $OUT/bench.err
+[ -s $OUT/bench_line.json ] || { echo "bench.py under rocprofv3 produced no line (see $OUT/bench.err)"; exit 1; }
 CSV=$(find $OUT/trace -name '*kernel_trace.csv' | head -1)
 python tools/trace_median.py "$CSV" 45 > $OUT/kernel_medians.txt
 STATS=$(find $OUT/trace -name '*kernel_stats.csv' | head -1)
@@ -29,7 +31,7 @@ if len(v) >= 170:
 PY
 rm -rf $OUT/trace
 for C in FETCH_SIZE WRITE_SIZE; do
-  rocprofv3 --pmc $C --output-format csv -d $OUT/pmc_$C -o k -- python tools/kernel_sweep.py --only-canonical > /dev/null 2> $OUT/pmc_$C.err
+  timeout -s KILL 400 rocprofv3 --pmc $C --output-format csv -d $OUT/pmc_$C -o k -- python tools/kernel_sweep.py --only-canonical > /dev/null 2> $OUT/pmc_$C.err
   F=$(find $OUT/pmc_$C -name '*counter_collection.csv' | head -1)
   python - "$F" $C >> $OUT/pmc_fused_kernel.txt <<'PY'
 import csv, sys, statistics
@@ -38,7 +40,7 @@ print(f"{sys.argv[2]:11s} n={len(v)} mean {statistics.mean(v):.1f} KB per launch
 PY
   rm -rf $OUT/pmc_$C
 done
-rocprofv3 --pmc MfmaUtil --output-format csv -d $OUT/pmc_mfma -o k -- python tools/mfma_util_probe.py > /dev/null 2> $OUT/pmc_mfma.err
+timeout -s KILL 600 rocprofv3 --pmc MfmaUtil --output-format csv -d $OUT/pmc_mfma -o k -- python tools/mfma_util_probe.py > /dev/null 2> $OUT/pmc_mfma.err
 F=$(find $OUT/pmc_mfma -name '*counter_collection.csv' | head -1)
 python - "$F" > $OUT/pmc_mfma_util.txt <<'PY'
 import csv, sys, collections, statistics, re
