@@ -476,9 +476,10 @@ def test_sampling_stream_advances_between_calls_and_follows_manual_seed(eng):
     assert torch.equal(n1, m1) and not torch.equal(n1, n2)
 
 
-def test_norm_fused_few_row_step_equals_the_unfused_step(eng):
+@pytest.mark.parametrize("n_img,per_img", [(1, 1), (1, 2), (1, 3), (1, 5), (2, 4)])      # 2, 4, 6, 10, 16 rows: every row bucket of the prologue
+def test_norm_fused_few_row_step_equals_the_unfused_step(eng, n_img, per_img):
     """<= 16 rows in flight: the decode step without RMSNorm launches (LanguageModel._decode_step_few_rows) against the 7-launch layer."""
-    ids, imgs = prompts(n_img=1, per_img=2, seed=31)                 # 2 questions x 2 branches = 4 rows
+    ids, imgs = prompts(n_img=n_img, per_img=per_img, seed=31)        # questions x 2 branches
     kw = dict(images=imgs, use_dd_unk=True, cd_alpha=1.0, cd_beta=0.1, temperature=0.5, max_new_tokens=8, cd_greedy=True, output_scores=True)
     assert eng.lm.fuse_norms
     a = eng.generate(ids, **kw)
@@ -489,7 +490,7 @@ def test_norm_fused_few_row_step_equals_the_unfused_step(eng):
         eng.lm.fuse_norms = True
     for sa, sb in zip(a.scores, b.scores):
         fin = torch.isfinite(sa) & torch.isfinite(sb)
-        assert (torch.isfinite(sa) ^ torch.isfinite(sb)).sum() <= 2 and (sa[fin].float() - sb[fin].float()).abs().max().item() <= 0.25
+        assert (torch.isfinite(sa) ^ torch.isfinite(sb)).sum() <= 2 * len(ids) and (sa[fin].float() - sb[fin].float()).abs().max().item() <= 0.25
     assert (a.tokens == b.tokens).float().mean().item() >= 0.75
 
 
