@@ -185,7 +185,9 @@ int vdd_skinny_swiglu(const void* X, const void* W_gate_up, void* act, int M, in
  *   vdd_skinny_gemm_resid_ss   Y = bf16(bf16(X W^T) + R): the d-wide projection (attention output / MLP down) writes the NEW residual
  *                              stream and ss_out[row * ceil(N/16) + block] = the sum of squares of the block's 16 columns of that row;
  *   vdd_skinny_gemm_normed     Y = rmsnorm(H) W^T with rmsnorm(H)[k] = bf16(bf16(H[k] * rstd) * ln_w[k]), rstd = rsqrt(sum(ss[row][0..nss))
- *                              / K + eps): H is the un-normalised residual stream (row length K), normalised as its fragments load;
+ *                              / K + eps): H is the un-normalised residual stream (row length K), normalised ONCE per workgroup into
+ *                              LDS.  K % 256 == 0, K <= 8192, nss % 4 == 0, nss <= 512, M * 2 K <= 142 KiB (VDD_ERR_UNSUPPORTED beyond:
+ *                              the caller takes vdd_rmsnorm + vdd_skinny_gemm);
  *   vdd_skinny_swiglu_normed   the same input form for the gate/up projection + SiLU*mul (vdd_skinny_swiglu).
  * The partial sums are added in a fixed order (deterministic); same bf16 rounding points as vdd_rmsnorm + the plain projections. */
 int vdd_skinny_gemm_resid_ss(const void* X, const void* W, const void* R, void* Y, float* ss_out, int M, int N, int K, int64_t ldx,
