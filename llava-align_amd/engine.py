@@ -693,7 +693,7 @@ class VddLlavaEngine:
     # generate() kwargs of the reference's drivers that have no effect on this path: KV caching is always on, attention maps /
     # hidden states are never materialised, masks are implied by the ragged prompts, length_penalty only acts on beam search
     IGNORED_GENERATE_KWARGS = frozenset({"use_cache", "output_attentions", "output_hidden_states", "attention_mask", "length_penalty",
-                                         "synced_gpus", "streamer", "use_image"})
+                                         "synced_gpus", "use_image"})
 
     def __init__(self, cfg: LlavaConfig | str = "llava-1.5-7b", weights: Optional[LlavaWeights] = None, device="cuda:0",
                  seed: int = 0, max_questions: int = 64, t_max: int = 0, use_graph: bool = True, lm_head_gain: float = 1.0):
@@ -795,7 +795,7 @@ class VddLlavaEngine:
                  share_prefix: bool = True, sync_every: int = 8, inputs_embeds=None, min_new_tokens: Optional[int] = None,
                  min_length: Optional[int] = None, stop_words_ids=None, repetition_penalty: Optional[float] = None,
                  logits_processor=None, max_length: Optional[int] = None, num_beams: Optional[int] = None,
-                 num_return_sequences: Optional[int] = None, embeds_prefix=None, **other) -> GenerateOutput:
+                 num_return_sequences: Optional[int] = None, embeds_prefix=None, streamer=None, **other) -> GenerateOutput:
         """Same kwargs as the reference's model.generate(...) call (llava_calibrate.py:161-177); `input_ids` is a
         list of 1-D id tensors (one per question, each with one -200 image slot) or a [Q, L] tensor; `images` one
         image per question (repeat the SAME tensor for questions about the same image to share its features and
@@ -812,12 +812,18 @@ class VddLlavaEngine:
         eos_token_id[0] once a stop sequence ends the row), then `logits_processor`: a list of HF-style callables
         `f(input_ids, scores)` run in eager mode on left-padded ids.  max_length (LAVIS passes it instead of max_new_tokens) =
         prompt length + new tokens; the prompt length of inputs_embeds prompts is 0.  Beam search / several return sequences are
-        not part of the patched sample() path: refused.  Any other keyword raises TypeError instead of being dropped."""
+        not part of the patched sample() path: refused.  Any other keyword raises TypeError instead of being dropped.
+
+        streamer (HF BaseStreamer: llava/serve/cli.py [ext] passes a TextStreamer): `put(prompt ids)` as HF's generate() does before
+        sampling, `put(next token)` after every step (vcd_sample.py:264-265: one device -> host copy per step) and `end()` at the
+        end (:299-300).  One question per call, as HF's own streamers require."""
         dev, lm = self.device, self.cfg.lm
         unknown = sorted(k for k in other if k not in self.IGNORED_GENERATE_KWARGS)
         if unknown:
             raise TypeError(f"generate() got unexpected keyword argument(s) {unknown}: not implemented by VddLlavaEngine "
                             f"(accepted without effect: {sorted(self.IGNORED_GENERATE_KWARGS)})")
+        if streamer is not None and (len(input_ids) if inputs_embeds is None else len(inputs_embeds)) != 1:
+            raise ValueError("streamer: one question per generate() call (HF's TextStreamer only supports batch size 1)")
         if num_beams not in (None, 1) or num_return_sequences not in (None, 1):
             raise ValueError("num_beams / num_return_sequences > 1: the reference patches sample() only (vcd_sample.py:325-326); "
                              "beam search never reaches contrastive decoding")
@@ -984,11 +990,19 @@ class VddLlavaEngine:
         run.load(pos=[seg[i]["pos0"] + seg[i]["T"] for i in sel], cpos=[seg[i]["T"] for i in sel], slot=[seg[i]["slot"] for i in sel],
                  rows=dec_rows)
         n_new = 1
+        if streamer is not None:
+            if inputs_embeds is None:
+                streamer.put(torch.tensor([ids_list[0]], dtype=torch.long))
+            streamer.put(run.gen[:, 0].cpu())
         while n_new < max_new_tokens:
             run.step(kv)
             if output_scores:
                 scores.append(run.scores_buf.clone())
             n_new += 1
+            if streamer is not None:
+                streamer.put(run.gen[:, n_new - 1].cpu())
+                if eos_t is not None and int(run.unfinished.max().item()) == 0:
+                    break
             # the "everybody finished" test costs a host sync: every sync_every steps, and at steps 2 and 4 on the way there (POPE answers
             # are 1-2 tokens: waiting for step 8 would run six decode steps for nobody)
             if eos_t is not None and (n_new % sync_every == 0 or n_new == max_new_tokens or (n_new in (2, 4) and n_new < sync_every)):
@@ -999,6 +1013,8 @@ class VddLlavaEngine:
                     break
         if bool((run.status | run.status0).ne(0).any().item()):
             raise RuntimeError("probability tensor contains either `inf`, `nan` or element < 0")   # torch.multinomial, :202
+        if streamer is not None:
+            streamer.end()
         gen = run.gen[:, :n_new].clone()
         if eos_t is not None:
             gen = self._trim_after_all_finished(gen, eos_t, pad_token_id)

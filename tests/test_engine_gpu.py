@@ -535,3 +535,34 @@ def test_text_only_prompts_share_their_common_system_prompt(eng, batch_invariant
     assert (a.tokens == b.tokens).float().mean().item() >= 0.8
     one = eng.generate(ids[:1], **kw)                                  # a single prompt: nothing to share
     assert one.stats["prefill_tokens"] == ids[0].numel()
+
+
+def test_streamer_receives_prompt_then_every_token_then_end(eng):
+    """`streamer=` (HF BaseStreamer protocol; the reference's loop: vcd_sample.py:264-265 put(next_tokens.cpu()), :299-300 end(); HF's
+    generate() puts the prompt ids first): one question per call, tokens arrive one per step, the stream stops with the EOS token."""
+    class Rec:
+        def __init__(self):
+            self.items, self.ended = [], 0
+        def put(self, value):
+            assert value.device.type == "cpu"
+            self.items.append(value.clone())
+        def end(self):
+            self.ended += 1
+    ids, imgs = prompts(n_img=1, per_img=1, seed=41)
+    kw = dict(images=imgs, use_dd_unk=True, cd_alpha=1.0, cd_beta=0.1, temperature=0.5, max_new_tokens=12, seed=5)
+    plain = eng.generate(ids, **kw)
+    rec = Rec()
+    out = eng.generate(ids, streamer=rec, **kw)
+    assert torch.equal(out.tokens, plain.tokens) and rec.ended == 1
+    assert rec.items[0].shape == (1, ids[0].numel()) and torch.equal(rec.items[0][0], ids[0])
+    assert torch.equal(torch.cat([t.reshape(1) for t in rec.items[1:]]), out.tokens[0].cpu())
+    # EOS: the stream ends with the EOS token, as the loop does (no pad tokens are streamed)
+    eos = int(plain.tokens[0, 3])
+    rec2 = Rec()
+    o2 = eng.generate(ids, streamer=rec2, eos_token_id=eos, pad_token_id=0, **kw)
+    got = torch.cat([t.reshape(1) for t in rec2.items[1:]])
+    assert int(got[-1]) == eos and torch.equal(got, o2.tokens[0, :got.numel()].cpu()) and rec2.ended == 1
+    assert eos not in got[:-1].tolist()
+    ids2, imgs2 = prompts(n_img=1, per_img=2, seed=41)
+    with pytest.raises(ValueError):
+        eng.generate(ids2, images=imgs2, streamer=Rec(), max_new_tokens=2)
