@@ -505,6 +505,10 @@ class GenerateOutput:
     stats: dict = field(default_factory=dict)
 
     def __getitem__(self, k):
+        if k in ("attentions", "hidden_states"):
+            raise KeyError(f"{k}: not produced by the native engine (attention is computed by flash-style kernels that never materialise the "
+                           f"maps; the reference reads them only for a commented-out plot, llava_calibrate.py:180-183) - use the generic "
+                           f"evolve_vcd_sampling() path on an HF model for them")
         return getattr(self, k)
 
 
