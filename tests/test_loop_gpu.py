@@ -125,3 +125,36 @@ def test_v5_entry_greedy_disables_contrast_with_warning():
         out = _sample_v5(m, ids, LogitsProcessorList(), _crit(6), gc, attention_mask=torch.ones_like(ids), use_dd_unk=True)
     assert m.i == 2                                   # one forward per step: no contrast branch ran
     assert out[0, 4:].cpu().tolist() == [int(bank[0].argmax()), int(bank[1].argmax())]
+
+
+def test_streamer_gets_every_step_and_one_end():
+    """vcd_sample.py:264-265 `streamer.put(next_tokens.cpu())` after every step (pad tokens of finished rows included, as in the
+    reference) and :299-300 `streamer.end()` once."""
+    from llava_align_amd import sample
+
+    class Rec:
+        def __init__(self):
+            self.items, self.ended = [], 0
+        def put(self, v):
+            assert v.device.type == "cpu"
+            self.items.append(v.clone())
+        def end(self):
+            self.ended += 1
+    g = load_json("eos_pad.json")
+    case = g["cases"][0]
+    plan = torch.tensor(case["plan"])
+    B, S = plan.shape
+    bank = []
+    for s in range(S):
+        for _ in range(2):
+            row = torch.zeros(B, case["V"], dtype=torch.float16)
+            row[torch.arange(B), plan[:, s]] = 9.0
+            bank.append(row)
+    ids = torch.ones(B, 4, dtype=torch.long, device=DEV)
+    rec = Rec()
+    out = sample(HostedBank(bank), ids, logits_warper=LogitsProcessorList([TopKLogitsWarper(1)]), stopping_criteria=_crit(4 + S),
+                 pad_token_id=case["pad"], eos_token_id=case["eos"], return_dict_in_generate=True, streamer=rec,
+                 attention_mask=torch.ones_like(ids), use_dd_unk=True, cd_alpha=1.0, cd_beta=0.1, cd_greedy=True)
+    seq = out["sequences"].cpu()
+    assert rec.ended == 1 and len(rec.items) == seq.shape[1] - 4
+    assert torch.equal(torch.stack(rec.items, 1), seq[:, 4:])
