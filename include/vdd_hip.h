@@ -246,6 +246,18 @@ int vdd_decode_attention_fused(const void* qkv, const int32_t* pos, const int32_
                                int M, int H, int Hkv, int D, int64_t slot_stride, int t_max, int64_t prefix_stride, int prefix_tmax,
                                float scale, void* stream);
 
+/* The same launch with the old keys of every (row, head) cut into n_split (2 or 4) slices, one workgroup each: for one or two
+ * questions in flight H x M workgroups leave most of the chip idle and each of them walks its context in three dependent fetch
+ * rounds.  A slice leaves an un-normalised partial in `workspace`; the workgroup that finishes last merges the n_split partials
+ * in slice order (deterministic) and writes the output row.  `workspace`: vdd_decode_attention_fused_split_workspace_bytes(M, H,
+ * n_split) bytes, ZEROED once by the caller (the per-(row, head) tickets behind the partials return to zero after every launch);
+ * one workspace per stream. */
+int64_t vdd_decode_attention_fused_split_workspace_bytes(int M, int H, int n_split);
+int vdd_decode_attention_fused_split(const void* qkv, const int32_t* pos, const int32_t* cpos, const int32_t* slot, const float* cos_sin,
+                                     void* k_cache, void* v_cache, const void* k_prefix, const void* v_prefix, const int32_t* rows, void* out,
+                                     int M, int H, int Hkv, int D, int64_t slot_stride, int t_max, int64_t prefix_stride, int prefix_tmax,
+                                     float scale, void* workspace, int n_split, void* hip_stream);
+
 /* Same result as vdd_decode_attention when every row with prefix_len > 0 is listed in exactly one group of rows
  * sharing (prefix_slot, prefix_len): groups[g] = {row_off, n_rows, prefix_slot, prefix_len} (int32 x4) indexes
  * group_rows[]; items[i] = {group, first_row_of_16_row_slice, item index inside the prefix, 0} (int32 x4) is the

@@ -23,6 +23,7 @@ namespace {
 
 typedef __attribute__((ext_vector_type(8))) short bf16x8_t;   // MFMA A/B fragment: 8 bf16
 typedef __attribute__((ext_vector_type(4))) uint32_t u32x4_nt;
+typedef __attribute__((ext_vector_type(2))) uint32_t u32x2_t;
 // data that crosses the chip once (an activation read by one kernel, a cache line written for a later step): nontemporal, so it
 // takes no L2 line from data that IS re-read (the GEMMs' shared operand panels, the next GEMM's X)
 __device__ __forceinline__ uint4 ld_stream(const uint16_t* p) { return __builtin_bit_cast(uint4, __builtin_nontemporal_load(reinterpret_cast<const u32x4_nt*>(p))); }
@@ -858,18 +859,26 @@ __global__ void __launch_bounds__(256) decode_attn_combine_kernel(const float* _
 // latency-bound launches, so RoPE, the KV-cache write, the whole-context attention and the merge run as ONE kernel:
 // block = (head, row), NW waves; key t belongs to 16-lane group (t mod 4 NW); the new token's K/V never round-trip
 // through the cache (they are rotated in registers, written once per KV head, and attended from registers).
-template <int D, int NW>
+// KSPLIT > 1 (one or two questions in flight: H x M blocks would leave most CUs idle and each block three dependent fetch rounds
+// deep): blockIdx.z takes the z-th slice of the old keys, leaves an un-normalised partial (128 sums, max, weight) in `ws` with
+// write-through stores and draws a ticket from the (row, head) counter; the block that draws the last ticket merges the KSPLIT
+// partials in slice order (deterministic) and writes the output row.  Same hand-off as the GEMM's stream-K fix-up: write-through
+// (sc1) stores + s_waitcnt before a relaxed agent-scope atomic, agent-scope (sc1) loads behind it, no fences; the counter is left
+// at zero for the next launch.
+constexpr int ATT_FS = 128 + 4;          // floats per partial of the split form: 128 sums, max, weight, 2 pad (16-byte rows)
+template <int D, int NW, int KSPLIT>
 __global__ void __launch_bounds__(NW * 64) decode_attn_fused_kernel(const uint16_t* __restrict__ qkv, const int* __restrict__ pos,
                                                                     const int* __restrict__ cpos, const int* __restrict__ slot,
                                                                     const float* __restrict__ cs_table, uint16_t* __restrict__ kc,
                                                                     uint16_t* __restrict__ vc, const uint16_t* __restrict__ kpre,
                                                                     const uint16_t* __restrict__ vpre, const AttnRow* __restrict__ rows,
                                                                     uint16_t* __restrict__ out, int H, int Hkv, long long slot_stride,
-                                                                    int t_max, long long pre_stride, int pre_tmax, float scale) {
+                                                                    int t_max, long long pre_stride, int pre_tmax, float scale,
+                                                                    float* __restrict__ ws, int* __restrict__ tickets) {
     static_assert(D == 128, "lane map assumes 16 lanes x 8 dims");
     __shared__ float part[NW][D + 2];
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, g = lane >> 4, j = lane & 15;
-    const int head = blockIdx.x, row = blockIdx.y;
+    const int head = blockIdx.x, row = blockIdx.y, zs = KSPLIT > 1 ? (int)blockIdx.z : 0;
     const AttnRow ar = rows[row];
     const int p = pos[row], cp = cpos[row];
     const int kvh = head / (H / Hkv);
@@ -880,8 +889,14 @@ __global__ void __launch_bounds__(NW * 64) decode_attn_fused_kernel(const uint16
     const uint16_t* v_own = vc + (size_t)ar.slot * slot_stride + hoff - (size_t)ar.plen * D;
     const uint16_t* k_pre = kpre + (size_t)ar.pslot * pre_stride + poff;
     const uint16_t* v_pre = vpre + (size_t)ar.pslot * pre_stride + poff;
-    const int n_old = ar.len - 1, kl = wave * 4 + g;
     constexpr int U = 4, STEP = NW * 4;
+    const int n_all = ar.len - 1;                       // keys already in the cache; the new token is attended from registers
+    // this block's slice [k_lo, n_old) of them (whole STEP-key rounds per slice); the last slice also takes the new token
+    const int per = KSPLIT > 1 ? ((n_all + KSPLIT * STEP - 1) / (KSPLIT * STEP)) * STEP : 0;
+    const int k_lo = KSPLIT > 1 ? min(zs * per, n_all) : 0;
+    const int n_old = KSPLIT > 1 ? min(k_lo + per, n_all) : n_all;
+    const bool last_slice = zs == KSPLIT - 1;
+    const int kl = k_lo + wave * 4 + g;
     uint4 kn_[U], vn_[U];
     auto fetch = [&](int t0) {
 #pragma unroll
@@ -914,7 +929,7 @@ __global__ void __launch_bounds__(NW * 64) decode_attn_fused_kernel(const uint16
     const uint4 qv = rope(src + (size_t)head * D);
     const uint4 kn = rope(src + (size_t)(H + kvh) * D);
     const uint4 vn = *reinterpret_cast<const uint4*>(src + (size_t)(H + Hkv + kvh) * D + j * 8);
-    if (wave == 0 && g == 0 && head % (H / Hkv) == 0) {      // one writer per KV head
+    if (last_slice && wave == 0 && g == 0 && head % (H / Hkv) == 0) {      // one writer per KV head
         const size_t o = (size_t)slot[row] * slot_stride + ((size_t)kvh * t_max + cp) * D + j * 8;
         *reinterpret_cast<uint4*>(kc + o) = kn;
         *reinterpret_cast<uint4*>(vc + o) = vn;
@@ -937,7 +952,7 @@ __global__ void __launch_bounds__(NW * 64) decode_attn_fused_kernel(const uint16
         float sc = dot8(qv, kn);
         sc += __shfl_xor(sc, 1); sc += __shfl_xor(sc, 2); sc += __shfl_xor(sc, 4); sc += __shfl_xor(sc, 8);
         sc *= scale;
-        if (kl == STEP - 1) ATT_ONLINE_STEP(sc, vn, m, l, acc);
+        if (last_slice && wave == NW - 1 && g == 3) ATT_ONLINE_STEP(sc, vn, m, l, acc);
     }
 #pragma unroll
     for (int o = 16; o <= 32; o <<= 1) {
@@ -962,12 +977,45 @@ __global__ void __launch_bounds__(NW * 64) decode_attn_fused_kernel(const uint16
         float L = 0.f, a0 = 0.f, a1 = 0.f;
 #pragma unroll
         for (int w = 0; w < NW; ++w) {
-            const float wgt = __expf(part[w][D] - Mx);       // empty waves: exp(-inf) = 0
+            const float wgt = part[w][D] == -INFINITY ? 0.f : __expf(part[w][D] - Mx);       // empty waves (and a whole empty slice)
             L += wgt * part[w][D + 1];
             a0 += wgt * part[w][2 * lane]; a1 += wgt * part[w][2 * lane + 1];
         }
-        const float inv = 1.f / L;
-        reinterpret_cast<uint32_t*>(out + ((size_t)row * H + head) * D)[lane] = pack(a0 * inv, a1 * inv);
+        if constexpr (KSPLIT == 1) {
+            const float inv = 1.f / L;
+            reinterpret_cast<uint32_t*>(out + ((size_t)row * H + head) * D)[lane] = pack(a0 * inv, a1 * inv);
+        } else {
+            const size_t rh = (size_t)row * H + head;
+            float* mine = ws + (rh * KSPLIT + zs) * ATT_FS;
+            const __amdgpu_buffer_rsrc_t rp = __builtin_amdgcn_make_buffer_rsrc((void*)mine, 0, ATT_FS * 4, 0x00020000);
+            __builtin_amdgcn_raw_buffer_store_b64(__builtin_bit_cast(u32x2_t, f32x2_hw{a0, a1}), rp, lane * 8, 0, 16);
+            if (lane == 0) __builtin_amdgcn_raw_buffer_store_b64(__builtin_bit_cast(u32x2_t, f32x2_hw{Mx, L}), rp, D * 4, 0, 16);
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+            int ticket = 0;
+            if (lane == 0) ticket = __hip_atomic_fetch_add(tickets + rh, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            ticket = __builtin_amdgcn_readfirstlane(ticket);
+            if (ticket == KSPLIT - 1) {                  // every other slice has published: merge in slice order
+                if (lane == 0) __hip_atomic_store(tickets + rh, 0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                const __amdgpu_buffer_rsrc_t rq = __builtin_amdgcn_make_buffer_rsrc((void*)(ws + rh * KSPLIT * ATT_FS), 0, KSPLIT * ATT_FS * 4, 0x00020000);
+                f32x2_hw av[KSPLIT], ml[KSPLIT];
+#pragma unroll
+                for (int k = 0; k < KSPLIT; ++k) {
+                    av[k] = __builtin_bit_cast(f32x2_hw, __builtin_amdgcn_raw_buffer_load_b64(rq, (k * ATT_FS) * 4 + lane * 8, 0, 16));
+                    ml[k] = __builtin_bit_cast(f32x2_hw, __builtin_amdgcn_raw_buffer_load_b64(rq, (k * ATT_FS + D) * 4, 0, 16));
+                }
+                float Mg = -INFINITY;
+#pragma unroll
+                for (int k = 0; k < KSPLIT; ++k) Mg = fmaxf(Mg, ml[k][0]);
+                float Lg = 0.f, b0 = 0.f, b1 = 0.f;
+#pragma unroll
+                for (int k = 0; k < KSPLIT; ++k) {
+                    const float wgt = ml[k][0] == -INFINITY ? 0.f : __expf(ml[k][0] - Mg);     // an empty slice weighs nothing
+                    Lg += wgt * ml[k][1]; b0 += wgt * av[k][0]; b1 += wgt * av[k][1];
+                }
+                const float inv = 1.f / Lg;
+                reinterpret_cast<uint32_t*>(out + rh * D)[lane] = pack(b0 * inv, b1 * inv);
+            }
+        }
     }
 }
 
@@ -1330,10 +1378,34 @@ int vdd_decode_attention_fused(const void* qkv, const int32_t* pos, const int32_
     if (M <= 0) return VDD_OK;
     if (!qkv || !pos || !cpos || !slot || !cos_sin || !k_cache || !v_cache || !k_prefix || !v_prefix || !rows || !out || D != 128 ||
         H % Hkv != 0 || M > 65535) return VDD_ERR_INVALID_ARG;
-    hipLaunchKernelGGL((decode_attn_fused_kernel<128, 16>), dim3(H, M), dim3(1024), 0, (hipStream_t)stream, (const uint16_t*)qkv, pos, cpos,
+    hipLaunchKernelGGL((decode_attn_fused_kernel<128, 16, 1>), dim3(H, M), dim3(1024), 0, (hipStream_t)stream, (const uint16_t*)qkv, pos, cpos,
                        slot, cos_sin, (uint16_t*)k_cache, (uint16_t*)v_cache, (const uint16_t*)k_prefix, (const uint16_t*)v_prefix,
                        (const AttnRow*)rows, (uint16_t*)out, H, Hkv, (long long)slot_stride, t_max, (long long)prefix_stride, prefix_tmax,
-                       scale);
+                       scale, (float*)nullptr, (int*)nullptr);
+    return ok(hipSuccess);
+}
+
+int64_t vdd_decode_attention_fused_split_workspace_bytes(int M, int H, int n_split) {
+    if (M <= 0 || H <= 0 || n_split < 1) return 0;
+    return ((int64_t)M * H * n_split * ATT_FS + (int64_t)M * H) * 4;
+}
+
+int vdd_decode_attention_fused_split(const void* qkv, const int32_t* pos, const int32_t* cpos, const int32_t* slot, const float* cos_sin,
+                                     void* k_cache, void* v_cache, const void* k_prefix, const void* v_prefix, const int32_t* rows, void* out,
+                                     int M, int H, int Hkv, int D, int64_t slot_stride, int t_max, int64_t prefix_stride, int prefix_tmax,
+                                     float scale, void* workspace, int n_split, void* stream) {
+    if (M <= 0) return VDD_OK;
+    if (!qkv || !pos || !cpos || !slot || !cos_sin || !k_cache || !v_cache || !k_prefix || !v_prefix || !rows || !out || !workspace || D != 128 ||
+        H % Hkv != 0 || M > 65535 || (n_split != 2 && n_split != 4)) return VDD_ERR_INVALID_ARG;
+    float* ws = (float*)workspace;
+    int* tickets = (int*)(ws + (size_t)M * H * n_split * ATT_FS);
+#define VDD_FUSED_SPLIT(KS)                                                                                                            \
+    hipLaunchKernelGGL((decode_attn_fused_kernel<128, 16, KS>), dim3(H, M, KS), dim3(1024), 0, (hipStream_t)stream, (const uint16_t*)qkv, pos, \
+                       cpos, slot, cos_sin, (uint16_t*)k_cache, (uint16_t*)v_cache, (const uint16_t*)k_prefix, (const uint16_t*)v_prefix,  \
+                       (const AttnRow*)rows, (uint16_t*)out, H, Hkv, (long long)slot_stride, t_max, (long long)prefix_stride, prefix_tmax, \
+                       scale, ws, tickets)
+    if (n_split == 2) VDD_FUSED_SPLIT(2); else VDD_FUSED_SPLIT(4);
+#undef VDD_FUSED_SPLIT
     return ok(hipSuccess);
 }
 

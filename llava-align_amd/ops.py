@@ -15,6 +15,7 @@ _SIGS = {
     "vdd_embed_scatter": [_P, _P, _P, _P, _I, _I, _I, _P],
     "vdd_skinny_swiglu": [_P, _P, _P, _I, _I, _I, _L, _P],
     "vdd_decode_attention_fused": [_P] * 11 + [_I, _I, _I, _I, _L, _I, _L, _I, _F, _P],
+    "vdd_decode_attention_fused_split": [_P] * 11 + [_I, _I, _I, _I, _L, _I, _L, _I, _F, _P, _I, _P],
     "vdd_rmsnorm": [_P, _P, _P, _I, _P, _P, _P, _I, _I, _F, _P],
     "vdd_gemm": [_P, _P, _P, _P, _P, _I, _I, _I, _L, _L, _L, _L, _I, _I, _P, _L, _P],
     "vdd_rope_kv_write": [_P, _P, _P, _P, _P, _P, _P, _P, _I, _I, _I, _I, _L, _I, _P],
@@ -398,15 +399,50 @@ def decode_attention(q, k_cache, v_cache, rows, H, Hkv, D, out=None, max_len=Non
 FUSED_ATTN_MAX_M = 16     # rows up to which RoPE + KV write + attention + merge run as one launch
 
 
-def decode_attention_fused(qkv, pos, cpos, slot, cos_sin, k_cache, v_cache, rows, H, Hkv, D, out=None, k_prefix=None, v_prefix=None):
+FUSED_ATTN_SPLIT = True   # cut the keys of a (row, head) over 2 / 4 workgroups while H x M of them would leave most CUs idle
+_fused_split_ws = {}
+
+
+def fused_attention_split(M, H):
+    """Key slices per (row, head) of the one-launch decode attention: 4 up to 64 (row, head) pairs (one question, two branches of 32
+    heads: 256 workgroups instead of 64), 2 up to 128, else 1."""
+    if not FUSED_ATTN_SPLIT:
+        return 1
+    return 4 if M * H <= 64 else (2 if M * H <= 128 else 1)
+
+
+def _fused_split_workspace(device, M, H, n_split):
+    """Partials + tickets of the split form, one buffer per (device, stream, shape); zeroed once (the tickets return to zero after
+    every launch).  Must exist before a graph capture, like the GEMM workspace."""
+    lib = _lib_ready()
+    lib.vdd_decode_attention_fused_split_workspace_bytes.restype = C.c_int64
+    key = (device, torch.cuda.current_stream(device).cuda_stream, M, H, n_split)
+    ws = _fused_split_ws.get(key)
+    if ws is None:
+        if torch.cuda.is_current_stream_capturing():
+            raise RuntimeError("the split-attention workspace must exist before a graph capture (run the step once eagerly on this stream)")
+        ws = _fused_split_ws[key] = torch.zeros(lib.vdd_decode_attention_fused_split_workspace_bytes(M, H, n_split), dtype=torch.uint8, device=device)
+    return ws
+
+
+def decode_attention_fused(qkv, pos, cpos, slot, cos_sin, k_cache, v_cache, rows, H, Hkv, D, out=None, k_prefix=None, v_prefix=None, n_split=None):
     """Small-M decode attention straight from the un-rotated qkv projection [M, (H+2Hkv)*D]: RoPE, KV-cache write of the new
     token (index cpos of slot), whole-context attention and merge in one kernel.  Same arguments as rope_kv_write +
-    decode_attention; rows[:, 1] (len) counts the new token."""
+    decode_attention; rows[:, 1] (len) counts the new token.  n_split (default: fused_attention_split(M, H)) > 1 cuts the old keys of
+    every (row, head) over that many workgroups; the last one to finish merges their partials in slice order."""
     _bf16(qkv, k_cache, v_cache)
     M = qkv.shape[0]
     k_prefix = k_cache if k_prefix is None else k_prefix
     v_prefix = v_cache if v_prefix is None else v_prefix
     out = torch.empty(M, H * D, dtype=qkv.dtype, device=qkv.device) if out is None else out
+    n_split = fused_attention_split(M, H) if n_split is None else n_split
+    if n_split > 1:
+        ws = _fused_split_workspace(qkv.device, M, H, n_split)
+        _lib.check(_lib_ready().vdd_decode_attention_fused_split(qkv.data_ptr(), pos.data_ptr(), cpos.data_ptr(), slot.data_ptr(), cos_sin.data_ptr(),
+                                                                k_cache.data_ptr(), v_cache.data_ptr(), k_prefix.data_ptr(), v_prefix.data_ptr(),
+                                                                rows.data_ptr(), out.data_ptr(), M, H, Hkv, D, k_cache.stride(0), k_cache.shape[2],
+                                                                k_prefix.stride(0), k_prefix.shape[2], D ** -0.5, ws.data_ptr(), n_split, _st(qkv)))
+        return out
     _lib.check(_lib_ready().vdd_decode_attention_fused(qkv.data_ptr(), pos.data_ptr(), cpos.data_ptr(), slot.data_ptr(), cos_sin.data_ptr(),
                                                       k_cache.data_ptr(), v_cache.data_ptr(), k_prefix.data_ptr(), v_prefix.data_ptr(),
                                                       rows.data_ptr(), out.data_ptr(), M, H, Hkv, D, k_cache.stride(0), k_cache.shape[2],

@@ -147,10 +147,14 @@ def test_decode_attention_ragged_and_prefix_shared():
         ref = attn_ref(q[m].view(H, D).float(), K, V)
         assert torch.allclose(out[m].float(), ref, rtol=2e-2, atol=2e-2), m
 
+@pytest.mark.parametrize("n_split", [1, 2, 4])
 @pytest.mark.parametrize("H,Hkv", [(8, 8), (8, 2)])
-def test_decode_attention_fused_equals_rope_write_then_attention(H, Hkv):
+def test_decode_attention_fused_equals_rope_write_then_attention(H, Hkv, n_split):
     """Small-M kernel (RoPE + KV write + whole-context attention + merge in one launch) vs the three-kernel path it
-    replaces: identical cache contents (bit-exact: same RoPE rounding), outputs equal up to the softmax partition order."""
+    replaces: identical cache contents (bit-exact: same RoPE rounding), outputs equal up to the softmax partition order.
+    n_split > 1: the keys of a (row, head) cut over 2 / 4 workgroups, merged by the last one to finish (contexts of 0, 1, 65, 699 and
+    649 old keys: empty slices, a slice holding only the new token, ragged last rounds); launched repeatedly - the tickets must return
+    to zero - and bit-identical from launch to launch (the merge order is the slice order, not the arrival order)."""
     O = ops()
     D, T, S, TP = 128, 720, 5, 640
     cs = rope_table(800, D)
@@ -166,9 +170,12 @@ def test_decode_attention_fused_equals_rope_write_then_attention(H, Hkv):
     k1, v1, k2, v2 = kc.clone(), vc.clone(), kc.clone(), vc.clone()
     q = O.rope_kv_write(qkv, pos, slot, cs, k1, v1, H, Hkv, D, cpos=cpos)
     want = O.decode_attention(q, k1, v1, rows, H, Hkv, D, k_prefix=kp, v_prefix=vp)
-    got = O.decode_attention_fused(qkv, pos, cpos, slot, cs, k2, v2, rows, H, Hkv, D, k_prefix=kp, v_prefix=vp)
+    got = O.decode_attention_fused(qkv, pos, cpos, slot, cs, k2, v2, rows, H, Hkv, D, k_prefix=kp, v_prefix=vp, n_split=n_split)
     assert torch.equal(k1, k2) and torch.equal(v1, v2)
     assert torch.allclose(got.float(), want.float(), rtol=2e-2, atol=2e-2), (got.float() - want.float()).abs().max().item()
+    for _ in range(20):
+        again = O.decode_attention_fused(qkv, pos, cpos, slot, cs, k2, v2, rows, H, Hkv, D, k_prefix=kp, v_prefix=vp, n_split=n_split)
+        assert torch.equal(again, got)
 
 @pytest.mark.parametrize("M", [1, 2, 7, 8])
 def test_swiglu_linear_equals_gemm_then_silu_mul(M):
