@@ -95,15 +95,25 @@ __global__ void __launch_bounds__(256) rmsnorm_kernel(const uint16_t* __restrict
     __shared__ float red[4];
     const int row = blockIdx.x, tid = threadIdx.x;
     const size_t off = (size_t)row * d;
-    uint4 h[VPT];
+    uint4 h[VPT], dl[VPT], wv[VPT];
     float ss = 0.f;
+    // every load of the row leaves before anything is consumed (x, the delta, the ln weights: ONE memory round trip), from clamped,
+    // never predicated addresses: a load inside `if (e < d)` is waited for inside that branch, which made the VPT chunks of a thread
+    // - and the weights behind them - a chain of round trips (13 us for 25 MB at 1,536 rows)
+#pragma unroll
+    for (int i = 0; i < VPT; ++i) {
+        const int e = (i * 256 + tid) * 8, ec = e < d ? e : 0;
+        h[i] = stream ? ld_stream(x + off + ec) : *reinterpret_cast<const uint4*>(x + off + ec);
+        if (delta != nullptr) dl[i] = stream ? ld_stream(delta + off + ec) : *reinterpret_cast<const uint4*>(delta + off + ec);
+        wv[i] = *reinterpret_cast<const uint4*>(w + ec);
+    }
 #pragma unroll
     for (int i = 0; i < VPT; ++i) {
         const int e = (i * 256 + tid) * 8;
         if (e < d) {
-            uint4 a = stream ? ld_stream(x + off + e) : *reinterpret_cast<const uint4*>(x + off + e);
+            uint4 a = h[i];
             if (delta != nullptr) {
-                uint4 b = stream ? ld_stream(delta + off + e) : *reinterpret_cast<const uint4*>(delta + off + e);
+                const uint4 b = dl[i];
                 a.x = pack(lo(a.x) + lo(b.x), hi(a.x) + hi(b.x)); a.y = pack(lo(a.y) + lo(b.y), hi(a.y) + hi(b.y));
                 a.z = pack(lo(a.z) + lo(b.z), hi(a.z) + hi(b.z)); a.w = pack(lo(a.w) + lo(b.w), hi(a.w) + hi(b.w));
             }
@@ -125,12 +135,6 @@ __global__ void __launch_bounds__(256) rmsnorm_kernel(const uint16_t* __restrict
             f = lo(a.x); ss += f * f; f = hi(a.x); ss += f * f; f = lo(a.y); ss += f * f; f = hi(a.y); ss += f * f;
             f = lo(a.z); ss += f * f; f = hi(a.z); ss += f * f; f = lo(a.w); ss += f * f; f = hi(a.w); ss += f * f;
         }
-    }
-    uint4 wv[VPT];                                   // issued before the barrier: off the dependent chain
-#pragma unroll
-    for (int i = 0; i < VPT; ++i) {
-        const int e = (i * 256 + tid) * 8;
-        wv[i] = e < d ? *reinterpret_cast<const uint4*>(w + e) : make_uint4(0, 0, 0, 0);
     }
     ss = wave_sum(ss);
     if ((tid & 63) == 0) red[tid >> 6] = ss;
@@ -166,33 +170,65 @@ __global__ void __launch_bounds__(256) rope_kv_kernel(const uint16_t* __restrict
     const int half = D / 2, h8 = half / 8;                      // a work item = 8 consecutive pairs (i, i + D/2) of one head
     const uint16_t* src = qkv + (size_t)row * (size_t)((Hq + 2 * Hkv) * D);
     const float* cs = cs_table + (size_t)p * half * 2;
-    for (int i = tid; i < (Hq + Hkv) * h8; i += 256) {
-        const int head = i / h8, pi = (i % h8) * 8;
-        const bool is_k = head >= Hq;
-        const uint16_t* hsrc = src + (size_t)head * D;           // q heads then k heads are contiguous in qkv
-        const uint4 a4 = stream ? ld_stream(hsrc + pi) : *reinterpret_cast<const uint4*>(hsrc + pi);
-        const uint4 b4 = stream ? ld_stream(hsrc + pi + half) : *reinterpret_cast<const uint4*>(hsrc + pi + half);
-        const float4 c0 = *reinterpret_cast<const float4*>(cs + pi * 2), c1 = *reinterpret_cast<const float4*>(cs + pi * 2 + 4),
-                     c2 = *reinterpret_cast<const float4*>(cs + pi * 2 + 8), c3 = *reinterpret_cast<const float4*>(cs + pi * 2 + 12);
-        auto rot = [](uint32_t av, uint32_t bv, float cA, float sA, float cB, float sB, uint32_t& r0, uint32_t& r1) {
-            const float a0 = lo(av), a1 = hi(av), b0 = lo(bv), b1 = hi(bv);
-            r0 = pack(a0 * cA - b0 * sA, a1 * cB - b1 * sB);
-            r1 = pack(b0 * cA + a0 * sA, b1 * cB + a1 * sB);
-        };
-        uint4 r0, r1;
-        rot(a4.x, b4.x, c0.x, c0.y, c0.z, c0.w, r0.x, r1.x); rot(a4.y, b4.y, c1.x, c1.y, c1.z, c1.w, r0.y, r1.y);
-        rot(a4.z, b4.z, c2.x, c2.y, c2.z, c2.w, r0.z, r1.z); rot(a4.w, b4.w, c3.x, c3.y, c3.z, c3.w, r0.w, r1.w);
-        uint16_t* dst = is_k ? k_cache + (size_t)s * slot_stride + ((size_t)(head - Hq) * t_max + cp) * D
-                             : q_out + (size_t)row * Hq * D + (size_t)head * D;
-        if (is_k && stream) { st_stream(dst + pi, r0); st_stream(dst + pi + half, r1); }
-        else { *reinterpret_cast<uint4*>(dst + pi) = r0; *reinterpret_cast<uint4*>(dst + pi + half) = r1; }
+    // All loads of a pass leave before the first result is used: work items tid, tid + 256, ... in batches of IT, read from clamped
+    // (always valid) indices, consumed under the `valid` predicate.  As `for (i = tid; i < n; i += 256) { load; rotate; store; }` every
+    // trip was a memory round trip of its own (two for q / k, two for v: 17 us per launch at 1,536 rows).
+    constexpr int IT = 2;                                     // 64 q / k heads x 8 items = 512 = one batch
+    const int n_qk = (Hq + Hkv) * h8;
+    for (int i0 = tid; i0 < n_qk; i0 += 256 * IT) {
+        uint4 a4[IT], b4[IT];
+        float4 c[IT][4];
+#pragma unroll
+        for (int k = 0; k < IT; ++k) {
+            const int i = i0 + 256 * k, ic = i < n_qk ? i : 0;
+            const int head = ic / h8, pi = (ic % h8) * 8;
+            const uint16_t* hsrc = src + (size_t)head * D;           // q heads then k heads are contiguous in qkv
+            a4[k] = stream ? ld_stream(hsrc + pi) : *reinterpret_cast<const uint4*>(hsrc + pi);
+            b4[k] = stream ? ld_stream(hsrc + pi + half) : *reinterpret_cast<const uint4*>(hsrc + pi + half);
+#pragma unroll
+            for (int q = 0; q < 4; ++q) c[k][q] = *reinterpret_cast<const float4*>(cs + pi * 2 + 4 * q);
+        }
+#pragma unroll
+        for (int k = 0; k < IT; ++k) {
+            const int i = i0 + 256 * k;
+            if (i < n_qk) {
+                const int head = i / h8, pi = (i % h8) * 8;
+                const bool is_k = head >= Hq;
+                auto rot = [](uint32_t av, uint32_t bv, float cA, float sA, float cB, float sB, uint32_t& r0, uint32_t& r1) {
+                    const float a0 = lo(av), a1 = hi(av), b0 = lo(bv), b1 = hi(bv);
+                    r0 = pack(a0 * cA - b0 * sA, a1 * cB - b1 * sB);
+                    r1 = pack(b0 * cA + a0 * sA, b1 * cB + a1 * sB);
+                };
+                uint4 r0, r1;
+                rot(a4[k].x, b4[k].x, c[k][0].x, c[k][0].y, c[k][0].z, c[k][0].w, r0.x, r1.x);
+                rot(a4[k].y, b4[k].y, c[k][1].x, c[k][1].y, c[k][1].z, c[k][1].w, r0.y, r1.y);
+                rot(a4[k].z, b4[k].z, c[k][2].x, c[k][2].y, c[k][2].z, c[k][2].w, r0.z, r1.z);
+                rot(a4[k].w, b4[k].w, c[k][3].x, c[k][3].y, c[k][3].z, c[k][3].w, r0.w, r1.w);
+                uint16_t* dst = is_k ? k_cache + (size_t)s * slot_stride + ((size_t)(head - Hq) * t_max + cp) * D
+                                     : q_out + (size_t)row * Hq * D + (size_t)head * D;
+                if (is_k && stream) { st_stream(dst + pi, r0); st_stream(dst + pi + half, r1); }
+                else { *reinterpret_cast<uint4*>(dst + pi) = r0; *reinterpret_cast<uint4*>(dst + pi + half) = r1; }
+            }
+        }
     }
     const uint16_t* vsrc = src + (size_t)(Hq + Hkv) * D;
-    for (int i = tid; i < Hkv * D / 8; i += 256) {
-        const int head = (i * 8) / D, dd = (i * 8) % D;
-        uint16_t* vd = v_cache + (size_t)s * slot_stride + ((size_t)head * t_max + cp) * D + dd;
-        if (stream) st_stream(vd, ld_stream(vsrc + (size_t)i * 8));
-        else *reinterpret_cast<uint4*>(vd) = *reinterpret_cast<const uint4*>(vsrc + (size_t)i * 8);
+    const int n_v = Hkv * D / 8;
+    for (int i0 = tid; i0 < n_v; i0 += 256 * IT) {
+        uint4 vv[IT];
+#pragma unroll
+        for (int k = 0; k < IT; ++k) {
+            const int i = i0 + 256 * k, ic = i < n_v ? i : 0;
+            vv[k] = stream ? ld_stream(vsrc + (size_t)ic * 8) : *reinterpret_cast<const uint4*>(vsrc + (size_t)ic * 8);
+        }
+#pragma unroll
+        for (int k = 0; k < IT; ++k) {
+            const int i = i0 + 256 * k;
+            if (i < n_v) {
+                const int head = (i * 8) / D, dd = (i * 8) % D;
+                uint16_t* vd = v_cache + (size_t)s * slot_stride + ((size_t)head * t_max + cp) * D + dd;
+                if (stream) st_stream(vd, vv[k]); else *reinterpret_cast<uint4*>(vd) = vv[k];
+            }
+        }
     }
 }
 
