@@ -185,10 +185,12 @@ __global__ void __launch_bounds__(256, 2) flash_attn2_kernel(const uint16_t* __r
             for (int b = 0; b < 2; ++b)
 #pragma unroll
                 for (int e = 0; e < 16; ++e) s[b][e] = 0.f;
+            __builtin_amdgcn_s_setprio(2);
 #pragma unroll
             for (int ks = 0; ks < KS; ++ks)
 #pragma unroll
                 for (int b = 0; b < 2; ++b) s[b] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(kf[b][ks], qf[ks], s[b], 0, 0, 0);
+            __builtin_amdgcn_s_setprio(0);
         }
         // ---- mask + online softmax: this lane's scores are keys kt + 32 b + (r & 3) + 8 (r >> 2) + 4 hi of query q ----
         // (masking only on the causal diagonal and on the ragged last tile: one wave-uniform branch)
@@ -264,11 +266,13 @@ __global__ void __launch_bounds__(256, 2) flash_attn2_kernel(const uint16_t* __r
             }
         };
         __builtin_amdgcn_sched_barrier(0);
+        __builtin_amdgcn_s_setprio(2);
         issue(0, va);
         issue(1, vn); landed(va, std::true_type{}); pv(0, va); __builtin_amdgcn_sched_barrier(0);
         issue(2, va); landed(vn, std::true_type{}); pv(1, vn); __builtin_amdgcn_sched_barrier(0);
         issue(3, vn); landed(va, std::true_type{}); pv(2, va); __builtin_amdgcn_sched_barrier(0);
         landed(vn, std::false_type{}); pv(3, vn);
+        __builtin_amdgcn_s_setprio(0);
     };
     if constexpr (!PACK) {
         stage(0, 0, sd.slot, Tk);
