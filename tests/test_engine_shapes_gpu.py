@@ -128,3 +128,27 @@ def test_qwen_7b_widths_bias_epilogue_and_151936_vocab_match_reference():
             if out.tokens[q, step].item() != r.sequences[0, step].item():
                 break
     assert checked >= 4
+
+
+@pytest.mark.parametrize("n_q", [1, 5, 8])
+def test_few_row_layer_at_7b_widths_equals_the_unfused_layer(n_q):
+    """One / five / eight questions in flight at LLaVA-1.5-7B widths (2, 10, 16 rows): the few-row decode layer - projections that
+    normalise their input once per workgroup (two 4-wave blocks per CU at 2 rows, one 8-wave block at 10 and 16), residual + sum of
+    squares in the d-wide projections, the one-launch attention with its keys cut over 4 workgroups (2 rows) - against the layer of
+    separate RMSNorm / projection / attention launches on the same weights."""
+    eng = _engine(dict(d=4096, n_heads=32, n_kv_heads=32, head_dim=128, ffn=11008, vocab=32000))
+    ids, imgs = _prompts((n_q + 5) // 6, 6, 32000, seed=23)
+    ids, imgs = ids[:n_q], imgs[:n_q]
+    kw = dict(images=imgs, use_dd_unk=True, cd_alpha=1.0, cd_beta=0.1, temperature=0.5, max_new_tokens=6, cd_greedy=True, output_scores=True)
+    a = eng.generate(ids, **kw)
+    from llava_align_amd import ops
+    try:
+        eng.lm.fuse_norms, ops.FUSED_ATTN_SPLIT = False, False
+        b = eng.generate(ids, **kw)
+    finally:
+        eng.lm.fuse_norms, ops.FUSED_ATTN_SPLIT = True, True
+    for step, (sa, sb) in enumerate(zip(a.scores, b.scores)):
+        fin = torch.isfinite(sa) & torch.isfinite(sb)
+        assert (torch.isfinite(sa) ^ torch.isfinite(sb)).sum() <= 2 * n_q, step
+        assert (sa[fin].float() - sb[fin].float()).abs().max().item() <= 0.25, step
+    assert (a.tokens == b.tokens).float().mean().item() >= 0.75
