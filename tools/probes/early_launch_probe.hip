@@ -11,29 +11,37 @@
 #include <hip/hip_runtime.h>
 #include <stdint.h>
 #include <stdio.h>
+#include <stdlib.h>
 #include <chrono>
 #include <vector>
 typedef __attribute__((ext_vector_type(4))) uint32_t u32x4;
 
 constexpr int NB = 16;                                   // 16-byte loads per lane and batch (two register stages of 8 in the real kernels)
 __global__ void __launch_bounds__(256) stream_launch(const char* w, size_t bytes, const int* wait_flag, int expect, int* set_flag, uint32_t* sink,
-                                                     int* timeouts) {
+                                                     int* timeouts, int variant) {
     const int tid = threadIdx.x;
     const size_t per_block = bytes / gridDim.x;           // contiguous slice per workgroup, walked in batches of NB x 4 KiB
     const char* p = w + (size_t)blockIdx.x * per_block + tid * 16;
     const int nbat = (int)(per_block / (NB * 4096));
     u32x4 v[NB], acc = {0, 0, 0, 0};
+    const bool late = (variant & 1) != 0;                 // variant bit 0: load only after the wait (no prefetch: the wait alone)
+    if (!late) {
 #pragma unroll
-    for (int i = 0; i < NB; ++i) v[i] = *reinterpret_cast<const u32x4*>(p + i * 4096);          // first batch: in flight before the wait
+        for (int i = 0; i < NB; ++i) v[i] = *reinterpret_cast<const u32x4*>(p + i * 4096);      // first batch: in flight before the wait
+    }
     if (wait_flag != nullptr) {
         if (tid == 0) {
             int spins = 0;
             while (__hip_atomic_load(wait_flag, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) < expect) {
-                __builtin_amdgcn_s_sleep(4);
+                if (variant & 4) __builtin_amdgcn_s_sleep(64); else __builtin_amdgcn_s_sleep(4);
                 if (++spins > (1 << 20)) { atomicAdd(timeouts, 1); break; }                       // never hang the box
             }
         }
         __syncthreads();
+    }
+    if (late) {
+#pragma unroll
+        for (int i = 0; i < NB; ++i) v[i] = *reinterpret_cast<const u32x4*>(p + i * 4096);
     }
     for (int b = 0; b < nbat; ++b) {
 #pragma unroll
@@ -48,7 +56,8 @@ __global__ void __launch_bounds__(256) stream_launch(const char* w, size_t bytes
     if (tid == 0 && set_flag != nullptr) __hip_atomic_fetch_add(set_flag, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
 }
 
-int main() {
+int main(int argc, char** argv) {
+    const int variant = argc > 1 ? atoi(argv[1]) : 0;     // bit 0: no prefetch before the wait; bit 1: wait for the FIRST arrival only; bit 2: long poll sleep
     const size_t pool = (size_t)4 << 30;
     char* buf; hipMalloc(&buf, pool); hipMemset(buf, 1, pool);
     uint32_t* sink; hipMalloc(&sink, 4);
@@ -64,21 +73,21 @@ int main() {
         hipGraph_t g; hipGraphExec_t ge;
         hipEvent_t fork, join; hipEventCreate(&fork); hipEventCreate(&join);
         hipStreamBeginCapture(s[0], hipStreamCaptureModeGlobal);
-        if (mode == 1) { hipEventRecord(fork, s[0]); hipStreamWaitEvent(s[1], fork, 0); }
+        if (mode >= 1) { hipEventRecord(fork, s[0]); hipStreamWaitEvent(s[1], fork, 0); }
         size_t off = 0;
         for (int i = 0; i < n; ++i) {
             size_t bytes = sizes[i % 5] / (grid * NB * 4096) * (grid * NB * 4096);
             if (off + bytes > pool) off = 0;
-            const int* wf = (mode == 1 && i > 0) ? flags + (i - 1) : nullptr;
-            hipLaunchKernelGGL(stream_launch, dim3(grid), dim3(256), 0, mode == 1 ? s[i & 1] : s[0], buf + off, bytes, wf, grid, flags + i, sink, timeouts);
+            const int* wf = (mode == 1 && i > 0) ? flags + (i - 1) : nullptr;      // mode 2: two streams, NO dependency at all (what the two queues alone cost)
+            hipLaunchKernelGGL(stream_launch, dim3(grid), dim3(256), 0, mode >= 1 ? s[i & 1] : s[0], buf + off, bytes, wf, (variant & 2) ? 1 : grid, flags + i, sink, timeouts, variant);
             off += bytes;
         }
-        if (mode == 1) { hipEventRecord(join, s[1]); hipStreamWaitEvent(s[0], join, 0); }
+        if (mode >= 1) { hipEventRecord(join, s[1]); hipStreamWaitEvent(s[0], join, 0); }
         hipStreamEndCapture(s[0], &g);
         hipGraphInstantiate(&ge, g, nullptr, nullptr, 0);
         return ge;
     };
-    hipGraphExec_t ge[2] = {build(0), build(1)};
+    hipGraphExec_t ge[3] = {build(0), build(1), build(2)};
     auto run = [&](int mode) {
         hipMemset(flags, 0, 4096 * 4); hipMemset(timeouts, 0, 4);
         hipDeviceSynchronize();
@@ -91,9 +100,10 @@ int main() {
     };
     size_t layer_bytes = 0; for (size_t b : sizes) layer_bytes += b / (grid * NB * 4096) * (grid * NB * 4096);
     for (int rep = 0; rep < 3; ++rep) {
-        auto a = run(0); auto b = run(1);
-        printf("{\"layer_MB\": %.1f, \"serial_us_per_layer\": %.1f, \"serial_TBps\": %.2f, \"two_stream_flag_us_per_layer\": %.1f, \"two_stream_TBps\": %.2f, \"flag_timeouts\": %d}\n",
-               layer_bytes / 1e6, a.first, layer_bytes / a.first / 1e6, b.first, layer_bytes / b.first / 1e6, b.second);
+        auto a = run(0); auto b = run(1); auto c = run(2);
+        printf("{\"layer_MB\": %.1f, \"serial_us_per_layer\": %.1f, \"serial_TBps\": %.2f, \"two_stream_flag_us_per_layer\": %.1f, \"two_stream_TBps\": %.2f, \"flag_timeouts\": %d, "
+               "\"two_stream_independent_us_per_layer\": %.1f}\n",
+               layer_bytes / 1e6, a.first, layer_bytes / a.first / 1e6, b.first, layer_bytes / b.first / 1e6, b.second, c.first);
     }
     return 0;
 }
