@@ -18,7 +18,7 @@ typedef __attribute__((ext_vector_type(4))) uint32_t u32x4;
 
 constexpr int NB = 16;                                   // 16-byte loads per lane and batch (two register stages of 8 in the real kernels)
 __global__ void __launch_bounds__(256) stream_launch(const char* w, size_t bytes, const int* wait_flag, int expect, int* set_flag, uint32_t* sink,
-                                                     int* timeouts, int variant) {
+                                                     int* timeouts, int variant, int* relay, int epoch, int* relay_set) {
     const int tid = threadIdx.x;
     const size_t per_block = bytes / gridDim.x;           // contiguous slice per workgroup, walked in batches of NB x 4 KiB
     const char* p = w + (size_t)blockIdx.x * per_block + tid * 16;
@@ -32,9 +32,27 @@ __global__ void __launch_bounds__(256) stream_launch(const char* w, size_t bytes
     if (wait_flag != nullptr) {
         if (tid == 0) {
             int spins = 0;
-            while (__hip_atomic_load(wait_flag, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) < expect) {
-                if (variant & 4) __builtin_amdgcn_s_sleep(64); else __builtin_amdgcn_s_sleep(4);
-                if (++spins > (1 << 20)) { atomicAdd(timeouts, 1); break; }                       // never hang the box
+            if (variant & 8) {
+                // two levels: 8 leader workgroups poll the arrival counter and each raises one relay word (256 B apart: its own memory
+                // channel); everybody else polls the relay word of its group - 8 pollers on the hot word instead of 512
+                int* relay_w = relay + (blockIdx.x & 7) * 64;
+                if (blockIdx.x < 8) {
+                    while (__hip_atomic_load(wait_flag, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) < expect) {
+                        __builtin_amdgcn_s_sleep(2);
+                        if (++spins > (1 << 20)) { atomicAdd(timeouts, 1); break; }
+                    }
+                    __hip_atomic_store(relay_w, epoch, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                } else {
+                    while (__hip_atomic_load(relay_w, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) < epoch) {
+                        __builtin_amdgcn_s_sleep(4);
+                        if (++spins > (1 << 20)) { atomicAdd(timeouts, 1); break; }
+                    }
+                }
+            } else {
+                while (__hip_atomic_load(wait_flag, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) < expect) {
+                    if (variant & 4) __builtin_amdgcn_s_sleep(64); else __builtin_amdgcn_s_sleep(4);
+                    if (++spins > (1 << 20)) { atomicAdd(timeouts, 1); break; }                   // never hang the box
+                }
             }
         }
         __syncthreads();
@@ -53,15 +71,25 @@ __global__ void __launch_bounds__(256) stream_launch(const char* w, size_t bytes
     }
     if ((acc.x ^ acc.y ^ acc.z ^ acc.w) == 0x12345678u) sink[0] = 1;
     __syncthreads();
-    if (tid == 0 && set_flag != nullptr) __hip_atomic_fetch_add(set_flag, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    if (tid == 0 && set_flag != nullptr) {
+        if (variant & 16) {
+            // hierarchical arrival: 8 group counters (256 B apart); the last arriver of a group adds the group's size to the launch's counter
+            int* grp = relay_set + 8 * 64 + (blockIdx.x & 7) * 64;
+            const int per = gridDim.x / 8;
+            if (__hip_atomic_fetch_add(grp, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) == per - 1)
+                __hip_atomic_fetch_add(set_flag, per, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        } else {
+            __hip_atomic_fetch_add(set_flag, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        }
+    }
 }
 
 int main(int argc, char** argv) {
-    const int variant = argc > 1 ? atoi(argv[1]) : 0;     // bit 0: no prefetch before the wait; bit 1: wait for the FIRST arrival only; bit 2: long poll sleep
+    const int variant = argc > 1 ? atoi(argv[1]) : 0;     // bit 0: no prefetch before the wait; bit 1: wait for the FIRST arrival only; bit 2: long poll sleep; bit 3: two-level poll (8 leaders + relay words); bit 4: hierarchical arrival (8 group counters)
     const size_t pool = (size_t)4 << 30;
     char* buf; hipMalloc(&buf, pool); hipMemset(buf, 1, pool);
     uint32_t* sink; hipMalloc(&sink, 4);
-    int *flags, *timeouts; hipMalloc(&flags, 4096 * 4); hipMalloc(&timeouts, 4);
+    int *flags, *timeouts, *relay; hipMalloc(&flags, 4096 * 4); hipMalloc(&timeouts, 4); hipMalloc(&relay, 4096 * 1024 * 4);
     hipStream_t s[2]; hipStreamCreateWithFlags(&s[0], hipStreamNonBlocking); hipStreamCreateWithFlags(&s[1], hipStreamNonBlocking);
     // a 7B decoder layer's five launches: qkv 100 MB, (attention: 21 MB of K/V), o 33.5, gate/up 180, down 90
     const size_t sizes[5] = {(size_t)100 << 20, (size_t)21 << 20, (size_t)33 << 20, (size_t)180 << 20, (size_t)90 << 20};
@@ -79,7 +107,7 @@ int main(int argc, char** argv) {
             size_t bytes = sizes[i % 5] / (grid * NB * 4096) * (grid * NB * 4096);
             if (off + bytes > pool) off = 0;
             const int* wf = (mode == 1 && i > 0) ? flags + (i - 1) : nullptr;      // mode 2: two streams, NO dependency at all (what the two queues alone cost)
-            hipLaunchKernelGGL(stream_launch, dim3(grid), dim3(256), 0, mode >= 1 ? s[i & 1] : s[0], buf + off, bytes, wf, (variant & 2) ? 1 : grid, flags + i, sink, timeouts, variant);
+            hipLaunchKernelGGL(stream_launch, dim3(grid), dim3(256), 0, mode >= 1 ? s[i & 1] : s[0], buf + off, bytes, wf, (variant & 2) ? 1 : grid, flags + i, sink, timeouts, variant, relay + (size_t)(i > 0 ? i - 1 : 0) * 1024, 1, relay + (size_t)i * 1024);
             off += bytes;
         }
         if (mode >= 1) { hipEventRecord(join, s[1]); hipStreamWaitEvent(s[0], join, 0); }
@@ -89,7 +117,7 @@ int main(int argc, char** argv) {
     };
     hipGraphExec_t ge[3] = {build(0), build(1), build(2)};
     auto run = [&](int mode) {
-        hipMemset(flags, 0, 4096 * 4); hipMemset(timeouts, 0, 4);
+        hipMemset(flags, 0, 4096 * 4); hipMemset(timeouts, 0, 4); hipMemset(relay, 0, 4096 * 1024 * 4);
         hipDeviceSynchronize();
         auto t0 = std::chrono::high_resolution_clock::now();
         hipGraphLaunch(ge[mode], s[0]);
