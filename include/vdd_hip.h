@@ -28,7 +28,7 @@
 extern "C" {
 #endif
 
-#define VDD_ABI_VERSION 2
+#define VDD_ABI_VERSION 3
 
 typedef enum vdd_status {
     VDD_OK = 0,
@@ -139,46 +139,53 @@ int vdd_add_diffusion_noise(const void* x, void* y, int64_t n, int dtype, float 
                             uint64_t offset, void* hip_stream);
 
 /* ---------------------------------------------------------------------------------------------
- * Branch-batched language-model step (all tensors bf16, device pointers, row-major).
+ * Branch-batched language-model step (device pointers, row-major).
  * These replace what the reference runs per branch and per token through HF's eager LlamaModel
  * (experiments/llava/model/language_model/llava_llama.py:88-103; vcd_sample.py:109,163,178):
  * rows of one call = (question, branch) pairs, so weights stream from HBM once per step.
+ *
+ * `dtype` (the argument in front of hip_stream of every model entry): VDD_BF16 or VDD_F16 - the storage type of EVERY 16-bit tensor
+ * of the call (activations, weights, KV caches); VDD_F32 is refused.  The reference runs the model in the checkpoint's dtype:
+ * fp16 in every released driver (experiments/llava/model/builder.py:40 `torch_dtype=torch.float16`, llava_calibrate.py:163
+ * `.half().cuda()`), bf16 in BASELINE config #2.  Accumulation is fp32 for both; "bf16(...)" in the comments below marks a
+ * round-to-nearest-even to the call's dtype (where the eager torch op of the reference rounds).  Both instantiations are the same
+ * source compiled per storage type (csrc/vdd_elem.h): same tile shapes, same summation orders, MFMA / dot opcodes of the type.
  * ------------------------------------------------------------------------------------------- */
 
 /* h = x (+ delta); resid_out = h (optional); y = bf16(bf16(h * rsqrt(mean h^2 + eps)) * w).  d % 8 == 0, d <= 8192.
  * delta is either bf16 [M, d] or, as delta_slabs, the n_slabs fp32 split-K partials [n_slabs][M][d] of vdd_skinny_gemm
  * (summed, rounded to bf16, then added - the same roundings as a bf16 GEMM output followed by the residual add). */
 int vdd_rmsnorm(const void* x, const void* delta, const float* delta_slabs, int n_slabs, const void* w, void* y, void* resid_out,
-                int M, int d, float eps, void* hip_stream);
+                int M, int d, float eps, int dtype, void* hip_stream);
 
 /* qkv [M, (Hq+2Hkv)*D] -> q_out [M, Hq, D] with rotary embedding at pos[row] (HF rotate_half pairing;
  * cos_sin fp32 [max_pos, D/2, 2]); k (rotated) and v are written to cache[slot[row]][kv_head][cpos[row]][D]
  * (cpos = index inside the slot: pos for a prefix slot, pos - prefix_len for a compact own slot;
  * cache slot stride in elements; t_max tokens per slot). */
 int vdd_rope_kv_write(const void* qkv, const int* pos, const int* cpos, const int* slot, const float* cos_sin, void* q_out,
-                      void* k_cache, void* v_cache, int M, int Hq, int Hkv, int D, int64_t slot_stride, int t_max, void* hip_stream);
+                      void* k_cache, void* v_cache, int M, int Hq, int Hkv, int D, int64_t slot_stride, int t_max, int dtype, void* hip_stream);
 
 /* out[m, f] = silu(gate_up[m, f]) * gate_up[m, F + f]. */
-int vdd_silu_mul(const void* gate_up, void* out, int64_t M, int F, void* hip_stream);
+int vdd_silu_mul(const void* gate_up, void* out, int64_t M, int F, int dtype, void* hip_stream);
 
-int vdd_embed(const int64_t* ids, const void* table, void* out, int M, int d, int vocab, void* hip_stream);
+int vdd_embed(const int64_t* ids, const void* table, void* out, int M, int d, int vocab, int dtype, void* hip_stream);
 
 /* Token-embedding gather written straight into the packed prefill matrix: out[rows[m], :] = table[ids[m], :] (int32 ids and
  * rows; the splice of llava_arch.py:122-163 - text chunks embedded around the image features - without an intermediate
  * [M, d] tensor and an index_put). */
-int vdd_embed_scatter(const int32_t* ids, const int32_t* rows, const void* table, void* out, int M, int d, int vocab, void* hip_stream);
+int vdd_embed_scatter(const int32_t* ids, const int32_t* rows, const void* table, void* out, int M, int d, int vocab, int dtype, void* hip_stream);
 
 /* Y[M,N] = X[M,K] W[N,K]^T (+ R[M,N]); M <= 64, K % (128 * n_split) == 0; W is read from HBM exactly once.
  * n_split > 1 (with Y_slabs fp32 [n_split][M][N], Y may be NULL): split-K across blocks too; the slabs are summed by
  * vdd_rmsnorm's delta_slabs input.  With n_split = 1 and N <= 8192 (N = 4096 gives only 256 column blocks) a block runs eight
  * waves that split K eight ways inside it. */
 int vdd_skinny_gemm(const void* X, const void* W, const void* R, void* Y, float* Y_slabs, int n_split, int M, int N, int K,
-                    int64_t ldx, int64_t ldr, int64_t ldy, void* hip_stream);
+                    int64_t ldx, int64_t ldr, int64_t ldy, int dtype, void* hip_stream);
 
 /* act[M,F] = silu(X Wg^T) * (X Wu^T) for W_gate_up = [Wg; Wu] ([2F, K] row-major), M <= 16, K % 128 == 0: the gate/up
  * projection and SiLU*mul of the Llama MLP (HF LlamaMLP.forward [ext] under llava_llama.py:88-103) in one weight-streaming
  * launch; replaces vdd_skinny_gemm(N = 2F) + vdd_silu_mul with the same bf16 rounding points. */
-int vdd_skinny_swiglu(const void* X, const void* W_gate_up, void* act, int M, int F, int K, int64_t ldx, void* hip_stream);
+int vdd_skinny_swiglu(const void* X, const void* W_gate_up, void* act, int M, int F, int K, int64_t ldx, int dtype, void* hip_stream);
 
 /* Small-M (M <= 16: one or a few questions in flight, the reference's own B = 1 regime) fusion of the decoder layer's two RMSNorm
  * launches into the weight-streaming projections around them (HF LlamaDecoderLayer [ext] under llava_llama.py:88-103):
@@ -191,11 +198,11 @@ int vdd_skinny_swiglu(const void* X, const void* W_gate_up, void* act, int M, in
  *   vdd_skinny_swiglu_normed   the same input form for the gate/up projection + SiLU*mul (vdd_skinny_swiglu).
  * The partial sums are added in a fixed order (deterministic); same bf16 rounding points as vdd_rmsnorm + the plain projections. */
 int vdd_skinny_gemm_resid_ss(const void* X, const void* W, const void* R, void* Y, float* ss_out, int M, int N, int K, int64_t ldx,
-                             int64_t ldr, int64_t ldy, void* hip_stream);
+                             int64_t ldr, int64_t ldy, int dtype, void* hip_stream);
 int vdd_skinny_gemm_normed(const void* H, const float* ss, int nss, const void* ln_w, float eps, const void* W, void* Y, int M, int N,
-                           int K, int64_t ldh, int64_t ldy, void* hip_stream);
+                           int K, int64_t ldh, int64_t ldy, int dtype, void* hip_stream);
 int vdd_skinny_swiglu_normed(const void* H, const float* ss, int nss, const void* ln_w, float eps, const void* W_gate_up, void* act,
-                             int M, int F, int K, int64_t ldh, void* hip_stream);
+                             int M, int F, int K, int64_t ldh, int dtype, void* hip_stream);
 
 /* Row-batched projection GEMM, any M above the skinny regime (csrc/vdd_gemm.hip): Y[M,N] = epilogue(X[M,K] W[N,K]^T), bf16 in,
  * fp32 accumulate (32x32x16 MFMA, both operands LDS-DMA'd into swizzled LDS tiles, persistent stream-K over one workgroup
@@ -222,7 +229,7 @@ int vdd_skinny_swiglu_normed(const void* H, const float* ss, int nss, const void
 int64_t vdd_gemm_workspace_bytes(int M, int N);
 int vdd_gemm(const void* X, const void* W, void* Y, const void* bias, const void* resid, int M, int N, int K,
              int64_t ldx, int64_t ldw, int64_t ldy, int64_t ldr, int epilogue, int config, void* workspace, int64_t workspace_bytes,
-             void* hip_stream);
+             int dtype, void* hip_stream);
 
 /* One query per (row, head) over that row's KV: rows[m] = {slot, len, prefix_slot, prefix_len} (int32 x4);
  * tokens [0, prefix_len) are read from the PREFIX pool (k_prefix/v_prefix, slot prefix_slot, index t: a shared
@@ -232,7 +239,7 @@ int vdd_gemm(const void* X, const void* W, void* Y, const void* bias, const void
  * vdd_decode_attention_workspace_bytes(M, H, D, max_len) bytes, max_len >= every rows[m].len) and merged. */
 int vdd_decode_attention(const void* q, const void* k_cache, const void* v_cache, const void* k_prefix, const void* v_prefix,
                          const int32_t* rows, void* out, void* workspace, int M, int H, int Hkv, int D, int64_t slot_stride, int t_max,
-                         int64_t prefix_stride, int prefix_tmax, int max_len, float scale, void* hip_stream);
+                         int64_t prefix_stride, int prefix_tmax, int max_len, float scale, int dtype, void* hip_stream);
 int64_t vdd_decode_attention_workspace_bytes(int M, int H, int D, int max_len);
 
 /* Small-M decode attention with RoPE, the KV-cache write and the chunk merge fused into ONE launch (the reference's own
@@ -244,7 +251,7 @@ int64_t vdd_decode_attention_workspace_bytes(int M, int H, int D, int max_len);
 int vdd_decode_attention_fused(const void* qkv, const int32_t* pos, const int32_t* cpos, const int32_t* slot, const float* cos_sin,
                                void* k_cache, void* v_cache, const void* k_prefix, const void* v_prefix, const int32_t* rows, void* out,
                                int M, int H, int Hkv, int D, int64_t slot_stride, int t_max, int64_t prefix_stride, int prefix_tmax,
-                               float scale, void* stream);
+                               float scale, int dtype, void* hip_stream);
 
 /* The same launch with the old keys of every (row, head) cut into n_split (2 or 4) slices, one workgroup each: for one or two
  * questions in flight H x M workgroups leave most of the chip idle and each of them walks its context in three dependent fetch
@@ -256,7 +263,7 @@ int64_t vdd_decode_attention_fused_split_workspace_bytes(int M, int H, int n_spl
 int vdd_decode_attention_fused_split(const void* qkv, const int32_t* pos, const int32_t* cpos, const int32_t* slot, const float* cos_sin,
                                      void* k_cache, void* v_cache, const void* k_prefix, const void* v_prefix, const int32_t* rows, void* out,
                                      int M, int H, int Hkv, int D, int64_t slot_stride, int t_max, int64_t prefix_stride, int prefix_tmax,
-                                     float scale, void* workspace, int n_split, void* hip_stream);
+                                     float scale, void* workspace, int n_split, int dtype, void* hip_stream);
 
 /* Same result as vdd_decode_attention when every row with prefix_len > 0 is listed in exactly one group of rows
  * sharing (prefix_slot, prefix_len): groups[g] = {row_off, n_rows, prefix_slot, prefix_len} (int32 x4) indexes
@@ -273,14 +280,14 @@ int vdd_decode_attention_grouped(const void* q, const void* k_cache, const void*
                                  const int32_t* rows, const int32_t* groups, const int32_t* group_rows, const int32_t* items, int n_items,
                                  void* out, void* workspace, int M, int H, int Hkv, int D, int64_t slot_stride, int t_max,
                                  int64_t prefix_stride, int prefix_tmax, int max_prefix_len, int max_own_len,
-                                 int prefix_chunks_per_item, float scale, void* hip_stream);
+                                 int prefix_chunks_per_item, float scale, int dtype, void* hip_stream);
 
 /* Fragment-major copy of the prefix pool for the MFMA prefix pass: prefix_frag[slot][kv_head][chunk] = one 32-KiB block per
  * 64-key chunk (t_max % 64 == 0; twice the bytes and slot stride of k_prefix), 16 K fragments then 16 V^T fragments, each
  * the 1-KiB lane-linear image of one 16x16x32 MFMA operand; keys >= prefix_len_of_slot[slot] are zero-filled.  Built once
  * after the prefix prefill; every fragment load of the decode pass is then one contiguous KiB straight from HBM. */
 int vdd_prefix_fragments(const void* k_prefix, const void* v_prefix, void* prefix_frag, const int32_t* prefix_len_of_slot, int n_slots,
-                         int Hkv, int t_max, int D, void* hip_stream);
+                         int Hkv, int t_max, int D, int dtype, void* hip_stream);
 
 /* Prefill attention (MFMA, flash-style).  q/out [Ttot, H*D] packed by sequence; seqs[s] = {q_row0, Tq, pos0,
  * slot, prefix_slot, prefix_len} (int32 x6): query i of sequence s sits at position pos0+i and attends keys
@@ -290,7 +297,7 @@ int vdd_prefix_fragments(const void* k_prefix, const void* v_prefix, void* prefi
  * Replaces the eager attention of LlamaModel / CLIPVisionModel at step 0 (llava_arch.py:82-204). */
 int vdd_flash_attention(const void* q, const void* k_cache, const void* v_cache, const void* k_prefix, const void* v_prefix,
                         const int32_t* seqs, void* out, int n_seq, int max_tq, int H, int Hkv, int D, int64_t slot_stride, int t_max,
-                        int64_t prefix_stride, int prefix_tmax, float scale, int causal, void* hip_stream);
+                        int64_t prefix_stride, int prefix_tmax, float scale, int causal, int dtype, void* hip_stream);
 
 /* The same attention for SHORT sequences (Tq <= 32 each, causal, D = 128) that continue shared prefixes - the suffix pass of the
  * prefill: packs[p] = 4 sequence indices (int32 x4, -1 = none) with the SAME (prefix_slot, prefix_len); a workgroup takes one
@@ -298,26 +305,26 @@ int vdd_flash_attention(const void* q, const void* k_cache, const void* v_cache,
  * sequence after the other.  Same result as vdd_flash_attention on the same descriptors. */
 int vdd_flash_attention_packed(const void* q, const void* k_cache, const void* v_cache, const void* k_prefix, const void* v_prefix,
                                const int32_t* seqs, const int32_t* packs, void* out, int n_packs, int H, int Hkv, int D,
-                               int64_t slot_stride, int t_max, int64_t prefix_stride, int prefix_tmax, float scale, void* hip_stream);
+                               int64_t slot_stride, int t_max, int64_t prefix_stride, int prefix_tmax, float scale, int dtype, void* hip_stream);
 
 /* ViT front-end glue around the patch-embed GEMM (HF CLIPVisionEmbeddings / CLIPAttention as run by clip_encoder.py:39-51):
- * im2col of the stride-P patch convolution (images [n,3,S,S] of vdd_dtype `dtype` -> bf16 patches [n*(S/P)^2, Kp], zero
+ * im2col of the stride-P patch convolution (images [n,3,S,S] of vdd_dtype `image_dtype`: fp32 / fp16 / bf16 -> patches of the model `dtype` [n*(S/P)^2, Kp], zero
  * padded from 3*P*P to Kp columns); class token + position embeddings (h[i,t] = (t ? emb[i*(T-1)+t-1] : cls) + pos[t]);
  * the fused qkv projection [n*T, 3, H, D] split into q [n*T, H*D] and the K / V caches [image][H][t_max][D]. */
-int vdd_vit_im2col(const void* images, int dtype, void* patches, int n, int S, int P, int Kp, void* hip_stream);
-int vdd_vit_assemble(const void* emb, const void* cls, const void* pos, void* out, int n, int T, int width, void* hip_stream);
+int vdd_vit_im2col(const void* images, int image_dtype, void* patches, int n, int S, int P, int Kp, int dtype, void* hip_stream);
+int vdd_vit_assemble(const void* emb, const void* cls, const void* pos, void* out, int n, int T, int width, int dtype, void* hip_stream);
 int vdd_vit_qkv_split(const void* qkv, void* q, void* k_cache, void* v_cache, int n, int T, int H, int D, int64_t slot_stride, int t_max,
-                      int parts /* 3: [q,k,v]; 2: a fused [k,v] projection (cross-attention), q unused */, void* hip_stream);
+                      int parts /* 3: [q,k,v]; 2: a fused [k,v] projection (cross-attention), q unused */, int dtype, void* hip_stream);
 
 /* out = a + b elementwise (bf16, n % 8 == 0 elements): word + position embeddings of the InstructBLIP Q-Former's text input
  * (lavis Qformer.py:95-99). */
-int vdd_add(const void* a, const void* b, void* out, int64_t n, void* hip_stream);
+int vdd_add(const void* a, const void* b, void* out, int64_t n, int dtype, void* hip_stream);
 
 /* CLIP ViT LayerNorm (with bias); d % 8 == 0, d <= 4096. */
-int vdd_layernorm(const void* x, const void* w, const void* b, void* y, int M, int d, float eps, void* hip_stream);
+int vdd_layernorm(const void* x, const void* w, const void* b, void* y, int M, int d, float eps, int dtype, void* hip_stream);
 
 /* y = act(x + bias): act 0 none, 1 quick_gelu (CLIP MLP), 2 gelu-erf (mlp2x_gelu projector, builder.py:33-46). */
-int vdd_bias_act(const void* x, const void* bias, void* y, int64_t M, int d, int act, void* hip_stream);
+int vdd_bias_act(const void* x, const void* bias, void* y, int64_t M, int d, int act, int dtype, void* hip_stream);
 
 /* Most candidates (finite scores left after top-k) a row may keep for the exact top-p arithmetic. */
 int vdd_topp_exact_max(void);

@@ -34,8 +34,21 @@ def _headers():
     return deps
 
 
-def _obj_of(src):
-    return os.path.join(OBJ, os.path.basename(src)[:-4] + ".o")
+# the model kernels are compiled once per storage type (csrc/vdd_elem.h): -DVDD_ELEM = the vdd_dtype value
+PER_DTYPE = ("vdd_llm_kernels.hip", "vdd_prefill_kernels.hip", "vdd_gemm.hip")
+ELEMS = (("bf16", 2), ("f16", 1))
+
+
+def units():
+    """(source, object, extra flags) of every compilation unit."""
+    out = []
+    for src in sources():
+        base = os.path.basename(src)
+        if base in PER_DTYPE:
+            out += [(src, os.path.join(OBJ, f"{base[:-4]}.{tag}.o"), [f"-DVDD_ELEM={val}"]) for tag, val in ELEMS]
+        else:
+            out.append((src, os.path.join(OBJ, base[:-4] + ".o"), []))
+    return out
 
 
 def _stale(target, deps):
@@ -55,10 +68,11 @@ def build_lib(force: bool = False, verbose: bool = False) -> str:
     os.makedirs(os.path.dirname(LIB), exist_ok=True)
     os.makedirs(OBJ, exist_ok=True)
     cc, hdrs = hipcc(), _headers()
-    todo = [s for s in sources() if force or _stale(_obj_of(s), [s] + hdrs)]
+    todo = [u for u in units() if force or _stale(u[1], [u[0]] + hdrs)]
 
-    def compile_one(src):
-        cmd = [cc, *CFLAGS, "-I", os.path.join(ROOT, "include"), "-I", CSRC, "-c", src, "-o", _obj_of(src)]
+    def compile_one(unit):
+        src, obj, extra = unit
+        cmd = [cc, *CFLAGS, *extra, "-I", os.path.join(ROOT, "include"), "-I", CSRC, "-c", src, "-o", obj]
         if verbose:
             print(" ".join(cmd), flush=True)
         subprocess.run(cmd, check=True)
@@ -66,7 +80,7 @@ def build_lib(force: bool = False, verbose: bool = False) -> str:
     with ThreadPoolExecutor(max_workers=max(1, min(len(todo), os.cpu_count() or 1))) as ex:
         list(ex.map(compile_one, todo))
     # objects of sources that no longer exist must not be linked
-    keep = {_obj_of(s) for s in sources()}
+    keep = {u[1] for u in units()}
     for f in os.listdir(OBJ):
         if os.path.join(OBJ, f) not in keep:
             os.remove(os.path.join(OBJ, f))

@@ -6,7 +6,7 @@ import ctypes as C
 import os
 
 PKG = os.path.dirname(os.path.abspath(__file__))
-ABI_VERSION = 2
+ABI_VERSION = 3
 
 VDD_F32, VDD_F16, VDD_BF16 = 0, 1, 2
 PICK_ARGMAX, CUTOFF_F32_SCALAR, TEMP_RECIPROCAL, NO_SAMPLE, TOPP_FP32_MASS = 1, 2, 4, 8, 16

@@ -69,15 +69,15 @@ PAD_D = 128                       # head width the attention kernel runs EVA's h
 
 
 class BlipWeights:
-    """bf16 device tensors under LAVIS's parameter names (`visual_encoder.*`, `ln_vision.*`, `Qformer.bert.*`, `query_tokens`,
+    """Device tensors of one 16-bit dtype (bf16, or fp16 as LAVIS loads the checkpoint) under LAVIS's parameter names (`visual_encoder.*`, `ln_vision.*`, `Qformer.bert.*`, `query_tokens`,
     `llm_proj.*`) plus the derived, head-padded attention weights of the ViT (`vit{i}.wqkv/bqkv/wo`)."""
 
-    def __init__(self, cfg: BlipConfig, device):
-        self.cfg, self.device = cfg, torch.device(device)
+    def __init__(self, cfg: BlipConfig, device, dtype=torch.bfloat16):
+        self.cfg, self.device, self.dtype = cfg, torch.device(device), dtype
         self.t: Dict[str, torch.Tensor] = {}
 
     @staticmethod
-    def random(cfg: BlipConfig, device, seed: int = 0, std: float = 0.02) -> "BlipWeights":
+    def random(cfg: BlipConfig, device, seed: int = 0, std: float = 0.02, dtype=torch.bfloat16) -> "BlipWeights":
         g = torch.Generator(device=device).manual_seed(seed)
         rnd = lambda *s, sc=std: torch.randn(*s, device=device, generator=g, dtype=torch.float32) * sc
         one = lambda n: 1.0 + torch.randn(n, device=device, generator=g) * 0.02
@@ -117,11 +117,11 @@ class BlipWeights:
                 sd[p + f"output{suf}.dense.weight"], sd[p + f"output{suf}.dense.bias"] = rnd(q.hidden, q.inter), rnd(q.hidden)
                 sd[p + f"output{suf}.LayerNorm.weight"], sd[p + f"output{suf}.LayerNorm.bias"] = one(q.hidden), rnd(q.hidden)
         sd["llm_proj.weight"], sd["llm_proj.bias"] = rnd(cfg.d_llm, q.hidden), rnd(cfg.d_llm)
-        return BlipWeights.from_state_dict(cfg, sd, device)
+        return BlipWeights.from_state_dict(cfg, sd, device, dtype)
 
     @staticmethod
     def from_state_dict(cfg: BlipConfig, sd: Dict[str, torch.Tensor], device, dtype=torch.bfloat16) -> "BlipWeights":
-        w = BlipWeights(cfg, device)
+        w = BlipWeights(cfg, device, dtype)
         v = cfg.vit
         for k, t in sd.items():
             w.t[k] = t.detach().to(device=device, dtype=dtype).contiguous()
@@ -166,7 +166,7 @@ class InstructBlipFrontEnd:
     def _kv(self, key, n, H, T, D):
         c = self._cache.get(key)
         if c is None or c[0].shape[0] < n or c[0].shape[2] < T:
-            mk = lambda: torch.zeros(n, H, T, D, dtype=torch.bfloat16, device=self.device)
+            mk = lambda: torch.zeros(n, H, T, D, dtype=self.w.dtype, device=self.device)
             c = self._cache[key] = (mk(), mk())
         return c
 
@@ -179,7 +179,7 @@ class InstructBlipFrontEnd:
         if x.dtype not in (torch.float32, torch.float16, torch.bfloat16):
             x = x.float()
         T, H = v.n_tokens, v.heads
-        patches = ops.vit_im2col(x.contiguous(), v.patch, t["vit.patch"].shape[1])
+        patches = ops.vit_im2col(x.contiguous(), v.patch, t["vit.patch"].shape[1], dtype=self.w.dtype)
         emb = ops.gemm(patches, t["vit.patch"], bias=t["visual_encoder.patch_embed.proj.bias"], epi=ops.EPI_BIAS)
         h = ops.vit_assemble(emb, t["vit.cls"], t["vit.pos"], n, T)
         kc, vc = self._kv("vit", n, H, T, PAD_D)

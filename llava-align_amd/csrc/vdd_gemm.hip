@@ -41,24 +41,17 @@
 
 #include <type_traits>
 
-#include "vdd_hip.h"
+#include "vdd_elem.h"
 
 namespace {
+namespace VDD_ELEM_NS {
+using namespace vdd_elem;
 
-typedef __attribute__((ext_vector_type(8))) __bf16 bf16x8_t;
-typedef __attribute__((ext_vector_type(16))) float f32x16_t;
-typedef __attribute__((ext_vector_type(4))) __bf16 bf16x4_t;
-typedef __attribute__((ext_vector_type(4))) float f32x4_t;
+typedef ex8_t frag8_t;                                       // MFMA A / B operand in the element type of this instantiation
 typedef __attribute__((ext_vector_type(4))) uint32_t u32x4_t;
 typedef __attribute__((ext_vector_type(2))) uint32_t u32x2_t;
 typedef __attribute__((address_space(3))) void* lds_ptr_t;
 
-__device__ __forceinline__ float bf2f(uint32_t h) { return __builtin_bit_cast(float, h << 16); }
-__device__ __forceinline__ float rbf(float f) { return (float)(__bf16)f; }     // round to bf16 (RNE, v_cvt_pk_bf16_f32), keep as float
-__device__ __forceinline__ uint2 pack4(float a, float b, float c, float d) {
-    const f32x4_t v = {a, b, c, d};
-    return __builtin_bit_cast(uint2, __builtin_convertvector(v, bf16x4_t));
-}
 __device__ __forceinline__ float act_quick_gelu(float x) { return x / (1.f + __expf(-1.702f * x)); }
 __device__ __forceinline__ float act_gelu(float x) { return 0.5f * x * (1.f + erff(x * 0.70710678118654752440f)); }
 
@@ -218,18 +211,18 @@ __global__ void __launch_bounds__(WM * WN * 64) gemm_kernel(const GemmArgs a) {
                 if (with_reads && i < NRD) __builtin_amdgcn_sched_group_barrier(0x100, 1, 0);
             }
         };
-        bf16x8_t xg[4][MI], wg[4][NI];
+        frag8_t xg[4][MI], wg[4][NI];
         auto rd = [&](int buf, int kk) {
 #pragma unroll
-            for (int i = 0; i < NI; ++i) wg[kk][i] = *reinterpret_cast<const bf16x8_t*>(lds + buf * BUF + ((wrow + i * 4096) ^ (kk << 5)));
+            for (int i = 0; i < NI; ++i) wg[kk][i] = *reinterpret_cast<const frag8_t*>(lds + buf * BUF + ((wrow + i * 4096) ^ (kk << 5)));
 #pragma unroll
-            for (int i = 0; i < MI; ++i) xg[kk][i] = *reinterpret_cast<const bf16x8_t*>(lds + buf * BUF + ((xrow + i * 4096) ^ (kk << 5)));
+            for (int i = 0; i < MI; ++i) xg[kk][i] = *reinterpret_cast<const frag8_t*>(lds + buf * BUF + ((xrow + i * 4096) ^ (kk << 5)));
         };
         auto mm = [&](int kk) {
 #pragma unroll
             for (int i = 0; i < NI; ++i)
 #pragma unroll
-                for (int j = 0; j < MI; ++j) acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(wg[kk][i], xg[kk][j], acc[i][j], 0, 0, 0);
+                for (int j = 0; j < MI; ++j) acc[i][j] = mfma32(wg[kk][i], xg[kk][j], acc[i][j]);
         };
         if constexpr (NSTG == 3) {
             // The 64-row tile (a few dozen rows of activations): the launch is a stream of W through the CUs, 2 MFMAs per wave and
@@ -329,8 +322,8 @@ __global__ void __launch_bounds__(WM * WN * 64) gemm_kernel(const GemmArgs a) {
             auto gated = [&](int i, int j, int q, float (&o)[4]) {
 #pragma unroll
                 for (int e = 0; e < 4; ++e) {
-                    const float g = rbf(acc[i][j][q * 4 + e]), up = rbf(acc[i + 1][j][q * 4 + e]);
-                    o[e] = rbf(g / (1.f + __expf(-g))) * up;
+                    const float g = rnd(acc[i][j][q * 4 + e]), up = rnd(acc[i + 1][j][q * 4 + e]);
+                    o[e] = rnd(g / (1.f + __expf(-g))) * up;
                 }
             };
             if ((TN == 64) && a.stage_out) {       // 32 feature columns per wave: 64-byte rows through LDS, 16 rows per store instruction
@@ -374,18 +367,18 @@ __global__ void __launch_bounds__(WM * WN * 64) gemm_kernel(const GemmArgs a) {
                 for (int e = 0; e < 4; ++e) v[e] = acc[i][j][q * 4 + e];
                 if constexpr (EPI != EPI_NONE) {
                     const uint2 bb = *reinterpret_cast<const uint2*>(a.bias + n);
-                    v[0] += bf2f(bb.x & 0xffffu); v[1] += bf2f(bb.x >> 16); v[2] += bf2f(bb.y & 0xffffu); v[3] += bf2f(bb.y >> 16);
+                    v[0] += e2f(bb.x & 0xffffu); v[1] += e2f(bb.x >> 16); v[2] += e2f(bb.y & 0xffffu); v[3] += e2f(bb.y >> 16);
                 }
                 if constexpr (EPI == EPI_BIAS_QUICK_GELU) {
 #pragma unroll
-                    for (int e = 0; e < 4; ++e) v[e] = act_quick_gelu(rbf(v[e]));
+                    for (int e = 0; e < 4; ++e) v[e] = act_quick_gelu(rnd(v[e]));
                 } else if constexpr (EPI == EPI_BIAS_GELU) {
 #pragma unroll
-                    for (int e = 0; e < 4; ++e) v[e] = act_gelu(rbf(v[e]));
+                    for (int e = 0; e < 4; ++e) v[e] = act_gelu(rnd(v[e]));
                 } else if constexpr (EPI == EPI_BIAS_RESID) {
                     const uint2 rr = *reinterpret_cast<const uint2*>(a.resid + (size_t)m * a.ldr + n);
-                    v[0] = rbf(v[0]) + bf2f(rr.x & 0xffffu); v[1] = rbf(v[1]) + bf2f(rr.x >> 16);
-                    v[2] = rbf(v[2]) + bf2f(rr.y & 0xffffu); v[3] = rbf(v[3]) + bf2f(rr.y >> 16);
+                    v[0] = rnd(v[0]) + e2f(rr.x & 0xffffu); v[1] = rnd(v[1]) + e2f(rr.x >> 16);
+                    v[2] = rnd(v[2]) + e2f(rr.y & 0xffffu); v[3] = rnd(v[3]) + e2f(rr.y >> 16);
                 }
             };
             // Stored from the accumulator layout a quad is 8 bytes and a store instruction touches 32 rows: every 128-byte line of Y
@@ -518,17 +511,20 @@ int launch_cfg(const GemmArgs& a0, int epi, int sched, void* workspace, int64_t 
     return hipGetLastError() == hipSuccess ? VDD_OK : VDD_ERR_LAUNCH;
 }
 
+}  // namespace VDD_ELEM_NS
 }  // namespace
+
+using namespace VDD_ELEM_NS;
 
 extern "C" {
 
-int64_t vdd_gemm_workspace_bytes(int M, int N) {
+VDD_HIDDEN int64_t VDD_IMPL(vdd_gemm_workspace_bytes)(int M, int N) {
     // fixed counter region (up to 2^20 tiles per launch) + one 256 x 256 fp32 partial per workgroup; the same for every shape
     (void)M; (void)N;
     return (int64_t)COUNTER_BYTES + (int64_t)num_workgroups() * 256 * 256 * 4;
 }
 
-int vdd_gemm(const void* X, const void* W, void* Y, const void* bias, const void* resid, int M, int N, int K,
+VDD_HIDDEN int VDD_IMPL(vdd_gemm)(const void* X, const void* W, void* Y, const void* bias, const void* resid, int M, int N, int K,
              int64_t ldx, int64_t ldw, int64_t ldy, int64_t ldr, int epilogue, int config, void* workspace, int64_t workspace_bytes,
              void* stream) {
     if (M <= 0 || N <= 0) return VDD_OK;

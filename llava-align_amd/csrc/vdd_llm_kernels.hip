@@ -17,47 +17,37 @@
 #include <hip/hip_runtime.h>
 #include <stdint.h>
 
-#include "vdd_hip.h"
+#include "vdd_elem.h"
 
 namespace {
+namespace VDD_ELEM_NS {
+using namespace vdd_elem;
 
-typedef __attribute__((ext_vector_type(8))) short bf16x8_t;   // MFMA A/B fragment: 8 bf16
+typedef __attribute__((ext_vector_type(8))) short frag8_t;    // MFMA A/B fragment: 8 elements (bf16 or fp16 bit patterns)
 typedef __attribute__((ext_vector_type(4))) uint32_t u32x4_nt;
 typedef __attribute__((ext_vector_type(2))) uint32_t u32x2_t;
 // data that crosses the chip once (an activation read by one kernel, a cache line written for a later step): nontemporal, so it
 // takes no L2 line from data that IS re-read (the GEMMs' shared operand panels, the next GEMM's X)
 __device__ __forceinline__ uint4 ld_stream(const uint16_t* p) { return __builtin_bit_cast(uint4, __builtin_nontemporal_load(reinterpret_cast<const u32x4_nt*>(p))); }
 __device__ __forceinline__ void st_stream(uint16_t* p, uint4 v) { __builtin_nontemporal_store(__builtin_bit_cast(u32x4_nt, v), reinterpret_cast<u32x4_nt*>(p)); }
-typedef __attribute__((ext_vector_type(4))) float f32x4_t;    // MFMA C/D fragment
 // a weight fragment of the weight-streaming projections: every byte of W is read by ONE wave, once per launch
 #ifndef VDD_W_NT
 #define VDD_W_NT 0   // measured: nontemporal weight loads are SLOWER here (one-question layer chain 90.2 vs 84.8 us)
 #endif
-__device__ __forceinline__ bf16x8_t ld_w(const uint16_t* p) {
+__device__ __forceinline__ frag8_t ld_w(const uint16_t* p) {
 #if VDD_W_NT
-    return __builtin_nontemporal_load(reinterpret_cast<const bf16x8_t*>(p));
+    return __builtin_nontemporal_load(reinterpret_cast<const frag8_t*>(p));
 #else
-    return *reinterpret_cast<const bf16x8_t*>(p);
+    return *reinterpret_cast<const frag8_t*>(p);
 #endif
 }
 
-__device__ __forceinline__ float bf2f(uint32_t b) { return __builtin_bit_cast(float, b << 16); }
-__device__ __forceinline__ uint32_t f2bf(float f) {
-    uint32_t u = __builtin_bit_cast(uint32_t, f);
-    if ((u & 0x7fffffffu) > 0x7f800000u) return (u >> 16) | 0x40u;
-    return (u + 0x7fffu + ((u >> 16) & 1u)) >> 16;
-}
-__device__ __forceinline__ float lo(uint32_t w) { return bf2f(w & 0xFFFFu); }
-__device__ __forceinline__ float hi(uint32_t w) { return __builtin_bit_cast(float, w & 0xFFFF0000u); }
-__device__ __forceinline__ uint32_t pack(float a, float b) { return f2bf(a) | (f2bf(b) << 16); }
-
-typedef __attribute__((ext_vector_type(2))) __bf16 bf16x2_t;
-// q.k over 8 packed bf16 pairs with v_dot2c_f32_bf16 (fp32 accumulate; bf16 x bf16 products are exact in fp32)
+// q.k over 8 packed pairs with v_dot2c_f32_{bf16,f16} (fp32 accumulate; the 16-bit x 16-bit products are exact in fp32)
 __device__ __forceinline__ float dot8(const uint4& a, const uint4& b) {
-    float s = __builtin_amdgcn_fdot2_f32_bf16(__builtin_bit_cast(bf16x2_t, a.x), __builtin_bit_cast(bf16x2_t, b.x), 0.f, false);
-    s = __builtin_amdgcn_fdot2_f32_bf16(__builtin_bit_cast(bf16x2_t, a.y), __builtin_bit_cast(bf16x2_t, b.y), s, false);
-    s = __builtin_amdgcn_fdot2_f32_bf16(__builtin_bit_cast(bf16x2_t, a.z), __builtin_bit_cast(bf16x2_t, b.z), s, false);
-    s = __builtin_amdgcn_fdot2_f32_bf16(__builtin_bit_cast(bf16x2_t, a.w), __builtin_bit_cast(bf16x2_t, b.w), s, false);
+    float s = dot2(a.x, b.x, 0.f);
+    s = dot2(a.y, b.y, s);
+    s = dot2(a.z, b.z, s);
+    s = dot2(a.w, b.w, s);
     return s;
 }
 // One key of the online softmax for a 16-lane group: s is already reduced over the group.  The running maximum only
@@ -125,7 +115,7 @@ __global__ void __launch_bounds__(256) rmsnorm_kernel(const uint16_t* __restrict
                     dsum[0] += p0.x; dsum[1] += p0.y; dsum[2] += p0.z; dsum[3] += p0.w;
                     dsum[4] += p1.x; dsum[5] += p1.y; dsum[6] += p1.z; dsum[7] += p1.w;
                 }
-                auto addr = [&](uint32_t hv, float d0, float d1) { return pack(lo(hv) + bf2f(f2bf(d0)), hi(hv) + bf2f(f2bf(d1))); };
+                auto addr = [&](uint32_t hv, float d0, float d1) { return pack(lo(hv) + e2f(f2e(d0)), hi(hv) + e2f(f2e(d1))); };
                 a.x = addr(a.x, dsum[0], dsum[1]); a.y = addr(a.y, dsum[2], dsum[3]);
                 a.z = addr(a.z, dsum[4], dsum[5]); a.w = addr(a.w, dsum[6], dsum[7]);
             }
@@ -146,7 +136,7 @@ __global__ void __launch_bounds__(256) rmsnorm_kernel(const uint16_t* __restrict
         if (e < d) {
             uint4 a = h[i], g = wv[i], o;
             auto nrm = [&](uint32_t hv, uint32_t gv) {
-                float n0 = bf2f(f2bf(lo(hv) * rstd)), n1 = bf2f(f2bf(hi(hv) * rstd));
+                float n0 = e2f(f2e(lo(hv) * rstd)), n1 = e2f(f2e(hi(hv) * rstd));
                 return pack(n0 * lo(gv), n1 * hi(gv));
             };
             o.x = nrm(a.x, g.x); o.y = nrm(a.y, g.y); o.z = nrm(a.z, g.z); o.w = nrm(a.w, g.w);
@@ -243,7 +233,7 @@ __global__ void __launch_bounds__(256) silu_mul_kernel(const uint16_t* __restric
     const uint4 u = *reinterpret_cast<const uint4*>(gu + m * 2 * F + F + f);
     auto act = [](uint32_t gv, uint32_t uv) {
         const float g0 = lo(gv), g1 = hi(gv);
-        const float s0 = bf2f(f2bf(g0 / (1.f + __expf(-g0)))), s1 = bf2f(f2bf(g1 / (1.f + __expf(-g1))));
+        const float s0 = e2f(f2e(g0 / (1.f + __expf(-g0)))), s1 = e2f(f2e(g1 / (1.f + __expf(-g1))));
         return pack(s0 * lo(uv), s1 * hi(uv));
     };
     uint4 o; o.x = act(g.x, u.x); o.y = act(g.y, u.y); o.z = act(g.z, u.z); o.w = act(g.w, u.w);
@@ -291,14 +281,11 @@ __global__ void __launch_bounds__(256) embed_scatter_kernel(const int* __restric
 //          bf16(bf16(h * rstd) * ln_w[k]) - the roundings of rmsnorm_kernel.
 struct NormIn { const float* ss; int nss; const uint16_t* lnw; float eps; };
 
-typedef __attribute__((ext_vector_type(2))) __bf16 bf16x2_hw;
 typedef __attribute__((ext_vector_type(2))) float f32x2_hw;
-// two bf16 (packed in a dword) -> bf16(bf16(h * rstd) * g) with the hardware's RNE pack conversion (v_cvt_pk_bf16_f32)
+// two elements (packed in a dword) -> rnd(rnd(h * rstd) * g) with the hardware's RNE pack conversion (v_cvt_pk_bf16_f32 / v_cvt_pk_f16_f32)
 __device__ __forceinline__ uint32_t norm_pair(uint32_t hv, uint32_t gv, float rstd) {
-    const f32x2_hw n = {lo(hv) * rstd, hi(hv) * rstd};
-    const uint32_t nb = __builtin_bit_cast(uint32_t, __builtin_convertvector(n, bf16x2_hw));
-    const f32x2_hw o = {lo(nb) * lo(gv), hi(nb) * hi(gv)};
-    return __builtin_bit_cast(uint32_t, __builtin_convertvector(o, bf16x2_hw));
+    const uint32_t nb = cvt_pk(lo(hv) * rstd, hi(hv) * rstd);
+    return cvt_pk(lo(nb) * lo(gv), hi(nb) * hi(gv));
 }
 __device__ __forceinline__ uint4 norm_chunk(uint4 a, uint4 w, float rstd) {
     return make_uint4(norm_pair(a.x, w.x, rstd), norm_pair(a.y, w.y, rstd), norm_pair(a.z, w.z, rstd), norm_pair(a.w, w.w, rstd));
@@ -347,8 +334,8 @@ __global__ void __launch_bounds__(NW * 64) skinny_normed_kernel(const uint16_t* 
         if constexpr (SWIGLU) { int f = cb * 8 + (ln & 7); if (f >= N) f = N - 1; return W + ((size_t)(ln < 8 ? 0 : N) + f) * K + kbeg + g * 8; }
         else { int nrow = cb * 16 + ln; if (nrow >= N) nrow = N - 1; return W + (size_t)nrow * K + kbeg + g * 8; }
     };
-    bf16x8_t b0[U], b1[U];
-    auto ldw = [&](bf16x8_t (&b)[U], const uint16_t* wp, int i) {
+    frag8_t b0[U], b1[U];
+    auto ldw = [&](frag8_t (&b)[U], const uint16_t* wp, int i) {
         const int kk = i * 32 * U;
         if (ragged && i == nb - 1) {
 #pragma unroll
@@ -431,20 +418,20 @@ __global__ void __launch_bounds__(NW * 64) skinny_normed_kernel(const uint16_t* 
     int rr = ln; if (rr >= M) rr = M - 1;
     const unsigned char* xrow = xs + (size_t)rr * rstride;
     const int xk0 = (kbeg + g * 8) * 2, xsw = (rr & 15) << 4;
-    auto xfrag = [&](int k) { return *reinterpret_cast<const bf16x8_t*>(xrow + ((xk0 + k * 2) ^ xsw)); };
-    auto mm = [&](const bf16x8_t (&b)[U], int i, f32x4_t& acc) {
+    auto xfrag = [&](int k) { return *reinterpret_cast<const frag8_t*>(xrow + ((xk0 + k * 2) ^ xsw)); };
+    auto mm = [&](const frag8_t (&b)[U], int i, f32x4_t& acc) {
         const int kk = i * 32 * U;
         if (ragged && i == nb - 1) {
-            const bf16x8_t zero = {0, 0, 0, 0, 0, 0, 0, 0};
+            const frag8_t zero = {0, 0, 0, 0, 0, 0, 0, 0};
 #pragma unroll
             for (int u = 0; u < U; ++u) {
                 const bool in = kk + 32 * u < kq;
-                acc = __builtin_amdgcn_mfma_f32_16x16x32_bf16(xfrag(in ? kk + 32 * u : kk), in ? b[u] : zero, acc, 0, 0, 0);
+                acc = mfma16(xfrag(in ? kk + 32 * u : kk), in ? b[u] : zero, acc);
             }
         } else {
 #pragma unroll
             for (int u = 0; u < U; ++u)
-                acc = __builtin_amdgcn_mfma_f32_16x16x32_bf16(xfrag(kk + 32 * u), b[u], acc, 0, 0, 0);
+                acc = mfma16(xfrag(kk + 32 * u), b[u], acc);
         }
         __builtin_amdgcn_sched_barrier(0);
     };
@@ -481,9 +468,9 @@ __global__ void __launch_bounds__(NW * 64) skinny_normed_kernel(const uint16_t* 
                     us = (part[0][lu][q] + part[1][lu][q]) + (part[2][lu][q] + part[3][lu][q]);
                     if constexpr (NW == 8) { gs += (part[4][lg][q] + part[5][lg][q]) + (part[6][lg][q] + part[7][lg][q]);
                                              us += (part[4][lu][q] + part[5][lu][q]) + (part[6][lu][q] + part[7][lu][q]); }
-                    const float gb = bf2f(f2bf(gs)), ub = bf2f(f2bf(us));
-                    const float sl = bf2f(f2bf(gb / (1.f + __expf(-gb))));
-                    Y[(size_t)row * ldy + cb * 8 + c] = (uint16_t)f2bf(sl * ub);
+                    const float gb = e2f(f2e(gs)), ub = e2f(f2e(us));
+                    const float sl = e2f(f2e(gb / (1.f + __expf(-gb))));
+                    Y[(size_t)row * ldy + cb * 8 + c] = (uint16_t)f2e(sl * ub);
                 }
             }
         } else {
@@ -493,7 +480,7 @@ __global__ void __launch_bounds__(NW * 64) skinny_normed_kernel(const uint16_t* 
                     const int row = g * 4 + r, col = cb * 16 + ln;
                     float sacc = (part[0][lane][r] + part[1][lane][r]) + (part[2][lane][r] + part[3][lane][r]);
                     if constexpr (NW == 8) sacc += (part[4][lane][r] + part[5][lane][r]) + (part[6][lane][r] + part[7][lane][r]);
-                    if (row < M && col < N) Y[(size_t)row * ldy + col] = (uint16_t)f2bf(sacc);
+                    if (row < M && col < N) Y[(size_t)row * ldy + col] = (uint16_t)f2e(sacc);
                 }
             }
         }
@@ -528,32 +515,32 @@ __global__ void __launch_bounds__(NW * 64) skinny_gemm_kernel(const uint16_t* __
     // one-question step is a chain of these launches: see DESIGN.md section 5).  Same MFMAs in the same order.
     constexpr int U = 8;
     const int nit = kq / (32 * U);
-    bf16x8_t b0[U], a0[U][MT], b1[U], a1[U][MT];
+    frag8_t b0[U], a0[U][MT], b1[U], a1[U][MT];
     constexpr int UG = NORM ? U : 1;
-    bf16x8_t g0[UG], g1[UG];                             // NORM: the ln weights of a batch's k positions
+    frag8_t g0[UG], g1[UG];                             // NORM: the ln weights of a batch's k positions
     const uint16_t* gp = NORM ? ni.lnw + kbeg + g * 8 : nullptr;
     float rstd = 1.f;
-    auto ld = [&](bf16x8_t (&b)[U], bf16x8_t (&a)[U][MT], bf16x8_t (&gw)[UG], int kk) {
+    auto ld = [&](frag8_t (&b)[U], frag8_t (&a)[U][MT], frag8_t (&gw)[UG], int kk) {
 #pragma unroll
         for (int u = 0; u < U; ++u) b[u] = ld_w(wp + (size_t)(kk + 32 * u) * WS);
 #pragma unroll
         for (int u = 0; u < U; ++u)
 #pragma unroll
-            for (int t = 0; t < MT; ++t) a[u][t] = *reinterpret_cast<const bf16x8_t*>(xp[t] + kk + 32 * u);
+            for (int t = 0; t < MT; ++t) a[u][t] = *reinterpret_cast<const frag8_t*>(xp[t] + kk + 32 * u);
         if constexpr (NORM) {
 #pragma unroll
-            for (int u = 0; u < U; ++u) gw[u] = *reinterpret_cast<const bf16x8_t*>(gp + kk + 32 * u);
+            for (int u = 0; u < U; ++u) gw[u] = *reinterpret_cast<const frag8_t*>(gp + kk + 32 * u);
         }
         __builtin_amdgcn_sched_barrier(0);
     };
-    auto mm = [&](const bf16x8_t (&b)[U], const bf16x8_t (&a)[U][MT], const bf16x8_t (&gw)[UG]) {
+    auto mm = [&](const frag8_t (&b)[U], const frag8_t (&a)[U][MT], const frag8_t (&gw)[UG]) {
 #pragma unroll
         for (int u = 0; u < U; ++u)
 #pragma unroll
             for (int t = 0; t < MT; ++t) {
-                bf16x8_t av = a[u][t];
-                if constexpr (NORM) av = __builtin_bit_cast(bf16x8_t, norm_chunk(__builtin_bit_cast(uint4, av), __builtin_bit_cast(uint4, gw[u]), rstd));
-                acc[t] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(av, b[u], acc[t], 0, 0, 0);
+                frag8_t av = a[u][t];
+                if constexpr (NORM) av = __builtin_bit_cast(frag8_t, norm_chunk(__builtin_bit_cast(uint4, av), __builtin_bit_cast(uint4, gw[u]), rstd));
+                acc[t] = mfma16(av, b[u], acc[t]);
             }
         __builtin_amdgcn_sched_barrier(0);
     };
@@ -581,14 +568,14 @@ __global__ void __launch_bounds__(NW * 64) skinny_gemm_kernel(const uint16_t* __
     // load -> MFMA is a chain of memory round trips at the end of every block
     const int krem = nit * 32 * U;
     if (krem < kq) {
-        const bf16x8_t zero = {0, 0, 0, 0, 0, 0, 0, 0};
+        const frag8_t zero = {0, 0, 0, 0, 0, 0, 0, 0};
 #pragma unroll
         for (int u = 0; u < U; ++u) {
             const int kk = krem + 32 * u, kc = kk < kq ? kk : krem;
             b0[u] = ld_w(wp + (size_t)kc * WS);
 #pragma unroll
-            for (int t = 0; t < MT; ++t) a0[u][t] = *reinterpret_cast<const bf16x8_t*>(xp[t] + kc);
-            if constexpr (NORM) g0[u] = *reinterpret_cast<const bf16x8_t*>(gp + kc);
+            for (int t = 0; t < MT; ++t) a0[u][t] = *reinterpret_cast<const frag8_t*>(xp[t] + kc);
+            if constexpr (NORM) g0[u] = *reinterpret_cast<const frag8_t*>(gp + kc);
         }
         __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
@@ -610,11 +597,11 @@ __global__ void __launch_bounds__(NW * 64) skinny_gemm_kernel(const uint16_t* __
             float sq = 0.f;
             if (row < M && col < N) {
                 if (Yslab != nullptr) { Yslab[((size_t)blockIdx.y * M + row) * N + col] = s; continue; }
-                float o = bf2f(f2bf(s));
-                if (R != nullptr) o = o + bf2f(MT == 1 ? rpre[r] : R[(size_t)row * ldr + col]);
-                const uint32_t ob = f2bf(o);
+                float o = e2f(f2e(s));
+                if (R != nullptr) o = o + e2f(MT == 1 ? rpre[r] : R[(size_t)row * ldr + col]);
+                const uint32_t ob = f2e(o);
                 Y[(size_t)row * ldy + col] = (uint16_t)ob;
-                if constexpr (SSOUT) { const float h = bf2f(ob); sq = h * h; }
+                if constexpr (SSOUT) { const float h = e2f(ob); sq = h * h; }
             }
             if constexpr (SSOUT) {      // the 16 lanes ln = 0..15 of a lane group hold the block's 16 columns of one row
                 sq += __shfl_xor(sq, 1); sq += __shfl_xor(sq, 2); sq += __shfl_xor(sq, 4); sq += __shfl_xor(sq, 8);
@@ -645,28 +632,28 @@ __global__ void __launch_bounds__(256) skinny_swiglu_kernel(const uint16_t* __re
     f32x4_t acc = f32x4_t{0.f, 0.f, 0.f, 0.f};
     constexpr int U = 8;             // two register stages, as in skinny_gemm_kernel
     const int nit = kq / (32 * U);
-    bf16x8_t b0[U], a0[U], b1[U], a1[U];
+    frag8_t b0[U], a0[U], b1[U], a1[U];
     constexpr int UG = NORM ? U : 1;
-    bf16x8_t g0[UG], g1[UG];
+    frag8_t g0[UG], g1[UG];
     const uint16_t* gp = NORM ? ni.lnw + kbeg + g * 8 : nullptr;
     float rstd = 1.f;
-    auto ld = [&](bf16x8_t (&b)[U], bf16x8_t (&a)[U], bf16x8_t (&gw)[UG], int kk) {
+    auto ld = [&](frag8_t (&b)[U], frag8_t (&a)[U], frag8_t (&gw)[UG], int kk) {
 #pragma unroll
         for (int u = 0; u < U; ++u) b[u] = ld_w(wp + (size_t)(kk + 32 * u) * WS);
 #pragma unroll
-        for (int u = 0; u < U; ++u) a[u] = *reinterpret_cast<const bf16x8_t*>(xp + kk + 32 * u);
+        for (int u = 0; u < U; ++u) a[u] = *reinterpret_cast<const frag8_t*>(xp + kk + 32 * u);
         if constexpr (NORM) {
 #pragma unroll
-            for (int u = 0; u < U; ++u) gw[u] = *reinterpret_cast<const bf16x8_t*>(gp + kk + 32 * u);
+            for (int u = 0; u < U; ++u) gw[u] = *reinterpret_cast<const frag8_t*>(gp + kk + 32 * u);
         }
         __builtin_amdgcn_sched_barrier(0);
     };
-    auto mm = [&](const bf16x8_t (&b)[U], const bf16x8_t (&a)[U], const bf16x8_t (&gw)[UG]) {
+    auto mm = [&](const frag8_t (&b)[U], const frag8_t (&a)[U], const frag8_t (&gw)[UG]) {
 #pragma unroll
         for (int u = 0; u < U; ++u) {
-            bf16x8_t av = a[u];
-            if constexpr (NORM) av = __builtin_bit_cast(bf16x8_t, norm_chunk(__builtin_bit_cast(uint4, av), __builtin_bit_cast(uint4, gw[u]), rstd));
-            acc = __builtin_amdgcn_mfma_f32_16x16x32_bf16(av, b[u], acc, 0, 0, 0);
+            frag8_t av = a[u];
+            if constexpr (NORM) av = __builtin_bit_cast(frag8_t, norm_chunk(__builtin_bit_cast(uint4, av), __builtin_bit_cast(uint4, gw[u]), rstd));
+            acc = mfma16(av, b[u], acc);
         }
         __builtin_amdgcn_sched_barrier(0);
     };
@@ -682,9 +669,9 @@ __global__ void __launch_bounds__(256) skinny_swiglu_kernel(const uint16_t* __re
     if (it < nit) mm(b0, a0, g0);
     int k = nit * 32 * U;
     for (; k < kq; k += 32) {
-        bf16x8_t a = *reinterpret_cast<const bf16x8_t*>(xp + k);
-        if constexpr (NORM) a = __builtin_bit_cast(bf16x8_t, norm_chunk(__builtin_bit_cast(uint4, a), *reinterpret_cast<const uint4*>(gp + k), rstd));
-        acc = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a, *reinterpret_cast<const bf16x8_t*>(wp + (size_t)k * WS), acc, 0, 0, 0);
+        frag8_t a = *reinterpret_cast<const frag8_t*>(xp + k);
+        if constexpr (NORM) a = __builtin_bit_cast(frag8_t, norm_chunk(__builtin_bit_cast(uint4, a), *reinterpret_cast<const uint4*>(gp + k), rstd));
+        acc = mfma16(a, *reinterpret_cast<const frag8_t*>(wp + (size_t)k * WS), acc);
     }
 #pragma unroll
     for (int rr = 0; rr < 4; ++rr) part[wave][lane][rr] = acc[rr];
@@ -696,9 +683,9 @@ __global__ void __launch_bounds__(256) skinny_swiglu_kernel(const uint16_t* __re
             const int lg = (row >> 2) * 16 + c, lu = lg + 8, rr = row & 3;
             const float gs = (part[0][lg][rr] + part[1][lg][rr]) + (part[2][lg][rr] + part[3][lg][rr]);
             const float us = (part[0][lu][rr] + part[1][lu][rr]) + (part[2][lu][rr] + part[3][lu][rr]);
-            const float gb = bf2f(f2bf(gs)), ub = bf2f(f2bf(us));
-            const float sl = bf2f(f2bf(gb / (1.f + __expf(-gb))));
-            A[(size_t)row * F + f0 + c] = (uint16_t)f2bf(sl * ub);
+            const float gb = e2f(f2e(gs)), ub = e2f(f2e(us));
+            const float sl = e2f(f2e(gb / (1.f + __expf(-gb))));
+            A[(size_t)row * F + f0 + c] = (uint16_t)f2e(sl * ub);
         }
     }
 }
@@ -1130,11 +1117,11 @@ __global__ void __launch_bounds__(256, 2) decode_attn_prefix_mfma_kernel(const u
     // B operand of S^T: this lane's query row
     int rq = r0 + ln; if (rq >= gd.n_rows) rq = gd.n_rows - 1;
     const int qrow = group_rows[gd.row_off + rq];
-    bf16x8_t qf[KS];
+    frag8_t qf[KS];
     {
         const uint16_t* qp = q + ((size_t)qrow * H + head) * D + g * 8;
 #pragma unroll
-        for (int ks = 0; ks < KS; ++ks) qf[ks] = *reinterpret_cast<const bf16x8_t*>(qp + ks * 32);
+        for (int ks = 0; ks < KS; ++ks) qf[ks] = *reinterpret_cast<const frag8_t*>(qp + ks * 32);
     }
     const uint16_t* fb = frag + 2 * ((size_t)gd.pslot * pre_stride + (size_t)kvh * pre_tmax * D) + (size_t)lane * 8;
     f32x4_t o[NT];
@@ -1152,16 +1139,16 @@ __global__ void __launch_bounds__(256, 2) decode_attn_prefix_mfma_kernel(const u
         // flight: ALL 32 fragment loads of the chunk are issued before the first MFMA.  Issued a few at a time behind their
         // consumers (as the compiler schedules them under a 128-VGPR cap) the pass ran at 4.2 TB/s with 1-2 loads in flight
         // per wave in its P V half.
-        bf16x8_t kf[4][KS], vf[2][NT];
+        frag8_t kf[4][KS], vf[2][NT];
         const uint16_t* cb = fb + (size_t)(k0 / ATT_CH) * FRAG_CHUNK_ELEMS;
 #pragma unroll
         for (int t = 0; t < 4; ++t)
 #pragma unroll
-            for (int ks = 0; ks < KS; ++ks) kf[t][ks] = __builtin_nontemporal_load(reinterpret_cast<const bf16x8_t*>(cb + (t * KS + ks) * 512));
+            for (int ks = 0; ks < KS; ++ks) kf[t][ks] = __builtin_nontemporal_load(reinterpret_cast<const frag8_t*>(cb + (t * KS + ks) * 512));
 #pragma unroll
         for (int kk = 0; kk < 2; ++kk)
 #pragma unroll
-            for (int nt = 0; nt < NT; ++nt) vf[kk][nt] = __builtin_nontemporal_load(reinterpret_cast<const bf16x8_t*>(cb + ATT_CH * D + (kk * NT + nt) * 512));
+            for (int nt = 0; nt < NT; ++nt) vf[kk][nt] = __builtin_nontemporal_load(reinterpret_cast<const frag8_t*>(cb + ATT_CH * D + (kk * NT + nt) * 512));
         __builtin_amdgcn_sched_barrier(0);
         // S^T: 4 tiles (a0, b0 | a1, b1); MFMA row i = ln of the A operand
         f32x4_t s[4];
@@ -1169,7 +1156,7 @@ __global__ void __launch_bounds__(256, 2) decode_attn_prefix_mfma_kernel(const u
         for (int t = 0; t < 4; ++t) {
             s[t] = f32x4_t{0.f, 0.f, 0.f, 0.f};
 #pragma unroll
-            for (int ks = 0; ks < KS; ++ks) s[t] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(kf[t][ks], qf[ks], s[t], 0, 0, 0);
+            for (int ks = 0; ks < KS; ++ks) s[t] = mfma16(kf[t][ks], qf[ks], s[t]);
         }
         // column = query ln; this lane's rows 4 g + r are keys k0 + 32 (t>>1) + 8 g + 4 (t&1) + r
         float mx = -INFINITY;
@@ -1185,14 +1172,14 @@ __global__ void __launch_bounds__(256, 2) decode_attn_prefix_mfma_kernel(const u
         const float mnew = fmaxf(mrun, mx);                      // finite: every chunk holds >= 1 valid key
         const float corr = __expf(mrun - mnew);                  // exp(-inf) = 0 on the first chunk
         float lsum = 0.f;
-        bf16x8_t pf[2];
+        frag8_t pf[2];
 #pragma unroll
         for (int kk = 0; kk < 2; ++kk)
 #pragma unroll
             for (int e = 0; e < 8; ++e) {
                 const float pv = __expf(s[kk * 2 + (e >> 2)][e & 3] - mnew);      // exp(-inf) = 0 for masked keys
                 lsum += pv;
-                pf[kk][e] = (short)f2bf(pv);
+                pf[kk][e] = (short)f2e(pv);
             }
         lsum += __shfl_xor(lsum, 16); lsum += __shfl_xor(lsum, 32);
         lrun = lrun * corr + lsum;
@@ -1210,7 +1197,7 @@ __global__ void __launch_bounds__(256, 2) decode_attn_prefix_mfma_kernel(const u
         for (int kk = 0; kk < 2; ++kk) {
             if (k0 + kk * 32 < k1) {
 #pragma unroll
-                for (int nt = 0; nt < NT; ++nt) o[nt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(pf[kk], vf[kk][nt], o[nt], 0, 0, 0);
+                for (int nt = 0; nt < NT; ++nt) o[nt] = mfma16(pf[kk], vf[kk][nt], o[nt]);
             }
         }
     }
@@ -1270,11 +1257,14 @@ static int normed_launch(const void* H, const float* ss, int nss, const void* ln
     return ok(hipSuccess);
 }
 
+}  // namespace VDD_ELEM_NS
 }  // namespace
+
+using namespace VDD_ELEM_NS;
 
 extern "C" {
 
-int vdd_rmsnorm(const void* x, const void* delta, const float* delta_slabs, int n_slabs, const void* w, void* y, void* resid_out,
+VDD_HIDDEN int VDD_IMPL(vdd_rmsnorm)(const void* x, const void* delta, const float* delta_slabs, int n_slabs, const void* w, void* y, void* resid_out,
                 int M, int d, float eps, void* stream) {
     if (M <= 0) return VDD_OK;
     if (!x || !w || !y || d % 8 != 0 || d > 8192 || (delta && delta_slabs) || (delta_slabs && n_slabs < 1)) return VDD_ERR_INVALID_ARG;
@@ -1291,7 +1281,7 @@ int vdd_rmsnorm(const void* x, const void* delta, const float* delta_slabs, int 
     return ok(hipSuccess);
 }
 
-int vdd_rope_kv_write(const void* qkv, const int* pos, const int* cpos, const int* slot, const float* cos_sin, void* q_out, void* k_cache,
+VDD_HIDDEN int VDD_IMPL(vdd_rope_kv_write)(const void* qkv, const int* pos, const int* cpos, const int* slot, const float* cos_sin, void* q_out, void* k_cache,
                       void* v_cache, int M, int Hq, int Hkv, int D, int64_t slot_stride, int t_max, void* stream) {
     if (M <= 0) return VDD_OK;
     if (!qkv || !pos || !cpos || !slot || !cos_sin || !q_out || !k_cache || !v_cache || D % 16 != 0) return VDD_ERR_INVALID_ARG;
@@ -1300,7 +1290,7 @@ int vdd_rope_kv_write(const void* qkv, const int* pos, const int* cpos, const in
     return ok(hipSuccess);
 }
 
-int vdd_silu_mul(const void* gate_up, void* out, int64_t M, int F, void* stream) {
+VDD_HIDDEN int VDD_IMPL(vdd_silu_mul)(const void* gate_up, void* out, int64_t M, int F, void* stream) {
     if (M <= 0) return VDD_OK;
     if (!gate_up || !out || F % 8 != 0) return VDD_ERR_INVALID_ARG;
     if (M > 65535) {        // gridDim.y limit: launch in row slabs
@@ -1315,14 +1305,14 @@ int vdd_silu_mul(const void* gate_up, void* out, int64_t M, int F, void* stream)
     return ok(hipSuccess);
 }
 
-int vdd_embed(const int64_t* ids, const void* table, void* out, int M, int d, int vocab, void* stream) {
+VDD_HIDDEN int VDD_IMPL(vdd_embed)(const int64_t* ids, const void* table, void* out, int M, int d, int vocab, void* stream) {
     if (M <= 0) return VDD_OK;
     if (!ids || !table || !out || d % 8 != 0 || vocab <= 0) return VDD_ERR_INVALID_ARG;
     hipLaunchKernelGGL(embed_kernel, dim3(M), dim3(256), 0, (hipStream_t)stream, (const long long*)ids, (const uint16_t*)table, (uint16_t*)out, d, vocab);
     return ok(hipSuccess);
 }
 
-int vdd_embed_scatter(const int32_t* ids, const int32_t* rows, const void* table, void* out, int M, int d, int vocab, void* stream) {
+VDD_HIDDEN int VDD_IMPL(vdd_embed_scatter)(const int32_t* ids, const int32_t* rows, const void* table, void* out, int M, int d, int vocab, void* stream) {
     if (M <= 0) return VDD_OK;
     if (!ids || !rows || !table || !out || d % 8 != 0 || vocab <= 0) return VDD_ERR_INVALID_ARG;
     hipLaunchKernelGGL(embed_scatter_kernel, dim3(M), dim3(256), 0, (hipStream_t)stream, ids, rows, (const uint16_t*)table, (uint16_t*)out, d, vocab);
@@ -1345,7 +1335,7 @@ static int skinny_gemm_launch(const void* X, const void* W, const void* R, void*
     return ok(hipSuccess);
 }
 
-int vdd_skinny_gemm(const void* X, const void* W, const void* R, void* Y, float* Y_slabs, int n_split, int M, int N, int K,
+VDD_HIDDEN int VDD_IMPL(vdd_skinny_gemm)(const void* X, const void* W, const void* R, void* Y, float* Y_slabs, int n_split, int M, int N, int K,
                     int64_t ldx, int64_t ldr, int64_t ldy, void* stream) {
     return skinny_gemm_launch(X, W, R, Y, Y_slabs, n_split, M, N, K, ldx, ldr, ldy, stream);
 }
@@ -1359,7 +1349,7 @@ static int skinny_swiglu_launch(const void* X, const void* W, void* act, int M, 
 }
 
 // ---- small-M decoder-layer fusions of the RMSNorm launches (see skinny_gemm_kernel)
-int vdd_skinny_gemm_resid_ss(const void* X, const void* W, const void* R, void* Y, float* ss_out, int M, int N, int K, int64_t ldx,
+VDD_HIDDEN int VDD_IMPL(vdd_skinny_gemm_resid_ss)(const void* X, const void* W, const void* R, void* Y, float* ss_out, int M, int N, int K, int64_t ldx,
                              int64_t ldr, int64_t ldy, void* stream) {
     if (M <= 0 || N <= 0) return VDD_OK;
     if (!X || !W || !R || !Y || !ss_out || M > 16 || K % 128 != 0 || (ldx % 8) != 0) return VDD_ERR_INVALID_ARG;
@@ -1374,24 +1364,24 @@ int vdd_skinny_gemm_resid_ss(const void* X, const void* W, const void* R, void* 
     return ok(hipSuccess);
 }
 
-int vdd_skinny_gemm_normed(const void* H, const float* ss, int nss, const void* ln_w, float eps, const void* W, void* Y, int M, int N,
+VDD_HIDDEN int VDD_IMPL(vdd_skinny_gemm_normed)(const void* H, const float* ss, int nss, const void* ln_w, float eps, const void* W, void* Y, int M, int N,
                            int K, int64_t ldh, int64_t ldy, void* stream) {
     if (M <= 0 || N <= 0) return VDD_OK;
     if (!H || !ss || nss <= 0 || (nss % 4) != 0 || !ln_w || !W || !Y || M > 16 || K % 256 != 0 || (ldh % 8) != 0) return VDD_ERR_INVALID_ARG;
     return normed_launch<false>(H, ss, nss, ln_w, eps, W, Y, M, N, K, ldh, ldy, (N + 15) / 16, stream);
 }
 
-int vdd_skinny_swiglu_normed(const void* H, const float* ss, int nss, const void* ln_w, float eps, const void* W_gate_up, void* act,
+VDD_HIDDEN int VDD_IMPL(vdd_skinny_swiglu_normed)(const void* H, const float* ss, int nss, const void* ln_w, float eps, const void* W_gate_up, void* act,
                              int M, int F, int K, int64_t ldh, void* stream) {
     if (M <= 0 || F <= 0) return VDD_OK;
     if (!H || !ss || nss <= 0 || (nss % 4) != 0 || !ln_w || !W_gate_up || !act || M > 16 || K % 256 != 0 || (ldh % 8) != 0) return VDD_ERR_INVALID_ARG;
     return normed_launch<true>(H, ss, nss, ln_w, eps, W_gate_up, act, M, F, K, ldh, (int64_t)F, (F + 7) / 8, stream);
 }
-int vdd_skinny_swiglu(const void* X, const void* W_gate_up, void* act, int M, int F, int K, int64_t ldx, void* stream) {
+VDD_HIDDEN int VDD_IMPL(vdd_skinny_swiglu)(const void* X, const void* W_gate_up, void* act, int M, int F, int K, int64_t ldx, void* stream) {
     return skinny_swiglu_launch(X, W_gate_up, act, M, F, K, ldx, stream);
 }
 
-int vdd_decode_attention(const void* q, const void* k_cache, const void* v_cache, const void* k_prefix, const void* v_prefix,
+VDD_HIDDEN int VDD_IMPL(vdd_decode_attention)(const void* q, const void* k_cache, const void* v_cache, const void* k_prefix, const void* v_prefix,
                          const int32_t* rows, void* out, void* workspace, int M, int H, int Hkv, int D, int64_t slot_stride, int t_max,
                          int64_t prefix_stride, int prefix_tmax, int max_len, float scale, void* stream) {
     if (M <= 0) return VDD_OK;
@@ -1407,7 +1397,7 @@ int vdd_decode_attention(const void* q, const void* k_cache, const void* v_cache
     return ok(hipSuccess);
 }
 
-int vdd_decode_attention_fused(const void* qkv, const int32_t* pos, const int32_t* cpos, const int32_t* slot, const float* cos_sin,
+VDD_HIDDEN int VDD_IMPL(vdd_decode_attention_fused)(const void* qkv, const int32_t* pos, const int32_t* cpos, const int32_t* slot, const float* cos_sin,
                                void* k_cache, void* v_cache, const void* k_prefix, const void* v_prefix, const int32_t* rows, void* out,
                                int M, int H, int Hkv, int D, int64_t slot_stride, int t_max, int64_t prefix_stride, int prefix_tmax,
                                float scale, void* stream) {
@@ -1421,12 +1411,12 @@ int vdd_decode_attention_fused(const void* qkv, const int32_t* pos, const int32_
     return ok(hipSuccess);
 }
 
-int64_t vdd_decode_attention_fused_split_workspace_bytes(int M, int H, int n_split) {
+VDD_HIDDEN int64_t VDD_IMPL(vdd_decode_attention_fused_split_workspace_bytes)(int M, int H, int n_split) {
     if (M <= 0 || H <= 0 || n_split < 1) return 0;
     return ((int64_t)M * H * n_split * ATT_FS + (int64_t)M * H) * 4;
 }
 
-int vdd_decode_attention_fused_split(const void* qkv, const int32_t* pos, const int32_t* cpos, const int32_t* slot, const float* cos_sin,
+VDD_HIDDEN int VDD_IMPL(vdd_decode_attention_fused_split)(const void* qkv, const int32_t* pos, const int32_t* cpos, const int32_t* slot, const float* cos_sin,
                                      void* k_cache, void* v_cache, const void* k_prefix, const void* v_prefix, const int32_t* rows, void* out,
                                      int M, int H, int Hkv, int D, int64_t slot_stride, int t_max, int64_t prefix_stride, int prefix_tmax,
                                      float scale, void* workspace, int n_split, void* stream) {
@@ -1445,7 +1435,7 @@ int vdd_decode_attention_fused_split(const void* qkv, const int32_t* pos, const 
     return ok(hipSuccess);
 }
 
-int vdd_decode_attention_grouped(const void* q, const void* k_cache, const void* v_cache, const void* k_prefix, const void* v_prefix,
+VDD_HIDDEN int VDD_IMPL(vdd_decode_attention_grouped)(const void* q, const void* k_cache, const void* v_cache, const void* k_prefix, const void* v_prefix,
                                  const void* prefix_frag, const int32_t* rows, const int32_t* groups, const int32_t* group_rows,
                                  const int32_t* items, int n_items, void* out, void* workspace, int M, int H, int Hkv, int D,
                                  int64_t slot_stride, int t_max, int64_t prefix_stride, int prefix_tmax, int max_prefix_len,
@@ -1479,7 +1469,7 @@ int vdd_decode_attention_grouped(const void* q, const void* k_cache, const void*
     return ok(hipSuccess);
 }
 
-int vdd_prefix_fragments(const void* k_prefix, const void* v_prefix, void* prefix_frag, const int32_t* prefix_len_of_slot, int n_slots,
+VDD_HIDDEN int VDD_IMPL(vdd_prefix_fragments)(const void* k_prefix, const void* v_prefix, void* prefix_frag, const int32_t* prefix_len_of_slot, int n_slots,
                          int Hkv, int t_max, int D, void* stream) {
     if (n_slots <= 0) return VDD_OK;
     if (!k_prefix || !v_prefix || !prefix_frag || !prefix_len_of_slot || D != 128 || t_max % ATT_CH != 0) return VDD_ERR_INVALID_ARG;
@@ -1488,7 +1478,7 @@ int vdd_prefix_fragments(const void* k_prefix, const void* v_prefix, void* prefi
     return ok(hipSuccess);
 }
 
-int64_t vdd_decode_attention_workspace_bytes(int M, int H, int D, int max_len) {
+VDD_HIDDEN int64_t VDD_IMPL(vdd_decode_attention_workspace_bytes)(int M, int H, int D, int max_len) {
     return (int64_t)M * H * ((max_len + ATT_CH - 1) / ATT_CH) * ATT_PS * 4;
 }
 

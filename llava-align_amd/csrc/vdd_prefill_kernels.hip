@@ -14,29 +14,13 @@
 
 #include <type_traits>
 
-#include "vdd_hip.h"
+#include "vdd_elem.h"
 
 namespace {
+namespace VDD_ELEM_NS {
+using namespace vdd_elem;
 
-typedef __attribute__((ext_vector_type(8))) short bf16x8_t;
-typedef __attribute__((ext_vector_type(4))) float f32x4_t;
-
-__device__ __forceinline__ float bf2f(uint32_t b) { return __builtin_bit_cast(float, b << 16); }
-__device__ __forceinline__ uint32_t f2bf(float f) {
-    uint32_t u = __builtin_bit_cast(uint32_t, f);
-    if ((u & 0x7fffffffu) > 0x7f800000u) return (u >> 16) | 0x40u;
-    return (u + 0x7fffu + ((u >> 16) & 1u)) >> 16;
-}
-__device__ __forceinline__ float lo(uint32_t w) { return bf2f(w & 0xFFFFu); }
-__device__ __forceinline__ float hi(uint32_t w) { return __builtin_bit_cast(float, w & 0xFFFF0000u); }
-__device__ __forceinline__ uint32_t pack(float a, float b) { return f2bf(a) | (f2bf(b) << 16); }
-
-typedef __attribute__((ext_vector_type(2))) float f32x2_t;
-typedef __attribute__((ext_vector_type(2))) __bf16 bf16x2_t;
-// two fp32 -> packed bf16, round-to-nearest-even, in ONE instruction (v_cvt_pk_bf16_f32)
-__device__ __forceinline__ uint32_t cvt_pk_bf16(float a, float b) {
-    return __builtin_bit_cast(uint32_t, __builtin_convertvector(f32x2_t{a, b}, bf16x2_t));
-}
+typedef __attribute__((ext_vector_type(8))) short frag8_t;    // MFMA A/B fragment: 8 elements (bf16 or fp16 bit patterns)
 
 struct SeqDesc { int q_row0, Tq, pos0, slot, pslot, plen; };
 
@@ -57,7 +41,6 @@ constexpr float NEG_BIG = -1.0e30f;
 //     banks), read TRANSPOSED with ds_read_b64_tr_b16: within a 16-lane group lane i receives element i % 4 of the 8 bytes
 //     addressed by lane 4 j + i / 4 (tools/probes/tr_read_probe.hip), i.e. 4 consecutive keys of one dim from a row-major image.
 // One barrier per tile.  Same sequence descriptors and prefix indirection as before.
-typedef __attribute__((ext_vector_type(16))) float f32x16_t;
 typedef __attribute__((address_space(3))) void* lds_ptr_t;
 typedef __attribute__((address_space(1))) void* g_ptr_t;
 
@@ -118,12 +101,12 @@ __global__ void __launch_bounds__(256, 2) flash_attn2_kernel(const uint16_t* __r
     const int wave_last_pos = sd.pos0 + min(r0 + 31, sd.Tq - 1);
 
     // Q fragments (B operand of S^T): lane (q, hi) holds Q[r0 + q][16 ks + 8 hi .. + 7]
-    bf16x8_t qf[KS];
+    frag8_t qf[KS];
     {
         int qr = r0 + ql; if (qr >= sd.Tq) qr = sd.Tq - 1;
         const uint16_t* qp = q + ((size_t)(sd.q_row0 + qr) * H + head) * D + hi * 8;
 #pragma unroll
-        for (int ks = 0; ks < KS; ++ks) qf[ks] = *reinterpret_cast<const bf16x8_t*>(qp + ks * 16);
+        for (int ks = 0; ks < KS; ++ks) qf[ks] = *reinterpret_cast<const frag8_t*>(qp + ks * 16);
     }
     const int qpos = sd.pos0 + r0 + ql;
     const size_t head_off = (size_t)kvh * t_max * D, pre_off = (size_t)kvh * pre_tmax * D;
@@ -174,12 +157,12 @@ __global__ void __launch_bounds__(256, 2) flash_attn2_kernel(const uint16_t* __r
         // ---- S^T = K Q^T: all 2 KS fragment reads in flight, then the two independent accumulator chains interleaved ----
         f32x16_t s[2];
         {
-            bf16x8_t kf[2][KS];
+            frag8_t kf[2][KS];
 #pragma unroll
             for (int ks = 0; ks < KS; ++ks)
 #pragma unroll
                 for (int b = 0; b < 2; ++b)
-                    kf[b][ks] = *reinterpret_cast<const bf16x8_t*>(kb + b * 32 * KROW + krow + (((2 * ks + hi) ^ kswz) * 16));
+                    kf[b][ks] = *reinterpret_cast<const frag8_t*>(kb + b * 32 * KROW + krow + (((2 * ks + hi) ^ kswz) * 16));
             __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
             for (int b = 0; b < 2; ++b)
@@ -189,7 +172,7 @@ __global__ void __launch_bounds__(256, 2) flash_attn2_kernel(const uint16_t* __r
 #pragma unroll
             for (int ks = 0; ks < KS; ++ks)
 #pragma unroll
-                for (int b = 0; b < 2; ++b) s[b] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(kf[b][ks], qf[ks], s[b], 0, 0, 0);
+                for (int b = 0; b < 2; ++b) s[b] = mfma32(kf[b][ks], qf[ks], s[b]);
             __builtin_amdgcn_s_setprio(0);
         }
         // ---- mask + online softmax: this lane's scores are keys kt + 32 b + (r & 3) + 8 (r >> 2) + 4 hi of query q ----
@@ -222,14 +205,14 @@ __global__ void __launch_bounds__(256, 2) flash_attn2_kernel(const uint16_t* __r
                 for (int e = 0; e < 16; ++e) o[nt][e] *= corr;
             mq = mn;
         }
-        bf16x8_t pf[4];                                       // step st = 2 b + j: keys 32 b + 16 j ..
+        frag8_t pf[4];                                       // step st = 2 b + j: keys 32 b + 16 j ..
 #pragma unroll
         for (int st = 0; st < 4; ++st) {
             float e[8];
 #pragma unroll
             for (int i = 0; i < 8; ++i) { e[i] = __builtin_amdgcn_exp2f(s[st >> 1][8 * (st & 1) + i] - mq); lq += e[i]; }    // masked: exp2(-1e30) = 0
-            const uint4 pk = make_uint4(cvt_pk_bf16(e[0], e[1]), cvt_pk_bf16(e[2], e[3]), cvt_pk_bf16(e[4], e[5]), cvt_pk_bf16(e[6], e[7]));
-            pf[st] = __builtin_bit_cast(bf16x8_t, pk);
+            const uint4 pk = make_uint4(cvt_pk(e[0], e[1]), cvt_pk(e[2], e[3]), cvt_pk(e[4], e[5]), cvt_pk(e[6], e[7]));
+            pf[st] = __builtin_bit_cast(frag8_t, pk);
         }
         // ---- O^T += V^T P^T: the 2 NT transposed reads of step st + 1 are issued before the NT MFMAs of step st ----
         uint2 va[2 * NT], vn[2 * NT];
@@ -261,8 +244,8 @@ __global__ void __launch_bounds__(256, 2) flash_attn2_kernel(const uint16_t* __r
         auto pv = [&](int st, uint2 (&v)[2 * NT]) {
 #pragma unroll
             for (int nt = 0; nt < NT; ++nt) {
-                const bf16x8_t vf = __builtin_bit_cast(bf16x8_t, make_uint4(v[2 * nt].x, v[2 * nt].y, v[2 * nt + 1].x, v[2 * nt + 1].y));
-                o[nt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(vf, pf[st], o[nt], 0, 0, 0);
+                const frag8_t vf = __builtin_bit_cast(frag8_t, make_uint4(v[2 * nt].x, v[2 * nt].y, v[2 * nt + 1].x, v[2 * nt + 1].y));
+                o[nt] = mfma32(vf, pf[st], o[nt]);
             }
         };
         __builtin_amdgcn_sched_barrier(0);
@@ -322,7 +305,7 @@ __global__ void __launch_bounds__(256, 2) flash_attn2_kernel(const uint16_t* __r
     for (int nt = 0; nt < NT; ++nt)
 #pragma unroll
         for (int r4 = 0; r4 < 4; ++r4) {
-            const uint2 w = make_uint2(cvt_pk_bf16(o[nt][4 * r4] * inv, o[nt][4 * r4 + 1] * inv), cvt_pk_bf16(o[nt][4 * r4 + 2] * inv, o[nt][4 * r4 + 3] * inv));
+            const uint2 w = make_uint2(cvt_pk(o[nt][4 * r4] * inv, o[nt][4 * r4 + 1] * inv), cvt_pk(o[nt][4 * r4 + 2] * inv, o[nt][4 * r4 + 3] * inv));
             *reinterpret_cast<uint2*>(ot + ql * OP + (32 * nt + 8 * r4 + 4 * hi) * 2) = w;
         }
     __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");    // same wave reads it back: LDS program order
@@ -392,7 +375,7 @@ __global__ void __launch_bounds__(256) bias_act_kernel(const uint16_t* __restric
         uint4 a = *reinterpret_cast<const uint4*>(x + i * 8);
         uint4 bb = bias ? *reinterpret_cast<const uint4*>(bias + e) : make_uint4(0, 0, 0, 0);
         auto f = [&](float v, float b) {
-            v = bf2f(f2bf(v + b));
+            v = e2f(f2e(v + b));
             if (act == 1) v = v / (1.f + __expf(-1.702f * v));
             else if (act == 2) v = 0.5f * v * (1.f + erff(v * 0.70710678118654752f));
             return v;
@@ -419,7 +402,7 @@ __global__ void __launch_bounds__(256) vit_im2col_kernel(const T* __restrict__ i
             const int c = col / (P * P), r = col - c * P * P, py = r / P, px = r - py * P;
             v = (float)base[(size_t)c * S * S + (size_t)py * S + px];
         }
-        out[(size_t)patch * Kp + col] = (uint16_t)f2bf(v);
+        out[(size_t)patch * Kp + col] = (uint16_t)f2e(v);
     }
 }
 
@@ -465,11 +448,14 @@ __global__ void __launch_bounds__(256) add_kernel(const uint16_t* __restrict__ a
 
 inline int ok() { return hipGetLastError() == hipSuccess ? VDD_OK : VDD_ERR_LAUNCH; }
 
+}  // namespace VDD_ELEM_NS
 }  // namespace
+
+using namespace VDD_ELEM_NS;
 
 extern "C" {
 
-int vdd_flash_attention(const void* q, const void* k_cache, const void* v_cache, const void* k_prefix, const void* v_prefix,
+VDD_HIDDEN int VDD_IMPL(vdd_flash_attention)(const void* q, const void* k_cache, const void* v_cache, const void* k_prefix, const void* v_prefix,
                         const int32_t* seqs, void* out, int n_seq, int max_tq, int H, int Hkv, int D, int64_t slot_stride, int t_max,
                         int64_t prefix_stride, int prefix_tmax, float scale, int causal, void* stream) {
     if (n_seq <= 0 || max_tq <= 0) return VDD_OK;
@@ -494,7 +480,7 @@ int vdd_flash_attention(const void* q, const void* k_cache, const void* v_cache,
     return ok();
 }
 
-int vdd_flash_attention_packed(const void* q, const void* k_cache, const void* v_cache, const void* k_prefix, const void* v_prefix,
+VDD_HIDDEN int VDD_IMPL(vdd_flash_attention_packed)(const void* q, const void* k_cache, const void* v_cache, const void* k_prefix, const void* v_prefix,
                                const int32_t* seqs, const int32_t* packs, void* out, int n_packs, int H, int Hkv, int D,
                                int64_t slot_stride, int t_max, int64_t prefix_stride, int prefix_tmax, float scale, void* stream) {
     if (n_packs <= 0) return VDD_OK;
@@ -510,7 +496,7 @@ int vdd_flash_attention_packed(const void* q, const void* k_cache, const void* v
     return ok();
 }
 
-int vdd_layernorm(const void* x, const void* w, const void* b, void* y, int M, int d, float eps, void* stream) {
+VDD_HIDDEN int VDD_IMPL(vdd_layernorm)(const void* x, const void* w, const void* b, void* y, int M, int d, float eps, void* stream) {
     if (M <= 0) return VDD_OK;
     if (!x || !w || !b || !y || d % 8 != 0 || d > 4096) return VDD_ERR_INVALID_ARG;
     hipLaunchKernelGGL(layernorm_kernel, dim3(M), dim3(256), 0, (hipStream_t)stream, (const uint16_t*)x, (const uint16_t*)w,
@@ -518,7 +504,7 @@ int vdd_layernorm(const void* x, const void* w, const void* b, void* y, int M, i
     return ok();
 }
 
-int vdd_bias_act(const void* x, const void* bias, void* y, int64_t M, int d, int act, void* stream) {
+VDD_HIDDEN int VDD_IMPL(vdd_bias_act)(const void* x, const void* bias, void* y, int64_t M, int d, int act, void* stream) {
     if (M <= 0) return VDD_OK;
     if (!x || !y || d % 8 != 0 || act < 0 || act > 2) return VDD_ERR_INVALID_ARG;
     long long n8 = (long long)M * (d / 8);
@@ -528,7 +514,7 @@ int vdd_bias_act(const void* x, const void* bias, void* y, int64_t M, int d, int
     return ok();
 }
 
-int vdd_vit_im2col(const void* images, int dtype, void* patches, int n, int S, int P, int Kp, void* stream) {
+VDD_HIDDEN int VDD_IMPL(vdd_vit_im2col)(const void* images, int dtype, void* patches, int n, int S, int P, int Kp, void* stream) {
     if (n <= 0) return VDD_OK;
     if (!images || !patches || P <= 0 || S % P != 0 || Kp < 3 * P * P) return VDD_ERR_INVALID_ARG;
     const int G = S / P;
@@ -541,7 +527,7 @@ int vdd_vit_im2col(const void* images, int dtype, void* patches, int n, int S, i
     return ok();
 }
 
-int vdd_vit_assemble(const void* emb, const void* cls, const void* pos, void* out, int n, int T, int width, void* stream) {
+VDD_HIDDEN int VDD_IMPL(vdd_vit_assemble)(const void* emb, const void* cls, const void* pos, void* out, int n, int T, int width, void* stream) {
     if (n <= 0) return VDD_OK;
     if (!emb || !cls || !pos || !out || width % 8 != 0 || T < 2) return VDD_ERR_INVALID_ARG;
     hipLaunchKernelGGL(vit_assemble_kernel, dim3(n * T), dim3(256), 0, (hipStream_t)stream, (const uint16_t*)emb, (const uint16_t*)cls,
@@ -549,7 +535,7 @@ int vdd_vit_assemble(const void* emb, const void* cls, const void* pos, void* ou
     return ok();
 }
 
-int vdd_vit_qkv_split(const void* qkv, void* q, void* k_cache, void* v_cache, int n, int T, int H, int D, int64_t slot_stride, int t_max,
+VDD_HIDDEN int VDD_IMPL(vdd_vit_qkv_split)(const void* qkv, void* q, void* k_cache, void* v_cache, int n, int T, int H, int D, int64_t slot_stride, int t_max,
                       int parts, void* stream) {
     if (n <= 0) return VDD_OK;
     if (!qkv || (!q && parts == 3) || !k_cache || !v_cache || D % 8 != 0 || T > t_max || (parts != 2 && parts != 3)) return VDD_ERR_INVALID_ARG;
@@ -558,7 +544,7 @@ int vdd_vit_qkv_split(const void* qkv, void* q, void* k_cache, void* v_cache, in
     return ok();
 }
 
-int vdd_add(const void* a, const void* b, void* out, int64_t n, void* stream) {
+VDD_HIDDEN int VDD_IMPL(vdd_add)(const void* a, const void* b, void* out, int64_t n, void* stream) {
     if (n <= 0) return VDD_OK;
     if (!a || !b || !out || n % 8 != 0) return VDD_ERR_INVALID_ARG;
     const long long n8 = n / 8;

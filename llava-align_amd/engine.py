@@ -21,7 +21,8 @@ Reference-compat details: <unk> is ONE token (#3), so image-free
 c == v afterwards (#1); use_dd alone or with use_dd_unk adds the image-token-dropped branch.
 
 Every compute op is a hand-written HIP kernel (ops.py), the GEMMs included (csrc/vdd_gemm.hip above 8 rows,
-the weight-streaming GEMV kernels below).  bf16 storage, fp32 accumulation.
+the weight-streaming GEMV kernels below).  16-bit storage - bf16 (BASELINE config #2) or fp16 (the dtype the reference's drivers load
+their checkpoints in, experiments/llava/model/builder.py:40) - with fp32 accumulation: `VddLlavaEngine(dtype=...)`.
 """
 from __future__ import annotations
 
@@ -101,26 +102,26 @@ def preset(name: str) -> LlavaConfig:
 
 # ------------------------------------------------------------------ weights
 class LlavaWeights:
-    """Flat container of bf16 device tensors.  `random()` draws N(0, 0.02) (no
+    """Flat container of device tensors of ONE 16-bit dtype (bf16 or fp16).  `random()` draws N(0, 0.02) (no
     checkpoints exist on either box); `from_state_dict()` maps HF LLaVA-1.5 parameter names."""
 
-    def __init__(self, cfg: LlavaConfig, device):
-        self.cfg, self.device = cfg, torch.device(device)
+    def __init__(self, cfg: LlavaConfig, device, dtype=torch.bfloat16):
+        self.cfg, self.device, self.dtype = cfg, torch.device(device), dtype       # (fp32 containers feed the tests' torch references)
         self.t: Dict[str, torch.Tensor] = {}
 
     @staticmethod
-    def random(cfg: LlavaConfig, device, seed: int = 0, std: float = 0.02, lm_head_gain: float = 1.0) -> "LlavaWeights":
+    def random(cfg: LlavaConfig, device, seed: int = 0, std: float = 0.02, lm_head_gain: float = 1.0, dtype=torch.bfloat16) -> "LlavaWeights":
         """lm_head_gain scales the output projection: N(0, 0.02) everywhere gives logits of sigma ~ 1.3 (d = 4096), so flat that
         the plausibility mask of a contrastive step keeps ~1000 tokens; a trained LLaVA answers POPE with a few candidates.
         gain 4 (sigma ~ 5) puts a random model in that regime (benchmarks use it; parity tests keep 1)."""
-        w = LlavaWeights(cfg, device)
+        w = LlavaWeights(cfg, device, dtype)
         g = torch.Generator(device=device).manual_seed(seed)
 
         def rnd(*shape, s=std):
-            return (torch.randn(*shape, device=device, generator=g, dtype=torch.float32) * s).to(torch.bfloat16)
+            return (torch.randn(*shape, device=device, generator=g, dtype=torch.float32) * s).to(dtype)
 
         def ones(n):
-            return (1.0 + torch.randn(n, device=device, generator=g) * 0.02).to(torch.bfloat16)
+            return (1.0 + torch.randn(n, device=device, generator=g) * 0.02).to(dtype)
         lm, v = cfg.lm, cfg.vision
         qkv_out = (lm.n_heads + 2 * lm.n_kv_heads) * lm.head_dim
         w.t["embed"] = rnd(lm.vocab, lm.d)
@@ -137,7 +138,7 @@ class LlavaWeights:
         w.t["lm_head"] = rnd(lm.vocab, lm.d, s=std * lm_head_gain)
         pd = 3 * v.patch * v.patch
         pd_pad = (pd + 127) // 128 * 128                         # K of the patch-embed GEMM: a multiple of its 128-deep unit
-        pw = torch.zeros(v.width, pd_pad, dtype=torch.bfloat16, device=device)
+        pw = torch.zeros(v.width, pd_pad, dtype=dtype, device=device)
         pw[:, :pd] = rnd(v.width, pd)
         w.t["v.patch"] = pw                                      # conv14x14/stride14 as a [width, 588 -> 640] GEMM
         w.t["v.cls"], w.t["v.pos"] = rnd(v.width), rnd(v.n_patches + 1, v.width)
@@ -162,7 +163,7 @@ class LlavaWeights:
         post_attention_layernorm}`, `model.norm`, `lm_head`, `model.mm_projector.{0,2}`; the CLIP tower either inside the
         checkpoint (`model.vision_tower.vision_tower.vision_model...`) or as a separate HF CLIP state dict (`vision_sd`,
         keys `vision_model...`).  q/k/v and gate/up are concatenated for the fused projections."""
-        w = LlavaWeights(cfg, device)
+        w = LlavaWeights(cfg, device, dtype)
         lm, v = cfg.lm, cfg.vision
 
         def get(d, k):
@@ -245,7 +246,7 @@ class VisionTower:
         v = self.cfg
         if self._kv is None or self._kv[0].shape[0] < n_img:
             n_alloc = max(n_img, self.GRAPH_BATCH)
-            mk = lambda: torch.empty(n_alloc, v.heads, self.T, v.width // v.heads, dtype=torch.bfloat16, device=self.w.device)
+            mk = lambda: torch.empty(n_alloc, v.heads, self.T, v.width // v.heads, dtype=self.w.dtype, device=self.w.device)
             self._kv = (mk(), mk())
             self._graphs.clear()                 # a captured forward points at the old buffers
         return self._kv
@@ -255,7 +256,7 @@ class VisionTower:
 
     @torch.no_grad()
     def __call__(self, images: torch.Tensor) -> torch.Tensor:
-        """images [n, 3, S, S] (any float dtype) -> projected patch features [n, n_patches, d_lm] bf16.
+        """images [n, 3, S, S] (any float dtype) -> projected patch features [n, n_patches, d_lm] in the model dtype.
         Batches of GRAPH_SIZES images replay a captured HIP graph: the tower is ~400 small launches per batch and runs
         when nothing else is queued, so issued from Python it is launch-bound (98 ms of host time for 43 ms of GPU work
         per 64 images, tools/host_phase_probe.py)."""
@@ -264,7 +265,7 @@ class VisionTower:
             st = self._graphs.get(n)
             if st is None:
                 self._kv_cache(self.GRAPH_BATCH)
-                g_in = torch.empty(n, *images.shape[1:], dtype=torch.bfloat16, device=self.w.device)
+                g_in = torch.empty(n, *images.shape[1:], dtype=self.w.dtype, device=self.w.device)
                 g_in.copy_(images)
                 side = torch.cuda.Stream(self.w.device)
                 side.wait_stream(torch.cuda.current_stream(self.w.device))
@@ -284,7 +285,7 @@ class VisionTower:
                         gc.enable()
                 st = self._graphs[n] = (g, g_in, g_out)
             g, g_in, g_out = st
-            g_in.copy_(images.to(self.w.device, non_blocking=True))      # H2D in the caller's dtype, bf16 cast on the device
+            g_in.copy_(images.to(self.w.device, non_blocking=True))      # H2D in the caller's dtype, cast to the model dtype on the device
             g.replay()
             return g_out.clone()
         return self._forward(images)
@@ -301,7 +302,7 @@ class VisionTower:
         if x.dtype not in (torch.float32, torch.float16, torch.bfloat16):
             x = x.float()
         T, H, D = self.T, v.heads, v.width // v.heads
-        patches = ops.vit_im2col(x.contiguous(), v.patch, t["v.patch"].shape[1])          # [n * 576, 640] bf16
+        patches = ops.vit_im2col(x.contiguous(), v.patch, t["v.patch"].shape[1], dtype=self.w.dtype)          # [n * 576, 640]
         emb = ops.gemm(patches, t["v.patch"])                                              # CLIP's patch conv has no bias
         h = ops.vit_assemble(emb, t["v.cls"], t["v.pos"], n, T)
         h = ops.layernorm(h, t["v.pre_ln.w"], t["v.pre_ln.b"], v.eps)
@@ -325,14 +326,15 @@ class VisionTower:
 
 # ------------------------------------------------------------------ language model
 class KVCache:
-    """Two pools per layer, both [n_slots, n_kv_heads, t_max, head_dim] bf16:
+    """Two pools per layer, both [n_slots, n_kv_heads, t_max, head_dim] in the model dtype:
     `pre`  shared prompt prefixes (system prompt + image patches / + <unk>), token t at index t;
     `own`  one COMPACT slot per (question, branch): token t at index t - prefix_len, so a slot only holds the
            question's own ~25 prompt tokens + the generated ones instead of a full-length context."""
 
-    def __init__(self, lm: LMConfig, n_pre: int, t_pre: int, n_own: int, t_own: int, device):
+    def __init__(self, lm: LMConfig, n_pre: int, t_pre: int, n_own: int, t_own: int, device, dtype=torch.bfloat16):
+        self.dtype = dtype
         self.n_pre, self.t_pre, self.n_own, self.t_own = n_pre, t_pre, n_own, t_own
-        mk = lambda n, t: [torch.empty((max(n, 1), lm.n_kv_heads, t, lm.head_dim), dtype=torch.bfloat16, device=device)
+        mk = lambda n, t: [torch.empty((max(n, 1), lm.n_kv_heads, t, lm.head_dim), dtype=dtype, device=device)
                            for _ in range(lm.n_layers)]
         self.kp, self.vp = mk(n_pre, t_pre), mk(n_pre, t_pre)
         self.ko, self.vo = mk(n_own, t_own), mk(n_own, t_own)
@@ -378,6 +380,21 @@ class LanguageModel:
     def __init__(self, w: LlavaWeights):
         self.w, self.cfg = w, w.cfg.lm
         self.cs = rope_table(self.cfg, w.device)
+        # A vocabulary that is not a multiple of 8 rows (resize_token_embeddings(len(tokenizer)) after add_tokens, builder.py:127-132:
+        # 32001 ... 32003): the output projection runs on a zero-padded copy of lm_head (the GEMM writes whole 8-byte quads) and the
+        # logits are a [rows, V] VIEW of its [rows, V_pad] result - the sampling kernel takes any row stride and never sees the padding.
+        V = self.cfg.vocab
+        self.lm_head = w.t["lm_head"]
+        if V % 8 != 0:
+            padded = torch.zeros((V + 7) // 8 * 8, self.lm_head.shape[1], dtype=self.lm_head.dtype, device=self.lm_head.device)
+            padded[:V] = self.lm_head
+            self.lm_head = padded
+
+    def _head(self, a=None, resid=None, ss=None):
+        """Final norm (fused for a few rows) + output projection -> [rows, V] logits."""
+        c = self.cfg
+        y = ops.linear(a, self.lm_head) if a is not None else ops.linear_normed(resid, ss, self.w.t["norm"], c.eps, self.lm_head)
+        return y if y.shape[1] == c.vocab else y[:, :c.vocab]
 
     @torch.no_grad()
     def prefill(self, x: torch.Tensor, pos: torch.Tensor, cpos: torch.Tensor, slot: torch.Tensor, seqs: torch.Tensor, n_seq: int,
@@ -425,7 +442,7 @@ class LanguageModel:
         if rows is not None:
             resid, delta = resid[rows].contiguous(), delta[rows].contiguous()
         a = ops.rmsnorm(resid, t["norm"], c.eps, delta=delta)
-        return ops.linear(a, t["lm_head"])
+        return self._head(a)
 
     fuse_norms = True         # few rows in flight: the RMSNorm launches ride inside the projections around them
 
@@ -451,7 +468,7 @@ class LanguageModel:
             resid, ss = ops.linear_resid_ss(att, t[p + "wo"], resid)
             act = ops.swiglu_linear_normed(resid, ss, t[p + "ln2"], c.eps, t[p + "wgu"])
             resid, ss = ops.linear_resid_ss(act, t[p + "wd"], resid)
-        return ops.linear_normed(resid, ss, t["norm"], c.eps, t["lm_head"])
+        return self._head(resid=resid, ss=ss)
 
     @torch.no_grad()
     def decode_step(self, tokens: torch.Tensor, pos: torch.Tensor, cpos: torch.Tensor, slot: torch.Tensor, attn_rows: torch.Tensor,
@@ -491,7 +508,7 @@ class LanguageModel:
             a = ops.rmsnorm(resid, t[p + "ln2"], c.eps, delta=o, resid_out=resid)
             delta = ops.linear_to_norm(ops.swiglu_linear(a, t[p + "wgu"]), t[p + "wd"])
         a = ops.rmsnorm(resid, t["norm"], c.eps, delta=delta)
-        return ops.linear(a, t["lm_head"])
+        return self._head(a)
 
 
 # ------------------------------------------------------------------ generation
@@ -507,8 +524,9 @@ class GenerateOutput:
     def __getitem__(self, k):
         if k in ("attentions", "hidden_states"):
             raise KeyError(f"{k}: not produced by the native engine (attention is computed by flash-style kernels that never materialise the "
-                           f"maps; the reference reads them only for a commented-out plot, llava_calibrate.py:180-183) - use the generic "
-                           f"evolve_vcd_sampling() path on an HF model for them")
+                           f"maps).  llava_calibrate.py:180-182 reads model_outputs['attentions'][0][-1] and averages it in live code, for a "
+                           f"plot whose call (:183) is commented out: delete those lines in a driver ported to the engine, or use the "
+                           f"generic evolve_vcd_sampling() path on an HF model for the maps")
         return getattr(self, k)
 
 
@@ -544,7 +562,7 @@ class _DecodeRunner:
         self.step_idx = torch.zeros(1, dtype=torch.long, device=dev)
         self.ctr = torch.zeros(1, dtype=torch.long, device=dev)
         self.status, self.status0, self._st = torch.zeros(Q, **i32), torch.zeros(Q, **i32), torch.zeros(Q, **i32)
-        self.scores_buf = torch.empty(Q, eng.cfg.lm.vocab, dtype=torch.bfloat16, device=dev) if tail["output_scores"] else None
+        self.scores_buf = torch.empty(Q, eng.cfg.lm.vocab, dtype=eng.dtype, device=dev) if tail["output_scores"] else None
         self.graph = None
         self._tried = False
         self.grouping = None
@@ -700,10 +718,18 @@ class VddLlavaEngine:
                                          "synced_gpus", "use_image"})
 
     def __init__(self, cfg: LlavaConfig | str = "llava-1.5-7b", weights: Optional[LlavaWeights] = None, device="cuda:0",
-                 seed: int = 0, max_questions: int = 64, t_max: int = 0, use_graph: bool = True, lm_head_gain: float = 1.0):
+                 seed: int = 0, max_questions: int = 64, t_max: int = 0, use_graph: bool = True, lm_head_gain: float = 1.0,
+                 dtype: Optional[torch.dtype] = None):
+        """dtype: torch.bfloat16 (default; BASELINE config #2) or torch.float16 - the dtype every released driver of the reference loads
+        its checkpoint in (builder.py:40, llava_calibrate.py:163).  With `weights` given, their dtype is the engine's."""
         self.cfg = preset(cfg) if isinstance(cfg, str) else cfg
         self.device = torch.device(device)
-        self.w = weights if weights is not None else LlavaWeights.random(self.cfg, self.device, seed, lm_head_gain=lm_head_gain)
+        if weights is not None and dtype is not None and weights.dtype != dtype:
+            raise ValueError(f"weights are {weights.dtype}, engine asked for {dtype}")
+        self.dtype = weights.dtype if weights is not None else (dtype if dtype is not None else torch.bfloat16)
+        if self.dtype not in (torch.bfloat16, torch.float16):
+            raise ValueError(f"model dtype must be torch.bfloat16 or torch.float16 (got {self.dtype}): the kernels are built for those two")
+        self.w = weights if weights is not None else LlavaWeights.random(self.cfg, self.device, seed, lm_head_gain=lm_head_gain, dtype=self.dtype)
         self.vit = VisionTower(self.w)
         self.vit.use_graph = use_graph
         self.lm = LanguageModel(self.w)
@@ -727,7 +753,7 @@ class VddLlavaEngine:
             if old is not None:
                 n_pre, t_pre, n_own, t_own = grow(n_pre, old.n_pre), grow(t_pre, old.t_pre), grow(n_own, old.n_own), grow(t_own, old.t_own)
             del old
-            self._kv = KVCache(self.cfg.lm, n_pre, t_pre, n_own, t_own, self.device)
+            self._kv = KVCache(self.cfg.lm, n_pre, t_pre, n_own, t_own, self.device, self.dtype)
         return self._kv
 
     def image_features(self, images: Sequence[torch.Tensor], keys: Optional[Sequence[int]] = None) -> List[torch.Tensor]:
@@ -804,7 +830,9 @@ class VddLlavaEngine:
         list of 1-D id tensors (one per question, each with one -200 image slot) or a [Q, L] tensor; `images` one
         image per question (repeat the SAME tensor for questions about the same image to share its features and
         prompt-prefix KV).  use_cache / output_attentions are accepted and ignored (attention maps are never
-        materialised: flash-style kernels; the reference only reads them for a commented-out plot, :180-183).
+        materialised: flash-style kernels; the reference's driver averages model_outputs['attentions'][0][-1] at :180-182 for a plot
+        whose call, :183, is commented out - those lines go when a driver moves to the engine).  attention_mask is accepted when
+        it is all ones (the reference's B = 1 calls) and refused when it masks anything.
 
         embeds_prefix (with inputs_embeds): per prompt `(key, n)` - the caller's promise that prompts with the same key start with the
         same n embedding rows (Qwen-VL: '<img>' + the 256 image slots of one image, shared by its questions): they are prefilled once
@@ -822,6 +850,10 @@ class VddLlavaEngine:
         sampling, `put(next token)` after every step (vcd_sample.py:264-265: one device -> host copy per step) and `end()` at the
         end (:299-300).  One question per call, as HF's own streamers require."""
         dev, lm = self.device, self.cfg.lm
+        am = other.get("attention_mask")
+        if am is not None and not bool(torch.as_tensor(am).ne(0).all()):
+            raise ValueError("attention_mask with zeros: a left-padded [Q, L] id tensor would be decoded with its pad tokens as prompt - "
+                             "pass a list of per-question id tensors (ragged prompts are batched natively)")
         unknown = sorted(k for k in other if k not in self.IGNORED_GENERATE_KWARGS)
         if unknown:
             raise TypeError(f"generate() got unexpected keyword argument(s) {unknown}: not implemented by VddLlavaEngine "
@@ -896,10 +928,10 @@ class VddLlavaEngine:
                 chunk = [im.reshape(im.shape[-3:]).to(dev) for im in imgs_cd[i0:i0 + VisionTower.GRAPH_BATCH]]
                 feats_cd += list(self.vit(torch.stack(chunk)))
         if inputs_embeds is not None:
-            main_dev = [e.to(dev, torch.bfloat16) for e in emb_main]
+            main_dev = [e.to(dev, self.dtype) for e in emb_main]
             branches = [("main", ids_list, main_dev)]
             if use_cd:
-                branches.append(("cd", ids_list, [e.to(dev, torch.bfloat16) for e in emb_cd]))
+                branches.append(("cd", ids_list, [e.to(dev, self.dtype) for e in emb_cd]))
             elif use_dd_unk:
                 branches.append(("unk", ids_list, main_dev))
             elif use_dd:
@@ -1210,7 +1242,7 @@ class VddLlavaEngine:
         total = int(T.sum())
         for s, r in zip(segs, q0.tolist()):
             s["q_row0"] = r
-        x = torch.empty(total, self.cfg.lm.d, dtype=torch.bfloat16, device=dev)
+        x = torch.empty(total, self.cfg.lm.d, dtype=self.dtype, device=dev)
         id_chunks, row_chunks = [], []
         for s, r in zip(segs, q0.tolist()):
             if s.get("tokens") is not None and s["img"] is None:

@@ -12,30 +12,30 @@ from . import _lib
 
 _P, _I, _L, _F = C.c_void_p, C.c_int, C.c_int64, C.c_float
 _SIGS = {
-    "vdd_embed_scatter": [_P, _P, _P, _P, _I, _I, _I, _P],
-    "vdd_skinny_swiglu": [_P, _P, _P, _I, _I, _I, _L, _P],
-    "vdd_decode_attention_fused": [_P] * 11 + [_I, _I, _I, _I, _L, _I, _L, _I, _F, _P],
-    "vdd_decode_attention_fused_split": [_P] * 11 + [_I, _I, _I, _I, _L, _I, _L, _I, _F, _P, _I, _P],
-    "vdd_rmsnorm": [_P, _P, _P, _I, _P, _P, _P, _I, _I, _F, _P],
-    "vdd_gemm": [_P, _P, _P, _P, _P, _I, _I, _I, _L, _L, _L, _L, _I, _I, _P, _L, _P],
-    "vdd_rope_kv_write": [_P, _P, _P, _P, _P, _P, _P, _P, _I, _I, _I, _I, _L, _I, _P],
-    "vdd_silu_mul": [_P, _P, _L, _I, _P],
-    "vdd_embed": [_P, _P, _P, _I, _I, _I, _P],
-    "vdd_skinny_gemm": [_P, _P, _P, _P, _P, _I, _I, _I, _I, _L, _L, _L, _P],
-    "vdd_decode_attention": [_P, _P, _P, _P, _P, _P, _P, _P, _I, _I, _I, _I, _L, _I, _L, _I, _I, _F, _P],
-    "vdd_prefix_fragments": [_P, _P, _P, _P, _I, _I, _I, _I, _P],
-    "vdd_decode_attention_grouped": [_P, _P, _P, _P, _P, _P, _P, _P, _P, _P, _I, _P, _P, _I, _I, _I, _I, _L, _I, _L, _I, _I, _I, _I, _F, _P],
-    "vdd_flash_attention": [_P, _P, _P, _P, _P, _P, _P, _I, _I, _I, _I, _I, _L, _I, _L, _I, _F, _I, _P],
-    "vdd_flash_attention_packed": [_P, _P, _P, _P, _P, _P, _P, _P, _I, _I, _I, _I, _L, _I, _L, _I, _F, _P],
-    "vdd_layernorm": [_P, _P, _P, _P, _I, _I, _F, _P],
-    "vdd_bias_act": [_P, _P, _P, _L, _I, _I, _P],
-    "vdd_add": [_P, _P, _P, _L, _P],
-    "vdd_vit_im2col": [_P, _I, _P, _I, _I, _I, _I, _P],
-    "vdd_vit_assemble": [_P, _P, _P, _P, _I, _I, _I, _P],
-    "vdd_vit_qkv_split": [_P, _P, _P, _P, _I, _I, _I, _I, _L, _I, _I, _P],
-    "vdd_skinny_gemm_resid_ss": [_P, _P, _P, _P, _P, _I, _I, _I, _L, _L, _L, _P],
-    "vdd_skinny_gemm_normed": [_P, _P, _I, _P, _F, _P, _P, _I, _I, _I, _L, _L, _P],
-    "vdd_skinny_swiglu_normed": [_P, _P, _I, _P, _F, _P, _P, _I, _I, _I, _L, _P],
+    "vdd_embed_scatter": [_P, _P, _P, _P, _I, _I, _I, _I, _P],
+    "vdd_skinny_swiglu": [_P, _P, _P, _I, _I, _I, _L, _I, _P],
+    "vdd_decode_attention_fused": [_P] * 11 + [_I, _I, _I, _I, _L, _I, _L, _I, _F, _I, _P],
+    "vdd_decode_attention_fused_split": [_P] * 11 + [_I, _I, _I, _I, _L, _I, _L, _I, _F, _P, _I, _I, _P],
+    "vdd_rmsnorm": [_P, _P, _P, _I, _P, _P, _P, _I, _I, _F, _I, _P],
+    "vdd_gemm": [_P, _P, _P, _P, _P, _I, _I, _I, _L, _L, _L, _L, _I, _I, _P, _L, _I, _P],
+    "vdd_rope_kv_write": [_P, _P, _P, _P, _P, _P, _P, _P, _I, _I, _I, _I, _L, _I, _I, _P],
+    "vdd_silu_mul": [_P, _P, _L, _I, _I, _P],
+    "vdd_embed": [_P, _P, _P, _I, _I, _I, _I, _P],
+    "vdd_skinny_gemm": [_P, _P, _P, _P, _P, _I, _I, _I, _I, _L, _L, _L, _I, _P],
+    "vdd_decode_attention": [_P, _P, _P, _P, _P, _P, _P, _P, _I, _I, _I, _I, _L, _I, _L, _I, _I, _F, _I, _P],
+    "vdd_prefix_fragments": [_P, _P, _P, _P, _I, _I, _I, _I, _I, _P],
+    "vdd_decode_attention_grouped": [_P, _P, _P, _P, _P, _P, _P, _P, _P, _P, _I, _P, _P, _I, _I, _I, _I, _L, _I, _L, _I, _I, _I, _I, _F, _I, _P],
+    "vdd_flash_attention": [_P, _P, _P, _P, _P, _P, _P, _I, _I, _I, _I, _I, _L, _I, _L, _I, _F, _I, _I, _P],
+    "vdd_flash_attention_packed": [_P, _P, _P, _P, _P, _P, _P, _P, _I, _I, _I, _I, _L, _I, _L, _I, _F, _I, _P],
+    "vdd_layernorm": [_P, _P, _P, _P, _I, _I, _F, _I, _P],
+    "vdd_bias_act": [_P, _P, _P, _L, _I, _I, _I, _P],
+    "vdd_add": [_P, _P, _P, _L, _I, _P],
+    "vdd_vit_im2col": [_P, _I, _P, _I, _I, _I, _I, _I, _P],
+    "vdd_vit_assemble": [_P, _P, _P, _P, _I, _I, _I, _I, _P],
+    "vdd_vit_qkv_split": [_P, _P, _P, _P, _I, _I, _I, _I, _L, _I, _I, _I, _P],
+    "vdd_skinny_gemm_resid_ss": [_P, _P, _P, _P, _P, _I, _I, _I, _L, _L, _L, _I, _P],
+    "vdd_skinny_gemm_normed": [_P, _P, _I, _P, _F, _P, _P, _I, _I, _I, _L, _L, _I, _P],
+    "vdd_skinny_swiglu_normed": [_P, _P, _I, _P, _F, _P, _P, _I, _I, _I, _L, _I, _P],
     "vdd_stop_words_match": [_P, _L, _L, _P, _P, _I, _P, _P, _I, _P, _I, _P],
     "vdd_repetition_penalty": [_P, _L, _I, _I, _I, _P, _I, _P, _L, _L, _P, _F, C.c_uint32, _P],
 }
@@ -58,16 +58,30 @@ def _st(t: torch.Tensor):
     return torch.cuda.current_stream(t.device).cuda_stream
 
 
-def _bf16(*ts):
+_MODEL_DT = {torch.bfloat16: _lib.VDD_BF16, torch.float16: _lib.VDD_F16}
+
+
+def _dt(*ts):
+    """The storage type of a model-kernel call (the `dtype` argument of the C ABI): every tensor of the call is a device tensor of ONE
+    16-bit float type - bf16 (BASELINE config #2) or fp16 (what the reference's drivers load: builder.py:40)."""
+    dt = None
     for t in ts:
-        if t is not None and (t.dtype != torch.bfloat16 or not t.is_cuda):
-            raise ValueError("model kernels take bf16 device tensors")
+        if t is None:
+            continue
+        if not t.is_cuda or t.dtype not in _MODEL_DT:
+            raise ValueError("model kernels take bf16 or fp16 device tensors")
+        if dt is not None and t.dtype != dt:
+            raise ValueError(f"model kernels take tensors of one dtype per call (got {dt} and {t.dtype})")
+        dt = t.dtype
+    if dt is None:
+        raise ValueError("model kernels take bf16 or fp16 device tensors")
+    return _MODEL_DT[dt]
 
 
 def rmsnorm(x, w, eps, delta=None, resid_out=None, out=None):
     """h = x (+ delta); resid_out <- h; returns h * rsqrt(mean h^2 + eps) * w.   x: [M, d].
     delta: bf16 [M, d], or fp32 [S, M, d] split-K slabs from skinny_gemm(..., n_split=S, slabs=True)."""
-    _bf16(x, w, resid_out)
+    dt = _dt(x, w, resid_out)
     M, d = x.shape
     out = torch.empty_like(x) if out is None else out
     dptr = sptr = None
@@ -78,48 +92,48 @@ def rmsnorm(x, w, eps, delta=None, resid_out=None, out=None):
                 raise ValueError("fp32 delta must be contiguous [n_slabs, M, d]")
             sptr, ns = delta.data_ptr(), delta.shape[0]
         else:
-            _bf16(delta)
+            _dt(delta, x)
             dptr = delta.data_ptr()
     _lib.check(_lib_ready().vdd_rmsnorm(x.data_ptr(), dptr, sptr, ns, w.data_ptr(), out.data_ptr(),
-                                        resid_out.data_ptr() if resid_out is not None else None, M, d, eps, _st(x)))
+                                        resid_out.data_ptr() if resid_out is not None else None, M, d, eps, dt, _st(x)))
     return out
 
 
 def rope_kv_write(qkv, pos, slot, cos_sin, k_cache, v_cache, Hq, Hkv, D, q_out=None, cpos=None):
     """qkv [M, (Hq+2Hkv)*D]; pos/slot int32 [M]; caches [n_slots, Hkv, t_max, D]; cpos = index inside the slot
     (default: pos).  Returns rotated q [M, Hq*D]."""
-    _bf16(qkv, k_cache, v_cache)
+    dt = _dt(qkv, k_cache, v_cache)
     M = qkv.shape[0]
     q_out = torch.empty(M, Hq * D, dtype=qkv.dtype, device=qkv.device) if q_out is None else q_out
     cpos = pos if cpos is None else cpos
     _lib.check(_lib_ready().vdd_rope_kv_write(qkv.data_ptr(), pos.data_ptr(), cpos.data_ptr(), slot.data_ptr(), cos_sin.data_ptr(), q_out.data_ptr(),
                                               k_cache.data_ptr(), v_cache.data_ptr(), M, Hq, Hkv, D, k_cache.stride(0),
-                                              k_cache.shape[2], _st(qkv)))
+                                              k_cache.shape[2], dt, _st(qkv)))
     return q_out
 
 
 def silu_mul(gate_up, out=None):
-    _bf16(gate_up)
+    dt = _dt(gate_up)
     M, F2 = gate_up.shape
     out = torch.empty(M, F2 // 2, dtype=gate_up.dtype, device=gate_up.device) if out is None else out
-    _lib.check(_lib_ready().vdd_silu_mul(gate_up.data_ptr(), out.data_ptr(), M, F2 // 2, _st(gate_up)))
+    _lib.check(_lib_ready().vdd_silu_mul(gate_up.data_ptr(), out.data_ptr(), M, F2 // 2, dt, _st(gate_up)))
     return out
 
 
 def embed(ids, table, out=None):
-    _bf16(table)
+    dt = _dt(table)
     M, d = ids.numel(), table.shape[1]
     out = torch.empty(M, d, dtype=table.dtype, device=table.device) if out is None else out
-    _lib.check(_lib_ready().vdd_embed(ids.data_ptr(), table.data_ptr(), out.data_ptr(), M, d, table.shape[0], _st(table)))
+    _lib.check(_lib_ready().vdd_embed(ids.data_ptr(), table.data_ptr(), out.data_ptr(), M, d, table.shape[0], dt, _st(table)))
     return out
 
 
 def embed_scatter(ids, rows, table, out):
     """out[rows[m]] = table[ids[m]] (int32 ids / rows): the text chunks of a packed multimodal prompt, in place."""
-    _bf16(table, out)
+    dt = _dt(table, out)
     if ids.dtype != torch.int32 or rows.dtype != torch.int32 or ids.numel() != rows.numel():
         raise ValueError("embed_scatter takes int32 ids and rows of equal length")
-    _lib.check(_lib_ready().vdd_embed_scatter(ids.data_ptr(), rows.data_ptr(), table.data_ptr(), out.data_ptr(), ids.numel(), table.shape[1], table.shape[0], _st(table)))
+    _lib.check(_lib_ready().vdd_embed_scatter(ids.data_ptr(), rows.data_ptr(), table.data_ptr(), out.data_ptr(), ids.numel(), table.shape[1], table.shape[0], dt, _st(table)))
     return out
 
 
@@ -128,16 +142,16 @@ def skinny_gemm(x, w, resid=None, out=None, n_split=1, slabs=False):
     slabs=True: returns the fp32 split-K partials [n_split, M, N] instead (feed them to rmsnorm as `delta`)."""
     N = w.shape[0]
     fn = _lib_ready().vdd_skinny_gemm
-    _bf16(x, w, resid)
+    dt = _dt(x, w, resid)
     M, K = x.shape
     if slabs:
         out = torch.empty(n_split, M, N, dtype=torch.float32, device=x.device) if out is None else out
-        _lib.check(fn(x.data_ptr(), w.data_ptr(), None, None, out.data_ptr(), n_split, M, N, K, x.stride(0), 0, N, _st(x)))
+        _lib.check(fn(x.data_ptr(), w.data_ptr(), None, None, out.data_ptr(), n_split, M, N, K, x.stride(0), 0, N, dt, _st(x)))
         return out
     out = torch.empty(M, N, dtype=x.dtype, device=x.device) if out is None else out
     _lib.check(fn(x.data_ptr(), w.data_ptr(), resid.data_ptr() if resid is not None else None,
                   out.data_ptr(), None, 1, M, N, K, x.stride(0), resid.stride(0) if resid is not None else 0,
-                  out.stride(0), _st(x)))
+                  out.stride(0), dt, _st(x)))
     return out
 
 
@@ -161,34 +175,34 @@ def norm_fused_rows(d: int) -> int:
 def linear_resid_ss(x, w, resid, out=None, ss=None):
     """h = bf16(bf16(x w^T) + resid) (the new residual stream) and ss [M, N/16] fp32: per-block partial sums of squares of h's rows,
     for linear_normed / swiglu_linear_normed.  M <= NORM_FUSED_MAX_M."""
-    _bf16(x, w, resid)
+    dt = _dt(x, w, resid)
     M, K = x.shape
     N = w.shape[0]
     out = torch.empty(M, N, dtype=x.dtype, device=x.device) if out is None else out
     ss = torch.empty(M, (N + 15) // 16, dtype=torch.float32, device=x.device) if ss is None else ss
     _lib.check(_lib_ready().vdd_skinny_gemm_resid_ss(x.data_ptr(), w.data_ptr(), resid.data_ptr(), out.data_ptr(), ss.data_ptr(), M, N, K,
-                                                     x.stride(0), resid.stride(0), out.stride(0), _st(x)))
+                                                     x.stride(0), resid.stride(0), out.stride(0), dt, _st(x)))
     return out, ss
 
 
 def linear_normed(h, ss, ln_w, eps, w, out=None, bias=None):
     """rmsnorm(h; ln_w, eps) @ w^T with the normalisation done as h's fragments load (h, ss from linear_resid_ss)."""
-    _bf16(h, w, ln_w)
+    dt = _dt(h, w, ln_w)
     M, K = h.shape
     N = w.shape[0]
     out = torch.empty(M, N, dtype=h.dtype, device=h.device) if out is None else out
     _lib.check(_lib_ready().vdd_skinny_gemm_normed(h.data_ptr(), ss.data_ptr(), ss.shape[1], ln_w.data_ptr(), eps, w.data_ptr(), out.data_ptr(),
-                                                   M, N, K, h.stride(0), out.stride(0), _st(h)))
+                                                   M, N, K, h.stride(0), out.stride(0), dt, _st(h)))
     return bias_act(out, bias, out=out) if bias is not None else out
 
 
 def swiglu_linear_normed(h, ss, ln_w, eps, w_gate_up, out=None):
-    _bf16(h, w_gate_up, ln_w)
+    dt = _dt(h, w_gate_up, ln_w)
     M, K = h.shape
     F = w_gate_up.shape[0] // 2
     out = torch.empty(M, F, dtype=h.dtype, device=h.device) if out is None else out
     _lib.check(_lib_ready().vdd_skinny_swiglu_normed(h.data_ptr(), ss.data_ptr(), ss.shape[1], ln_w.data_ptr(), eps, w_gate_up.data_ptr(),
-                                                     out.data_ptr(), M, F, K, h.stride(0), _st(h)))
+                                                     out.data_ptr(), M, F, K, h.stride(0), dt, _st(h)))
     return out
 
 
@@ -245,15 +259,16 @@ def gemm_workspace_reset(device=None):
 
 
 def _gemm_call(x, w, out, bias, resid, M, N, K, epi, config, ws):
+    dt = _MODEL_DT[x.dtype]                                   # (gemm() has checked the operands)
     _lib.check(_lib_ready().vdd_gemm(x.data_ptr(), w.data_ptr(), out.data_ptr(), bias.data_ptr() if bias is not None else None,
                                      resid.data_ptr() if resid is not None else None, M, N, K, x.stride(0), w.stride(0), out.stride(0),
-                                     resid.stride(0) if resid is not None else 0, epi, config, ws.data_ptr(), ws.numel(), _st(x)))
+                                     resid.stride(0) if resid is not None else 0, epi, config, ws.data_ptr(), ws.numel(), dt, _st(x)))
 
 
 def gemm(x, w, bias=None, resid=None, epi=EPI_NONE, out=None, config=None):
-    """out[M, N] = epilogue(x[M, K] @ w[N, K]^T) on the hand-written MFMA kernel (bf16, fp32 accumulate).  epi=EPI_SWIGLU:
+    """out[M, N] = epilogue(x[M, K] @ w[N, K]^T) on the hand-written MFMA kernel (bf16 or fp16 operands, fp32 accumulate).  epi=EPI_SWIGLU:
     w = [Wgate; Wup], N = w.shape[0] // 2.  No library fallback: unsupported shapes raise."""
-    _bf16(x, w, bias, resid)
+    dt = _dt(x, w, bias, resid)
     M, K = x.shape
     N = w.shape[0] // 2 if epi == EPI_SWIGLU else w.shape[0]
     if K % 128 != 0 or N % 4 != 0 or x.stride(1) != 1 or w.stride(1) != 1:
@@ -263,7 +278,7 @@ def gemm(x, w, bias=None, resid=None, epi=EPI_NONE, out=None, config=None):
         return out
     ws = _gemm_workspace(x.device, M, N)
     if config is None:
-        key = _gemm_key(M, N, K, epi)
+        key = _gemm_key(M, N, K, epi, dt)
         config = _gemm_choice.get(key)
         if config is None:
             config = 1 + 16 if GEMM_BATCH_INVARIANT else 1
@@ -280,11 +295,11 @@ def gemm(x, w, bias=None, resid=None, epi=EPI_NONE, out=None, config=None):
 GEMM_AUTOTUNE = True            # False: 256 x 256 tiles + the hybrid schedule for every shape (no timing runs at all)
 
 
-def _gemm_key(M, N, K, epi):
+def _gemm_key(M, N, K, epi, dt=_lib.VDD_BF16):
     """Tuning granularity: shapes up to GEMM_TUNE_MAX_M rows are bucketed by their number of 64-row units (the decode batch and
     the per-image ViT calls repeat a handful of sizes; a prefill length that differs by a few tokens must not re-run 24 candidates
     and clone 640 MiB of weights); everything above shares one entry."""
-    return (-(-M // 64) if M <= GEMM_TUNE_MAX_M else 0, N, K, epi, GEMM_BATCH_INVARIANT)
+    return (-(-M // 64) if M <= GEMM_TUNE_MAX_M else 0, N, K, epi, GEMM_BATCH_INVARIANT, dt)
 
 
 def gemm_choices_export() -> dict:
@@ -297,8 +312,8 @@ def gemm_choices_export() -> dict:
 
 def gemm_choices_import(d: dict):
     for k, v in d.items():
-        b, N, K, epi, inv = k.split(",")
-        _gemm_choice[(int(b), int(N), int(K), int(epi), inv == "True")] = int(v)
+        b, N, K, epi, inv, *dt = k.split(",")
+        _gemm_choice[(int(b), int(N), int(K), int(epi), inv == "True", int(dt[0]) if dt else _lib.VDD_BF16)] = int(v)
 
 
 def _gemm_tune(x, w, out, bias, resid, M, N, K, epi, ws, iters=8):
@@ -356,9 +371,9 @@ def swiglu_linear(x, w_gate_up, out=None):
     M, K = x.shape
     F = w_gate_up.shape[0] // 2
     if M <= min(16, skinny_rows(2 * F, K)) and K % 128 == 0:          # the fused kernel holds one 16-row MFMA tile
-        _bf16(x, w_gate_up)
+        dt = _dt(x, w_gate_up)
         out = torch.empty(M, F, dtype=x.dtype, device=x.device) if out is None else out
-        _lib.check(_lib_ready().vdd_skinny_swiglu(x.data_ptr(), w_gate_up.data_ptr(), out.data_ptr(), M, F, K, x.stride(0), _st(x)))
+        _lib.check(_lib_ready().vdd_skinny_swiglu(x.data_ptr(), w_gate_up.data_ptr(), out.data_ptr(), M, F, K, x.stride(0), dt, _st(x)))
         return out
     if F % 128 == 0:
         return gemm(x, w_gate_up, epi=EPI_SWIGLU, out=out)
@@ -371,7 +386,7 @@ _attn_ws = {}
 def decode_attention(q, k_cache, v_cache, rows, H, Hkv, D, out=None, max_len=None, k_prefix=None, v_prefix=None, workspace=None):
     """q [M, H*D]; rows int32 [M, 4] = (slot, len, prefix_slot, prefix_len); max_len bounds every len.
     k_prefix/v_prefix: separate pool holding the shared prefixes (default: the same buffers, index t)."""
-    _bf16(q, k_cache, v_cache)
+    dt = _dt(q, k_cache, v_cache)
     M = q.shape[0]
     lib = _lib_ready()
     k_prefix = k_cache if k_prefix is None else k_prefix
@@ -392,7 +407,7 @@ def decode_attention(q, k_cache, v_cache, rows, H, Hkv, D, out=None, max_len=Non
     out = torch.empty_like(q) if out is None else out
     _lib.check(lib.vdd_decode_attention(q.data_ptr(), k_cache.data_ptr(), v_cache.data_ptr(), k_prefix.data_ptr(), v_prefix.data_ptr(),
                                         rows.data_ptr(), out.data_ptr(), ws.data_ptr(), M, H, Hkv, D, k_cache.stride(0), k_cache.shape[2],
-                                        k_prefix.stride(0), k_prefix.shape[2], max_len, D ** -0.5, _st(q)))
+                                        k_prefix.stride(0), k_prefix.shape[2], max_len, D ** -0.5, dt, _st(q)))
     return out
 
 
@@ -430,7 +445,7 @@ def decode_attention_fused(qkv, pos, cpos, slot, cos_sin, k_cache, v_cache, rows
     token (index cpos of slot), whole-context attention and merge in one kernel.  Same arguments as rope_kv_write +
     decode_attention; rows[:, 1] (len) counts the new token.  n_split (default: fused_attention_split(M, H)) > 1 cuts the old keys of
     every (row, head) over that many workgroups; the last one to finish merges their partials in slice order."""
-    _bf16(qkv, k_cache, v_cache)
+    dt = _dt(qkv, k_cache, v_cache)
     M = qkv.shape[0]
     k_prefix = k_cache if k_prefix is None else k_prefix
     v_prefix = v_cache if v_prefix is None else v_prefix
@@ -441,12 +456,12 @@ def decode_attention_fused(qkv, pos, cpos, slot, cos_sin, k_cache, v_cache, rows
         _lib.check(_lib_ready().vdd_decode_attention_fused_split(qkv.data_ptr(), pos.data_ptr(), cpos.data_ptr(), slot.data_ptr(), cos_sin.data_ptr(),
                                                                 k_cache.data_ptr(), v_cache.data_ptr(), k_prefix.data_ptr(), v_prefix.data_ptr(),
                                                                 rows.data_ptr(), out.data_ptr(), M, H, Hkv, D, k_cache.stride(0), k_cache.shape[2],
-                                                                k_prefix.stride(0), k_prefix.shape[2], D ** -0.5, ws.data_ptr(), n_split, _st(qkv)))
+                                                                k_prefix.stride(0), k_prefix.shape[2], D ** -0.5, ws.data_ptr(), n_split, dt, _st(qkv)))
         return out
     _lib.check(_lib_ready().vdd_decode_attention_fused(qkv.data_ptr(), pos.data_ptr(), cpos.data_ptr(), slot.data_ptr(), cos_sin.data_ptr(),
                                                       k_cache.data_ptr(), v_cache.data_ptr(), k_prefix.data_ptr(), v_prefix.data_ptr(),
                                                       rows.data_ptr(), out.data_ptr(), M, H, Hkv, D, k_cache.stride(0), k_cache.shape[2],
-                                                      k_prefix.stride(0), k_prefix.shape[2], D ** -0.5, _st(qkv)))
+                                                      k_prefix.stride(0), k_prefix.shape[2], D ** -0.5, dt, _st(qkv)))
     return out
 
 
@@ -480,19 +495,19 @@ def prefix_work_items(groups, chunks_per_item=1):
 def prefix_fragments(k_prefix, v_prefix, prefix_frag, prefix_len_of_slot):
     """k_prefix / v_prefix [n_slots, Hkv, t_max, D] -> prefix_frag [n_slots, Hkv, 2 * t_max, D]: per 64-key chunk one 32-KiB block of
     MFMA operand images (16 K fragments, 16 V^T fragments) for the grouped decode pass."""
-    _bf16(k_prefix, v_prefix, prefix_frag)
+    dt = _dt(k_prefix, v_prefix, prefix_frag)
     n, Hkv, t_max, D = k_prefix.shape
     if tuple(prefix_frag.shape) != (n, Hkv, 2 * t_max, D) or v_prefix.shape != k_prefix.shape or not prefix_frag.is_contiguous():
         raise ValueError("prefix_frag must be a contiguous [n_slots, Hkv, 2 * t_max, D] tensor")
     _lib.check(_lib_ready().vdd_prefix_fragments(k_prefix.data_ptr(), v_prefix.data_ptr(), prefix_frag.data_ptr(), prefix_len_of_slot.data_ptr(),
-                                                 prefix_len_of_slot.numel(), Hkv, t_max, D, _st(k_prefix)))
+                                                 prefix_len_of_slot.numel(), Hkv, t_max, D, dt, _st(k_prefix)))
     return prefix_frag
 
 
 def decode_attention_grouped(q, k_cache, v_cache, k_prefix, v_prefix, rows, groups, group_rows, items, n_items,
                              H, Hkv, D, max_prefix_len, max_own_len, out=None, workspace=None, prefix_frag=None, chunks_per_item=1, scale=None):
     """decode_attention with the shared prefixes attended once per group of rows (MFMA over the group's queries)."""
-    _bf16(q, k_cache, v_cache, k_prefix, v_prefix)
+    dt = _dt(q, k_cache, v_cache, k_prefix, v_prefix)
     M = q.shape[0]
     lib = _lib_ready()
     r64 = lambda v: (int(v) + 63) // 64 * 64
@@ -509,7 +524,7 @@ def decode_attention_grouped(q, k_cache, v_cache, k_prefix, v_prefix, rows, grou
                                                 prefix_frag.data_ptr() if prefix_frag is not None else None, rows.data_ptr(), groups.data_ptr(), group_rows.data_ptr(), items.data_ptr(), n_items,
                                                 out.data_ptr(), ws.data_ptr(), M, H, Hkv, D, k_cache.stride(0), k_cache.shape[2],
                                                 k_prefix.stride(0), k_prefix.shape[2], int(max_prefix_len), int(max_own_len),
-                                                int(chunks_per_item), D ** -0.5 if scale is None else scale, _st(q)))
+                                                int(chunks_per_item), D ** -0.5 if scale is None else scale, dt, _st(q)))
     return out
 
 
@@ -517,14 +532,14 @@ def flash_attention(q, k_cache, v_cache, seqs, n_seq, max_tq, H, Hkv, D, causal=
     """Prefill attention.  q [Ttot, H*D] packed by sequence; seqs int32 [n_seq, 6] =
     (q_row0, Tq, pos0, slot, prefix_slot, prefix_len): query i of a sequence sits at position pos0+i and
     attends keys [0, pos0+i] (causal) or [0, pos0+Tq) (non-causal) of its slot / prefix slot."""
-    _bf16(q, k_cache, v_cache)
+    dt = _dt(q, k_cache, v_cache)
     out = torch.empty_like(q) if out is None else out
     k_prefix = k_cache if k_prefix is None else k_prefix
     v_prefix = v_cache if v_prefix is None else v_prefix
     _lib.check(_lib_ready().vdd_flash_attention(q.data_ptr(), k_cache.data_ptr(), v_cache.data_ptr(), k_prefix.data_ptr(), v_prefix.data_ptr(),
                                                 seqs.data_ptr(), out.data_ptr(), n_seq, max_tq, H, Hkv, D, k_cache.stride(0),
                                                 k_cache.shape[2], k_prefix.stride(0), k_prefix.shape[2], D ** -0.5 if scale is None else float(scale),
-                                                1 if causal else 0, _st(q)))
+                                                1 if causal else 0, dt, _st(q)))
     return out
 
 
@@ -545,22 +560,22 @@ def flash_packs(seq_rows, max_per_pack=4):
 def flash_attention_packed(q, k_cache, v_cache, seqs, packs, n_packs, H, Hkv, D, out=None, k_prefix=None, v_prefix=None, scale=None):
     """flash_attention (causal) for sequences of at most 32 query rows that continue shared prefixes, four to a workgroup:
     packs int32 [n_packs, 4] from flash_packs().  The tiles inside the prefix are staged once per pack, not once per sequence."""
-    _bf16(q, k_cache, v_cache)
+    dt = _dt(q, k_cache, v_cache)
     out = torch.empty_like(q) if out is None else out
     k_prefix = k_cache if k_prefix is None else k_prefix
     v_prefix = v_cache if v_prefix is None else v_prefix
     _lib.check(_lib_ready().vdd_flash_attention_packed(q.data_ptr(), k_cache.data_ptr(), v_cache.data_ptr(), k_prefix.data_ptr(), v_prefix.data_ptr(),
                                                        seqs.data_ptr(), packs.data_ptr(), out.data_ptr(), n_packs, H, Hkv, D, k_cache.stride(0),
                                                        k_cache.shape[2], k_prefix.stride(0), k_prefix.shape[2],
-                                                       D ** -0.5 if scale is None else float(scale), _st(q)))
+                                                       D ** -0.5 if scale is None else float(scale), dt, _st(q)))
     return out
 
 
 def layernorm(x, w, b, eps, out=None):
-    _bf16(x, w, b)
+    dt = _dt(x, w, b)
     M, d = x.shape
     out = torch.empty_like(x) if out is None else out
-    _lib.check(_lib_ready().vdd_layernorm(x.data_ptr(), w.data_ptr(), b.data_ptr(), out.data_ptr(), M, d, eps, _st(x)))
+    _lib.check(_lib_ready().vdd_layernorm(x.data_ptr(), w.data_ptr(), b.data_ptr(), out.data_ptr(), M, d, eps, dt, _st(x)))
     return out
 
 
@@ -569,54 +584,55 @@ ACT_NONE, ACT_QUICK_GELU, ACT_GELU = 0, 1, 2
 
 def bias_act(x, bias, act=ACT_NONE, out=None):
     """out = act(x + bias) rowwise; bias may be None."""
-    _bf16(x, bias)
+    dt = _dt(x, bias)
     M, d = x.shape
     out = torch.empty_like(x) if out is None else out
-    _lib.check(_lib_ready().vdd_bias_act(x.data_ptr(), bias.data_ptr() if bias is not None else None, out.data_ptr(), M, d, act, _st(x)))
+    _lib.check(_lib_ready().vdd_bias_act(x.data_ptr(), bias.data_ptr() if bias is not None else None, out.data_ptr(), M, d, act, dt, _st(x)))
     return out
 
 
 _IMG_DT = {torch.float32: _lib.VDD_F32, torch.float16: _lib.VDD_F16, torch.bfloat16: _lib.VDD_BF16}
 
 
-def vit_im2col(images, patch, k_pad, out=None):
-    """images [n, 3, S, S] (fp32 / fp16 / bf16, device) -> bf16 patches [n * (S/patch)^2, k_pad] (zero padded columns)."""
+def vit_im2col(images, patch, k_pad, out=None, dtype=torch.bfloat16):
+    """images [n, 3, S, S] (fp32 / fp16 / bf16, device) -> patches [n * (S/patch)^2, k_pad] of the model `dtype` (zero padded columns)."""
     if not images.is_cuda or images.dtype not in _IMG_DT or not images.is_contiguous():
         raise ValueError("vit_im2col takes a contiguous fp32 / fp16 / bf16 device tensor [n, 3, S, S]")
     n, _, S, _ = images.shape
     G = S // patch
-    out = torch.empty(n * G * G, k_pad, dtype=torch.bfloat16, device=images.device) if out is None else out
-    _lib.check(_lib_ready().vdd_vit_im2col(images.data_ptr(), _IMG_DT[images.dtype], out.data_ptr(), n, S, patch, k_pad, _st(images)))
+    out = torch.empty(n * G * G, k_pad, dtype=dtype, device=images.device) if out is None else out
+    dt = _dt(out)
+    _lib.check(_lib_ready().vdd_vit_im2col(images.data_ptr(), _IMG_DT[images.dtype], out.data_ptr(), n, S, patch, k_pad, dt, _st(images)))
     return out
 
 
 def vit_assemble(emb, cls, pos, n, T, out=None):
     """h[i, t] = (cls if t == 0 else emb[i * (T - 1) + t - 1]) + pos[t]  ->  [n * T, width]."""
-    _bf16(emb, cls, pos)
+    dt = _dt(emb, cls, pos)
     w = emb.shape[1]
     out = torch.empty(n * T, w, dtype=emb.dtype, device=emb.device) if out is None else out
-    _lib.check(_lib_ready().vdd_vit_assemble(emb.data_ptr(), cls.data_ptr(), pos.data_ptr(), out.data_ptr(), n, T, w, _st(emb)))
+    _lib.check(_lib_ready().vdd_vit_assemble(emb.data_ptr(), cls.data_ptr(), pos.data_ptr(), out.data_ptr(), n, T, w, dt, _st(emb)))
     return out
 
 
 def vit_qkv_split(qkv, k_cache, v_cache, n, T, H, D, q_out=None, kv_only=False):
     """qkv [n * T, 3 * H * D] -> q [n * T, H * D]; K / V written to caches [>= n, H, t_max, D] (or views of them starting at a later
     token).  kv_only: the input is a fused [k, v] projection [n * T, 2 * H * D] (cross-attention); returns None."""
-    _bf16(qkv, k_cache, v_cache)
+    dt = _dt(qkv, k_cache, v_cache)
     if not kv_only:
         q_out = torch.empty(n * T, H * D, dtype=qkv.dtype, device=qkv.device) if q_out is None else q_out
     _lib.check(_lib_ready().vdd_vit_qkv_split(qkv.data_ptr(), q_out.data_ptr() if not kv_only else None, k_cache.data_ptr(), v_cache.data_ptr(),
-                                              n, T, H, D, k_cache.stride(0), k_cache.stride(1) // D, 2 if kv_only else 3, _st(qkv)))
+                                              n, T, H, D, k_cache.stride(0), k_cache.stride(1) // D, 2 if kv_only else 3, dt, _st(qkv)))
     return None if kv_only else q_out
 
 
 def add(a, b, out=None):
-    """out = a + b (bf16, same shape, contiguous)."""
-    _bf16(a, b)
+    """out = a + b (one dtype, same shape, contiguous)."""
+    dt = _dt(a, b)
     if a.shape != b.shape or not a.is_contiguous() or not b.is_contiguous():
         raise ValueError("add takes two contiguous tensors of one shape")
     out = torch.empty_like(a) if out is None else out
-    _lib.check(_lib_ready().vdd_add(a.data_ptr(), b.data_ptr(), out.data_ptr(), a.numel(), _st(a)))
+    _lib.check(_lib_ready().vdd_add(a.data_ptr(), b.data_ptr(), out.data_ptr(), a.numel(), dt, _st(a)))
     return out
 
 

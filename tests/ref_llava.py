@@ -14,17 +14,19 @@ from toy_lm import IMAGE_TOKEN_INDEX, _Proto, _gen_cfg
 
 
 class RefLlava(_Proto):
-    def __init__(self, weights, device="cpu", logit_dtype=torch.bfloat16, pad=0, eos=None, dtype=torch.float32,
-                 output_attentions=False, logits_on_device=False):
+    def __init__(self, weights, device="cpu", logit_dtype=None, pad=0, eos=None, dtype=torch.float32,
+                 output_attentions=False, logits_on_device=False, store=None):
         """dtype=float32: numerics reference.  dtype=bfloat16/float16: what the reference's eager HF stack executes
         (weights and matmuls in the model dtype, fp32 softmax / norm statistics, KV cache grown by torch.cat)."""
         self.cfg = weights.cfg
         self.dtype = dtype
+        # what the engine under test stores pixels / embeddings in (its weights' dtype): inputs are rounded through it first
+        self.store = store if store is not None else (weights.dtype if getattr(weights, "dtype", None) in (torch.bfloat16, torch.float16) else torch.bfloat16)
         self.logits_on_device = logits_on_device              # the eager GPU pipeline keeps the logits where they were computed
         self.materialize_attn = output_attentions            # llava_calibrate.py:175 asks for the [H, T, S] maps every step
         self.w = {k: v.detach().to(device=device, dtype=dtype) for k, v in weights.t.items()}
         self.device = torch.device(device)
-        self.logit_dtype = logit_dtype
+        self.logit_dtype = logit_dtype if logit_dtype is not None else self.store      # the model dtype (vcd_sample.py:119 reads outputs.logits)
         self.generation_config = _gen_cfg(pad, eos)
         lm = self.cfg.lm
         inv = 1.0 / (lm.rope_theta ** (torch.arange(0, lm.head_dim, 2, dtype=torch.float32) / lm.head_dim))
@@ -35,7 +37,7 @@ class RefLlava(_Proto):
     # ---- vision ----
     def encode_images(self, images):
         v, w = self.cfg.vision, self.w
-        x = images.to(self.device, torch.bfloat16).to(self.dtype)
+        x = images.to(self.device, self.store).to(self.dtype)
         n = x.shape[0]
         P, G = v.patch, v.image // v.patch
         patches = x.view(n, 3, G, P, G, P).permute(0, 2, 4, 1, 3, 5).reshape(n, G * G, 3 * P * P)
@@ -107,7 +109,7 @@ class RefLlava(_Proto):
         past_len = int(past_key_values[0][0].shape[-2]) if past_key_values else 0
         if inputs_embeds is not None:                           # LAVIS Llama (modeling_llama.py:764-792): prompt as embeddings
             self.calls.append((tuple(inputs_embeds.shape[:2]), False, past_len))
-            emb = inputs_embeds.to(self.device, torch.bfloat16).to(self.dtype)
+            emb = inputs_embeds.to(self.device, self.store).to(self.dtype)
             logits, past = self._lm(emb, past_key_values)
             return SimpleNamespace(logits=logits.to(self.logit_dtype) if self.logits_on_device else logits.to(self.logit_dtype).cpu(), past_key_values=past, attentions=None, hidden_states=None)
         ids = input_ids.to(self.device)
@@ -119,7 +121,7 @@ class RefLlava(_Proto):
             s = int(torch.where(row == IMAGE_TOKEN_INDEX)[0][0])
             feat = self.encode_images(images)[0]
             emb = torch.cat([self.w["embed"][row[:s]], feat, self.w["embed"][row[s + 1:]]], 0)[None]
-        emb = emb.to(torch.bfloat16).to(self.dtype)
+        emb = emb.to(self.store).to(self.dtype)
         logits, past = self._lm(emb, past_key_values)
         return SimpleNamespace(logits=logits.to(self.logit_dtype) if self.logits_on_device else logits.to(self.logit_dtype).cpu(), past_key_values=past, attentions=None, hidden_states=None)
 

@@ -24,7 +24,7 @@ def declared_functions():
     for fn in os.listdir(os.path.join(ROOT, "include")):
         src = open(os.path.join(ROOT, "include", fn)).read()
         src = re.sub(r"/\*.*?\*/", "", src, flags=re.S)
-        names += re.findall(r"^\s*(?:const\s+)?(?:int|void|char\s*\*|const char\s*\*)\s*\*?\s*(vdd_\w+)\s*\(", src, flags=re.M)
+        names += re.findall(r"^\s*(?:const\s+)?(?:int64_t|int|void|char\s*\*|const char\s*\*)\s*\*?\s*(vdd_\w+)\s*\(", src, flags=re.M)
     return sorted(set(names))
 
 
@@ -35,9 +35,54 @@ def test_exports_every_declared_symbol(lib):
         assert hasattr(lib, n), f"{n} declared in include/ but not exported"
 
 
+def test_exports_nothing_but_the_declared_symbols(lib):
+    """The per-dtype instantiations (`*_bf16` / `*_f16`, csrc/vdd_elem.h) are hidden: the dynamic symbol table holds the header's
+    entries and nothing else."""
+    from llava_align_amd._lib import lib_path
+    out = subprocess.run(["nm", "-D", "--defined-only", lib_path()], check=True, capture_output=True, text=True).stdout
+    exported = sorted(l.split()[2] for l in out.splitlines() if len(l.split()) == 3 and l.split()[1] == "T" and l.split()[2].startswith("vdd_"))
+    assert exported == declared_functions()
+
+
+def _declared_params():
+    """name -> list of parameter declarations of every function in include/vdd_hip.h."""
+    src = open(os.path.join(ROOT, "include", "vdd_hip.h")).read()
+    src = re.sub(r"/\*.*?\*/", "", src, flags=re.S)
+    out = {}
+    for m in re.finditer(r"^\s*(?:int64_t|int)\s+(vdd_\w+)\s*\((.*?)\)\s*;", src, flags=re.M | re.S):
+        out[m.group(1)] = [a.strip() for a in m.group(2).split(",")]
+    return out
+
+
+def test_ctypes_signatures_match_the_header():
+    """Every binding in ops._SIGS has the header's arity and pointer / integer / float kinds, and every model entry takes the storage
+    type right in front of the stream (ABI 3)."""
+    from llava_align_amd import ops
+    decl = _declared_params()
+    kind = {ops._P: "p", ops._I: "i", ops._L: "l", ops._F: "f", C.c_uint32: "i"}
+    for name, sig in ops._SIGS.items():
+        params = decl[name]
+        assert len(params) == len(sig), (name, len(params), len(sig))
+        for prm, ct in zip(params, sig):
+            want = "p" if "*" in prm else ("f" if prm.startswith("float") else ("l" if prm.startswith("int64_t") else "i"))
+            assert kind[ct] == want, (name, prm, ct)
+        if name not in ("vdd_stop_words_match", "vdd_repetition_penalty"):
+            assert params[-2] == "int dtype" and params[-1].startswith("void*"), (name, params[-2:])
+
+
+def test_model_entries_refuse_other_storage_types(lib):
+    """dtype is checked before anything is launched: fp32 (or garbage) -> VDD_ERR_INVALID_ARG, no GPU needed."""
+    from llava_align_amd import ops
+    ops._lib_ready()
+    for bad in (0, 3, -1):
+        assert lib.vdd_silu_mul(None, None, 4, 8, bad, None) == -1
+        assert lib.vdd_add(None, None, None, 8, bad, None) == -1
+    assert lib.vdd_silu_mul(None, None, 0, 8, 2, None) == 0 and lib.vdd_silu_mul(None, None, 0, 8, 1, None) == 0     # empty: nothing to do
+
+
 def test_abi_version(lib):
     from llava_align_amd._lib import ABI_VERSION
-    assert lib.vdd_abi_version() == ABI_VERSION == 2
+    assert lib.vdd_abi_version() == ABI_VERSION == 3
     assert lib.vdd_lds_row_capacity(1) >= 32000 and lib.vdd_lds_row_capacity(0) >= 32000
     assert lib.vdd_kernel_name(2, 32000).decode() == "vdd_contrast_sample_kernel"
 

@@ -8,6 +8,19 @@ import torch.nn.functional as F
 
 pytestmark = pytest.mark.gpu
 DEV = "cuda:0"
+DT = torch.bfloat16          # storage type of the current test run (set by the fixture below)
+
+
+@pytest.fixture(autouse=True, params=[torch.bfloat16, torch.float16], ids=["bf16", "fp16"])
+def storage_dtype(request):
+    """Every test of this file runs once per storage type of the model kernels (csrc/vdd_elem.h): bf16 (BASELINE config #2) and fp16
+    (what the reference's drivers load, builder.py:40).  The tolerances are written for bf16 (8 significant bits); fp16 (11) sits inside them."""
+    global DT
+    DT = request.param
+    yield
+    DT = torch.bfloat16
+
+
 GUARD = 1 << 18
 
 
@@ -23,14 +36,14 @@ def test_every_gemm_candidate_stays_inside_its_buffers(case):
     from llava_align_amd import ops as E
     M, N, K, epi = _cases()[case]
     g = torch.Generator(device=DEV).manual_seed(case)
-    x = (torch.randn(M, K, device=DEV, generator=g) * 0.5).bfloat16()
-    w = (torch.randn(N, K, device=DEV, generator=g) * 0.02).bfloat16()
+    x = (torch.randn(M, K, device=DEV, generator=g) * 0.5).to(DT)
+    w = (torch.randn(N, K, device=DEV, generator=g) * 0.02).to(DT)
     No = N // 2 if epi == E.EPI_SWIGLU else N
-    bias = (torch.randn(No, device=DEV, generator=g) * 0.1).bfloat16() if epi in (E.EPI_BIAS, E.EPI_BIAS_QUICK_GELU, E.EPI_BIAS_GELU, E.EPI_BIAS_RESID) else None
-    resid = (torch.randn(M, No, device=DEV, generator=g) * 0.5).bfloat16() if epi == E.EPI_BIAS_RESID else None
+    bias = (torch.randn(No, device=DEV, generator=g) * 0.1).to(DT) if epi in (E.EPI_BIAS, E.EPI_BIAS_QUICK_GELU, E.EPI_BIAS_GELU, E.EPI_BIAS_RESID) else None
+    resid = (torch.randn(M, No, device=DEV, generator=g) * 0.5).to(DT) if epi == E.EPI_BIAS_RESID else None
     acc = x.float() @ w.float().t()
     if epi == E.EPI_SWIGLU:
-        want = F.silu(acc[:, :No].bfloat16().float()).bfloat16().float() * acc[:, No:].bfloat16().float()
+        want = F.silu(acc[:, :No].to(DT).float()).to(DT).float() * acc[:, No:].to(DT).float()
     else:
         want = acc if bias is None else acc + bias.float()
         if epi == E.EPI_BIAS_QUICK_GELU:
@@ -38,7 +51,7 @@ def test_every_gemm_candidate_stays_inside_its_buffers(case):
         if epi == E.EPI_BIAS_GELU:
             want = F.gelu(want)
         if resid is not None:
-            want = want.bfloat16().float() + resid.float()
+            want = want.to(DT).float() + resid.float()
     need = E._gemm_workspace(x.device, M, No).numel()
     scale = want.abs().max().item()
     n = 0
@@ -48,7 +61,7 @@ def test_every_gemm_candidate_stays_inside_its_buffers(case):
         wsbuf = torch.full((need + 2 * GUARD,), 0x5A, dtype=torch.uint8, device=DEV)
         ws = wsbuf[GUARD:GUARD + need]
         ws.zero_()
-        obuf = torch.full((M * No + 2 * GUARD,), -7.0, dtype=torch.bfloat16, device=DEV)
+        obuf = torch.full((M * No + 2 * GUARD,), -7.0, dtype=DT, device=DEV)
         out = obuf[GUARD:GUARD + M * No].view(M, No)
         for _ in range(2):
             E._gemm_call(x, w, out, bias, resid, M, No, K, epi, c + 16 * sch, ws)

@@ -1,0 +1,148 @@
+"""attach_engine(): the native engine behind the reference's own call - `model.generate(input_ids[1, L], images=[1, 3, S, S].half().cuda(),
+use_dd / use_dd_unk / images_cd, cd_alpha, cd_beta, output_scores, return_dict_in_generate)` on a LlavaLlamaForCausalLM-shaped HF model in
+the reference's dtype (fp16, builder.py:40) - against the drop-in loop (evolve_vcd_sampling() + HF's eager forward) on the SAME model
+object.  7B widths at 2 layers and the tiny preset; all five modes."""
+import pytest
+import torch
+import transformers
+
+import hf_llava
+
+pytestmark = pytest.mark.gpu
+DEV = "cuda:0"
+IMG = hf_llava.IMAGE_TOKEN_INDEX
+
+SIZES = {
+    "tiny": dict(),
+    "7b_widths_2_layers": dict(d=4096, layers=2, heads=32, ffn=11008, vocab=32000, clip_width=1024, clip_layers=3, clip_heads=16, clip_mlp=4096,
+                               image=336, patch=14, max_pos=2048),
+}
+
+
+@pytest.fixture()
+def hooked():
+    import llava_align_amd as L
+    mixin = transformers.generation.utils.GenerationMixin
+    saved = (mixin.__dict__.get("sample"), mixin.__dict__.get("_sample"))
+    L.evolve_vcd_sampling()
+    yield
+    if saved[0] is None:
+        del mixin.sample
+    else:
+        mixin.sample = saved[0]
+    mixin._sample = saved[1]
+
+
+@pytest.fixture(scope="module", params=[("tiny", torch.float16), ("tiny", torch.bfloat16), ("7b_widths_2_layers", torch.float16)],
+                ids=["tiny-fp16", "tiny-bf16", "7b2l-fp16"])
+def model(request):
+    size, dtype = request.param
+    m = hf_llava.build(DEV, dtype, **SIZES[size])
+    m._size = size
+    yield m
+    del m
+    torch.cuda.empty_cache()
+
+
+def question(model, n_sys=12, n_txt=9, seed=0):
+    g = torch.Generator().manual_seed(seed)
+    V, S = model.config.vocab_size, model.get_vision_tower().vision_tower.config.image_size
+    sys_ = [1] + torch.randint(3, V, (n_sys - 1,), generator=g).tolist()
+    txt = torch.randint(3, V, (n_txt,), generator=g).tolist()
+    ids = torch.tensor([sys_ + [IMG] + txt], device=DEV)
+    img = torch.randn(1, 3, S, S, generator=g)
+    return ids, img
+
+
+MODES = {"plain": {}, "dd_unk": {"use_dd_unk": True}, "dd": {"use_dd": True}, "both": {"use_dd": True, "use_dd_unk": True}, "cd": {}}
+
+
+@pytest.mark.parametrize("mode", list(MODES))
+def test_generate_through_the_adapter_matches_the_drop_in_loop_on_the_same_model(model, hooked, mode):
+    from llava_align_amd.hf_adapter import attach_engine, detach_engine
+    ids, img = question(model, seed=3)
+    img = img.to(DEV, model.dtype)                               # `.half().cuda()`, llava_calibrate.py:163
+    kw = dict(MODES[mode])
+    if mode == "cd":
+        kw["images_cd"] = (img.float() + 0.5 * torch.randn(img.shape, device=DEV, generator=torch.Generator(DEV).manual_seed(1))).to(model.dtype)
+    n_new = 5
+    call = dict(images=img, cd_alpha=1.0, cd_beta=0.1, do_sample=True, temperature=0.5, top_p=None, top_k=None, max_new_tokens=n_new,
+                use_cache=True, output_scores=True, return_dict_in_generate=True, cd_greedy=True, **kw)
+    detach_engine(model)
+    want = model.generate(ids, attention_mask=torch.ones_like(ids), **call)          # HF eager forward under the drop-in loop
+    eng = attach_engine(model)
+    assert eng.dtype == model.dtype and "generate" in model.__dict__
+    got = model.generate(ids, **call, output_attentions=True)                        # the reference's call, llava_calibrate.py:161-177
+    L = ids.shape[1]
+    assert got["sequences"].shape == (1, L + n_new) and torch.equal(got["sequences"][:, :L], ids)       # prompt echoed with its -200
+    assert len(got["scores"]) == n_new and got["scores"][0].shape == (1, model.config.vocab_size) and got["scores"][0].dtype == model.dtype
+    with pytest.raises(KeyError, match="llava_calibrate.py:180-182"):
+        got["attentions"]
+    # The two stacks round differently inside a layer (HF: library GEMMs + SDPA in the model dtype; engine: its own kernels, fp32
+    # accumulation everywhere), so scores are compared at the measured noise of the dtype and tokens where the margin clears it.
+    # Raw logit noise at this depth: fp16 ~ 3e-3 of the logit scale, bf16 ~ 2e-2; the contrast amplifies it by (1 + 2 alpha) / T = 6.
+    tol = (0.06 if model.dtype == torch.float16 else 0.4) * (1 if mode != "plain" else 0.4)
+    checked = 0
+    for step in range(n_new):
+        a, b = got["scores"][step][0].float(), want["scores"][step][0].float()
+        fin = torch.isfinite(a) & torch.isfinite(b)
+        assert int(fin.sum()) >= 1 and int((torch.isfinite(a) ^ torch.isfinite(b)).sum()) <= 3 + 0.05 * int(fin.sum())
+        assert (a[fin] - b[fin]).abs().max().item() <= tol, (step, (a[fin] - b[fin]).abs().max().item())
+        top2 = torch.topk(b, 2).values
+        t_got, t_want = int(got["sequences"][0, L + step]), int(want["sequences"][0, L + step])
+        if (top2[0] - top2[1]).item() > 2 * tol:
+            assert t_got == t_want, step
+            checked += 1
+        if t_got != t_want:
+            break
+    assert checked >= 2
+    detach_engine(model)
+    assert "generate" not in model.__dict__ and not hasattr(model, "_vdd_engine")
+
+
+def test_shared_storage_keeps_the_hf_forward_intact_and_adds_no_second_copy(model, hooked):
+    """share_storage: q/k/v and gate/up of the HF modules become views of the engine's fused tensors - same values, same bytes."""
+    from llava_align_amd.hf_adapter import attach_engine, detach_engine
+    ids, img = question(model, seed=5)
+    img = img.to(DEV, model.dtype)
+    with torch.no_grad():
+        before = model(input_ids=ids, images=img).logits
+    eng = attach_engine(model)
+    lay = model.model.layers[0]
+    nq = eng.cfg.lm.n_heads * eng.cfg.lm.head_dim
+    assert lay.self_attn.q_proj.weight.data_ptr() == eng.w.t["l0.wqkv"].data_ptr()
+    assert lay.self_attn.k_proj.weight.data_ptr() == eng.w.t["l0.wqkv"][nq:].data_ptr()
+    assert lay.mlp.up_proj.weight.data_ptr() == eng.w.t["l0.wgu"][eng.cfg.lm.ffn:].data_ptr()
+    assert model.lm_head.weight.data_ptr() == eng.w.t["lm_head"].data_ptr() and model.model.embed_tokens.weight.data_ptr() == eng.w.t["embed"].data_ptr()
+    assert lay.mlp.down_proj.weight.data_ptr() == eng.w.t["l0.wd"].data_ptr()
+    with torch.no_grad():
+        after = model(input_ids=ids, images=img).logits
+    assert torch.equal(before, after)
+    detach_engine(model)
+
+
+def test_hf_defaults_and_overrides_are_resolved_like_generate(model):
+    """Explicit keywords (None included) win over model.generation_config; do_sample defaults to False -> greedy WITHOUT contrast
+    (SURVEY A.3 #5); eos without pad -> pad = eos; max_length when no max_new_tokens."""
+    from llava_align_amd.hf_adapter import attach_engine, detach_engine
+    if model._size != "tiny":
+        pytest.skip("argument handling: once")
+    ids, img = question(model, seed=7)
+    img = img.to(DEV, model.dtype)
+    attach_engine(model)
+    try:
+        out = model.generate(ids, images=img, max_length=ids.shape[1] + 3)
+        assert torch.is_tensor(out) and out.shape == (1, ids.shape[1] + 3)                      # a plain tensor without return_dict_in_generate
+        with torch.no_grad():
+            first = int(model(input_ids=ids, images=img).logits[0, -1].float().argmax())
+        assert int(out[0, ids.shape[1]]) == first                                              # greedy, no contrast, no warpers
+        with pytest.warns(UserWarning, match="pad_token_id"):
+            o2 = model.generate(ids, images=img, do_sample=True, top_k=1, max_new_tokens=4, eos_token_id=first, pad_token_id=None, use_dd_unk=True,
+                                return_dict_in_generate=True)
+        assert o2["sequences"].shape[1] <= ids.shape[1] + 4
+        with pytest.raises(ValueError, match="attention_mask"):
+            model.generate(ids, images=img, attention_mask=torch.zeros_like(ids), max_new_tokens=2)
+        with pytest.raises(TypeError):
+            model.generate(ids, images=img, max_new_tokens=2, no_such_kwarg=1)
+    finally:
+        detach_engine(model)

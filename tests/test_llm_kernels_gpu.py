@@ -7,6 +7,19 @@ import torch
 
 pytestmark = pytest.mark.gpu
 DEV = "cuda:0"
+DT = torch.bfloat16          # storage type of the current test run (set by the fixture below)
+
+
+@pytest.fixture(autouse=True, params=[torch.bfloat16, torch.float16], ids=["bf16", "fp16"])
+def storage_dtype(request):
+    """Every test of this file runs once per storage type of the model kernels (csrc/vdd_elem.h): bf16 (BASELINE config #2) and fp16
+    (what the reference's drivers load, builder.py:40).  The tolerances are written for bf16 (8 significant bits); fp16 (11) sits inside them."""
+    global DT
+    DT = request.param
+    yield
+    DT = torch.bfloat16
+
+
 
 
 def ops():
@@ -16,7 +29,7 @@ def ops():
 
 def bf(*shape, scale=1.0, seed=0):
     g = torch.Generator(device=DEV).manual_seed(seed)
-    return (torch.randn(*shape, device=DEV, generator=g) * scale).to(torch.bfloat16)
+    return (torch.randn(*shape, device=DEV, generator=g) * scale).to(DT)
 
 
 @pytest.mark.parametrize("M,d", [(1, 4096), (7, 4096), (3, 5120), (5, 1024), (2, 256)])
@@ -25,12 +38,12 @@ def test_rmsnorm(M, d):
     x, dl, w = bf(M, d, seed=1), bf(M, d, seed=2), bf(d, seed=3) * 0.1 + 1
     ro = torch.empty_like(x)
     y = O.rmsnorm(x, w, 1e-5, delta=dl, resid_out=ro)
-    h = (x.float() + dl.float()).to(torch.bfloat16)
+    h = (x.float() + dl.float()).to(DT)
     assert torch.equal(ro, h)
-    ref = (h.float() * torch.rsqrt(h.float().pow(2).mean(-1, keepdim=True) + 1e-5)).to(torch.bfloat16).float() * w.float()
+    ref = (h.float() * torch.rsqrt(h.float().pow(2).mean(-1, keepdim=True) + 1e-5)).to(DT).float() * w.float()
     assert torch.allclose(y.float(), ref, rtol=1.6e-2, atol=1e-3)       # 2 bf16 roundings
     y2 = O.rmsnorm(x, w, 1e-5)
-    ref2 = (x.float() * torch.rsqrt(x.float().pow(2).mean(-1, keepdim=True) + 1e-5)).to(torch.bfloat16).float() * w.float()
+    ref2 = (x.float() * torch.rsqrt(x.float().pow(2).mean(-1, keepdim=True) + 1e-5)).to(DT).float() * w.float()
     assert torch.allclose(y2.float(), ref2, rtol=1.6e-2, atol=1e-3)
 
 
@@ -46,7 +59,7 @@ def test_rope_kv_write():
     qkv = bf(M, (H + 2 * Hkv) * D, seed=4)
     pos = torch.tensor([0, 3, 31, 7, 7, 12], dtype=torch.int32, device=DEV)
     slot = torch.tensor([0, 1, 2, 3, 4, 0], dtype=torch.int32, device=DEV)
-    kc = torch.zeros(S, Hkv, T, D, dtype=torch.bfloat16, device=DEV)
+    kc = torch.zeros(S, Hkv, T, D, dtype=DT, device=DEV)
     vc = torch.zeros_like(kc)
     cs = rope_table(64, D)
     q = O.rope_kv_write(qkv, pos, slot, cs, kc, vc, H, Hkv, D).view(M, H, D)
@@ -67,11 +80,11 @@ def test_rope_kv_write():
 def test_embed_scatter_writes_rows_in_place():
     O = ops()
     table = bf(1000, 256, seed=61)
-    out = torch.full((40, 256), 7.0, dtype=torch.bfloat16, device=DEV)
+    out = torch.full((40, 256), 7.0, dtype=DT, device=DEV)
     ids = torch.tensor([5, 999, 0, 5], dtype=torch.int32, device=DEV)
     rows = torch.tensor([3, 0, 39, 17], dtype=torch.int32, device=DEV)
     O.embed_scatter(ids, rows, table, out)
-    want = torch.full((40, 256), 7.0, dtype=torch.bfloat16, device=DEV)
+    want = torch.full((40, 256), 7.0, dtype=DT, device=DEV)
     want[rows.long()] = table[ids.long()]
     assert torch.equal(out, want)
 
@@ -81,7 +94,7 @@ def test_silu_mul_and_embed():
     gu = bf(5, 2 * 11008, seed=5)
     y = O.silu_mul(gu)
     g, u = gu[:, :11008].float(), gu[:, 11008:].float()
-    ref = torch.nn.functional.silu(g).to(torch.bfloat16).float() * u
+    ref = torch.nn.functional.silu(g).to(DT).float() * u
     assert torch.allclose(y.float(), ref, rtol=1.6e-2, atol=1e-3)
     table = bf(1000, 4096, seed=6)
     ids = torch.tensor([0, 999, 5, 5, 17], device=DEV)
@@ -100,7 +113,7 @@ def test_skinny_gemm(M, N, K):
     tol = 2e-2 * ref.abs().max().item()
     assert (y.float() - ref).abs().max().item() <= tol          # fp32 accumulate, one bf16 rounding (+ ordering)
     y2 = O.skinny_gemm(x, w, resid=r)
-    ref2 = ref.to(torch.bfloat16).float() + r.float()
+    ref2 = ref.to(DT).float() + r.float()
     assert (y2.float() - ref2).abs().max().item() <= 2e-2 * ref2.abs().max().item()
     for ns in (2, 4):                                       # split-K slabs (consumed by rmsnorm)
         if K % (128 * ns) == 0:
@@ -189,8 +202,8 @@ def test_swiglu_linear_equals_gemm_then_silu_mul(M):
         assert got.shape == (M, F)
         if F % 8 == 0:
             assert torch.equal(got, O.silu_mul(O.skinny_gemm(x, w)))
-        ref = torch.nn.functional.silu((x.float() @ w[:F].float().t()).to(torch.bfloat16).float()).to(torch.bfloat16).float() \
-            * (x.float() @ w[F:].float().t()).to(torch.bfloat16).float()
+        ref = torch.nn.functional.silu((x.float() @ w[:F].float().t()).to(DT).float()).to(DT).float() \
+            * (x.float() @ w[F:].float().t()).to(DT).float()
         assert torch.allclose(got.float(), ref, rtol=3e-2, atol=3e-2)
 
 
@@ -253,10 +266,10 @@ def test_layernorm_and_bias_act():
     assert torch.allclose(y.float(), ref, rtol=1e-2, atol=1e-2)
     z = bf(7, 4096, seed=34)
     bias = bf(4096, seed=35)
-    zb = (z.float() + bias.float()).to(torch.bfloat16).float()
+    zb = (z.float() + bias.float()).to(DT).float()
     assert torch.allclose(O.bias_act(z, bias, O.ACT_QUICK_GELU).float(), zb * torch.sigmoid(1.702 * zb), rtol=1e-2, atol=1e-2)
     assert torch.allclose(O.bias_act(z, bias, O.ACT_GELU).float(), torch.nn.functional.gelu(zb), rtol=1e-2, atol=1e-2)
-    assert torch.equal(O.bias_act(z, bias, O.ACT_NONE), zb.to(torch.bfloat16))
+    assert torch.equal(O.bias_act(z, bias, O.ACT_NONE), zb.to(DT))
     assert torch.equal(O.bias_act(z, None, O.ACT_NONE), z)
 
 
@@ -290,7 +303,7 @@ def test_grouped_prefix_decode_attention_equals_per_row():
                                    torch.tensor(grp_rows_p, dtype=torch.int32, device=DEV),
                                    torch.tensor(items, dtype=torch.int32, device=DEV), len(items), H, Hkv, D, 611, 128)
     # MFMA prefix pass on the fragment-major image: per 64-key chunk 16 K fragments then 16 V^T fragments of 1 KiB (lane-linear)
-    pf = torch.full((kp.shape[0], Hkv, 2 * 640, D), float("nan"), dtype=torch.bfloat16, device=DEV)
+    pf = torch.full((kp.shape[0], Hkv, 2 * 640, D), float("nan"), dtype=DT, device=DEV)
     plen_of_slot = torch.tensor([611, 0, 36], dtype=torch.int32, device=DEV)
     O.prefix_fragments(kp, vp, pf, plen_of_slot)
     blk = pf[0].view(Hkv, 10, 2, 16, 64, 8)             # [head][chunk][K | V^T][fragment][lane][8]
@@ -342,7 +355,7 @@ def _gemm_ref(x, w, epi, bias, resid):
     """Plain fp32 PyTorch restatement of vdd_gemm's epilogues, bf16 rounding where the HF modules round."""
     O = ops()
     acc = x.float() @ w.float().t()
-    r = lambda t: t.to(torch.bfloat16).float()
+    r = lambda t: t.to(DT).float()
     if epi == O.EPI_NONE:
         return r(acc)
     if epi == O.EPI_SWIGLU:
@@ -370,7 +383,7 @@ def test_gemm_matches_fp32_reference(M, N, K):
     product; tolerance = 2 bf16 ulps of the largest output (bf16 output rounding + fp32 accumulation-order differences)."""
     O = ops()
     x, w = bf(M, K, seed=51), bf(N, K, scale=0.02, seed=52)
-    w[:, 0] += torch.arange(N, device=DEV).to(torch.bfloat16) * 1e-3        # asymmetric: a transposed / shifted tile is an O(1) error
+    w[:, 0] += torch.arange(N, device=DEV).to(DT) * 1e-3        # asymmetric: a transposed / shifted tile is an O(1) error
     ref = _gemm_ref(x, w, O.EPI_NONE, None, None)
     tol = 2 ** -7 * ref.abs().max().item() + 1e-3
     for cfg, sched in O.GEMM_CANDIDATES:
@@ -444,7 +457,7 @@ def test_norm_fused_small_m_projections(M, d, F):
     points; the only licence is the summation order of the fp32 sum of squares (one ulp of rstd)."""
     O = ops()
     x, resid = bf(M, d, seed=70), bf(M, d, seed=71)
-    wo, ln = bf(d, d, scale=0.02, seed=72), (1 + 0.1 * bf(d, seed=73).float()).to(torch.bfloat16)
+    wo, ln = bf(d, d, scale=0.02, seed=72), (1 + 0.1 * bf(d, seed=73).float()).to(DT)
     h, ss = O.linear_resid_ss(x, wo, resid)
     want_h = O.skinny_gemm(x, wo, resid=resid)
     assert torch.equal(h, want_h)                                            # same kernel arithmetic as the unfused projection
@@ -475,17 +488,17 @@ def test_vit_glue_kernels():
     O = ops()
     n, S, P, H, D = 3, 56, 14, 2, 64
     G, T, w = S // P, (S // P) ** 2 + 1, H * D
-    for dt in (torch.float32, torch.float16, torch.bfloat16):
+    for dt in (torch.float32, torch.float16, DT):
         img = torch.randn(n, 3, S, S, device=DEV).to(dt)
         got = O.vit_im2col(img, P, 640)
-        want = img.to(torch.bfloat16).view(n, 3, G, P, G, P).permute(0, 2, 4, 1, 3, 5).reshape(n * G * G, 3 * P * P)
+        want = img.to(DT).view(n, 3, G, P, G, P).permute(0, 2, 4, 1, 3, 5).reshape(n * G * G, 3 * P * P)
         assert torch.equal(got[:, : 3 * P * P], want) and not got[:, 3 * P * P:].any()
     emb, cls, pos = bf(n * (T - 1), w, seed=71), bf(w, seed=72), bf(T, w, seed=73)
     h = O.vit_assemble(emb, cls, pos, n, T)
-    want = (torch.cat([cls.view(1, 1, w).expand(n, 1, w), emb.view(n, T - 1, w)], 1).float() + pos.float()[None]).to(torch.bfloat16)
+    want = (torch.cat([cls.view(1, 1, w).expand(n, 1, w), emb.view(n, T - 1, w)], 1).float() + pos.float()[None]).to(DT)
     assert torch.equal(h.view(n, T, w), want)
     qkv = bf(n * T, 3 * w, seed=74)
-    kc, vc = torch.zeros(n + 1, H, T + 3, D, dtype=torch.bfloat16, device=DEV), torch.zeros(n + 1, H, T + 3, D, dtype=torch.bfloat16, device=DEV)
+    kc, vc = torch.zeros(n + 1, H, T + 3, D, dtype=DT, device=DEV), torch.zeros(n + 1, H, T + 3, D, dtype=DT, device=DEV)
     q = O.vit_qkv_split(qkv, kc, vc, n, T, H, D)
     v5 = qkv.view(n, T, 3, H, D)
     assert torch.equal(q.view(n, T, H, D), v5[:, :, 0])
@@ -499,7 +512,7 @@ def test_rmsnorm_sums_split_k_slabs():
     slabs = torch.randn(4, M, d, device=DEV) * 0.5
     ro = torch.empty_like(x)
     y = O.rmsnorm(x, w, 1e-5, delta=slabs, resid_out=ro)
-    h = (x.float() + slabs.sum(0).to(torch.bfloat16).float()).to(torch.bfloat16)
+    h = (x.float() + slabs.sum(0).to(DT).float()).to(DT)
     assert (ro.float() - h.float()).abs().max().item() <= 0.04          # fp32 summation order may move one bf16 ulp
-    ref = (h.float() * torch.rsqrt(h.float().pow(2).mean(-1, keepdim=True) + 1e-5)).to(torch.bfloat16).float() * w.float()
+    ref = (h.float() * torch.rsqrt(h.float().pow(2).mean(-1, keepdim=True) + 1e-5)).to(DT).float() * w.float()
     assert torch.allclose(y.float(), ref, rtol=3e-2, atol=2e-2)
