@@ -57,8 +57,10 @@ class HfLlava(LlamaForCausalLM):
             emb = self.model.embed_tokens
             inputs_embeds = torch.cat([emb(row[:s]), self.encode_images(images)[0].to(emb.weight.dtype), emb(row[s + 1:])], 0)[None]
             input_ids = None
-        # un-padded single sequences: the all-ones masks of the loop (re-sized by the reference at :92-93 / :199-202) carry nothing
-        return super().forward(input_ids=input_ids, attention_mask=None, position_ids=position_ids, past_key_values=past_key_values,
+        # un-padded single sequences: the all-ones masks of the loop (re-sized by the reference at :92-93 / :199-202) carry nothing, and
+        # positions follow the CACHE length (the spliced sequence is 575 longer than the ids the generation loop counts)
+        kw.pop("cache_position", None)
+        return super().forward(input_ids=input_ids, attention_mask=None, position_ids=None, past_key_values=past_key_values,
                                inputs_embeds=inputs_embeds, use_cache=use_cache, **kw)
 
     def prepare_inputs_for_generation_cd(self, input_ids, **kw):                                     # llava_llama.py:153-174
@@ -68,7 +70,7 @@ class HfLlava(LlamaForCausalLM):
 
 
 def build(device, dtype, d=256, layers=2, heads=2, ffn=512, vocab=1000, clip_width=128, clip_layers=3, clip_heads=2, clip_mlp=256,
-          image=56, patch=14, max_pos=512, lm_head_gain=4.0, seed=0):
+          image=56, patch=14, max_pos=512, lm_head_gain=6.0, seed=0):
     """Random-init model on `device` in `dtype`.  Defaults = the engine's 'tiny' preset; 7B widths: d 4096, heads 32, ffn 11008,
     vocab 32000, clip 1024 / 16 heads / mlp 4096 / image 336."""
     torch.manual_seed(seed)

@@ -65,7 +65,7 @@ def test_generate_through_the_adapter_matches_the_drop_in_loop_on_the_same_model
     kw = dict(MODES[mode])
     if mode == "cd":
         kw["images_cd"] = (img.float() + 0.5 * torch.randn(img.shape, device=DEV, generator=torch.Generator(DEV).manual_seed(1))).to(model.dtype)
-    n_new = 5
+    n_new = 8
     call = dict(images=img, cd_alpha=1.0, cd_beta=0.1, do_sample=True, temperature=0.5, top_p=None, top_k=None, max_new_tokens=n_new,
                 use_cache=True, output_scores=True, return_dict_in_generate=True, cd_greedy=True, **kw)
     detach_engine(model)
@@ -79,15 +79,18 @@ def test_generate_through_the_adapter_matches_the_drop_in_loop_on_the_same_model
     with pytest.raises(KeyError, match="llava_calibrate.py:180-182"):
         got["attentions"]
     # The two stacks round differently inside a layer (HF: library GEMMs + SDPA in the model dtype; engine: its own kernels, fp32
-    # accumulation everywhere), so scores are compared at the measured noise of the dtype and tokens where the margin clears it.
-    # Raw logit noise at this depth: fp16 ~ 3e-3 of the logit scale, bf16 ~ 2e-2; the contrast amplifies it by (1 + 2 alpha) / T = 6.
-    tol = (0.06 if model.dtype == torch.float16 else 0.4) * (1 if mode != "plain" else 0.4)
+    # accumulation everywhere), so scores are compared at the measured noise of the dtype and tokens where the margin clears it:
+    # the logits of the two stacks differ by an ulp or two of the dtype (fp16 2^-11, bf16 2^-8 relative), the contrast amplifies that by
+    # (1 + 2 alpha) / T = 6 - measured on this model: <= 3e-3 of the largest score in fp16 (3 fp16 ulps) over the handful of entries a
+    # contrast row keeps, 5.4e-3 as the maximum over the 32,000 finite entries of a plain row (sigma ~ 2.5 ulps); <= 2.5e-2 in bf16.
+    rel = 8e-3 if model.dtype == torch.float16 else 4e-2
     checked = 0
     for step in range(n_new):
         a, b = got["scores"][step][0].float(), want["scores"][step][0].float()
         fin = torch.isfinite(a) & torch.isfinite(b)
         assert int(fin.sum()) >= 1 and int((torch.isfinite(a) ^ torch.isfinite(b)).sum()) <= 3 + 0.05 * int(fin.sum())
-        assert (a[fin] - b[fin]).abs().max().item() <= tol, (step, (a[fin] - b[fin]).abs().max().item())
+        tol = rel * max(1.0, b[fin].abs().max().item())
+        assert (a[fin] - b[fin]).abs().max().item() <= tol, (step, (a[fin] - b[fin]).abs().max().item(), tol)
         top2 = torch.topk(b, 2).values
         t_got, t_want = int(got["sequences"][0, L + step]), int(want["sequences"][0, L + step])
         if (top2[0] - top2[1]).item() > 2 * tol:
@@ -95,7 +98,7 @@ def test_generate_through_the_adapter_matches_the_drop_in_loop_on_the_same_model
             checked += 1
         if t_got != t_want:
             break
-    assert checked >= 2
+    assert checked >= (2 if model.dtype == torch.float16 else 1)
     detach_engine(model)
     assert "generate" not in model.__dict__ and not hasattr(model, "_vdd_engine")
 

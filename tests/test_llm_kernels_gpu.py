@@ -201,7 +201,12 @@ def test_swiglu_linear_equals_gemm_then_silu_mul(M):
         got = O.swiglu_linear(x, w)
         assert got.shape == (M, F)
         if F % 8 == 0:
-            assert torch.equal(got, O.silu_mul(O.skinny_gemm(x, w)))
+            two = O.silu_mul(O.skinny_gemm(x, w))
+            if 2 * F > 8192:
+                assert torch.equal(got, two)
+            else:       # narrow outputs: skinny_gemm splits K over EIGHT waves, the fused kernel over four - another fp32 summation order,
+                        # visible as an ulp of the output here and there (fp16 keeps 11 bits of it, bf16 8)
+                assert (got.float() - two.float()).abs().max().item() <= 2 ** -9 * two.float().abs().max().item()
         ref = torch.nn.functional.silu((x.float() @ w[:F].float().t()).to(DT).float()).to(DT).float() \
             * (x.float() @ w[F:].float().t()).to(DT).float()
         assert torch.allclose(got.float(), ref, rtol=3e-2, atol=3e-2)
@@ -383,7 +388,7 @@ def test_gemm_matches_fp32_reference(M, N, K):
     product; tolerance = 2 bf16 ulps of the largest output (bf16 output rounding + fp32 accumulation-order differences)."""
     O = ops()
     x, w = bf(M, K, seed=51), bf(N, K, scale=0.02, seed=52)
-    w[:, 0] += torch.arange(N, device=DEV).to(DT) * 1e-3        # asymmetric: a transposed / shifted tile is an O(1) error
+    w[:, 0] += (torch.arange(N, device=DEV) * 1e-3).to(DT)        # asymmetric: a transposed / shifted tile is an O(1) error
     ref = _gemm_ref(x, w, O.EPI_NONE, None, None)
     tol = 2 ** -7 * ref.abs().max().item() + 1e-3
     for cfg, sched in O.GEMM_CANDIDATES:
@@ -490,7 +495,7 @@ def test_vit_glue_kernels():
     G, T, w = S // P, (S // P) ** 2 + 1, H * D
     for dt in (torch.float32, torch.float16, DT):
         img = torch.randn(n, 3, S, S, device=DEV).to(dt)
-        got = O.vit_im2col(img, P, 640)
+        got = O.vit_im2col(img, P, 640, dtype=DT)
         want = img.to(DT).view(n, 3, G, P, G, P).permute(0, 2, 4, 1, 3, 5).reshape(n * G * G, 3 * P * P)
         assert torch.equal(got[:, : 3 * P * P], want) and not got[:, 3 * P * P:].any()
     emb, cls, pos = bf(n * (T - 1), w, seed=71), bf(w, seed=72), bf(T, w, seed=73)
