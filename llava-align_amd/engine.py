@@ -574,6 +574,7 @@ class _DecodeRunner:
         self.prompt_tail = torch.full((Q, pr["stop"].max_len), -1, dtype=torch.long, device=dev) if pr.get("stop") is not None else None
         self.prompt_ids = (torch.full((Q, max(1, pr["hist_len"])), -1, dtype=torch.long, device=dev)
                            if (pr.get("rep") is not None or pr.get("python")) else None)
+        self.prompt_cols = 0
         lm = eng.cfg.lm
         # the step's own partials buffer (also for the ungrouped split-KV pass): a captured graph must not point into a
         # shared buffer that a later, larger call re-allocates
@@ -592,6 +593,7 @@ class _DecodeRunner:
             self.prompt_tail.copy_(prompt_tail)
         if self.prompt_ids is not None:
             self.prompt_ids.fill_(-1)                                   # LEFT-padded with -1, like an HF batch
+            self.prompt_cols = int(prompt_ids.shape[1])                 # the longest prompt of THIS call (0: inputs_embeds prompts)
             if prompt_ids.shape[1]:
                 self.prompt_ids[:, -prompt_ids.shape[1]:].copy_(prompt_ids)
 
@@ -616,9 +618,12 @@ class _DecodeRunner:
                 from .sampling import GPU_SCALAR_SEMANTICS
                 ops.repetition_penalty_(x, pr["rep"], self.prompt_ids, self.gen, step=step, step_ptr=step_ptr,
                                         reciprocal=GPU_SCALAR_SEMANTICS)
-            if pr.get("python"):                 # eager only (step is a host integer here): HF-style callables on left-padded ids
+            if pr.get("python"):                 # eager only (step is a host integer here): HF-style callables see what HF would hand them -
+                # exactly max(prompt length) prompt columns (none for inputs_embeds prompts), shorter rows LEFT-padded with the pad id
                 pad = t["pad"] if t["pad"] is not None else 0
-                ids = torch.cat([torch.where(self.prompt_ids < 0, pad, self.prompt_ids), self.gen[:, :step]], 1)
+                L = self.prompt_cols
+                pids = self.prompt_ids[:, self.prompt_ids.shape[1] - L:] if L > 0 else self.prompt_ids[:, :0]
+                ids = torch.cat([torch.where(pids < 0, pad, pids), self.gen[:, :step]], 1)
                 for f in pr["python"]:
                     x = f(ids, x)
             v, c, d = x, None, None
@@ -1157,9 +1162,12 @@ class VddLlavaEngine:
                     T = int(feats[qi].shape[0])
                     key = (feats[qi].data_ptr(), T)
                     unshared += T; max_len = max(max_len, T); n_slots += 1
-                    if share_prefix and embeds_prefix is not None and embeds_prefix[qi] is not None and 0 < int(embeds_prefix[qi][1]) < T:
+                    if (share_prefix and embeds_prefix is not None and feats is branches[0][2] and embeds_prefix[qi] is not None
+                            and 0 < int(embeds_prefix[qi][1]) < T):
                         # caller-declared common leading rows (same image): one prefix slot per (embedding source, key, length) - the
-                        # degenerate branches read the main branch's list, so they land in the same slot
+                        # degenerate branches read the main branch's list, so they land in the same slot.  The promise is about the MAIN
+                        # prompts only: a 'cd' branch built from images_cd embeddings carries per-question noise in exactly those rows
+                        # (run_qwen.py:182, blip_calibrate.py:80 draw it per question) and never shares them
                         n_pre = int(embeds_prefix[qi][1])
                         pkey = ("emb", id(feats), embeds_prefix[qi][0], n_pre)
                         if pkey not in prefix_slots:

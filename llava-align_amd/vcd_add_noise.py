@@ -47,7 +47,14 @@ def schedule(num_steps: int = 1000):
 
 
 def add_diffusion_noise(image_tensor: torch.Tensor, noise_step: int, noise: Optional[torch.Tensor] = None,
-                        seed: Optional[int] = None) -> torch.Tensor:
+                        seed=None) -> torch.Tensor:
+    """vcd_add_noise.py:3-28.  `noise`: explicit epsilon (tests).  Random numbers, by `seed`:
+      None             like the reference: every call draws fresh noise from torch's global generator state (torch.manual_seed
+                       reproduces a run);
+      (seed, call)     a PURE function of (seed, call, shape): `call` is the caller's own index of this draw (the question number in a
+                       driver loop) - thread-safe, repeatable in-process, independent of what else was noised;
+      int              shorthand for (seed, n) with n = the number of earlier int-seeded calls under that seed in this PROCESS
+                       (module state, not thread-safe: consecutive images get different epsilon; reset_noise_calls() restarts it)."""
     lib = _lib.load_lib()
     if not torch.cuda.is_available():
         raise _lib.VddLibraryError("add_diffusion_noise needs a GPU: this package has no CPU path")
@@ -67,18 +74,25 @@ def add_diffusion_noise(image_tensor: torch.Tensor, noise_step: int, noise: Opti
     lib.vdd_add_diffusion_noise.argtypes = [C.c_void_p, C.c_void_p, C.c_int64, C.c_int, C.c_float, C.c_float,
                                             C.c_void_p, C.c_uint64, C.c_uint64, C.c_void_p]
     lib.vdd_add_diffusion_noise.restype = C.c_int
+    call_idx = None
+    if isinstance(seed, (tuple, list)):
+        seed, call_idx = int(seed[0]), int(seed[1])
+        if call_idx < 0:
+            raise ValueError("add_diffusion_noise: seed=(seed, call) takes a non-negative call index")
     sd = (torch.initial_seed() if seed is None else int(seed)) & 0xFFFFFFFFFFFFFFFF
     # Philox counter of element i = off + i / 4: the low 24 bits index inside the call (images up to 2^26 elements), the upper 40
     # the CALL.  No seed: the call id is drawn from torch's generator (each call advances it like the reference's randn_like,
     # vcd_add_noise.py:24; torch.manual_seed reproduces a run; 40 bits: two of ~10^3 images collide with probability ~5e-7).
-    # Explicit seed: the call id counts the calls made under that seed, so consecutive images get different epsilon while the
-    # sequence as a whole is a pure function of the seed (reset_noise_calls() restarts it).  The data-parallel rank is folded into
+    # seed=(s, call): the caller names the call.  Plain int seed: the call id counts the calls made under that seed in this process, so
+    # consecutive images get different epsilon (reset_noise_calls() restarts it).  The data-parallel rank is folded into
     # the key so that ranks seeded alike do not noise their shards with one stream.
     from .sampling import fresh_offset
     if x.numel() > (1 << 26):
         raise ValueError("add_diffusion_noise: more than 2^26 elements in one call")
     if seed is None:
         call = fresh_offset() & ((1 << 40) - 1)
+    elif call_idx is not None:
+        call = call_idx
     else:
         call = _calls[sd] = _calls.get(sd, -1) + 1
     off = (call & ((1 << 40) - 1)) << 24

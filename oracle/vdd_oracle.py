@@ -129,7 +129,16 @@ class RepetitionPenalty:
         if input_ids.shape[1] == 0:
             return scores
         score = torch.gather(scores, 1, input_ids)
-        score = torch.where(score < 0, score * self.penalty, score / self.penalty)
+        if GPU_SCALAR and score.dtype != torch.float32:
+            # torch-GPU divides a tensor by a python scalar as a multiplication by fl32(1 / p) in fp32 opmath, rounded once to the
+            # tensor's dtype (ATen BinaryDivTrueKernel.cu: `inv_b = 1 / b`); torch-CPU (the form the goldens pin) does a true division
+            inv = torch.tensor(1.0, dtype=torch.float32) / torch.tensor(self.penalty, dtype=torch.float32)
+            quot = (score.float() * inv).to(score.dtype)
+        elif GPU_SCALAR:
+            quot = score * (torch.tensor(1.0, dtype=torch.float32) / torch.tensor(self.penalty, dtype=torch.float32))
+        else:
+            quot = score / self.penalty
+        score = torch.where(score < 0, score * self.penalty, quot)
         return scores.scatter(1, input_ids, score)
 
 

@@ -28,6 +28,12 @@ class ClipTower(nn.Module):
         return out.hidden_states[self.select_layer][:, 1:].to(images.dtype)                      # :29-37
 
 
+def splice(embed_tokens, row, feat):
+    """llava_arch.py:122-163, one sequence, one image slot (pinned by tests/golden/splice.npz)."""
+    s = int(torch.where(row == IMAGE_TOKEN_INDEX)[0][0])
+    return torch.cat([embed_tokens(row[:s]), feat, embed_tokens(row[s + 1:])], 0)
+
+
 class HfLlava(LlamaForCausalLM):
     def __init__(self, config, clip_cfg):
         super().__init__(config)
@@ -52,10 +58,8 @@ class HfLlava(LlamaForCausalLM):
         # (:91-94); else the text chunks are embedded around the projected patch features (:122-163)
         if images is not None and input_ids is not None and input_ids.shape[1] != 1:
             assert input_ids.shape[0] == 1, "one question per call"
-            row = input_ids[0]
-            s = int(torch.where(row == IMAGE_TOKEN_INDEX)[0][0])
             emb = self.model.embed_tokens
-            inputs_embeds = torch.cat([emb(row[:s]), self.encode_images(images)[0].to(emb.weight.dtype), emb(row[s + 1:])], 0)[None]
+            inputs_embeds = splice(emb, input_ids[0], self.encode_images(images)[0].to(emb.weight.dtype))[None]
             input_ids = None
         # un-padded single sequences: the all-ones masks of the loop (re-sized by the reference at :92-93 / :199-202) carry nothing, and
         # positions follow the CACHE length (the spliced sequence is 575 longer than the ids the generation loop counts)

@@ -13,6 +13,13 @@ import torch.nn.functional as F
 from toy_lm import IMAGE_TOKEN_INDEX, _Proto, _gen_cfg
 
 
+def splice(embed, row, feat):
+    """llava_arch.py:122-163 for one sequence with one image slot: the text chunks embedded around the projected patch features
+    (pinned to the reference's own function by tests/golden/splice.npz, tests/test_splice_golden.py)."""
+    s = int(torch.where(row == IMAGE_TOKEN_INDEX)[0][0])
+    return torch.cat([embed[row[:s]], feat, embed[row[s + 1:]]], 0)
+
+
 class RefLlava(_Proto):
     def __init__(self, weights, device="cpu", logit_dtype=None, pad=0, eos=None, dtype=torch.float32,
                  output_attentions=False, logits_on_device=False, store=None):
@@ -117,10 +124,7 @@ class RefLlava(_Proto):
         if images is None or ids.shape[1] == 1:                 # llava_arch.py:91-94
             emb = self.w["embed"][ids]
         else:                                                   # llava_arch.py:122-163 (batch 1)
-            row = ids[0]
-            s = int(torch.where(row == IMAGE_TOKEN_INDEX)[0][0])
-            feat = self.encode_images(images)[0]
-            emb = torch.cat([self.w["embed"][row[:s]], feat, self.w["embed"][row[s + 1:]]], 0)[None]
+            emb = splice(self.w["embed"], ids[0], self.encode_images(images)[0])[None]
         emb = emb.to(self.store).to(self.dtype)
         logits, past = self._lm(emb, past_key_values)
         return SimpleNamespace(logits=logits.to(self.logit_dtype) if self.logits_on_device else logits.to(self.logit_dtype).cpu(), past_key_values=past, attentions=None, hidden_states=None)

@@ -84,6 +84,7 @@ def run_ref(ref, ids, img, mode_kw, n_new, img_cd=None, eos=None, pad=None):
 MODES = {"plain": {}, "dd_unk": {"use_dd_unk": True}, "dd": {"use_dd": True}, "both": {"use_dd": True, "use_dd_unk": True}}
 
 
+@pytest.mark.both_scalar_forms
 @pytest.mark.parametrize("mode", list(MODES))
 @pytest.mark.parametrize("share", [True, False])
 def test_generation_matches_reference_semantics(eng, ref, mode, share):
@@ -242,6 +243,7 @@ def test_grouped_prefix_attention_is_transparent(eng):
     assert checked >= len(ids)
 
 
+@pytest.mark.both_scalar_forms
 def test_lavis_call_shape_inputs_embeds_with_vcd_embeddings(eng):
     """BASELINE config #5 call shape: the LM is driven with inputs_embeds (Q-Former output ++ text embeddings) and the
     noisy-image branch arrives as EMBEDDINGS in images_cd (blip2_vicuna_instruct.py:380-410, modeling_llama.py:764-792)."""
@@ -521,6 +523,36 @@ def test_embedding_prompts_share_declared_prefixes_transparently(eng, batch_inva
         assert (x.tokens == b.tokens).float().mean().item() >= 0.8
     with pytest.raises(ValueError, match="embeds_prefix"):
         eng.generate(None, inputs_embeds=embs, embeds_prefix=keys[:2], max_new_tokens=1)
+
+
+def test_declared_prefixes_never_cover_the_noised_cd_branch(eng, batch_invariant):
+    """embeds_prefix is a promise about the MAIN prompts.  The VCD branch of the Qwen / LAVIS call shapes arrives as images_cd
+    EMBEDDINGS whose image rows carry fresh noise per question (run_qwen.py:182, blip_calibrate.py:80): two questions about one
+    image must each be contrasted against THEIR noised rows (all cd rows of a key used to share the first
+    question's prefix slot, silently)."""
+    d = eng.cfg.lm.d
+    g = torch.Generator(device=DEV).manual_seed(11)
+    img = (torch.randn(20, d, device=DEV, generator=g) * 0.3).to(eng.dtype)
+    embs, embs_cd, keys = [], [], []
+    for q in range(4):
+        txt = (torch.randn(5 + q, d, device=DEV, generator=g) * 0.3).to(eng.dtype)
+        noisy = (img.float() + torch.randn(20, d, device=DEV, generator=g) * 0.5).to(eng.dtype)      # a different draw per question
+        embs.append(torch.cat([img, txt], 0))
+        embs_cd.append(torch.cat([noisy, txt], 0))
+        keys.append(("image0", 20))
+    kw = dict(inputs_embeds=embs, images_cd=embs_cd, cd_alpha=1.0, cd_beta=0.1, temperature=0.5, max_new_tokens=3, cd_greedy=True, output_scores=True)
+    a = eng.generate(None, embeds_prefix=keys, **kw)
+    b = eng.generate(None, share_prefix=False, **kw)
+    # the main rows share the image prefix (1 x 20 rows + texts); every cd row is prefilled whole (4 x (20 + text))
+    assert a.stats["prefill_tokens"] == 20 + sum(5 + q for q in range(4)) + sum(25 + q for q in range(4))
+    L = eng.debug_logits0.float()
+    eng.generate(None, share_prefix=False, **{**kw, "max_new_tokens": 1})
+    Lb = eng.debug_logits0.float()
+    assert (L[4:] - Lb[4:]).abs().max().item() <= 0.06 * Lb[4:].abs().max().item()          # cd logits: each question against its own noise
+    assert (Lb[4] - Lb[5]).abs().max().item() > 0.2 * Lb[4:].abs().max().item()             # ... which really differs between questions
+    for sa, sb in zip(a.scores, b.scores):
+        fin = torch.isfinite(sa) & torch.isfinite(sb)
+        assert (torch.isfinite(sa) ^ torch.isfinite(sb)).sum() <= 2 and (sa[fin].float() - sb[fin].float()).abs().max().item() <= 0.3
 
 
 def test_text_only_prompts_share_their_common_system_prompt(eng, batch_invariant):

@@ -1,5 +1,6 @@
 """The engine at FULL depth (32 decoder layers of LLaVA-1.5-7B shapes) against the fp32 torch LLaVA (tests/ref_llava.py) driven by the
-oracle loop.  A bf16 engine cannot be bit-exact with an fp32 (or any other) GEMM implementation, so what is asserted is what IS
+oracle loop, in both storage types: bf16 (BASELINE config #2) and fp16 (the dtype the reference's drivers load, builder.py:40).  A 16-bit
+engine cannot be bit-exact with an fp32 (or any other) GEMM implementation, so what is asserted is what IS
 guaranteed, with the measured numbers recorded in DESIGN.md section 2:
   * step-0 logit error against depth (1 / 8 / 16 / 32 layers of the same weights) grows like sqrt(depth) - accumulated bf16
     rounding of the residual stream, not a systematic error - and stays below the error of the reference's own eager bf16 stack;
@@ -32,12 +33,17 @@ def _prompts(n_img, per_img, seed, vocab=32000):
     return ids, imgs
 
 
-@pytest.fixture(scope="module")
-def model():
+# per storage type: (a, b) of the step-0 bound a + b sqrt(depth), the post-contrast score-noise bound of the decode tests
+BOUNDS = {torch.bfloat16: dict(a=0.10, b=0.17, noise=3.0), torch.float16: dict(a=0.02, b=0.03, noise=0.5)}
+
+
+@pytest.fixture(scope="module", params=[torch.bfloat16, torch.float16], ids=["bf16", "fp16"])
+def model(request):
     from llava_align_amd.engine import LlavaConfig, LlavaWeights, LMConfig, VisionConfig
     cfg = LlavaConfig(LMConfig(n_layers=32, max_pos=1024), VisionConfig(layers=3), "full-depth")
-    w = LlavaWeights.random(cfg, DEV, seed=5, std=0.02, lm_head_gain=2.0)
-    return cfg, w, RefLlava(w, device=DEV)
+    w = LlavaWeights.random(cfg, DEV, seed=5, std=0.02, lm_head_gain=2.0, dtype=request.param)
+    yield cfg, w, RefLlava(w, device=DEV)
+    torch.cuda.empty_cache()
 
 
 def _engine(w, n_layers, use_graph):
@@ -50,7 +56,8 @@ def _engine(w, n_layers, use_graph):
 
 def test_logit_error_grows_like_sqrt_depth_and_stays_below_eager_bf16(model):
     full, w, ref = model
-    ref16 = RefLlava(w, device=DEV, dtype=torch.bfloat16)             # what the reference's eager HF stack computes in (bf16 weights / matmuls)
+    ref16 = RefLlava(w, device=DEV, dtype=w.dtype)                    # what the reference's eager HF stack computes in (16-bit weights / matmuls)
+    bd = BOUNDS[w.dtype]
     ids, imgs = _prompts(1, 6, seed=31)
     rows = []
     for L in (1, 8, 16, 32):
@@ -66,13 +73,13 @@ def test_logit_error_grows_like_sqrt_depth_and_stays_below_eager_bf16(model):
                 e_eng.append((got[b * len(ids) + q] - want).abs().max().item())
                 e_16.append((ref16(input_ids=i_[None], images=im).logits[0, -1].float() - want).abs().max().item())
         rows.append((L, max(e_eng), float(np.mean(e_eng)), max(e_16), float(np.mean(e_16))))
-        print(f"depth {L:2d}: engine max |dlogit| {max(e_eng):.3f} (mean of row maxima {np.mean(e_eng):.3f}); eager bf16 {max(e_16):.3f} ({np.mean(e_16):.3f})")
+        print(f"{w.dtype} depth {L:2d}: engine max |dlogit| {max(e_eng):.4f} (mean of row maxima {np.mean(e_eng):.4f}); eager {w.dtype} {max(e_16):.4f} ({np.mean(e_16):.4f})")
         del eng
         torch.cuda.empty_cache()
     ref.cfg = full
     for L, emax, emean, bmax, bmean in rows:
-        assert emax <= 0.10 + 0.17 * L ** 0.5, (L, emax)              # measured 0.16 / 0.45 / 0.56 / 0.81 at logit sigma 2.56
-        assert emean <= 1.25 * bmean + 0.05, (L, emean, bmean)        # no worse than the reference's own bf16 arithmetic
+        assert emax <= bd["a"] + bd["b"] * L ** 0.5, (L, emax)        # bf16: measured 0.16 / 0.45 / 0.56 / 0.81 at logit sigma 2.56
+        assert emean <= 1.25 * bmean + 0.3 * bd["a"], (L, emean, bmean)   # no worse than the reference's own 16-bit arithmetic
     assert rows[-1][2] <= 8.0 * rows[0][2]                             # sqrt(32) = 5.7x: random-walk growth, not linear (32x)
 
 
@@ -116,8 +123,8 @@ def test_full_depth_decode_matches_fp32_where_the_margin_clears_the_noise(model)
                        output_scores=True)
     assert out.stats["graph"] and out.stats["n_rows"] == 12
     checked, agree, noise = _agreement(out, ref, ids, imgs, range(6), n_new, dict(use_dd_unk=True), dict(temperature=1.0))
-    print(f"32 layers, 6 questions x 2 branches, {n_new} tokens: score noise {noise:.3f}; {agree}/{checked} tokens agree where margin > 2 x noise")
-    assert noise <= 3.0                                               # (1+a) e_v + a e_c with |e| <= 0.8: measured ~1.5
+    print(f"{w.dtype} 32 layers, 6 questions x 2 branches, {n_new} tokens: score noise {noise:.3f}; {agree}/{checked} tokens agree where margin > 2 x noise")
+    assert noise <= BOUNDS[w.dtype]["noise"]                          # (1+a) e_v + a e_c with |e| <= 0.8 in bf16: measured ~1.5
     assert checked >= 8 and agree == checked            # (12 rows: the norm-fused few-row step at full depth; a near-tie flip ends a question's comparison)
 
 
@@ -131,5 +138,5 @@ def test_full_depth_at_1536_rows_sampled_questions_match_fp32(model):
     assert out.stats["n_rows"] == 1536 and out.stats["n_groups"] > 0
     sample = list(range(0, 768, 37))                                  # 21 questions from different images
     checked, agree, noise = _agreement(out, ref, ids, imgs, sample, n_new, dict(use_dd_unk=True), dict(temperature=1.0))
-    print(f"32 layers, 1,536 rows: score noise {noise:.3f}; {agree}/{checked} tokens agree where margin > 2 x noise")
-    assert noise <= 3.0 and checked >= 6 and agree == checked
+    print(f"{w.dtype} 32 layers, 1,536 rows: score noise {noise:.3f}; {agree}/{checked} tokens agree where margin > 2 x noise")
+    assert noise <= BOUNDS[w.dtype]["noise"] and checked >= 6 and agree == checked

@@ -139,6 +139,7 @@ def _compare(out, refs, ids, n_new, tol):
     return checked
 
 
+@pytest.mark.both_scalar_forms
 def test_min_new_tokens_and_stop_words_in_the_captured_step(eng, ref):
     """Qwen's MME call shape (run_qwen.py:190-213 + modeling_qwen.py:1061-1075): min_new_tokens, pad = eos, stop words."""
     ids, imgs = prompts(seed=21)
@@ -160,6 +161,7 @@ def test_min_new_tokens_and_stop_words_in_the_captured_step(eng, ref):
     assert _compare(out, refs, ids, n_new, tol=0.4) >= len(ids)
 
 
+@pytest.mark.both_scalar_forms
 def test_min_length_counts_the_prompt(eng, ref):
     ids, imgs = prompts(seed=22)
     kw = dict(images=imgs, temperature=0.5, cd_greedy=True, output_scores=True, max_new_tokens=4)
@@ -178,6 +180,7 @@ def test_min_length_counts_the_prompt(eng, ref):
     assert _compare(out, refs, ids, 4, tol=0.15) >= 2
 
 
+@pytest.mark.both_scalar_forms
 def test_repetition_penalty_and_python_processors(eng, ref):
     """InstructBLIP-style kwargs (blip2_vicuna_instruct.py:396-402) on slot-free prompts + an HF-style callable."""
     from llava_align_amd import add_diffusion_noise
@@ -207,8 +210,27 @@ def test_repetition_penalty_and_python_processors(eng, ref):
     ban = Ban()
     out2 = eng.generate(ids, logits_processor=[ban], **kw)
     assert not out2.stats["graph"] and (out2.tokens == 11).all()
-    Lp = (max(i.numel() for i in ids) + 63) // 64 * 64
+    Lp = max(i.numel() for i in ids)                              # what HF hands a processor: the longest prompt, no rounding
     assert ban.seen == [(4, Lp + s) for s in range(6)]
+
+    class Probe:                                                  # shorter rows are LEFT-padded with the pad id; real tokens sit right-aligned
+        def __init__(self):
+            self.first = None
+
+        def __call__(self, input_ids, scores):
+            if self.first is None:
+                self.first = input_ids.clone()
+            return scores
+    pr = Probe()
+    eng.generate(ids, logits_processor=[pr], pad_token_id=0, eos_token_id=None, **kw)
+    for q, i in enumerate(ids):
+        row = pr.first[q].tolist()
+        assert row[Lp - i.numel():] == i.tolist() and all(t == 0 for t in row[:Lp - i.numel()])
+    # prompts given as embeddings have HF length 0: a processor sees only the generated ids
+    ban2 = Ban()
+    emb = [torch.randn(9 + q, 256, device=DEV).to(eng.dtype) * 0.1 for q in range(2)]
+    eng.generate(None, inputs_embeds=emb, logits_processor=[ban2], temperature=0.5, cd_greedy=True, max_new_tokens=3)
+    assert ban2.seen == [(2, s) for s in range(3)]
     with pytest.raises(ValueError, match="-200"):
         ids_img, imgs = prompts(seed=3)
         eng.generate(ids_img, images=imgs, repetition_penalty=1.2, max_new_tokens=2)
