@@ -333,7 +333,8 @@ def run_strong(a, eng, dev, rank, world):
     eos_t = torch.tensor(eos, device=dev)
     hit = (toks[:, :, None] == eos_t[None, None, :]).any(-1)
     n_tok = torch.where(hit.any(1), hit.float().argmax(1) + 1, torch.full((toks.shape[0],), toks.shape[1], device=dev))
-    res = gather_results(torch.tensor(list(mine), dtype=torch.long, device=dev), toks, n_tok, tt, tp, N)      # ragged T across ranks
+    cap = max(len(get_chunk(N, world, k, group=6)) for k in range(world))             # known on every rank: no size exchange
+    res = gather_results(torch.tensor(list(mine), dtype=torch.long, device=dev), toks, n_tok, tt, tp, N, capacity=cap, width=n_new)   # ragged T across ranks
     torch.cuda.synchronize(dev)
     if world > 1:
         dist.barrier()
@@ -422,7 +423,7 @@ def main():
     for _ in range(a.steps):
         out = step()
     res = gather_results(torch.arange(rank * Q, (rank + 1) * Q, device=dev), out.tokens, torch.full((Q,), out.tokens.shape[1], device=dev),
-                         out.top_tok, out.top_prob, world * Q)                       # the one result gather
+                         out.top_tok, out.top_prob, world * Q, capacity=Q, width=n_new)   # the one result gather (one collective)
     torch.cuda.synchronize(dev)
     if use_dist:
         dist.barrier()

@@ -44,21 +44,29 @@ def run_blip_pope(engine: VddLlavaEngine, front: InstructBlipFrontEnd, questions
                   batch_questions: int = 128, use_cd: bool = False, noise_step: int = 500, cd_beta: Optional[float] = 0.1,
                   cd_alpha: Optional[float] = None, top_p: float = 1.0, temperature: float = 1.0, repetition_penalty: float = 1.0,
                   max_length: int = 256, min_length: int = 1, eos_token_id=2, pad_token_id: Optional[int] = 2,
-                  model_id: str = "instruct_blip", **generate_kw) -> dict:
+                  model_id: str = "instruct_blip", rank: Optional[int] = None, world: Optional[int] = None, **generate_kw) -> dict:
     """questions: POPE json lines (question_id, image, text[, label]).  Defaults are the reference driver's: top_p 1, temperature 1,
     repetition_penalty 1, max_length 256, min_length 1, cd_alpha left at the sampler's default (None -> 0.5), noise_step 500.
-    generate_kw: seed, cd_greedy, sync_every ...  Returns {"answers": [...], "scores": {...}}; the JSONL has the reference's
+    generate_kw: seed, cd_greedy, sync_every ...  rank / world (default: the initialised torch.distributed group): every rank decodes
+    its chunk of whole images (shard.ShardPlan; BASELINE config #5 runs on 4 GPUs), ONE collective gathers the results, rank 0 writes
+    the file, every rank returns the full result.  Returns {"answers": [...], "scores": {...}}; the JSONL has the reference's
     fields (question_id, prompt, text, model_id, image, naive, noise, zeros, metadata; blip_calibrate.py:100-109)."""
+    from .pope_driver import ResultRows, cut_at_eos
+    from .shard import ShardPlan
     order = sorted(range(len(questions)), key=lambda i: (questions[i]["image"], i))
+    plan = ShardPlan([questions[i]["image"] for i in order], rank, world)
+    mine = [order[p_] for p_ in plan.mine]
+    if generate_kw.get("seed") is not None:
+        generate_kw = dict(generate_kw, seed=int(generate_kw["seed"]) + plan.rank)
     decode_token = lambda t: decode([t])
     embed = engine.w.t["embed"]
     eos_set = set([eos_token_id] if isinstance(eos_token_id, int) else (eos_token_id or []))
     base_kw = dict(do_sample=True, top_p=top_p, temperature=temperature, num_beams=1, repetition_penalty=repetition_penalty,
                    min_length=min_length, eos_token_id=eos_token_id, pad_token_id=pad_token_id, n_top=10, cd_beta=cd_beta,
                    cd_alpha=cd_alpha, **generate_kw)
-    answers: Dict[int, dict] = {}
-    for b0 in range(0, len(order), batch_questions):
-        idx = order[b0:b0 + batch_questions]
+    rows = ResultRows(engine.device, max_length, pad_token_id if pad_token_id is not None else 0, n_sets=3)
+    for b0 in range(0, len(mine), batch_questions):
+        idx = mine[b0:b0 + batch_questions]
         qs = [questions[i] for i in idx]
         prompts = [q["text"] + QUESTION_SUFFIX for q in qs]
         llm_ids = [tokenize_llm(p) for p in prompts]
@@ -88,18 +96,14 @@ def run_blip_pope(engine: VddLlavaEngine, front: InstructBlipFrontEnd, questions
         prior_kw = {k: v for k, v in base_kw.items() if k not in ("cd_beta", "cd_alpha")}
         noise = engine.generate(None, inputs_embeds=emb_n, max_length=1, **prior_kw)
         zeros = engine.generate(None, inputs_embeds=emb_z, max_length=1, **prior_kw)
-        dicts = [[C.label_dict_from_top(t, p, decode_token) for t, p in zip(o.top_tok.cpu().tolist(), o.top_prob.cpu().tolist())]
-                 for o in (main, noise, zeros)]
-        toks_all = map_pad_to_eos(main.tokens).tolist()
-        for j, i in enumerate(idx):
-            toks = toks_all[j]
-            for k, t in enumerate(toks):
-                if t in eos_set:
-                    toks = toks[:k + 1]
-                    break
-            answers[i] = {"question_id": qs[j]["question_id"], "prompt": prompts[j], "text": decode(toks).strip(), "model_id": model_id,
-                          "image": qs[j]["image"], "naive": dicts[0][j], "noise": dicts[1][j], "zeros": dicts[2][j], "metadata": {}}
-    ordered = [answers[i] for i in range(len(questions))]
+        rows.add(idx, map_pad_to_eos(main.tokens), [(o.top_tok, o.top_prob) for o in (main, noise, zeros)])
+    got = rows.gather(plan, len(questions))                    # ONE collective; every rank holds every question's results behind it
+    dicts = [[C.label_dict_from_top(t, p_, decode_token) for t, p_ in got["tops"][s_]] for s_ in range(3)]
+    ordered = [{"question_id": q["question_id"], "prompt": q["text"] + QUESTION_SUFFIX, "text": decode(cut_at_eos(got["tokens"][i], eos_set)).strip(),
+                "model_id": model_id, "image": q["image"], "naive": dicts[0][i], "noise": dicts[1][i], "zeros": dicts[2][i], "metadata": {}}
+               for i, q in enumerate(questions)]
+    if plan.rank != 0:
+        answers_path = None                                    # rank 0 owns the file
     if answers_path is not None:
         with open(answers_path, "w") as f:
             for a in ordered:

@@ -97,24 +97,35 @@ def run_mme(engine: VddLlavaEngine, questions: Sequence[dict], build_inputs: Cal
             batch_questions: int = 256, eos_token_id=None, pad_token_id: Optional[int] = None, stop_str: Optional[str] = None,
             max_new_tokens: int = 20, min_new_tokens: Optional[int] = None, noise_step: Optional[int] = None,
             gt: Optional[Dict[tuple, str]] = None, results_root: Optional[str] = None, experiment: str = "exp",
-            subsets: Optional[Sequence[str]] = MME_SUBSETS, chunk: Optional[tuple] = None, **generate_kw) -> dict:
+            subsets: Optional[Sequence[str]] = MME_SUBSETS, chunk: Optional[tuple] = None, rank: Optional[int] = None,
+            world: Optional[int] = None, **generate_kw) -> dict:
     """questions: the llava_mme.jsonl lines (question_id 'category/image.ext', image, text, category); subsets filters them as the
     reference does; chunk=(n, k) takes the reference's k-th of n contiguous ceil-chunks (get_chunk, run_llava.py:32-40).
     generate_kw: cd_alpha, cd_beta, use_dd, use_dd_unk, temperature, top_p, top_k, seed - the reference's generate kwargs; the Qwen
     call shape adds min_new_tokens=1 and pad = eos = eod id (run_qwen.py:190-213); noise_step adds the VCD branch for LLaVA inputs.
     gt + results_root: also convert ('naive', 'none', 'unk', 'none_unk') and score.
+    rank / world (default: the initialised torch.distributed group): the data-parallel form of the reference's --num-chunks /
+    --chunk-idx processes (run_llava.py:261-262) - every rank calls this with the same list, decodes its chunk of whole images
+    (shard.ShardPlan), ONE collective gathers the per-question results, rank 0 writes the answers / result files; every rank returns
+    the full result.
     Returns {"answers": [...], "results": {name: dir}, "scores": {name: mme_scores}}."""
     from .shard import get_chunk
     qs_all = [q for q in questions if subsets is None or q.get("category") in subsets]
     if chunk is not None:
         qs_all = [qs_all[i] for i in get_chunk(len(qs_all), chunk[0], chunk[1], group=1)]
+    from .pope_driver import ResultRows, cut_at_eos
+    from .shard import ShardPlan
     order = sorted(range(len(qs_all)), key=lambda i: (qs_all[i]["image"], i))          # an image's two questions adjacent: shared features
+    plan = ShardPlan([qs_all[i]["image"] for i in order], rank, world)
+    mine = [order[p_] for p_ in plan.mine]
     decode_token = lambda t: decode([t])
     eos_set = set([eos_token_id] if isinstance(eos_token_id, int) else (eos_token_id or []))
-    records: Dict[int, dict] = {}
+    if generate_kw.get("seed") is not None:
+        generate_kw = dict(generate_kw, seed=int(generate_kw["seed"]) + plan.rank)
+    rows = ResultRows(engine.device, max_new_tokens, pad_token_id if pad_token_id is not None else 0, n_sets=3)
     plain_kw = {k: v for k, v in generate_kw.items() if k in ("temperature", "top_p", "top_k", "seed", "cd_alpha", "cd_beta")}
-    for b0 in range(0, len(order), batch_questions):
-        idx = order[b0:b0 + batch_questions]
+    for b0 in range(0, len(mine), batch_questions):
+        idx = mine[b0:b0 + batch_questions]
         lines = [qs_all[i] for i in idx]
         img_cache: Dict[str, dict] = {}
 
@@ -138,21 +149,19 @@ def run_mme(engine: VddLlavaEngine, questions: Sequence[dict], build_inputs: Cal
             prior_kw.update(min_new_tokens=min_new_tokens, eos_token_id=eos_token_id, pad_token_id=pad_token_id)
         none = _generate(engine, [build_inputs(l, "none") for l in lines], **prior_kw)
         unk = _generate(engine, [build_inputs(l, "unk") for l in lines], **prior_kw)
-        dicts = [[C.label_dict_from_top(t, p, decode_token) for t, p in zip(o.top_tok.cpu().tolist(), o.top_prob.cpu().tolist())]
-                 for o in (main, none, unk)]
-        for j, i in enumerate(idx):
-            toks = main.tokens[j].tolist()
-            for k, t in enumerate(toks):                       # cut at the first EOS (the rest is padding)
-                if t in eos_set:
-                    toks = toks[:k + 1]
-                    break
-            text = decode(toks).strip()
-            if stop_str and text.endswith(stop_str):
-                text = text[:-len(stop_str)]
-            records[i] = {"question_id": lines[j]["question_id"], "prompt": lines[j]["text"], "text": text.strip(), "naive": dicts[0][j],
-                          "none": dicts[1][j], "unk": dicts[2][j], "answer_id": uuid.uuid4().hex[:22], "model_id": model_id, "metadata": {}}
+        rows.add(idx, main.tokens, [(o.top_tok, o.top_prob) for o in (main, none, unk)])
         engine.clear_image_cache()
-    answers = [records[i] for i in range(len(qs_all))]
+    got = rows.gather(plan, len(qs_all))                       # ONE collective; every rank holds every question's results behind it
+    dicts = [[C.label_dict_from_top(t, p_, decode_token) for t, p_ in got["tops"][s_]] for s_ in range(3)]
+    answers = []
+    for i, line in enumerate(qs_all):
+        text = decode(cut_at_eos(got["tokens"][i], eos_set)).strip()
+        if stop_str and text.endswith(stop_str):
+            text = text[:-len(stop_str)]
+        answers.append({"question_id": line["question_id"], "prompt": line["text"], "text": text.strip(), "naive": dicts[0][i],
+                        "none": dicts[1][i], "unk": dicts[2][i], "answer_id": uuid.uuid4().hex[:22], "model_id": model_id, "metadata": {}})
+    if plan.rank != 0:
+        answers_path = results_root = None                     # rank 0 owns the files
     if answers_path is not None:
         import json
         import os

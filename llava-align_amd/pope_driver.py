@@ -39,21 +39,77 @@ def _top_dicts(out, decode_token: Callable[[int], str]) -> List[Dict[str, float]
     return [C.label_dict_from_top(t, p, decode_token) for t, p in zip(tt, tp)]
 
 
+def cut_at_eos(toks: List[int], eos_set) -> List[int]:
+    for k, t in enumerate(toks):                       # cut at the first EOS (the rest is padding)
+        if t in eos_set:
+            return toks[:k + 1]
+    return toks
+
+
+class ResultRows:
+    """Per-question results of a rank's chunk as device tensors - generated ids (padded to `width` columns) and the step-0 top-10
+    (token, probability) lists of the main pass and of the prior passes side by side - in the layout of the one result gather
+    (shard.gather_results)."""
+
+    def __init__(self, device, width: int, pad: int, n_sets: int, k: int = 10):
+        self.device, self.width, self.pad, self.n_sets, self.k = device, int(width), int(pad), n_sets, k
+        self.qids: List[int] = []
+        self.tokens, self.n_tok, self.top_tok, self.top_prob = [], [], [], []
+
+    def add(self, qids: Sequence[int], main_tokens: torch.Tensor, tops: Sequence):
+        """tops: one (top_tok [n, k], top_prob [n, k]) pair per set, main pass first."""
+        n, T = main_tokens.shape
+        assert len(tops) == self.n_sets and T <= self.width and n == len(qids)
+        self.qids += list(qids)
+        self.tokens.append(torch.nn.functional.pad(main_tokens, (0, self.width - T), value=self.pad))
+        self.n_tok.append(torch.full((n,), T, dtype=torch.long, device=self.device))
+        self.top_tok.append(torch.cat([t for t, _ in tops], 1))
+        self.top_prob.append(torch.cat([p_ for _, p_ in tops], 1))
+
+    def gather(self, plan, n_total: int) -> dict:
+        """-> host lists for ALL questions on every rank: tokens[i] (valid columns only), tops[s][i] = (tok list, prob list)."""
+        from .shard import gather_results
+        dev, k = self.device, self.n_sets * self.k
+        z = lambda *shape, dt=torch.long: torch.zeros(*shape, dtype=dt, device=dev)
+        res = gather_results(torch.tensor(self.qids, dtype=torch.long, device=dev),
+                             torch.cat(self.tokens) if self.tokens else z(0, self.width), torch.cat(self.n_tok) if self.n_tok else z(0),
+                             torch.cat(self.top_tok) if self.top_tok else z(0, k), torch.cat(self.top_prob) if self.top_prob else z(0, k, dt=torch.float32),
+                             n_total, pad=self.pad, capacity=plan.capacity, width=self.width, world=plan.world)
+        if not bool((res["count"] == 1).all().item()):
+            raise RuntimeError(f"result gather: {int((res['count'] != 1).sum())} of {n_total} questions were not delivered exactly once")
+        n_tok, toks = res["n_tokens"].cpu().tolist(), res["tokens"].cpu().tolist()
+        tt, tp = res["top_tok"].cpu().tolist(), res["top_prob"].cpu().tolist()
+        K = self.k
+        return {"tokens": [r[:n] for r, n in zip(toks, n_tok)],
+                "tops": [[(tt[i][s_ * K:(s_ + 1) * K], tp[i][s_ * K:(s_ + 1) * K]) for i in range(n_total)] for s_ in range(self.n_sets)]}
+
+
 def run_pope(engine: VddLlavaEngine, questions: Sequence[dict], encode: Callable[[str, bool], List[int]],
              decode: Callable[[List[int]], str], load_image: Callable[[str], torch.Tensor], answers_path: Optional[str] = None,
              model_id: str = "llava-align_amd", batch_questions: int = 384, unk_token_id: int = 0, eos_token_id=None,
              pad_token_id: Optional[int] = None, stop_str: Optional[str] = "</s>", max_new_tokens: int = 64, noise_step: Optional[int] = None,
-             **generate_kw) -> dict:
+             rank: Optional[int] = None, world: Optional[int] = None, **generate_kw) -> dict:
     """questions: dicts with question_id, image, text, label (the POPE json lines).  generate_kw: cd_alpha, cd_beta, use_dd,
     use_dd_unk, temperature, top_p, top_k, seed ... exactly the reference's model.generate kwargs (llava_calibrate.py:161-177);
     noise_step adds the VCD branch (images_cd = add_diffusion_noise(image, noise_step), :152-155).
+
+    Data-parallel (the reference: one process per chunk, `--num-chunks / --chunk-idx`, scripts/pope/run_dataset.sh:14-33):
+    with `rank` / `world` (default: the initialised torch.distributed group, else one rank) every rank calls this with the SAME
+    question list, decodes its contiguous chunk of whole images (shard.ShardPlan), the per-question results are gathered in ONE
+    collective, and rank 0 writes the answers file; every rank returns the full result.  An explicit `seed` is offset by the rank
+    (sampled runs then differ from a 1-rank run; cd_greedy / top_k = 1 runs are shard-invariant).
     Returns {"answers": [...], "scores": {"string_match": ..., "naive": ..., "none": ..., "unk": ..., "none_unk": ...}}."""
+    from .shard import ShardPlan
     order = sorted(range(len(questions)), key=lambda i: (questions[i]["image"], i))      # one image's questions adjacent
+    plan = ShardPlan([questions[i]["image"] for i in order], rank, world)
+    mine = [order[p_] for p_ in plan.mine]
     decode_token = lambda t: decode([t])
-    answers: Dict[int, dict] = {}
+    if generate_kw.get("seed") is not None:
+        generate_kw = dict(generate_kw, seed=int(generate_kw["seed"]) + plan.rank)
+    rows = ResultRows(engine.device, max_new_tokens, pad_token_id if pad_token_id is not None else 0, n_sets=3)
     img_cache: Dict[str, torch.Tensor] = {}
-    for b0 in range(0, len(order), batch_questions):
-        idx = order[b0:b0 + batch_questions]
+    for b0 in range(0, len(mine), batch_questions):
+        idx = mine[b0:b0 + batch_questions]
         qs = [questions[i] for i in idx]
         for q in qs:
             if q["image"] not in img_cache:
@@ -73,26 +129,24 @@ def run_pope(engine: VddLlavaEngine, questions: Sequence[dict], encode: Callable
         plain_kw = {k: v for k, v in generate_kw.items() if k in ("temperature", "top_p", "top_k", "seed", "cd_alpha", "cd_beta")}
         # (one call for both priors: 2 x len(qs) text-only prompts that share the conversation template's system prompt as a prefix slot)
         prior = engine.generate(ids_none + ids_unk, images=None, max_new_tokens=1, n_top=10, **plain_kw)
-        prior_d = _top_dicts(prior, decode_token)
-        naive_d, none_d, unk_d = _top_dicts(main, decode_token), prior_d[:len(qs)], prior_d[len(qs):]
-        eos_set = set([eos_token_id] if isinstance(eos_token_id, int) else (eos_token_id or []))
-        for j, i in enumerate(idx):
-            toks = main.tokens[j].tolist()
-            for k, t in enumerate(toks):                       # cut at the first EOS (the rest is padding)
-                if t in eos_set:
-                    toks = toks[:k + 1]
-                    break
-            text = decode(toks).strip()
-            if stop_str and text.endswith(stop_str):
-                text = text[:-len(stop_str)]
-            answers[i] = {"question_id": qs[j]["question_id"], "prompt": qs[j]["text"], "text": text.strip(), "model_id": model_id,
-                          "image": qs[j]["image"], "logits_score": C.get_prob_from_logits(naive_d[j]), "naive": naive_d[j],
-                          "unk": unk_d[j], "none": none_d[j], "metadata": {}}
-        for k in [k for k in img_cache if not any(questions[i]["image"] == k for i in order[b0 + batch_questions:b0 + 2 * batch_questions])]:
+        n = len(qs)
+        rows.add(idx, main.tokens, [(main.top_tok, main.top_prob), (prior.top_tok[:n], prior.top_prob[:n]), (prior.top_tok[n:], prior.top_prob[n:])])
+        ahead = {questions[i]["image"] for i in mine[b0 + batch_questions:b0 + 2 * batch_questions]}
+        for k in [k for k in img_cache if k not in ahead]:
             img_cache.pop(k)                                   # images are revisited only within a sorted neighbourhood
         engine.clear_image_cache()
-    ordered = [answers[i] for i in range(len(questions))]
-    if answers_path is not None:
+    got = rows.gather(plan, len(questions))                    # ONE collective; every rank holds every question's results behind it
+    eos_set = set([eos_token_id] if isinstance(eos_token_id, int) else (eos_token_id or []))
+    dicts = [[C.label_dict_from_top(t, p_, decode_token) for t, p_ in got["tops"][s_]] for s_ in range(3)]
+    ordered = []
+    for i, q in enumerate(questions):
+        text = decode(cut_at_eos(got["tokens"][i], eos_set)).strip()
+        if stop_str and text.endswith(stop_str):
+            text = text[:-len(stop_str)]
+        ordered.append({"question_id": q["question_id"], "prompt": q["text"], "text": text.strip(), "model_id": model_id,
+                        "image": q["image"], "logits_score": C.get_prob_from_logits(dicts[0][i]), "naive": dicts[0][i],
+                        "unk": dicts[2][i], "none": dicts[1][i], "metadata": {}})
+    if answers_path is not None and plan.rank == 0:
         with C.AnswerWriter(answers_path) as w:
             for a in ordered:
                 w.write(a["question_id"], a["prompt"], a["text"], a["model_id"], a["image"], a["logits_score"], a["naive"], a["unk"], a["none"])
@@ -102,7 +156,7 @@ def run_pope(engine: VddLlavaEngine, questions: Sequence[dict], encode: Callable
         scores["string_match"] = _try(C.pope_scores, gt, ordered)
         for name in ("naive", "none", "unk", "none_unk"):
             scores[name] = _try(C.pope_scores_calibrated, gt, ordered, name)
-    return {"answers": ordered, "scores": scores}
+    return {"answers": ordered, "scores": scores, "rank": plan.rank, "world": plan.world}
 
 
 def _try(f, *a):
@@ -115,7 +169,10 @@ def _try(f, *a):
 def main(argv=None):
     """python -m llava_align_amd.pope_driver --model-path DIR --question-file Q.json --image-folder IMGS --answers-file OUT.jsonl
     [--use_dd --use_dd_unk --cd_alpha 1 --cd_beta 0.1 --temperature 0.2 --noise_step N]: the reference CLI's arguments
-    (llava_calibrate.py:222-246) over the native engine.  Needs a LLaVA-1.5 checkpoint directory (HF safetensors + tokenizer)."""
+    (llava_calibrate.py:222-246) over the native engine.  Needs a LLaVA-1.5 checkpoint directory (HF safetensors + tokenizer).
+    On a node: `python -m torch.distributed.run --nnodes=1 --nproc-per-node 8 --master-addr 127.0.0.1 -m llava_align_amd.pope_driver ...`
+    - one rank per GPU, the question list sharded by images, one RCCL gather, rank 0 writes OUT.jsonl and prints the scores (this
+    replaces the reference's --num-chunks / --chunk-idx processes + `cat` of their files, scripts/pope/run_dataset.sh:14-33)."""
     import argparse
     import json
     import os
@@ -134,7 +191,10 @@ def main(argv=None):
     ap.add_argument("--cd_alpha", type=float, default=1.0)
     ap.add_argument("--cd_beta", type=float, default=0.1)
     ap.add_argument("--batch", type=int, default=384)
+    ap.add_argument("--dtype", choices=("float16", "bfloat16"), default="float16", help="model dtype (the reference loads fp16, builder.py:40)")
     a = ap.parse_args(argv)
+    from .shard import init_from_env
+    rank, world, device = init_from_env()
     from PIL import Image
     from safetensors.torch import load_file
     from transformers import AutoTokenizer, CLIPImageProcessor
@@ -145,7 +205,7 @@ def main(argv=None):
         if f.endswith(".safetensors"):
             sd.update(load_file(os.path.join(a.model_path, f)))
     cfg = preset(a.preset)
-    eng = VddLlavaEngine(cfg, weights=LlavaWeights.from_state_dict(cfg, sd, "cuda:0"))
+    eng = VddLlavaEngine(cfg, weights=LlavaWeights.from_state_dict(cfg, sd, device, dtype=getattr(torch, a.dtype)), device=device)
     proc = CLIPImageProcessor.from_pretrained(a.model_path)
 
     def encode(text, with_image):              # tokenizer_image_token (experiments/llava/mm_utils.py): split at <image>, join with -200
@@ -162,8 +222,13 @@ def main(argv=None):
                    answers_path=a.answers_file, model_id=os.path.basename(a.model_path.rstrip("/")), batch_questions=a.batch,
                    unk_token_id=tok.unk_token_id, eos_token_id=tok.eos_token_id, pad_token_id=tok.pad_token_id or 0,
                    noise_step=a.noise_step, use_dd=a.use_dd, use_dd_unk=a.use_dd_unk, cd_alpha=a.cd_alpha, cd_beta=a.cd_beta,
-                   temperature=a.temperature, top_p=a.top_p, top_k=a.top_k)
-    print(json.dumps(res["scores"], indent=1))
+                   temperature=a.temperature, top_p=a.top_p, top_k=a.top_k, rank=rank, world=world)
+    if rank == 0:
+        print(json.dumps(res["scores"], indent=1))
+    if world > 1:
+        import torch.distributed as dist
+        dist.barrier()
+        dist.destroy_process_group()
 
 
 if __name__ == "__main__":

@@ -196,3 +196,35 @@ def test_drivers_at_7b_widths_with_shared_image_prefixes(tmp_path):
     out = run_mme(eng, qs, build, decode, answers_path=str(tmp_path / "mme.jsonl"), batch_questions=32, max_new_tokens=4, eos_token_id=2, pad_token_id=0,
                   gt=gt, results_root=str(tmp_path / "res"), experiment="w7b", use_dd=True, use_dd_unk=True, cd_alpha=1.0, cd_beta=0.1, temperature=0.2, seed=2)
     assert len(out["answers"]) == 32 and all(out["scores"][n] is not None for n in ("naive", "none", "unk", "none_unk"))
+
+
+def test_run_pope_sharded_over_two_ranks_equals_one_rank(tmp_path):
+    """SURVEY 8e / VERDICT r3 item 4: `torchrun -m ...pope_driver` shape - every rank runs run_pope on the same list, decodes its chunk
+    of whole images, ONE gather, rank 0 writes the file.  Two ranks (sharing this box's one GPU over gloo) return, on BOTH ranks, the
+    answers of the one-rank run, token for token under cd_greedy, and the JSONL is written once."""
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    worker = os.path.join(root, "tests", "pope_shard_worker.py")
+    env = dict(os.environ, VDD_FORCE_DEVICE="0", VDD_DIST_BACKEND="gloo")
+    for k in ("RANK", "WORLD_SIZE", "LOCAL_RANK", "MASTER_ADDR", "MASTER_PORT"):
+        env.pop(k, None)
+    one = str(tmp_path / "one")
+    p1 = subprocess.run([sys.executable, worker, one], capture_output=True, text=True, env=env, timeout=600)
+    assert p1.returncode == 0, p1.stderr[-3000:]
+    two = str(tmp_path / "two")
+    p2 = subprocess.run([sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr", "127.0.0.1",
+                         "--master-port", "29547", worker, two], capture_output=True, text=True, env=env, timeout=900)
+    assert p2.returncode == 0, p2.stderr[-3000:]
+    r1 = json.load(open(one + ".rank0.json"))
+    ra, rb = json.load(open(two + ".rank0.json")), json.load(open(two + ".rank1.json"))
+    assert (r1["world"], ra["world"], rb["world"], ra["rank"], rb["rank"]) == (1, 2, 2, 0, 1)
+    assert [a["question_id"] for a in r1["answers"]] == list(range(1000, 1021))
+    for r in (ra, rb):                                        # every rank holds the full, identical result
+        assert [a["text"] for a in r["answers"]] == [a["text"] for a in r1["answers"]]
+        for x, y in zip(r["answers"], r1["answers"]):
+            for name in ("naive", "none", "unk"):
+                assert x[name].keys() == y[name].keys() and all(abs(x[name][k] - y[name][k]) <= 1e-6 for k in x[name]), (x["question_id"], name)
+        assert r["scores"] == r1["scores"]
+    lines = [json.loads(l) for l in open(two + ".jsonl")]
+    assert [l["question_id"] for l in lines] == list(range(1000, 1021)) and lines == [json.loads(l) for l in open(one + ".jsonl")]
