@@ -290,6 +290,35 @@ def bench_cpu(eng):
                                           f"{full} layers -> {t_full:.1f}s"}}
 
 
+def bench_fp16(a, dev, ids, host_imgs, n_new):
+    """Secondary object of the bench line: the headline workload (same prompts, same kwargs) on an fp16 engine - every model kernel in
+    its fp16 instantiation (csrc/vdd_elem.h), fp16 KV pools and logits - plus one question in flight, the reference's own regime."""
+    import torch
+    from llava_align_amd.engine import VddLlavaEngine
+    eng = VddLlavaEngine(a.model, device=dev, seed=0, use_graph=True, lm_head_gain=4.0, dtype=torch.float16)
+    on_dev = {}
+    imgs = [on_dev.setdefault(id(im), im.to(dev).to(torch.float16)) for im in host_imgs]
+    kw = dict(images=imgs, use_dd_unk=True, cd_alpha=1.0, cd_beta=0.1, temperature=0.2, max_new_tokens=n_new, seed=1, n_top=10)
+    eng.generate(ids, **kw)
+    torch.cuda.synchronize(dev)
+    t0 = time.perf_counter(); eng.generate(ids, **kw); torch.cuda.synchronize(dev); dt = time.perf_counter() - t0
+    kw2 = dict(kw, max_new_tokens=2)
+    eng.generate(ids, **kw2)
+    torch.cuda.synchronize(dev)
+    t1 = time.perf_counter(); eng.generate(ids, **kw2); torch.cuda.synchronize(dev); t_pre = time.perf_counter() - t1
+    ids1, imgs1 = pope_prompts(1, per_img=1, seed=99)
+    kw1 = dict(images=imgs1, use_dd_unk=True, cd_alpha=1.0, cd_beta=0.1, temperature=0.2, max_new_tokens=N_NEW, seed=3)
+    eng.generate(ids1, **kw1); eng.generate(ids1, **kw1)
+    torch.cuda.synchronize(dev)
+    t2 = time.perf_counter(); eng.generate(ids1, **kw1); torch.cuda.synchronize(dev); t_b1 = time.perf_counter() - t2
+    Q = len(ids)
+    return {"dtype": "fp16", "tokens_per_s_per_gpu": round(Q * n_new / dt, 1), "ms_per_step": round(dt * 1e3, 2),
+            "decode_step_ms": round((dt - t_pre) / (n_new - 2) * 1e3, 3), "prefill_plus_first_token_s": round(t_pre, 4),
+            "single_question_tokens_per_s": round(N_NEW / t_b1, 1), "hbm_peak_GB": round(torch.cuda.max_memory_allocated(dev) / 1e9, 1),
+            "note": "the headline workload on VddLlavaEngine(dtype=torch.float16): the dtype the reference's drivers load (builder.py:40); one timed step "
+                    "after one warm-up; same kernels compiled for fp16 storage (v_mfma_*_f16, v_dot2c_f32_f16, fp16 KV pools)"}
+
+
 # ------------------------------------------------------------------ strong scaling: one question list split over the ranks
 def run_strong(a, eng, dev, rank, world):
     """`--strong N`: what the eval drivers do on a node (MME/run_llava.py:32-40): ONE seeded POPE-like list of N questions,
@@ -499,9 +528,20 @@ def main():
             line["speedup_vs_eager_gpu"] = round(line["value"] / line["eager_gpu"]["value"], 1)
             line["speedup_vs_eager_gpu_single_question"] = round(line["single_question"]["tokens_per_s"] / line["eager_gpu"]["value"], 1)
             line["cpu_baseline"] = bench_cpu(eng)
+            # the same workload in the reference's own dtype (fp16: builder.py:40; config #2 - the headline - says bf16): the bf16 engine
+            # and its KV pools go first (two engines do not fit 288 GB at 768 questions)
+            del eng, out, oe, o2
+            import gc
+            gc.collect()
+            torch.cuda.empty_cache()
+            line["fp16"] = bench_fp16(a, dev, ids, host_imgs, n_new)
         else:
             line["cpu_baseline"] = None
         line["collective_backend"] = (os.environ.get("VDD_DIST_BACKEND", "nccl") if use_dist else None)
+        if os.path.isdir(os.path.join(ROOT, "gpurun_out")):        # the tuner's picks of this run (source of llava-align_amd/gemm_choices_mi355x.json)
+            from llava_align_amd import ops
+            with open(os.path.join(ROOT, "gpurun_out", "gemm_choices_bench.json"), "w") as f:
+                json.dump({"device": torch.cuda.get_device_name(dev), "choices": ops.gemm_choices_export()}, f, indent=0, sort_keys=True)
         print(json.dumps(line))
     if use_dist:
         dist.barrier()

@@ -69,6 +69,10 @@ struct GemmArgs {
     int UP, U, P;                // K units (128 deep) per tile, units in total, workgroups
     int dp_rounds;               // whole-tile rounds before the stream-K part (host-chosen schedule)
     int stage_out;               // Y rows are 16-byte aligned: the epilogue may store whole rows out of LDS
+#ifdef VDD_GEMM_ABLATE
+    int ablate;                  // probe builds only (tools/gemm_ablate_probe.py): bit 0 no X LDS-DMA after the first tiles, 1 no W LDS-DMA,
+                                 // 2 no W fragment reads, 3 no X fragment reads, 4 no barriers - WRONG results, timing of what is left
+#endif
 };
 
 template <int BM, int BN, int WM, int WN, int EPI>
@@ -170,14 +174,23 @@ __global__ void __launch_bounds__(WM * WN * 64) gemm_kernel(const GemmArgs a) {
             woff[j] = (uint32_t)src * (uint32_t)(a.ldw * 2) + c * 16;
         }
     };
+#ifdef VDD_GEMM_ABLATE
+    const int ab = a.ablate;
+#else
+    constexpr int ab = 0;
+#endif
     auto stage = [&](int t, int buf) {
         const int so = t * 128;
+        if (!((ab & 1) && t >= 2)) {
 #pragma unroll
         for (int j = 0; j < XJ; ++j)
             __builtin_amdgcn_raw_ptr_buffer_load_lds(rx, (lds_ptr_t)(lds + buf * BUF + (j * NW + wave) * 1024), 16, xoff[j], so, 0, 0);
+        }
+        if (!((ab & 2) && t >= 2)) {
 #pragma unroll
         for (int j = 0; j < WJ; ++j)
             __builtin_amdgcn_raw_ptr_buffer_load_lds(rw, (lds_ptr_t)(lds + buf * BUF + (XIMG + j * NW + wave) * 1024), 16, woff[j], so, 0, 0);
+        }
     };
 
     bool more = advance();
@@ -212,11 +225,18 @@ __global__ void __launch_bounds__(WM * WN * 64) gemm_kernel(const GemmArgs a) {
             }
         };
         frag8_t xg[4][MI], wg[4][NI];
+        int rd_n = 0;
         auto rd = [&](int buf, int kk) {
+            const bool first = !ab || rd_n < 4;                 // (probe builds: the first four sets are always read - the registers must hold something)
+            ++rd_n;
+            if (first || !(ab & 4)) {
 #pragma unroll
             for (int i = 0; i < NI; ++i) wg[kk][i] = *reinterpret_cast<const frag8_t*>(lds + buf * BUF + ((wrow + i * 4096) ^ (kk << 5)));
+            }
+            if (first || !(ab & 8)) {
 #pragma unroll
             for (int i = 0; i < MI; ++i) xg[kk][i] = *reinterpret_cast<const frag8_t*>(lds + buf * BUF + ((xrow + i * 4096) ^ (kk << 5)));
+            }
         };
         auto mm = [&](int kk) {
 #pragma unroll
@@ -251,7 +271,7 @@ __global__ void __launch_bounds__(WM * WN * 64) gemm_kernel(const GemmArgs a) {
             rd(buf, 2); mm(0); interleave(false, true); __builtin_amdgcn_sched_barrier(0);
             rd(buf, 3); mm(1); interleave(false, true); __builtin_amdgcn_sched_barrier(0);
             asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");   // own fragment reads of this tile done; tile t+1 landed
-            __builtin_amdgcn_s_barrier();
+            if (!(ab & 16)) __builtin_amdgcn_s_barrier();
             __builtin_amdgcn_sched_barrier(0);
             if constexpr (ST) stage(t + 2, buf);
             if constexpr (NX) rd(buf ^ 1, 0);
@@ -541,6 +561,9 @@ VDD_HIDDEN int VDD_IMPL(vdd_gemm)(const void* X, const void* W, void* Y, const v
     a.M = M; a.N = N; a.K = K; a.ldx = ldx; a.ldw = ldw; a.ldy = ldy; a.ldr = ldr;
     hipStream_t st = (hipStream_t)stream;
     const int sched = (config >> 4) & 3;            // tuning: 0 hybrid, 1 data-parallel only, 2 stream-K only
+#ifdef VDD_GEMM_ABLATE
+    a.ablate = (config >> 8) & 31;
+#endif
     config &= 15;
     if (config == 0) config = 1;
     switch (config) {

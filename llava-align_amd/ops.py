@@ -280,11 +280,15 @@ def gemm(x, w, bias=None, resid=None, epi=EPI_NONE, out=None, config=None):
     if config is None:
         key = _gemm_key(M, N, K, epi, dt)
         config = _gemm_choice.get(key)
+        if config is None and GEMM_AUTOTUNE:
+            _load_persisted(x.device)
+            config = _gemm_choice.get(key)
         if config is None:
             config = 1 + 16 if GEMM_BATCH_INVARIANT else 1
             if M <= GEMM_TUNE_MAX_M and GEMM_AUTOTUNE:
                 if not torch.cuda.is_current_stream_capturing():
                     config = _gemm_choice[key] = _gemm_tune(x, w, out, bias, resid, M, N, K, epi, ws)
+                    _store_persisted(key, config)
                 # (under capture: the default for this launch only - caching it would pin an untuned choice for the process)
             else:
                 _gemm_choice[key] = config
@@ -303,10 +307,7 @@ def _gemm_key(M, N, K, epi, dt=_lib.VDD_BF16):
 
 
 def gemm_choices_export() -> dict:
-    """The tuner's choices so far as a JSON-able dict.  The winner among schedules is picked by wall-clock timing and stream-K cuts
-    change the fp32 summation order of a tile, so two processes may settle on different (equally valid) low-order bits for the same
-    seed; a deployment that needs run-to-run identical logits exports the choices once and imports them at start-up (or sets
-    GEMM_BATCH_INVARIANT, which pins the data-parallel schedule)."""
+    """The tuner's choices so far as a JSON-able dict (key "bucket,N,K,epi,batch_invariant,dtype" -> config)."""
     return {",".join(map(str, k)): v for k, v in _gemm_choice.items()}
 
 
@@ -314,6 +315,78 @@ def gemm_choices_import(d: dict):
     for k, v in d.items():
         b, N, K, epi, inv, *dt = k.split(",")
         _gemm_choice[(int(b), int(N), int(K), int(epi), inv == "True", int(dt[0]) if dt else _lib.VDD_BF16)] = int(v)
+
+
+# ---- persistence of the tuner's choices: run-to-run identical logits.  The winner among (tile, schedule) candidates is picked by
+# wall-clock timing and a stream-K cut changes the fp32 summation order of a tile, so two processes that tune for themselves may
+# settle on different (equally valid) low-order bits - and then sample different tokens from the same seed, where the reference is
+# run-to-run deterministic on one machine.  So choices are looked up, in this order: the process's own table; the user's cache file
+# (`VDD_GEMM_CHOICES=<path>`, default ~/.cache/llava_align_amd/gemm_choices.json; "off" disables persistence) under the section of
+# this device and this build of the library; the in-tree defaults measured on MI355X (gemm_choices_mi355x.json) for the shapes of the
+# supported models.  Only a shape found nowhere is timed, once per machine: the result is written back to the cache file at once.
+_persist = {"loaded": None, "path": None, "section": None}
+
+
+def _choices_file():
+    import os
+    v = os.environ.get("VDD_GEMM_CHOICES")
+    if v is not None and v.lower() in ("off", "0", "none", ""):
+        return None
+    return v if v else os.path.join(os.path.expanduser("~"), ".cache", "llava_align_amd", "gemm_choices.json")
+
+
+def _lib_fingerprint() -> str:
+    import hashlib
+    h = hashlib.sha256()
+    with open(_lib.lib_path(), "rb") as f:
+        for blk in iter(lambda: f.read(1 << 20), b""):
+            h.update(blk)
+    return h.hexdigest()[:16]
+
+
+def _load_persisted(device):
+    """Once per process (and per device name): the in-tree defaults, then the user's cache file on top."""
+    import json
+    import os
+    name = torch.cuda.get_device_name(device)
+    if _persist["loaded"] == name:
+        return
+    _persist.update(loaded=name, path=_choices_file(), section=f"{name}|{_lib_fingerprint()}")
+    default = os.path.join(os.path.dirname(os.path.abspath(__file__)), "gemm_choices_mi355x.json")
+    if "MI355" in name and os.path.exists(default):
+        with open(default) as f:
+            for k, v in json.load(f).get("choices", {}).items():
+                kk = k.split(",")
+                key = (int(kk[0]), int(kk[1]), int(kk[2]), int(kk[3]), kk[4] == "True", int(kk[5]))
+                _gemm_choice.setdefault(key, int(v))
+    if _persist["path"] and os.path.exists(_persist["path"]):
+        try:
+            with open(_persist["path"]) as f:
+                gemm_choices_import(json.load(f).get(_persist["section"], {}))
+        except (OSError, ValueError):
+            pass                                                   # an unreadable cache is no cache
+
+
+def _store_persisted(key, cfg):
+    """Append one freshly tuned choice to the cache file (read - merge - atomic replace: concurrent ranks tune the same shapes)."""
+    import json
+    import os
+    path = _persist["path"]
+    if not path:
+        return
+    try:
+        os.makedirs(os.path.dirname(path), exist_ok=True)
+        data = {}
+        if os.path.exists(path):
+            with open(path) as f:
+                data = json.load(f)
+        data.setdefault(_persist["section"], {})[",".join(map(str, key))] = int(cfg)
+        tmp = f"{path}.{os.getpid()}.tmp"
+        with open(tmp, "w") as f:
+            json.dump(data, f, indent=0, sort_keys=True)
+        os.replace(tmp, path)
+    except (OSError, ValueError):
+        pass
 
 
 def _gemm_tune(x, w, out, bias, resid, M, N, K, epi, ws, iters=8):

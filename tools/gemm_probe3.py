@@ -16,7 +16,7 @@ from llava_align_amd import _lib  # noqa: E402
 
 _P, _I, _L = C.c_void_p, C.c_int, C.c_int64
 lib = _lib.load_lib()
-lib.vdd_gemm.argtypes = [_P, _P, _P, _P, _P, _I, _I, _I, _L, _L, _L, _L, _I, _I, _P, _L, _P]
+lib.vdd_gemm.argtypes = [_P, _P, _P, _P, _P, _I, _I, _I, _L, _L, _L, _L, _I, _I, _P, _L, _I, _P]      # ABI 3: dtype in front of the stream
 lib.vdd_gemm.restype = C.c_int
 lib.vdd_gemm_workspace_bytes.argtypes = [_I, _I]
 lib.vdd_gemm_workspace_bytes.restype = C.c_int64
@@ -38,10 +38,11 @@ def gemm(x, w, epi="none", bias=None, resid=None, cfg=1, out=None):
     N = w.shape[0] // 2 if epi == "swiglu" else w.shape[0]
     st = torch.cuda.current_stream().cuda_stream
     ws = workspace(M, N)
-    out = torch.empty(M, N, dtype=torch.bfloat16, device=dev) if out is None else out
+    out = torch.empty(M, N, dtype=x.dtype, device=dev) if out is None else out
     rc = lib.vdd_gemm(x.data_ptr(), w.data_ptr(), out.data_ptr(), bias.data_ptr() if bias is not None else None,
                       resid.data_ptr() if resid is not None else None, M, N, K, x.stride(0), w.stride(0), out.stride(0),
-                      resid.stride(0) if resid is not None else 0, EPI[epi], cfg, ws.data_ptr(), ws.numel(), st)
+                      resid.stride(0) if resid is not None else 0, EPI[epi], cfg, ws.data_ptr(), ws.numel(),
+                      _lib.VDD_F16 if x.dtype == torch.float16 else _lib.VDD_BF16, st)
     assert rc == 0, (rc, lib.vdd_last_error())
     return out
 
