@@ -326,26 +326,50 @@ class VisionTower:
 
 # ------------------------------------------------------------------ language model
 class KVCache:
-    """Two pools per layer, both [n_slots, n_kv_heads, t_max, head_dim] in the model dtype:
-    `pre`  shared prompt prefixes (system prompt + image patches / + <unk>), token t at index t;
-    `own`  one COMPACT slot per (question, branch): token t at index t - prefix_len, so a slot only holds the
-           question's own ~25 prompt tokens + the generated ones instead of a full-length context."""
+    """Pools per layer, all in the model dtype:
+    `own`   one COMPACT slot per (question, branch), [n_own, n_kv_heads, t_own, head_dim]: token t at index t - prefix_len, so a slot only
+            holds the question's own ~25 prompt tokens + the generated ones instead of a full-length context;
+    shared prompt prefixes (system prompt + image patches / + <unk>), in ONE of two forms:
+    `frag`  (frag_only=True: the decode steps attend the prefixes through the grouped MFMA pass) a fragment-major image per layer,
+            [n_pre, n_kv_heads, 2 t_pre, head_dim]: one 32-KiB block of MFMA operand images per 64-key chunk (vdd_prefix_fragments).
+            The row-major K / V a prefill layer writes and its suffix pass reads live in ONE scratch pair shared by all layers
+            (`kp[i]` / `vp[i]` are the same tensor for every i): the prefill walks prefix and suffix rows layer by layer together
+            and converts the scratch into `pfrag[i]` before the next layer overwrites it.  Round 3 kept both forms for every layer:
+            129 slots x 4 x 168 MB = 87 GB of the 189 GB peak of a 768-question batch, half of it read once;
+    `pre`   (frag_only=False: few rows in flight / nothing worth grouping - the decode kernels read row-major prefixes) per-layer
+            row-major pools [n_pre, n_kv_heads, t_pre, head_dim], token t at index t, and no fragment image at all."""
 
-    def __init__(self, lm: LMConfig, n_pre: int, t_pre: int, n_own: int, t_own: int, device, dtype=torch.bfloat16):
-        self.dtype = dtype
+    def __init__(self, lm: LMConfig, n_pre: int, t_pre: int, n_own: int, t_own: int, device, dtype=torch.bfloat16, frag_only: bool = False):
+        self.dtype, self.frag_only = dtype, frag_only
         self.n_pre, self.t_pre, self.n_own, self.t_own = n_pre, t_pre, n_own, t_own
-        mk = lambda n, t: [torch.empty((max(n, 1), lm.n_kv_heads, t, lm.head_dim), dtype=dtype, device=device)
-                           for _ in range(lm.n_layers)]
-        self.kp, self.vp = mk(n_pre, t_pre), mk(n_pre, t_pre)
+        mk1 = lambda n, t: torch.empty((max(n, 1), lm.n_kv_heads, t, lm.head_dim), dtype=dtype, device=device)
+        mk = lambda n, t: [mk1(n, t) for _ in range(lm.n_layers)]
+        if frag_only:
+            k1, v1 = mk1(n_pre, t_pre), mk1(n_pre, t_pre)
+            self.kp, self.vp = [k1] * lm.n_layers, [v1] * lm.n_layers
+            self.pfrag = mk(n_pre, 2 * t_pre)
+        else:
+            self.kp, self.vp = mk(n_pre, t_pre), mk(n_pre, t_pre)
+            self.pfrag = [None] * lm.n_layers
         self.ko, self.vo = mk(n_own, t_own), mk(n_own, t_own)
-        # fragment-major copy of the prefix K / V (one 32-KiB block of MFMA operand images per 64-key chunk) for the decode prefix pass
-        self.pfrag = mk(n_pre, 2 * t_pre)
 
-    def fits(self, n_pre, t_pre, n_own, t_own):
-        return n_pre <= self.n_pre and t_pre <= self.t_pre and n_own <= self.n_own and t_own <= self.t_own
+    @staticmethod
+    def bytes_needed(lm: LMConfig, n_pre, t_pre, n_own, t_own, dtype, frag_only) -> int:
+        per = lm.n_kv_heads * lm.head_dim * (2 if dtype in (torch.bfloat16, torch.float16) else 4)
+        pre = max(n_pre, 1) * t_pre * per * 2
+        return lm.n_layers * max(n_own, 1) * t_own * per * 2 + (lm.n_layers * pre + pre if frag_only else lm.n_layers * pre)
+
+    def fits(self, n_pre, t_pre, n_own, t_own, frag_only):
+        return (frag_only == self.frag_only and n_pre <= self.n_pre and t_pre <= self.t_pre and n_own <= self.n_own and t_own <= self.t_own)
 
     def nbytes(self):
-        return sum(t.numel() * 2 for pool in (self.kp, self.vp, self.pfrag, self.ko, self.vo) for t in pool)
+        seen, total = set(), 0
+        for pool in (self.kp, self.vp, self.pfrag, self.ko, self.vo):
+            for t in pool:
+                if t is not None and t.data_ptr() not in seen:
+                    seen.add(t.data_ptr())
+                    total += t.numel() * t.element_size()
+        return total
 
 
 def h2d_int32(device, *arrays):
@@ -397,43 +421,53 @@ class LanguageModel:
         return y if y.shape[1] == c.vocab else y[:, :c.vocab]
 
     @torch.no_grad()
-    def prefill(self, x: torch.Tensor, pos: torch.Tensor, cpos: torch.Tensor, slot: torch.Tensor, seqs: torch.Tensor, n_seq: int,
-                max_tq: int, kv: KVCache, to_prefix_pool: bool, last_rows: Optional[torch.Tensor] = None,
-                last_seqs: Optional[torch.Tensor] = None, packs: Optional[torch.Tensor] = None):
-        """x [T, d] packed embeddings; pos (rotary) / cpos (index inside the slot) / slot int32 [T]; seqs [n_seq, 6]
-        (ops.flash_attention).  Writes K/V into the prefix pool (prefix pass) or the own pool (suffix pass) and returns
-        (residual, delta) of the LAST token of every sequence: the final hidden state is their sum (added inside the last
-        norm).  The last decoder layer only computes what someone reads: its K/V for every token (decode attends them), but
-        attention / o-proj / MLP for the last token of each sequence alone (`last_rows` int64 [n_seq], `last_seqs` [n_seq, 6]
-        one-query descriptors) - and nothing past the KV write in the prefix pass, whose hidden states feed no logits
-        (the reference runs all positions through everything, llava_llama.py:88-103)."""
+    def prefill(self, passes: List[dict], kv: KVCache, frag_plen: Optional[torch.Tensor] = None):
+        """The prompt prefill.  passes: one dict per set of packed sequences, walked LAYER BY LAYER together, in order - the prefix pass
+        (`to_prefix_pool=True`: the shared prompt prefixes, K/V into the prefix pool) before the suffix pass whose sequences continue
+        them - each with x [T, d] packed embeddings; pos (rotary) / cpos (index inside the slot) / slot int32 [T]; seqs [n_seq, 6]
+        (ops.flash_attention); n_seq, max_tq; optionally last_rows int64 [n_seq] + last_seqs [n_seq, 6] (one-query descriptors) and
+        packs (ops.flash_packs).  Returns per pass (residual, delta) of the LAST token of every sequence - the final hidden state is
+        their sum (added inside the last norm) - or (None, None) for a pass without last_rows.  The last decoder layer only computes
+        what someone reads: its K/V for every token (decode attends them), but attention / o-proj / MLP for the last token of each
+        sequence alone, and nothing past the KV write in a pass whose hidden states feed no logits (the reference runs all
+        positions through everything, llava_llama.py:88-103).
+        frag_plen (int32 [n_prefix slots], with kv.frag_only): after a layer's passes its row-major prefix K/V - the scratch every
+        layer shares - is converted into that layer's fragment image for the decode steps."""
         c, t = self.cfg, self.w.t
         H, Hkv, D = c.n_heads, c.n_kv_heads, c.head_dim
-        resid, delta = x, None
+        state = [dict(resid=p["x"], delta=None, done=False) for p in passes]
         for i in range(c.n_layers):
-            p = f"l{i}."
+            pfx = f"l{i}."
             final = i == c.n_layers - 1
-            new_resid = torch.empty_like(resid) if delta is not None else None
-            a = ops.rmsnorm(resid, t[p + "ln1"], c.eps, delta=delta, resid_out=new_resid)
-            resid = new_resid if new_resid is not None else resid
-            qkv = ops.linear(a, t[p + "wqkv"], bias=t[p + "bqkv_lm"] if c.qkv_bias else None)
-            kw_, vw_ = (kv.kp[i], kv.vp[i]) if to_prefix_pool else (kv.ko[i], kv.vo[i])
-            q = ops.rope_kv_write(qkv, pos, slot, self.cs, kw_, vw_, H, Hkv, D, cpos=cpos)
-            if final and last_rows is None:
-                return None, None                              # prefix pass: only this layer's K/V were still needed
-            if final:
-                q, resid = q[last_rows].contiguous(), resid[last_rows].contiguous()
-            sq, tq = (last_seqs, 1) if final else (seqs, max_tq)
-            if packs is not None:
-                att = ops.flash_attention_packed(q, kw_, vw_, sq, packs, packs.shape[0], H, Hkv, D, k_prefix=kv.kp[i], v_prefix=kv.vp[i])
-            else:
-                att = ops.flash_attention(q, kw_, vw_, sq, n_seq, tq, H, Hkv, D, causal=True, k_prefix=kv.kp[i], v_prefix=kv.vp[i])
-            o = ops.linear(att, t[p + "wo"])
-            new_resid = torch.empty_like(resid)
-            a = ops.rmsnorm(resid, t[p + "ln2"], c.eps, delta=o, resid_out=new_resid)
-            resid = new_resid
-            delta = ops.linear(ops.swiglu_linear(a, t[p + "wgu"]), t[p + "wd"])
-        return resid, delta
+            for p, st in zip(passes, state):
+                if st["done"]:
+                    continue
+                resid, delta = st["resid"], st["delta"]
+                new_resid = torch.empty_like(resid) if delta is not None else None
+                a = ops.rmsnorm(resid, t[pfx + "ln1"], c.eps, delta=delta, resid_out=new_resid)
+                resid = new_resid if new_resid is not None else resid
+                qkv = ops.linear(a, t[pfx + "wqkv"], bias=t[pfx + "bqkv_lm"] if c.qkv_bias else None)
+                kw_, vw_ = (kv.kp[i], kv.vp[i]) if p["to_prefix_pool"] else (kv.ko[i], kv.vo[i])
+                q = ops.rope_kv_write(qkv, p["pos"], p["slot"], self.cs, kw_, vw_, H, Hkv, D, cpos=p["cpos"])
+                last_rows = p.get("last_rows")
+                if final and last_rows is None:
+                    st.update(resid=None, delta=None, done=True)       # only this layer's K/V were still needed
+                    continue
+                if final:
+                    q, resid = q[last_rows].contiguous(), resid[last_rows].contiguous()
+                sq, tq = (p["last_seqs"], 1) if final else (p["seqs"], p["max_tq"])
+                if p.get("packs") is not None:
+                    att = ops.flash_attention_packed(q, kw_, vw_, sq, p["packs"], p["packs"].shape[0], H, Hkv, D, k_prefix=kv.kp[i], v_prefix=kv.vp[i])
+                else:
+                    att = ops.flash_attention(q, kw_, vw_, sq, p["n_seq"], tq, H, Hkv, D, causal=True, k_prefix=kv.kp[i], v_prefix=kv.vp[i])
+                o = ops.linear(att, t[pfx + "wo"])
+                new_resid = torch.empty_like(resid)
+                a = ops.rmsnorm(resid, t[pfx + "ln2"], c.eps, delta=o, resid_out=new_resid)
+                st["resid"] = new_resid
+                st["delta"] = ops.linear(ops.swiglu_linear(a, t[pfx + "wgu"]), t[pfx + "wd"])
+            if frag_plen is not None:
+                ops.prefix_fragments(kv.kp[i], kv.vp[i], kv.pfrag[i], frag_plen)
+        return [(st["resid"], st["delta"]) for st in state]
 
     @torch.no_grad()
     def logits(self, resid, delta, rows: Optional[torch.Tensor] = None) -> torch.Tensor:
@@ -549,9 +583,9 @@ class _DecodeRunner:
     token broadcast -> 32 x (rmsnorm, qkv, rope+KV write, attention, o-proj, rmsnorm, gate/up, silu*mul, down)
     -> final norm -> lm_head -> fused contrastive sampling tail -> state update.  No host interaction."""
 
-    def __init__(self, eng, Q, nb, max_new, tail):
+    def __init__(self, eng, Q, nb, max_new, tail, kv):
         dev = eng.device
-        self.eng, self.Q, self.nb, self.tail = eng, Q, nb, tail
+        self.eng, self.Q, self.nb, self.tail, self.kv = eng, Q, nb, tail, kv
         R = nb * Q
         i32 = dict(dtype=torch.int32, device=dev)
         self.tokens_rows = torch.zeros(R, dtype=torch.long, device=dev)
@@ -578,7 +612,7 @@ class _DecodeRunner:
         lm = eng.cfg.lm
         # the step's own partials buffer (also for the ungrouped split-KV pass): a captured graph must not point into a
         # shared buffer that a later, larger call re-allocates
-        self.workspace = ops.attention_workspace(R, lm.n_heads, lm.head_dim, eng._kv.t_pre + (eng._kv.t_own + 63) // 64 * 64, dev)
+        self.workspace = ops.attention_workspace(R, lm.n_heads, lm.head_dim, kv.t_pre + (kv.t_own + 63) // 64 * 64, dev)
         if tail.get("n_groups", 0) > 0:
             self.grouping = dict(groups=torch.zeros(max(1, tail["n_groups"]), 4, **i32), group_rows=torch.zeros(R, **i32),
                                  n_groups=tail["n_groups"], items=torch.zeros(max(1, tail["n_items"]), 4, **i32), n_items=tail["n_items"],
@@ -741,24 +775,46 @@ class VddLlavaEngine:
         self.max_q, self.t_max, self.use_graph = max_questions, t_max, use_graph
         # decode attention reads each shared prompt prefix once per GROUP of rows (K/V tiles staged in LDS)
         self.group_attention = True
-        self._kv: Optional[KVCache] = None
+        self._kv: Optional[KVCache] = None          # the pools of the most recent call
+        self._kvs: Dict[bool, KVCache] = {}
         self._feat_cache: Dict[int, torch.Tensor] = {}
         self._graphs: dict = {}
 
     # -- plumbing ---------------------------------------------------------------------------
-    def kv(self, n_pre, t_pre, n_own, t_own):
+    def kv(self, n_pre, t_pre, n_own, t_own, frag_only=False):
+        """The KV pools for a call, one cache per prefix-pool form (KVCache.frag_only): a driver alternates calls that group their
+        decode rows (the image questions) with calls that do not (a handful of rows), and each keeps its pools - and the decode
+        graphs captured over them - across calls; a cache only grows."""
         # prefix slots are whole 64-key chunks (the fragment image); own slots only need whole 16-key groups: 92 own tokens take
         # 96 rows, not 128 (a quarter of the own pool, 26 GB at 768 questions)
         t_pre, t_own = (max(t_pre, 64) + 63) // 64 * 64, (max(t_own, 64) + 15) // 16 * 16
-        if self._kv is None or not self._kv.fits(n_pre, t_pre, n_own, t_own):
-            old = self._kv
-            self._kv = None
-            self._graphs.clear()
+        cur = self._kvs.get(frag_only)
+        if cur is None or not cur.fits(n_pre, t_pre, n_own, t_own, frag_only):
+            self._kvs.pop(frag_only, None)
+            for k in [k for k, r in self._graphs.items() if r.kv is cur]:     # captured steps point into the pools being replaced
+                self._graphs.pop(k)
             grow = lambda a, b: max(a, b)
-            if old is not None:
-                n_pre, t_pre, n_own, t_own = grow(n_pre, old.n_pre), grow(t_pre, old.t_pre), grow(n_own, old.n_own), grow(t_own, old.t_own)
-            del old
-            self._kv = KVCache(self.cfg.lm, n_pre, t_pre, n_own, t_own, self.device, self.dtype)
+            if cur is not None:
+                n_pre, t_pre, n_own, t_own = grow(n_pre, cur.n_pre), grow(t_pre, cur.t_pre), grow(n_own, cur.n_own), grow(t_own, cur.t_own)
+            if self._kv is cur:
+                self._kv = None
+            del cur
+            need = KVCache.bytes_needed(self.cfg.lm, n_pre, t_pre, n_own, t_own, self.dtype, frag_only)
+            other = self._kvs.get(not frag_only)
+            if other is not None and self.device.type == "cuda":
+                free, _total = torch.cuda.mem_get_info(self.device)
+                if need > free + torch.cuda.memory_reserved(self.device) - torch.cuda.memory_allocated(self.device):
+                    # both forms do not fit side by side: the other one (and its graphs) goes
+                    for k in [k for k, r in self._graphs.items() if r.kv is other]:
+                        self._graphs.pop(k)
+                    self._kvs.pop(not frag_only)
+                    if self._kv is other:
+                        self._kv = None
+                    del other
+                    gc.collect()
+                    torch.cuda.empty_cache()
+            self._kvs[frag_only] = KVCache(self.cfg.lm, n_pre, t_pre, n_own, t_own, self.device, self.dtype, frag_only=frag_only)
+        self._kv = self._kvs[frag_only]
         return self._kv
 
     def image_features(self, images: Sequence[torch.Tensor], keys: Optional[Sequence[int]] = None) -> List[torch.Tensor]:
@@ -962,37 +1018,43 @@ class VddLlavaEngine:
         if embeds_prefix is not None and (inputs_embeds is None or len(embeds_prefix) != Q):
             raise ValueError("embeds_prefix goes with inputs_embeds: one (key, n_rows) per prompt")
         plan = self._plan(branches, n_img_tok, share_prefix, embeds_only=inputs_embeds is not None, embeds_prefix=embeds_prefix)
+        # which rows decode, and whether their shared prefixes are attended through the grouped MFMA pass - decided BEFORE the prefill: it
+        # settles the form the prefix K/V are kept in (KVCache: fragment image only, or row-major only)
+        seg = plan["suffix"]
+        keep = [i for i, (name, _, _) in enumerate(branches) if not (use_cd and name == "cd")]
+        sel = [b_ * Q + q for b_ in keep for q in range(Q)]
+        dec_rows = [[seg[i]["slot"], seg[i]["pos0"] + seg[i]["T"] + 1, seg[i]["pslot"], seg[i]["plen"]] for i in sel]
+        grp, _members = group_rows_by_prefix(dec_rows) if self.group_attention else ([], [])
+        if grp and (not grouping_pays(grp, dec_rows) or (len(dec_rows) <= ops.FUSED_ATTN_MAX_M and lm.head_dim == 128)):
+            grp = []      # (up to 16 rows the one-launch RoPE + KV write + attention kernel beats the three launches of the grouped
+                          #  path although it reads a shared prefix once per row: tools/small_batch_attn_probe.py, +4 ... 9 %)
         kv = self.kv(len(plan["prefix"]), max([s_["T"] for s_ in plan["prefix"]] + [0]), len(plan["suffix"]),
-                     max(s_["T"] for s_ in plan["suffix"]) + max_new_tokens)
+                     max(s_["T"] for s_ in plan["suffix"]) + max_new_tokens, frag_only=bool(grp))
         assert plan["max_len"] + max_new_tokens <= self.cfg.lm.max_pos, "prompt + new tokens exceed the rotary table"
         stats = {"n_rows": nb * Q, "prefill_tokens": plan["prefill_tokens"], "unshared_prefill_tokens": plan["unshared_tokens"]}
 
-        last_rows = None
-        for phase in ("prefix", "suffix"):
-            segs = plan[phase]
-            if not segs:
-                continue
+        passes, frag_plen = [], None
+        if plan["prefix"]:
+            segs = plan["prefix"]
             x, pos, cpos, slot, seqs, max_tq = self._pack(segs)
-            if phase == "prefix":
-                self.lm.prefill(x, pos, cpos, slot, seqs, len(segs), max_tq, kv, to_prefix_pool=True)     # K/V only: no logits from here
-                if self.group_attention:
-                    (plen_t,) = h2d_int32(dev, [s_["T"] for s_ in segs])
-                    for li in range(lm.n_layers):
-                        ops.prefix_fragments(kv.kp[li], kv.vp[li], kv.pfrag[li], plen_t)
-            else:
-                # short suffixes behind shared prefixes: four sequences of one prefix per attention workgroup (ops.flash_packs)
-                packs_h = ops.flash_packs([[0, 0, 0, 0, s["pslot"], s["plen"]] for s in segs]) if (max_tq <= 32 and lm.head_dim == 128) else None
-                last, last_seqs, packs = h2d_int32(dev, [s["q_row0"] + s["T"] - 1 for s in segs],
-                                                   [[i, 1, s["pos0"] + s["T"] - 1, s["slot"], s["pslot"], s["plen"]] for i, s in enumerate(segs)],
-                                                   packs_h if packs_h is not None else [[0, -1, -1, -1]])
-                resid, delta = self.lm.prefill(x, pos, cpos, slot, seqs, len(segs), max_tq, kv, to_prefix_pool=False,
-                                               last_rows=last.long(), last_seqs=last_seqs, packs=packs if packs_h is not None else None)
-                logits0 = self.lm.logits(resid, delta)                                        # [nb*Q, V], rows ordered branch-major
-                self.debug_logits0 = logits0
+            passes.append(dict(x=x, pos=pos, cpos=cpos, slot=slot, seqs=seqs, n_seq=len(segs), max_tq=max_tq, to_prefix_pool=True))   # K/V only
+            if kv.frag_only:
+                (frag_plen,) = h2d_int32(dev, [s_["T"] for s_ in segs])
+        segs = plan["suffix"]
+        x, pos, cpos, slot, seqs, max_tq = self._pack(segs)
+        # short suffixes behind shared prefixes: four sequences of one prefix per attention workgroup (ops.flash_packs)
+        packs_h = ops.flash_packs([[0, 0, 0, 0, s["pslot"], s["plen"]] for s in segs]) if (max_tq <= 32 and lm.head_dim == 128) else None
+        last, last_seqs, packs = h2d_int32(dev, [s["q_row0"] + s["T"] - 1 for s in segs],
+                                           [[i, 1, s["pos0"] + s["T"] - 1, s["slot"], s["pslot"], s["plen"]] for i, s in enumerate(segs)],
+                                           packs_h if packs_h is not None else [[0, -1, -1, -1]])
+        passes.append(dict(x=x, pos=pos, cpos=cpos, slot=slot, seqs=seqs, n_seq=len(segs), max_tq=max_tq, to_prefix_pool=False,
+                           last_rows=last.long(), last_seqs=last_seqs, packs=packs if packs_h is not None else None))
+        resid, delta = self.lm.prefill(passes, kv, frag_plen=frag_plen)[-1]
+        logits0 = self.lm.logits(resid, delta)                                        # [nb*Q, V], rows ordered branch-major
+        self.debug_logits0 = logits0
         V = lm.vocab
 
         # ---- step 0: sample from the prefill logits (eager; also yields the top-n for calibration) -----------
-        seg = plan["suffix"]
         # device-side Philox counter = (stream, step): graphs are seed-agnostic.  seed=None: the stream id is drawn from torch's
         # default generator, so every generate() call samples fresh numbers (the reference's torch.multinomial advances the
         # generator too) and torch.manual_seed() reproduces a run's random numbers; an explicit seed is a pure function of the seed.
@@ -1003,19 +1065,12 @@ class VddLlavaEngine:
         eos_t = torch.tensor(eos_token_id, dtype=torch.long, device=dev) if eos_token_id is not None else None
         cfgkey = (Q, nb, max_new_tokens, alpha, beta, warp.t, warp.k, warp.p, use_cd, use_dd, use_dd_unk, cd_greedy,
                   tuple(eos_token_id) if eos_token_id is not None else None, pad_token_id, output_scores)
-        keep = [i for i, (name, _, _) in enumerate(branches) if not (use_cd and name == "cd")]
-        sel = [b * Q + q for b in keep for q in range(Q)]
-        dec_rows = [[seg[i]["slot"], seg[i]["pos0"] + seg[i]["T"] + 1, seg[i]["pslot"], seg[i]["plen"]] for i in sel]
-        grp, _members = group_rows_by_prefix(dec_rows) if self.group_attention else ([], [])
-        if grp and (not grouping_pays(grp, dec_rows) or (len(dec_rows) <= ops.FUSED_ATTN_MAX_M and lm.head_dim == 128)):
-            grp = []      # (up to 16 rows the one-launch RoPE + KV write + attention kernel beats the three launches of the grouped
-                          #  path although it reads a shared prefix once per row: tools/small_batch_attn_probe.py, +4 ... 9 %)
         cpi = ops.prefix_chunks_per_item(grp, lm.n_heads)
         n_groups, n_items = len(grp), len(ops.prefix_work_items(grp, cpi))
         cfgkey = cfgkey + (n_groups, n_items, cpi, proc_key)
         run = self._runner(cfgkey, Q, len(keep), max_new_tokens, dict(alpha=alpha, beta=beta, warp=warp, contrast=contrast,
                            is_vcd=use_cd, both=(use_dd and use_dd_unk), greedy=cd_greedy, eos_t=eos_t, pad=pad_token_id,
-                           output_scores=output_scores, n_groups=n_groups, n_items=n_items, cpi=cpi, proc=proc))
+                           output_scores=output_scores, n_groups=n_groups, n_items=n_items, cpi=cpi, proc=proc), kv)
         run.reset(ctr0)
         if proc:
             run.set_processor_inputs(**self._processor_inputs(proc, prompt_lens, ids_list, min_new_tokens, min_length))
@@ -1121,12 +1176,15 @@ class VddLlavaEngine:
                                              dtype=torch.long, device=dev).reshape(len(ids_list), L)
         return out
 
-    def _runner(self, key, Q, nb, max_new, tail):
+    def _runner(self, key, Q, nb, max_new, tail, kv):
         r = self._graphs.get(key)
+        if r is not None and r.kv is not kv:
+            self._graphs.pop(key)
+            r = None
         if r is None:
             if len(self._graphs) >= 4:
                 self._graphs.pop(next(iter(self._graphs)))
-            r = _DecodeRunner(self, Q, nb, max_new, tail)
+            r = _DecodeRunner(self, Q, nb, max_new, tail, kv)
             self._graphs[key] = r
         return r
 
