@@ -219,7 +219,11 @@ int vdd_skinny_swiglu_normed(const void* H, const float* ss, int nss, const void
  *   buffer per stream: launches on one stream may share it, launches that can run concurrently must not.
  * config: low 4 bits = macro tile (0 = 256x256; 1..8 = 256x256, 128x256, 256x128, 192x256, 256x192, 192x192, 192x128 (these
  *         three: no SwiGLU), 64x256 (a few dozen rows: the launch is a W stream)); bits 4-5 = schedule (0 hybrid: whole-tile rounds + stream-K remainder, 1 data-parallel only,
- *         2 stream-K only).  Every choice writes the same result up to the fp32 summation order of a K-split tile. */
+ *         2 stream-K only).  Every choice writes the same result up to the fp32 summation order of a K-split tile.
+ *         Schedule 3 = split-K SLABS (epilogue NONE only): bits 8-15 = S (1 .. K / 128); Y is then an fp32 buffer [S][M][N] (ldy = N,
+ *         16-byte aligned) receiving the S partial products of every output tile - one (tile, K part) per workgroup, no fix-up, no
+ *         waiting - for a consumer that adds them (vdd_rmsnorm's delta_slabs: the attention-output / MLP-down projections of a few
+ *         dozen rows, whose 16 - 32 output tiles would otherwise be finished by one workgroup each reading 15 partial tiles in turn). */
 #define VDD_GEMM_NONE 0
 #define VDD_GEMM_BIAS 1
 #define VDD_GEMM_BIAS_QUICK_GELU 2

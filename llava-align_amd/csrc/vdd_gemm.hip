@@ -69,6 +69,8 @@ struct GemmArgs {
     int UP, U, P;                // K units (128 deep) per tile, units in total, workgroups
     int dp_rounds;               // whole-tile rounds before the stream-K part (host-chosen schedule)
     int stage_out;               // Y rows are 16-byte aligned: the epilogue may store whole rows out of LDS
+    float* slabs;                // split-K slab mode (slab_S > 0): fp32 partial products [slab_S][M][N], one (tile, K part) per workgroup, no
+    int slab_S;                  // fix-up - the consumer (vdd_rmsnorm's delta_slabs) adds the slabs
 #ifdef VDD_GEMM_ABLATE
     int ablate;                  // probe builds only (tools/gemm_ablate_probe.py): bit 0 no X LDS-DMA after the first tiles, 1 no W LDS-DMA,
                                  // 2 no W fragment reads, 3 no X fragment reads, 4 no barriers - WRONG results, timing of what is left
@@ -102,7 +104,9 @@ __global__ void __launch_bounds__(WM * WN * 64) gemm_kernel(const GemmArgs a) {
     // workgroup rng, and workgroup b runs on XCD b % 8, so rng is XCD-contiguous: the 32 CUs of an XCD work on 32 neighbouring
     // tiles at any time (shared X row-panels / W column-panels in its L2).  Then the stream-K part: the tiles that do not
     // fill a round, as one contiguous range of 128-deep K units per workgroup.
-    const int T = a.Mt * a.Nt, rounds = a.dp_rounds, dp_tiles = min(T, rounds * a.P);
+    // Split-K slab mode: the work items are (tile, K part) pairs, handed out like whole tiles; nothing is left for stream-K.
+    const int S_ = a.slab_S, T = a.Mt * a.Nt, items = S_ > 0 ? T * S_ : T;
+    const int rounds = S_ > 0 ? (items + a.P - 1) / a.P : a.dp_rounds, dp_tiles = S_ > 0 ? T : min(T, rounds * a.P);
     const long long SU = (long long)(T - dp_tiles) * a.UP;            // stream-K units
     const int Psk = (int)min((long long)a.P, SU);                      // never more ranges than units: no empty range
     // n work items for the P workgroups of a round: XCD x (= blockIdx % 8) takes a contiguous run of ceil / floor (n / 8) items,
@@ -117,12 +121,17 @@ __global__ void __launch_bounds__(WM * WN * 64) gemm_kernel(const GemmArgs a) {
     if (rng >= 0) { u = (long long)rng * SU / Psk; u_end = (long long)(rng + 1) * SU / Psk; }
     auto owner = [&](long long uu) { return (int)(((uu + 1) * Psk + SU - 1) / SU - 1); };     // stream-K range that holds unit uu
     int dp_i = 0;
-    int L = 0, ku0 = 0, ku1 = 0;
+    int L = 0, ku0 = 0, ku1 = 0, part = 0;
     auto advance = [&]() -> bool {
         while (dp_i < rounds) {
-            const int j = spread(min(a.P, T - dp_i * a.P));
+            const int j = spread(min(a.P, items - dp_i * a.P));
             ++dp_i;
-            if (j >= 0) { L = (dp_i - 1) * a.P + j; ku0 = 0; ku1 = a.UP; return true; }
+            if (j >= 0) {
+                const int it = (dp_i - 1) * a.P + j;
+                if (S_ > 0) { L = it / S_; part = it - L * S_; ku0 = (int)((long long)part * a.UP / S_); ku1 = (int)((long long)(part + 1) * a.UP / S_); }
+                else { L = it; ku0 = 0; ku1 = a.UP; }
+                return true;
+            }
         }
         if (u < u_end) {
             const int ls = (int)(u / a.UP);
@@ -200,7 +209,7 @@ __global__ void __launch_bounds__(WM * WN * 64) gemm_kernel(const GemmArgs a) {
     };
     if (more) { setup(); stage_first(); }
     while (more) {
-        const int cL = L, cku0 = ku0, cku1 = ku1, ctn = tn, cm0 = m0, cn0 = n0;      // this segment (the state moves on to the next one below)
+        const int cL = L, cku0 = ku0, cku1 = ku1, ctn = tn, cm0 = m0, cn0 = n0, cpart = part;      // this segment (the state moves on to the next one below)
         f32x16_t acc[NI][MI];
 #pragma unroll
         for (int i = 0; i < NI; ++i)
@@ -290,6 +299,23 @@ __global__ void __launch_bounds__(WM * WN * 64) gemm_kernel(const GemmArgs a) {
         more = advance();
         if (more) { setup(); stage_first(); }
 
+        // ---- split-K slab mode: the partial product of this (tile, K part) goes to its slab as it is; the consumer adds the slabs
+        if (S_ > 0) {
+            float* sl = a.slabs + (size_t)cpart * a.M * a.N;
+#pragma unroll
+            for (int i = 0; i < NI; ++i)
+#pragma unroll
+                for (int j = 0; j < MI; ++j) {
+                    const int m = cm0 + wr * TM + j * 32 + (lane & 31);
+#pragma unroll
+                    for (int q = 0; q < 4; ++q) {
+                        const int n = cn0 + wc * TN + i * 32 + q * 8 + 4 * (lane >> 5);
+                        if (m < a.M && n < a.N)
+                            *reinterpret_cast<f32x4_t*>(sl + (size_t)m * a.N + n) = f32x4_t{acc[i][j][q * 4], acc[i][j][q * 4 + 1], acc[i][j][q * 4 + 2], acc[i][j][q * 4 + 3]};
+                    }
+                }
+            continue;
+        }
         // ---- a tile cut across workgroups
         const bool whole = (cku0 == 0 && cku1 == a.UP);
         if (!whole) {
@@ -488,7 +514,8 @@ int launch_cfg(const GemmArgs& a0, int epi, int sched, void* workspace, int64_t 
     {   // schedule: whole-tile rounds, then stream-K over what is left.  The stream-K part always spans at least one tile per
         // workgroup when it exists beside full rounds ("two-tile" stream-K), so a tile is cut into 2 (rarely 3) parts.
         const int T = a.Mt * a.Nt, full = T / P, rem = T % P;
-        if (sched == 1) a.dp_rounds = (T + P - 1) / P;            // data-parallel only
+        if (a.slab_S > 0) { if (a.slab_S > a.UP) return VDD_ERR_INVALID_ARG; a.dp_rounds = 0; }
+        else if (sched == 1) a.dp_rounds = (T + P - 1) / P;       // data-parallel only
         else if (sched == 2) a.dp_rounds = 0;                     // stream-K only
         else a.dp_rounds = rem == 0 ? full : (full > 0 ? full - 1 : 0);
     }
@@ -560,10 +587,15 @@ VDD_HIDDEN int VDD_IMPL(vdd_gemm)(const void* X, const void* W, void* Y, const v
     a.bias = (const uint16_t*)bias; a.resid = (const uint16_t*)resid;
     a.M = M; a.N = N; a.K = K; a.ldx = ldx; a.ldw = ldw; a.ldy = ldy; a.ldr = ldr;
     hipStream_t st = (hipStream_t)stream;
-    const int sched = (config >> 4) & 3;            // tuning: 0 hybrid, 1 data-parallel only, 2 stream-K only
+    const int sched = (config >> 4) & 3;            // tuning: 0 hybrid, 1 data-parallel only, 2 stream-K only, 3 split-K slabs
 #ifdef VDD_GEMM_ABLATE
-    a.ablate = (config >> 8) & 31;
+    a.ablate = (config >> 16) & 31;
 #endif
+    if (sched == 3) {                               // Y = fp32 [S][M][N] (ldy = N), S = config bits 8-15; plain product only
+        a.slab_S = (config >> 8) & 255;
+        a.slabs = (float*)Y;
+        if (a.slab_S < 1 || epilogue != EPI_NONE || ldy != N || ((uintptr_t)Y & 15)) return VDD_ERR_INVALID_ARG;
+    }
     config &= 15;
     if (config == 0) config = 1;
     switch (config) {

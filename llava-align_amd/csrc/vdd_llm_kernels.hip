@@ -690,6 +690,126 @@ __global__ void __launch_bounds__(256) skinny_swiglu_kernel(const uint16_t* __re
     }
 }
 
+// ------------------------------------------------------------------ weight streaming for 17 - 64 rows
+// A few dozen rows in flight (an 8-GPU split of config #3 leaves 34 rows per rank; config #5 on 4 GPUs ~190): too many for the
+// 16-column blocks above - every block re-reads ALL of X from L2, 4 X fragments per W fragment at 64 rows, and that traffic (400 MB
+// for the qkv projection against 100 MB of weights) is what the launch then moves - and too few for the MFMA GEMM, whose 64 x 256
+// tiles cover a fraction of the CUs and pay a serial stream-K fix-up (30 - 43 us per projection whatever M <= 64).
+// Here a block owns 32 output columns - two MFMA column tiles sharing every X fragment - its NW waves split K, and the loads of
+// batch i + 1 (U k-steps: 2 U W fragments + MT U X fragments per lane) are in flight under the MFMAs of batch i.  W is still read
+// from HBM exactly once.  SWIGLU: the two column tiles are 16 gate columns and the 16 matching up columns of W = [Wg; Wu], so the
+// epilogue pairs them in registers: act = rnd(rnd(silu(rnd(gate))) * rnd(up)), the rounding points of the unfused pair.
+template <int MT, int NW, bool SWIGLU>
+__global__ void __launch_bounds__(NW * 64) skinny_wide_kernel(const uint16_t* __restrict__ X, const uint16_t* __restrict__ W,
+                                                             const uint16_t* __restrict__ R, uint16_t* __restrict__ Y, int M, int N, int K,
+                                                             long long ldx, long long ldr, long long ldy) {
+    extern __shared__ __attribute__((aligned(16))) float wide_part[];            // [NW][MT][2][64][4]
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int ln = lane & 15, g = lane >> 4;
+    const int n0 = blockIdx.x * (SWIGLU ? 16 : 32);                               // SWIGLU: N = F features, 16 per block
+    const int kq = K / NW, kbeg = wave * kq;
+    const uint16_t* wp[2];
+#pragma unroll
+    for (int c = 0; c < 2; ++c) {
+        int row = SWIGLU ? n0 + ln : n0 + 16 * c + ln;
+        if (row >= N) row = N - 1;
+        wp[c] = W + ((size_t)(SWIGLU && c == 1 ? N : 0) + row) * K + kbeg + g * 8;
+    }
+    const uint16_t* xp[MT];
+#pragma unroll
+    for (int t = 0; t < MT; ++t) { int r = t * 16 + ln; if (r >= M) r = M - 1; xp[t] = X + (size_t)r * ldx + kbeg + g * 8; }
+    f32x4_t acc[MT][2];
+#pragma unroll
+    for (int t = 0; t < MT; ++t) { acc[t][0] = f32x4_t{0.f, 0.f, 0.f, 0.f}; acc[t][1] = f32x4_t{0.f, 0.f, 0.f, 0.f}; }
+    constexpr int U = MT >= 4 ? 2 : 4;           // k-steps per register stage (64 rows: 2 x (2 + 4) fragments x 2 stages + 32 accumulators fill the file)
+    const int nit = kq / (32 * U);
+    frag8_t b0[U][2], a0[U][MT], b1[U][2], a1[U][MT];
+    auto ld = [&](frag8_t (&b)[U][2], frag8_t (&a)[U][MT], int kk) {
+#pragma unroll
+        for (int u = 0; u < U; ++u) { b[u][0] = ld_w(wp[0] + kk + 32 * u); b[u][1] = ld_w(wp[1] + kk + 32 * u); }
+#pragma unroll
+        for (int u = 0; u < U; ++u)
+#pragma unroll
+            for (int t = 0; t < MT; ++t) a[u][t] = *reinterpret_cast<const frag8_t*>(xp[t] + kk + 32 * u);
+        __builtin_amdgcn_sched_barrier(0);
+    };
+    auto mm = [&](const frag8_t (&b)[U][2], const frag8_t (&a)[U][MT]) {
+#pragma unroll
+        for (int u = 0; u < U; ++u)
+#pragma unroll
+            for (int t = 0; t < MT; ++t) {
+                acc[t][0] = mfma16(a[u][t], b[u][0], acc[t][0]);
+                acc[t][1] = mfma16(a[u][t], b[u][1], acc[t][1]);
+            }
+        __builtin_amdgcn_sched_barrier(0);
+    };
+    if (nit > 0) ld(b0, a0, 0);
+    int it = 0;
+    for (; it + 2 <= nit; it += 2) {
+        ld(b1, a1, (it + 1) * 32 * U);
+        mm(b0, a0);
+        if (it + 2 < nit) ld(b0, a0, (it + 2) * 32 * U);
+        mm(b1, a1);
+    }
+    if (it < nit) mm(b0, a0);
+    const int krem = nit * 32 * U;
+    if (krem < kq) {            // the slice's ragged tail (11008 / 8 = 1376 = 10 batches + 96): one more batch, k-steps beyond it with zero W
+        const frag8_t zero = {0, 0, 0, 0, 0, 0, 0, 0};
+#pragma unroll
+        for (int u = 0; u < U; ++u) {
+            const int kk = krem + 32 * u, kc = kk < kq ? kk : krem;
+            b0[u][0] = ld_w(wp[0] + kc); b0[u][1] = ld_w(wp[1] + kc);
+#pragma unroll
+            for (int t = 0; t < MT; ++t) a0[u][t] = *reinterpret_cast<const frag8_t*>(xp[t] + kc);
+        }
+        __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+        for (int u = 0; u < U; ++u) if (krem + 32 * u >= kq) { b0[u][0] = zero; b0[u][1] = zero; }
+        mm(b0, a0);
+    }
+    auto part = [&](int w, int t, int c) { return wide_part + ((((size_t)w * MT + t) * 2 + c) * 64) * 4; };
+#pragma unroll
+    for (int t = 0; t < MT; ++t)
+#pragma unroll
+        for (int c = 0; c < 2; ++c) *reinterpret_cast<f32x4_t*>(part(wave, t, c) + lane * 4) = acc[t][c];
+    __syncthreads();
+    // C/D map of 16x16x32: col = lane & 15, row = (lane >> 4) * 4 + r.  The NW partials of an entry are added in wave order (fixed).
+    auto total = [&](int t, int c) {
+        f32x4_t s = *reinterpret_cast<const f32x4_t*>(part(0, t, c) + lane * 4);
+#pragma unroll
+        for (int w = 1; w < NW; ++w) { const f32x4_t v = *reinterpret_cast<const f32x4_t*>(part(w, t, c) + lane * 4); s[0] += v[0]; s[1] += v[1]; s[2] += v[2]; s[3] += v[3]; }
+        return s;
+    };
+    if constexpr (SWIGLU) {
+        for (int t = wave; t < MT; t += NW) {
+            const f32x4_t gs = total(t, 0), us = total(t, 1);
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                const int row = t * 16 + g * 4 + r, col = n0 + ln;
+                if (row < M && col < N) {
+                    const float gb = e2f(f2e(gs[r])), ub = e2f(f2e(us[r]));
+                    const float sl = e2f(f2e(gb / (1.f + __expf(-gb))));
+                    Y[(size_t)row * ldy + col] = (uint16_t)f2e(sl * ub);
+                }
+            }
+        }
+    } else {
+        for (int tc = wave; tc < MT * 2; tc += NW) {
+            const int t = tc >> 1, c = tc & 1;
+            const f32x4_t sv = total(t, c);
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                const int row = t * 16 + g * 4 + r, col = n0 + 16 * c + ln;
+                if (row < M && col < N) {
+                    float o = e2f(f2e(sv[r]));
+                    if (R != nullptr) o = o + e2f(R[(size_t)row * ldr + col]);
+                    Y[(size_t)row * ldy + col] = (uint16_t)f2e(o);
+                }
+            }
+        }
+    }
+}
+
 // ------------------------------------------------------------------ decode attention
 // One wave per (row, head).  Lane group g = lane>>4 takes keys t = 4i + g, lane j = lane&15 the
 // dims 8j..8j+7: per iteration a wave reads 4 consecutive K rows (1 KiB contiguous) and the 4
@@ -1329,6 +1449,20 @@ static int skinny_gemm_launch(const void* X, const void* W, const void* R, void*
     auto x = (const uint16_t*)X; auto w = (const uint16_t*)W; auto r = (const uint16_t*)R; auto y = (uint16_t*)Y;
 #define VDD_SKINNY(MT, NW) hipLaunchKernelGGL((skinny_gemm_kernel<MT, NW>), grid, dim3(NW * 64), 0, st, x, w, r, y, Y_slabs, M, N, K, (long long)ldx, (long long)ldr, (long long)ldy, NormIn{}, (float*)nullptr)
     // few column blocks (N = d projections): eight waves per block split K eight ways instead of fp32 slabs across blocks
+    if (M > 16 && n_split == 1 && Y != nullptr && K % 256 == 0 && N > 8192) {          // 17 - 64 rows, wide outputs: 32 columns per block
+        const int mt = (M + 15) / 16;
+        const dim3 g2((N + 31) / 32);
+#define VDD_WIDE(MT)                                                                                                                   \
+        do {                                                                                                                           \
+            constexpr int smem = 4 * MT * 2 * 64 * 4 * (int)sizeof(float);                                                             \
+            static bool attr = false;                                                                                                  \
+            if (!attr) { (void)hipFuncSetAttribute((const void*)skinny_wide_kernel<MT, 4, false>, hipFuncAttributeMaxDynamicSharedMemorySize, smem); attr = true; } \
+            hipLaunchKernelGGL((skinny_wide_kernel<MT, 4, false>), g2, dim3(256), smem, st, x, w, r, y, M, N, K, (long long)ldx, (long long)ldr, (long long)ldy); \
+        } while (0)
+        if (mt == 2) VDD_WIDE(2); else if (mt == 3) VDD_WIDE(3); else VDD_WIDE(4);
+#undef VDD_WIDE
+        return ok(hipSuccess);
+    }
     if (M <= 16 && n_split == 1 && N <= 8192 && K % 256 == 0) VDD_SKINNY(1, 8);
     else if (M <= 16) VDD_SKINNY(1, 4); else if (M <= 32) VDD_SKINNY(2, 4); else VDD_SKINNY(4, 4);
 #undef VDD_SKINNY
@@ -1342,7 +1476,23 @@ VDD_HIDDEN int VDD_IMPL(vdd_skinny_gemm)(const void* X, const void* W, const voi
 
 static int skinny_swiglu_launch(const void* X, const void* W, void* act, int M, int F, int K, int64_t ldx, void* stream) {
     if (M <= 0 || F <= 0) return VDD_OK;
-    if (!X || !W || !act || M > 16 || K % 128 != 0 || (ldx % 8) != 0) return VDD_ERR_INVALID_ARG;
+    if (!X || !W || !act || M > 64 || K % 128 != 0 || (ldx % 8) != 0 || (M > 16 && K % 256 != 0)) return VDD_ERR_INVALID_ARG;
+    if (M > 16) {                                                           // 17 - 64 rows: 16 features (gate + up tiles) per block
+        const int mt = (M + 15) / 16;
+        const dim3 g2((F + 15) / 16);
+        hipStream_t st = (hipStream_t)stream;
+#define VDD_WIDE(MT)                                                                                                                   \
+        do {                                                                                                                           \
+            constexpr int smem = 4 * MT * 2 * 64 * 4 * (int)sizeof(float);                                                             \
+            static bool attr = false;                                                                                                  \
+            if (!attr) { (void)hipFuncSetAttribute((const void*)skinny_wide_kernel<MT, 4, true>, hipFuncAttributeMaxDynamicSharedMemorySize, smem); attr = true; } \
+            hipLaunchKernelGGL((skinny_wide_kernel<MT, 4, true>), g2, dim3(256), smem, st, (const uint16_t*)X, (const uint16_t*)W, (const uint16_t*)nullptr, \
+                               (uint16_t*)act, M, F, K, (long long)ldx, 0LL, (long long)F);                                            \
+        } while (0)
+        if (mt == 2) VDD_WIDE(2); else if (mt == 3) VDD_WIDE(3); else VDD_WIDE(4);
+#undef VDD_WIDE
+        return ok(hipSuccess);
+    }
     hipLaunchKernelGGL(skinny_swiglu_kernel<false>, dim3((F + 7) / 8), dim3(256), 0, (hipStream_t)stream, (const uint16_t*)X,
                             (const uint16_t*)W, (uint16_t*)act, M, F, K, (long long)ldx, NormIn{});
     return ok(hipSuccess);

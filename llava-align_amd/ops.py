@@ -155,11 +155,46 @@ def skinny_gemm(x, w, resid=None, out=None, n_split=1, slabs=False):
     return out
 
 
+SLAB_NORM_MAX_M = 128   # rows up to which a d-wide projection that would take the MFMA GEMM leaves fp32 split-K slabs for its RMSNorm instead (0: off)
+
+
+def gemm_slabs(x, w, n_split, out=None, tile=8):
+    """fp32 [n_split, M, N] partial products of x @ w^T (split-K over n_split parts of K, one (tile, part) per workgroup, no fix-up):
+    for a consumer that adds them - rmsnorm(delta=slabs)."""
+    dt = _dt(x, w)
+    M, K = x.shape
+    N = w.shape[0]
+    if K % 128 != 0 or N % 4 != 0 or not 1 <= n_split <= min(255, K // 128):
+        raise ValueError(f"gemm_slabs: K % 128, N % 4, 1 <= n_split <= K / 128 (got M={M} N={N} K={K} n_split={n_split})")
+    out = torch.empty(n_split, M, N, dtype=torch.float32, device=x.device) if out is None else out
+    ws = _gemm_workspace(x.device, M, N)
+    _lib.check(_lib_ready().vdd_gemm(x.data_ptr(), w.data_ptr(), out.data_ptr(), None, None, M, N, K, x.stride(0), w.stride(0), N, 0,
+                                     EPI_NONE, tile + 16 * 3 + (n_split << 8), ws.data_ptr(), ws.numel(), dt, _st(x)))
+    return out
+
+
+def slab_splits(M, N, K, n_cu=256):
+    """K parts for gemm_slabs of an [M, K] x [N, K] product on 64 x 256 tiles: as many as give every CU one (tile, part) - but parts of
+    at least two 128-deep K units, and none when the tiles alone fill half the chip."""
+    tiles = -(-M // 64) * -(-N // 256)
+    s = min(n_cu // tiles, K // 256)
+    return s if s >= 4 else 0
+
+
 def linear_to_norm(x, w):
-    """Projection whose only consumer is the next RMSNorm's residual add (attention output / MLP down projection).  In the skinny
-    regime N = d gives only d/16 column blocks: the kernel then splits K eight ways INSIDE a block (eight waves, K % 256 == 0 for
-    every LLaVA / Qwen width).  (A second form - fp32 split-K slabs across blocks, summed by the norm - never fired for any K the
-    8-wave form does not cover and was removed; skinny_gemm(..., slabs=True) + rmsnorm(delta=slabs) remain as kernels.)"""
+    """Projection whose only consumer is the next RMSNorm's residual add (attention output / MLP down projection): returns either
+    the [M, N] product or, between skinny_rows() and SLAB_NORM_MAX_M rows, fp32 split-K slabs [S, M, N] that rmsnorm(delta=...) adds,
+    rounds and then adds to the residual stream - the same roundings as a rounded product followed by the add.  N = d gives the MFMA
+    GEMM 16 - 32 output tiles at these row counts: as a finished product each is cut over 8 - 16 workgroups and put together by ONE
+    that reads the others' partial tiles in turn; as slabs nobody waits (projection + norm, tools/skinny_crossover_probe.py: down
+    43.8 -> 38.6 us at 64 rows, 42.2 -> 37.6 at 96; o 29.1 -> 24.3 at 96 - both forms are launch- and latency-bound, ~20 us for the
+    33 MB of the o-projection).  Up to skinny_rows() rows: the weight-streaming kernel (eight waves per 16-column block split K)."""
+    M, K = x.shape
+    N = w.shape[0]
+    if skinny_rows(N, K) < M <= SLAB_NORM_MAX_M and N <= 8192 and K % 256 == 0 and not GEMM_BATCH_INVARIANT:
+        s = slab_splits(M, N, K)
+        if s:
+            return gemm_slabs(x, w, s)
     return linear(x, w)
 
 
@@ -210,16 +245,21 @@ SKINNY_MAX_M = 8      # up to here every projection is a weight-streaming kernel
 
 
 def skinny_rows(N, K):
-    """Up to how many rows the weight-streaming kernel beats the row-batched MFMA GEMM for an [N, K] weight
-    (tools/skinny_crossover_probe.py, LLaVA-1.5-7B shapes, MI355X): the GEMM's time is flat in M below one macro tile (qkv 31, o 28,
-    gate/up 46, down 41 us with the 64-row tile), the streaming kernel's grows with its 16-row MFMA tiles - wide outputs (qkv,
-    gate/up) win up to 16 rows (26 vs 31, 46 vs 46 us), the d-wide ones (eight waves per block) up to 32 (down: 36 vs 41 us) and,
-    with K <= 5120, up to 64 (o: 23 vs 29 us).  Under GEMM_BATCH_INVARIANT the switch stays at SKINNY_MAX_M rows."""
+    """Up to how many rows the weight-streaming kernels take an [N, K] projection before the row-batched MFMA GEMM does.  Up to 16 rows:
+    16-column blocks (one X fragment per W fragment).  17 - 64 rows (round 4): 32-column blocks whose two MFMA column tiles share every
+    X fragment, eight waves splitting K, two register stages (skinny_wide_kernel) - the GEMM's time is flat in M below one macro tile
+    (qkv 31, o 27, gate/up 43, down 38 us: a 64 x 256 tile grid that covers a fraction of the CUs plus a serial stream-K fix-up), the
+    16-column kernel re-read X four times per weight byte at 64 rows (tools/skinny_crossover_probe.py).  Needs K % 256 == 0 (every
+    LLaVA / Qwen width).  Under GEMM_BATCH_INVARIANT the switch stays at SKINNY_MAX_M rows."""
     if GEMM_BATCH_INVARIANT:
         return SKINNY_MAX_M
     if N > 8192:
-        return 16
+        return SKINNY_WIDE_MAX_M if K % 256 == 0 else 16
     return 64 if K <= 5120 else 32
+
+
+SKINNY_WIDE_MAX_M = 24   # rows up to which wide outputs (qkv, gate/up, lm_head) take the 32-column weight-streaming kernel: 26.8 - 29.3 us
+                         # against the GEMM's 30.5 (qkv), 39.7 - 43.7 against 43 (gate/up) at 17 - 24 rows; beyond, its X re-reads cost more
 
 # ---- row-batched MFMA GEMM (csrc/vdd_gemm.hip): every projection above SKINNY_MAX_M rows
 EPI_NONE, EPI_BIAS, EPI_BIAS_QUICK_GELU, EPI_BIAS_GELU, EPI_SWIGLU, EPI_BIAS_RESID = range(6)
@@ -443,7 +483,7 @@ def swiglu_linear(x, w_gate_up, out=None):
     handful of rows, the MFMA GEMM with the SwiGLU epilogue above (no [M, 2F] round trip, no silu_mul launch)."""
     M, K = x.shape
     F = w_gate_up.shape[0] // 2
-    if M <= min(16, skinny_rows(2 * F, K)) and K % 128 == 0:          # the fused kernel holds one 16-row MFMA tile
+    if M <= min(16 if K % 256 else 64, skinny_rows(2 * F, K)) and K % 128 == 0:   # <= 16 rows: 8 features per block; 17 - 64: 16 (gate + up tiles)
         dt = _dt(x, w_gate_up)
         out = torch.empty(M, F, dtype=x.dtype, device=x.device) if out is None else out
         _lib.check(_lib_ready().vdd_skinny_swiglu(x.data_ptr(), w_gate_up.data_ptr(), out.data_ptr(), M, F, K, x.stride(0), dt, _st(x)))

@@ -125,6 +125,32 @@ def test_skinny_gemm(M, N, K):
     assert (y3.float() - big[:, :K].float() @ w.float().t()).abs().max().item() <= tol
 
 
+@pytest.mark.parametrize("M", [17, 31, 32, 33, 48, 50, 64])
+def test_wide_weight_streaming_17_to_64_rows(M):
+    """skinny_wide_kernel: 32-column blocks, eight waves split K (ragged tails: 11008 / 8 = 1376 = 10 batches + 96; 13824 / 8), residual
+    add, the SwiGLU form (16 gate + 16 up columns per block), N not a multiple of 32."""
+    O = ops()
+    for N, K in ((12288, 4096), (4096, 11008), (5120, 13824), (1000, 256), (40, 512)):
+        x, w, r = bf(M, K, seed=81), bf(N, K, scale=0.02, seed=82), bf(M, N, seed=83)
+        ref = x.float() @ w.float().t()
+        y = O.skinny_gemm(x, w)
+        assert (y.float() - ref).abs().max().item() <= 2e-2 * ref.abs().max().item()
+        y2 = O.skinny_gemm(x, w, resid=r)
+        ref2 = ref.to(DT).float() + r.float()
+        assert (y2.float() - ref2).abs().max().item() <= 2e-2 * ref2.abs().max().item()
+        if M <= O.skinny_rows(N, K):
+            assert torch.equal(O.linear(x, w), y)                           # ops.linear routes these rows here
+    for F, K in ((11008, 4096), (13824, 5120), (520, 256)):
+        x, w = bf(M, K, seed=84), bf(2 * F, K, seed=85) * 0.05
+        got = O.swiglu_linear(x, w)
+        g, u = (x.float() @ w[:F].float().t()).to(DT).float(), (x.float() @ w[F:].float().t()).to(DT).float()
+        ref = torch.nn.functional.silu(g).to(DT).float() * u
+        assert got.shape == (M, F) and torch.allclose(got.float(), ref, rtol=3e-2, atol=3e-2)
+        two = O.silu_mul(O.gemm(x, w)) if K % 128 == 0 else None           # the MFMA GEMM + SiLU*mul: same roundings, another k order
+        if two is not None:
+            assert (got.float() - two.float()).abs().max().item() <= 2 ** -6 * ref.abs().max().item()
+
+
 def test_skinny_gemm_eight_wave_blocks_for_narrow_outputs():
     """N <= 8192 without slabs: eight waves per block split K eight ways (o / down projections of one question in flight);
     same result up to the summation order as the four-wave kernel on a wider N made of the same rows."""
@@ -521,3 +547,25 @@ def test_rmsnorm_sums_split_k_slabs():
     assert (ro.float() - h.float()).abs().max().item() <= 0.04          # fp32 summation order may move one bf16 ulp
     ref = (h.float() * torch.rsqrt(h.float().pow(2).mean(-1, keepdim=True) + 1e-5)).to(DT).float() * w.float()
     assert torch.allclose(y.float(), ref, rtol=3e-2, atol=2e-2)
+
+
+@pytest.mark.parametrize("M,N,K", [(40, 4096, 4096), (64, 4096, 11008), (128, 5120, 13824), (33, 520, 512), (100, 4096, 4096)])
+def test_gemm_split_k_slabs_feed_the_rmsnorm(M, N, K):
+    """Schedule 3 of vdd_gemm: fp32 slabs [S, M, N], one (tile, K part) per workgroup, no fix-up; their sum is the product, and
+    rmsnorm(delta=slabs) == rmsnorm(delta=rounded product) up to the summation order."""
+    O = ops()
+    x, w = bf(M, K, seed=91), bf(N, K, scale=0.02, seed=92)
+    ref = x.float() @ w.float().t()
+    for S in sorted(s_ for s_ in {1, 2, 5, O.slab_splits(M, N, K) or 3, min(16, K // 128)} if s_ <= K // 128):
+        sl = O.gemm_slabs(x, w, S)
+        assert sl.shape == (S, M, N) and sl.dtype == torch.float32
+        assert (sl.sum(0) - ref).abs().max().item() <= 1e-3 * ref.abs().max().item() + 1e-3, S
+    res, lnw = bf(M, N, seed=93), bf(N, seed=94) * 0.1 + 1
+    S = O.slab_splits(M, N, K) or 4
+    r1, r2 = torch.empty_like(res), torch.empty_like(res)
+    y1 = O.rmsnorm(res, lnw, 1e-5, delta=O.gemm_slabs(x, w, S), resid_out=r1)
+    y2 = O.rmsnorm(res, lnw, 1e-5, delta=O.gemm(x, w), resid_out=r2)
+    assert (r1.float() - r2.float()).abs().max().item() <= 2 ** -7 * r2.float().abs().max().item()
+    assert (y1.float() - y2.float()).abs().max().item() <= 2 ** -6 * y2.float().abs().max().item()
+    out = O.linear_to_norm(x, w)                                     # the engine's entry: slabs in the 33 - 128-row band, a product elsewhere
+    assert (out.dim() == 3) == (O.skinny_rows(N, K) < M <= 128 and O.slab_splits(M, N, K) > 0)

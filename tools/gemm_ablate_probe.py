@@ -50,7 +50,7 @@ def main():
             rec = dict(tag=f"M{M}.{name}")
             for cfg in ((1, 4) if M <= 4096 else (1,)):
                 for vn, bits in variants:
-                    t = timeit(lambda i: gemm(xs[i & 1], ws[i], "none", cfg=cfg + (bits << 8), out=y), n_rot)
+                    t = timeit(lambda i: gemm(xs[i & 1], ws[i], "none", cfg=cfg + (bits << 16), out=y), n_rot)
                     rec[f"c{cfg}.{vn}"] = [round(t, 1), round(flop / t / 1e9, 3)]
             print(json.dumps(rec), flush=True)
             del ws, xs, y
