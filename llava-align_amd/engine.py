@@ -753,6 +753,8 @@ class VddLlavaEngine:
 
     # generate() kwargs of the reference's drivers that have no effect on this path: KV caching is always on, attention maps /
     # hidden states are never materialised, masks are implied by the ragged prompts, length_penalty only acts on beam search
+    LAUNCH_WINDOW = 16        # decode steps between host waits (see the decode loop): bounds the kernel packets queued at any time
+
     IGNORED_GENERATE_KWARGS = frozenset({"use_cache", "output_attentions", "output_hidden_states", "attention_mask", "length_penalty",
                                          "synced_gpus", "use_image"})
 
@@ -1090,11 +1092,23 @@ class VddLlavaEngine:
             if inputs_embeds is None:
                 streamer.put(torch.tensor([ids_list[0]], dtype=torch.long))
             streamer.put(run.gen[:, 0].cpu())
+        # The host runs ahead of the device (a captured step is one graph launch): without an EOS check nothing ever waits, and a 256-token
+        # generation used to leave > 100,000 kernel packets queued at once.  The HIP runtime copes (it blocks on a full queue), a tool
+        # intercepting the queue does not: rocprofv3 aborted the process / segfaulted at a deterministic dispatch index once ~30 - 60
+        # thousand packets were outstanding (tools/rocprof_abort_bisect.py: 64 new tokens fine, 128 x 2 and 256 not, eager fine).
+        # So the loop waits for the step launched LAUNCH_WINDOW steps ago before going on: at most 2 x 16 steps in flight, no measurable cost.
+        marks = []
         while n_new < max_new_tokens:
             run.step(kv)
             if output_scores:
                 scores.append(run.scores_buf.clone())
             n_new += 1
+            if n_new % self.LAUNCH_WINDOW == 0:
+                ev = torch.cuda.Event()
+                ev.record(torch.cuda.current_stream(dev))
+                marks.append(ev)
+                if len(marks) > 1:
+                    marks.pop(0).synchronize()
             if streamer is not None:
                 streamer.put(run.gen[:, n_new - 1].cpu())
                 if eos_t is not None and int(run.unfinished.max().item()) == 0:
