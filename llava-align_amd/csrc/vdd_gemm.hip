@@ -43,6 +43,10 @@
 
 #include "vdd_elem.h"
 
+#ifndef VDD_GEMM_SPLIT_STAGE
+#define VDD_GEMM_SPLIT_STAGE 1
+#endif
+
 namespace {
 namespace VDD_ELEM_NS {
 using namespace vdd_elem;
@@ -56,7 +60,9 @@ __device__ __forceinline__ float act_quick_gelu(float x) { return x / (1.f + __e
 __device__ __forceinline__ float act_gelu(float x) { return 0.5f * x * (1.f + erff(x * 0.70710678118654752440f)); }
 
 enum { EPI_NONE = VDD_GEMM_NONE, EPI_BIAS = VDD_GEMM_BIAS, EPI_BIAS_QUICK_GELU = VDD_GEMM_BIAS_QUICK_GELU,
-       EPI_BIAS_GELU = VDD_GEMM_BIAS_GELU, EPI_SWIGLU = VDD_GEMM_SWIGLU, EPI_BIAS_RESID = VDD_GEMM_BIAS_RESID };
+       EPI_BIAS_GELU = VDD_GEMM_BIAS_GELU, EPI_SWIGLU = VDD_GEMM_SWIGLU, EPI_BIAS_RESID = VDD_GEMM_BIAS_RESID,
+       EPI_SLABS = 6 };          // internal: schedule 3 of vdd_gemm (split-K slabs) - its own instantiation: the 256 x 256 tile sits at the
+                                 // register cliff (24 - 38 spilled VGPRs), and a run-time slab branch in every instance cost it 200 more
 
 struct GemmArgs {
     const uint16_t* X; const uint16_t* W; uint16_t* Y;
@@ -105,8 +111,9 @@ __global__ void __launch_bounds__(WM * WN * 64) gemm_kernel(const GemmArgs a) {
     // tiles at any time (shared X row-panels / W column-panels in its L2).  Then the stream-K part: the tiles that do not
     // fill a round, as one contiguous range of 128-deep K units per workgroup.
     // Split-K slab mode: the work items are (tile, K part) pairs, handed out like whole tiles; nothing is left for stream-K.
-    const int S_ = a.slab_S, T = a.Mt * a.Nt, items = S_ > 0 ? T * S_ : T;
-    const int rounds = S_ > 0 ? (items + a.P - 1) / a.P : a.dp_rounds, dp_tiles = S_ > 0 ? T : min(T, rounds * a.P);
+    constexpr bool SLAB = EPI == EPI_SLABS;
+    const int S_ = SLAB ? a.slab_S : 1, T = a.Mt * a.Nt, items = SLAB ? T * S_ : T;
+    const int rounds = SLAB ? (items + a.P - 1) / a.P : a.dp_rounds, dp_tiles = SLAB ? T : min(T, rounds * a.P);
     const long long SU = (long long)(T - dp_tiles) * a.UP;            // stream-K units
     const int Psk = (int)min((long long)a.P, SU);                      // never more ranges than units: no empty range
     // n work items for the P workgroups of a round: XCD x (= blockIdx % 8) takes a contiguous run of ceil / floor (n / 8) items,
@@ -128,7 +135,7 @@ __global__ void __launch_bounds__(WM * WN * 64) gemm_kernel(const GemmArgs a) {
             ++dp_i;
             if (j >= 0) {
                 const int it = (dp_i - 1) * a.P + j;
-                if (S_ > 0) { L = it / S_; part = it - L * S_; ku0 = (int)((long long)part * a.UP / S_); ku1 = (int)((long long)(part + 1) * a.UP / S_); }
+                if constexpr (SLAB) { L = it / S_; part = it - L * S_; ku0 = (int)((long long)part * a.UP / S_); ku1 = (int)((long long)(part + 1) * a.UP / S_); }
                 else { L = it; ku0 = 0; ku1 = a.UP; }
                 return true;
             }
@@ -202,6 +209,18 @@ __global__ void __launch_bounds__(WM * WN * 64) gemm_kernel(const GemmArgs a) {
         }
     };
 
+    auto stage_x = [&](int t, int buf) {
+        const int so = t * 128;
+#pragma unroll
+        for (int j = 0; j < XJ; ++j)
+            __builtin_amdgcn_raw_ptr_buffer_load_lds(rx, (lds_ptr_t)(lds + buf * BUF + (j * NW + wave) * 1024), 16, xoff[j], so, 0, 0);
+    };
+    auto stage_w = [&](int t, int buf) {
+        const int so = t * 128;
+#pragma unroll
+        for (int j = 0; j < WJ; ++j)
+            __builtin_amdgcn_raw_ptr_buffer_load_lds(rw, (lds_ptr_t)(lds + buf * BUF + (XIMG + j * NW + wave) * 1024), 16, woff[j], so, 0, 0);
+    };
     bool more = advance();
     auto stage_first = [&]() {
         stage(0, 0); stage(1, 1);
@@ -230,6 +249,14 @@ __global__ void __launch_bounds__(WM * WN * 64) gemm_kernel(const GemmArgs a) {
             for (int i = 0; i < NMMA; ++i) {
                 __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
                 if (with_dma && i < NLD) __builtin_amdgcn_sched_group_barrier(0x020, 1, 0);
+                if (with_reads && i < NRD) __builtin_amdgcn_sched_group_barrier(0x100, 1, 0);
+            }
+        };
+        auto interleave_n = [&](int n_dma, bool with_reads) {               // MFMA, [DMA] (the first n_dma), [read], MFMA, ...
+#pragma unroll
+            for (int i = 0; i < NMMA; ++i) {
+                __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
+                if (i < n_dma) __builtin_amdgcn_sched_group_barrier(0x020, 1, 0);
                 if (with_reads && i < NRD) __builtin_amdgcn_sched_group_barrier(0x100, 1, 0);
             }
         };
@@ -282,11 +309,23 @@ __global__ void __launch_bounds__(WM * WN * 64) gemm_kernel(const GemmArgs a) {
             asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");   // own fragment reads of this tile done; tile t+1 landed
             if (!(ab & 16)) __builtin_amdgcn_s_barrier();
             __builtin_amdgcn_sched_barrier(0);
+#if VDD_GEMM_SPLIT_STAGE
+            // the LDS-DMA of tile t + 2 spread over BOTH post-barrier MFMA groups (X images behind the MFMAs of k-step 2, W images behind
+            // those of k-step 3) instead of all of it behind k-step 2: +1 ... 3 % at prefill and decode sizes, A/B in one process
+            // (tools/gemm_ablate_probe.py --build-variant -DVDD_GEMM_SPLIT_STAGE=0); W first or X first: the same
+            if constexpr (ST) stage_x(t + 2, buf);
+            if constexpr (NX) rd(buf ^ 1, 0);
+            mm(2); interleave_n(ST ? XJ : 0, NX); __builtin_amdgcn_sched_barrier(0);
+            if constexpr (ST) stage_w(t + 2, buf);
+            if constexpr (NX) rd(buf ^ 1, 1);
+            mm(3); interleave_n(ST ? WJ : 0, NX); __builtin_amdgcn_sched_barrier(0);
+#else
             if constexpr (ST) stage(t + 2, buf);
             if constexpr (NX) rd(buf ^ 1, 0);
             mm(2); interleave(ST, NX); __builtin_amdgcn_sched_barrier(0);
             if constexpr (NX) rd(buf ^ 1, 1);
             mm(3); interleave(false, NX); __builtin_amdgcn_sched_barrier(0);
+#endif
         };
         using T_ = std::true_type; using F_ = std::false_type;
         int t = 0;                                  // nk is even: tiles alternate between the two buffers
@@ -300,7 +339,7 @@ __global__ void __launch_bounds__(WM * WN * 64) gemm_kernel(const GemmArgs a) {
         if (more) { setup(); stage_first(); }
 
         // ---- split-K slab mode: the partial product of this (tile, K part) goes to its slab as it is; the consumer adds the slabs
-        if (S_ > 0) {
+        if constexpr (SLAB) {
             float* sl = a.slabs + (size_t)cpart * a.M * a.N;
 #pragma unroll
             for (int i = 0; i < NI; ++i)
@@ -538,6 +577,10 @@ int launch_cfg(const GemmArgs& a0, int epi, int sched, void* workspace, int64_t 
         if (!attr_set) { (void)hipFuncSetAttribute((const void*)kfn, hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem); attr_set = true; } \
         hipLaunchKernelGGL(kfn, grid, block, smem, st, a);                                                            \
         break;                                                                                                        \
+    }
+    if (a.slab_S > 0) {
+        if constexpr (BM == 64) { epi = EPI_SLABS; switch (epi) { VDD_GEMM_LAUNCH(EPI_SLABS) } return hipGetLastError() == hipSuccess ? VDD_OK : VDD_ERR_LAUNCH; }
+        else return VDD_ERR_INVALID_ARG;           // split-K slabs: the 64 x 256 tile (config 8) only
     }
     switch (epi) {
         VDD_GEMM_LAUNCH(EPI_NONE)

@@ -472,6 +472,37 @@ def test_torch_gpu_eager_agrees_within_reference_tolerance():
     assert torch.equal(_bits(out3.scores), _bits(out2.scores))
 
 
+@pytest.mark.gpu_scalar
+@pytest.mark.parametrize("dtype", [torch.float16, torch.bfloat16, torch.float32], ids=["fp16", "bf16", "fp32"])
+@pytest.mark.parametrize("n_in", [2, 3], ids=["dd_unk", "both"])
+def test_sweep_against_torch_rocm_eager(dtype, n_in):
+    """The package default (GPU scalar arithmetic) against the REAL thing it stands for: the reference's own statements
+    (vcd_sample.py:185-200 + HF's TemperatureLogitsWarper / TopKLogitsWarper) executed by torch-ROCm eager on this device - every
+    dtype x beta x temperature x the both-branch average; post-warp scores bit for bit.  (The second golden set pins the same form
+    to an EMULATION of torch-GPU inside a CPU run, tests/golden/make_golden.py:83-137; this is the device itself.)"""
+    L = _L()
+    V, B = 32000, 6
+    rows = [r.to(DEV) for r in logit_rows(7 + n_in, B, V, dtype, n_in)[0]]
+    v, c, d = rows[0], rows[1], (rows[2] if n_in == 3 else None)
+    total = 0
+    for alpha in (1.0, 0.5):
+        for beta in (1.0, 0.5, 0.2, 0.1, 1e-6):
+            for T, top_k in ((None, None), (0.2, None), (0.7, None), (1.5, 50)):
+                cc = (c + d) / 2 if d is not None else c                                            # :185
+                cutoff = torch.log(torch.tensor(beta)) + v.max(dim=-1, keepdim=True).values         # :191 (0-dim CPU fp32 tensor + device tensor)
+                x = ((1 + alpha) * v - alpha * cc).masked_fill(v < cutoff, -float("inf"))           # :193-194
+                if T is not None:
+                    x = x / T                                                                       # TemperatureLogitsWarper
+                if top_k is not None:
+                    kth = torch.topk(x, top_k)[0][..., -1, None]                                    # TopKLogitsWarper
+                    x = x.masked_fill(x < kth, -float("inf"))
+                out = L.contrast_sample(v, c, d, alpha=alpha, beta=beta, warp=L.WarpSpec(temperature=T, top_k=top_k), return_scores=True)
+                n_diff = int((_bits(out.scores) != _bits(x)).sum())
+                total += n_diff
+                assert n_diff == 0, (alpha, beta, T, top_k, n_diff)
+    assert total == 0
+
+
 def test_add_diffusion_noise_matches_oracle_with_explicit_noise(golden_dir):
     L = _L()
     z = np.load(f"{golden_dir}/noise.npz")

@@ -15,7 +15,8 @@ sys.path.insert(0, ROOT)
 LIB = os.path.join(ROOT, "tools", "probes", "libvdd_ablate.so")
 
 
-def build():
+def build(extra_defs=("-DVDD_GEMM_ABLATE",), lib=None):
+    lib = lib or LIB
     from importlib import import_module
     B = import_module("llava_align_amd._build")
     obj_dir = os.path.join(ROOT, "build", "obj_ablate")
@@ -24,11 +25,11 @@ def build():
     for src, obj, extra in B.units():
         o = os.path.join(obj_dir, os.path.basename(obj))
         objs.append(o)
-        cmd = [B.hipcc(), *B.CFLAGS, *extra, "-DVDD_GEMM_ABLATE", "-I", os.path.join(ROOT, "include"), "-I", B.CSRC, "-c", src, "-o", o]
+        cmd = [B.hipcc(), *B.CFLAGS, *extra, *extra_defs, "-I", os.path.join(ROOT, "include"), "-I", B.CSRC, "-c", src, "-o", o]
         procs.append(subprocess.Popen(cmd))
     assert all(p.wait() == 0 for p in procs)
-    subprocess.run([B.hipcc(), "--offload-arch=gfx950", "-shared", "-fPIC", *objs, "-o", LIB], check=True)
-    print(LIB)
+    subprocess.run([B.hipcc(), "--offload-arch=gfx950", "-shared", "-fPIC", *objs, "-o", lib], check=True)
+    print(lib)
 
 
 def main():
@@ -57,4 +58,10 @@ def main():
 
 
 if __name__ == "__main__":
-    build() if "--build" in sys.argv else main()
+    if "--build-variant" in sys.argv:          # e.g. --build-variant -DVDD_GEMM_SPLIT_STAGE=0 tools/probes/libvdd_nosplit.so: an A/B library for gemm_cfg_probe.py
+        i = sys.argv.index("--build-variant")
+        build((sys.argv[i + 1],), os.path.join(ROOT, sys.argv[i + 2]))
+    elif "--build" in sys.argv:
+        build()
+    else:
+        main()
