@@ -393,7 +393,8 @@ def _load_persisted(device):
         return
     _persist.update(loaded=name, path=_choices_file(), section=f"{name}|{_lib_fingerprint()}")
     default = os.path.join(os.path.dirname(os.path.abspath(__file__)), "gemm_choices_mi355x.json")
-    if "MI355" in name and os.path.exists(default):
+    arch = getattr(torch.cuda.get_device_properties(device), "gcnArchName", "")
+    if arch.startswith("gfx950") and os.path.exists(default):
         with open(default) as f:
             for k, v in json.load(f).get("choices", {}).items():
                 kk = k.split(",")
