@@ -311,6 +311,15 @@ int vdd_flash_attention_packed(const void* q, const void* k_cache, const void* v
                                const int32_t* seqs, const int32_t* packs, void* out, int n_packs, int H, int Hkv, int D,
                                int64_t slot_stride, int t_max, int64_t prefix_stride, int prefix_tmax, float scale, int dtype, void* hip_stream);
 
+/* The attention PROBABILITIES of one prompt, materialised: out [H, Tq, Tk] (Tk = pos0 + Tq) of the call's dtype,
+ * out[h][i][t] = softmax over t <= pos0 + i of (q_i . k_t) * scale computed in fp32 and rounded (HF's eager attention), 0 behind the
+ * diagonal.  q [.., H*D] rotated queries (row q_row0 + i), keys from [prefix slot | own slot] as in vdd_flash_attention; `seq` is a
+ * HOST array {q_row0, Tq, pos0, slot, prefix_slot, prefix_len}.  D == 128, Tk <= 16384.  This is what the reference's POPE driver
+ * reads of generate(output_attentions=True): model_outputs['attentions'][0][-1], step 0 / last layer (llava_calibrate.py:175,180-182);
+ * the flash kernels of the path never build the matrix. */
+int vdd_attention_probs(const void* q, const void* k_cache, const void* k_prefix, const int32_t* seq /* host */, void* out, int H, int Hkv,
+                        int D, int64_t slot_stride, int t_max, int64_t prefix_stride, int prefix_tmax, float scale, int dtype, void* hip_stream);
+
 /* ViT front-end glue around the patch-embed GEMM (HF CLIPVisionEmbeddings / CLIPAttention as run by clip_encoder.py:39-51):
  * im2col of the stride-P patch convolution (images [n,3,S,S] of vdd_dtype `image_dtype`: fp32 / fp16 / bf16 -> patches of the model `dtype` [n*(S/P)^2, Kp], zero
  * padded from 3*P*P to Kp columns); class token + position embeddings (h[i,t] = (t ? emb[i*(T-1)+t-1] : cls) + pos[t]);

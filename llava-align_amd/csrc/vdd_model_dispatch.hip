@@ -86,6 +86,10 @@ VDD_MODEL_FN(vdd_flash_attention_packed,
                    const int32_t* packs, void* out, int n_packs, int H, int Hkv, int D, int64_t slot_stride, int t_max, int64_t prefix_stride,
                    int prefix_tmax, float scale),
              VDD_P(q, k_cache, v_cache, k_prefix, v_prefix, seqs, packs, out, n_packs, H, Hkv, D, slot_stride, t_max, prefix_stride, prefix_tmax, scale))
+VDD_MODEL_FN(vdd_attention_probs,
+             VDD_P(const void* q, const void* k_cache, const void* k_prefix, const int32_t* seq, void* out, int H, int Hkv, int D, int64_t slot_stride,
+                   int t_max, int64_t prefix_stride, int prefix_tmax, float scale),
+             VDD_P(q, k_cache, k_prefix, seq, out, H, Hkv, D, slot_stride, t_max, prefix_stride, prefix_tmax, scale))
 VDD_MODEL_FN(vdd_vit_im2col, VDD_P(const void* images, int image_dtype, void* patches, int n, int S, int P, int Kp),
              VDD_P(images, image_dtype, patches, n, S, P, Kp))
 VDD_MODEL_FN(vdd_vit_assemble, VDD_P(const void* emb, const void* cls, const void* pos, void* out, int n, int T, int width),

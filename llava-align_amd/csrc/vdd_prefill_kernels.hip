@@ -446,6 +446,49 @@ __global__ void __launch_bounds__(256) add_kernel(const uint16_t* __restrict__ a
     }
 }
 
+// ------------------------------------------------------------------ attention probabilities of one prompt (materialised on request)
+// The reference's POPE driver asks generate() for the attention maps (output_attentions=True, llava_calibrate.py:175) and reads ONE of
+// them: model_outputs['attentions'][0][-1] - step 0, last layer, [1, H, T, T] - to average it (:180-182).  The flash kernels never
+// build that matrix; this kernel does, for one sequence, from the rotated q of the last layer and the K already in the caches:
+// out[h][i][t] = softmax_t(q_i . k_t * scale) over t <= pos0 + i in fp32, rounded to the model dtype (HF's eager attention:
+// fp32 softmax, then `.to(query.dtype)`), zeros behind the diagonal.  One block per (query row, head); a 16-lane group per key.
+__global__ void __launch_bounds__(256) attn_probs_kernel(const uint16_t* __restrict__ q, const uint16_t* __restrict__ kc, const uint16_t* __restrict__ kpre,
+                                                         SeqDesc sd, uint16_t* __restrict__ out, int H, int Hkv, long long slot_stride, int t_max,
+                                                         long long pre_stride, int pre_tmax, float scale) {
+    constexpr int D = 128;
+    extern __shared__ float sc[];                                  // Tk scores of this (row, head)
+    __shared__ float red[8];
+    const int i = blockIdx.x, head = blockIdx.y, tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, g = lane >> 4, j = lane & 15;
+    const int Tk = sd.pos0 + sd.Tq, n = sd.pos0 + i + 1;           // keys this query sees
+    const int kvh = head / (H / Hkv);
+    const uint4 qv = *reinterpret_cast<const uint4*>(q + ((size_t)(sd.q_row0 + i) * H + head) * D + j * 8);
+    const uint16_t* k_pre = kpre + (size_t)sd.pslot * pre_stride + (size_t)kvh * pre_tmax * D + j * 8;
+    const uint16_t* k_own = kc + (size_t)sd.slot * slot_stride + (size_t)kvh * t_max * D + j * 8 - (size_t)sd.plen * D;
+    float mx = -INFINITY;
+    for (int t0 = wave * 4 + g; t0 < n; t0 += 16) {
+        const uint4 kv = *reinterpret_cast<const uint4*>((t0 < sd.plen ? k_pre : k_own) + (size_t)t0 * D);
+        float s_ = dot2(qv.x, kv.x, 0.f); s_ = dot2(qv.y, kv.y, s_); s_ = dot2(qv.z, kv.z, s_); s_ = dot2(qv.w, kv.w, s_);
+        s_ += __shfl_xor(s_, 1); s_ += __shfl_xor(s_, 2); s_ += __shfl_xor(s_, 4); s_ += __shfl_xor(s_, 8);
+        s_ *= scale;
+        if (j == 0) sc[t0] = s_;
+        mx = fmaxf(mx, s_);
+    }
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) mx = fmaxf(mx, __shfl_xor(mx, o));
+    if (lane == 0) red[wave] = mx;
+    __syncthreads();
+    mx = fmaxf(fmaxf(red[0], red[1]), fmaxf(red[2], red[3]));
+    float sum = 0.f;
+    for (int t = tid; t < n; t += 256) { const float e = expf(sc[t] - mx); sc[t] = e; sum += e; }
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) sum += __shfl_xor(sum, o);
+    if (lane == 0) red[4 + wave] = sum;
+    __syncthreads();
+    const float inv = 1.f / ((red[4] + red[5]) + (red[6] + red[7]));
+    uint16_t* orow = out + ((size_t)head * sd.Tq + i) * Tk;
+    for (int t = tid; t < Tk; t += 256) orow[t] = t < n ? (uint16_t)f2e(sc[t] * inv) : (uint16_t)0;
+}
+
 inline int ok() { return hipGetLastError() == hipSuccess ? VDD_OK : VDD_ERR_LAUNCH; }
 
 }  // namespace VDD_ELEM_NS
@@ -493,6 +536,20 @@ VDD_HIDDEN int VDD_IMPL(vdd_flash_attention_packed)(const void* q, const void* k
     hipLaunchKernelGGL(kfn, grid, block, smem, (hipStream_t)stream, (const uint16_t*)q, (const uint16_t*)k_cache, (const uint16_t*)v_cache,
                        (const uint16_t*)k_prefix, (const uint16_t*)v_prefix, (const SeqDesc*)seqs, (uint16_t*)out, H, Hkv, (long long)slot_stride,
                        t_max, (long long)prefix_stride, prefix_tmax, scale, 1, n_packs, (const int4*)packs);
+    return ok();
+}
+
+VDD_HIDDEN int VDD_IMPL(vdd_attention_probs)(const void* q, const void* k_cache, const void* k_prefix, const int32_t* seq, void* out, int H, int Hkv,
+                                             int D, int64_t slot_stride, int t_max, int64_t prefix_stride, int prefix_tmax, float scale, void* stream) {
+    if (!q || !k_cache || !k_prefix || !seq || !out || D != 128 || H <= 0 || Hkv <= 0 || H % Hkv != 0) return VDD_ERR_INVALID_ARG;
+    SeqDesc sd;                                                   // HOST descriptor of the one sequence: {q_row0, Tq, pos0, slot, prefix_slot, prefix_len}
+    sd.q_row0 = seq[0]; sd.Tq = seq[1]; sd.pos0 = seq[2]; sd.slot = seq[3]; sd.pslot = seq[4]; sd.plen = seq[5];
+    if (sd.Tq <= 0) return VDD_OK;
+    const int Tk = sd.pos0 + sd.Tq;
+    if (sd.pos0 < 0 || sd.plen < 0 || sd.plen > Tk || Tk > 16384 || H > 65535) return VDD_ERR_INVALID_ARG;
+    hipLaunchKernelGGL(attn_probs_kernel, dim3(sd.Tq, H), dim3(256), (size_t)Tk * sizeof(float), (hipStream_t)stream, (const uint16_t*)q,
+                       (const uint16_t*)k_cache, (const uint16_t*)k_prefix, sd, (uint16_t*)out, H, Hkv, (long long)slot_stride, t_max,
+                       (long long)prefix_stride, prefix_tmax, scale);
     return ok();
 }
 

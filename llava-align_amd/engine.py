@@ -449,6 +449,8 @@ class LanguageModel:
                 qkv = ops.linear(a, t[pfx + "wqkv"], bias=t[pfx + "bqkv_lm"] if c.qkv_bias else None)
                 kw_, vw_ = (kv.kp[i], kv.vp[i]) if p["to_prefix_pool"] else (kv.ko[i], kv.vo[i])
                 q = ops.rope_kv_write(qkv, p["pos"], p["slot"], self.cs, kw_, vw_, H, Hkv, D, cpos=p["cpos"])
+                if final and p.get("keep_q"):
+                    p["q_last"] = q                                # the rotated queries of the last layer, every row (attention maps on request)
                 last_rows = p.get("last_rows")
                 if final and last_rows is None:
                     st.update(resid=None, delta=None, done=True)       # only this layer's K/V were still needed
@@ -554,14 +556,48 @@ class GenerateOutput:
     top_prob: Optional[torch.Tensor] = None  # step-0 top-10 softmax(scores) (metrics.py:102-104)
     top_tok: Optional[torch.Tensor] = None
     stats: dict = field(default_factory=dict)
+    attentions: Optional["StepAttentions"] = None      # output_attentions=True with ONE question: what llava_calibrate.py:180 reads
 
     def __getitem__(self, k):
+        if k == "attentions" and self.attentions is not None:
+            return self.attentions
         if k in ("attentions", "hidden_states"):
             raise KeyError(f"{k}: not produced by the native engine (attention is computed by flash-style kernels that never materialise the "
                            f"maps).  llava_calibrate.py:180-182 reads model_outputs['attentions'][0][-1] and averages it in live code, for a "
                            f"plot whose call (:183) is commented out: delete those lines in a driver ported to the engine, or use the "
                            f"generic evolve_vcd_sampling() path on an HF model for the maps")
         return getattr(self, k)
+
+
+class StepAttentions:
+    """`model_outputs['attentions']` as far as the reference's driver reads it (llava_calibrate.py:180: `['attentions'][0][-1]`): a
+    sequence over generation steps whose step 0 is a sequence over layers whose LAST entry is the materialised map [1, H, T, T] of the
+    main branch's prompt (ops.attention_probs).  HF returns every layer of every step; the engine's flash-style kernels build none of
+    them, and only this one is computed afterwards from the prefill's rotated queries and cached keys - any other index says so."""
+
+    class _Layers:
+        def __init__(self, last, n_layers):
+            self.last, self.n = last, n_layers
+
+        def __len__(self):
+            return self.n
+
+        def __getitem__(self, i):
+            if i in (-1, self.n - 1):
+                return self.last
+            raise IndexError(f"attentions[0][{i}]: only the LAST layer's map of step 0 is materialised (what llava_calibrate.py:180 reads); the "
+                             f"other layers are computed by flash-style kernels that never build the matrix")
+
+    def __init__(self, last_layer_map, n_layers, n_steps):
+        self.step0, self.n_steps = StepAttentions._Layers(last_layer_map, n_layers), n_steps
+
+    def __len__(self):
+        return self.n_steps
+
+    def __getitem__(self, i):
+        if i == 0 or (i < 0 and i == -self.n_steps):
+            return self.step0
+        raise IndexError(f"attentions[{i}]: only step 0 is materialised (llava_calibrate.py:180 reads ['attentions'][0][-1])")
 
 
 def group_rows_by_prefix(rows):
@@ -755,8 +791,7 @@ class VddLlavaEngine:
     # hidden states are never materialised, masks are implied by the ragged prompts, length_penalty only acts on beam search
     LAUNCH_WINDOW = 16        # decode steps between host waits (see the decode loop): bounds the kernel packets queued at any time
 
-    IGNORED_GENERATE_KWARGS = frozenset({"use_cache", "output_attentions", "output_hidden_states", "attention_mask", "length_penalty",
-                                         "synced_gpus", "use_image"})
+    IGNORED_GENERATE_KWARGS = frozenset({"use_cache", "output_hidden_states", "attention_mask", "length_penalty", "synced_gpus", "use_image"})
 
     def __init__(self, cfg: LlavaConfig | str = "llava-1.5-7b", weights: Optional[LlavaWeights] = None, device="cuda:0",
                  seed: int = 0, max_questions: int = 64, t_max: int = 0, use_graph: bool = True, lm_head_gain: float = 1.0,
@@ -888,14 +923,16 @@ class VddLlavaEngine:
                  share_prefix: bool = True, sync_every: int = 8, inputs_embeds=None, min_new_tokens: Optional[int] = None,
                  min_length: Optional[int] = None, stop_words_ids=None, repetition_penalty: Optional[float] = None,
                  logits_processor=None, max_length: Optional[int] = None, num_beams: Optional[int] = None,
-                 num_return_sequences: Optional[int] = None, embeds_prefix=None, streamer=None, **other) -> GenerateOutput:
+                 num_return_sequences: Optional[int] = None, embeds_prefix=None, streamer=None, output_attentions: bool = False,
+                 **other) -> GenerateOutput:
         """Same kwargs as the reference's model.generate(...) call (llava_calibrate.py:161-177); `input_ids` is a
         list of 1-D id tensors (one per question, each with one -200 image slot) or a [Q, L] tensor; `images` one
         image per question (repeat the SAME tensor for questions about the same image to share its features and
-        prompt-prefix KV).  use_cache / output_attentions are accepted and ignored (attention maps are never
-        materialised: flash-style kernels; the reference's driver averages model_outputs['attentions'][0][-1] at :180-182 for a plot
-        whose call, :183, is commented out - those lines go when a driver moves to the engine).  attention_mask is accepted when
-        it is all ones (the reference's B = 1 calls) and refused when it masks anything.
+        prompt-prefix KV).  use_cache is accepted and ignored.  output_attentions=True with ONE question (the reference's call,
+        llava_calibrate.py:161-177) materialises what the driver reads of it - `['attentions'][0][-1]`, step 0 / last layer, [1, H, T, T]
+        of the main branch's prompt (:180-182) - from the prefill's rotated queries and the cached keys (ops.attention_probs); with several
+        questions it is accepted without effect and `['attentions']` raises.  attention_mask is accepted when it is all ones (the
+        reference's B = 1 calls) and refused when it masks anything.
 
         embeds_prefix (with inputs_embeds): per prompt `(key, n)` - the caller's promise that prompts with the same key start with the
         same n embedding rows (Qwen-VL: '<img>' + the 256 image slots of one image, shared by its questions): they are prefilled once
@@ -1035,11 +1072,12 @@ class VddLlavaEngine:
         assert plan["max_len"] + max_new_tokens <= self.cfg.lm.max_pos, "prompt + new tokens exceed the rotary table"
         stats = {"n_rows": nb * Q, "prefill_tokens": plan["prefill_tokens"], "unshared_prefill_tokens": plan["unshared_tokens"]}
 
+        want_maps = bool(output_attentions) and Q == 1 and lm.head_dim == 128 and lm.n_layers > 0
         passes, frag_plen = [], None
         if plan["prefix"]:
             segs = plan["prefix"]
             x, pos, cpos, slot, seqs, max_tq = self._pack(segs)
-            passes.append(dict(x=x, pos=pos, cpos=cpos, slot=slot, seqs=seqs, n_seq=len(segs), max_tq=max_tq, to_prefix_pool=True))   # K/V only
+            passes.append(dict(x=x, pos=pos, cpos=cpos, slot=slot, seqs=seqs, n_seq=len(segs), max_tq=max_tq, to_prefix_pool=True, keep_q=want_maps))   # K/V only
             if kv.frag_only:
                 (frag_plen,) = h2d_int32(dev, [s_["T"] for s_ in segs])
         segs = plan["suffix"]
@@ -1050,10 +1088,25 @@ class VddLlavaEngine:
                                            [[i, 1, s["pos0"] + s["T"] - 1, s["slot"], s["pslot"], s["plen"]] for i, s in enumerate(segs)],
                                            packs_h if packs_h is not None else [[0, -1, -1, -1]])
         passes.append(dict(x=x, pos=pos, cpos=cpos, slot=slot, seqs=seqs, n_seq=len(segs), max_tq=max_tq, to_prefix_pool=False,
-                           last_rows=last.long(), last_seqs=last_seqs, packs=packs if packs_h is not None else None))
+                           last_rows=last.long(), last_seqs=last_seqs, packs=packs if packs_h is not None else None, keep_q=want_maps))
         resid, delta = self.lm.prefill(passes, kv, frag_plen=frag_plen)[-1]
         logits0 = self.lm.logits(resid, delta)                                        # [nb*Q, V], rows ordered branch-major
         self.debug_logits0 = logits0
+        attn_maps = None
+        if want_maps:
+            # question 0, main branch = suffix sequence 0 (+ its prefix slot): [prefix rows | suffix rows] of the last layer's rotated queries
+            s0 = plan["suffix"][0]
+            q_rows = [passes[-1]["q_last"][s0["q_row0"]: s0["q_row0"] + s0["T"]]]
+            if s0["plen"] > 0:
+                p0 = plan["prefix"][s0["pslot"]]
+                q_rows.insert(0, passes[0]["q_last"][p0["q_row0"]: p0["q_row0"] + p0["T"]])
+            q_full = torch.cat(q_rows, 0) if len(q_rows) > 1 else q_rows[0].contiguous()
+            li = lm.n_layers - 1
+            m = ops.attention_probs(q_full, kv.ko[li], (0, q_full.shape[0], 0, s0["slot"], s0["pslot"], s0["plen"]), lm.n_heads, lm.n_kv_heads,
+                                    lm.head_dim, k_prefix=kv.kp[li])
+            attn_maps = m[None]                                                      # [1, H, T, T] like HF's attention weights
+            for p_ in passes:
+                p_.pop("q_last", None)
         V = lm.vocab
 
         # ---- step 0: sample from the prefill logits (eager; also yields the top-n for calibration) -----------
@@ -1141,7 +1194,8 @@ class VddLlavaEngine:
         stats["steps"] = int(gen.shape[1])
         stats["graph"] = run.graph is not None
         stats["n_groups"] = n_groups          # > 0: the decode steps ran the grouped (shared-prefix) attention
-        return GenerateOutput(seqs_out, gen, scores, top_prob, top_tok, stats)
+        return GenerateOutput(seqs_out, gen, scores, top_prob, top_tok, stats,
+                              attentions=StepAttentions(attn_maps, lm.n_layers, int(gen.shape[1])) if attn_maps is not None else None)
 
     def _processor_config(self, prompt_lens, ids_list, eos_token_id, min_new_tokens, min_length, stop_words_ids, repetition_penalty,
                           logits_processor, max_new_tokens):

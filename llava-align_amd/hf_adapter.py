@@ -29,10 +29,10 @@ import torch
 
 from .engine import IMAGE_TOKEN_INDEX, LlavaConfig, LlavaWeights, LMConfig, VddLlavaEngine, VisionConfig
 
-_NO_MAPS = ("{}: not produced by the native engine - attention is computed by flash-style kernels that never materialise the "
-            "[heads, T, T] maps.  llava_calibrate.py:180-182 reads model_outputs['attentions'][0][-1] and averages it for a plot "
-            "whose call is commented out (:183): delete those three lines, or detach_engine(model) to get the maps from the "
-            "generic evolve_vcd_sampling() loop on the HF model")
+_NO_MAPS = ("{}: not produced for this call - the native engine's flash-style kernels never materialise the [heads, T, T] maps; what the "
+            "reference's driver reads (llava_calibrate.py:180-182: model_outputs['attentions'][0][-1], step 0 / last layer) is computed on "
+            "request for ONE question per call with output_attentions=True; hidden states and the maps of a batch are not - "
+            "detach_engine(model) gives HF's generate (with the generic evolve_vcd_sampling() loop) back")
 
 
 def _rope_theta(c) -> float:
@@ -117,7 +117,7 @@ class NativeGenerateOutput(dict):
     GenerateDecoderOnlyOutput; plus the engine's extras (`tokens`, `top_prob`, `top_tok`, `stats`)."""
 
     def __getitem__(self, k):
-        if k in ("attentions", "hidden_states"):
+        if k in ("attentions", "hidden_states") and k not in self:
             raise KeyError(_NO_MAPS.format(k))
         return super().__getitem__(k)
 
@@ -168,9 +168,10 @@ def _native_generate(model, inputs=None, generation_config=None, **kw):
         warnings.warn(f"Setting `pad_token_id` to `eos_token_id`:{pad} for open-end generation.")
     args.update(eos_token_id=eos, pad_token_id=pad)
     return_dict = bool(opt("return_dict_in_generate", False))
-    for k in ("output_attentions", "output_hidden_states", "use_cache", "synced_gpus"):     # accepted: see NativeGenerateOutput
+    want_attn = bool(opt("output_attentions", False))
+    for k in ("output_hidden_states", "use_cache", "synced_gpus"):     # accepted without effect
         opt(k, None)
-    out = eng.generate(input_ids, **args, **kw)
+    out = eng.generate(input_ids, output_attentions=want_attn, **args, **kw)
     seqs = torch.stack(list(out.sequences)) if input_ids is not None else out.tokens       # embeddings prompts: no ids to echo (HF)
     if not return_dict:
         return seqs
@@ -179,6 +180,8 @@ def _native_generate(model, inputs=None, generation_config=None, **kw):
         res["scores"] = tuple(out.scores)
     if out.top_prob is not None:
         res["top_prob"], res["top_tok"] = out.top_prob, out.top_tok
+    if getattr(out, "attentions", None) is not None:                  # one question + output_attentions: ['attentions'][0][-1] as llava_calibrate.py:180 reads it
+        res["attentions"] = out.attentions
     return res
 
 

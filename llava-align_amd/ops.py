@@ -28,6 +28,7 @@ _SIGS = {
     "vdd_flash_attention": [_P, _P, _P, _P, _P, _P, _P, _I, _I, _I, _I, _I, _L, _I, _L, _I, _F, _I, _I, _P],
     "vdd_flash_attention_packed": [_P, _P, _P, _P, _P, _P, _P, _P, _I, _I, _I, _I, _L, _I, _L, _I, _F, _I, _P],
     "vdd_layernorm": [_P, _P, _P, _P, _I, _I, _F, _I, _P],
+    "vdd_attention_probs": [_P, _P, _P, _P, _P, _I, _I, _I, _L, _I, _L, _I, _F, _I, _P],
     "vdd_bias_act": [_P, _P, _P, _L, _I, _I, _I, _P],
     "vdd_add": [_P, _P, _P, _L, _I, _P],
     "vdd_vit_im2col": [_P, _I, _P, _I, _I, _I, _I, _I, _P],
@@ -654,6 +655,21 @@ def flash_attention(q, k_cache, v_cache, seqs, n_seq, max_tq, H, Hkv, D, causal=
                                                 seqs.data_ptr(), out.data_ptr(), n_seq, max_tq, H, Hkv, D, k_cache.stride(0),
                                                 k_cache.shape[2], k_prefix.stride(0), k_prefix.shape[2], D ** -0.5 if scale is None else float(scale),
                                                 1 if causal else 0, dt, _st(q)))
+    return out
+
+
+def attention_probs(q, k_cache, seq, H, Hkv, D, k_prefix=None, scale=None):
+    """The materialised attention map of ONE sequence: q [.., H*D] rotated queries, seq = (q_row0, Tq, pos0, slot, prefix_slot, prefix_len)
+    host integers, keys from [prefix slot of k_prefix | own slot of k_cache].  Returns [H, Tq, pos0 + Tq] in q's dtype: fp32 softmax over the
+    causal keys, rounded; zeros behind the diagonal (what HF's eager attention returns as attention weights)."""
+    dt = _dt(q, k_cache)
+    k_prefix = k_cache if k_prefix is None else k_prefix
+    q_row0, Tq, pos0 = int(seq[0]), int(seq[1]), int(seq[2])
+    out = torch.empty(H, Tq, pos0 + Tq, dtype=q.dtype, device=q.device)
+    desc = (C.c_int32 * 6)(*[int(v) for v in seq])
+    _lib.check(_lib_ready().vdd_attention_probs(q.data_ptr(), k_cache.data_ptr(), k_prefix.data_ptr(), C.cast(desc, C.c_void_p), out.data_ptr(), H, Hkv, D,
+                                                k_cache.stride(0), k_cache.shape[2], k_prefix.stride(0), k_prefix.shape[2],
+                                                D ** -0.5 if scale is None else float(scale), dt, _st(q)))
     return out
 
 

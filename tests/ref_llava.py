@@ -101,6 +101,8 @@ class RefLlava(_Proto):
             S = kk.shape[2]
             mask = torch.ones(T, S, dtype=torch.bool, device=self.device).tril(diagonal=S - T)
             pw = s.masked_fill(~mask, -float("inf")).float().softmax(-1).to(self.dtype)     # materialised [1, H, T, S]
+            if i == lm.n_layers - 1:
+                self.last_attn = pw                        # what HF hands back as attentions[step][-1] (llava_calibrate.py:180)
             att = pw @ vv
             h = h + att.transpose(1, 2).reshape(1, T, H * D) @ w[p + "wo"].t()
             a = rms(h, w[p + "ln2"])

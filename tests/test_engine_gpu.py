@@ -601,3 +601,28 @@ def test_streamer_receives_prompt_then_every_token_then_end(eng):
     ids2, imgs2 = prompts(n_img=1, per_img=2, seed=41)
     with pytest.raises(ValueError):
         eng.generate(ids2, images=imgs2, streamer=Rec(), max_new_tokens=2)
+
+
+def test_output_attentions_for_one_question_is_the_last_layer_map_of_step_zero(eng, ref):
+    """llava_calibrate.py:175,180-182: generate(output_attentions=True) -> ['attentions'][0][-1], [1, H, T, T] of the spliced prompt.
+    The engine computes exactly that one map (ops.attention_probs over the prefill's q and cached K); against the fp32 reference."""
+    ids, imgs = prompts(n_img=1, per_img=1, seed=29)
+    for share in (True, False):
+        out = eng.generate(ids, images=imgs, use_dd_unk=True, cd_alpha=1.0, cd_beta=0.1, temperature=0.5, max_new_tokens=3, cd_greedy=True,
+                           output_attentions=True, share_prefix=share)
+        m = out["attentions"][0][-1]
+        T = ids[0].numel() - 1 + eng.cfg.vision.n_patches
+        assert m.shape == (1, eng.cfg.lm.n_heads, T, T) and m.dtype == eng.dtype and len(out["attentions"]) == 3
+        ref(input_ids=ids[0][None], images=imgs[0][None])
+        want = ref.last_attn.float()
+        assert (m.float() - want).abs().max().item() <= 0.02 and not m.float().triu(1).any()
+        avg = torch.mean(m, dim=1).squeeze()                        # what the driver does with it (:182)
+        assert avg.shape == (T, T)
+        with pytest.raises(IndexError, match="LAST layer"):
+            out["attentions"][0][0]
+        with pytest.raises(IndexError, match="step 0"):
+            out["attentions"][1]
+    many_ids, many_imgs = prompts()
+    o2 = eng.generate(many_ids, images=many_imgs, max_new_tokens=1, output_attentions=True)       # a batch: accepted, nothing materialised
+    with pytest.raises(KeyError, match="attentions"):
+        o2["attentions"]

@@ -69,9 +69,9 @@ def test_generate_keywords_are_resolved_like_hf(model):
         kw = stub.calls[-1]
         assert kw["do_sample"] is True and kw["temperature"] == 0.2 and kw["top_p"] is None and kw["top_k"] is None
         assert kw["max_new_tokens"] == 64 and "max_length" not in kw and kw["use_dd_unk"] is True and kw["cd_alpha"] == 1.0
-        assert "use_cache" not in kw and "output_attentions" not in kw and "return_dict_in_generate" not in kw
+        assert "use_cache" not in kw and kw["output_attentions"] is True and "return_dict_in_generate" not in kw
         assert out["sequences"].shape == (1, 4 + 64) and out.sequences is out["sequences"] and len(out["scores"]) == 64
-        with pytest.raises(KeyError, match="commented out"):
+        with pytest.raises(KeyError, match="llava_calibrate.py:180-182"):     # (the stub engine produced no map)
             out["attentions"]
         # nothing given: the model's generation_config decides (greedy, its warper defaults, max_length 20)
         seq = A._native_generate(model, ids, images=torch.zeros(1))

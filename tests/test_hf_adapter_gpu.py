@@ -76,8 +76,12 @@ def test_generate_through_the_adapter_matches_the_drop_in_loop_on_the_same_model
     L = ids.shape[1]
     assert got["sequences"].shape == (1, L + n_new) and torch.equal(got["sequences"][:, :L], ids)       # prompt echoed with its -200
     assert len(got["scores"]) == n_new and got["scores"][0].shape == (1, model.config.vocab_size) and got["scores"][0].dtype == model.dtype
-    with pytest.raises(KeyError, match="llava_calibrate.py:180-182"):
-        got["attentions"]
+    # llava_calibrate.py:180-182, verbatim: the one map the driver reads exists (step 0, last layer), [1, H, T, T] of the spliced prompt
+    attentions = got["attentions"][0][-1]
+    attention = torch.mean(attentions, dim=1).squeeze()
+    T = L - 1 + (model.get_vision_tower().vision_tower.config.image_size // model.get_vision_tower().vision_tower.config.patch_size) ** 2
+    assert attentions.shape == (1, model.config.num_attention_heads, T, T) and attention.shape == (T, T)
+    assert torch.allclose(attentions.float().sum(-1), torch.ones(1, model.config.num_attention_heads, T, device=DEV), atol=2e-2)
     # The two stacks round differently inside a layer (HF: library GEMMs + SDPA in the model dtype; engine: its own kernels, fp32
     # accumulation everywhere), so scores are compared at the measured noise of the dtype and tokens where the margin clears it:
     # the logits of the two stacks differ by an ulp or two of the dtype (fp16 2^-11, bf16 2^-8 relative), the contrast amplifies that by

@@ -569,3 +569,25 @@ def test_gemm_split_k_slabs_feed_the_rmsnorm(M, N, K):
     assert (y1.float() - y2.float()).abs().max().item() <= 2 ** -6 * y2.float().abs().max().item()
     out = O.linear_to_norm(x, w)                                     # the engine's entry: slabs in the 33 - 128-row band, a product elsewhere
     assert (out.dim() == 3) == (O.skinny_rows(N, K) < M <= 128 and O.slab_splits(M, N, K) > 0)
+
+
+def test_attention_probs_materialises_the_causal_map():
+    """vdd_attention_probs: [H, Tq, Tk] softmax of one sequence whose keys sit in [prefix slot | own slot] (GQA included), against torch."""
+    O = ops()
+    H, Hkv, D, plen, Ts = 8, 4, 128, 37, 21
+    T = plen + Ts
+    kp, ko = bf(3, Hkv, 64, D, seed=101), bf(5, Hkv, 32, D, seed=102)
+    q = bf(T + 4, H * D, seed=103)
+    got = O.attention_probs(q, ko, (2, T, 0, 4, 1, plen), H, Hkv, D, k_prefix=kp)             # rows 2 .. 2 + T of q; own slot 4, prefix slot 1
+    K = torch.cat([kp[1, :, :plen], ko[4, :, :Ts]], 1).float().repeat_interleave(H // Hkv, 0)   # [H, T, D]
+    qq = q[2:2 + T].view(T, H, D).float().permute(1, 0, 2)
+    s_ = (qq @ K.transpose(1, 2)) * D ** -0.5
+    mask = torch.ones(T, T, dtype=torch.bool, device=DEV).tril()
+    want = s_.masked_fill(~mask, -float("inf")).softmax(-1)
+    assert got.shape == (H, T, T) and got.dtype == DT
+    assert (got.float() - want).abs().max().item() <= 2 ** -8 + 1e-3 and not got.float().triu(1).any()
+    assert torch.allclose(got.float().sum(-1), torch.ones(H, T, device=DEV), atol=2e-2)
+    own_only = O.attention_probs(q, ko, (0, 9, 0, 3, 0, 0), H, Hkv, D, k_prefix=kp)            # no prefix at all
+    K2 = ko[3, :, :9].float().repeat_interleave(H // Hkv, 0)
+    w2 = ((q[:9].view(9, H, D).float().permute(1, 0, 2) @ K2.transpose(1, 2)) * D ** -0.5).masked_fill(~mask[:9, :9], -float("inf")).softmax(-1)
+    assert (own_only.float() - w2).abs().max().item() <= 2 ** -8 + 1e-3
