@@ -43,6 +43,9 @@
 
 #include "vdd_elem.h"
 
+#ifndef VDD_GEMM_STREAM_SIMPLE
+#define VDD_GEMM_STREAM_SIMPLE 0
+#endif
 #ifndef VDD_GEMM_SPLIT_STAGE
 #define VDD_GEMM_SPLIT_STAGE 1
 #endif
@@ -83,6 +86,19 @@ struct GemmArgs {
 #endif
 };
 
+// K-tile buffers of a tile shape.  Two for the compute-bound shapes (tile t + 1 lands under the MFMAs of tile t).  The shapes the
+// tuner picks for a few dozen to ~250 rows of activations are W STREAMS - one or two row-tiles, every CU pulling its own column
+// panel of W from HBM - and what bounds those is the bytes a CU has in flight: with two buffers ONE K-tile (16 KiB of W for the
+// 192 x 128 shape), i.e. one HBM round trip (2 us under load) per K-tile whose MFMAs take 0.35 us.  They get as many buffers as
+// the 160 KiB of LDS hold beside the epilogue's staging blocks.
+constexpr int LDS_BYTES = 160 * 1024;
+constexpr int gemm_staging_bytes(int BN, int WM, int WN) { return ((BN / WN) % 64 == 0) ? WM * WN * 4096 : 0; }
+constexpr int gemm_stages(int BM, int BN, int WM, int WN) {
+    if (BM == 64) return 3;
+    if (BN == 128 && BM <= 192) { const int n = (LDS_BYTES - gemm_staging_bytes(BN, WM, WN)) / ((BM + BN) * 128); return n > 5 ? 5 : n; }
+    return 2;
+}
+
 template <int BM, int BN, int WM, int WN, int EPI>
 __global__ void __launch_bounds__(WM * WN * 64) gemm_kernel(const GemmArgs a) {
 #if defined(__HIP_DEVICE_COMPILE__)   // the host pass only needs the launch stub: it drops a kernel whose body holds LDS-DMA builtins
@@ -91,7 +107,7 @@ __global__ void __launch_bounds__(WM * WN * 64) gemm_kernel(const GemmArgs a) {
     constexpr int XIMG = BM / 8, WIMG = BN / 8;            // 1-KiB LDS-DMA images (8 rows x 128 B) per K-tile
     constexpr int XJ = XIMG / NW, WJ = WIMG / NW;          // images per wave
     constexpr int BUF = (BM + BN) * 128;                   // bytes of one K-tile buffer
-    constexpr int NSTG = (BM == 64) ? 3 : 2;                // K-tile buffers (the 64-row tile is a W stream: see the K pipeline below)
+    constexpr int NSTG = gemm_stages(BM, BN, WM, WN);      // K-tile buffers (> 2: a W stream, see the K pipeline below)
     constexpr int NMMA = NI * MI, NRD = NI + MI, NLD = XJ + WJ;
     static_assert(XIMG % NW == 0 && WIMG % NW == 0 && TM % 32 == 0 && TN % 32 == 0, "tile / wave shape");
     static_assert(EPI != EPI_SWIGLU || NI % 2 == 0, "SwiGLU pairs gate/up 32-column blocks inside a wave");
@@ -224,7 +240,10 @@ __global__ void __launch_bounds__(WM * WN * 64) gemm_kernel(const GemmArgs a) {
     bool more = advance();
     auto stage_first = [&]() {
         stage(0, 0); stage(1, 1);
-        if constexpr (NSTG == 3) { if (nk > 2) stage(2, 2); }
+        if constexpr (NSTG >= 3) {
+#pragma unroll
+            for (int i = 2; i < NSTG; ++i) if (nk > i) stage(i, i);
+        }
     };
     if (more) { setup(); stage_first(); }
     while (more) {
@@ -280,25 +299,64 @@ __global__ void __launch_bounds__(WM * WN * 64) gemm_kernel(const GemmArgs a) {
 #pragma unroll
                 for (int j = 0; j < MI; ++j) acc[i][j] = mfma32(wg[kk][i], xg[kk][j], acc[i][j]);
         };
-        if constexpr (NSTG == 3) {
-            // The 64-row tile (a few dozen rows of activations): the launch is a stream of W through the CUs, 2 MFMAs per wave and
-            // k-step, and what bounds it is the bytes in flight - with two buffers one K-tile (40 KiB) per CU, 2.6 TB/s.  Three
-            // buffers, two tiles in flight behind the one being multiplied; nothing to interleave, two barriers per K-tile.
+#if VDD_GEMM_STREAM_SIMPLE
+        if constexpr (NSTG >= 3) {       // (A/B form: read everything, barrier, stage, multiply - two barriers per K-tile, nothing overlapped)
+            // A W stream (the 64-row tile: a few dozen rows of activations; the 128-column tiles of up to 192 rows): 2 - 3 MFMAs per wave
+            // and k-step, and what bounds the launch is the bytes in flight - with two buffers one K-tile (40 KiB) per CU, 2.6 TB/s.
+            // NSTG buffers, NSTG - 1 tiles in flight behind the one being multiplied; nothing to interleave, two barriers per K-tile.
             const int cnk = nk;
+            int buf = 0;
             for (int t = 0; t < cnk; ++t) {
-                const int ahead = min(2, cnk - 1 - t);                // tiles staged beyond t
+                const int ahead = min(NSTG - 1, cnk - 1 - t);         // tiles staged beyond t
                 // (t = 0: the previous segment's epilogue stores are counted by vmcnt too and retire out of order with the loads)
-                if (ahead == 2 && t > 0) asm volatile("s_waitcnt vmcnt(%0)" :: "n"(2 * NLD) : "memory");
-                else if (ahead == 1 && t > 0) asm volatile("s_waitcnt vmcnt(%0)" :: "n"(NLD) : "memory");
-                else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+                if (t == 0 || ahead == 0) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+                else if (ahead == 1) asm volatile("s_waitcnt vmcnt(%0)" :: "n"(NLD) : "memory");
+                else if (ahead == 2) asm volatile("s_waitcnt vmcnt(%0)" :: "n"(2 * NLD) : "memory");
+                else if (NSTG > 3 && ahead == 3) asm volatile("s_waitcnt vmcnt(%0)" :: "n"(NSTG > 3 ? 3 * NLD : 0) : "memory");
+                else asm volatile("s_waitcnt vmcnt(%0)" :: "n"(NSTG > 4 ? 4 * NLD : 0) : "memory");
                 __builtin_amdgcn_s_barrier();
-                const int buf = t % 3;
                 rd(buf, 0); rd(buf, 1); rd(buf, 2); rd(buf, 3);
                 asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
                 __builtin_amdgcn_s_barrier();                         // every wave holds its fragments of tile t: the buffer is free
-                if (t + 3 < cnk) stage(t + 3, buf);
+                if (t + NSTG < cnk) stage(t + NSTG, buf);
                 mm(0); mm(1); mm(2); mm(3);
+                buf = buf + 1 == NSTG ? 0 : buf + 1;
             }
+        } else
+#endif
+        if constexpr (NSTG >= 3) {
+            // A W stream (the 64-row tile: a few dozen rows of activations; the 128-column tiles of up to 192 rows): a handful of MFMAs per
+            // wave and k-step, and what bounds the launch is first the bytes in flight - with two buffers one K-tile (40 KiB) per CU,
+            // 2.6 TB/s - and then the wave's own instruction stream: fragment reads (0.2 us per tile), LDS-DMA issue (0.3), MFMAs (0.2) run
+            // one after the other cost 1 us per 16 KiB of W.  So: NSTG buffers, NSTG - 2 tiles in flight behind the two being worked
+            // on, and the pipeline of the compute-bound shapes below (reads two k-steps ahead, ONE barrier per tile, the LDS-DMA of
+            // tile t + NSTG into the buffer that barrier frees), with run-time buffer indices.
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");          // (the previous segment's epilogue stores are counted by vmcnt too)
+            __builtin_amdgcn_s_barrier();
+            rd(0, 0); rd(0, 1);
+            __builtin_amdgcn_sched_barrier(0);
+            auto tile = [&](int t, int buf, int nbuf, auto do_stage, auto do_next, auto wait_n) {
+                constexpr bool ST = decltype(do_stage)::value, NX = decltype(do_next)::value;
+                constexpr int WN_ = decltype(wait_n)::value;
+                rd(buf, 2); mm(0); interleave(false, true); __builtin_amdgcn_sched_barrier(0);
+                rd(buf, 3); mm(1); interleave(false, true); __builtin_amdgcn_sched_barrier(0);
+                asm volatile("s_waitcnt vmcnt(%0) lgkmcnt(0)" :: "n"(WN_) : "memory");   // own fragment reads of this tile done; tile t+1 landed
+                __builtin_amdgcn_s_barrier();
+                __builtin_amdgcn_sched_barrier(0);
+                if constexpr (ST) stage_x(t + NSTG, buf);
+                if constexpr (NX) rd(nbuf, 0);
+                mm(2); interleave_n(ST ? XJ : 0, NX); __builtin_amdgcn_sched_barrier(0);
+                if constexpr (ST) stage_w(t + NSTG, buf);
+                if constexpr (NX) rd(nbuf, 1);
+                mm(3); interleave_n(ST ? WJ : 0, NX); __builtin_amdgcn_sched_barrier(0);
+            };
+            using T_ = std::true_type; using F_ = std::false_type;
+            using WS_ = std::integral_constant<int, (NSTG - 2) * NLD>; using W0_ = std::integral_constant<int, 0>;
+            int t = 0, buf = 0;
+            auto nxt = [&](int b) { return b + 1 == NSTG ? 0 : b + 1; };
+            for (; t + NSTG < nk; ++t) { tile(t, buf, nxt(buf), T_{}, T_{}, WS_{}); buf = nxt(buf); }
+            for (; t + 1 < nk; ++t) { tile(t, buf, nxt(buf), F_{}, T_{}, W0_{}); buf = nxt(buf); }     // the last tiles: everything staged is waited for
+            tile(t, buf, buf, F_{}, F_{}, W0_{});
         } else {
         rd(0, 0); rd(0, 1);
         __builtin_amdgcn_sched_barrier(0);
@@ -386,17 +444,55 @@ __global__ void __launch_bounds__(WM * WN * 64) gemm_kernel(const GemmArgs a) {
             __syncthreads();
             // the slabs are read with agent-scope (sc1) loads, straight from where the write-through stores put them: an acquire
             // FENCE here is a buffer_inv sc1, which drops this XCD's whole L2 under the 31 workgroups still streaming through it
-            for (int r = rng + 1; r <= r_last; ++r) {
+            // The small tiles of the W-stream shapes are cut 4 - 8 ways (32 tiles of the attention-output projection over 256 workgroups),
+            // and one slab after the other is one memory round trip (~2 us) each: the finisher of such a tile spent 10 - 15 us here, most
+            // of the launch.  So the loads of up to RU slabs go out together (32 - 64 registers each); they are ADDED in slab order as
+            // before - the same bits.  (RU = 1 for the large tiles: a slab is 96 - 128 registers there, and a tile is cut in two.)
+            constexpr int PER = NI * MI * 16, RU = PER <= 32 ? 4 : PER <= 64 ? 3 : 1;
+            auto load_slab = [&](int r, f32x4_t (&v)[NI * MI * 4]) {
                 const __amdgpu_buffer_rsrc_t rq = __builtin_amdgcn_make_buffer_rsrc((void*)(a.partial + (size_t)r * (BM * BN)), 0, BM * BN * 4, 0x00020000);
+#pragma unroll
+                for (int x = 0; x < NI * MI * 4; ++x)
+                    v[x] = __builtin_bit_cast(f32x4_t, __builtin_amdgcn_raw_buffer_load_b128(rq, (x * NT + tid) * 16, 0, 16));
+            };
+            auto add_slab = [&](const f32x4_t (&v)[NI * MI * 4]) {
 #pragma unroll
                 for (int i = 0; i < NI; ++i)
 #pragma unroll
                     for (int j = 0; j < MI; ++j)
 #pragma unroll
                         for (int q = 0; q < 4; ++q) {
-                            const f32x4_t v = __builtin_bit_cast(f32x4_t, __builtin_amdgcn_raw_buffer_load_b128(rq, (((i * MI + j) * 4 + q) * NT + tid) * 16, 0, 16));
-                            acc[i][j][q * 4] += v[0]; acc[i][j][q * 4 + 1] += v[1]; acc[i][j][q * 4 + 2] += v[2]; acc[i][j][q * 4 + 3] += v[3];
+                            const f32x4_t& w = v[(i * MI + j) * 4 + q];
+                            acc[i][j][q * 4] += w[0]; acc[i][j][q * 4 + 1] += w[1]; acc[i][j][q * 4 + 2] += w[2]; acc[i][j][q * 4 + 3] += w[3];
                         }
+            };
+            if constexpr (RU > 1) {
+                int r = rng + 1;
+                for (; r + RU - 1 <= r_last; r += RU) {
+                    f32x4_t v[RU][NI * MI * 4];
+#pragma unroll
+                    for (int g = 0; g < RU; ++g) load_slab(r + g, v[g]);
+#pragma unroll
+                    for (int g = 0; g < RU; ++g) add_slab(v[g]);
+                }
+                for (; r <= r_last; ++r) {
+                    f32x4_t v[NI * MI * 4];
+                    load_slab(r, v);
+                    add_slab(v);
+                }
+            } else {
+                for (int r = rng + 1; r <= r_last; ++r) {
+                    const __amdgpu_buffer_rsrc_t rq = __builtin_amdgcn_make_buffer_rsrc((void*)(a.partial + (size_t)r * (BM * BN)), 0, BM * BN * 4, 0x00020000);
+#pragma unroll
+                    for (int i = 0; i < NI; ++i)
+#pragma unroll
+                        for (int j = 0; j < MI; ++j)
+#pragma unroll
+                            for (int q = 0; q < 4; ++q) {
+                                const f32x4_t v = __builtin_bit_cast(f32x4_t, __builtin_amdgcn_raw_buffer_load_b128(rq, (((i * MI + j) * 4 + q) * NT + tid) * 16, 0, 16));
+                                acc[i][j][q * 4] += v[0]; acc[i][j][q * 4 + 1] += v[1]; acc[i][j][q * 4 + 2] += v[2]; acc[i][j][q * 4 + 3] += v[3];
+                            }
+                }
             }
         }
 
@@ -568,7 +664,9 @@ int launch_cfg(const GemmArgs& a0, int epi, int sched, void* workspace, int64_t 
     a.counter = (int*)workspace;
     a.partial = (float*)((char*)workspace + COUNTER_BYTES);
     const dim3 grid(P), block(WM * WN * 64);
-    const size_t smem = (BM == 64 ? 3 : 2) * (BM + BN) * 128 + (((BN / WN) % 64 == 0) ? WM * WN * 4096 : 0);      // + the epilogue's staging blocks
+    const size_t smem = (size_t)gemm_stages(BM, BN, WM, WN) * (BM + BN) * 128 + gemm_staging_bytes(BN, WM, WN);      // + the epilogue's staging blocks
+    static_assert(gemm_stages(BM, BN, WM, WN) * (BM + BN) * 128 + gemm_staging_bytes(BN, WM, WN) <= LDS_BYTES, "LDS");
+    static_assert((gemm_stages(BM, BN, WM, WN) - 1) * ((BM + BN) / 8 / (WM * WN)) <= 63, "vmcnt is 6 bits");
     a.stage_out = ((a.ldy % 8) == 0 && (((uintptr_t)a.Y) & 15) == 0) ? 1 : 0;
 #define VDD_GEMM_LAUNCH(E)                                                                                            \
     case E: {                                                                                                         \
@@ -651,6 +749,10 @@ VDD_HIDDEN int VDD_IMPL(vdd_gemm)(const void* X, const void* W, void* Y, const v
         case 7: return launch_cfg<192, 128, 2, 4>(a, epilogue, sched, workspace, workspace_bytes, st);      // 8 waves of 96 x 32
         case 8: return launch_cfg<64, 256, 2, 4>(a, epilogue, sched, workspace, workspace_bytes, st);       // a few dozen rows: W streaming,
                                                                                                             // 64-KiB partial slabs
+        // W streams for 65 - 256 rows (gemm_stages: 4 - 5 K-tile buffers); 10 / 11 pair gate / up inside a wave (SwiGLU epilogue)
+        case 9: return launch_cfg<128, 128, 2, 4>(a, epilogue, sched, workspace, workspace_bytes, st);      // 8 waves of 64 x 32
+        case 10: return launch_cfg<128, 128, 2, 2>(a, epilogue, sched, workspace, workspace_bytes, st);     // 4 waves of 64 x 64
+        case 11: return launch_cfg<192, 128, 2, 2>(a, epilogue, sched, workspace, workspace_bytes, st);     // 4 waves of 96 x 64
         default: return VDD_ERR_INVALID_ARG;
     }
 }

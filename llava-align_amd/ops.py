@@ -266,7 +266,7 @@ SKINNY_WIDE_MAX_M = 24   # rows up to which wide outputs (qkv, gate/up, lm_head)
 EPI_NONE, EPI_BIAS, EPI_BIAS_QUICK_GELU, EPI_BIAS_GELU, EPI_SWIGLU, EPI_BIAS_RESID = range(6)
 GEMM_TUNE_MAX_M = 4096          # shapes up to here (the decode batch, single images) pick their tile shape / schedule by a
                                 # one-off timing run; above, 256 x 256 tiles + the hybrid schedule (tools/gemm_sched.py)
-GEMM_CANDIDATES = [(c, s_) for c in (1, 2, 3, 4, 5, 6, 7, 8) for s_ in (0, 1, 2)]     # (macro tile id, schedule) -> config = c + 16 * s
+GEMM_CANDIDATES = [(c, s_) for c in (1, 2, 3, 4, 5, 6, 7, 8, 9, 10, 11) for s_ in (0, 1, 2)]     # (macro tile id, schedule) -> config = c + 16 * s
 GEMM_BATCH_INVARIANT = False    # True: data-parallel schedule only.  Every output element is then accumulated over K in one fixed
                                 # order whatever the macro tile, i.e. a row's result does not depend on which other rows are in the
                                 # batch (stream-K cuts K where the batch shape puts the cut); costs the load balance at decode size
@@ -364,7 +364,7 @@ def gemm_choices_import(d: dict):
 # run-to-run deterministic on one machine.  So choices are looked up, in this order: the process's own table; the user's cache file
 # (`VDD_GEMM_CHOICES=<path>`, default ~/.cache/llava_align_amd/gemm_choices.json; "off" disables persistence) under the section of
 # this device and this build of the library; the in-tree defaults measured on MI355X (gemm_choices_mi355x.json) for the shapes of the
-# supported models.  Only a shape found nowhere is timed, once per machine: the result is written back to the cache file at once.
+# supported models (`VDD_GEMM_DEFAULTS=off` skips them: re-tuning after a kernel change).  Only a shape found nowhere is timed, once per machine: the result is written back to the cache file at once.
 _persist = {"loaded": None, "path": None, "section": None}
 
 
@@ -395,7 +395,7 @@ def _load_persisted(device):
     _persist.update(loaded=name, path=_choices_file(), section=f"{name}|{_lib_fingerprint()}")
     default = os.path.join(os.path.dirname(os.path.abspath(__file__)), "gemm_choices_mi355x.json")
     arch = getattr(torch.cuda.get_device_properties(device), "gcnArchName", "")
-    if arch.startswith("gfx950") and os.path.exists(default):
+    if arch.startswith("gfx950") and os.path.exists(default) and os.environ.get("VDD_GEMM_DEFAULTS", "").lower() not in ("off", "0", "none"):
         with open(default) as f:
             for k, v in json.load(f).get("choices", {}).items():
                 kk = k.split(",")
@@ -451,7 +451,7 @@ def _gemm_tune(x, w, out, bias, resid, M, N, K, epi, ws, iters=8):
     short = M <= 128
     chunks, reps = (int(min(6, max(1, 2.5e-3 / max(flops / 1.0e15, 30e-6) / iters))), 2) if short else (1, 1)
     for c, sch in GEMM_CANDIDATES:
-        if (epi == EPI_SWIGLU and c in (5, 6, 7)) or (GEMM_BATCH_INVARIANT and sch != 1) or (c == 8 and M > 256):
+        if (epi == EPI_SWIGLU and c in (5, 6, 7, 9)) or (GEMM_BATCH_INVARIANT and sch != 1) or (c in (8, 9, 10, 11) and M > 256):
             continue
         cfg = c + 16 * sch
         _gemm_call(x, copies[turn % len(copies)], out, bias, resid, M, N, K, epi, cfg, ws); turn += 1

@@ -47,7 +47,7 @@ for M, name, N, K, epi in SH:
         if resid is not None: want = want.bfloat16().float() + resid.float()
     need = ops._gemm_workspace(x.device, M, No).numel()
     for c, sch in ops.GEMM_CANDIDATES:
-        if (epi == E.EPI_SWIGLU and c in (5, 6, 7)) or (c == 8 and M > 256):
+        if (epi == E.EPI_SWIGLU and c in (5, 6, 7, 9)) or (c == 8 and M > 256):
             continue
         cfg = c + 16 * sch
         wsbuf = torch.full((need + 2 * G,), 0x5A, dtype=torch.uint8, device=dev)

@@ -8,6 +8,7 @@ dev = "cuda:0"
 NC = 5
 SHAPES = [("qkv", 12288, 4096, ops.EPI_NONE), ("o", 4096, 4096, ops.EPI_NONE), ("gate_up", 22016, 4096, ops.EPI_SWIGLU), ("down", 4096, 11008, ops.EPI_NONE)]
 W = {n: [torch.randn(N, K, device=dev, dtype=torch.bfloat16) * 0.02 for _ in range(NC)] for n, N, K, _ in SHAPES}
+ops._load_persisted(torch.device(dev)); ops._gemm_choice.clear(); ops._persist["path"] = None     # time the tuner afresh at every M
 Ms = [int(a) for a in sys.argv[1:]] or [66, 96, 128, 160, 192, 224, 256, 320, 384, 512, 768]
 for M in Ms:
     rec, tot = {"M": M}, 0.0
