@@ -421,7 +421,10 @@ def main():
     if rank == 0 and not tiny and not a.strong:
         roof = kernel_point(dev, 4096, 32000)
         roof_extra = [kernel_point(dev, 4096, 32000, beta=1e-6, iters=50), kernel_point(dev, 1024, 151936, iters=50),
-                      kernel_point(dev, 1024, 151936, scores=False, iters=50)]
+                      kernel_point(dev, 1024, 151936, scores=False, iters=50),
+                      # 768 rows are resident at a time (3 workgroups x 256 CUs): 1,024 rows = one full round + a third of one.  The same
+                      # shape at a multiple of 768 shows the kernel without that quantisation (tools: profiles/r04_kernel_v151936_by_batch.jsonl)
+                      kernel_point(dev, 3072, 151936, scores=False, iters=30)]
     eng = VddLlavaEngine(a.model, device=dev, seed=0, use_graph=True, lm_head_gain=4.0)
     if a.strong:
         return run_strong(a, eng, dev, rank, world)

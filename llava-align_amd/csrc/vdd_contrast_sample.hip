@@ -483,6 +483,10 @@ __global__ void __launch_bounds__(BLOCK, 6) vdd_contrast_sample_kernel(KP p) {
         [[maybe_unused]] const float lb_a = (p.flags & VDD_CUTOFF_F32_SCALAR) ? p.log_beta : rnd<DT>(p.log_beta);
         float bm = -INFINITY;
         int kb_a = 0;
+        if constexpr (!LDSROW) {        // the published wave maxima of the stash cut (the histogram's place: not in use before the selection passes)
+            if (tid < NWAVE) sm.histf[0][tid] = -INFINITY;
+            __syncthreads();
+        }
         for (int base = tid; LDSROW ? base < nch : base - tid < nch; base += UNR * BLOCK, kb_a += UNR) {   // (!LDSROW: uniform trip count, block-wide exchanges inside)
             uint32_t q[UNR][4];
 #pragma unroll
@@ -503,14 +507,17 @@ __global__ void __launch_bounds__(BLOCK, 6) vdd_contrast_sample_kernel(KP p) {
             }
             if constexpr (!LDSROW) {
                 if (stash_ok) {
-                    // block-wide maximum up to and including this batch (one exchange per batch of UNR * BLOCK chunks)
-                    float t = wave_max(vmax);
-                    if (lane == 0) sm.f[1][wave] = t;
-                    __syncthreads();
-                    float nb = sm.f[1][0];
+                    // a LOWER BOUND of the block-wide maximum so far: this wave's own running maximum and whatever the other waves have
+                    // published by now - no barrier (any value ever stored in lag[] is a maximum over elements of this row, hence <= the
+                    // final one, which is all the superset argument above needs; WHICH chunks get stashed beyond the live ones may then differ
+                    // from run to run, the result cannot).  With two barriers per batch the loads of a batch only went out after the
+                    // previous one had been exchanged: one memory round trip per 16K elements, 3.0 TB/s at V = 151,936.
+                    const float t = wave_max(vmax);
+                    volatile float* lag = sm.histf[0];
+                    if (lane == 0) lag[wave] = t;
+                    float nb = t;
 #pragma unroll
-                    for (int w = 1; w < NWAVE; ++w) nb = fmaxf(nb, sm.f[1][w]);
-                    __syncthreads();
+                    for (int w = 0; w < NWAVE; ++w) nb = fmaxf(nb, lag[w]);
                     bm = fmaxf(bm, nb);
                     const float cut_lag = rnd<DT>(__fadd_rn(bm, lb_a));
 #pragma unroll

@@ -20,9 +20,9 @@ for nq in points:
             eng.generate(ids, max_new_tokens=n_new, **kw)
         torch.cuda.synchronize()
         ts = []
-        for _ in range(3):
+        for _ in range(5):
             t0 = time.perf_counter(); eng.generate(ids, max_new_tokens=n_new, **kw); torch.cuda.synchronize(); ts.append(time.perf_counter() - t0)
-        return sorted(ts)[1]
+        return min(ts)            # host pauses only ever add time (a median of three still moved single points by 1 ms)
     t64, t32 = timed(64), timed(32)
     step = (t64 - t32) / 32
     print(json.dumps({"questions": nq, "rows": 2 * nq, "ms_per_step": round(step * 1e3, 3), "us_per_row": round(step * 1e6 / (2 * nq), 1),
