@@ -43,6 +43,9 @@
 
 #include "vdd_elem.h"
 
+#ifndef VDD_GEMM_DMA_SPACING
+#define VDD_GEMM_DMA_SPACING 1
+#endif
 #ifndef VDD_GEMM_STREAM_SIMPLE
 #define VDD_GEMM_STREAM_SIMPLE 0
 #endif
@@ -271,11 +274,12 @@ __global__ void __launch_bounds__(WM * WN * 64) gemm_kernel(const GemmArgs a) {
                 if (with_reads && i < NRD) __builtin_amdgcn_sched_group_barrier(0x100, 1, 0);
             }
         };
-        auto interleave_n = [&](int n_dma, bool with_reads) {               // MFMA, [DMA] (the first n_dma), [read], MFMA, ...
+        auto interleave_n = [&](int n_dma, bool with_reads) {               // MFMA, [DMA] (n_dma of them, one behind every SP-th MFMA), [read], MFMA, ...
+            constexpr int SP = (VDD_GEMM_DMA_SPACING > 1 && NMMA >= 2 * VDD_GEMM_DMA_SPACING) ? VDD_GEMM_DMA_SPACING : 1;
 #pragma unroll
             for (int i = 0; i < NMMA; ++i) {
                 __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
-                if (i < n_dma) __builtin_amdgcn_sched_group_barrier(0x020, 1, 0);
+                if (i % SP == 0 && i / SP < n_dma) __builtin_amdgcn_sched_group_barrier(0x020, 1, 0);
                 if (with_reads && i < NRD) __builtin_amdgcn_sched_group_barrier(0x100, 1, 0);
             }
         };
