@@ -757,6 +757,9 @@ VDD_HIDDEN int VDD_IMPL(vdd_gemm)(const void* X, const void* W, void* Y, const v
         case 9: return launch_cfg<128, 128, 2, 4>(a, epilogue, sched, workspace, workspace_bytes, st);      // 8 waves of 64 x 32
         case 10: return launch_cfg<128, 128, 2, 2>(a, epilogue, sched, workspace, workspace_bytes, st);     // 4 waves of 64 x 64
         case 11: return launch_cfg<192, 128, 2, 2>(a, epilogue, sched, workspace, workspace_bytes, st);     // 4 waves of 96 x 64
+        // (launch_cfg<256, 256, 2, 2> - four waves of 128 x 128, one per SIMD with 512 registers, the vendor kernel's shape - instantiates as it
+        //  is and was measured: 1.10 PF/s on random data, 1.27 on zero operands against 1.27 / 1.6 for the 8-wave tile: a lone wave per SIMD
+        //  stalls its own MFMAs behind every LDS-DMA issue and fragment read.  profiles/r04_gemm_data_dependence.jsonl)
         default: return VDD_ERR_INVALID_ARG;
     }
 }
