@@ -43,6 +43,9 @@
 
 #include "vdd_elem.h"
 
+#ifndef VDD_GEMM_W_AHEAD
+#define VDD_GEMM_W_AHEAD 1
+#endif
 #ifndef VDD_GEMM_DMA_SPACING
 #define VDD_GEMM_DMA_SPACING 1
 #endif
@@ -112,6 +115,13 @@ __global__ void __launch_bounds__(WM * WN * 64) gemm_kernel(const GemmArgs a) {
     constexpr int BUF = (BM + BN) * 128;                   // bytes of one K-tile buffer
     constexpr int NSTG = gemm_stages(BM, BN, WM, WN);      // K-tile buffers (> 2: a W stream, see the K pipeline below)
     constexpr int NMMA = NI * MI, NRD = NI + MI, NLD = XJ + WJ;
+#if defined(VDD_GEMM_ABLATE)
+    constexpr bool WAHEAD = false;
+#else
+    // (the 192 x 256 tile of the decode batch only: down-projection 134 -> 120 us, o 57 -> 53 on cold weights; the 256 x 256 tile lost 5 - 12 % with it
+    //  at 1,536 rows - 13 more spilled registers at the cliff - and gained nothing at prefill size, where the panels are L2 hits)
+    constexpr bool WAHEAD = VDD_GEMM_W_AHEAD && NSTG == 2 && gemm_staging_bytes(BN, WM, WN) >= BN * 128 && BM == 192 && BN == 256;
+#endif
     static_assert(XIMG % NW == 0 && WIMG % NW == 0 && TM % 32 == 0 && TN % 32 == 0, "tile / wave shape");
     static_assert(EPI != EPI_SWIGLU || NI % 2 == 0, "SwiGLU pairs gate/up 32-column blocks inside a wave");
     extern __shared__ __attribute__((aligned(16))) char lds[];
@@ -361,6 +371,60 @@ __global__ void __launch_bounds__(WM * WN * 64) gemm_kernel(const GemmArgs a) {
             for (; t + NSTG < nk; ++t) { tile(t, buf, nxt(buf), T_{}, T_{}, WS_{}); buf = nxt(buf); }
             for (; t + 1 < nk; ++t) { tile(t, buf, nxt(buf), F_{}, T_{}, W0_{}); buf = nxt(buf); }     // the last tiles: everything staged is waited for
             tile(t, buf, buf, F_{}, F_{}, W0_{});
+        } else if constexpr (WAHEAD) {
+            // Two K-tile buffers + a THIRD W image in the epilogue's staging blocks (a W image of a 256-column tile is exactly their 32 KiB):
+            // W runs two tiles ahead of the MFMAs, X one.  At the decode batch W is what comes from HBM (13 GB of weights per step, every
+            // K-tile a miss that the eight workgroups sharing the column panel wait for together) while X sits in the L2: with one tile
+            // (0.7 us) of lead against ~2 us of latency the cold launch ran 5 - 12 % behind the same launch on resident weights
+            // (profiles/r04_gemm_decode_cold_vs_hot.jsonl).  X images alternate between the two buffers (literal indices, as below), W images
+            // rotate through three slots (run-time base); the staging blocks are only borrowed between the top-of-segment barrier and the
+            // last tile: nothing is in flight into them while an epilogue uses them.
+            auto wbase = [&](int sl) { return sl == 2 ? 2 * BUF - BM * 128 : sl * BUF; };            // slot 2: the W image starts at the staging blocks
+            auto stage_w3 = [&](int t, int sl) {
+                const int so = t * 128;
+#pragma unroll
+                for (int j = 0; j < WJ; ++j)
+                    __builtin_amdgcn_raw_ptr_buffer_load_lds(rw, (lds_ptr_t)(lds + wbase(sl) + (XIMG + j * NW + wave) * 1024), 16, woff[j], so, 0, 0);
+            };
+            auto rd3 = [&](int buf, int sl, int kk) {
+#pragma unroll
+                for (int i = 0; i < NI; ++i) wg[kk][i] = *reinterpret_cast<const frag8_t*>(lds + wbase(sl) + ((wrow + i * 4096) ^ (kk << 5)));
+#pragma unroll
+                for (int i = 0; i < MI; ++i) xg[kk][i] = *reinterpret_cast<const frag8_t*>(lds + buf * BUF + ((xrow + i * 4096) ^ (kk << 5)));
+            };
+            if (nk > 2) stage_w3(2, 2);                           // (behind the barrier above: every wave is through its epilogue)
+            rd3(0, 0, 0); rd3(0, 0, 1);
+            __builtin_amdgcn_sched_barrier(0);
+            auto tile = [&](int t, int buf, int sl, int sl1, auto do_x, auto do_w, auto do_next, auto wait_n) {      // buf is a literal at every call site
+                constexpr bool STX = decltype(do_x)::value, STW = decltype(do_w)::value, NX = decltype(do_next)::value;
+                constexpr int WN_ = decltype(wait_n)::value;
+                rd3(buf, sl, 2); mm(0); interleave(false, true); __builtin_amdgcn_sched_barrier(0);
+                rd3(buf, sl, 3); mm(1); interleave(false, true); __builtin_amdgcn_sched_barrier(0);
+                asm volatile("s_waitcnt vmcnt(%0) lgkmcnt(0)" :: "n"(WN_) : "memory");   // own reads of tile t done; X and W of tile t+1 landed (W of t+2 may be in flight)
+                __builtin_amdgcn_s_barrier();
+                __builtin_amdgcn_sched_barrier(0);
+                if constexpr (STX) stage_x(t + 2, buf);
+                if constexpr (NX) rd3(buf ^ 1, sl1, 0);
+                mm(2); interleave_n(STX ? XJ : 0, NX); __builtin_amdgcn_sched_barrier(0);
+                if constexpr (STW) stage_w3(t + 3, sl);
+                if constexpr (NX) rd3(buf ^ 1, sl1, 1);
+                mm(3); interleave_n(STW ? WJ : 0, NX); __builtin_amdgcn_sched_barrier(0);
+            };
+            using T_ = std::true_type; using F_ = std::false_type;
+            using WW_ = std::integral_constant<int, WJ>; using W0_ = std::integral_constant<int, 0>;
+            auto nxt = [&](int sl) { return sl == 2 ? 0 : sl + 1; };
+            int t = 0, sl = 0;
+            for (; t + 4 < nk; t += 2) {
+                tile(t, 0, sl, nxt(sl), T_{}, T_{}, T_{}, WW_{}); sl = nxt(sl);
+                tile(t + 1, 1, sl, nxt(sl), T_{}, T_{}, T_{}, WW_{}); sl = nxt(sl);
+            }
+            if (nk - t == 4) {
+                tile(t, 0, sl, nxt(sl), T_{}, T_{}, T_{}, WW_{}); sl = nxt(sl);
+                tile(t + 1, 1, sl, nxt(sl), T_{}, F_{}, T_{}, WW_{}); sl = nxt(sl);
+                t += 2;
+            }
+            tile(t, 0, sl, nxt(sl), F_{}, F_{}, T_{}, W0_{}); sl = nxt(sl);
+            tile(t + 1, 1, sl, sl, F_{}, F_{}, F_{}, W0_{});
         } else {
         rd(0, 0); rd(0, 1);
         __builtin_amdgcn_sched_barrier(0);
