@@ -149,6 +149,10 @@ struct ToppScratch { float gx[TOPP_EXACT_MAX]; int gi[TOPP_EXACT_MAX]; float sp[
 // contrasted chunk out.  448 entries keep three 32000-wide bf16 rows per CU (40 KiB LDS row part + Smem + the list each).
 constexpr int LIVE_CAP = 448;
 struct LiveList { uint4 data[LIVE_CAP]; int ch[LIVE_CAP]; };
+#ifndef VDD_DEBUG_NO_FAST_TAIL
+#define VDD_DEBUG_NO_FAST_TAIL 0          // probe builds: every row takes the block-wide tail (what does that tail cost by itself?)
+#endif
+constexpr int FAST_TAIL_MAX = VDD_DEBUG_NO_FAST_TAIL ? 0 : 64;       // candidates the single-wave tail holds (one per lane)
 constexpr int TOPK_LIST_MAX = 1024;      // ordered keys of the top-k candidate list (same scratch region)
 static_assert(TOPK_LIST_MAX * 4 <= (int)sizeof(LiveList), "");
 
@@ -801,7 +805,7 @@ __global__ void __launch_bounds__(BLOCK, 6) vdd_contrast_sample_kernel(KP p) {
     // share of the scores row - sorts the list into the thread-major enumeration order of the general path, scans,
     // draws (or arg-maxes) and extracts the top-n.  One or two barriers instead of three passes over the row and five
     // block-wide barriers, during which the 64 KiB LDS row and all 16 wave slots of the workgroup were held.
-    if (!row_bad && nfin <= 64 && nch <= 64 * BLOCK) {
+    if (!row_bad && nfin <= FAST_TAIL_MAX && nch <= 64 * BLOCK) {
         const bool warp_on = p.top_k > 0 || p.use_topp;
         const bool tail_on = !((p.flags & VDD_NO_SAMPLE) && !want_top);
         if (warp_on || tail_on) {
