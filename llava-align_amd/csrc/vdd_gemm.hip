@@ -43,6 +43,9 @@
 
 #include "vdd_elem.h"
 
+#ifndef VDD_GEMM_SNAKE
+#define VDD_GEMM_SNAKE 1
+#endif
 #ifndef VDD_GEMM_W_AHEAD
 #define VDD_GEMM_W_AHEAD 1
 #endif
@@ -311,7 +314,13 @@ __global__ void __launch_bounds__(WM * WN * 64) gemm_kernel(const GemmArgs a) {
 #pragma unroll
             for (int i = 0; i < NI; ++i)
 #pragma unroll
-                for (int j = 0; j < MI; ++j) acc[i][j] = mfma32(wg[kk][i], xg[kk][j], acc[i][j]);
+                for (int jj = 0; jj < MI; ++jj) {
+                    // boustrophedon over the wave tile: consecutive MFMAs differ in ONE operand (the MFMA pipe's sustained rate on real data
+                    // depends on how much its operand inputs toggle: tools/probes/mfma_power_probe.hip - both operands new every time 1.52
+                    // PF/s, one held for four instructions 1.60, both held 1.87)
+                    const int j = (VDD_GEMM_SNAKE && (i & 1)) ? MI - 1 - jj : jj;
+                    acc[i][j] = mfma32(wg[kk][i], xg[kk][j], acc[i][j]);
+                }
         };
 #if VDD_GEMM_STREAM_SIMPLE
         if constexpr (NSTG >= 3) {       // (A/B form: read everything, barrier, stage, multiply - two barriers per K-tile, nothing overlapped)

@@ -16,7 +16,7 @@ typedef __attribute__((ext_vector_type(8))) _Float16 h8;
 typedef __attribute__((ext_vector_type(4))) float f4;
 typedef __attribute__((ext_vector_type(16))) float f16v;
 
-template <int SHAPE, bool F16>
+template <int SHAPE, bool F16, int ORDER = 0>
 __global__ void __launch_bounds__(512) mfma_loop(const uint4* __restrict__ src, float* __restrict__ sink, int iters) {
     const int tid = blockIdx.x * blockDim.x + threadIdx.x;
     uint4 a[4], b[4];
@@ -33,7 +33,7 @@ __global__ void __launch_bounds__(512) mfma_loop(const uint4* __restrict__ src, 
 #pragma unroll
             for (int i = 0; i < 8; ++i) {
                 if constexpr (F16) acc[i] = __builtin_amdgcn_mfma_f32_32x32x16_f16(__builtin_bit_cast(h8, a[i & 3]), __builtin_bit_cast(h8, b[(i + it) & 3]), acc[i], 0, 0, 0);
-                else acc[i] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf8, a[i & 3]), __builtin_bit_cast(bf8, b[(i + it) & 3]), acc[i], 0, 0, 0);
+                else acc[i] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf8, a[ORDER == 0 ? (i & 3) : ORDER == 1 ? (i >> 2) : 0]), __builtin_bit_cast(bf8, b[ORDER == 2 ? 0 : ((i + it) & 3)]), acc[i], 0, 0, 0);
             }
         }
 #pragma unroll
@@ -60,13 +60,13 @@ __global__ void __launch_bounds__(512) mfma_loop(const uint4* __restrict__ src, 
 static uint16_t to_bf16(float f) { uint32_t u; memcpy(&u, &f, 4); return (uint16_t)((u + 0x7fffu + ((u >> 16) & 1u)) >> 16); }
 static uint16_t to_f16(float f) { _Float16 h = (_Float16)f; uint16_t u; memcpy(&u, &h, 2); return u; }
 
-template <int SHAPE, bool F16>
+template <int SHAPE, bool F16, int ORDER = 0>
 double run(const uint4* d_src, float* d_sink, int blocks, int iters) {
     hipEvent_t e0, e1; hipEventCreate(&e0); hipEventCreate(&e1);
-    mfma_loop<SHAPE, F16><<<blocks, 512>>>(d_src, d_sink, iters / 8);          // warm-up
+    mfma_loop<SHAPE, F16, ORDER><<<blocks, 512>>>(d_src, d_sink, iters / 8);          // warm-up
     hipDeviceSynchronize();
     hipEventRecord(e0);
-    for (int r = 0; r < 4; ++r) mfma_loop<SHAPE, F16><<<blocks, 512>>>(d_src, d_sink, iters);
+    for (int r = 0; r < 4; ++r) mfma_loop<SHAPE, F16, ORDER><<<blocks, 512>>>(d_src, d_sink, iters);
     hipEventRecord(e1); hipEventSynchronize(e1);
     float ms = 0.f; hipEventElapsedTime(&ms, e0, e1);
     const double flops_per = SHAPE == 32 ? 2.0 * 32 * 32 * 16 : 2.0 * 16 * 16 * 32;
@@ -96,7 +96,9 @@ int main() {
             hipMemcpy(d_src, h, n16 * 2, hipMemcpyHostToDevice);
             double r32 = f16 ? run<32, true>(d_src, d_sink, blocks, iters) : run<32, false>(d_src, d_sink, blocks, iters);
             double r16 = f16 ? run<16, true>(d_src, d_sink, blocks, iters) : run<16, false>(d_src, d_sink, blocks, iters);
-            printf("{\"data\": \"%s\", \"dtype\": \"%s\", \"mfma_32x32x16_PFs\": %.3f, \"mfma_16x16x32_PFs\": %.3f}\n", dset.name, f16 ? "fp16" : "bf16", r32, r16);
+            printf("{\"data\": \"%s\", \"dtype\": \"%s\", \"mfma_32x32x16_PFs\": %.3f, \"mfma_16x16x32_PFs\": %.3f", dset.name, f16 ? "fp16" : "bf16", r32, r16);
+            if (!f16) printf(", \"32x32x16_A_held_for_4\": %.3f, \"32x32x16_same_A_B_every_time\": %.3f", run<32, false, 1>(d_src, d_sink, blocks, iters), run<32, false, 2>(d_src, d_sink, blocks, iters));
+            printf("}\n");
             fflush(stdout);
         }
     }
