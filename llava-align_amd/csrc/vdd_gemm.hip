@@ -44,7 +44,7 @@
 #include "vdd_elem.h"
 
 #ifndef VDD_GEMM_SNAKE
-#define VDD_GEMM_SNAKE 1
+#define VDD_GEMM_SNAKE 2
 #endif
 #ifndef VDD_GEMM_W_AHEAD
 #define VDD_GEMM_W_AHEAD 1
@@ -311,6 +311,13 @@ __global__ void __launch_bounds__(WM * WN * 64) gemm_kernel(const GemmArgs a) {
             }
         };
         auto mm = [&](int kk) {
+            if constexpr (VDD_GEMM_SNAKE == 2) {       // X fragment outer, W inner, boustrophedon: another +0.3 ... 0.9 % over the W-outer walk (A/B builds)
+#pragma unroll
+                for (int j = 0; j < MI; ++j)
+#pragma unroll
+                    for (int ii = 0; ii < NI; ++ii) { const int i = (j & 1) ? NI - 1 - ii : ii; acc[i][j] = mfma32(wg[kk][i], xg[kk][j], acc[i][j]); }
+                return;
+            }
 #pragma unroll
             for (int i = 0; i < NI; ++i)
 #pragma unroll
