@@ -723,7 +723,14 @@ int launch_cfg(const GemmArgs& a0, int epi, int sched, void* workspace, int64_t 
     const int ncols = epi == EPI_SWIGLU ? 2 * a.N : a.N;
     a.Mt = (a.M + BM - 1) / BM;
     a.Nt = (ncols + BN - 1) / BN;
-    a.GM = a.Mt < 8 ? a.Mt : 8;
+    // row-tiles per group of the tile order (a group = GM row-tiles x all column tiles, row-tile fastest: an XCD's 32 workgroups hold GM x 32 / GM
+    // tiles).  A/B builds at 39,140 rows (profiles/r04_gemm_tile_order_ab.jsonl): 8 is best for 48 and 16 column tiles (qkv, o, down: 4 costs qkv 1.3 %,
+    // 16 costs down 2.6 %), 4 for the 86 column tiles of gate/up (+2.9 %; 16: -5.5 %).  The decode batch (8 row-tiles) keeps one group.
+#ifdef VDD_GEMM_GM
+    a.GM = a.Mt < VDD_GEMM_GM ? a.Mt : VDD_GEMM_GM;
+#else
+    a.GM = a.Mt < 8 ? a.Mt : ((a.Mt >= 32 && a.Nt >= 80) ? 4 : 8);
+#endif
     a.UP = a.K / 128;
     const long long U = (long long)a.Mt * a.Nt * a.UP;
     if (U > 0x7fffffffLL) return VDD_ERR_INVALID_ARG;
