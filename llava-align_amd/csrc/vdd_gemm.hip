@@ -43,6 +43,9 @@
 
 #include "vdd_elem.h"
 
+#ifndef VDD_GEMM_W_AUX
+#define VDD_GEMM_W_AUX 0          // cache policy bits of the W LDS-DMA (probe builds: 2 = nt: 1 - 3 % slower at the 1,536-row decode batch, eight workgroups share every W tile)
+#endif
 #ifndef VDD_GEMM_SNAKE
 #define VDD_GEMM_SNAKE 2
 #endif
@@ -237,7 +240,7 @@ __global__ void __launch_bounds__(WM * WN * 64) gemm_kernel(const GemmArgs a) {
         if (!((ab & 2) && t >= 2)) {
 #pragma unroll
         for (int j = 0; j < WJ; ++j)
-            __builtin_amdgcn_raw_ptr_buffer_load_lds(rw, (lds_ptr_t)(lds + buf * BUF + (XIMG + j * NW + wave) * 1024), 16, woff[j], so, 0, 0);
+            __builtin_amdgcn_raw_ptr_buffer_load_lds(rw, (lds_ptr_t)(lds + buf * BUF + (XIMG + j * NW + wave) * 1024), 16, woff[j], so, 0, VDD_GEMM_W_AUX);
         }
     };
 
@@ -251,7 +254,7 @@ __global__ void __launch_bounds__(WM * WN * 64) gemm_kernel(const GemmArgs a) {
         const int so = t * 128;
 #pragma unroll
         for (int j = 0; j < WJ; ++j)
-            __builtin_amdgcn_raw_ptr_buffer_load_lds(rw, (lds_ptr_t)(lds + buf * BUF + (XIMG + j * NW + wave) * 1024), 16, woff[j], so, 0, 0);
+            __builtin_amdgcn_raw_ptr_buffer_load_lds(rw, (lds_ptr_t)(lds + buf * BUF + (XIMG + j * NW + wave) * 1024), 16, woff[j], so, 0, VDD_GEMM_W_AUX);
     };
     bool more = advance();
     auto stage_first = [&]() {
@@ -400,7 +403,7 @@ __global__ void __launch_bounds__(WM * WN * 64) gemm_kernel(const GemmArgs a) {
                 const int so = t * 128;
 #pragma unroll
                 for (int j = 0; j < WJ; ++j)
-                    __builtin_amdgcn_raw_ptr_buffer_load_lds(rw, (lds_ptr_t)(lds + wbase(sl) + (XIMG + j * NW + wave) * 1024), 16, woff[j], so, 0, 0);
+                    __builtin_amdgcn_raw_ptr_buffer_load_lds(rw, (lds_ptr_t)(lds + wbase(sl) + (XIMG + j * NW + wave) * 1024), 16, woff[j], so, 0, VDD_GEMM_W_AUX);
             };
             auto rd3 = [&](int buf, int sl, int kk) {
 #pragma unroll
