@@ -33,7 +33,7 @@ __global__ void __launch_bounds__(512) mfma_loop(const uint4* __restrict__ src, 
 #pragma unroll
             for (int i = 0; i < 8; ++i) {
                 if constexpr (F16) acc[i] = __builtin_amdgcn_mfma_f32_32x32x16_f16(__builtin_bit_cast(h8, a[i & 3]), __builtin_bit_cast(h8, b[(i + it) & 3]), acc[i], 0, 0, 0);
-                else acc[i] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf8, a[ORDER == 0 ? (i & 3) : ORDER == 1 ? (i >> 2) : 0]), __builtin_bit_cast(bf8, b[ORDER == 2 ? 0 : ((i + it) & 3)]), acc[i], 0, 0, 0);
+                else acc[i] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf8, a[ORDER == 0 ? (i & 3) : ORDER == 1 ? (i >> 2) : ORDER == 3 ? ((i + it) & 3) : ORDER == 4 ? (((i + 1) >> 1) & 1) : 0]), __builtin_bit_cast(bf8, b[ORDER == 2 ? 0 : ORDER == 3 ? (i >> 2) : ORDER == 4 ? ((i >> 1) & 3) : ((i + it) & 3)]), acc[i], 0, 0, 0);
             }
         }
 #pragma unroll
@@ -97,7 +97,7 @@ int main() {
             double r32 = f16 ? run<32, true>(d_src, d_sink, blocks, iters) : run<32, false>(d_src, d_sink, blocks, iters);
             double r16 = f16 ? run<16, true>(d_src, d_sink, blocks, iters) : run<16, false>(d_src, d_sink, blocks, iters);
             printf("{\"data\": \"%s\", \"dtype\": \"%s\", \"mfma_32x32x16_PFs\": %.3f, \"mfma_16x16x32_PFs\": %.3f", dset.name, f16 ? "fp16" : "bf16", r32, r16);
-            if (!f16) printf(", \"32x32x16_A_held_for_4\": %.3f, \"32x32x16_same_A_B_every_time\": %.3f", run<32, false, 1>(d_src, d_sink, blocks, iters), run<32, false, 2>(d_src, d_sink, blocks, iters));
+            if (!f16) printf(", \"32x32x16_A_held_for_4\": %.3f, \"32x32x16_same_A_B_every_time\": %.3f, \"32x32x16_B_held_for_4\": %.3f, \"32x32x16_B_held_for_2_A_alternates_snake\": %.3f", run<32, false, 1>(d_src, d_sink, blocks, iters), run<32, false, 2>(d_src, d_sink, blocks, iters), run<32, false, 3>(d_src, d_sink, blocks, iters), run<32, false, 4>(d_src, d_sink, blocks, iters));
             printf("}\n");
             fflush(stdout);
         }
