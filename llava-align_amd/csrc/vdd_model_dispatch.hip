@@ -101,6 +101,26 @@ VDD_MODEL_FN(vdd_add, VDD_P(const void* a, const void* b, void* out, int64_t n),
 VDD_MODEL_FN(vdd_layernorm, VDD_P(const void* x, const void* w, const void* b, void* y, int M, int d, float eps), VDD_P(x, w, b, y, M, d, eps))
 VDD_MODEL_FN(vdd_bias_act, VDD_P(const void* x, const void* bias, void* y, int64_t M, int d, int act), VDD_P(x, bias, y, M, d, act))
 
+VDD_MODEL_FN(vdd_decode_layers,
+             VDD_P(const vdd_layer_desc* layers, int n_layers, const void* resid_in, void* resid_out, float* ss_out, const int32_t* pos,
+                   const int32_t* cpos, const int32_t* slot, const float* cos_sin, const int32_t* rows, int M, int d, int H, int Hkv, int F, int D,
+                   float eps, float scale, int64_t slot_stride, int t_max, int64_t prefix_stride, int prefix_tmax, int has_qkv_bias,
+                   void* workspace, int64_t workspace_bytes),
+             VDD_P(layers, n_layers, resid_in, resid_out, ss_out, pos, cpos, slot, cos_sin, rows, M, d, H, Hkv, F, D, eps, scale, slot_stride, t_max,
+                   prefix_stride, prefix_tmax, has_qkv_bias, workspace, workspace_bytes))
+VDD_HIDDEN int vdd_decode_layers_max_rows_bf16(int d, int H, int F, int D, int n_layers);
+VDD_HIDDEN int64_t vdd_decode_layers_workspace_bytes_bf16(int M, int d, int H, int F, int D);
+VDD_HIDDEN int vdd_decode_layers_ss_cols_bf16(int d, int H, int F, int D);
+int vdd_decode_layers_ss_cols(int d, int H, int F, int D, int dtype) {
+    return (dtype == VDD_BF16 || dtype == VDD_F16) ? vdd_decode_layers_ss_cols_bf16(d, H, F, D) : 0;
+}
+int vdd_decode_layers_max_rows(int d, int H, int F, int D, int n_layers, int dtype) {
+    return (dtype == VDD_BF16 || dtype == VDD_F16) ? vdd_decode_layers_max_rows_bf16(d, H, F, D, n_layers) : 0;
+}
+int64_t vdd_decode_layers_workspace_bytes(int M, int d, int H, int F, int D, int dtype) {
+    return (dtype == VDD_BF16 || dtype == VDD_F16) ? vdd_decode_layers_workspace_bytes_bf16(M, d, H, F, D) : 0;
+}
+
 // workspace sizes do not depend on the storage type (fp32 partials, int32 counters): one instantiation answers
 VDD_HIDDEN int64_t vdd_gemm_workspace_bytes_bf16(int M, int N);
 VDD_HIDDEN int64_t vdd_decode_attention_workspace_bytes_bf16(int M, int H, int D, int max_len);

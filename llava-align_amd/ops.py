@@ -38,6 +38,7 @@ _SIGS = {
     "vdd_skinny_gemm_normed": [_P, _P, _I, _P, _F, _P, _P, _I, _I, _I, _L, _L, _I, _P],
     "vdd_skinny_swiglu_normed": [_P, _P, _I, _P, _F, _P, _P, _I, _I, _I, _L, _I, _P],
     "vdd_stop_words_match": [_P, _L, _L, _P, _P, _I, _P, _P, _I, _P, _I, _P],
+    "vdd_decode_layers": [_P, _I, _P, _P, _P, _P, _P, _P, _P, _P, _I, _I, _I, _I, _I, _I, _F, _F, _L, _I, _L, _I, _I, _P, _L, _I, _P],
     "vdd_repetition_penalty": [_P, _L, _I, _I, _I, _P, _I, _P, _L, _L, _P, _F, C.c_uint32, _P],
 }
 _bound = False
@@ -240,6 +241,65 @@ def swiglu_linear_normed(h, ss, ln_w, eps, w_gate_up, out=None):
     _lib.check(_lib_ready().vdd_skinny_swiglu_normed(h.data_ptr(), ss.data_ptr(), ss.shape[1], ln_w.data_ptr(), eps, w_gate_up.data_ptr(),
                                                      out.data_ptr(), M, F, K, h.stride(0), dt, _st(h)))
     return out
+
+
+# ---------------------------------------------------------------- persistent few-row decode layers (csrc/vdd_layer_persistent.hip)
+PERSISTENT_LAYERS = True     # one launch for ALL decoder layers of a 1 - 4 row decode step (False: the five-launch layer)
+LAYER_DESC_FIELDS = 11       # vdd_layer_desc: ln1, wqkv, bqkv, wo, ln2, wgu, wd, k_own, v_own, k_pre, v_pre
+
+
+def decode_layers_max_rows(d: int, H: int, Hkv: int, F: int, D: int, n_layers: int, dtype=torch.bfloat16) -> int:
+    """Rows one persistent launch takes for this model shape on the current device (0: not served - GQA, head_dim != 128, ...)."""
+    if not PERSISTENT_LAYERS or Hkv != H or n_layers < 1 or n_layers > 120:
+        return 0
+    lib = _lib_ready()
+    lib.vdd_decode_layers_max_rows.argtypes, lib.vdd_decode_layers_max_rows.restype = [_I, _I, _I, _I, _I, _I], C.c_int
+    return int(lib.vdd_decode_layers_max_rows(d, H, F, D, n_layers, _MODEL_DT[dtype]))
+
+
+def decode_layers_workspace(M: int, d: int, H: int, F: int, D: int, device, dtype=torch.bfloat16) -> torch.Tensor:
+    """Granule exchange buffers + launch counter + give-up word of the persistent layers: ZEROED once, then owned by the launches
+    (the epochs of the hand-offs derive from the launch counter in it, also under graph replay).  Allocate before a capture."""
+    lib = _lib_ready()
+    lib.vdd_decode_layers_workspace_bytes.restype = C.c_int64
+    lib.vdd_decode_layers_workspace_bytes.argtypes = [_I, _I, _I, _I, _I, _I]
+    n = int(lib.vdd_decode_layers_workspace_bytes(M, d, H, F, D, _MODEL_DT[dtype]))
+    if n <= 0:
+        raise ValueError(f"persistent decode layers do not serve M={M}, d={d}, H={H}, F={F}, D={D}")
+    return torch.zeros(n, dtype=torch.uint8, device=device)
+
+
+def layer_descriptors(layers, device) -> torch.Tensor:
+    """[n_layers, 11] int64 device tensor of vdd_layer_desc records; `layers`: per layer a dict with the tensors ln1, wqkv, bqkv (or
+    None), wo, ln2, wgu, wd, k_own, v_own, k_pre, v_pre.  The caller keeps the tensors alive."""
+    keys = ("ln1", "wqkv", "bqkv", "wo", "ln2", "wgu", "wd", "k_own", "v_own", "k_pre", "v_pre")
+    rows = [[0 if l.get(k) is None else l[k].data_ptr() for k in keys] for l in layers]
+    return torch.tensor(rows, dtype=torch.int64).to(device)
+
+
+def decode_layers(desc, n_layers, resid_in, pos, cpos, slot, cos_sin, rows, H, F, D, eps, slot_stride, t_max, prefix_stride, prefix_tmax,
+                  has_qkv_bias, workspace, resid_out=None, ss_out=None):
+    """All decoder layers of one decode step for M <= decode_layers_max_rows rows in ONE persistent launch.  resid_in [M, d]: the
+    embeddings.  Returns (resid [M, d], ss [M, n]): the residual stream behind the last layer + partial sums of squares of its rows,
+    what linear_normed takes for the final norm + lm_head.  The KV pools behind `desc` get the new token's K / V."""
+    dt = _dt(resid_in)
+    M, d = resid_in.shape
+    resid_out = torch.empty_like(resid_in) if resid_out is None else resid_out
+    if ss_out is None:
+        lib = _lib_ready()
+        lib.vdd_decode_layers_ss_cols.argtypes, lib.vdd_decode_layers_ss_cols.restype = [_I, _I, _I, _I, _I], C.c_int
+        ss_out = torch.empty(M, int(lib.vdd_decode_layers_ss_cols(d, H, F, D, dt)), dtype=torch.float32, device=resid_in.device)
+    _lib.check(_lib_ready().vdd_decode_layers(desc.data_ptr(), n_layers, resid_in.data_ptr(), resid_out.data_ptr(), ss_out.data_ptr(),
+                                              pos.data_ptr(), cpos.data_ptr(), slot.data_ptr(), cos_sin.data_ptr(), rows.data_ptr(), M, d, H, H,
+                                              F, D, eps, D ** -0.5, slot_stride, t_max, prefix_stride, prefix_tmax, 1 if has_qkv_bias else 0,
+                                              workspace.data_ptr(), workspace.numel(), dt, _st(resid_in)))
+    return resid_out, ss_out
+
+
+def decode_layers_status(workspace) -> int:
+    """The give-up word of the persistent layers (forces a sync): 0, or the code of the first wait that timed out
+    (low 16 bits: phase code of csrc/vdd_layer_persistent.hip, high bits: workgroup) - the step's results are garbage then."""
+    return int(workspace[4:8].view(torch.int32).item())
 
 
 SKINNY_MAX_M = 8      # up to here every projection is a weight-streaming kernel
