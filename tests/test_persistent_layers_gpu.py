@@ -193,9 +193,15 @@ def test_engine_decodes_through_the_persistent_layers(n_q, mode):
     finally:
         eng.lm.persistent = False
         eng._graphs.clear()
-    for step, (sa, sb) in enumerate(zip(a.scores, b.scores)):
-        fin = torch.isfinite(sa) & torch.isfinite(sb)
-        assert (torch.isfinite(sa) ^ torch.isfinite(sb)).sum() <= 2 * n_q, step
-        tol = max(0.25, 2.0 ** -6 * sb[fin].float().abs().max().item())       # two ulps of the 16-bit type at the largest score
-        assert (sa[fin].float() - sb[fin].float()).abs().max().item() <= tol, step
-    assert (a.tokens == b.tokens).float().mean().item() >= 0.75
+    same = 0
+    for q in range(n_q):                                        # a question is compared while both runs are still on the same tokens
+        for step, (sa, sb) in enumerate(zip(a.scores, b.scores)):
+            ra, rb = sa[q].float(), sb[q].float()
+            fin = torch.isfinite(ra) & torch.isfinite(rb)
+            assert (torch.isfinite(ra) ^ torch.isfinite(rb)).sum() <= 3 + 0.25 * int(fin.sum()), (q, step)     # candidate density x logit noise
+            tol = max(0.25, 2.0 ** -6 * rb[fin].abs().max().item())       # two ulps of the 16-bit type at the largest score
+            assert (ra[fin] - rb[fin]).abs().max().item() <= tol, (q, step)
+            if a.tokens[q, step].item() != b.tokens[q, step].item():
+                break
+            same += 1
+    assert same >= 4 * n_q
