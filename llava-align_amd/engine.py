@@ -230,7 +230,8 @@ class VisionTower:
         v = self.cfg
         self.T = v.n_patches + 1
         dh = v.width // v.heads
-        assert dh == 64, "the ViT attention kernel is instantiated for head_dim 64"
+        if dh != 64:
+            raise ValueError(f"vision tower head_dim {dh}: the ViT attention kernel is instantiated for head_dim 64 (CLIP ViT-L/14)")
         self._kv = None
         self.use_graph = False               # set by the engine; a full GRAPH_BATCH of images then replays a HIP graph
         self._graphs: Dict[int, tuple] = {}
@@ -1106,7 +1107,9 @@ class VddLlavaEngine:
                           #  path although it reads a shared prefix once per row: tools/small_batch_attn_probe.py, +4 ... 9 %)
         kv = self.kv(len(plan["prefix"]), max([s_["T"] for s_ in plan["prefix"]] + [0]), len(plan["suffix"]),
                      max(s_["T"] for s_ in plan["suffix"]) + max_new_tokens, frag_only=bool(grp))
-        assert plan["max_len"] + max_new_tokens <= self.cfg.lm.max_pos, "prompt + new tokens exceed the rotary table"
+        if plan["max_len"] + max_new_tokens > self.cfg.lm.max_pos:
+            raise ValueError(f"prompt ({plan['max_len']} positions) + max_new_tokens ({max_new_tokens}) exceed the rotary table "
+                             f"(max_pos = {self.cfg.lm.max_pos}): lower max_new_tokens or build the engine with a larger LMConfig.max_pos")
         stats = {"n_rows": nb * Q, "prefill_tokens": plan["prefill_tokens"], "unshared_prefill_tokens": plan["unshared_tokens"]}
 
         want_maps = bool(output_attentions) and Q == 1 and lm.head_dim == 128 and lm.n_layers > 0

@@ -84,7 +84,10 @@ def weights_from_hf(model, cfg: Optional[LlavaConfig] = None, share_storage: boo
     """The live parameters of `model` in the engine's layout, in the model's dtype, on the model's device.  Tensors the kernels
     read as HF stores them ([N, K] row-major: embeddings, o / down projections, lm_head, norms, the ViT's out / fc weights) are
     the SAME storage; q/k/v and gate/up are concatenated once, and with share_storage the HF parameters become views of the
-    concatenated tensors (HF's eager forward keeps working on them; the model's memory does not grow by a second copy)."""
+    concatenated tensors (HF's eager forward keeps working on them; the model's memory does not grow by a second copy).
+    SIDE EFFECT of share_storage: those parameters are then non-contiguous slices of one storage per layer - `save_pretrained` /
+    safetensors refuse such tensors.  `detach_engine(model)` gives every re-pointed parameter its own contiguous storage back
+    (`model._vdd_shared` lists them); `share_storage=False` never touches the model and costs one extra copy of q/k/v and gate/up."""
     cfg = cfg if cfg is not None else config_from_hf(model)
     p0 = model.lm_head.weight
     if not p0.is_cuda or p0.dtype not in (torch.float16, torch.bfloat16):
@@ -94,12 +97,14 @@ def weights_from_hf(model, cfg: Optional[LlavaConfig] = None, share_storage: boo
     w = LlavaWeights.from_state_dict(cfg, sd, p0.device, dtype=p0.dtype)
     if share_storage:
         lm, v = cfg.lm, cfg.vision
+        shared = model.__dict__.setdefault("_vdd_shared", [])
         nq, nkv = lm.n_heads * lm.head_dim, lm.n_kv_heads * lm.head_dim
         for i, layer in enumerate(model.model.layers):
             a, m = layer.self_attn, layer.mlp
             qkv, gu = w.t[f"l{i}.wqkv"], w.t[f"l{i}.wgu"]
             a.q_proj.weight.data, a.k_proj.weight.data, a.v_proj.weight.data = qkv[:nq], qkv[nq:nq + nkv], qkv[nq + nkv:]
             m.gate_proj.weight.data, m.up_proj.weight.data = gu[:lm.ffn], gu[lm.ffn:]
+            shared += [a.q_proj.weight, a.k_proj.weight, a.v_proj.weight, m.gate_proj.weight, m.up_proj.weight]
         enc = model.get_vision_tower().vision_tower
         enc = getattr(enc, "vision_model", enc)
         for i in range(v.run_layers):
@@ -108,6 +113,7 @@ def weights_from_hf(model, cfg: Optional[LlavaConfig] = None, share_storage: boo
             W = v.width
             a.q_proj.weight.data, a.k_proj.weight.data, a.v_proj.weight.data = qkv[:W], qkv[W:2 * W], qkv[2 * W:]
             a.q_proj.bias.data, a.k_proj.bias.data, a.v_proj.bias.data = b[:W], b[W:2 * W], b[2 * W:]
+            shared += [a.q_proj.weight, a.k_proj.weight, a.v_proj.weight, a.q_proj.bias, a.k_proj.bias, a.v_proj.bias]
     return w
 
 
@@ -136,6 +142,9 @@ def _native_generate(model, inputs=None, generation_config=None, **kw):
     `VddLlavaEngine.generate`.  Explicit keywords (None included: llava_calibrate.py:170-171 pass top_p=None, top_k=None) override
     `model.generation_config`, as `generation_config.update(**kwargs)` does in HF."""
     eng: VddLlavaEngine = model._vdd_engine
+    if model.lm_head.weight.data_ptr() != eng.w.t["lm_head"].data_ptr():
+        raise RuntimeError("the model's parameters moved since attach_engine(model) (model.to() / .half() / resize_token_embeddings re-allocate "
+                           "them): the engine would decode with the old weights - call attach_engine(model) again")
     gc = generation_config if generation_config is not None else model.generation_config
     input_ids = inputs if inputs is not None else kw.pop("input_ids", None)
     if input_ids is None and kw.get("inputs_embeds") is None:
@@ -198,8 +207,12 @@ def attach_engine(model, share_storage: bool = True, use_graph: bool = True, max
 
 
 def detach_engine(model) -> None:
+    """HF's own generate back, and (after attach_engine(..., share_storage=True)) every parameter that was re-pointed at a slice of a
+    fused tensor gets a contiguous storage of its own again, so that save_pretrained / safetensors take the model as before."""
     model.__dict__.pop("generate", None)
     model.__dict__.pop("_vdd_engine", None)
+    for p in model.__dict__.pop("_vdd_shared", []):
+        p.data = p.data.clone(memory_format=torch.contiguous_format)
 
 
 __all__ = ["attach_engine", "detach_engine", "config_from_hf", "weights_from_hf", "NativeGenerateOutput", "IMAGE_TOKEN_INDEX"]

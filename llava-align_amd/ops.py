@@ -388,8 +388,12 @@ def gemm(x, w, bias=None, resid=None, epi=EPI_NONE, out=None, config=None):
             config = 1 + 16 if GEMM_BATCH_INVARIANT else 1
             if M <= GEMM_TUNE_MAX_M and GEMM_AUTOTUNE:
                 if not torch.cuda.is_current_stream_capturing():
-                    config = _gemm_choice[key] = _gemm_tune(x, w, out, bias, resid, M, N, K, epi, ws)
-                    _store_persisted(key, config)
+                    with _CacheLock():                             # one rank of a node tunes, the others read its pick
+                        _read_cache_section()
+                        config = _gemm_choice.get(key)
+                        if config is None:
+                            config = _gemm_choice[key] = _gemm_tune(x, w, out, bias, resid, M, N, K, epi, ws)
+                            _store_persisted(key, config)
                 # (under capture: the default for this launch only - caching it would pin an untuned choice for the process)
             else:
                 _gemm_choice[key] = config
@@ -445,6 +449,33 @@ def _lib_fingerprint() -> str:
     return h.hexdigest()[:16]
 
 
+def gemm_source_fingerprint() -> str:
+    """What the in-tree defaults are bound to: the GEMM kernel's SOURCE (csrc/vdd_gemm.hip + csrc/vdd_elem.h), not the binary - two
+    builds of the same source differ in embedded paths.  "" when the sources do not travel with the package."""
+    import hashlib
+    import os
+    h = hashlib.sha256()
+    for f in ("vdd_gemm.hip", "vdd_elem.h"):
+        path = os.path.join(os.path.dirname(os.path.abspath(__file__)), "csrc", f)
+        if not os.path.exists(path):
+            return ""
+        with open(path, "rb") as fh:
+            h.update(fh.read())
+    return h.hexdigest()[:16]
+
+
+def _read_cache_section():
+    """The cache file's choices for this device and library build (re-read on every call: another rank may have tuned meanwhile)."""
+    import json
+    import os
+    if _persist["path"] and os.path.exists(_persist["path"]):
+        try:
+            with open(_persist["path"]) as f:
+                gemm_choices_import(json.load(f).get(_persist["section"], {}))
+        except (OSError, ValueError):
+            pass                                                   # an unreadable cache is no cache
+
+
 def _load_persisted(device):
     """Once per process (and per device name): the in-tree defaults, then the user's cache file on top."""
     import json
@@ -457,20 +488,48 @@ def _load_persisted(device):
     arch = getattr(torch.cuda.get_device_properties(device), "gcnArchName", "")
     if arch.startswith("gfx950") and os.path.exists(default) and os.environ.get("VDD_GEMM_DEFAULTS", "").lower() not in ("off", "0", "none"):
         with open(default) as f:
-            for k, v in json.load(f).get("choices", {}).items():
+            doc = json.load(f)
+        # defaults measured on another revision of the kernel are still valid configurations, but no longer the measured winners:
+        # skip them (the shapes are then tuned once per machine and cached) unless the caller insists (VDD_GEMM_DEFAULTS=force)
+        bound, here = doc.get("gemm_source_sha", ""), gemm_source_fingerprint()
+        if not bound or not here or bound == here or os.environ.get("VDD_GEMM_DEFAULTS", "").lower() == "force":
+            for k, v in doc.get("choices", {}).items():
                 kk = k.split(",")
                 key = (int(kk[0]), int(kk[1]), int(kk[2]), int(kk[3]), kk[4] == "True", int(kk[5]))
                 _gemm_choice.setdefault(key, int(v))
-    if _persist["path"] and os.path.exists(_persist["path"]):
-        try:
-            with open(_persist["path"]) as f:
-                gemm_choices_import(json.load(f).get(_persist["section"], {}))
-        except (OSError, ValueError):
-            pass                                                   # an unreadable cache is no cache
+    _read_cache_section()
+
+
+class _CacheLock:
+    """Exclusive advisory lock beside the cache file: the ranks of one node tune a missing shape ONE AT A TIME - the second one finds
+    the first one's pick in the file instead of timing its own (and possibly landing on another, equally fast, summation order)."""
+
+    def __enter__(self):
+        import os
+        self.f = None
+        path = _persist["path"]
+        if path:
+            try:
+                import fcntl
+                os.makedirs(os.path.dirname(path), exist_ok=True)
+                self.f = open(path + ".lock", "w")
+                fcntl.flock(self.f, fcntl.LOCK_EX)
+            except (OSError, ImportError):
+                self.f = None
+        return self
+
+    def __exit__(self, *exc):
+        if self.f is not None:
+            try:
+                import fcntl
+                fcntl.flock(self.f, fcntl.LOCK_UN)
+            finally:
+                self.f.close()
+        return False
 
 
 def _store_persisted(key, cfg):
-    """Append one freshly tuned choice to the cache file (read - merge - atomic replace: concurrent ranks tune the same shapes)."""
+    """Append one freshly tuned choice to the cache file (read - merge - atomic replace; the caller holds _CacheLock)."""
     import json
     import os
     path = _persist["path"]

@@ -626,3 +626,46 @@ def test_output_attentions_for_one_question_is_the_last_layer_map_of_step_zero(e
     o2 = eng.generate(many_ids, images=many_imgs, max_new_tokens=1, output_attentions=True)       # a batch: accepted, nothing materialised
     with pytest.raises(KeyError, match="attentions"):
         o2["attentions"]
+
+
+@pytest.mark.parametrize("n_img,per_img", [(1, 1), (2, 4), (5, 6)])         # 2 rows (weight-streaming + fused norms), 16 rows, 60 rows (MFMA GEMM)
+def test_vocabulary_that_is_not_a_multiple_of_eight(n_img, per_img):
+    """resize_token_embeddings(len(tokenizer)) after add_tokens leaves V = 32001 ... 32003 (builder.py:127-132).  lm_head then
+    runs on a zero-padded copy and the logits are a strided [rows, V] VIEW of the [rows, V_pad] product; that view flows through the fused
+    tail, its scores buffer, the repetition-penalty kernel, top-n and the captured graph.  V = 1003 here, against the fp32 reference."""
+    from dataclasses import replace
+    from llava_align_amd.engine import LlavaWeights, VddLlavaEngine, preset
+    cfg = preset("tiny")
+    cfg = replace(cfg, lm=replace(cfg.lm, vocab=1003))
+    w = LlavaWeights.random(cfg, DEV, seed=11, std=0.06)
+    ids, imgs = prompts(n_img=n_img, per_img=per_img, seed=5, vocab=1003)
+    kw = dict(images=imgs, use_dd_unk=True, cd_alpha=1.0, cd_beta=0.1, temperature=0.5, max_new_tokens=5, cd_greedy=True, output_scores=True, n_top=10)
+    outs = {}
+    for graph in (False, True):
+        e = VddLlavaEngine(cfg, weights=w, device=DEV, t_max=256, use_graph=graph)
+        assert e.lm.lm_head.shape[0] == 1008 and e.lm.lm_head.data_ptr() != w.t["lm_head"].data_ptr()
+        outs[graph] = e.generate(ids, **kw)
+        o = outs[graph]
+        assert all(s.shape == (len(ids), 1003) for s in o.scores) and int(o.tokens.max()) < 1003 and int(o.top_tok.max()) < 1003
+        # with a repetition penalty (the contrast-only / plain split materialises the scores row in between) and sampling
+        r = e.generate(ids, **dict(kw, repetition_penalty=1.3, cd_greedy=False, seed=4))
+        assert r.tokens.shape == o.tokens.shape and int(r.tokens.max()) < 1003
+    assert torch.equal(outs[False].tokens, outs[True].tokens)
+    for a, b in zip(outs[False].scores, outs[True].scores):
+        assert torch.equal(a, b)
+    ref = RefLlava(w, device=DEV)
+    checked = 0
+    for q in range(0, len(ids), max(1, len(ids) // 3)):
+        r = run_ref(ref, ids[q], imgs[q], {"use_dd_unk": True}, 5)
+        for step in range(5):
+            s_got, s_want = outs[True].scores[step][q].float().cpu(), r.scores[step][0].float().cpu()
+            fin = torch.isfinite(s_got) & torch.isfinite(s_want)
+            assert fin.sum() >= 1 and (torch.isfinite(s_got) ^ torch.isfinite(s_want)).sum() <= 3 + 0.05 * int(fin.sum())
+            assert (s_got[fin] - s_want[fin]).abs().max().item() <= 0.4, (q, step)
+            top2 = torch.topk(s_want, 2).values
+            if (top2[0] - top2[1]).item() > 0.8:
+                assert outs[True].tokens[q, step].item() == r.sequences[0, ids[q].numel() + step].item(), (q, step)
+                checked += 1
+            if outs[True].tokens[q, step].item() != r.sequences[0, ids[q].numel() + step].item():
+                break
+    assert checked >= 2

@@ -125,7 +125,24 @@ def test_shared_storage_keeps_the_hf_forward_intact_and_adds_no_second_copy(mode
     with torch.no_grad():
         after = model(input_ids=ids, images=img).logits
     assert torch.equal(before, after)
+    assert not lay.self_attn.k_proj.weight.data.is_contiguous() or lay.self_attn.k_proj.weight.data.storage_offset() != 0
     detach_engine(model)
+    # detach gives every re-pointed parameter its own contiguous storage back (save_pretrained / safetensors refuse slices
+    # that share one storage), with the same values; a model whose parameters moved after attach is refused, not decoded stale
+    for p in (lay.self_attn.q_proj.weight, lay.self_attn.k_proj.weight, lay.self_attn.v_proj.weight, lay.mlp.gate_proj.weight, lay.mlp.up_proj.weight):
+        assert p.data.is_contiguous() and p.data.storage_offset() == 0
+    assert lay.self_attn.k_proj.weight.data_ptr() != eng.w.t["l0.wqkv"][nq:].data_ptr() and "_vdd_shared" not in model.__dict__
+    with torch.no_grad():
+        assert torch.equal(model(input_ids=ids, images=img).logits, before)
+    attach_engine(model, share_storage=False)
+    old = model.lm_head.weight.data
+    try:
+        model.lm_head.weight.data = old.clone()
+        with pytest.raises(RuntimeError, match="attach_engine"):
+            model.generate(ids, images=img, max_new_tokens=1)
+    finally:
+        model.lm_head.weight.data = old
+        detach_engine(model)
 
 
 def test_hf_defaults_and_overrides_are_resolved_like_generate(model):

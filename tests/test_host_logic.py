@@ -158,3 +158,37 @@ def test_norm_fused_row_limit_follows_the_lds_budget():
     kernel's chunk map does not cover (d % 256, d > 8192) take the unfused layer."""
     from llava_align_amd import ops
     assert [ops.norm_fused_rows(d) for d in (4096, 5120, 8192, 2048, 16384, 4000)] == [16, 14, 8, 16, 0, 0]
+
+
+def test_in_tree_gemm_defaults_are_bound_to_the_kernel_source():
+    """ADVICE r4: gemm_choices_mi355x.json carries the hash of the GEMM kernel SOURCE it was measured on (ops.gemm_source_fingerprint);
+    a kernel edit without re-measuring (or re-stamping) the defaults fails here instead of silently shipping stale picks."""
+    import json
+    import os
+    from llava_align_amd import ops
+    pkg = os.path.dirname(os.path.abspath(ops.__file__))
+    doc = json.load(open(os.path.join(pkg, "gemm_choices_mi355x.json")))
+    assert doc["gemm_source_sha"] == ops.gemm_source_fingerprint() != ""
+
+
+def test_tuner_cache_merges_under_the_lock(tmp_path, monkeypatch):
+    """Two writers (ranks of one node) append different shapes: read - merge - replace under the advisory lock keeps both."""
+    import json
+    from llava_align_amd import ops
+    path = str(tmp_path / "choices.json")
+    monkeypatch.setitem(ops._persist, "path", path)
+    monkeypatch.setitem(ops._persist, "section", "dev|abc")
+    saved = dict(ops._gemm_choice)
+    try:
+        with ops._CacheLock():
+            ops._store_persisted((1, 4096, 4096, 0, False, 2), 40)
+        with ops._CacheLock():
+            ops._store_persisted((2, 4096, 4096, 0, False, 2), 42)
+        doc = json.load(open(path))
+        assert doc["dev|abc"] == {"1,4096,4096,0,False,2": 40, "2,4096,4096,0,False,2": 42}
+        ops._gemm_choice.clear()
+        ops._read_cache_section()
+        assert ops._gemm_choice[(1, 4096, 4096, 0, False, 2)] == 40 and ops._gemm_choice[(2, 4096, 4096, 0, False, 2)] == 42
+    finally:
+        ops._gemm_choice.clear()
+        ops._gemm_choice.update(saved)
