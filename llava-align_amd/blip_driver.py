@@ -42,10 +42,12 @@ def run_blip_pope(engine: VddLlavaEngine, front: InstructBlipFrontEnd, questions
                   tokenize_llm: Callable[[str], List[int]], tokenize_qformer: Callable[[str], List[int]],
                   decode: Callable[[List[int]], str], load_image: Callable[[str], torch.Tensor], answers_path: Optional[str] = None,
                   batch_questions: int = 128, use_cd: bool = False, noise_step: int = 500, cd_beta: Optional[float] = 0.1,
-                  cd_alpha: Optional[float] = None, top_p: float = 1.0, temperature: float = 1.0, repetition_penalty: float = 1.0,
+                  cd_alpha: Optional[float] = None, top_p: float = 1.0, top_k: Optional[int] = 50, temperature: float = 1.0,
+                  repetition_penalty: float = 1.0,
                   max_length: int = 256, min_length: int = 1, eos_token_id=2, pad_token_id: Optional[int] = 2,
                   model_id: str = "instruct_blip", rank: Optional[int] = None, world: Optional[int] = None, **generate_kw) -> dict:
     """questions: POPE json lines (question_id, image, text[, label]).  Defaults are the reference driver's: top_p 1, temperature 1,
+    top_k 50 (LAVIS never passes top_k, so HF's GenerationConfig default warps every sampled step: blip2_vicuna_instruct.py:390-410),
     repetition_penalty 1, max_length 256, min_length 1, cd_alpha left at the sampler's default (None -> 0.5), noise_step 500.
     generate_kw: seed, cd_greedy, sync_every ...  rank / world (default: the initialised torch.distributed group): every rank decodes
     its chunk of whole images (shard.ShardPlan; BASELINE config #5 runs on 4 GPUs), ONE collective gathers the results, rank 0 writes
@@ -61,7 +63,7 @@ def run_blip_pope(engine: VddLlavaEngine, front: InstructBlipFrontEnd, questions
     decode_token = lambda t: decode([t])
     embed = engine.w.t["embed"]
     eos_set = set([eos_token_id] if isinstance(eos_token_id, int) else (eos_token_id or []))
-    base_kw = dict(do_sample=True, top_p=top_p, temperature=temperature, num_beams=1, repetition_penalty=repetition_penalty,
+    base_kw = dict(do_sample=True, top_p=top_p, top_k=top_k, temperature=temperature, num_beams=1, repetition_penalty=repetition_penalty,
                    min_length=min_length, eos_token_id=eos_token_id, pad_token_id=pad_token_id, n_top=10, cd_beta=cd_beta,
                    cd_alpha=cd_alpha, **generate_kw)
     rows = ResultRows(engine.device, max_length, pad_token_id if pad_token_id is not None else 0, n_sets=3)

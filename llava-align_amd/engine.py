@@ -894,6 +894,9 @@ class VddLlavaEngine:
 
     def image_features(self, images: Sequence[torch.Tensor], keys: Optional[Sequence[int]] = None) -> List[torch.Tensor]:
         """ViT + projector per DISTINCT image (POPE: 6 questions share one image)."""
+        if "v.patch" not in self.w.t:
+            raise ValueError("this engine was built from a language model only (hf_adapter.attach_lm_engine / attach_blip_engine / "
+                             "attach_qwen_engine): it takes inputs_embeds or text ids, not images")
         if keys is not None:                     # caller-supplied identities: cache persists across generate() calls
             keys, cache = list(keys), self._feat_cache
         else:                                    # same storage within this call = same image
