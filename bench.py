@@ -23,9 +23,12 @@ Extra objects on the line:
   decode_step   measured ms per decode step of the engine vs the weight-streaming floor
   cpu_baseline  the reference path on the host CPU: config #1 end to end on the toy LM (value), the sampling tail
                 with a stubbed forward (ms/step, comparable with BASELINE.md §2), and a bounded LLaVA-7B sample
-  eager_gpu     the reference path on this GPU: oracle restatement of the patched sample() over tests/ref_llava.py, this repo's
-                plain-torch LLaVA (checked against HF modules on CPU, tests/test_hf_architecture.py) - B=1, one eager forward per
-                branch per token, cat-grown KV, attention maps materialised
+  eager_gpu     the reference path on this GPU: the oracle restatement of the patched sample() over HF's OWN eager stack - the installed
+                transformers' LlamaForCausalLM + CLIPVisionModel composed like LlavaLlamaForCausalLM (tests/hf_llava.py), 7B widths, 32 + 24
+                layers, fp16 (builder.py:40), eager attention with output_attentions=True (llava_calibrate.py:175) - B=1, one forward
+                per branch per token; `dropin_gpu` = this package's sample() over the same object
+  eager_gpu_port / dropin_gpu_port   the same two over tests/ref_llava.py (this repo's plain-torch LLaVA, bf16): the comparator of
+                rounds 1 - 4, kept for continuity
 """
 from __future__ import annotations
 
@@ -217,6 +220,60 @@ def bench_eager_gpu(eng, dev, n_q=2, n_new=N_NEW):
                     "this repo's own plain-torch model, checked against HF Llama / CLIP modules on CPU, not HF Llama itself): B=1, "
                     "one forward per branch per token, KV grown by torch.cat, attention maps materialised",
             "sample": f"{n_q} questions x {n_new} new tokens in {dt:.1f}s"}
+
+
+def _hf_reference_stack(dev):
+    """What `load_pretrained_model` hands the reference's scripts, minus the checkpoint (tests/hf_llava.py): the INSTALLED transformers'
+    LlamaForCausalLM + CLIPVisionModel composed like LlavaLlamaForCausalLM, LLaVA-1.5-7B widths, 32 + 24 layers, fp16 (builder.py:40),
+    eager attention (the reference era's LlamaAttention materialised its maps; llava_calibrate.py:175 asks for them)."""
+    import torch
+    import hf_llava
+    return hf_llava.build(dev, torch.float16, d=4096, layers=32, heads=32, ffn=11008, vocab=32000, clip_width=1024, clip_layers=24, clip_heads=16,
+                          clip_mlp=4096, image=336, patch=14, max_pos=4096, lm_head_gain=4.0, attn_implementation="eager")
+
+
+def bench_hf_gpu(dev, n_q=2, n_new=N_NEW):
+    """`eager_gpu` / `dropin_gpu` on HF's own eager stack in the reference's dtype: (a) the oracle restatement of the
+    reference's patched sample() - B = 1, one forward per branch per token, attention maps materialised, tail on the logits as the loop
+    reads them; (b) this package's drop-in sample() over the same object (fused HIP tail, logits stay on the device)."""
+    import torch
+    import transformers
+    import hf_llava
+    from oracle import vdd_oracle as O
+    from llava_align_amd import sample
+    m = _hf_reference_stack(dev)
+    ids, imgs = pope_prompts(1, per_img=n_q, seed=99)
+
+    def eager(q, n):
+        proto = hf_llava.HfProto(m, output_attentions=True)
+        kw = dict(images=imgs[q][None], attention_mask=torch.ones(1, ids[q].numel(), dtype=torch.long), use_cache=True, cd_alpha=1.0, cd_beta=0.1,
+                  use_dd_unk=True)
+        torch.cuda.synchronize(); t0 = time.perf_counter()
+        O.reference_loop(proto, ids[q][None].clone(), warp=O.WarpConfig(temperature=0.2), max_length=ids[q].numel() + n, pad_token_id=None,
+                         eos_token_id=None, pick=O.pick_multinomial, **kw)
+        torch.cuda.synchronize(); return time.perf_counter() - t0
+
+    def dropin(q, n):
+        proto = hf_llava.HfProto(m, output_attentions=True, logits_on_device=True)
+        ids_d = ids[q][None].to(dev)
+        kw = dict(images=imgs[q][None], attention_mask=torch.ones(1, ids[q].numel(), dtype=torch.long, device=dev), use_cache=True, cd_alpha=1.0,
+                  cd_beta=0.1, use_dd_unk=True)
+        crit = transformers.StoppingCriteriaList([transformers.MaxLengthCriteria(max_length=ids[q].numel() + n)])
+        warp = transformers.LogitsProcessorList([transformers.TemperatureLogitsWarper(0.2)])
+        torch.cuda.synchronize(); t0 = time.perf_counter()
+        sample(proto, ids_d, logits_warper=warp, stopping_criteria=crit, **kw)
+        torch.cuda.synchronize(); return time.perf_counter() - t0
+    eager(0, 2); dropin(0, 2)
+    te = sum(eager(q, n_new) for q in range(n_q))
+    td = sum(dropin(q, n_new) for q in range(n_q))
+    del m
+    torch.cuda.empty_cache()
+    what = ("installed transformers' LlamaForCausalLM + CLIPVisionModel composed like LlavaLlamaForCausalLM (tests/hf_llava.py), LLaVA-1.5-7B widths, "
+            "32 + 24 layers, fp16, eager attention with output_attentions=True as llava_calibrate.py:175 passes it; B = 1, use_dd_unk")
+    return ({"value": round(n_q * n_new / te, 2), "unit": "tokens/s", "kind": "reference stack (HF eager) + oracle restatement of the patched sample()",
+             "what": what, "sample": f"{n_q} questions x {n_new} new tokens in {te:.1f}s"},
+            {"value": round(n_q * n_new / td, 2), "unit": "tokens/s", "what": "this package's drop-in sample() over the same HF object: " + what,
+             "sample": f"{n_q} questions x {n_new} new tokens in {td:.1f}s"})
 
 
 def bench_cpu(eng):
@@ -529,8 +586,10 @@ def main():
             t2 = time.perf_counter(); eng.generate(ids1, **kw1); torch.cuda.synchronize(dev); t_b1 = time.perf_counter() - t2
             line["single_question"] = {"tokens_per_s": round(N_NEW / t_b1, 1), "ms_per_token": round(t_b1 / N_NEW * 1e3, 2),
                                        "note": "B=1 (2 rows: main + <unk> branch), prefill + 64 tokens, HIP-graph decode"}
-            line["eager_gpu"] = bench_eager_gpu(eng, dev)
-            line["dropin_gpu"] = bench_dropin_gpu(eng, dev)
+            # the >= 6x comparator (north_star): HF's own eager stack in the reference's dtype; the repo's plain-torch port stays beside it
+            line["eager_gpu"], line["dropin_gpu"] = bench_hf_gpu(dev)
+            line["eager_gpu_port"] = bench_eager_gpu(eng, dev)
+            line["dropin_gpu_port"] = bench_dropin_gpu(eng, dev)
             line["speedup_vs_eager_gpu"] = round(line["value"] / line["eager_gpu"]["value"], 1)
             line["speedup_vs_eager_gpu_single_question"] = round(line["single_question"]["tokens_per_s"] / line["eager_gpu"]["value"], 1)
             line["cpu_baseline"] = bench_cpu(eng)

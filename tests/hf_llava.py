@@ -73,16 +73,61 @@ class HfLlava(LlamaForCausalLM):
         return d
 
 
+class HfProto:
+    """The 4.31-era GenerationMixin hooks the reference's sample() calls (vcd_sample.py:106-114,150,161,266-277; llava_llama.py:130-174),
+    over an HfLlava: lets oracle.reference_loop - the restatement of the reference's OWN loop - and this package's drop-in `sample()`
+    drive the installed transformers' eager Llama + CLIP stack exactly like the reference's scripts drive LlavaLlamaForCausalLM
+    (bench.py `eager_gpu` / `dropin_gpu`).  output_attentions as the driver passes it (llava_calibrate.py:175): with the eager attention
+    implementation every layer materialises its [1, H, T, S] map, as the reference era's LlamaAttention always did."""
+
+    def __init__(self, model, output_attentions=True, logits_on_device=False):
+        from types import SimpleNamespace
+        self.m, self.attn, self.on_dev = model, output_attentions, logits_on_device
+        self.config = SimpleNamespace(is_encoder_decoder=False)
+        self.generation_config = model.generation_config
+        self.device = model.lm_head.weight.device
+
+    def prepare_inputs_for_generation(self, input_ids, past_key_values=None, attention_mask=None, inputs_embeds=None, **kw):
+        if past_key_values:
+            input_ids = input_ids[:, -1:]
+        return {"input_ids": input_ids, "past_key_values": past_key_values, "use_cache": kw.get("use_cache"), "attention_mask": attention_mask,
+                "images": kw.get("images", None)}
+
+    def prepare_inputs_for_generation_cd(self, input_ids, past_key_values=None, attention_mask=None, inputs_embeds=None, **kw):
+        d = self.prepare_inputs_for_generation(input_ids, past_key_values=past_key_values, attention_mask=attention_mask, **kw)
+        d["images"] = kw.get("images_cd", None)                                                   # llava_llama.py:170
+        return d
+
+    def _update_model_kwargs_for_generation(self, outputs, model_kwargs, is_encoder_decoder=False, **_):
+        model_kwargs["past_key_values"] = outputs.past_key_values
+        am = model_kwargs.get("attention_mask")
+        if am is not None:
+            model_kwargs["attention_mask"] = torch.cat([am, am.new_ones((am.shape[0], 1))], dim=-1)
+        return model_kwargs
+
+    @torch.no_grad()
+    def __call__(self, input_ids=None, attention_mask=None, past_key_values=None, use_cache=None, images=None, return_dict=True,
+                 output_attentions=None, output_hidden_states=None, **_):
+        from types import SimpleNamespace
+        dev = self.device
+        out = self.m(input_ids=input_ids.to(dev), past_key_values=past_key_values, use_cache=True,
+                     images=images.to(dev, self.m.dtype) if images is not None else None, output_attentions=self.attn)
+        logits = out.logits if self.on_dev else out.logits.cpu()
+        return SimpleNamespace(logits=logits, past_key_values=out.past_key_values, attentions=out.attentions, hidden_states=None)
+
+
 def build(device, dtype, d=256, layers=2, heads=2, ffn=512, vocab=1000, clip_width=128, clip_layers=3, clip_heads=2, clip_mlp=256,
-          image=56, patch=14, max_pos=512, lm_head_gain=6.0, seed=0):
+          image=56, patch=14, max_pos=512, lm_head_gain=6.0, seed=0, attn_implementation=None):
     """Random-init model on `device` in `dtype`.  Defaults = the engine's 'tiny' preset; 7B widths: d 4096, heads 32, ffn 11008,
     vocab 32000, clip 1024 / 16 heads / mlp 4096 / image 336."""
     torch.manual_seed(seed)
     cfg = LlamaConfig(vocab_size=vocab, hidden_size=d, intermediate_size=ffn, num_hidden_layers=layers, num_attention_heads=heads,
                       num_key_value_heads=heads, head_dim=d // heads, rms_norm_eps=1e-5, max_position_embeddings=max_pos,
-                      attention_bias=False, mlp_bias=False, tie_word_embeddings=False, pad_token_id=0, eos_token_id=None, bos_token_id=1)
+                      attention_bias=False, mlp_bias=False, tie_word_embeddings=False, pad_token_id=0, eos_token_id=None, bos_token_id=1,
+                      **({"attn_implementation": attn_implementation} if attn_implementation else {}))
     ccfg = CLIPVisionConfig(hidden_size=clip_width, intermediate_size=clip_mlp, num_hidden_layers=clip_layers, num_attention_heads=clip_heads,
-                            image_size=image, patch_size=patch, hidden_act="quick_gelu", layer_norm_eps=1e-5)
+                            image_size=image, patch_size=patch, hidden_act="quick_gelu", layer_norm_eps=1e-5,
+                            **({"attn_implementation": attn_implementation} if attn_implementation else {}))
     with torch.device(device):
         m = HfLlava(cfg, ccfg)
     with torch.no_grad():
