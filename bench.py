@@ -276,6 +276,42 @@ def bench_hf_gpu(dev, n_q=2, n_new=N_NEW):
              "sample": f"{n_q} questions x {n_new} new tokens in {td:.1f}s"})
 
 
+def bench_llava_bench_eos(eng, dev, n_q=90, max_new=512, n_eos=250):
+    """BASELINE config #3's call shape on this GPU's engine (llava_sampling.py:100-116: open-ended answers, use_dd + use_dd_unk, top-p 0.9;
+    one image per question, so no shared image prefixes): answer lengths geometric (a random EOS set: ~0.8 % per step, capped at max_new),
+    with and without row retirement + growing own-KV pools (VddLlavaEngine.retire).  tokens/s counts answer tokens only."""
+    import numpy as np
+    import torch
+    ids, imgs = pope_prompts(n_q, per_img=1, seed=777)
+    imgs = [im.to(dev).to(eng.dtype) for im in imgs]
+    eos = sorted(set(np.random.default_rng(5).integers(3, eng.cfg.lm.vocab, size=n_eos).tolist()))
+    kw = dict(images=imgs, use_dd=True, use_dd_unk=True, cd_alpha=1.0, cd_beta=0.1, temperature=1.0, top_p=0.9, max_new_tokens=max_new,
+              eos_token_id=eos, pad_token_id=0, seed=11, sync_every=8)
+    eos_t = torch.tensor(eos, device=dev)
+    out = {}
+    for name, on in (("static", False), ("retire", True)):
+        eng._kvs.clear(); eng._graphs.clear(); eng._kv = None
+        torch.cuda.empty_cache()
+        eng.retire = on
+        torch.cuda.reset_peak_memory_stats(dev)                                   # (peak over warm-up + timed call: the pools of the two are the same)
+        eng.generate(ids, **kw)                                                    # warm-up: tuner picks, graph capture paths
+        torch.cuda.synchronize(dev)
+        t0 = time.perf_counter(); o = eng.generate(ids, **kw); torch.cuda.synchronize(dev); dt = time.perf_counter() - t0
+        is_eos = (o.tokens[:, :, None] == eos_t).any(-1)
+        lens = torch.where(is_eos.any(1), is_eos.float().argmax(1) + 1, torch.full((n_q,), o.tokens.shape[1], device=dev)).float()
+        out[name] = {"tokens_per_s": round(float(lens.sum()) / dt, 1), "seconds": round(dt, 2), "decode_steps": int(o.tokens.shape[1]),
+                     "mean_answer_tokens": round(float(lens.mean()), 1), "max_answer_tokens": int(lens.max()),
+                     "hbm_peak_GB": round(torch.cuda.max_memory_allocated(dev) / 1e9, 1),
+                     **({"retire_events": o.stats["retire_events"], "rows_at_end": o.stats["rows_at_end"]} if on else {})}
+    eng.retire = True
+    eng._kvs.clear(); eng._graphs.clear(); eng._kv = None
+    torch.cuda.empty_cache()
+    out["speedup"] = round(out["retire"]["tokens_per_s"] / out["static"]["tokens_per_s"], 2)
+    out["workload"] = (f"{n_q} questions x 3 branches (use_dd + use_dd_unk) = {3 * n_q} rows, one image each, top-p 0.9, T = 1, max_new_tokens {max_new}, "
+                       f"{len(eos)} random EOS ids (sampled runs: the two legs draw different random streams, so their length samples differ slightly)")
+    return out
+
+
 def bench_cpu(eng):
     """SURVEY §8(d) CPU comparators, all fully measured on this host:
     (b) BASELINE config #1 end to end - 32 POPE-like questions, B=1, use_dd, top-k 1, 8 new tokens, toy LM with V = 32000 - through
@@ -593,6 +629,7 @@ def main():
             line["speedup_vs_eager_gpu"] = round(line["value"] / line["eager_gpu"]["value"], 1)
             line["speedup_vs_eager_gpu_single_question"] = round(line["single_question"]["tokens_per_s"] / line["eager_gpu"]["value"], 1)
             line["cpu_baseline"] = bench_cpu(eng)
+            line["llava_bench_eos"] = bench_llava_bench_eos(eng, dev)
             # the same workload in the reference's own dtype (fp16: builder.py:40; config #2 - the headline - says bf16): the bf16 engine
             # and its KV pools go first (two engines do not fit 288 GB at 768 questions)
             del eng, out, oe, o2

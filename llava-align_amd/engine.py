@@ -363,6 +363,25 @@ class KVCache:
     def fits(self, n_pre, t_pre, n_own, t_own, frag_only):
         return (frag_only == self.frag_only and n_pre <= self.n_pre and t_pre <= self.t_pre and n_own <= self.n_own and t_own <= self.t_own)
 
+    def repack_own(self, keep_slots: torch.Tensor, live_len: int, t_own: int):
+        """Row retirement / growth of the own pools: keep the slots `keep_slots` (int64 device tensor, in their new order: old slot
+        keep_slots[i] becomes slot i), with room for `t_own` own tokens each; the first `live_len` rows of every kept slot are
+        copied.  One layer at a time (the old tensor of a layer is released before the next layer's new one is allocated), so the
+        peak is the new pools + one layer of the old ones.  Tensors change address: captured steps over this cache are stale."""
+        t_own = (max(t_own, 64) + 15) // 16 * 16
+        n = int(keep_slots.numel())
+        live = min(live_len, self.t_own, t_own)
+        for pool in (self.ko, self.vo):
+            for i in range(len(pool)):
+                old = pool[i]
+                new = torch.empty((max(n, 1), old.shape[1], t_own, old.shape[3]), dtype=old.dtype, device=old.device)
+                if n and live:
+                    new[:n, :, :live].copy_(old[:, :, :live].index_select(0, keep_slots))
+                pool[i] = new
+                del old
+        self.n_own, self.t_own = max(n, 1), t_own
+        self.__dict__.pop("_persist", None)
+
     def nbytes(self):
         seen, total = set(), 0
         for pool in (self.kp, self.vp, self.pfrag, self.ko, self.vo):
@@ -762,6 +781,23 @@ class _DecodeRunner:
         self.step_idx.fill_(1)
         self.ctr += 1
 
+    def adopt(self, old: "_DecodeRunner", q_idx: torch.Tensor, n_new: int):
+        """Continue `old`'s decoding with the questions q_idx (int64 device tensor, ascending) only: their rows (branch-major in both
+        runners) take the slots 0 .. len - 1 of the repacked own pools, in row order.  Device -> device, no sync."""
+        Qo, Qn, nb = old.Q, self.Q, self.nb
+        rows_idx = torch.cat([q_idx + b * Qo for b in range(nb)])
+        self.pos.copy_(old.pos[rows_idx]); self.cpos.copy_(old.cpos[rows_idx])
+        self.rows.copy_(old.rows[rows_idx])
+        new_slot = torch.arange(nb * Qn, dtype=torch.int32, device=self.pos.device)
+        self.slot.copy_(new_slot)
+        self.rows[:, 0] = new_slot
+        self.tok.copy_(old.tok[q_idx])
+        self.unfinished.copy_(old.unfinished[q_idx])
+        self.gen[:, :n_new] = old.gen[q_idx, :n_new]
+        self.step_idx.copy_(old.step_idx); self.ctr.copy_(old.ctr)
+        self.status.copy_(old.status[q_idx]); self.status0.copy_(old.status0[q_idx])
+        return old.slot[rows_idx].long()                           # the old slots of the kept rows, in the new slot order
+
     def body(self, kv):
         t, Q, nb = self.tail, self.Q, self.nb
         self.tokens_rows.view(nb, Q).copy_(self.tok[None].expand(nb, Q))        # same new token for every branch of a question
@@ -848,6 +884,12 @@ class VddLlavaEngine:
         self.vit.use_graph = use_graph
         self.lm = LanguageModel(self.w)
         self.max_q, self.t_max, self.use_graph = max_questions, t_max, use_graph
+        # Open-ended answers (LLaVA-Bench: 20 - 1,000 tokens, llava_sampling.py:100-116): rows that emitted EOS leave the batch at the
+        # next host check once half of it is done (a re-captured step costs ~0.2 s: tools, bench `llava_bench_eos`), and the own KV pools start at `kv_chunk` new tokens per row and grow by half
+        # when the longest live row gets near the end - instead of n_rows x (suffix + max_new_tokens) up front and a batch that decodes
+        # at full width until its slowest member stops.  (retire=False: the static form.)
+        self.retire, self.retire_fraction, self.kv_chunk = True, 0.5, 128
+        self.retire_min_rows = 0          # > 0: no retirement below this many live rows (the pools still grow)
         # decode attention reads each shared prompt prefix once per GROUP of rows (K/V tiles staged in LDS)
         self.group_attention = True
         self._kv: Optional[KVCache] = None          # the pools of the most recent call
@@ -1108,8 +1150,14 @@ class VddLlavaEngine:
         if grp and (not grouping_pays(grp, dec_rows) or (len(dec_rows) <= ops.FUSED_ATTN_MAX_M and lm.head_dim == 128)):
             grp = []      # (up to 16 rows the one-launch RoPE + KV write + attention kernel beats the three launches of the grouped
                           #  path although it reads a shared prefix once per row: tools/small_batch_attn_probe.py, +4 ... 9 %)
+        # retirement / growth of the own pools needs an EOS to retire on, per-question state that lives only in the runner's row order
+        # (no processor stage, no per-step scores rows, no streamer) and the ungrouped attention (slots are renumbered)
+        suffix_max = max(s_["T"] for s_ in plan["suffix"])
+        retire = bool(self.retire and eos_token_id is not None and not output_scores and streamer is None and not proc and not grp
+                      and max_new_tokens > self.kv_chunk)
+        own_cap = min(max_new_tokens, self.kv_chunk) if retire else max_new_tokens
         kv = self.kv(len(plan["prefix"]), max([s_["T"] for s_ in plan["prefix"]] + [0]), len(plan["suffix"]),
-                     max(s_["T"] for s_ in plan["suffix"]) + max_new_tokens, frag_only=bool(grp))
+                     suffix_max + own_cap, frag_only=bool(grp))
         if plan["max_len"] + max_new_tokens > self.cfg.lm.max_pos:
             raise ValueError(f"prompt ({plan['max_len']} positions) + max_new_tokens ({max_new_tokens}) exceed the rotary table "
                              f"(max_pos = {self.cfg.lm.max_pos}): lower max_new_tokens or build the engine with a larger LMConfig.max_pos")
@@ -1184,6 +1232,12 @@ class VddLlavaEngine:
         run.load(pos=[seg[i]["pos0"] + seg[i]["T"] for i in sel], cpos=[seg[i]["T"] for i in sel], slot=[seg[i]["slot"] for i in sel],
                  rows=dec_rows)
         n_new = 1
+        # retirement state: `alive` = the original question index of every question still in the runner; `master` collects the tokens
+        alive = list(range(Q))
+        master = None
+        if retire:
+            master = torch.full((Q, max_new_tokens), pad_token_id if pad_token_id is not None else 0, dtype=torch.long, device=dev)
+            stats.update(retire_events=0, rows_at_end=nb * Q, own_capacity=kv.t_own - suffix_max)
         if streamer is not None:
             if inputs_embeds is None:
                 streamer.put(torch.tensor([ids_list[0]], dtype=torch.long))
@@ -1212,6 +1266,38 @@ class VddLlavaEngine:
             # the "everybody finished" test costs a host sync: every sync_every steps, and at steps 2 and 4 on the way there (POPE answers
             # are 1-2 tokens: waiting for step 8 would run six decode steps for nobody)
             if eos_t is not None and (n_new % sync_every == 0 or n_new == max_new_tokens or (n_new in (2, 4) and n_new < sync_every)):
+                if retire:
+                    state = torch.cat([run.unfinished, (run.status | run.status0).ne(0).any().long()[None]]).tolist()    # ONE sync
+                    unf, bad = state[:-1], state[-1]
+                    if bad or not any(unf):
+                        break
+                    live_q = [j for j, u in enumerate(unf) if u]
+                    own_len = suffix_max + n_new                                         # own rows of the longest live slot (an upper bound)
+                    grow = own_len + sync_every + 1 > kv.t_own and n_new < max_new_tokens
+                    shrink = len(live_q) <= self.retire_fraction * len(unf) and run.nb * len(live_q) >= self.retire_min_rows
+                    if not shrink:
+                        live_q = list(range(len(unf)))                                  # growth only: everybody stays
+                    if n_new < max_new_tokens and (grow or shrink):
+                        # finished questions leave: their tokens go to `master`, the live rows move to the front of new own pools
+                        idx_all = torch.tensor(alive, dtype=torch.long, device=dev)
+                        master[idx_all, :n_new] = run.gen[:, :n_new]
+                        q_idx = torch.tensor(live_q, dtype=torch.long, device=dev)
+                        cap = kv.t_own - suffix_max
+                        if grow:
+                            cap = min(max_new_tokens, max(cap + cap // 2, n_new + 2 * sync_every + 2))
+                        Qn = len(live_q)
+                        self._graphs = {k_: r_ for k_, r_ in self._graphs.items() if r_.kv is not kv}    # captured steps point into the old pools
+                        new_run = _DecodeRunner(self, Qn, run.nb, max_new_tokens, dict(run.tail), kv)
+                        old_slots = new_run.adopt(run, q_idx, n_new)
+                        kv.repack_own(old_slots, own_len, suffix_max + cap)
+                        new_run.workspace = ops.attention_workspace(run.nb * Qn, lm.n_heads, lm.head_dim, kv.t_pre + (kv.t_own + 63) // 64 * 64, dev)
+                        self._graphs[cfgkey + ("retired", Qn, kv.t_own, stats["retire_events"])] = new_run
+                        alive = [alive[j] for j in live_q]
+                        run = new_run
+                        stats["retire_events"] += 1
+                        stats.setdefault("retire_log", []).append((n_new, run.nb * Qn, cap))
+                        stats["rows_at_end"], stats["own_capacity"] = run.nb * Qn, cap
+                    continue
                 done_bad = torch.stack([run.unfinished.max() == 0, (run.status | run.status0).ne(0).any()]).tolist()   # ONE sync
                 if done_bad[1]:                                 # a row lost every finite score: stop decoding from token -1
                     break
@@ -1225,7 +1311,13 @@ class VddLlavaEngine:
             raise RuntimeError("probability tensor contains either `inf`, `nan` or element < 0")   # torch.multinomial, :202
         if streamer is not None:
             streamer.end()
-        gen = run.gen[:, :n_new].clone()
+        if retire:
+            master[torch.tensor(alive, dtype=torch.long, device=dev), :n_new] = run.gen[:, :n_new]
+            gen = master[:, :n_new].clone()
+            if run.Q != Q:                                     # the pools (and the last runner) are those of the survivors only
+                self._graphs = {k_: r_ for k_, r_ in self._graphs.items() if r_.kv is not kv}
+        else:
+            gen = run.gen[:, :n_new].clone()
         if eos_t is not None:
             gen = self._trim_after_all_finished(gen, eos_t, pad_token_id)
             if scores is not None:
