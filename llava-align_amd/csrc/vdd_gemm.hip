@@ -38,6 +38,7 @@
 
 #include <hip/hip_runtime.h>
 #include <stdint.h>
+#include <stdlib.h>
 
 #include <type_traits>
 
@@ -716,6 +717,10 @@ int num_workgroups() {
         if (hipGetDevice(&dev) != hipSuccess || hipDeviceGetAttribute(&n, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess || n <= 0) n = 256;
         g_num_cu = n & ~7;       // one workgroup per CU, a multiple of the 8 XCDs
         if (g_num_cu < 8) g_num_cu = 8;
+#ifdef VDD_PROBE_BUILD
+        // tools/overlap_cu_probe.py: a persistent grid of P < #CUs workgroups on a CU-masked stream (the rest of the chip runs attention)
+        if (const char* e = getenv("VDD_PROBE_GEMM_WORKGROUPS")) { const int v = atoi(e); if (v >= 8 && v <= g_num_cu) g_num_cu = v & ~7; }
+#endif
     }
     return g_num_cu;
 }
