@@ -149,10 +149,8 @@ struct ToppScratch { float gx[TOPP_EXACT_MAX]; int gi[TOPP_EXACT_MAX]; float sp[
 // contrasted chunk out.  448 entries keep three 32000-wide bf16 rows per CU (40 KiB LDS row part + Smem + the list each).
 constexpr int LIVE_CAP = 448;
 struct LiveList { uint4 data[LIVE_CAP]; int ch[LIVE_CAP]; };
-#ifndef VDD_DEBUG_NO_FAST_TAIL
-#define VDD_DEBUG_NO_FAST_TAIL 0          // probe builds: every row takes the block-wide tail (what does that tail cost by itself?)
-#endif
-constexpr int FAST_TAIL_MAX = VDD_DEBUG_NO_FAST_TAIL ? 0 : 64;       // candidates the single-wave tail holds (one per lane)
+constexpr int FAST_TAIL_MAX = 64;       // candidates the single-wave tail holds (one per lane); 0 sends every row through the block-wide tail
+                                         // (how round 4 priced that tail: +7 us per launch on one-survivor rows, DESIGN_APPENDIX.md)
 constexpr int TOPK_LIST_MAX = 1024;      // ordered keys of the top-k candidate list (same scratch region)
 static_assert(TOPK_LIST_MAX * 4 <= (int)sizeof(LiveList), "");
 

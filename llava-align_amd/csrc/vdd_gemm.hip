@@ -44,25 +44,6 @@
 
 #include "vdd_elem.h"
 
-#ifndef VDD_GEMM_W_AUX
-#define VDD_GEMM_W_AUX 0          // cache policy bits of the W LDS-DMA (probe builds: 2 = nt: 1 - 3 % slower at the 1,536-row decode batch, eight workgroups share every W tile)
-#endif
-#ifndef VDD_GEMM_SNAKE
-#define VDD_GEMM_SNAKE 2
-#endif
-#ifndef VDD_GEMM_W_AHEAD
-#define VDD_GEMM_W_AHEAD 1
-#endif
-#ifndef VDD_GEMM_DMA_SPACING
-#define VDD_GEMM_DMA_SPACING 1
-#endif
-#ifndef VDD_GEMM_STREAM_SIMPLE
-#define VDD_GEMM_STREAM_SIMPLE 0
-#endif
-#ifndef VDD_GEMM_SPLIT_STAGE
-#define VDD_GEMM_SPLIT_STAGE 1
-#endif
-
 namespace {
 namespace VDD_ELEM_NS {
 using namespace vdd_elem;
@@ -93,10 +74,6 @@ struct GemmArgs {
     int stage_out;               // Y rows are 16-byte aligned: the epilogue may store whole rows out of LDS
     float* slabs;                // split-K slab mode (slab_S > 0): fp32 partial products [slab_S][M][N], one (tile, K part) per workgroup, no
     int slab_S;                  // fix-up - the consumer (vdd_rmsnorm's delta_slabs) adds the slabs
-#ifdef VDD_GEMM_ABLATE
-    int ablate;                  // probe builds only (tools/gemm_ablate_probe.py): bit 0 no X LDS-DMA after the first tiles, 1 no W LDS-DMA,
-                                 // 2 no W fragment reads, 3 no X fragment reads, 4 no barriers - WRONG results, timing of what is left
-#endif
 };
 
 // K-tile buffers of a tile shape.  Two for the compute-bound shapes (tile t + 1 lands under the MFMAs of tile t).  The shapes the
@@ -122,13 +99,9 @@ __global__ void __launch_bounds__(WM * WN * 64) gemm_kernel(const GemmArgs a) {
     constexpr int BUF = (BM + BN) * 128;                   // bytes of one K-tile buffer
     constexpr int NSTG = gemm_stages(BM, BN, WM, WN);      // K-tile buffers (> 2: a W stream, see the K pipeline below)
     constexpr int NMMA = NI * MI, NRD = NI + MI, NLD = XJ + WJ;
-#if defined(VDD_GEMM_ABLATE)
-    constexpr bool WAHEAD = false;
-#else
     // (the 192 x 256 tile of the decode batch only: down-projection 134 -> 120 us, o 57 -> 53 on cold weights; the 256 x 256 tile lost 5 - 12 % with it
     //  at 1,536 rows - 13 more spilled registers at the cliff - and gained nothing at prefill size, where the panels are L2 hits)
-    constexpr bool WAHEAD = VDD_GEMM_W_AHEAD && NSTG == 2 && gemm_staging_bytes(BN, WM, WN) >= BN * 128 && BM == 192 && BN == 256;
-#endif
+    constexpr bool WAHEAD = NSTG == 2 && gemm_staging_bytes(BN, WM, WN) >= BN * 128 && BM == 192 && BN == 256;
     static_assert(XIMG % NW == 0 && WIMG % NW == 0 && TM % 32 == 0 && TN % 32 == 0, "tile / wave shape");
     static_assert(EPI != EPI_SWIGLU || NI % 2 == 0, "SwiGLU pairs gate/up 32-column blocks inside a wave");
     extern __shared__ __attribute__((aligned(16))) char lds[];
@@ -226,23 +199,14 @@ __global__ void __launch_bounds__(WM * WN * 64) gemm_kernel(const GemmArgs a) {
             woff[j] = (uint32_t)src * (uint32_t)(a.ldw * 2) + c * 16;
         }
     };
-#ifdef VDD_GEMM_ABLATE
-    const int ab = a.ablate;
-#else
-    constexpr int ab = 0;
-#endif
     auto stage = [&](int t, int buf) {
         const int so = t * 128;
-        if (!((ab & 1) && t >= 2)) {
 #pragma unroll
         for (int j = 0; j < XJ; ++j)
             __builtin_amdgcn_raw_ptr_buffer_load_lds(rx, (lds_ptr_t)(lds + buf * BUF + (j * NW + wave) * 1024), 16, xoff[j], so, 0, 0);
-        }
-        if (!((ab & 2) && t >= 2)) {
 #pragma unroll
         for (int j = 0; j < WJ; ++j)
-            __builtin_amdgcn_raw_ptr_buffer_load_lds(rw, (lds_ptr_t)(lds + buf * BUF + (XIMG + j * NW + wave) * 1024), 16, woff[j], so, 0, VDD_GEMM_W_AUX);
-        }
+            __builtin_amdgcn_raw_ptr_buffer_load_lds(rw, (lds_ptr_t)(lds + buf * BUF + (XIMG + j * NW + wave) * 1024), 16, woff[j], so, 0, 0);
     };
 
     auto stage_x = [&](int t, int buf) {
@@ -255,7 +219,7 @@ __global__ void __launch_bounds__(WM * WN * 64) gemm_kernel(const GemmArgs a) {
         const int so = t * 128;
 #pragma unroll
         for (int j = 0; j < WJ; ++j)
-            __builtin_amdgcn_raw_ptr_buffer_load_lds(rw, (lds_ptr_t)(lds + buf * BUF + (XIMG + j * NW + wave) * 1024), 16, woff[j], so, 0, VDD_GEMM_W_AUX);
+            __builtin_amdgcn_raw_ptr_buffer_load_lds(rw, (lds_ptr_t)(lds + buf * BUF + (XIMG + j * NW + wave) * 1024), 16, woff[j], so, 0, 0);
     };
     bool more = advance();
     auto stage_first = [&]() {
@@ -291,73 +255,31 @@ __global__ void __launch_bounds__(WM * WN * 64) gemm_kernel(const GemmArgs a) {
                 if (with_reads && i < NRD) __builtin_amdgcn_sched_group_barrier(0x100, 1, 0);
             }
         };
-        auto interleave_n = [&](int n_dma, bool with_reads) {               // MFMA, [DMA] (n_dma of them, one behind every SP-th MFMA), [read], MFMA, ...
-            constexpr int SP = (VDD_GEMM_DMA_SPACING > 1 && NMMA >= 2 * VDD_GEMM_DMA_SPACING) ? VDD_GEMM_DMA_SPACING : 1;
+        auto interleave_n = [&](int n_dma, bool with_reads) {               // MFMA, [DMA] (n_dma of them, one behind each MFMA), [read], MFMA, ...
 #pragma unroll
             for (int i = 0; i < NMMA; ++i) {
                 __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
-                if (i % SP == 0 && i / SP < n_dma) __builtin_amdgcn_sched_group_barrier(0x020, 1, 0);
+                if (i < n_dma) __builtin_amdgcn_sched_group_barrier(0x020, 1, 0);
                 if (with_reads && i < NRD) __builtin_amdgcn_sched_group_barrier(0x100, 1, 0);
             }
         };
         frag8_t xg[4][MI], wg[4][NI];
-        int rd_n = 0;
         auto rd = [&](int buf, int kk) {
-            const bool first = !ab || rd_n < 4;                 // (probe builds: the first four sets are always read - the registers must hold something)
-            ++rd_n;
-            if (first || !(ab & 4)) {
 #pragma unroll
             for (int i = 0; i < NI; ++i) wg[kk][i] = *reinterpret_cast<const frag8_t*>(lds + buf * BUF + ((wrow + i * 4096) ^ (kk << 5)));
-            }
-            if (first || !(ab & 8)) {
 #pragma unroll
             for (int i = 0; i < MI; ++i) xg[kk][i] = *reinterpret_cast<const frag8_t*>(lds + buf * BUF + ((xrow + i * 4096) ^ (kk << 5)));
-            }
         };
+        // The wave tile is walked boustrophedon with the X fragment outer and the W fragment inner: consecutive MFMAs differ in ONE operand
+        // and the two operand ports take turns (the MFMA pipe's sustained rate on real data depends on how much its inputs toggle:
+        // tools/probes/mfma_power_probe.hip - a new operand on one port at every instruction 1.58 PF/s, ports taking turns 1.83).  Worth
+        // +0.7 ... 1.9 % over the row-major walk at prefill size (profiles/r04_gemm_mfma_order_ab.jsonl); same accumulation order per accumulator.
         auto mm = [&](int kk) {
-            if constexpr (VDD_GEMM_SNAKE == 2) {       // X fragment outer, W inner, boustrophedon: another +0.3 ... 0.9 % over the W-outer walk (A/B builds)
 #pragma unroll
-                for (int j = 0; j < MI; ++j)
+            for (int j = 0; j < MI; ++j)
 #pragma unroll
-                    for (int ii = 0; ii < NI; ++ii) { const int i = (j & 1) ? NI - 1 - ii : ii; acc[i][j] = mfma32(wg[kk][i], xg[kk][j], acc[i][j]); }
-                return;
-            }
-#pragma unroll
-            for (int i = 0; i < NI; ++i)
-#pragma unroll
-                for (int jj = 0; jj < MI; ++jj) {
-                    // boustrophedon over the wave tile: consecutive MFMAs differ in ONE operand (the MFMA pipe's sustained rate on real data
-                    // depends on how much its operand inputs toggle: tools/probes/mfma_power_probe.hip - both operands new every time 1.52
-                    // PF/s, one held for four instructions 1.60, both held 1.87)
-                    const int j = (VDD_GEMM_SNAKE && (i & 1)) ? MI - 1 - jj : jj;
-                    acc[i][j] = mfma32(wg[kk][i], xg[kk][j], acc[i][j]);
-                }
+                for (int ii = 0; ii < NI; ++ii) { const int i = (j & 1) ? NI - 1 - ii : ii; acc[i][j] = mfma32(wg[kk][i], xg[kk][j], acc[i][j]); }
         };
-#if VDD_GEMM_STREAM_SIMPLE
-        if constexpr (NSTG >= 3) {       // (A/B form: read everything, barrier, stage, multiply - two barriers per K-tile, nothing overlapped)
-            // A W stream (the 64-row tile: a few dozen rows of activations; the 128-column tiles of up to 192 rows): 2 - 3 MFMAs per wave
-            // and k-step, and what bounds the launch is the bytes in flight - with two buffers one K-tile (40 KiB) per CU, 2.6 TB/s.
-            // NSTG buffers, NSTG - 1 tiles in flight behind the one being multiplied; nothing to interleave, two barriers per K-tile.
-            const int cnk = nk;
-            int buf = 0;
-            for (int t = 0; t < cnk; ++t) {
-                const int ahead = min(NSTG - 1, cnk - 1 - t);         // tiles staged beyond t
-                // (t = 0: the previous segment's epilogue stores are counted by vmcnt too and retire out of order with the loads)
-                if (t == 0 || ahead == 0) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-                else if (ahead == 1) asm volatile("s_waitcnt vmcnt(%0)" :: "n"(NLD) : "memory");
-                else if (ahead == 2) asm volatile("s_waitcnt vmcnt(%0)" :: "n"(2 * NLD) : "memory");
-                else if (NSTG > 3 && ahead == 3) asm volatile("s_waitcnt vmcnt(%0)" :: "n"(NSTG > 3 ? 3 * NLD : 0) : "memory");
-                else asm volatile("s_waitcnt vmcnt(%0)" :: "n"(NSTG > 4 ? 4 * NLD : 0) : "memory");
-                __builtin_amdgcn_s_barrier();
-                rd(buf, 0); rd(buf, 1); rd(buf, 2); rd(buf, 3);
-                asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
-                __builtin_amdgcn_s_barrier();                         // every wave holds its fragments of tile t: the buffer is free
-                if (t + NSTG < cnk) stage(t + NSTG, buf);
-                mm(0); mm(1); mm(2); mm(3);
-                buf = buf + 1 == NSTG ? 0 : buf + 1;
-            }
-        } else
-#endif
         if constexpr (NSTG >= 3) {
             // A W stream (the 64-row tile: a few dozen rows of activations; the 128-column tiles of up to 192 rows): a handful of MFMAs per
             // wave and k-step, and what bounds the launch is first the bytes in flight - with two buffers one K-tile (40 KiB) per CU,
@@ -404,7 +326,7 @@ __global__ void __launch_bounds__(WM * WN * 64) gemm_kernel(const GemmArgs a) {
                 const int so = t * 128;
 #pragma unroll
                 for (int j = 0; j < WJ; ++j)
-                    __builtin_amdgcn_raw_ptr_buffer_load_lds(rw, (lds_ptr_t)(lds + wbase(sl) + (XIMG + j * NW + wave) * 1024), 16, woff[j], so, 0, VDD_GEMM_W_AUX);
+                    __builtin_amdgcn_raw_ptr_buffer_load_lds(rw, (lds_ptr_t)(lds + wbase(sl) + (XIMG + j * NW + wave) * 1024), 16, woff[j], so, 0, 0);
             };
             auto rd3 = [&](int buf, int sl, int kk) {
 #pragma unroll
@@ -453,25 +375,17 @@ __global__ void __launch_bounds__(WM * WN * 64) gemm_kernel(const GemmArgs a) {
             rd(buf, 2); mm(0); interleave(false, true); __builtin_amdgcn_sched_barrier(0);
             rd(buf, 3); mm(1); interleave(false, true); __builtin_amdgcn_sched_barrier(0);
             asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");   // own fragment reads of this tile done; tile t+1 landed
-            if (!(ab & 16)) __builtin_amdgcn_s_barrier();
+            __builtin_amdgcn_s_barrier();
             __builtin_amdgcn_sched_barrier(0);
-#if VDD_GEMM_SPLIT_STAGE
             // the LDS-DMA of tile t + 2 spread over BOTH post-barrier MFMA groups (X images behind the MFMAs of k-step 2, W images behind
             // those of k-step 3) instead of all of it behind k-step 2: +1 ... 3 % at prefill and decode sizes, A/B in one process
-            // (tools/gemm_ablate_probe.py --build-variant -DVDD_GEMM_SPLIT_STAGE=0); W first or X first: the same
+            // (profiles/r04_gemm_ablation.jsonl); W first or X first: the same
             if constexpr (ST) stage_x(t + 2, buf);
             if constexpr (NX) rd(buf ^ 1, 0);
             mm(2); interleave_n(ST ? XJ : 0, NX); __builtin_amdgcn_sched_barrier(0);
             if constexpr (ST) stage_w(t + 2, buf);
             if constexpr (NX) rd(buf ^ 1, 1);
             mm(3); interleave_n(ST ? WJ : 0, NX); __builtin_amdgcn_sched_barrier(0);
-#else
-            if constexpr (ST) stage(t + 2, buf);
-            if constexpr (NX) rd(buf ^ 1, 0);
-            mm(2); interleave(ST, NX); __builtin_amdgcn_sched_barrier(0);
-            if constexpr (NX) rd(buf ^ 1, 1);
-            mm(3); interleave(false, NX); __builtin_amdgcn_sched_barrier(0);
-#endif
         };
         using T_ = std::true_type; using F_ = std::false_type;
         int t = 0;                                  // nk is even: tiles alternate between the two buffers
@@ -734,11 +648,7 @@ int launch_cfg(const GemmArgs& a0, int epi, int sched, void* workspace, int64_t 
     // row-tiles per group of the tile order (a group = GM row-tiles x all column tiles, row-tile fastest: an XCD's 32 workgroups hold GM x 32 / GM
     // tiles).  A/B builds at 39,140 rows (profiles/r04_gemm_tile_order_ab.jsonl): 8 is best for 48 and 16 column tiles (qkv, o, down: 4 costs qkv 1.3 %,
     // 16 costs down 2.6 %), 4 for the 86 column tiles of gate/up (+2.9 %; 16: -5.5 %).  The decode batch (8 row-tiles) keeps one group.
-#ifdef VDD_GEMM_GM
-    a.GM = a.Mt < VDD_GEMM_GM ? a.Mt : VDD_GEMM_GM;
-#else
     a.GM = a.Mt < 8 ? a.Mt : ((a.Mt >= 32 && a.Nt >= 80) ? 4 : 8);
-#endif
     a.UP = a.K / 128;
     const long long U = (long long)a.Mt * a.Nt * a.UP;
     if (U > 0x7fffffffLL) return VDD_ERR_INVALID_ARG;
@@ -828,9 +738,6 @@ VDD_HIDDEN int VDD_IMPL(vdd_gemm)(const void* X, const void* W, void* Y, const v
     a.M = M; a.N = N; a.K = K; a.ldx = ldx; a.ldw = ldw; a.ldy = ldy; a.ldr = ldr;
     hipStream_t st = (hipStream_t)stream;
     const int sched = (config >> 4) & 3;            // tuning: 0 hybrid, 1 data-parallel only, 2 stream-K only, 3 split-K slabs
-#ifdef VDD_GEMM_ABLATE
-    a.ablate = (config >> 16) & 31;
-#endif
     if (sched == 3) {                               // Y = fp32 [S][M][N] (ldy = N), S = config bits 8-15; plain product only
         a.slab_S = (config >> 8) & 255;
         a.slabs = (float*)Y;

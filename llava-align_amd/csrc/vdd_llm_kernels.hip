@@ -30,17 +30,9 @@ typedef __attribute__((ext_vector_type(2))) uint32_t u32x2_t;
 // takes no L2 line from data that IS re-read (the GEMMs' shared operand panels, the next GEMM's X)
 __device__ __forceinline__ uint4 ld_stream(const uint16_t* p) { return __builtin_bit_cast(uint4, __builtin_nontemporal_load(reinterpret_cast<const u32x4_nt*>(p))); }
 __device__ __forceinline__ void st_stream(uint16_t* p, uint4 v) { __builtin_nontemporal_store(__builtin_bit_cast(u32x4_nt, v), reinterpret_cast<u32x4_nt*>(p)); }
-// a weight fragment of the weight-streaming projections: every byte of W is read by ONE wave, once per launch
-#ifndef VDD_W_NT
-#define VDD_W_NT 0   // measured: nontemporal weight loads are SLOWER here (one-question layer chain 90.2 vs 84.8 us)
-#endif
-__device__ __forceinline__ frag8_t ld_w(const uint16_t* p) {
-#if VDD_W_NT
-    return __builtin_nontemporal_load(reinterpret_cast<const frag8_t*>(p));
-#else
-    return *reinterpret_cast<const frag8_t*>(p);
-#endif
-}
+// a weight fragment of the weight-streaming projections: every byte of W is read by ONE wave, once per launch.  Default cache policy:
+// nontemporal weight loads measured SLOWER here (one-question layer chain 90.2 vs 84.8 us)
+__device__ __forceinline__ frag8_t ld_w(const uint16_t* p) { return *reinterpret_cast<const frag8_t*>(p); }
 
 // q.k over 8 packed pairs with v_dot2c_f32_{bf16,f16} (fp32 accumulate; the 16-bit x 16-bit products are exact in fp32)
 __device__ __forceinline__ float dot8(const uint4& a, const uint4& b) {

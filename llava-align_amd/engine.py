@@ -470,6 +470,10 @@ class LanguageModel:
                 qkv = ops.linear(a, t[pfx + "wqkv"], bias=t[pfx + "bqkv_lm"] if c.qkv_bias else None)
                 kw_, vw_ = (kv.kp[i], kv.vp[i]) if p["to_prefix_pool"] else (kv.ko[i], kv.vo[i])
                 q = ops.rope_kv_write(qkv, p["pos"], p["slot"], self.cs, kw_, vw_, H, Hkv, D, cpos=p["cpos"])
+                if p.get("parent_copy") is not None:          # two-level prefixes: the rows in front of an image prefix = its system prompt's
+                    dst, src, n = p["parent_copy"]             # (this layer's K / V of the parent slot, computed by the pass before)
+                    kw_[dst, :, :n] = kw_[src, :, :n]
+                    vw_[dst, :, :n] = vw_[src, :, :n]
                 if final and p.get("keep_q"):
                     p["q_last"] = q                                # the rotated queries of the last layer, every row (attention maps on request)
                 last_rows = p.get("last_rows")
@@ -482,7 +486,8 @@ class LanguageModel:
                 if p.get("packs") is not None:
                     att = ops.flash_attention_packed(q, kw_, vw_, sq, p["packs"], p["packs"].shape[0], H, Hkv, D, k_prefix=kv.kp[i], v_prefix=kv.vp[i])
                 else:
-                    att = ops.flash_attention(q, kw_, vw_, sq, p["n_seq"], tq, H, Hkv, D, causal=True, k_prefix=kv.kp[i], v_prefix=kv.vp[i])
+                    att = ops.flash_attention(q, kw_, vw_, sq, p["n_seq"], tq, H, Hkv, D, causal=True, k_prefix=kv.kp[i], v_prefix=kv.vp[i],
+                                              own_row_offset=p.get("own_row_offset", 0))
                 o = ops.linear(att, t[pfx + "wo"])
                 new_resid = torch.empty_like(resid)
                 a = ops.rmsnorm(resid, t[pfx + "ln2"], c.eps, delta=o, resid_out=new_resid)
@@ -1140,6 +1145,8 @@ class VddLlavaEngine:
         if embeds_prefix is not None and (inputs_embeds is None or len(embeds_prefix) != Q):
             raise ValueError("embeds_prefix goes with inputs_embeds: one (key, n_rows) per prompt")
         plan = self._plan(branches, n_img_tok, share_prefix, embeds_only=inputs_embeds is not None, embeds_prefix=embeds_prefix)
+        if self.two_level_prefix and inputs_embeds is None and not (output_attentions and Q == 1):
+            self._split_system_prompt(plan)
         # which rows decode, and whether their shared prefixes are attended through the grouped MFMA pass - decided BEFORE the prefill: it
         # settles the form the prefix K/V are kept in (KVCache: fragment image only, or row-major only)
         seg = plan["suffix"]
@@ -1156,7 +1163,7 @@ class VddLlavaEngine:
         retire = bool(self.retire and eos_token_id is not None and not output_scores and streamer is None and not proc and not grp
                       and max_new_tokens > self.kv_chunk)
         own_cap = min(max_new_tokens, self.kv_chunk) if retire else max_new_tokens
-        kv = self.kv(len(plan["prefix"]), max([s_["T"] for s_ in plan["prefix"]] + [0]), len(plan["suffix"]),
+        kv = self.kv(len(plan["prefix"]), max([s_.get("full_T", s_["T"]) for s_ in plan["prefix"]] + [0]), len(plan["suffix"]),
                      suffix_max + own_cap, frag_only=bool(grp))
         if plan["max_len"] + max_new_tokens > self.cfg.lm.max_pos:
             raise ValueError(f"prompt ({plan['max_len']} positions) + max_new_tokens ({max_new_tokens}) exceed the rotary table "
@@ -1166,11 +1173,21 @@ class VddLlavaEngine:
         want_maps = bool(output_attentions) and Q == 1 and lm.head_dim == 128 and lm.n_layers > 0
         passes, frag_plen = [], None
         if plan["prefix"]:
-            segs = plan["prefix"]
-            x, pos, cpos, slot, seqs, max_tq = self._pack(segs)
-            passes.append(dict(x=x, pos=pos, cpos=cpos, slot=slot, seqs=seqs, n_seq=len(segs), max_tq=max_tq, to_prefix_pool=True, keep_q=want_maps))   # K/V only
+            # level 0: the prefixes that continue nothing; level 1: image prefixes behind a shared system prompt (their pass runs second in
+            # every layer: it attends the parent's K / V of that layer, and copies them in front of its own rows)
+            for level in (0, 1):
+                segs = [s_ for s_ in plan["prefix"] if (s_.get("cpos0", 0) > 0) == bool(level)]
+                if not segs:
+                    continue
+                x, pos, cpos, slot, seqs, max_tq = self._pack(segs)
+                pd = dict(x=x, pos=pos, cpos=cpos, slot=slot, seqs=seqs, n_seq=len(segs), max_tq=max_tq, to_prefix_pool=True, keep_q=want_maps)   # K/V only
+                if level:
+                    n_sys = segs[0]["cpos0"]
+                    pd.update(own_row_offset=n_sys, parent_copy=(torch.tensor([s_["slot"] for s_ in segs], dtype=torch.long, device=dev),
+                                                                   segs[0]["pslot"], n_sys))
+                passes.append(pd)
             if kv.frag_only:
-                (frag_plen,) = h2d_int32(dev, [s_["T"] for s_ in segs])
+                (frag_plen,) = h2d_int32(dev, [s_.get("full_T", s_["T"]) for s_ in plan["prefix"]])
         segs = plan["suffix"]
         x, pos, cpos, slot, seqs, max_tq = self._pack(segs)
         # short suffixes behind shared prefixes: four sequences of one prefix per attention workgroup (ops.flash_packs)
@@ -1395,6 +1412,31 @@ class VddLlavaEngine:
             self._graphs[key] = r
         return r
 
+    two_level_prefix = True      # [system prompt] prefilled once, the image prefixes behind it (False: every [sys + image] prefix in full)
+
+    @staticmethod
+    def _split_system_prompt(plan, min_tokens: int = 8):
+        """Two-level prefixes: the [system prompt + 576 patch embeddings] prefixes of a call all start with the same tokens (the
+        conversation template, 35 ids for LLaVA-1.5): that part is prefilled ONCE into a slot of its own, and each image prefix only
+        runs its patch rows, attending [parent slot | own rows] and keeping the rows in front for a copy of the parent's K / V - the slot
+        the decode steps and the suffix pass read is the same [sys + image] prefix as before, 4 % fewer prefill tokens on the POPE batch.
+        Causal attention makes the parent's K / V independent of what follows, so the results are those of the one-level prefill."""
+        groups: Dict[tuple, list] = {}
+        for s_ in plan["prefix"]:
+            if s_.get("img") is not None and s_.get("tokens") and s_["pos0"] == 0:
+                groups.setdefault(tuple(s_["tokens"]), []).append(s_)
+        # one parent per call keeps the level-1 pass uniform (one row offset); take the prompt shared by the most images
+        best = max(groups.items(), key=lambda kv_: len(kv_[1]), default=None)
+        if best is None or len(best[1]) < 2 or len(best[0]) < min_tokens:
+            return
+        toks, members = list(best[0]), best[1]
+        parent = dict(slot=len(plan["prefix"]), tokens=toks, img=None, T=len(toks), pos0=0, pslot=0, plen=0)
+        plan["prefix"].append(parent)
+        n = len(toks)
+        for s_ in members:
+            s_.update(full_T=s_["T"], T=s_["T"] - n, tokens=[], pos0=n, cpos0=n, pslot=parent["slot"], plen=n)
+        plan["prefill_tokens"] -= n * (len(members) - 1)
+
     @staticmethod
     def _trim_after_all_finished(gen, eos_t, pad):
         """The reference stops at the first step after which every row has emitted EOS (:291); we check every
@@ -1534,7 +1576,8 @@ class VddLlavaEngine:
         rows_h = np.concatenate(row_chunks).astype(np.int32) if row_chunks else np.zeros(0, np.int32)
         within = np.arange(total) - np.repeat(q0, T)                                      # index inside the slot (= pos - plen)
         pos_h = (within + np.repeat(np.fromiter((s["pos0"] for s in segs), dtype=np.int64, count=len(segs)), T)).astype(np.int32)
-        cpos_h = within.astype(np.int32)
+        # (a two-level image prefix writes behind the rows kept for its system prompt: cpos0 = that many rows)
+        cpos_h = (within + np.repeat(np.fromiter((s.get("cpos0", 0) for s in segs), dtype=np.int64, count=len(segs)), T)).astype(np.int32)
         slot_h = np.repeat(np.fromiter((s["slot"] for s in segs), dtype=np.int64, count=len(segs)), T).astype(np.int32)
         seqs_h = np.array([[s["q_row0"], s["T"], s["pos0"], s["slot"], s["pslot"], s["plen"]] for s in segs], dtype=np.int32)
         pos, cpos, slot, seqs, ids_d, rows_d = h2d_int32(dev, *(torch.from_numpy(a) for a in (pos_h, cpos_h, slot_h, seqs_h, ids_h, rows_h)))

@@ -762,15 +762,19 @@ def decode_attention_grouped(q, k_cache, v_cache, k_prefix, v_prefix, rows, grou
     return out
 
 
-def flash_attention(q, k_cache, v_cache, seqs, n_seq, max_tq, H, Hkv, D, causal=True, out=None, k_prefix=None, v_prefix=None, scale=None):
+def flash_attention(q, k_cache, v_cache, seqs, n_seq, max_tq, H, Hkv, D, causal=True, out=None, k_prefix=None, v_prefix=None, scale=None,
+                    own_row_offset=0):
     """Prefill attention.  q [Ttot, H*D] packed by sequence; seqs int32 [n_seq, 6] =
     (q_row0, Tq, pos0, slot, prefix_slot, prefix_len): query i of a sequence sits at position pos0+i and
-    attends keys [0, pos0+i] (causal) or [0, pos0+Tq) (non-causal) of its slot / prefix slot."""
+    attends keys [0, pos0+i] (causal) or [0, pos0+Tq) (non-causal) of its slot / prefix slot.
+    own_row_offset: the sequences' own keys start at row `own_row_offset` of their slots instead of row 0 (two-level prefixes: an image
+    prefix keeps the rows in front for the system prompt it continues) - the own pools are handed over that many rows further on."""
     dt = _dt(q, k_cache, v_cache)
     out = torch.empty_like(q) if out is None else out
     k_prefix = k_cache if k_prefix is None else k_prefix
     v_prefix = v_cache if v_prefix is None else v_prefix
-    _lib.check(_lib_ready().vdd_flash_attention(q.data_ptr(), k_cache.data_ptr(), v_cache.data_ptr(), k_prefix.data_ptr(), v_prefix.data_ptr(),
+    off = int(own_row_offset) * D * k_cache.element_size()
+    _lib.check(_lib_ready().vdd_flash_attention(q.data_ptr(), k_cache.data_ptr() + off, v_cache.data_ptr() + off, k_prefix.data_ptr(), v_prefix.data_ptr(),
                                                 seqs.data_ptr(), out.data_ptr(), n_seq, max_tq, H, Hkv, D, k_cache.stride(0),
                                                 k_cache.shape[2], k_prefix.stride(0), k_prefix.shape[2], D ** -0.5 if scale is None else float(scale),
                                                 1 if causal else 0, dt, _st(q)))

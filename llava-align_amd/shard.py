@@ -27,33 +27,6 @@ def get_chunk(n_items: int, n_chunks: int, k: int, group: int = 1) -> range:
     return range(min(lo, n_items), min(hi, n_items))
 
 
-def gather_tokens(local_ids: torch.Tensor, local_tokens: torch.Tensor, n_total: int, pad: int = 0) -> torch.Tensor | None:
-    """local_ids [n_local] int64 question indices, local_tokens [n_local, T] int64.  Returns on every rank the
-    [n_total, T] matrix of generated ids (one all_gather of a few hundred bytes per question)."""
-    if not (dist.is_available() and dist.is_initialized()) or dist.get_world_size() == 1:
-        out = torch.full((n_total, local_tokens.shape[1]), pad, dtype=torch.long, device=local_tokens.device)
-        out[local_ids] = local_tokens
-        return out
-    world = dist.get_world_size()
-    dev = local_tokens.device
-    meta = torch.tensor([local_ids.numel(), local_tokens.shape[1]], dtype=torch.long, device=dev)
-    metas = [torch.zeros(2, dtype=torch.long, device=dev) for _ in range(world)]
-    dist.all_gather(metas, meta)
-    cap = int(max(c[0].item() for c in metas))
-    T = int(max(c[1].item() for c in metas))               # a rank whose batch hit EOS early returns fewer columns: pad to the longest
-    buf = torch.full((cap, T + 1), -1, dtype=torch.long, device=dev)          # column 0: question index, -1 = padding row
-    buf[:, 1:] = pad
-    buf[: local_ids.numel(), 0] = local_ids
-    buf[: local_ids.numel(), 1: 1 + local_tokens.shape[1]] = local_tokens
-    bufs = [torch.empty_like(buf) for _ in range(world)]
-    dist.all_gather(bufs, buf)
-    out = torch.full((n_total, T), pad, dtype=torch.long, device=dev)
-    for b in bufs:
-        ok = b[:, 0] >= 0
-        out[b[ok, 0]] = b[ok, 1:]
-    return out
-
-
 def rank_world(rank=None, world=None):
     """(rank, world) of this process: the arguments if given, else the initialised process group's, else (0, 1)."""
     if rank is not None and world is not None:

@@ -97,3 +97,27 @@ def test_grouping_only_when_it_removes_kv_traffic():
     groups, _ = group_rows_by_prefix(rows)
     assert len(groups) == 92 and not grouping_pays(groups, rows)
     assert not grouping_pays([], [])
+
+
+def test_two_level_prefixes_prefill_the_system_prompt_once():
+    """VERDICT r4 #2c: the 35 system-prompt tokens in front of every [sys + image] prefix are prefilled once; an image prefix runs its 576
+    patch rows at positions 35.., attends [parent | own] and leaves rows 0..34 of its slot to a copy of the parent's K / V, so the slot
+    the suffix pass and the decode steps read still holds 611 keys."""
+    sys_tok = list(range(100, 135))
+    img_a, img_b = torch.zeros(576, 8), torch.zeros(576, 8)
+    ids = [sys_tok + [IMG] + [7, 8, 9], sys_tok + [IMG] + [7, 8, 9, 10], sys_tok + [IMG] + [5]]
+    plan = PlanOnly()._plan(branches_for(ids, [img_a, img_a, img_b], use_none=True), 576, True)
+    before = plan["prefill_tokens"]
+    VddLlavaEngine._split_system_prompt(plan)
+    pre = plan["prefix"]
+    assert [p["slot"] for p in pre] == [0, 1, 2, 3, 4] and pre[4]["tokens"] == sys_tok and pre[4]["img"] is None and pre[4]["T"] == 35
+    for p in pre[:2]:                                                   # the two image prefixes: patch rows only, behind the parent
+        assert p["T"] == 576 and p["full_T"] == 611 and p["pos0"] == 35 and p["cpos0"] == 35 and p["pslot"] == 4 and p["plen"] == 35 and p["tokens"] == []
+    assert pre[2]["T"] == 36 and "cpos0" not in pre[2] and pre[3]["T"] == 35          # sys + <unk>, bare sys: untouched
+    assert plan["prefill_tokens"] == before - 35                        # two images: one copy of the system prompt saved
+    assert all(s["plen"] == 611 and s["pslot"] in (0, 1) for s in plan["suffix"][:3])   # the suffixes still see a 611-key prefix slot
+    # a single image (or a short template) shares nothing worth a second pass
+    plan1 = PlanOnly()._plan(branches_for(ids[:1], [img_a]), 576, True)
+    n = len(plan1["prefix"])
+    VddLlavaEngine._split_system_prompt(plan1)
+    assert len(plan1["prefix"]) == n and "cpos0" not in plan1["prefix"][0]
