@@ -517,7 +517,11 @@ def main():
                       kernel_point(dev, 1024, 151936, scores=False, iters=50),
                       # 768 rows are resident at a time (3 workgroups x 256 CUs): 1,024 rows = one full round + a third of one.  The same
                       # shape at a multiple of 768 shows the kernel without that quantisation (tools: profiles/r04_kernel_v151936_by_batch.jsonl)
-                      kernel_point(dev, 3072, 151936, scores=False, iters=30)]
+                      kernel_point(dev, 3072, 151936, scores=False, iters=30),
+                      # the launches the ENGINE makes on the headline workload: one row per question (768) - and 1,536 for a batch twice
+                      # the size; 768 rows are exactly one resident round (3 workgroups x 256 CUs), so launch overhead and the ramp of a
+                      # single round weigh more than at B = 4096
+                      kernel_point(dev, 768, 32000, iters=100), kernel_point(dev, 1536, 32000, iters=100)]
     eng = VddLlavaEngine(a.model, device=dev, seed=0, use_graph=True, lm_head_gain=4.0)
     if a.strong:
         return run_strong(a, eng, dev, rank, world)
