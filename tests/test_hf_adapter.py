@@ -44,8 +44,10 @@ def test_mapped_weights_reproduce_the_hf_module(model):
 
 
 class _StubEngine:
-    def __init__(self):
+    def __init__(self, model=None):
         self.calls = []
+        # what the adapter's stale-weights check reads: the engine's lm_head is the model's own storage after attach_engine
+        self.w = types.SimpleNamespace(t={"lm_head": model.lm_head.weight if model is not None else torch.zeros(1)})
 
     def generate(self, input_ids, **kw):
         self.calls.append(kw)
@@ -56,7 +58,7 @@ class _StubEngine:
 
 
 def test_generate_keywords_are_resolved_like_hf(model):
-    stub = _StubEngine()
+    stub = _StubEngine(model)
     model._vdd_engine = stub
     ids = torch.tensor([[1, 9, -200, 4]])
     gc = model.generation_config
@@ -85,5 +87,9 @@ def test_generate_keywords_are_resolved_like_hf(model):
             A._native_generate(model, ids, attention_mask=torch.tensor([[0, 1, 1, 1]]), max_new_tokens=1)
         with pytest.raises(ValueError, match=r"\[batch, length\]"):
             A._native_generate(model, [ids[0]], max_new_tokens=1)
+        # parameters re-allocated behind the engine's back (model.to() / .half()): refuse instead of decoding with the old weights
+        stub.w.t["lm_head"] = model.lm_head.weight.clone()
+        with pytest.raises(RuntimeError, match="attach_engine"):
+            A._native_generate(model, ids, max_new_tokens=1)
     finally:
         del model._vdd_engine
