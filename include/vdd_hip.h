@@ -182,7 +182,8 @@ int vdd_embed_scatter(const int32_t* ids, const int32_t* rows, const void* table
 int vdd_skinny_gemm(const void* X, const void* W, const void* R, void* Y, float* Y_slabs, int n_split, int M, int N, int K,
                     int64_t ldx, int64_t ldr, int64_t ldy, int dtype, void* hip_stream);
 
-/* act[M,F] = silu(X Wg^T) * (X Wu^T) for W_gate_up = [Wg; Wu] ([2F, K] row-major), M <= 16, K % 128 == 0: the gate/up
+/* act[M,F] = silu(X Wg^T) * (X Wu^T) for W_gate_up = [Wg; Wu] ([2F, K] row-major), M <= 16 with K % 128 == 0 (8 features per
+ * workgroup) or 17 <= M <= 64 with K % 256 == 0 (16 features per workgroup, gate + up tiles on 16x16x32 MFMAs): the gate/up
  * projection and SiLU*mul of the Llama MLP (HF LlamaMLP.forward [ext] under llava_llama.py:88-103) in one weight-streaming
  * launch; replaces vdd_skinny_gemm(N = 2F) + vdd_silu_mul with the same bf16 rounding points. */
 int vdd_skinny_swiglu(const void* X, const void* W_gate_up, void* act, int M, int F, int K, int64_t ldx, int dtype, void* hip_stream);
@@ -315,6 +316,20 @@ int vdd_decode_attention_grouped(const void* q, const void* k_cache, const void*
                                  void* out, void* workspace, int M, int H, int Hkv, int D, int64_t slot_stride, int t_max,
                                  int64_t prefix_stride, int prefix_tmax, int max_prefix_len, int max_own_len,
                                  int prefix_chunks_per_item, float scale, int dtype, void* hip_stream);
+
+/* vdd_rope_kv_write + vdd_decode_attention_grouped in the two launches of the latter: qkv [M, (H + 2 Hkv) D] is the projection itself;
+ * the prefix pass rotates the queries it loads, the own pass rotates its query and its KV head's new key in registers, writes the new
+ * token's K / V to k_cache / v_cache[slot[row]] at cpos[row] (= len - prefix_len - 1) and attends it from registers in cache order.
+ * Bit for bit the result (out AND caches) of the two separate calls; one launch and one HBM round trip of q / K / V less per decoder
+ * layer.  Own ranges up to 256 keys (VDD_ERR_UNSUPPORTED beyond: use the two separate calls).
+ * Replaces, per decode step: apply_rotary_pos_emb + the cache concat + attention of HF LlamaAttention.forward as driven from
+ * vcd_utils/vcd_sample.py:109-114,163-183. */
+int vdd_decode_attention_grouped_rope(const void* qkv, const int32_t* pos, const int32_t* cpos, const int32_t* slot, const float* cos_sin,
+                                      void* k_cache, void* v_cache, const void* k_prefix, const void* v_prefix, const void* prefix_frag,
+                                      const int32_t* rows, const int32_t* groups, const int32_t* group_rows, const int32_t* items, int n_items,
+                                      void* out, void* workspace, int M, int H, int Hkv, int D, int64_t slot_stride, int t_max,
+                                      int64_t prefix_stride, int prefix_tmax, int max_prefix_len, int max_own_len,
+                                      int prefix_chunks_per_item, float scale, int dtype, void* hip_stream);
 
 /* Fragment-major copy of the prefix pool for the MFMA prefix pass: prefix_frag[slot][kv_head][chunk] = one 32-KiB block per
  * 64-key chunk (t_max % 64 == 0; twice the bytes and slot stride of k_prefix), 16 K fragments then 16 V^T fragments, each

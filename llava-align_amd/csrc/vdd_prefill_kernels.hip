@@ -547,6 +547,9 @@ VDD_HIDDEN int VDD_IMPL(vdd_attention_probs)(const void* q, const void* k_cache,
     if (sd.Tq <= 0) return VDD_OK;
     const int Tk = sd.pos0 + sd.Tq;
     if (sd.pos0 < 0 || sd.plen < 0 || sd.plen > Tk || Tk > 16384 || H > 65535) return VDD_ERR_INVALID_ARG;
+    // one score row of Tk floats in dynamic LDS (+ 32 B static): up to 64 KiB needs no opt-in, 16,384 keys (64 KiB + 32 B) do
+    static bool attr_set = false;
+    if (!attr_set) { (void)hipFuncSetAttribute((const void*)attn_probs_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, 16384 * (int)sizeof(float)); attr_set = true; }
     hipLaunchKernelGGL(attn_probs_kernel, dim3(sd.Tq, H), dim3(256), (size_t)Tk * sizeof(float), (hipStream_t)stream, (const uint16_t*)q,
                        (const uint16_t*)k_cache, (const uint16_t*)k_prefix, sd, (uint16_t*)out, H, Hkv, (long long)slot_stride, t_max,
                        (long long)prefix_stride, prefix_tmax, scale);

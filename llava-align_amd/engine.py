@@ -265,7 +265,7 @@ class VisionTower:
         if self.use_graph and n in self.GRAPH_SIZES and self.w.device.type == "cuda":
             st = self._graphs.get(n)
             if st is None:
-                self._kv_cache(self.GRAPH_BATCH)
+                self._kv_cache(max(n, self.GRAPH_BATCH))
                 g_in = torch.empty(n, *images.shape[1:], dtype=self.w.dtype, device=self.w.device)
                 g_in.copy_(images)
                 side = torch.cuda.Stream(self.w.device)
@@ -507,6 +507,7 @@ class LanguageModel:
         return self._head(a)
 
     fuse_norms = True         # few rows in flight: the RMSNorm launches ride inside the projections around them
+    fuse_rope = True          # grouped decode attention: RoPE + the KV write ride inside its two launches (no rope_kv launch per layer)
     # 1 - 4 rows: ALL decoder layers of the step in ONE persistent launch (ops.decode_layers, csrc/vdd_layer_persistent.hip).  Correct and
     # tested, but OFF: measured 120 - 126 us per 7B layer against 94 us for the five launches below - four activation all-gathers of
     # 8 - 22 MB per layer (256 CUs each sweeping the whole vector) and two local hops cost 55 us of waits, which the run-ahead weight
@@ -576,6 +577,10 @@ class LanguageModel:
         ungrouped attention; a captured step must own it (the module-level one is re-allocated when a later call needs more)."""
         c, t = self.cfg, self.w.t
         H, Hkv, D = c.n_heads, c.n_kv_heads, c.head_dim
+        if kv.frag_only and grouping is None:
+            # a fragment-only cache keeps ONE row-major prefix scratch for all layers (it holds the last layer's K / V after the prefill):
+            # only the grouped pass, which reads the per-layer fragment images, may decode from it
+            raise ValueError("decode_step: a frag_only KVCache decodes through the grouped attention only (pass `grouping`)")
         resid = ops.embed(tokens, t["embed"])
         if (self.fuse_norms and grouping is None and tokens.shape[0] <= min(ops.FUSED_ATTN_MAX_M, ops.norm_fused_rows(c.d)) and D == 128
                 and c.ffn % 128 == 0 and c.n_layers > 0):
@@ -588,16 +593,18 @@ class LanguageModel:
             else:
                 a = ops.rmsnorm(resid, t[p + "ln1"], c.eps, delta=delta, resid_out=resid)
             qkv = ops.linear(a, t[p + "wqkv"], bias=t[p + "bqkv_lm"] if c.qkv_bias else None)
-            if grouping is None and tokens.shape[0] <= ops.FUSED_ATTN_MAX_M and D == 128:
+            if grouping is None and tokens.shape[0] <= ops.fused_attention_rows() and D == 128:
                 # a few rows (one question in flight): RoPE + KV write + attention + merge in one launch
                 att = ops.decode_attention_fused(qkv, pos, cpos, slot, self.cs, kv.ko[i], kv.vo[i], attn_rows, H, Hkv, D,
                                                  k_prefix=kv.kp[i], v_prefix=kv.vp[i])
             elif grouping is not None:    # rows sharing a prompt prefix attend it once per group (MFMA), own tokens per row
-                q = ops.rope_kv_write(qkv, pos, slot, self.cs, kv.ko[i], kv.vo[i], H, Hkv, D, cpos=cpos)
+                fused = self.fuse_rope and kv.t_own <= ops.GROUPED_ROPE_MAX_OWN     # RoPE + KV write inside the two attention launches
+                q = qkv if fused else ops.rope_kv_write(qkv, pos, slot, self.cs, kv.ko[i], kv.vo[i], H, Hkv, D, cpos=cpos)
                 att = ops.decode_attention_grouped(q, kv.ko[i], kv.vo[i], kv.kp[i], kv.vp[i], attn_rows, grouping["groups"],
                                                    grouping["group_rows"], grouping["items"], grouping["n_items"], H, Hkv, D,
                                                    kv.t_pre, kv.t_own, workspace=grouping["workspace"],
-                                                   prefix_frag=kv.pfrag[i], chunks_per_item=grouping["cpi"])
+                                                   prefix_frag=kv.pfrag[i], chunks_per_item=grouping["cpi"],
+                                                   rope=(pos, cpos, slot, self.cs) if fused else None)
             else:
                 q = ops.rope_kv_write(qkv, pos, slot, self.cs, kv.ko[i], kv.vo[i], H, Hkv, D, cpos=cpos)
                 att = ops.decode_attention(q, kv.ko[i], kv.vo[i], attn_rows, H, Hkv, D, k_prefix=kv.kp[i], v_prefix=kv.vp[i],
@@ -939,6 +946,11 @@ class VddLlavaEngine:
         self._kv = self._kvs[frag_only]
         return self._kv
 
+    # Distinct images per vision-tower forward.  The tower's GEMMs have K = 1,024 / 4,096 and N = 1,024 ... 4,096: at 16 images (9,232
+    # rows) they are 148 - 592 tiles of 256 x 256 on 256 CUs and ran at 0.5 PF/s in the bench trace; at 64 images every product is
+    # 2 - 9 full rounds (tools/vit_batch_probe.py).  A full chunk replays a captured graph (VisionTower.GRAPH_SIZES).
+    VIT_CHUNK = 16
+
     def image_features(self, images: Sequence[torch.Tensor], keys: Optional[Sequence[int]] = None) -> List[torch.Tensor]:
         """ViT + projector per DISTINCT image (POPE: 6 questions share one image)."""
         if "v.patch" not in self.w.t:
@@ -952,13 +964,14 @@ class VddLlavaEngine:
         for k, im in zip(keys, images):
             if k not in cache and k not in seen:
                 todo.append((k, im)); seen.add(k)
-        for i in range(0, len(todo), 16):
-            chunk = todo[i:i + 16]
+        C_ = self.VIT_CHUNK
+        for i in range(0, len(todo), C_):
+            chunk = todo[i:i + C_]
             ims = [im.reshape(im.shape[-3:]) for _, im in chunk]
-            staged = self._stage_host_images(ims, i // 16)
+            staged = self._stage_host_images(ims, i // C_)
             feats = self.vit(staged if staged is not None else torch.stack(ims))
             if staged is not None:
-                self._pin_done[(i // 16) % 2].record(torch.cuda.current_stream(self.device))
+                self._pin_done[(i // C_) % 2].record(torch.cuda.current_stream(self.device))
             for (k, _), f in zip(chunk, feats):
                 cache[k] = f
         return [cache[k] for k in keys]
@@ -972,7 +985,7 @@ class VddLlavaEngine:
             return None
         key = (ims[0].dtype, tuple(ims[0].shape))
         if getattr(self, "_pin_key", None) != key:
-            self._pin = [torch.empty((16,) + key[1], dtype=key[0], pin_memory=True) for _ in range(2)]
+            self._pin = [torch.empty((self.VIT_CHUNK,) + key[1], dtype=key[0], pin_memory=True) for _ in range(2)]
             self._pin_done = [torch.cuda.Event() for _ in range(2)]
             self._pin_key = key
             self._pin_used = [False, False]
