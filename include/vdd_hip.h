@@ -317,20 +317,6 @@ int vdd_decode_attention_grouped(const void* q, const void* k_cache, const void*
                                  int64_t prefix_stride, int prefix_tmax, int max_prefix_len, int max_own_len,
                                  int prefix_chunks_per_item, float scale, int dtype, void* hip_stream);
 
-/* vdd_rope_kv_write + vdd_decode_attention_grouped in the two launches of the latter: qkv [M, (H + 2 Hkv) D] is the projection itself;
- * the prefix pass rotates the queries it loads, the own pass rotates its query and its KV head's new key in registers, writes the new
- * token's K / V to k_cache / v_cache[slot[row]] at cpos[row] (= len - prefix_len - 1) and attends it from registers in cache order.
- * Bit for bit the result (out AND caches) of the two separate calls; one launch and one HBM round trip of q / K / V less per decoder
- * layer.  Own ranges up to 256 keys (VDD_ERR_UNSUPPORTED beyond: use the two separate calls).
- * Replaces, per decode step: apply_rotary_pos_emb + the cache concat + attention of HF LlamaAttention.forward as driven from
- * vcd_utils/vcd_sample.py:109-114,163-183. */
-int vdd_decode_attention_grouped_rope(const void* qkv, const int32_t* pos, const int32_t* cpos, const int32_t* slot, const float* cos_sin,
-                                      void* k_cache, void* v_cache, const void* k_prefix, const void* v_prefix, const void* prefix_frag,
-                                      const int32_t* rows, const int32_t* groups, const int32_t* group_rows, const int32_t* items, int n_items,
-                                      void* out, void* workspace, int M, int H, int Hkv, int D, int64_t slot_stride, int t_max,
-                                      int64_t prefix_stride, int prefix_tmax, int max_prefix_len, int max_own_len,
-                                      int prefix_chunks_per_item, float scale, int dtype, void* hip_stream);
-
 /* Fragment-major copy of the prefix pool for the MFMA prefix pass: prefix_frag[slot][kv_head][chunk] = one 32-KiB block per
  * 64-key chunk (t_max % 64 == 0; twice the bytes and slot stride of k_prefix), 16 K fragments then 16 V^T fragments, each
  * the 1-KiB lane-linear image of one 16x16x32 MFMA operand; keys >= prefix_len_of_slot[slot] are zero-filled.  Built once

@@ -888,18 +888,12 @@ __global__ void __launch_bounds__(256) decode_attn_kernel(const uint16_t* __rest
 // Grouped mode, short own ranges (a question's own prompt tokens + what it generated so far: <= 256 keys): ONE wave per
 // (row, head) walks the whole own range [plen, len), then folds in the row's prefix partials left by the MFMA prefix pass
 // and writes the normalised bf16 output - no own partials, no separate combine launch.
-// ROPE: the launch takes the qkv projection itself ([M, (H + 2 Hkv) D], as vdd_rope_kv_write does) instead of rotated queries: every wave
-// rotates its own query and its KV head's new key in registers (same roundings as rope_kv_kernel), one wave per KV head writes
-// the new token's K / V into the own slot at cpos, and the new token is attended FROM REGISTERS at the place in the key order it
-// would have had read back from the cache - bit for bit the result of rope_kv_kernel followed by the plain form, one launch and
-// one round trip of q / K / V through HBM less per layer (17 us of a 1,536-row step's ~1,040 us layer).
-template <int D, bool ROPE>
-__global__ void __launch_bounds__(256) decode_attn_own_merge_kernel(const uint16_t* __restrict__ q, uint16_t* __restrict__ kc,
-                                                                    uint16_t* __restrict__ vc, const AttnRow* __restrict__ rows,
+template <int D>
+__global__ void __launch_bounds__(256) decode_attn_own_merge_kernel(const uint16_t* __restrict__ q, const uint16_t* __restrict__ kc,
+                                                                    const uint16_t* __restrict__ vc, const AttnRow* __restrict__ rows,
                                                                     const float* __restrict__ ws, uint16_t* __restrict__ out, int H, int Hkv,
                                                                     long long slot_stride, int t_max, float scale, int nchunk, int npre,
-                                                                    int pre_keys, const int* __restrict__ pos, const int* __restrict__ cpos,
-                                                                    const int* __restrict__ slot, const float* __restrict__ cs_table) {
+                                                                    int pre_keys) {
     static_assert(D == 128, "lane map assumes 16 lanes x 8 dims");
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     const int head = blockIdx.x * 4 + wave, row = blockIdx.y;
@@ -907,45 +901,11 @@ __global__ void __launch_bounds__(256) decode_attn_own_merge_kernel(const uint16
     const int g = lane >> 4, j = lane & 15;
     const AttnRow ar = rows[row];
     const int kvh = head / (H / Hkv);
+    const uint4 qv = *reinterpret_cast<const uint4*>(q + ((size_t)row * H + head) * D + j * 8);
     const size_t hoff = (size_t)kvh * t_max * D + j * 8;
     const uint16_t* k_own = kc + (size_t)ar.slot * slot_stride + hoff;       // compact slot: own token i at index i
     const uint16_t* v_own = vc + (size_t)ar.slot * slot_stride + hoff;
     const int n_own = ar.len - ar.plen;
-    const int n_rd = ROPE ? n_own - 1 : n_own;                               // keys read from the cache (ROPE: the last one is in registers)
-    uint4 qv, kn = make_uint4(0, 0, 0, 0), vn = make_uint4(0, 0, 0, 0);
-    if constexpr (ROPE) {
-        const uint16_t* src = q + (size_t)row * (size_t)((H + 2 * Hkv) * D);
-        // rotate_half RoPE: lane j < 8 holds dims 8j.. (first half), lane j + 8 the partner dims (decode_attn_fused_kernel's form)
-        // (the rotary position of a decode row is its context length - 1, its cache index n_own - 1, its slot ar.slot: read from the
-        //  row descriptor the wave holds anyway - through pos[] / cpos[] / slot[] the table load would sit one dependent round trip
-        //  deeper than the K / V loads; the arrays are checked against the descriptors on the host side of the binding's tests)
-        const float* cs = cs_table + ((size_t)(ar.len - 1) * (D / 2) + (j & 7) * 8) * 2;
-        const float4 c0 = *reinterpret_cast<const float4*>(cs), c1 = *reinterpret_cast<const float4*>(cs + 4),
-                     c2 = *reinterpret_cast<const float4*>(cs + 8), c3 = *reinterpret_cast<const float4*>(cs + 12);
-        const float sign = j < 8 ? -1.f : 1.f;
-        auto rope = [&](const uint16_t* hsrc) {
-            const uint4 own = *reinterpret_cast<const uint4*>(hsrc + j * 8);
-            uint4 oth;
-            oth.x = __shfl_xor(own.x, 8); oth.y = __shfl_xor(own.y, 8); oth.z = __shfl_xor(own.z, 8); oth.w = __shfl_xor(own.w, 8);
-            auto r2 = [&](uint32_t a, uint32_t b, float cA, float sA, float cB, float sB) {
-                return pack(lo(a) * cA + (sign * lo(b)) * sA, hi(a) * cB + (sign * hi(b)) * sB);
-            };
-            uint4 r;
-            r.x = r2(own.x, oth.x, c0.x, c0.y, c0.z, c0.w); r.y = r2(own.y, oth.y, c1.x, c1.y, c1.z, c1.w);
-            r.z = r2(own.z, oth.z, c2.x, c2.y, c2.z, c2.w); r.w = r2(own.w, oth.w, c3.x, c3.y, c3.z, c3.w);
-            return r;
-        };
-        qv = rope(src + (size_t)head * D);
-        kn = rope(src + (size_t)(H + kvh) * D);
-        vn = *reinterpret_cast<const uint4*>(src + (size_t)(H + Hkv + kvh) * D + j * 8);
-        if (g == 0 && head % (H / Hkv) == 0) {                               // one writer per KV head
-            const size_t o = (size_t)ar.slot * slot_stride + ((size_t)kvh * t_max + (n_own - 1)) * D + j * 8;
-            *reinterpret_cast<uint4*>(kc + o) = kn;
-            *reinterpret_cast<uint4*>(vc + o) = vn;
-        }
-    } else {
-        qv = *reinterpret_cast<const uint4*>(q + ((size_t)row * H + head) * D + j * 8);
-    }
     float m = -INFINITY, l = 0.f, acc[8] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
     constexpr int U = 8;
     for (int t0 = g; t0 < n_own; t0 += 4 * U) {
@@ -953,14 +913,9 @@ __global__ void __launch_bounds__(256) decode_attn_own_merge_kernel(const uint16
 #pragma unroll
         for (int u = 0; u < U; ++u) {
             const int t = t0 + 4 * u;
-            const int tt = t < n_rd ? t : (n_rd > 0 ? n_rd - 1 : 0);
+            const int tt = t < n_own ? t : n_own - 1;
             kv[u] = ld_stream(k_own + (size_t)tt * D);
             vv[u] = ld_stream(v_own + (size_t)tt * D);
-        }
-        if constexpr (ROPE) {
-#pragma unroll
-            for (int u = 0; u < U; ++u)
-                if (t0 + 4 * u == n_rd) { kv[u] = kn; vv[u] = vn; }
         }
 #pragma unroll
         for (int u = 0; u < U; ++u) {
@@ -1253,15 +1208,12 @@ __global__ void __launch_bounds__(256) prefix_fragments_kernel(const uint16_t* _
 
 // waves-per-SIMD hint 4: left alone the compiler hoists all 16 K (then V) fragment loads of a chunk and lands at 140
 // registers = 3 waves per SIMD; capped at 128 the pass is 10 % faster (tools/attn_probe.py: 314 -> 274 us per layer).
-// ROPE: q is the qkv projection (row stride q_ld = (H + 2 Hkv) D); the lane rotates its query fragments itself - the partner dims
-// (i, i + 64) of rotate_half are fragments ks and ks + 2 of the SAME lane - with rope_kv_kernel's roundings.
-template <int D, bool ROPE>
+template <int D>
 __global__ void __launch_bounds__(256, 2) decode_attn_prefix_mfma_kernel(const uint16_t* __restrict__ q, const uint16_t* __restrict__ frag,
                                                                       const GroupDesc* __restrict__ groups,
                                                                       const int* __restrict__ group_rows, const int4* __restrict__ items,
                                                                       float* __restrict__ ws, int H, int Hkv, long long pre_stride,
-                                                                      int pre_tmax, float scale, int nchunk, int sub, long long q_ld,
-                                                                      const int* __restrict__ pos, const float* __restrict__ cs_table) {
+                                                                      int pre_tmax, float scale, int nchunk, int sub) {
     static_assert(D == 128, "");
     constexpr int KS = D / 32, NT = D / 16;
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, ln = lane & 15, g = lane >> 4;
@@ -1279,31 +1231,9 @@ __global__ void __launch_bounds__(256, 2) decode_attn_prefix_mfma_kernel(const u
     const int qrow = group_rows[gd.row_off + rq];
     frag8_t qf[KS];
     {
-        const uint16_t* qp = q + (size_t)qrow * (size_t)q_ld + (size_t)head * D + g * 8;
+        const uint16_t* qp = q + ((size_t)qrow * H + head) * D + g * 8;
 #pragma unroll
         for (int ks = 0; ks < KS; ++ks) qf[ks] = *reinterpret_cast<const frag8_t*>(qp + ks * 32);
-        if constexpr (ROPE) {
-            const float* cs = cs_table + (size_t)pos[qrow] * (D / 2) * 2;
-#pragma unroll
-            for (int ks = 0; ks < KS / 2; ++ks) {          // pairs (32 ks + 8 g + e, + 64), e = 0 .. 7
-                const int pi = ks * 32 + g * 8;
-                float4 c[4];
-#pragma unroll
-                for (int qq = 0; qq < 4; ++qq) c[qq] = *reinterpret_cast<const float4*>(cs + pi * 2 + 4 * qq);
-                const uint4 a4 = __builtin_bit_cast(uint4, qf[ks]), b4 = __builtin_bit_cast(uint4, qf[ks + KS / 2]);
-                auto rot = [](uint32_t av, uint32_t bv, float cA, float sA, float cB, float sB, uint32_t& r0, uint32_t& r1) {
-                    const float a0 = lo(av), a1 = hi(av), b0 = lo(bv), b1 = hi(bv);
-                    r0 = pack(a0 * cA - b0 * sA, a1 * cB - b1 * sB);
-                    r1 = pack(b0 * cA + a0 * sA, b1 * cB + a1 * sB);
-                };
-                uint4 r0, r1;
-                rot(a4.x, b4.x, c[0].x, c[0].y, c[0].z, c[0].w, r0.x, r1.x);
-                rot(a4.y, b4.y, c[1].x, c[1].y, c[1].z, c[1].w, r0.y, r1.y);
-                rot(a4.z, b4.z, c[2].x, c[2].y, c[2].z, c[2].w, r0.z, r1.z);
-                rot(a4.w, b4.w, c[3].x, c[3].y, c[3].z, c[3].w, r0.w, r1.w);
-                qf[ks] = __builtin_bit_cast(frag8_t, r0); qf[ks + KS / 2] = __builtin_bit_cast(frag8_t, r1);
-            }
-        }
     }
     const uint16_t* fb = frag + 2 * ((size_t)gd.pslot * pre_stride + (size_t)kvh * pre_tmax * D) + (size_t)lane * 8;
     f32x4_t o[NT];
@@ -1647,46 +1577,29 @@ VDD_HIDDEN int VDD_IMPL(vdd_decode_attention_fused_split)(const void* qkv, const
     return ok(hipSuccess);
 }
 
-static int grouped_launch(const void* q, void* k_cache, void* v_cache, const void* k_prefix, const void* v_prefix,
-                          const void* prefix_frag, const int32_t* rows, const int32_t* groups, const int32_t* group_rows,
-                          const int32_t* items, int n_items, void* out, void* workspace, int M, int H, int Hkv, int D,
-                          int64_t slot_stride, int t_max, int64_t prefix_stride, int prefix_tmax, int max_prefix_len,
-                          int max_own_len, int prefix_chunks_per_item, float scale, const int32_t* pos, const int32_t* cpos,
-                          const int32_t* slot, const float* cos_sin, void* stream) {
+VDD_HIDDEN int VDD_IMPL(vdd_decode_attention_grouped)(const void* q, const void* k_cache, const void* v_cache, const void* k_prefix, const void* v_prefix,
+                                 const void* prefix_frag, const int32_t* rows, const int32_t* groups, const int32_t* group_rows,
+                                 const int32_t* items, int n_items, void* out, void* workspace, int M, int H, int Hkv, int D,
+                                 int64_t slot_stride, int t_max, int64_t prefix_stride, int prefix_tmax, int max_prefix_len,
+                                 int max_own_len, int prefix_chunks_per_item, float scale, void* stream) {
     if (M <= 0) return VDD_OK;
-    const bool rope = pos != nullptr;            // q is the qkv projection: RoPE + the KV write ride inside the two passes
     if (!q || !k_cache || !v_cache || !k_prefix || !v_prefix || !rows || !groups || !group_rows || !items || !out || !workspace || D != 128 ||
         H % Hkv != 0 || max_own_len <= 0 || max_prefix_len < 0 || n_items < 0 || n_items > 65535 || prefix_chunks_per_item < 1) return VDD_ERR_INVALID_ARG;
     if (n_items > 0 && (prefix_frag == nullptr || prefix_tmax % ATT_CH != 0)) return VDD_ERR_INVALID_ARG;     // the MFMA prefix pass reads the fragment-major image
-    if (rope && (!cpos || !slot || !cos_sin)) return VDD_ERR_INVALID_ARG;
-    if (rope && max_own_len > 256) return VDD_ERR_UNSUPPORTED;                 // long own ranges: vdd_rope_kv_write + the plain entry
     const int sub = prefix_chunks_per_item;                                     // it leaves one partial per item of `sub` 64-key chunks
     const int pre_keys = ATT_CH * sub;
     const int npre = (max_prefix_len + pre_keys - 1) / pre_keys, nown = (max_own_len + ATT_CH - 1) / ATT_CH;
     const int nchunk = npre + nown;
     hipStream_t st = (hipStream_t)stream;
     if (n_items > 0 && npre > 0) {
-        if (rope)
-            hipLaunchKernelGGL((decode_attn_prefix_mfma_kernel<128, true>), dim3((H + 3) / 4, n_items), dim3(256), 0, st,
-                               (const uint16_t*)q, (const uint16_t*)prefix_frag, (const GroupDesc*)groups, group_rows,
-                               (const int4*)items, (float*)workspace, H, Hkv, (long long)prefix_stride, prefix_tmax, scale, nchunk, sub,
-                               (long long)(H + 2 * Hkv) * D, pos, cos_sin);
-        else
-            hipLaunchKernelGGL((decode_attn_prefix_mfma_kernel<128, false>), dim3((H + 3) / 4, n_items), dim3(256), 0, st,
-                               (const uint16_t*)q, (const uint16_t*)prefix_frag, (const GroupDesc*)groups, group_rows,
-                               (const int4*)items, (float*)workspace, H, Hkv, (long long)prefix_stride, prefix_tmax, scale, nchunk, sub,
-                               (long long)H * D, (const int*)nullptr, (const float*)nullptr);
+        hipLaunchKernelGGL(decode_attn_prefix_mfma_kernel<128>, dim3((H + 3) / 4, n_items), dim3(256), 0, st,
+                           (const uint16_t*)q, (const uint16_t*)prefix_frag, (const GroupDesc*)groups, group_rows,
+                           (const int4*)items, (float*)workspace, H, Hkv, (long long)prefix_stride, prefix_tmax, scale, nchunk, sub);
     }
     if (max_own_len <= 256) {        // short own ranges: one wave per (row, head) finishes the row (own keys + prefix partials)
-        if (rope)
-            hipLaunchKernelGGL((decode_attn_own_merge_kernel<128, true>), dim3((H + 3) / 4, M), dim3(256), 0, st, (const uint16_t*)q,
-                               (uint16_t*)k_cache, (uint16_t*)v_cache, (const AttnRow*)rows, (const float*)workspace,
-                               (uint16_t*)out, H, Hkv, (long long)slot_stride, t_max, scale, nchunk, npre, pre_keys, pos, cpos, slot, cos_sin);
-        else
-            hipLaunchKernelGGL((decode_attn_own_merge_kernel<128, false>), dim3((H + 3) / 4, M), dim3(256), 0, st, (const uint16_t*)q,
-                               (uint16_t*)k_cache, (uint16_t*)v_cache, (const AttnRow*)rows, (const float*)workspace,
-                               (uint16_t*)out, H, Hkv, (long long)slot_stride, t_max, scale, nchunk, npre, pre_keys,
-                               (const int*)nullptr, (const int*)nullptr, (const int*)nullptr, (const float*)nullptr);
+        hipLaunchKernelGGL(decode_attn_own_merge_kernel<128>, dim3((H + 3) / 4, M), dim3(256), 0, st, (const uint16_t*)q,
+                           (const uint16_t*)k_cache, (const uint16_t*)v_cache, (const AttnRow*)rows, (const float*)workspace,
+                           (uint16_t*)out, H, Hkv, (long long)slot_stride, t_max, scale, nchunk, npre, pre_keys);
         return ok(hipSuccess);
     }
     hipLaunchKernelGGL(decode_attn_kernel<128>, dim3((H + 3) / 4, M, nown), dim3(256), 0, st, (const uint16_t*)q,
@@ -1696,28 +1609,6 @@ static int grouped_launch(const void* q, void* k_cache, void* v_cache, const voi
     hipLaunchKernelGGL(decode_attn_combine_kernel<128>, dim3((H + 3) / 4, M), dim3(256), 0, st, (const float*)workspace,
                        (const AttnRow*)rows, (uint16_t*)out, H, nchunk, npre, pre_keys);
     return ok(hipSuccess);
-}
-
-VDD_HIDDEN int VDD_IMPL(vdd_decode_attention_grouped)(const void* q, const void* k_cache, const void* v_cache, const void* k_prefix, const void* v_prefix,
-                                 const void* prefix_frag, const int32_t* rows, const int32_t* groups, const int32_t* group_rows,
-                                 const int32_t* items, int n_items, void* out, void* workspace, int M, int H, int Hkv, int D,
-                                 int64_t slot_stride, int t_max, int64_t prefix_stride, int prefix_tmax, int max_prefix_len,
-                                 int max_own_len, int prefix_chunks_per_item, float scale, void* stream) {
-    return grouped_launch(q, const_cast<void*>(k_cache), const_cast<void*>(v_cache), k_prefix, v_prefix, prefix_frag, rows, groups, group_rows, items,
-                          n_items, out, workspace, M, H, Hkv, D, slot_stride, t_max, prefix_stride, prefix_tmax, max_prefix_len, max_own_len,
-                          prefix_chunks_per_item, scale, nullptr, nullptr, nullptr, nullptr, stream);
-}
-
-VDD_HIDDEN int VDD_IMPL(vdd_decode_attention_grouped_rope)(const void* qkv, const int32_t* pos, const int32_t* cpos, const int32_t* slot, const float* cos_sin,
-                                 void* k_cache, void* v_cache, const void* k_prefix, const void* v_prefix,
-                                 const void* prefix_frag, const int32_t* rows, const int32_t* groups, const int32_t* group_rows,
-                                 const int32_t* items, int n_items, void* out, void* workspace, int M, int H, int Hkv, int D,
-                                 int64_t slot_stride, int t_max, int64_t prefix_stride, int prefix_tmax, int max_prefix_len,
-                                 int max_own_len, int prefix_chunks_per_item, float scale, void* stream) {
-    if (!pos) return VDD_ERR_INVALID_ARG;
-    return grouped_launch(qkv, k_cache, v_cache, k_prefix, v_prefix, prefix_frag, rows, groups, group_rows, items,
-                          n_items, out, workspace, M, H, Hkv, D, slot_stride, t_max, prefix_stride, prefix_tmax, max_prefix_len, max_own_len,
-                          prefix_chunks_per_item, scale, pos, cpos, slot, cos_sin, stream);
 }
 
 VDD_HIDDEN int VDD_IMPL(vdd_prefix_fragments)(const void* k_prefix, const void* v_prefix, void* prefix_frag, const int32_t* prefix_len_of_slot, int n_slots,

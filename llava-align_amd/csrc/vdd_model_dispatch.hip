@@ -73,14 +73,6 @@ VDD_MODEL_FN(vdd_decode_attention_grouped,
                    int max_own_len, int prefix_chunks_per_item, float scale),
              VDD_P(q, k_cache, v_cache, k_prefix, v_prefix, prefix_frag, rows, groups, group_rows, items, n_items, out, workspace, M, H, Hkv, D,
                    slot_stride, t_max, prefix_stride, prefix_tmax, max_prefix_len, max_own_len, prefix_chunks_per_item, scale))
-VDD_MODEL_FN(vdd_decode_attention_grouped_rope,
-             VDD_P(const void* qkv, const int32_t* pos, const int32_t* cpos, const int32_t* slot, const float* cos_sin, void* k_cache, void* v_cache,
-                   const void* k_prefix, const void* v_prefix, const void* prefix_frag,
-                   const int32_t* rows, const int32_t* groups, const int32_t* group_rows, const int32_t* items, int n_items, void* out, void* workspace,
-                   int M, int H, int Hkv, int D, int64_t slot_stride, int t_max, int64_t prefix_stride, int prefix_tmax, int max_prefix_len,
-                   int max_own_len, int prefix_chunks_per_item, float scale),
-             VDD_P(qkv, pos, cpos, slot, cos_sin, k_cache, v_cache, k_prefix, v_prefix, prefix_frag, rows, groups, group_rows, items, n_items, out, workspace,
-                   M, H, Hkv, D, slot_stride, t_max, prefix_stride, prefix_tmax, max_prefix_len, max_own_len, prefix_chunks_per_item, scale))
 VDD_MODEL_FN(vdd_prefix_fragments,
              VDD_P(const void* k_prefix, const void* v_prefix, void* prefix_frag, const int32_t* prefix_len_of_slot, int n_slots, int Hkv, int t_max, int D),
              VDD_P(k_prefix, v_prefix, prefix_frag, prefix_len_of_slot, n_slots, Hkv, t_max, D))

@@ -507,7 +507,6 @@ class LanguageModel:
         return self._head(a)
 
     fuse_norms = True         # few rows in flight: the RMSNorm launches ride inside the projections around them
-    fuse_rope = True          # grouped decode attention: RoPE + the KV write ride inside its two launches (no rope_kv launch per layer)
     # 1 - 4 rows: ALL decoder layers of the step in ONE persistent launch (ops.decode_layers, csrc/vdd_layer_persistent.hip).  Correct and
     # tested, but OFF: measured 120 - 126 us per 7B layer against 94 us for the five launches below - four activation all-gathers of
     # 8 - 22 MB per layer (256 CUs each sweeping the whole vector) and two local hops cost 55 us of waits, which the run-ahead weight
@@ -598,13 +597,11 @@ class LanguageModel:
                 att = ops.decode_attention_fused(qkv, pos, cpos, slot, self.cs, kv.ko[i], kv.vo[i], attn_rows, H, Hkv, D,
                                                  k_prefix=kv.kp[i], v_prefix=kv.vp[i])
             elif grouping is not None:    # rows sharing a prompt prefix attend it once per group (MFMA), own tokens per row
-                fused = self.fuse_rope and kv.t_own <= ops.GROUPED_ROPE_MAX_OWN     # RoPE + KV write inside the two attention launches
-                q = qkv if fused else ops.rope_kv_write(qkv, pos, slot, self.cs, kv.ko[i], kv.vo[i], H, Hkv, D, cpos=cpos)
+                q = ops.rope_kv_write(qkv, pos, slot, self.cs, kv.ko[i], kv.vo[i], H, Hkv, D, cpos=cpos)
                 att = ops.decode_attention_grouped(q, kv.ko[i], kv.vo[i], kv.kp[i], kv.vp[i], attn_rows, grouping["groups"],
                                                    grouping["group_rows"], grouping["items"], grouping["n_items"], H, Hkv, D,
                                                    kv.t_pre, kv.t_own, workspace=grouping["workspace"],
-                                                   prefix_frag=kv.pfrag[i], chunks_per_item=grouping["cpi"],
-                                                   rope=(pos, cpos, slot, self.cs) if fused else None)
+                                                   prefix_frag=kv.pfrag[i], chunks_per_item=grouping["cpi"])
             else:
                 q = ops.rope_kv_write(qkv, pos, slot, self.cs, kv.ko[i], kv.vo[i], H, Hkv, D, cpos=cpos)
                 att = ops.decode_attention(q, kv.ko[i], kv.vo[i], attn_rows, H, Hkv, D, k_prefix=kv.kp[i], v_prefix=kv.vp[i],
@@ -948,8 +945,9 @@ class VddLlavaEngine:
 
     # Distinct images per vision-tower forward.  The tower's GEMMs have K = 1,024 / 4,096 and N = 1,024 ... 4,096: at 16 images (9,232
     # rows) they are 148 - 592 tiles of 256 x 256 on 256 CUs and ran at 0.5 PF/s in the bench trace; at 64 images every product is
-    # 2 - 9 full rounds (tools/vit_batch_probe.py).  A full chunk replays a captured graph (VisionTower.GRAPH_SIZES).
-    VIT_CHUNK = 16
+    # 2 - 9 full rounds: 0.761 -> 0.568 ms per image (0.524 at 128; tools/vit_batch_probe.py, profiles/r05_vit_batch_probe.jsonl).  Chunks
+    # of VisionTower.GRAPH_SIZES images replay a captured graph; larger ones are GPU-bound issued from Python (same time either way).
+    VIT_CHUNK = 64
 
     def image_features(self, images: Sequence[torch.Tensor], keys: Optional[Sequence[int]] = None) -> List[torch.Tensor]:
         """ViT + projector per DISTINCT image (POPE: 6 questions share one image)."""

@@ -25,7 +25,6 @@ _SIGS = {
     "vdd_decode_attention": [_P, _P, _P, _P, _P, _P, _P, _P, _I, _I, _I, _I, _L, _I, _L, _I, _I, _F, _I, _P],
     "vdd_prefix_fragments": [_P, _P, _P, _P, _I, _I, _I, _I, _I, _P],
     "vdd_decode_attention_grouped": [_P, _P, _P, _P, _P, _P, _P, _P, _P, _P, _I, _P, _P, _I, _I, _I, _I, _L, _I, _L, _I, _I, _I, _I, _F, _I, _P],
-    "vdd_decode_attention_grouped_rope": [_P] * 14 + [_I, _P, _P, _I, _I, _I, _I, _L, _I, _L, _I, _I, _I, _I, _F, _I, _P],
     "vdd_flash_attention": [_P, _P, _P, _P, _P, _P, _P, _I, _I, _I, _I, _I, _L, _I, _L, _I, _F, _I, _I, _P],
     "vdd_flash_attention_packed": [_P, _P, _P, _P, _P, _P, _P, _P, _I, _I, _I, _I, _L, _I, _L, _I, _F, _I, _P],
     "vdd_layernorm": [_P, _P, _P, _P, _I, _I, _F, _I, _P],
@@ -749,15 +748,9 @@ def prefix_fragments(k_prefix, v_prefix, prefix_frag, prefix_len_of_slot):
     return prefix_frag
 
 
-GROUPED_ROPE_MAX_OWN = 256   # own ranges up to which RoPE + the KV write ride inside the grouped attention's two launches
-
-
 def decode_attention_grouped(q, k_cache, v_cache, k_prefix, v_prefix, rows, groups, group_rows, items, n_items,
-                             H, Hkv, D, max_prefix_len, max_own_len, out=None, workspace=None, prefix_frag=None, chunks_per_item=1, scale=None,
-                             rope=None):
-    """decode_attention with the shared prefixes attended once per group of rows (MFMA over the group's queries).
-    rope=(pos, cpos, slot, cos_sin): `q` is the qkv projection [M, (H + 2 Hkv) D]; the launch rotates q / k itself and writes the new
-    token's K / V into the caches (= rope_kv_write followed by the plain form, bit for bit; max_own_len <= GROUPED_ROPE_MAX_OWN)."""
+                             H, Hkv, D, max_prefix_len, max_own_len, out=None, workspace=None, prefix_frag=None, chunks_per_item=1, scale=None):
+    """decode_attention with the shared prefixes attended once per group of rows (MFMA over the group's queries)."""
     dt = _dt(q, k_cache, v_cache, k_prefix, v_prefix)
     M = q.shape[0]
     lib = _lib_ready()
@@ -770,19 +763,6 @@ def decode_attention_grouped(q, k_cache, v_cache, k_prefix, v_prefix, rows, grou
             raise ValueError("attention workspace too small")
         ws = torch.empty((need + 3) // 4, dtype=torch.float32, device=q.device)
         _attn_ws[(q.device,)] = ws
-    if rope is not None:
-        pos, cpos, slot, cos_sin = rope
-        if q.shape[1] != (H + 2 * Hkv) * D or not q.is_contiguous():
-            raise ValueError("decode_attention_grouped(rope=...): q must be the contiguous qkv projection [M, (H + 2 Hkv) D]")
-        out = torch.empty(M, H * D, dtype=q.dtype, device=q.device) if out is None else out
-        _lib.check(lib.vdd_decode_attention_grouped_rope(q.data_ptr(), pos.data_ptr(), cpos.data_ptr(), slot.data_ptr(), cos_sin.data_ptr(),
-                                                         k_cache.data_ptr(), v_cache.data_ptr(), k_prefix.data_ptr(), v_prefix.data_ptr(),
-                                                         prefix_frag.data_ptr() if prefix_frag is not None else None, rows.data_ptr(), groups.data_ptr(),
-                                                         group_rows.data_ptr(), items.data_ptr(), n_items, out.data_ptr(), ws.data_ptr(), M, H, Hkv, D,
-                                                         k_cache.stride(0), k_cache.shape[2], k_prefix.stride(0), k_prefix.shape[2],
-                                                         int(max_prefix_len), int(max_own_len), int(chunks_per_item),
-                                                         D ** -0.5 if scale is None else scale, dt, _st(q)))
-        return out
     out = torch.empty_like(q) if out is None else out
     _lib.check(lib.vdd_decode_attention_grouped(q.data_ptr(), k_cache.data_ptr(), v_cache.data_ptr(), k_prefix.data_ptr(), v_prefix.data_ptr(),
                                                 prefix_frag.data_ptr() if prefix_frag is not None else None, rows.data_ptr(), groups.data_ptr(), group_rows.data_ptr(), items.data_ptr(), n_items,

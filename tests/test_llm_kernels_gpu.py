@@ -382,57 +382,6 @@ def test_grouped_prefix_decode_attention_equals_per_row():
         assert torch.allclose(b[m].view(H, D).float(), ref, rtol=2e-2, atol=2e-2), m
 
 
-def test_grouped_attention_with_rope_and_kv_write_inside_equals_the_two_calls():
-    """vdd_decode_attention_grouped_rope (qkv in: the prefix pass rotates the queries it loads, the own pass rotates q / k, writes the new
-    token's K / V and attends it from registers) == vdd_rope_kv_write + vdd_decode_attention_grouped, bit for bit: output AND caches.
-    GQA (two query heads per KV head), own ranges of 1 .. 128 keys, groups of 1 / 6 / 21 rows, rows without a prefix."""
-    O = ops()
-    dt = DT
-    H, Hkv, D = 8, 4, 128
-    mk = lambda *shape, seed: bf(*shape, scale=0.7, seed=seed)
-    kp, vp = mk(3, Hkv, 640, D, seed=41), mk(3, Hkv, 640, D, seed=42)
-    ko0, vo0 = mk(40, Hkv, 128, D, seed=43), mk(40, Hkv, 128, D, seed=44)
-    rows, groups, grp_rows = [], [], []
-    for i in range(6):
-        rows.append([i, 611 + 20 + i, 0, 611])
-    groups.append([0, 6, 0, 611]); grp_rows += list(range(0, 6))
-    for i in range(21):
-        rows.append([6 + i, 36 + 5 + 3 * i, 2, 36])
-    groups.append([6, 21, 2, 36]); grp_rows += list(range(6, 27))
-    rows.append([27, 36 + 128, 2, 36]); groups.append([27, 1, 2, 36]); grp_rows.append(27)     # a full own slot (128 keys), group of one
-    rows += [[28, 90, 0, 0], [29, 1, 0, 0]]                                                   # no prefix: 90 own keys; the new token alone
-    perm = torch.randperm(len(rows), generator=torch.Generator().manual_seed(1)).tolist()
-    inv = {old: new for new, old in enumerate(perm)}
-    rows_p = [rows[o] for o in perm]
-    M = len(rows)
-    rt = torch.tensor(rows_p, dtype=torch.int32, device=DEV)
-    gt = torch.tensor(groups, dtype=torch.int32, device=DEV)
-    gr = torch.tensor([inv[r] for r in grp_rows], dtype=torch.int32, device=DEV)
-    qkv = mk(M, (H + 2 * Hkv) * D, seed=46)
-    pos = torch.tensor([r[1] - 1 for r in rows_p], dtype=torch.int32, device=DEV)              # rotary position of the new token
-    cpos = torch.tensor([r[1] - r[3] - 1 for r in rows_p], dtype=torch.int32, device=DEV)      # its index inside the own slot
-    slot = torch.tensor([r[0] for r in rows_p], dtype=torch.int32, device=DEV)
-    t = torch.arange(1024, dtype=torch.float32)[:, None] * (10000.0 ** (-torch.arange(0, D, 2, dtype=torch.float32) / D))[None]
-    cs = torch.stack([t.cos(), t.sin()], -1).contiguous().to(DEV)                              # [max_pos, D/2, 2]
-    pf = torch.zeros((kp.shape[0], Hkv, 2 * 640, D), dtype=dt, device=DEV)
-    O.prefix_fragments(kp, vp, pf, torch.tensor([611, 0, 36], dtype=torch.int32, device=DEV))
-    for cpi in (1, 4):
-        items = torch.tensor(O.prefix_work_items(groups, cpi), dtype=torch.int32, device=DEV)
-        ka, va = ko0.clone(), vo0.clone()
-        q = O.rope_kv_write(qkv, pos, slot, cs, ka, va, H, Hkv, D, cpos=cpos)
-        a = O.decode_attention_grouped(q, ka, va, kp, vp, rt, gt, gr, items, items.shape[0], H, Hkv, D, 611, 128, prefix_frag=pf,
-                                       chunks_per_item=cpi)
-        kb, vb = ko0.clone(), vo0.clone()
-        b = O.decode_attention_grouped(qkv, kb, vb, kp, vp, rt, gt, gr, items, items.shape[0], H, Hkv, D, 611, 128, prefix_frag=pf,
-                                       chunks_per_item=cpi, rope=(pos, cpos, slot, cs))
-        assert torch.equal(ka, kb) and torch.equal(va, vb), cpi
-        assert not torch.equal(ka, ko0)
-        assert torch.equal(a, b), cpi
-    with pytest.raises(RuntimeError):                  # own ranges past 256 keys keep the separate RoPE launch
-        O.decode_attention_grouped(qkv, kb, vb, kp, vp, rt, gt, gr, items, items.shape[0], H, Hkv, D, 611, 320, prefix_frag=pf,
-                                   chunks_per_item=4, rope=(pos, cpos, slot, cs))
-
-
 def _gemm_ref(x, w, epi, bias, resid):
     """Plain fp32 PyTorch restatement of vdd_gemm's epilogues, bf16 rounding where the HF modules round."""
     O = ops()
