@@ -981,8 +981,12 @@ class VddLlavaEngine:
         buffers: 0.4 s per 128 images, a tenth of the batch time (`pcie_inclusive` on the bench line)."""
         if not ims or ims[0].is_cuda or any(im.is_cuda or im.dtype != ims[0].dtype or im.shape != ims[0].shape for im in ims):
             return None
-        key = (ims[0].dtype, tuple(ims[0].shape))
+        key = (ims[0].dtype, tuple(ims[0].shape), self.VIT_CHUNK)
         if getattr(self, "_pin_key", None) != key:
+            if getattr(self, "_pin_used", None):                 # uploads still reading the buffers about to be dropped
+                for b_, used in enumerate(self._pin_used):
+                    if used:
+                        self._pin_done[b_].synchronize()
             self._pin = [torch.empty((self.VIT_CHUNK,) + key[1], dtype=key[0], pin_memory=True) for _ in range(2)]
             self._pin_done = [torch.cuda.Event() for _ in range(2)]
             self._pin_key = key
@@ -1120,11 +1124,11 @@ class VddLlavaEngine:
         feats_cd = None
         if use_cd and inputs_embeds is None:
             imgs_cd = [images_cd[i] for i in range(Q)] if torch.is_tensor(images_cd) else list(images_cd)
-            # the noised copies differ per question (fresh noise, llava_calibrate.py:152-155): no feature cache, but full tower batches
-            # of 16 (the captured-graph size) instead of one launch chain per question
+            # the noised copies differ per question (fresh noise, llava_calibrate.py:152-155): no feature cache, but full tower chunks
+            # instead of one launch chain per question
             feats_cd = []
-            for i0 in range(0, Q, VisionTower.GRAPH_BATCH):
-                chunk = [im.reshape(im.shape[-3:]).to(dev) for im in imgs_cd[i0:i0 + VisionTower.GRAPH_BATCH]]
+            for i0 in range(0, Q, self.VIT_CHUNK):
+                chunk = [im.reshape(im.shape[-3:]).to(dev) for im in imgs_cd[i0:i0 + self.VIT_CHUNK]]
                 feats_cd += list(self.vit(torch.stack(chunk)))
         if inputs_embeds is not None:
             main_dev = [e.to(dev, self.dtype) for e in emb_main]

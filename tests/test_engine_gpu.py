@@ -360,19 +360,31 @@ def test_vit_graph_replay_equals_eager_forward():
 
 def test_host_images_through_the_pinned_staging_buffers_equal_device_images():
     """CPU image tensors (what the reference's drivers hand to generate()) are stacked into two pinned staging buffers and uploaded
-    asynchronously, 16 at a time: 40 images = three chunks, so the first buffer is reused while its upload may still be in
-    flight.  Same features as the same images already on the device, repeatedly, and in fp16 as well as fp32."""
+    asynchronously, VIT_CHUNK at a time: 2 chunks + 8 images = three chunks, so the first buffer is reused while its upload may
+    still be in flight.  Same features as the same images already on the device, repeatedly, and in fp16 as well as fp32.  The chunk
+    size itself is transparent up to the GEMM schedule (a 16-image and a 64-image forward cut K differently: rounding-sized)."""
     from llava_align_amd.engine import LlavaWeights, VddLlavaEngine, preset
     cfg = preset("tiny")
     e = VddLlavaEngine(cfg, weights=LlavaWeights.random(cfg, DEV, seed=3, std=0.06), device=DEV, use_graph=True)
+    assert e.VIT_CHUNK == 64
     g = torch.Generator().manual_seed(9)
-    for dt in (torch.float32, torch.float16):
-        for rep in range(2):
-            host = [torch.randn(3, cfg.vision.image, cfg.vision.image, generator=g).to(dt) for _ in range(40)]
-            dev = [im.to(DEV) for im in host]
-            fh, fd = e.image_features(host), e.image_features(dev)
-            assert all(torch.equal(a, b) for a, b in zip(fh, fd)), (dt, rep)
-    assert e._pin[0].is_pinned() and e._pin_key[0] == torch.float16
+    for chunk in (16, 64):
+        e.VIT_CHUNK = chunk
+        n = 2 * chunk + 8
+        for dt in (torch.float32, torch.float16):
+            for rep in range(2):
+                host = [torch.randn(3, cfg.vision.image, cfg.vision.image, generator=g).to(dt) for _ in range(n)]
+                dev = [im.to(DEV) for im in host]
+                fh, fd = e.image_features(host), e.image_features(dev)
+                assert all(torch.equal(a, b) for a, b in zip(fh, fd)), (chunk, dt, rep)
+        assert e._pin[0].is_pinned() and e._pin[0].shape[0] == chunk and e._pin_key[0] == torch.float16
+    e.VIT_CHUNK = 16
+    f16 = e.image_features(dev)
+    e.VIT_CHUNK = 64
+    f64 = e.image_features(dev)
+    err = max(float((a.float() - b.float()).abs().max()) for a, b in zip(f16, f64))
+    ref = max(float(a.float().abs().max()) for a in f16)
+    assert err <= 2e-2 * ref, (err, ref)
 
 
 def test_captured_steps_survive_a_later_larger_batch():
