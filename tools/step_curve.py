@@ -21,9 +21,9 @@ for nq in points:
         torch.cuda.synchronize()
         ts = []
         for _ in range(5):
-            t0 = time.perf_counter(); eng.generate(ids, max_new_tokens=n_new, **kw); torch.cuda.synchronize(); ts.append(time.perf_counter() - t0)
-        return min(ts)            # host pauses only ever add time (a median of three still moved single points by 1 ms)
-    t64, t32 = timed(64), timed(32)
+            t0 = time.perf_counter(); out = eng.generate(ids, max_new_tokens=n_new, **kw); torch.cuda.synchronize(); ts.append(time.perf_counter() - t0)
+        return min(ts), out.stats      # host pauses only ever add time (a median of three still moved single points by 1 ms)
+    (t64, st), (t32, _) = timed(64), timed(32)
     step = (t64 - t32) / 32
     print(json.dumps({"questions": nq, "rows": 2 * nq, "ms_per_step": round(step * 1e3, 3), "us_per_row": round(step * 1e6 / (2 * nq), 1),
-                      "decode_tokens_per_s": round(nq / step, 1)}), flush=True)
+                      "decode_tokens_per_s": round(nq / step, 1), "captured_step": bool(st.get("graph")), "n_groups": st.get("n_groups")}), flush=True)
