@@ -515,8 +515,8 @@ def main():
         roof = kernel_point(dev, 4096, 32000)
         roof_extra = [kernel_point(dev, 4096, 32000, beta=1e-6, iters=50), kernel_point(dev, 1024, 151936, iters=50),
                       kernel_point(dev, 1024, 151936, scores=False, iters=50),
-                      # 768 rows are resident at a time (3 workgroups x 256 CUs): 1,024 rows = one full round + a third of one.  The same
-                      # shape at a multiple of 768 shows the kernel without that quantisation (tools: profiles/r04_kernel_v151936_by_batch.jsonl)
+                      # rows that stay in global memory run four workgroups per CU since round 5 (1,024 resident rows: one round at B = 1,024;
+                      # before: 768 resident, 105 us -> 94 us); 3,072 rows = three full rounds (profiles/r05_kernel_points_qwen.jsonl)
                       kernel_point(dev, 3072, 151936, scores=False, iters=30),
                       # the launches the ENGINE makes on the headline workload: one row per question (768) - and 1,536 for a batch twice
                       # the size; 768 rows are exactly one resident round (3 workgroups x 256 CUs), so launch overhead and the ramp of a

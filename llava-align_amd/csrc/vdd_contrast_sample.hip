@@ -430,7 +430,12 @@ __device__ __forceinline__ void mask_below_key(const Row<DT, L>& R, int nch, uin
 
 // ------------------------------------------------------------------ the kernel
 template <int DT, bool LDSROW, bool PROC>
-__global__ void __launch_bounds__(BLOCK, 6) vdd_contrast_sample_kernel(KP p) {
+// Waves per SIMD: 6 = three workgroups per CU for the rows that live in LDS (40 KiB each at V = 32000: LDS is the limit anyway).  Rows that
+// stay in global memory (V = 151,936) hold no LDS row, and three workgroups per CU made 768 rows a round: 1,024 rows cost two.  Their
+// plain instance is built for 8 waves per SIMD (64 registers, 18 - 70 spilled into the L1-resident scratch): four workgroups per CU,
+// V = 151,936 without scores at 1,024 rows 105 -> 94 us, at 3,072 rows 250 -> 237 us (tools/kernel_points_qwen.py).  The processor
+// instance of those rows would spill 270 registers: it keeps 6.
+__global__ void __launch_bounds__(BLOCK, (LDSROW || PROC) ? 6 : 8) vdd_contrast_sample_kernel(KP p) {
     constexpr int EPC = Tr<DT>::EPC;
     constexpr uint32_t NINF = Tr<DT>::NEG_INF;
     extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
