@@ -160,6 +160,20 @@ def test_norm_fused_row_limit_follows_the_lds_budget():
     assert [ops.norm_fused_rows(d) for d in (4096, 5120, 8192, 2048, 16384, 4000)] == [16, 14, 8, 16, 0, 0]
 
 
+def test_one_launch_attention_band_and_its_batch_invariant_form():
+    """Ungrouped decode steps take the one-launch RoPE + KV write + attention kernel up to 32 rows (round 5: tools/few_row_curve.py); with
+    GEMM_BATCH_INVARIANT the band stays at the 16 rows of the few-row layer, so a batch that shrinks through 17 - 32 rows (row retirement)
+    keeps summing its keys in one order."""
+    from llava_align_amd import ops
+    assert ops.FUSED_ATTN_MAX_M == 16 and ops.FUSED_ATTN_UNGROUPED_MAX_M == 32 and ops.fused_attention_rows() == 32
+    old = ops.GEMM_BATCH_INVARIANT
+    try:
+        ops.GEMM_BATCH_INVARIANT = True
+        assert ops.fused_attention_rows() == 16
+    finally:
+        ops.GEMM_BATCH_INVARIANT = old
+
+
 def test_in_tree_gemm_defaults_are_bound_to_the_kernel_source():
     """ADVICE r4: gemm_choices_mi355x.json carries the hash of the GEMM kernel SOURCE it was measured on (ops.gemm_source_fingerprint);
     a kernel edit without re-measuring (or re-stamping) the defaults fails here instead of silently shipping stale picks."""
