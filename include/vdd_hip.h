@@ -205,6 +205,25 @@ int vdd_skinny_gemm_normed(const void* H, const float* ss, int nss, const void* 
 int vdd_skinny_swiglu_normed(const void* H, const float* ss, int nss, const void* ln_w, float eps, const void* W_gate_up, void* act,
                              int M, int F, int K, int64_t ldh, int dtype, void* hip_stream);
 
+/* The same three projections for 17 - 64 rows in flight (the per-rank batch of an 8-GPU split of LLaVA-Bench / a 4-GPU split of POPE:
+ * experiments/eval/MME/run_llava.py:32-40, experiments/eval/llava_sampling.py:100-116), csrc/vdd_skinny_slab.hip: the grid is the CU
+ * count, a workgroup owns a range of 16-column tiles of W and ONE slab of K, stages X[:, slab] once into LDS (normalised on the way
+ * when `ss` is given), streams W global -> registers -> MFMA, and the last of a tile's KS arrivals adds the fp32 slabs in slab order
+ * and runs the epilogue (deterministic; nobody waits for anybody).
+ *   ss / nss / ln_w / eps   NULL / 0: X is the input as is.  Else X is the un-normalised residual stream H (row length K) and the
+ *                           staging applies bf16(bf16(h * rstd) * ln_w[k]), rstd = rsqrt(sum(ss[row][0 .. nss)) / K + eps); nss % 16 == 0.
+ *   swiglu = 0              Y[M, N] = bf16(X W^T) (+ R, rounded again: the new residual stream); ss_out (or NULL) [M, ceil(N / 16)]:
+ *                           sums of squares of the 16 columns of each tile of the rows of Y - the `ss` of the next call.
+ *   swiglu = 1              W = [Wg; Wu] ([2 N, K]), Y[M, N] = silu(X Wg^T) * (X Wu^T) with the rounding points of vdd_skinny_swiglu;
+ *                           R and ss_out must be NULL.
+ * K % 32 == 0, ldx % 8 == 0, 1 <= M <= 64.  workspace: vdd_skinny_slab_workspace_bytes(M, N, K, swiglu) bytes (-1: shape not served,
+ * the call would return VDD_ERR_UNSUPPORTED), ZEROED once by the caller (tile tickets, left zero by every completed launch); launches
+ * that may overlap (different streams) need their own. */
+int64_t vdd_skinny_slab_workspace_bytes(int M, int N, int K, int swiglu);
+int vdd_skinny_slab(const void* X, const float* ss, int nss, const void* ln_w, float eps, const void* W, const void* R, void* Y,
+                    float* ss_out, int M, int N, int K, int64_t ldx, int64_t ldr, int64_t ldy, int swiglu, void* workspace,
+                    int64_t workspace_bytes, int dtype, void* hip_stream);
+
 /* ALL decoder layers of one decode step for 1 - 4 rows (one or two questions x their branches in flight: the reference's own
  * operating point, llava_calibrate.py:130,161-177 / llava_llama.py:88-103) as ONE persistent launch (csrc/vdd_layer_persistent.hip):
  * per CU four weight-streaming waves (a four-batch register pipeline that runs ahead across op and layer boundaries) and four

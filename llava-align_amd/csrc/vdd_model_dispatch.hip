@@ -45,6 +45,10 @@ VDD_MODEL_FN(vdd_skinny_gemm_normed,
 VDD_MODEL_FN(vdd_skinny_swiglu_normed,
              VDD_P(const void* H, const float* ss, int nss, const void* ln_w, float eps, const void* W_gate_up, void* act, int M, int F, int K, int64_t ldh),
              VDD_P(H, ss, nss, ln_w, eps, W_gate_up, act, M, F, K, ldh))
+VDD_MODEL_FN(vdd_skinny_slab,
+             VDD_P(const void* X, const float* ss, int nss, const void* ln_w, float eps, const void* W, const void* R, void* Y, float* ss_out, int M, int N,
+                   int K, int64_t ldx, int64_t ldr, int64_t ldy, int swiglu, void* workspace, int64_t workspace_bytes),
+             VDD_P(X, ss, nss, ln_w, eps, W, R, Y, ss_out, M, N, K, ldx, ldr, ldy, swiglu, workspace, workspace_bytes))
 VDD_MODEL_FN(vdd_gemm,
              VDD_P(const void* X, const void* W, void* Y, const void* bias, const void* resid, int M, int N, int K, int64_t ldx, int64_t ldw, int64_t ldy,
                    int64_t ldr, int epilogue, int config, void* workspace, int64_t workspace_bytes),
@@ -123,8 +127,10 @@ int64_t vdd_decode_layers_workspace_bytes(int M, int d, int H, int F, int D, int
 
 // workspace sizes do not depend on the storage type (fp32 partials, int32 counters): one instantiation answers
 VDD_HIDDEN int64_t vdd_gemm_workspace_bytes_bf16(int M, int N);
+VDD_HIDDEN int64_t vdd_skinny_slab_workspace_bytes_bf16(int M, int N, int K, int swiglu);
 VDD_HIDDEN int64_t vdd_decode_attention_workspace_bytes_bf16(int M, int H, int D, int max_len);
 VDD_HIDDEN int64_t vdd_decode_attention_fused_split_workspace_bytes_bf16(int M, int H, int n_split);
+int64_t vdd_skinny_slab_workspace_bytes(int M, int N, int K, int swiglu) { return vdd_skinny_slab_workspace_bytes_bf16(M, N, K, swiglu); }
 int64_t vdd_gemm_workspace_bytes(int M, int N) { return vdd_gemm_workspace_bytes_bf16(M, N); }
 int64_t vdd_decode_attention_workspace_bytes(int M, int H, int D, int max_len) { return vdd_decode_attention_workspace_bytes_bf16(M, H, D, max_len); }
 int64_t vdd_decode_attention_fused_split_workspace_bytes(int M, int H, int n_split) {

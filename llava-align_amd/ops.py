@@ -37,6 +37,7 @@ _SIGS = {
     "vdd_skinny_gemm_resid_ss": [_P, _P, _P, _P, _P, _I, _I, _I, _L, _L, _L, _I, _P],
     "vdd_skinny_gemm_normed": [_P, _P, _I, _P, _F, _P, _P, _I, _I, _I, _L, _L, _I, _P],
     "vdd_skinny_swiglu_normed": [_P, _P, _I, _P, _F, _P, _P, _I, _I, _I, _L, _I, _P],
+    "vdd_skinny_slab": [_P, _P, _I, _P, _F, _P, _P, _P, _P, _I, _I, _I, _L, _L, _L, _I, _P, _L, _I, _P],
     "vdd_stop_words_match": [_P, _L, _L, _P, _P, _I, _P, _P, _I, _P, _I, _P],
     "vdd_decode_layers": [_P, _I, _P, _P, _P, _P, _P, _P, _P, _P, _I, _I, _I, _I, _I, _I, _F, _F, _L, _I, _L, _I, _I, _P, _L, _I, _P],
     "vdd_repetition_penalty": [_P, _L, _I, _I, _I, _P, _I, _P, _L, _L, _P, _F, C.c_uint32, _P],
@@ -241,6 +242,55 @@ def swiglu_linear_normed(h, ss, ln_w, eps, w_gate_up, out=None):
     _lib.check(_lib_ready().vdd_skinny_swiglu_normed(h.data_ptr(), ss.data_ptr(), ss.shape[1], ln_w.data_ptr(), eps, w_gate_up.data_ptr(),
                                                      out.data_ptr(), M, F, K, h.stride(0), dt, _st(h)))
     return out
+
+
+# ---------------------------------------------------------------- 17 - 64 rows: K cut over workgroups (csrc/vdd_skinny_slab.hip)
+SLAB_MIN_M, SLAB_MAX_M = 17, 64     # rows the slab projections take in the decoder layer (below: the <= 16-row kernels above)
+_slab_ws = {}
+
+
+def _slab_workspace(device, nbytes):
+    """Tile tickets + fp32 partial slabs of the slab projections, one per (device, STREAM) like the GEMM's scratch: launches on one
+    stream are ordered and share it; the tickets start at zero and every completed launch leaves them zero."""
+    key = (torch.device(device).index, torch.cuda.current_stream(device).cuda_stream)
+    ws = _slab_ws.get(key)
+    if ws is None or ws.numel() < nbytes:
+        if torch.cuda.is_current_stream_capturing():
+            raise RuntimeError("the slab workspace must exist before a graph capture (run the step once eagerly on this stream)")
+        ws = _slab_ws[key] = torch.zeros(max(int(nbytes), 48 << 20), dtype=torch.uint8, device=device)
+    return ws
+
+
+def slab_workspace_reset():
+    _slab_ws.clear()
+
+
+def slab_serves(M, N, K, swiglu=False) -> bool:
+    lib = _lib_ready()
+    lib.vdd_skinny_slab_workspace_bytes.argtypes, lib.vdd_skinny_slab_workspace_bytes.restype = [_I, _I, _I, _I], C.c_int64
+    return lib.vdd_skinny_slab_workspace_bytes(M, N, K, int(swiglu)) >= 0
+
+
+def slab_linear(x, w, resid=None, ss=None, ln_w=None, eps=0.0, swiglu=False, want_ss=False, out=None, workspace=None):
+    """x [M <= 64, K] @ w[N, K]^T on the slab kernels.  ss / ln_w: x is the un-normalised residual stream, normalised as it is staged
+    (ss [M, nss] partial sums of squares from a previous call with want_ss).  resid: y = rnd(rnd(x w^T) + resid).  swiglu: w = [Wg; Wu],
+    y = silu(x Wg^T) * (x Wu^T).  want_ss: also returns ss_out [M, ceil(N / 16)].  A captured step passes its own `workspace`."""
+    dt = _dt(x, w, resid, ln_w)
+    M, K = x.shape
+    N = w.shape[0] // 2 if swiglu else w.shape[0]
+    lib = _lib_ready()
+    lib.vdd_skinny_slab_workspace_bytes.argtypes, lib.vdd_skinny_slab_workspace_bytes.restype = [_I, _I, _I, _I], C.c_int64
+    need = lib.vdd_skinny_slab_workspace_bytes(M, N, K, int(swiglu))
+    if need < 0:
+        raise ValueError(f"slab_linear: shape M={M} N={N} K={K} is not served")
+    ws = _slab_workspace(x.device, need) if workspace is None else workspace
+    out = torch.empty(M, N, dtype=x.dtype, device=x.device) if out is None else out
+    ss_out = torch.empty(M, (N + 15) // 16, dtype=torch.float32, device=x.device) if want_ss else None
+    _lib.check(lib.vdd_skinny_slab(x.data_ptr(), ss.data_ptr() if ss is not None else None, ss.shape[1] if ss is not None else 0,
+                                   ln_w.data_ptr() if ss is not None else None, eps, w.data_ptr(), resid.data_ptr() if resid is not None else None,
+                                   out.data_ptr(), ss_out.data_ptr() if want_ss else None, M, N, K, x.stride(0),
+                                   resid.stride(0) if resid is not None else 0, out.stride(0), int(swiglu), ws.data_ptr(), ws.numel(), dt, _st(x)))
+    return (out, ss_out) if want_ss else out
 
 
 # ---------------------------------------------------------------- persistent few-row decode layers (csrc/vdd_layer_persistent.hip)
