@@ -537,9 +537,11 @@ __global__ void __launch_bounds__(NW * 64) skinny_gemm_kernel(const uint16_t* __
         __builtin_amdgcn_sched_barrier(0);
     };
     uint16_t rpre[4] = {0, 0, 0, 0};                    // MT == 1: wave 0's residual entries, fetched under the weight stream
-    if constexpr (MT == 1) {
+    if constexpr (MT <= 2) {     // up to 32 rows: two register stages (MT = 2: 2 x (32 + 64) registers; a single stage paid one memory round
+                                 // trip per batch - 11 in a row for the down projection's 2,752-deep wave slices: 33.3 -> 26.6 us for its 90 MB at 17
+                                 // rows, 34.3 -> 33.8 at 32; eight waves per block with two stages: 29.6 / 37.6, tools/skinny_crossover_probe.py)
         if (nit > 0) ld(b0, a0, g0, 0);
-        if (R != nullptr && wave == 0 && Yslab == nullptr) {
+        if (MT == 1 && R != nullptr && wave == 0 && Yslab == nullptr) {
 #pragma unroll
             for (int r = 0; r < 4; ++r) { const int row = g * 4 + r, col = n0 + ln; if (row < M && col < N) rpre[r] = R[(size_t)row * ldr + col]; }
         }
@@ -552,7 +554,7 @@ __global__ void __launch_bounds__(NW * 64) skinny_gemm_kernel(const uint16_t* __
             mm(b1, a1, g1);
         }
         if (it < nit) mm(b0, a0, g0);
-    } else {            // 32 - 64 rows: the X fragments alone are 64 - 128 registers per batch; one stage
+    } else {            // 33 - 64 rows: the X fragments alone are 96 - 128 registers per batch; one stage
         for (int it = 0; it < nit; ++it) { ld(b0, a0, g0, it * 32 * U); mm(b0, a0, g0); }
     }
     // the K slice's remainder (K = 11008 over 8 waves: 1376 = 5 batches + 96): ONE more batch whose loads all go out together, the
@@ -1444,19 +1446,20 @@ static int skinny_gemm_launch(const void* X, const void* W, const void* R, void*
     if (M > 16 && n_split == 1 && Y != nullptr && K % 256 == 0 && N > 8192) {          // 17 - 64 rows, wide outputs: 32 columns per block
         const int mt = (M + 15) / 16;
         const dim3 g2((N + 31) / 32);
-#define VDD_WIDE(MT)                                                                                                                   \
+#define VDD_WIDE(MT, NW)                                                                                                               \
         do {                                                                                                                           \
-            constexpr int smem = 4 * MT * 2 * 64 * 4 * (int)sizeof(float);                                                             \
+            constexpr int smem = NW * MT * 2 * 64 * 4 * (int)sizeof(float);                                                            \
             static bool attr = false;                                                                                                  \
-            if (!attr) { (void)hipFuncSetAttribute((const void*)skinny_wide_kernel<MT, 4, false>, hipFuncAttributeMaxDynamicSharedMemorySize, smem); attr = true; } \
-            hipLaunchKernelGGL((skinny_wide_kernel<MT, 4, false>), g2, dim3(256), smem, st, x, w, r, y, M, N, K, (long long)ldx, (long long)ldr, (long long)ldy); \
+            if (!attr) { (void)hipFuncSetAttribute((const void*)skinny_wide_kernel<MT, NW, false>, hipFuncAttributeMaxDynamicSharedMemorySize, smem); attr = true; } \
+            hipLaunchKernelGGL((skinny_wide_kernel<MT, NW, false>), g2, dim3(NW * 64), smem, st, x, w, r, y, M, N, K, (long long)ldx, (long long)ldr, (long long)ldy); \
         } while (0)
-        if (mt == 2) VDD_WIDE(2); else if (mt == 3) VDD_WIDE(3); else VDD_WIDE(4);
+        if (mt == 2) VDD_WIDE(2, 4); else if (mt == 3) VDD_WIDE(3, 4); else VDD_WIDE(4, 4);
 #undef VDD_WIDE
         return ok(hipSuccess);
     }
     if (M <= 16 && n_split == 1 && N <= 8192 && K % 256 == 0) VDD_SKINNY(1, 8);
-    else if (M <= 16) VDD_SKINNY(1, 4); else if (M <= 32) VDD_SKINNY(2, 4); else VDD_SKINNY(4, 4);
+    else if (M <= 16) VDD_SKINNY(1, 4);
+    else if (M <= 32) VDD_SKINNY(2, 4); else VDD_SKINNY(4, 4);
 #undef VDD_SKINNY
     return ok(hipSuccess);
 }
@@ -1473,15 +1476,15 @@ static int skinny_swiglu_launch(const void* X, const void* W, void* act, int M, 
         const int mt = (M + 15) / 16;
         const dim3 g2((F + 15) / 16);
         hipStream_t st = (hipStream_t)stream;
-#define VDD_WIDE(MT)                                                                                                                   \
+#define VDD_WIDE(MT, NW)                                                                                                               \
         do {                                                                                                                           \
-            constexpr int smem = 4 * MT * 2 * 64 * 4 * (int)sizeof(float);                                                             \
+            constexpr int smem = NW * MT * 2 * 64 * 4 * (int)sizeof(float);                                                            \
             static bool attr = false;                                                                                                  \
-            if (!attr) { (void)hipFuncSetAttribute((const void*)skinny_wide_kernel<MT, 4, true>, hipFuncAttributeMaxDynamicSharedMemorySize, smem); attr = true; } \
-            hipLaunchKernelGGL((skinny_wide_kernel<MT, 4, true>), g2, dim3(256), smem, st, (const uint16_t*)X, (const uint16_t*)W, (const uint16_t*)nullptr, \
+            if (!attr) { (void)hipFuncSetAttribute((const void*)skinny_wide_kernel<MT, NW, true>, hipFuncAttributeMaxDynamicSharedMemorySize, smem); attr = true; } \
+            hipLaunchKernelGGL((skinny_wide_kernel<MT, NW, true>), g2, dim3(NW * 64), smem, st, (const uint16_t*)X, (const uint16_t*)W, (const uint16_t*)nullptr, \
                                (uint16_t*)act, M, F, K, (long long)ldx, 0LL, (long long)F);                                            \
         } while (0)
-        if (mt == 2) VDD_WIDE(2); else if (mt == 3) VDD_WIDE(3); else VDD_WIDE(4);
+        if (mt == 2) VDD_WIDE(2, 4); else if (mt == 3) VDD_WIDE(3, 4); else VDD_WIDE(4, 4);
 #undef VDD_WIDE
         return ok(hipSuccess);
     }

@@ -103,7 +103,8 @@ def test_silu_mul_and_embed():
 
 @pytest.mark.parametrize("M,N,K", [(1, 4096, 4096), (2, 12288, 4096), (3, 4096, 11008), (16, 4096, 4096), (17, 32000, 4096),
                                     (33, 22016, 4096), (64, 4096, 11008), (5, 1000, 256), (4, 40, 128),
-                                    (2, 15360, 5120), (3, 5120, 13824), (8, 27648, 5120), (6, 5120, 5120)])      # last row: LLaVA-1.5-13B dims
+                                    (2, 15360, 5120), (3, 5120, 13824), (8, 27648, 5120), (6, 5120, 5120),      # this row: LLaVA-1.5-13B dims
+                                    (24, 4096, 11008), (32, 4096, 4096), (18, 5120, 13824), (48, 4096, 4096), (40, 5120, 5120)])    # 17 - 64 rows, d-wide: eight-wave blocks
 def test_skinny_gemm(M, N, K):
     O = ops()
     x, w = bf(M, K, seed=7), bf(N, K, scale=0.02, seed=8)
