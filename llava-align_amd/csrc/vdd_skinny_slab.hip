@@ -234,7 +234,9 @@ __global__ void __launch_bounds__(SLAB_NW * 64) skinny_slab_kernel(const SlabArg
     int* cnt = a.tickets + team * 2;
     if (tid == 0) {
         __hip_atomic_fetch_add(cnt, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-        while (__hip_atomic_load(cnt, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) < a.KS) __builtin_amdgcn_s_sleep(2);
+        // bounded (~seconds): counters left dirty by a launch that died must not hang the device; the results are garbage then and
+        // the caller re-zeroes the workspace (ops.slab_workspace_reset)
+        for (int spin = 0; spin < (1 << 22) && __hip_atomic_load(cnt, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) < a.KS; ++spin) __builtin_amdgcn_s_sleep(2);
     }
     __syncthreads();
     asm volatile("" ::: "memory");
