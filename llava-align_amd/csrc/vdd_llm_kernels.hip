@@ -505,7 +505,7 @@ __global__ void __launch_bounds__(NW * 64) skinny_gemm_kernel(const uint16_t* __
     // Two register stages: the loads of batch i + 1 (8 x 16 B of W per lane) go out before the MFMAs of batch i, so a wave's K
     // slice (1,024 - 2,752 elements = 4 - 10 batches) costs ONE memory round trip plus streaming instead of one per batch (a
     // one-question step is a chain of these launches: see DESIGN.md section 5).  Same MFMAs in the same order.
-    constexpr int U = 8;
+    constexpr int U = MT > 2 ? 4 : 8;                  // k-steps per register stage (33 - 64 rows: 4, so that TWO stages of 16 - 20 fragments fit)
     const int nit = kq / (32 * U);
     frag8_t b0[U], a0[U][MT], b1[U], a1[U][MT];
     constexpr int UG = NORM ? U : 1;
@@ -537,9 +537,10 @@ __global__ void __launch_bounds__(NW * 64) skinny_gemm_kernel(const uint16_t* __
         __builtin_amdgcn_sched_barrier(0);
     };
     uint16_t rpre[4] = {0, 0, 0, 0};                    // MT == 1: wave 0's residual entries, fetched under the weight stream
-    if constexpr (MT <= 2) {     // up to 32 rows: two register stages (MT = 2: 2 x (32 + 64) registers; a single stage paid one memory round
-                                 // trip per batch - 11 in a row for the down projection's 2,752-deep wave slices: 33.3 -> 26.6 us for its 90 MB at 17
-                                 // rows, 34.3 -> 33.8 at 32; eight waves per block with two stages: 29.6 / 37.6, tools/skinny_crossover_probe.py)
+    {   // Two register stages at every row count (MT = 2: 2 x (32 + 64) registers; MT = 3 / 4 with U = 4: 2 x (16 + 64)).  A single stage
+        // paid one memory round trip per batch - 11 in a row for the down projection's 2,752-deep wave slices: 33.3 -> 26.6 us for its
+        // 90 MB at 17 rows, 34.3 -> 33.8 at 32; the attention output at 40 / 48 / 64 rows 19.5 / 20.7 / 23.5 -> 17.1 / 18.3 / 20.9 us.
+        // (Eight waves per block with two stages at 17 - 32 rows: 29.6 / 37.6 - slower; tools/skinny_crossover_probe.py.)
         if (nit > 0) ld(b0, a0, g0, 0);
         if (MT == 1 && R != nullptr && wave == 0 && Yslab == nullptr) {
 #pragma unroll
@@ -554,8 +555,6 @@ __global__ void __launch_bounds__(NW * 64) skinny_gemm_kernel(const uint16_t* __
             mm(b1, a1, g1);
         }
         if (it < nit) mm(b0, a0, g0);
-    } else {            // 33 - 64 rows: the X fragments alone are 96 - 128 registers per batch; one stage
-        for (int it = 0; it < nit; ++it) { ld(b0, a0, g0, it * 32 * U); mm(b0, a0, g0); }
     }
     // the K slice's remainder (K = 11008 over 8 waves: 1376 = 5 batches + 96): ONE more batch whose loads all go out together, the
     // k-steps beyond the slice with a zero W fragment (+0 to the accumulators; X is read at a clamped, valid address) - a loop of
@@ -1433,6 +1432,17 @@ VDD_HIDDEN int VDD_IMPL(vdd_embed_scatter)(const int32_t* ids, const int32_t* ro
     return ok(hipSuccess);
 }
 
+// Eight waves per 16-column block (K split eight ways inside the block) are ONE resident block per CU: right when the column blocks
+// fill the chip in whole rounds (N = 4096: 256 blocks on 256 CUs).  N = 5120 (LLaVA-1.5-13B) is 320 blocks - a second round for a
+// quarter of the chip, 0.62 of the stream rate (o-projection 23.9 us for 52 MB, down 48.9 us for 141 MB at 12 rows); four-wave
+// blocks are small enough for three per CU, so all 320 stream at once.
+static bool eight_wave_blocks(int N) {
+    static int n_cu = 0;
+    if (n_cu == 0) { int dev = 0, n = 0; n_cu = (hipGetDevice(&dev) == hipSuccess && hipDeviceGetAttribute(&n, hipDeviceAttributeMultiprocessorCount, dev) == hipSuccess && n > 0) ? n : 256; }
+    const int blocks = (N + 15) / 16;
+    return blocks <= n_cu || blocks % n_cu == 0;
+}
+
 static int skinny_gemm_launch(const void* X, const void* W, const void* R, void* Y, float* Y_slabs, int n_split, int M, int N, int K,
                               int64_t ldx, int64_t ldr, int64_t ldy, void* stream) {
     if (M <= 0 || N <= 0) return VDD_OK;
@@ -1457,7 +1467,7 @@ static int skinny_gemm_launch(const void* X, const void* W, const void* R, void*
 #undef VDD_WIDE
         return ok(hipSuccess);
     }
-    if (M <= 16 && n_split == 1 && N <= 8192 && K % 256 == 0) VDD_SKINNY(1, 8);
+    if (M <= 16 && n_split == 1 && N <= 8192 && K % 256 == 0 && eight_wave_blocks(N)) VDD_SKINNY(1, 8);
     else if (M <= 16) VDD_SKINNY(1, 4);
     else if (M <= 32) VDD_SKINNY(2, 4); else VDD_SKINNY(4, 4);
 #undef VDD_SKINNY
@@ -1500,7 +1510,7 @@ VDD_HIDDEN int VDD_IMPL(vdd_skinny_gemm_resid_ss)(const void* X, const void* W, 
     if (!X || !W || !R || !Y || !ss_out || M > 16 || K % 128 != 0 || (ldx % 8) != 0) return VDD_ERR_INVALID_ARG;
     dim3 grid((N + 15) / 16, 1);
     hipStream_t st = (hipStream_t)stream;
-    if (N <= 8192 && K % 256 == 0)
+    if (N <= 8192 && K % 256 == 0 && eight_wave_blocks(N))
         hipLaunchKernelGGL((skinny_gemm_kernel<1, 8, false, true>), grid, dim3(512), 0, st, (const uint16_t*)X, (const uint16_t*)W, (const uint16_t*)R,
                            (uint16_t*)Y, (float*)nullptr, M, N, K, (long long)ldx, (long long)ldr, (long long)ldy, NormIn{}, ss_out);
     else

@@ -194,11 +194,33 @@ def linear_to_norm(x, w):
     33 MB of the o-projection).  Up to skinny_rows() rows: the weight-streaming kernel (eight waves per 16-column block split K)."""
     M, K = x.shape
     N = w.shape[0]
-    if skinny_rows(N, K) < M <= SLAB_NORM_MAX_M and N <= 8192 and K % 256 == 0 and not GEMM_BATCH_INVARIANT:
+    if ((skinny_rows(N, K) < M or (M > SKINNY_MAX_M and uneven_column_blocks(N))) and M <= SLAB_NORM_MAX_M and N <= 8192 and K % 256 == 0
+            and not GEMM_BATCH_INVARIANT):
         s = slab_splits(M, N, K)
         if s:
             return gemm_slabs(x, w, s)
     return linear(x, w)
+
+
+UNEVEN_BLOCKS_TO_SLABS = True
+_n_cu = {}
+
+
+def uneven_column_blocks(N) -> bool:
+    """The weight-streaming kernels cut a d-wide output into N / 16 column blocks, one or a few per CU.  N = 4096 is 256 blocks on the
+    MI355X's 256 CUs; N = 5120 (LLaVA-1.5-13B) is 320 - a second round for a quarter of the chip with eight-wave blocks, or four-wave
+    blocks whose waves each walk a quarter of K in one dependent chain (down projection, K = 13,824: 38 - 77 us at 3 - 32 rows).  The
+    split-K slabs of the MFMA GEMM (12 parts x 20 tiles = 240 workgroups) stream the same weights in 27 - 29 us, the attention output
+    in 13.5 - 15 against 16.6 - 30.7 (profiles/r05_13b_d_wide_projections.jsonl).  Decode step of the 13B model, 3 branches per question:
+    15 rows 9.14 -> 8.42 ms, 24 rows 10.68 -> 9.41, 33 rows 9.73 -> 9.34; up to SKINNY_MAX_M rows the norm-fused five-launch layer stays
+    ahead (3 rows 6.2 vs 6.6 ms)."""
+    if not UNEVEN_BLOCKS_TO_SLABS:
+        return False
+    dev = torch.cuda.current_device()
+    if dev not in _n_cu:
+        _n_cu[dev] = torch.cuda.get_device_properties(dev).multi_processor_count
+    blocks = (N + 15) // 16
+    return blocks > _n_cu[dev] and blocks % _n_cu[dev] != 0
 
 
 NORM_FUSED_MAX_M = 16   # rows up to which the decoder layer's RMSNorms ride inside the projections around them
