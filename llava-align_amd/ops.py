@@ -387,8 +387,18 @@ def skinny_rows(N, K):
     if GEMM_BATCH_INVARIANT:
         return SKINNY_MAX_M
     if N > 8192:
+        if (N, K) in SKINNY_ROWS_MEASURED:
+            return SKINNY_ROWS_MEASURED[(N, K)]
         return SKINNY_WIDE_MAX_M if K % 256 == 0 else 16
     return 64 if K <= 5120 else 32
+
+
+# Wide outputs whose crossover is NOT where LLaVA-1.5-7B's is (tools/proj_form_probe.py, profiles/r05_proj_form_probe.jsonl: weight-streaming
+# kernel / MFMA GEMM in us).  The GEMM's time is flat in M and, once the weights are a few hundred MB, it streams them at 5.4 TB/s; the
+# weight-streaming kernels start at 5.8 TB/s and lose a few percent per row to their X fragments - so the bigger the matrix, the earlier
+# the GEMM wins: 13B gate/up (283 MB) 49.8 / 51.3 at 4 rows, 60.6 / 51.5 at 8, 73.2 / 52.1 at 24; 13B lm_head 70.7 / 59.2 at 8 rows;
+# 13B qkv 37.0 / 39.3 at 10 rows, 43.0 / 39.0 at 16; Qwen-VL's lm_head (V = 151,936, 1.24 GB) 222 / 226 at 8 rows, 276 / 228 at 16.
+SKINNY_ROWS_MEASURED = {(27648, 5120): 5, (32000, 5120): 3, (15360, 5120): 10, (151936, 4096): 8}
 
 
 SKINNY_WIDE_MAX_M = 24   # rows up to which wide outputs (qkv, gate/up, lm_head) take the 32-column weight-streaming kernel: 26.8 - 29.3 us

@@ -14,9 +14,13 @@ for nq in [int(a) for a in sys.argv[1:]] or [1, 2, 4, 5, 8, 11]:
     ids = [torch.tensor(sys_tok + [-200] + rng.integers(3, 32000, size=int(np.clip(rng.normal(60, 20), 10, 120))).tolist()) for _ in range(nq)]
     imgs = [torch.randn(3, 336, 336, generator=g) for _ in range(nq)]
     rec = {"model": "13b", "questions": nq, "rows": 3 * nq}
-    for name, fuse, slabs in (("old_policy", True, False), ("new_policy", True, True), ("old_policy_again", True, False), ("new_policy_again", True, True)):
-        LanguageModel.fuse_norms = fuse
+    table = dict(ops.SKINNY_ROWS_MEASURED)
+    for name, slabs, measured in (("old_policy", False, False), ("slabs", True, False), ("slabs+measured_crossovers", True, True), ("old_policy_again", False, False),
+                                  ("slabs+measured_crossovers_again", True, True)):
         ops.UNEVEN_BLOCKS_TO_SLABS = slabs
+        ops.SKINNY_ROWS_MEASURED.clear()
+        if measured:
+            ops.SKINNY_ROWS_MEASURED.update(table)
         e = VddLlavaEngine(eng.cfg, weights=eng.w, device=dev, use_graph=True)
         kw = dict(images=imgs, use_dd=True, use_dd_unk=True, cd_alpha=1.0, cd_beta=0.1, temperature=1.0, top_p=0.9, seed=1)
         def timed(n_new):
@@ -27,4 +31,5 @@ for nq in [int(a) for a in sys.argv[1:]] or [1, 2, 4, 5, 8, 11]:
             return min(ts)
         rec[name] = round((timed(48) - timed(16)) / 32 * 1e3, 3)
         del e
+    ops.SKINNY_ROWS_MEASURED.update(table)
     print(json.dumps(rec), flush=True)
