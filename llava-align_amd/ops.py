@@ -390,8 +390,12 @@ def skinny_rows(N, K):
         if (N, K) in SKINNY_ROWS_MEASURED:
             return SKINNY_ROWS_MEASURED[(N, K)]
         return SKINNY_WIDE_MAX_M if K % 256 == 0 else 16
-    return 64 if K <= 5120 else 32
+    return 64 if K <= 5120 else SKINNY_DEEP_K_MAX_M
 
+
+SKINNY_DEEP_K_MAX_M = 26   # d-wide projections with K > 5120 (MLP down): projection + the norm that follows, weight-streaming kernel vs split-K slabs of the
+                           # GEMM: 31.6 / 34.3 us at 17 rows, 34.9 / 34.8 at 24, 38.8 / 35.2 at 32 (7B widths, two-stage kernel); decode step at 26 / 28 / 32
+                           # rows with the switch at 32: 5.24 / 5.36 / 5.47 ms, at 24: 5.27 / 5.26 / 5.31 (round 4: 32)
 
 # Wide outputs whose crossover is NOT where LLaVA-1.5-7B's is (tools/proj_form_probe.py, profiles/r05_proj_form_probe.jsonl: weight-streaming
 # kernel / MFMA GEMM in us).  The GEMM's time is flat in M and, once the weights are a few hundred MB, it streams them at 5.4 TB/s; the
