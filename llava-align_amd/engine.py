@@ -581,8 +581,7 @@ class LanguageModel:
             # only the grouped pass, which reads the per-layer fragment images, may decode from it
             raise ValueError("decode_step: a frag_only KVCache decodes through the grouped attention only (pass `grouping`)")
         resid = ops.embed(tokens, t["embed"])
-        if (self.fuse_norms and grouping is None and tokens.shape[0] <= min(ops.FUSED_ATTN_MAX_M, ops.norm_fused_rows(c.d)) and D == 128
-                and (tokens.shape[0] <= ops.SKINNY_MAX_M or not ops.uneven_column_blocks(c.d))       # (d = 5120: split-K slabs + norms win above 8 rows)
+        if (self.fuse_norms and grouping is None and tokens.shape[0] <= ops.FUSED_ATTN_MAX_M and ops.norm_fused_pays(tokens.shape[0], c.d) and D == 128
                 and c.ffn % 128 == 0 and c.n_layers > 0):
             return self._decode_step_few_rows(resid, pos, cpos, slot, attn_rows, kv)
         delta = None

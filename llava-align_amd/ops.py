@@ -194,7 +194,7 @@ def linear_to_norm(x, w):
     33 MB of the o-projection).  Up to skinny_rows() rows: the weight-streaming kernel (eight waves per 16-column block split K)."""
     M, K = x.shape
     N = w.shape[0]
-    if ((skinny_rows(N, K) < M or (M > SKINNY_MAX_M and uneven_column_blocks(N))) and M <= SLAB_NORM_MAX_M and N <= 8192 and K % 256 == 0
+    if ((skinny_rows(N, K) < M or (M > UNEVEN_FUSED_MAX_M and uneven_column_blocks(N))) and M <= SLAB_NORM_MAX_M and N <= 8192 and K % 256 == 0
             and not GEMM_BATCH_INVARIANT):
         s = slab_splits(M, N, K)
         if s:
@@ -203,6 +203,8 @@ def linear_to_norm(x, w):
 
 
 UNEVEN_BLOCKS_TO_SLABS = True
+UNEVEN_FUSED_MAX_M = 7      # rows up to which a model with uneven column blocks keeps the norm-fused five-launch layer (engine.LanguageModel.decode_step):
+                            # 13B decode step, five-launch / seven-launch + slabs: 6.01 / 6.55 ms at 2 rows, 6.45 / 6.90 at 4, 6.79 / 6.98 at 6, 7.58 / 7.31 at 8
 _n_cu = {}
 
 
@@ -216,14 +218,24 @@ def uneven_column_blocks(N) -> bool:
     ahead (3 rows 6.2 vs 6.6 ms)."""
     if not UNEVEN_BLOCKS_TO_SLABS:
         return False
-    dev = torch.cuda.current_device()
+    dev = torch.cuda.current_device() if torch.cuda.is_available() else -1
     if dev not in _n_cu:
-        _n_cu[dev] = torch.cuda.get_device_properties(dev).multi_processor_count
+        _n_cu[dev] = torch.cuda.get_device_properties(dev).multi_processor_count if dev >= 0 else 256      # (no device: the MI355X's CU count)
     blocks = (N + 15) // 16
     return blocks > _n_cu[dev] and blocks % _n_cu[dev] != 0
 
 
 NORM_FUSED_MAX_M = 16   # rows up to which the decoder layer's RMSNorms ride inside the projections around them
+NORM_FUSED_GAP = (9, 12)  # ... except here: from 9 rows the normalise-once kernels run ONE eight-wave block per CU with a 16-row prologue (two four-wave
+                          # blocks up to 8 rows), and until ~12 rows the seven-launch layer is ahead - 7B decode step 4.26 / 4.09 ms at 10 rows,
+                          # 4.51 / 4.47 at 12, 4.65 / 4.66 at 14, 4.80 / 4.91 at 16 (five / seven launches per layer)
+
+
+def norm_fused_pays(M: int, d: int) -> bool:
+    """Does a decode step of M rows take the norm-fused five-launch layer?"""
+    if M > norm_fused_rows(d) or NORM_FUSED_GAP[0] <= M <= NORM_FUSED_GAP[1]:
+        return False
+    return M <= UNEVEN_FUSED_MAX_M or not uneven_column_blocks(d)
 
 
 def norm_fused_rows(d: int) -> int:

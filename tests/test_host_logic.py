@@ -160,6 +160,18 @@ def test_norm_fused_row_limit_follows_the_lds_budget():
     assert [ops.norm_fused_rows(d) for d in (4096, 5120, 8192, 2048, 16384, 4000)] == [16, 14, 8, 16, 0, 0]
 
 
+def test_which_decode_steps_take_the_five_launch_layer():
+    """ops.norm_fused_pays (measured bands): 7B widths take the norm-fused layer up to 16 rows except 9 - 12 (the
+    normalise-once kernels change their block plan at 9 rows); d = 5120 (LLaVA-1.5-13B: 320 column blocks of 16 on 256 CUs) only up to 7
+    rows - above, its d-wide projections go to the GEMM's split-K slabs, which need the stand-alone norms."""
+    from llava_align_amd import ops
+    assert not ops.uneven_column_blocks(4096) and ops.uneven_column_blocks(5120) and not ops.uneven_column_blocks(8192)
+    assert [m for m in range(1, 20) if ops.norm_fused_pays(m, 4096)] == [1, 2, 3, 4, 5, 6, 7, 8, 13, 14, 15, 16]
+    assert [m for m in range(1, 20) if ops.norm_fused_pays(m, 5120)] == [1, 2, 3, 4, 5, 6, 7]
+    assert not ops.norm_fused_pays(2, 4000)                      # widths the normalise-once kernels do not cover
+    assert ops.skinny_rows(27648, 5120) == 5 and ops.skinny_rows(22016, 4096) == ops.SKINNY_WIDE_MAX_M      # 13B gate/up crosses over early
+
+
 def test_one_launch_attention_band_and_its_batch_invariant_form():
     """Ungrouped decode steps take the one-launch RoPE + KV write + attention kernel up to 32 rows (round 5: tools/few_row_curve.py); with
     GEMM_BATCH_INVARIANT the band stays at the 16 rows of the few-row layer, so a batch that shrinks through 17 - 32 rows (row retirement)
