@@ -158,7 +158,9 @@ def skinny_gemm(x, w, resid=None, out=None, n_split=1, slabs=False):
     return out
 
 
-SLAB_NORM_MAX_M = 128   # rows up to which a d-wide projection that would take the MFMA GEMM leaves fp32 split-K slabs for its RMSNorm instead (0: off)
+SLAB_NORM_MAX_M = 256   # rows up to which a d-wide projection that would take the MFMA GEMM leaves fp32 split-K slabs for its RMSNorm instead (0: off).
+                        # (128 until round 5: decode step at 144 rows 7.69 -> 7.43 ms, 256 rows 9.80 -> 9.65, 160 / 192 rows unchanged; beyond 256 rows the
+                        # 64 x 256 tiles alone fill a quarter of the chip and slab_splits() returns 0)
 
 
 def gemm_slabs(x, w, n_split, out=None, tile=8):

@@ -552,7 +552,7 @@ def test_rmsnorm_sums_split_k_slabs():
 
 
 @pytest.mark.parametrize("M,N,K", [(40, 4096, 4096), (64, 4096, 11008), (128, 5120, 13824), (33, 520, 512), (100, 4096, 4096),
-                                   (12, 5120, 13824), (24, 5120, 5120), (4, 5120, 13824), (12, 4096, 11008)])     # 13B widths from 9 rows: slabs
+                                   (12, 5120, 13824), (24, 5120, 5120), (4, 5120, 13824), (12, 4096, 11008), (200, 4096, 4096), (256, 4096, 11008)])     # 13B widths from 8 rows: slabs
 def test_gemm_split_k_slabs_feed_the_rmsnorm(M, N, K):
     """Schedule 3 of vdd_gemm: fp32 slabs [S, M, N], one (tile, K part) per workgroup, no fix-up; their sum is the product, and
     rmsnorm(delta=slabs) == rmsnorm(delta=rounded product) up to the summation order."""
@@ -572,9 +572,9 @@ def test_gemm_split_k_slabs_feed_the_rmsnorm(M, N, K):
     assert (y1.float() - y2.float()).abs().max().item() <= 2 ** -6 * y2.float().abs().max().item()
     out = O.linear_to_norm(x, w)                                     # the engine's entry: slabs in the 33 - 128-row band, a product elsewhere
     slabs_band = O.skinny_rows(N, K) < M or (M > O.SKINNY_MAX_M and O.uneven_column_blocks(N))     # (N = 5120: 320 column blocks on 256 CUs)
-    assert (out.dim() == 3) == (slabs_band and M <= 128 and O.slab_splits(M, N, K) > 0)
+    assert (out.dim() == 3) == (slabs_band and M <= O.SLAB_NORM_MAX_M and O.slab_splits(M, N, K) > 0)
     if N == 5120 and K >= 5120:
-        assert (out.dim() == 3) == (M > 8)             # LLaVA-1.5-13B's d-wide projections: the five-launch layer up to 8 rows, slabs above
+        assert (out.dim() == 3) == (M > O.UNEVEN_FUSED_MAX_M)      # LLaVA-1.5-13B's d-wide projections: the five-launch layer up to 7 rows, slabs above
     if (M, N, K) == (12, 4096, 11008):
         assert out.dim() == 2                          # 7B widths keep the weight-streaming kernel at 12 rows
 
