@@ -35,7 +35,7 @@ def _headers():
 
 
 # the model kernels are compiled once per storage type (csrc/vdd_elem.h): -DVDD_ELEM = the vdd_dtype value
-PER_DTYPE = ("vdd_llm_kernels.hip", "vdd_prefill_kernels.hip", "vdd_gemm.hip", "vdd_layer_persistent.hip", "vdd_skinny_slab.hip")
+PER_DTYPE = ("vdd_llm_kernels.hip", "vdd_prefill_kernels.hip", "vdd_gemm.hip")
 ELEMS = (("bf16", 2), ("f16", 1))
 
 

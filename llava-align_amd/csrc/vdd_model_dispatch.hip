@@ -45,10 +45,6 @@ VDD_MODEL_FN(vdd_skinny_gemm_normed,
 VDD_MODEL_FN(vdd_skinny_swiglu_normed,
              VDD_P(const void* H, const float* ss, int nss, const void* ln_w, float eps, const void* W_gate_up, void* act, int M, int F, int K, int64_t ldh),
              VDD_P(H, ss, nss, ln_w, eps, W_gate_up, act, M, F, K, ldh))
-VDD_MODEL_FN(vdd_skinny_slab,
-             VDD_P(const void* X, const float* ss, int nss, const void* ln_w, float eps, const void* W, const void* R, void* Y, float* ss_out, int M, int N,
-                   int K, int64_t ldx, int64_t ldr, int64_t ldy, int swiglu, void* workspace, int64_t workspace_bytes),
-             VDD_P(X, ss, nss, ln_w, eps, W, R, Y, ss_out, M, N, K, ldx, ldr, ldy, swiglu, workspace, workspace_bytes))
 VDD_MODEL_FN(vdd_gemm,
              VDD_P(const void* X, const void* W, void* Y, const void* bias, const void* resid, int M, int N, int K, int64_t ldx, int64_t ldw, int64_t ldy,
                    int64_t ldr, int epilogue, int config, void* workspace, int64_t workspace_bytes),
@@ -105,32 +101,10 @@ VDD_MODEL_FN(vdd_add, VDD_P(const void* a, const void* b, void* out, int64_t n),
 VDD_MODEL_FN(vdd_layernorm, VDD_P(const void* x, const void* w, const void* b, void* y, int M, int d, float eps), VDD_P(x, w, b, y, M, d, eps))
 VDD_MODEL_FN(vdd_bias_act, VDD_P(const void* x, const void* bias, void* y, int64_t M, int d, int act), VDD_P(x, bias, y, M, d, act))
 
-VDD_MODEL_FN(vdd_decode_layers,
-             VDD_P(const vdd_layer_desc* layers, int n_layers, const void* resid_in, void* resid_out, float* ss_out, const int32_t* pos,
-                   const int32_t* cpos, const int32_t* slot, const float* cos_sin, const int32_t* rows, int M, int d, int H, int Hkv, int F, int D,
-                   float eps, float scale, int64_t slot_stride, int t_max, int64_t prefix_stride, int prefix_tmax, int has_qkv_bias,
-                   void* workspace, int64_t workspace_bytes),
-             VDD_P(layers, n_layers, resid_in, resid_out, ss_out, pos, cpos, slot, cos_sin, rows, M, d, H, Hkv, F, D, eps, scale, slot_stride, t_max,
-                   prefix_stride, prefix_tmax, has_qkv_bias, workspace, workspace_bytes))
-VDD_HIDDEN int vdd_decode_layers_max_rows_bf16(int d, int H, int F, int D, int n_layers);
-VDD_HIDDEN int64_t vdd_decode_layers_workspace_bytes_bf16(int M, int d, int H, int F, int D);
-VDD_HIDDEN int vdd_decode_layers_ss_cols_bf16(int d, int H, int F, int D);
-int vdd_decode_layers_ss_cols(int d, int H, int F, int D, int dtype) {
-    return (dtype == VDD_BF16 || dtype == VDD_F16) ? vdd_decode_layers_ss_cols_bf16(d, H, F, D) : 0;
-}
-int vdd_decode_layers_max_rows(int d, int H, int F, int D, int n_layers, int dtype) {
-    return (dtype == VDD_BF16 || dtype == VDD_F16) ? vdd_decode_layers_max_rows_bf16(d, H, F, D, n_layers) : 0;
-}
-int64_t vdd_decode_layers_workspace_bytes(int M, int d, int H, int F, int D, int dtype) {
-    return (dtype == VDD_BF16 || dtype == VDD_F16) ? vdd_decode_layers_workspace_bytes_bf16(M, d, H, F, D) : 0;
-}
-
 // workspace sizes do not depend on the storage type (fp32 partials, int32 counters): one instantiation answers
 VDD_HIDDEN int64_t vdd_gemm_workspace_bytes_bf16(int M, int N);
-VDD_HIDDEN int64_t vdd_skinny_slab_workspace_bytes_bf16(int M, int N, int K, int swiglu);
 VDD_HIDDEN int64_t vdd_decode_attention_workspace_bytes_bf16(int M, int H, int D, int max_len);
 VDD_HIDDEN int64_t vdd_decode_attention_fused_split_workspace_bytes_bf16(int M, int H, int n_split);
-int64_t vdd_skinny_slab_workspace_bytes(int M, int N, int K, int swiglu) { return vdd_skinny_slab_workspace_bytes_bf16(M, N, K, swiglu); }
 int64_t vdd_gemm_workspace_bytes(int M, int N) { return vdd_gemm_workspace_bytes_bf16(M, N); }
 int64_t vdd_decode_attention_workspace_bytes(int M, int H, int D, int max_len) { return vdd_decode_attention_workspace_bytes_bf16(M, H, D, max_len); }
 int64_t vdd_decode_attention_fused_split_workspace_bytes(int M, int H, int n_split) {

@@ -380,7 +380,6 @@ class KVCache:
                 pool[i] = new
                 del old
         self.n_own, self.t_own = max(n, 1), t_own
-        self.__dict__.pop("_persist", None)
 
     def nbytes(self):
         seen, total = set(), 0
@@ -424,7 +423,6 @@ class LanguageModel:
     def __init__(self, w: LlavaWeights):
         self.w, self.cfg = w, w.cfg.lm
         self.cs = rope_table(self.cfg, w.device)
-        self._persist_rows, self._persist_ws = None, None
         # A vocabulary that is not a multiple of 8 rows (resize_token_embeddings(len(tokenizer)) after add_tokens, builder.py:127-132:
         # 32001 ... 32003): the output projection runs on a zero-padded copy of lm_head (the GEMM writes whole 8-byte quads) and the
         # logits are a [rows, V] VIEW of its [rows, V_pad] result - the sampling kernel takes any row stride and never sees the padding.
@@ -507,37 +505,6 @@ class LanguageModel:
         return self._head(a)
 
     fuse_norms = True         # few rows in flight: the RMSNorm launches ride inside the projections around them
-    # 1 - 4 rows: ALL decoder layers of the step in ONE persistent launch (ops.decode_layers, csrc/vdd_layer_persistent.hip).  Correct and
-    # tested, but OFF: measured 120 - 126 us per 7B layer against 94 us for the five launches below - four activation all-gathers of
-    # 8 - 22 MB per layer (256 CUs each sweeping the whole vector) and two local hops cost 55 us of waits, which the run-ahead weight
-    # pipeline (96 KiB per CU = 4 us of stream) cannot cover (`profiles/r05_persistent_layer_timeline.jsonl`).
-    persistent = False
-
-    def _persistent_state(self, kv: "KVCache", M: int):
-        """Descriptor table + exchange workspace of the persistent layers for this KV cache, or None when the shape / row count is not
-        served.  Built once per cache (eagerly: a captured step replays the same pointers)."""
-        c = self.cfg
-        if not (self.persistent and ops.PERSISTENT_LAYERS) or kv.frag_only:
-            return None
-        if self._persist_rows is None:
-            self._persist_rows = ops.decode_layers_max_rows(c.d, c.n_heads, c.n_kv_heads, c.ffn, c.head_dim, c.n_layers, self.w.dtype)
-        if M > self._persist_rows:
-            return None
-        st = getattr(kv, "_persist", None)
-        if st is None or st["lm"] is not self:
-            t = self.w.t
-            layers = [dict(ln1=t[f"l{i}.ln1"], wqkv=t[f"l{i}.wqkv"], bqkv=t[f"l{i}.bqkv_lm"] if c.qkv_bias else None, wo=t[f"l{i}.wo"],
-                           ln2=t[f"l{i}.ln2"], wgu=t[f"l{i}.wgu"], wd=t[f"l{i}.wd"], k_own=kv.ko[i], v_own=kv.vo[i], k_pre=kv.kp[i],
-                           v_pre=kv.vp[i]) for i in range(c.n_layers)]
-            if self._persist_ws is None:
-                self._persist_ws = ops.decode_layers_workspace(self._persist_rows, c.d, c.n_heads, c.ffn, c.head_dim, self.w.device, self.w.dtype)
-            st = kv._persist = dict(lm=self, desc=ops.layer_descriptors(layers, self.w.device))
-        return st
-
-    def persistent_status(self) -> int:
-        """0, or the give-up code of a persistent launch whose hand-off wait timed out (forces a sync)."""
-        return 0 if self._persist_ws is None else ops.decode_layers_status(self._persist_ws)
-
     @torch.no_grad()
     def _decode_step_few_rows(self, resid, pos, cpos, slot, attn_rows, kv):
         """One question (2-3 branch rows) up to 16 rows: 5 launches per layer instead of 7.  The attention-output and MLP-down
@@ -547,12 +514,6 @@ class LanguageModel:
         stand-alone kernel."""
         c, t = self.cfg, self.w.t
         H, Hkv, D = c.n_heads, c.n_kv_heads, c.head_dim
-        st = self._persistent_state(kv, resid.shape[0])
-        if st is not None:
-            resid, ss = ops.decode_layers(st["desc"], c.n_layers, resid, pos, cpos, slot, self.cs, attn_rows, H, c.ffn, D, c.eps,
-                                          kv.ko[0].stride(0), kv.ko[0].shape[2], kv.kp[0].stride(0), kv.kp[0].shape[2], c.qkv_bias,
-                                          self._persist_ws)
-            return self._head(resid=resid, ss=ss)
         ss = None
         for i in range(c.n_layers):
             p = f"l{i}."
@@ -1335,10 +1296,6 @@ class VddLlavaEngine:
                     break
                 if done_bad[0]:                                                               # :291, amortised over sync_every steps
                     break
-        code = self.lm.persistent_status()
-        if code:                                                  # a hand-off wait of the persistent layers timed out: never return garbage
-            raise RuntimeError(f"persistent decode layers gave up (code {code & 0xffff:#x}, workgroup {code >> 16}); "
-                               "set ops.PERSISTENT_LAYERS = False to use the five-launch layer")
         if bool((run.status | run.status0).ne(0).any().item()):
             raise RuntimeError("probability tensor contains either `inf`, `nan` or element < 0")   # torch.multinomial, :202
         if streamer is not None:

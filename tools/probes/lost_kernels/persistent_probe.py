@@ -1,10 +1,10 @@
 """Persistent few-row decode layers against the five-launch layer chain: time per step of n_layers at 7B (or 13B) widths, both
-captured in a HIP graph (what the engine replays).  python tools/persistent_probe.py [--layers 32] [--rows 2] [--model 7b]"""
+captured in a HIP graph (what the engine replays).  python tools/probes/lost_kernels/persistent_probe.py [--layers 32] [--rows 2] [--model 7b]"""
 import argparse, json, os, sys, time
-sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+sys.path.insert(0, os.path.dirname(os.path.abspath(__file__)))                       # lost_ops.py, the lab tests
 import torch
-import tests.test_persistent_layers_gpu as T
-from llava_align_amd import ops
+import test_persistent_layers_gpu as T
+import lost_ops as ops                   # lab entries + the product's ops
 
 
 def main():

@@ -2,12 +2,12 @@
 one phase of the five-launch layer in which HBM idles - shorten the layer?  The captured chain (engine.LanguageModel.
 _decode_step_few_rows) against the same chain with a forked branch per layer that reads W_o (and optionally the head of W_gate/up)
 on a second stream beside the attention launch.  The stand-in prefetch is a plain read (torch sum over an int32 view): it fills the
-XCD L2s / the Infinity Cache exactly as a dedicated prefetch kernel would.  python tools/prefetch_overlap_probe.py [--mb 33]"""
+XCD L2s / the Infinity Cache exactly as a dedicated prefetch kernel would.  python tools/probes/lost_kernels/prefetch_overlap_probe.py [--mb 33]"""
 import argparse, json, os, sys, time
-sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+sys.path.insert(0, os.path.dirname(os.path.abspath(__file__)))                       # lost_ops.py, the lab tests
 import torch
-import tests.test_persistent_layers_gpu as T
-from llava_align_amd import ops
+import test_persistent_layers_gpu as T
+import lost_ops as ops                   # lab entries + the product's ops
 
 ap = argparse.ArgumentParser()
 ap.add_argument("--layers", type=int, default=32)

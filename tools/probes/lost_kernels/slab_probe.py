@@ -1,9 +1,9 @@
-"""17 - 64 rows: the slab projections (csrc/vdd_skinny_slab.hip, K cut over workgroups, X staged once per workgroup) against what the
+"""17 - 64 rows: the slab projections (vdd_skinny_slab.hip, K cut over workgroups, X staged once per workgroup) against what the
 decoder layer ran before them - the 16 / 32-column weight-streaming kernels and the MFMA GEMM, with the RMSNorm launches they need -
 per projection of LLaVA-1.5-7B (or 13B: argv[1] = 13b), weights rotated through > 600 MB.  One JSON line per row count."""
 import sys, json, os, torch
-sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
-from llava_align_amd import ops
+sys.path.insert(0, os.path.dirname(os.path.abspath(__file__)))                       # lost_ops.py, the lab tests
+import lost_ops as ops                   # lab entries + the product's ops
 dev = "cuda"
 d, F = (5120, 13824) if len(sys.argv) > 1 and sys.argv[1] == "13b" else (4096, 11008)
 def t(fn, n=24):

@@ -1,11 +1,11 @@
-"""Where a launch of the 17 - 64-row slab projections (csrc/vdd_skinny_slab.hip) spends its time: per-wave phase stamps (X staged, main
+"""Where a launch of the 17 - 64-row slab projections (vdd_skinny_slab.hip) spends its time: per-wave phase stamps (X staged, main
 loop done, team barrier passed, slabs summed, epilogue issued, done) of ONE launch per projection of LLaVA-1.5-7B.  Needs a library
 built with -DVDD_PROBE_BUILD (exports vdd_dbg_slab_timeline_bf16).  Record: profiles/r05_slab_timeline.jsonl."""
 import sys, os, torch, ctypes as C, json
-sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
-from llava_align_amd import ops as O, _lib
-lib = _lib.load_lib()
-NW = 4   # SLAB_NW of csrc/vdd_skinny_slab.hip
+sys.path.insert(0, os.path.dirname(os.path.abspath(__file__)))                       # lost_ops.py, the lab tests
+import lost_ops as O
+lib = O._lib_ready()                      # build with `python lost_ops.py --probe` (VDD_PROBE_BUILD: the timeline stamps)
+NW = 4   # SLAB_NW of vdd_skinny_slab.hip
 dbg = torch.zeros(512 * NW * 8, dtype=torch.int64, device="cuda")
 d, F = 4096, 11008
 for M in (18, 64):

@@ -1,4 +1,4 @@
-"""Persistent few-row decode layers (csrc/vdd_layer_persistent.hip, ops.decode_layers): ALL decoder layers of a 1 - 4 row decode step
+"""Persistent few-row decode layers (vdd_layer_persistent.hip, lost_ops.decode_layers; laboratory code since round 6): ALL decoder layers of a 1 - 4 row decode step
 in one launch, against the five-launch layer of the same package (vdd_skinny_gemm_normed + vdd_decode_attention_fused +
 vdd_skinny_gemm_resid_ss + vdd_skinny_swiglu_normed + vdd_skinny_gemm_resid_ss) and an fp32 torch reference of the layer
 (reference: one HF-eager LlamaDecoderLayer per branch and token, llava_llama.py:88-103; B = 1 per call, llava_calibrate.py:130)."""
@@ -7,7 +7,7 @@ import math
 import pytest
 import torch
 
-pytestmark = pytest.mark.gpu
+pytestmark = [pytest.mark.gpu, pytest.mark.probe]
 DEV = "cuda:0"
 
 
@@ -20,7 +20,7 @@ def storage_dtype(request):
 
 @pytest.fixture(scope="module")
 def ops():
-    from llava_align_amd import ops as o
+    import lost_ops as o          # decode_layers* + (through its __getattr__) the product's ops
     return o
 
 
@@ -169,39 +169,3 @@ def test_persistent_layers_against_fp32_torch_layer(ops):
     tol = 0.06 if DT == torch.bfloat16 else 0.01
     assert (rb.float() - want).abs().max().item() <= tol * max(1.0, want.abs().max().item())
     assert torch.allclose(sb.sum(1), (want * want).sum(1), rtol=3e-2)
-
-
-@pytest.mark.parametrize("n_q,mode", [(1, dict(use_dd_unk=True)), (1, dict(use_dd=True, use_dd_unk=True)), (2, dict(use_dd_unk=True))])
-def test_engine_decodes_through_the_persistent_layers(n_q, mode):
-    """One / two questions in flight (2, 3, 4 rows) at LLaVA-1.5-7B widths through VddLlavaEngine with `lm.persistent = True` (captured
-    in the step's HIP graph, replayed per token: fresh epochs from the workspace's launch counter) against the five-launch layer."""
-    from test_engine_shapes_gpu import _engine, _prompts
-    from llava_align_amd import ops as o
-    if DT != torch.bfloat16:
-        pytest.skip("one storage type is enough for the engine wiring (the kernel tests above run both)")
-    eng = _engine(dict(d=4096, n_heads=32, n_kv_heads=32, head_dim=128, ffn=11008, vocab=32000))
-    ids, imgs = _prompts(1, 6, 32000, seed=23)
-    ids, imgs = ids[:n_q], imgs[:n_q]
-    kw = dict(images=imgs, cd_alpha=1.0, cd_beta=0.1, temperature=0.5, max_new_tokens=6, cd_greedy=True, output_scores=True, **mode)
-    b = eng.generate(ids, **kw)
-    try:
-        eng.lm.persistent = True
-        eng._graphs.clear()                                        # captured steps are cached per shape: re-capture with the other layer
-        a = eng.generate(ids, **kw)
-        assert eng.lm._persist_ws is not None and int(eng.lm._persist_ws[:4].view(torch.int32).item()) >= 6      # it really ran, once per step
-        assert eng.lm.persistent_status() == 0
-    finally:
-        eng.lm.persistent = False
-        eng._graphs.clear()
-    same = 0
-    for q in range(n_q):                                        # a question is compared while both runs are still on the same tokens
-        for step, (sa, sb) in enumerate(zip(a.scores, b.scores)):
-            ra, rb = sa[q].float(), sb[q].float()
-            fin = torch.isfinite(ra) & torch.isfinite(rb)
-            assert (torch.isfinite(ra) ^ torch.isfinite(rb)).sum() <= 3 + 0.25 * int(fin.sum()), (q, step)     # candidate density x logit noise
-            tol = max(0.25, 2.0 ** -6 * rb[fin].abs().max().item())       # two ulps of the 16-bit type at the largest score
-            assert (ra[fin] - rb[fin]).abs().max().item() <= tol, (q, step)
-            if a.tokens[q, step].item() != b.tokens[q, step].item():
-                break
-            same += 1
-    assert same >= 4 * n_q

@@ -1,10 +1,10 @@
-"""The 17 - 64-row weight-streaming projections with K cut over workgroups (csrc/vdd_skinny_slab.hip) against fp32 references of
+"""The 17 - 64-row weight-streaming projections with K cut over workgroups (vdd_skinny_slab.hip, laboratory code since round 6) against fp32 references of
 the same ops, in both storage types: plain / residual + sums of squares / normalise-on-staging / SwiGLU, ragged shapes, the ticket
 protocol (repeated launches, bit-identical results, tickets left zero)."""
 import pytest
 import torch
 
-pytestmark = pytest.mark.gpu
+pytestmark = [pytest.mark.gpu, pytest.mark.probe]
 DEV = "cuda:0"
 DT = torch.bfloat16
 
@@ -18,7 +18,7 @@ def storage_dtype(request):
 
 
 def ops():
-    from llava_align_amd import ops as O
+    import lost_ops as O          # the slab entries + (through its __getattr__) the product's ops
     return O
 
 

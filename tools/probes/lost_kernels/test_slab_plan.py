@@ -1,16 +1,18 @@
-"""Host logic of the 17 - 64-row slab projections (csrc/vdd_skinny_slab.hip): the cut of a projection over the chip, read through the
+"""Host logic of the 17 - 64-row slab projections (vdd_skinny_slab.hip, laboratory code since round 6): the cut of a projection over the chip, read through the
 C ABI's workspace query (no GPU needed: without a device the planner assumes the MI355X's 256 CUs)."""
 import ctypes as C
 
 import pytest
 
-from llava_align_amd import _lib
+import lost_ops
+
+pytestmark = pytest.mark.probe
 
 TICKETS = 16384 * 4        # fixed ticket / counter region at the head of the workspace
 
 
 def ws_bytes(M, N, K, swiglu=0):
-    lib = _lib.load_lib()
+    lib = lost_ops._lib_ready()
     lib.vdd_skinny_slab_workspace_bytes.argtypes, lib.vdd_skinny_slab_workspace_bytes.restype = [C.c_int] * 4, C.c_int64
     return lib.vdd_skinny_slab_workspace_bytes(M, N, K, swiglu)
 

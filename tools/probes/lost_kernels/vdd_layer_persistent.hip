@@ -33,6 +33,7 @@
 #include <stdint.h>
 
 #include "vdd_elem.h"
+#include "vdd_lost.h"
 
 namespace {
 namespace VDD_ELEM_NS {

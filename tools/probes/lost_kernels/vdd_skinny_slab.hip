@@ -17,10 +17,16 @@
 //   * each of its 4 waves walks its own column tiles: W fragments go global -> registers (every byte of W is read by one wave, once),
 //     four register stages of eight k-steps run ahead ACROSS tile boundaries (16 - 24 KiB in flight per wave: the 2 us x 6 TB/s the
 //     memory system needs), MFMA 16x16x32 against the X fragments in LDS;
-//   * a finished (tile, slab) partial goes to an fp32 slab with write-through stores; the wave takes one ticket per tile, and the
-//     LAST of the KS arrivals of a tile adds the slabs in slab order (deterministic) and runs the epilogue: bf16 round (+ residual,
-//     + per-row sums of squares of the tile's 16 columns for the next NORM staging), or SiLU(gate) * up for W = [Wg; Wu].
-// No workgroup ever waits for another (the last arriver works, nobody spins), so co-residency is not assumed.
+//   * a finished (tile, slab) partial goes to an fp32 slab with write-through stores; the team's KS workgroups then MEET at one
+//     arrival counter and each runs the epilogue of every KS-th tile of the team, adding the slabs in slab order (deterministic):
+//     bf16 round (+ residual, + per-row sums of squares of the tile's 16 columns for the next NORM staging), or SiLU(gate) * up
+//     for W = [Wg; Wu].  (The first form - the LAST arriver of a tile does its epilogue, nobody waits - left all of a team's tiles
+//     to its one late workgroup: 6 - 18 us tails.)
+// The meeting ASSUMES the whole grid (one workgroup per CU) is co-resident: under a CU mask, beside another stream's kernel or on a
+// partitioned part a team's workgroups may never all run at once.  The wait is therefore bounded, and a workgroup that gives up writes
+// 1 + its index into the workspace's status word (vdd_skinny_slab_status_offset) before it goes on: the launch's outputs are garbage
+// then, the C entry still returns VDD_OK (it is asynchronous), and the caller reads the word after a sync (lost_ops.slab_status).
+// Laboratory code (round 6): measured 1.07 - 1.25x SLOWER than the shipped 17 - 64-row path, not part of libvdd_hip.so.
 #include <hip/hip_runtime.h>
 #include <stdint.h>
 
@@ -56,6 +62,7 @@ constexpr int SLAB_NW = 4;            // waves per workgroup (one per SIMD: the 
 constexpr int SLAB_STAGES = 4;
 constexpr int SLAB_LDS_CAP = 150 * 1024;
 constexpr int SLAB_MAX_TILES = 16384;  // ticket words at the head of the workspace (N <= 262,144 output columns)
+constexpr int SLAB_STATUS_WORD = SLAB_MAX_TILES - 1;   // the give-up word (team counters use words < 2 x the CU count)
 
 __device__ __forceinline__ uint32_t norm_pair(uint32_t hv, uint32_t gv, float rstd) {
     const uint32_t nb = cvt_pk(lo(hv) * rstd, hi(hv) * rstd);
@@ -236,7 +243,13 @@ __global__ void __launch_bounds__(SLAB_NW * 64) skinny_slab_kernel(const SlabArg
         __hip_atomic_fetch_add(cnt, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
         // bounded (~seconds): counters left dirty by a launch that died must not hang the device; the results are garbage then and
         // the caller re-zeroes the workspace (ops.slab_workspace_reset)
-        for (int spin = 0; spin < (1 << 22) && __hip_atomic_load(cnt, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) < a.KS; ++spin) __builtin_amdgcn_s_sleep(2);
+        int spin = 0;
+        for (; spin < (1 << 22) && __hip_atomic_load(cnt, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) < a.KS; ++spin) __builtin_amdgcn_s_sleep(2);
+        if (spin == (1 << 22)) {                     // gave up: say so (first one wins) - the sums below read slabs nobody wrote
+            int zero = 0;
+            __hip_atomic_compare_exchange_strong(a.tickets + SLAB_STATUS_WORD, &zero, 1 + (int)blockIdx.x, __ATOMIC_RELAXED, __ATOMIC_RELAXED,
+                                                 __HIP_MEMORY_SCOPE_AGENT);
+        }
     }
     __syncthreads();
     asm volatile("" ::: "memory");
@@ -378,7 +391,7 @@ static bool slab_plan(int M, int N, int K, int swiglu, SlabPlan& p) {
     p.RS = (kslab + 127) / 128 * 256;
     p.lds = 512 + (M * p.RS > 49152 ? M * p.RS : 49152);             // >= the epilogue's scratch (<= 12 KiB per wave)
     const int C = swiglu ? 2 : 1;
-    if (p.NT > SLAB_MAX_TILES || 2 * cus > SLAB_MAX_TILES) return false;
+    if (p.NT > SLAB_MAX_TILES || 2 * cus >= SLAB_STATUS_WORD) return false;
     p.tickets_bytes = (int64_t)SLAB_MAX_TILES * 4;                    // a FIXED region: launches of different widths share one workspace
     p.ws_bytes = p.tickets_bytes + (int64_t)p.NT * ks * p.MT * C * 1024;
     return true;
@@ -406,6 +419,8 @@ extern "C" {
 #ifdef VDD_PROBE_BUILD
 __attribute__((visibility("default"))) void VDD_IMPL(vdd_dbg_slab_timeline)(void* p) { g_slab_dbg = (long long*)p; }
 #endif
+
+VDD_HIDDEN int64_t VDD_IMPL(vdd_skinny_slab_status_offset)(void) { return (int64_t)SLAB_STATUS_WORD * 4; }
 
 VDD_HIDDEN int64_t VDD_IMPL(vdd_skinny_slab_workspace_bytes)(int M, int N, int K, int swiglu) {
     SlabPlan p;
