@@ -412,6 +412,243 @@ def bench_fp16(a, dev, ids, host_imgs, n_new):
                     "after one warm-up; same kernels compiled for fp16 storage (v_mfma_*_f16, v_dot2c_f32_f16, fp16 KV pools)"}
 
 
+# ------------------------------------------------------------------ the other BASELINE configs, driver-timed (world == 1)
+def _kv_bytes_per_token(lm, es=2):
+    return 2 * lm.n_layers * lm.n_kv_heads * lm.head_dim * es
+
+
+def step_roofline(eng, calls):
+    """HBM roofline of the decode steps of the logged generate() calls that decoded more than one token (the main passes of a driver):
+    SURVEY 8(d) bytes per step = LM weights once + K / V of the step's context + one logits row per decode row, over 8 TB/s, against
+    the measured step (HIP events of VddLlavaEngine.call_log).  `frac` counts every SHARED prompt prefix once (the bytes that must
+    cross the chip at least once per step); `frac_kv_per_row` is 8(d)'s literal sum over rows (it can exceed what the engine moves
+    when rows share a prefix)."""
+    lm, W = eng.cfg.lm, eng.w.lm_stream_bytes()
+    kvb = _kv_bytes_per_token(lm)
+    steps = ms = floor = floor_rows = rows = 0.0
+    for st in calls:
+        t = eng.call_timing(st)
+        n = t["decode_steps"]
+        if n < 1:
+            continue
+        R = st["decode_rows"]
+        grow = R * (n + 1) / 2.0                                   # mean number of generated tokens in the context, summed over rows
+        floor += n * (W + (st["ctx_tokens_distinct"] + grow) * kvb + R * lm.vocab * 2)
+        floor_rows += n * (W + (st["ctx_tokens_rows"] + grow) * kvb + R * lm.vocab * 2)
+        steps += n; ms += t["decode_ms"]; rows += R * n
+    if not steps:
+        return None
+    step_ms = ms / steps
+    return {"bound": "hbm", "peak": HBM_PEAK_GBS, "unit": "GB/s", "decode_step_ms": round(step_ms, 3), "rows_per_step": round(rows / steps, 1),
+            "floor_ms": round(floor / steps / (HBM_PEAK_GBS * 1e6), 3), "frac": round(floor / (HBM_PEAK_GBS * 1e6) / ms, 4),
+            "frac_kv_per_row": round(floor_rows / (HBM_PEAK_GBS * 1e6) / ms, 4), "bytes_per_step": int(floor / steps),
+            "lm_weight_bytes": W, "decode_steps_timed": int(steps),
+            "note": "bytes = LM weights once + K/V of the context (shared prefixes once) + logits rows, SURVEY 8(d); measured with HIP events around the decode loop"}
+
+
+def _timed(fn, dev):
+    import torch
+    torch.cuda.synchronize(dev)
+    t0 = time.perf_counter(); out = fn(); torch.cuda.synchronize(dev)
+    return out, time.perf_counter() - t0
+
+
+def _release(*engines):
+    import gc
+    import torch
+    for e in engines:
+        e._kvs.clear(); e._graphs.clear(); e._kv = None; e.call_log = None
+    gc.collect()
+    torch.cuda.empty_cache()
+
+
+def _split_calls(eng, log):
+    t = [eng.call_timing(st) for st in log]
+    return {"prefill_s": round(sum(x["prefill_ms"] for x in t) / 1e3, 3), "decode_s": round(sum(x["decode_ms"] for x in t) / 1e3, 3), "generate_calls": len(log)}
+
+
+def bench_config3(dev, n_q=90, n_new=256):
+    """BASELINE config #3 (llava_sampling.py:96-109): LLaVA-1.5-13B shapes, LLaVA-Bench-like open generation - 90 questions, one image each,
+    text 80 +- 30 tokens, use_dd + use_dd_unk (3 branches), top-p 0.9, T = 1, 256 new tokens - (a) the whole list on this GPU (270 rows)
+    and (b) the questions ShardPlan gives rank 0 of 8 (ceil-chunks of whole images, MME/run_llava.py:32-40: 12 questions = 36 rows),
+    i.e. the slowest rank of the 8-GPU run, whose time IS the 8-GPU job's time (no data-path collective)."""
+    import torch as _t
+    _t.cuda.reset_peak_memory_stats(dev)
+    import numpy as np
+    import torch
+    from llava_align_amd.engine import VddLlavaEngine
+    from llava_align_amd.shard import ShardPlan
+    rng = np.random.default_rng(5)
+    sys_tok = [1] + rng.integers(3, 32000, size=34).tolist()
+    g = torch.Generator().manual_seed(3)
+    ids, imgs = [], []
+    for _ in range(n_q):
+        n = int(np.clip(rng.normal(80, 30), 10, 170))
+        ids.append(torch.tensor(sys_tok + [-200] + rng.integers(3, 32000, size=n).tolist()))
+        imgs.append(torch.randn(3, 336, 336, generator=g).to(dev).to(torch.bfloat16))
+    eng = VddLlavaEngine("llava-1.5-13b", device=dev, seed=0, use_graph=True)
+    kw = dict(use_dd=True, use_dd_unk=True, cd_alpha=1.0, cd_beta=0.1, temperature=1.0, top_p=0.9, max_new_tokens=n_new, seed=1)
+    out = {"workload": f"LLaVA-1.5-13B shapes (40 layers, d 5120, synthetic weights), {n_q} questions x 3 branches (use_dd + use_dd_unk), one 336 px image each, "
+                       f"text 80 +- 30 tokens, top-p 0.9, T = 1, {n_new} new tokens (no EOS), ViT + prefill + decode inside the timed call"}
+    mine = list(ShardPlan([f"im{i}" for i in range(n_q)], 0, 8).mine)
+    for name, sel in (("one_gpu", list(range(n_q))), ("rank0_of_8", mine)):
+        a, b = [ids[i] for i in sel], [imgs[i] for i in sel]
+        eng.generate(a, images=b, **kw)                                      # warm-up: tuner picks, graph capture
+        eng.call_log = []
+        o, dt = _timed(lambda: eng.generate(a, images=b, **kw), dev)
+        out[name] = {"questions": len(sel), "rows_per_step": 3 * len(sel), "seconds": round(dt, 3), "tokens_per_s": round(len(sel) * n_new / dt, 1),
+                     **_split_calls(eng, eng.call_log), "step_roofline": step_roofline(eng, eng.call_log)}
+        eng.call_log = None
+    t8 = out["rank0_of_8"]["seconds"]
+    out["expected_8_gpus"] = {"tokens_per_s": round(n_q * n_new / t8, 1), "speedup_vs_one_gpu": round(out["one_gpu"]["seconds"] / t8, 2),
+                              "note": f"every rank decodes its own {len(mine)}-question chunk (the last one {n_q - 7 * len(mine)}): job time = rank 0's time above + one result "
+                                      "gather; strong scaling of a 90-question list is bounded by the 36-row step, not by the fabric"}
+    out["hbm_peak_GB"] = round(torch.cuda.max_memory_allocated(dev) / 1e9, 1)
+    _release(eng)
+    del eng
+    return out
+
+
+_word = lambda t: ("yes", "no", "maybe")[t % 3]
+_decode_words = lambda ids: " ".join(_word(t) for t in ids)
+
+
+def bench_config4(dev, n_items=504):
+    """BASELINE config #4 (MME/run_qwen.py:190-221): Qwen-VL-7B LM shape (32 layers, d 4096, qkv bias, V = 151,936), MME-like: 504 items =
+    252 images x 2 questions, prompt = '<img>' + 256 resampler slots + ~40 text tokens as embeddings (the Qwen ViT + resampler are
+    upstream of this path), use_dd_unk dual pass (the image-free branch re-runs the same inputs), 20 new tokens,
+    min_new_tokens 1, pad = eos = eod, step-0 top-10, + the two text-only prior passes, the calibrate converter and the MME scorer."""
+    import torch as _t
+    _t.cuda.reset_peak_memory_stats(dev)
+    import numpy as np
+    import torch
+    from llava_align_amd.engine import LlavaWeights, VddLlavaEngine, preset
+    from llava_align_amd.mme_driver import MME_SUBSETS, qwen_mme_inputs, run_mme
+    cfg = preset("qwen-vl-7b-lm")
+    eng = VddLlavaEngine(cfg, weights=LlavaWeights.random(cfg, dev, seed=0, lm_head_gain=4.0), device=dev, use_graph=True)
+    qs, gt = [], {}
+    for i in range(n_items // 2):
+        cat = MME_SUBSETS[i % 8]
+        for k in range(2):
+            text = f"Is item {i} {k} shown in the picture? Please answer yes or no."
+            qs.append({"question_id": f"{cat}/{i:04d}.png", "image": f"{cat}/{i:04d}.png", "category": cat, "text": text})
+            gt[(cat, f"{i:04d}.txt", text)] = ("Yes", "No")[(i + k) % 2]
+    table = eng.w.t["embed"]
+    g = torch.Generator(device=dev).manual_seed(2)
+    feats, lead = {}, table[torch.tensor([151857, 151857], device=dev)]
+
+    def embed_prompt(text, path):
+        rng = np.random.default_rng(sum(map(ord, text)))                 # the same prompt embeds the same way in every pass
+        e = table[torch.from_numpy(rng.integers(3, 151000, size=40 + (len(text) % 9))).to(dev)]
+        if path is None:
+            return e
+        if path not in feats:
+            feats[path] = (torch.randn(256, cfg.lm.d, device=dev, generator=g) * 0.02).to(torch.bfloat16)
+        return torch.cat([lead, feats[path], e[2:]], 0), 258              # '<img>' + the 256 slots: shared by both questions about the image
+    root = os.path.join(ROOT, "gpurun_out", "bench_mme") if os.path.isdir(os.path.join(ROOT, "gpurun_out")) else "/tmp/bench_mme"
+    kw = dict(batch_questions=n_items, max_new_tokens=20, min_new_tokens=1, eos_token_id=151643, pad_token_id=151643, gt=gt, results_root=root,
+              experiment="qwen", answers_path=os.path.join(root, "answers.jsonl"), use_dd_unk=True, cd_alpha=1.0, cd_beta=0.1, temperature=1.0, seed=1)
+    build = qwen_mme_inputs(embed_prompt)
+    run_mme(eng, qs, build, _decode_words, **kw)
+    eng.call_log = []
+    res, dt = _timed(lambda: run_mme(eng, qs, build, _decode_words, **kw), dev)
+    out = {"workload": f"Qwen-VL-7B LM shape (V 151,936, qkv bias, synthetic weights), {n_items} MME-like items = {n_items // 2} images x 2, prompt = 258 shared image rows + ~40 text "
+                       "rows as embeddings, use_dd_unk dual pass, 20 new tokens, min_new_tokens 1, + none / unk prior passes (1 token), converter + scorer (mme_driver.run_mme)",
+           "items": len(qs), "seconds": round(dt, 3), "items_per_s": round(len(qs) / dt, 1),
+           "main_pass_tokens_per_s": round(sum(len(a["text"].split()) for a in res["answers"]) / dt, 1), **_split_calls(eng, eng.call_log),
+           "host_s": None, "step_roofline": step_roofline(eng, eng.call_log), "scored_subsets": sorted(k for k, v in res["scores"].items() if v is not None),
+           "hbm_peak_GB": round(torch.cuda.max_memory_allocated(dev) / 1e9, 1)}
+    out["host_s"] = round(dt - out["prefill_s"] - out["decode_s"], 3)
+    _release(eng)
+    del eng
+    return out
+
+
+def bench_config5(eng, dev, n_q=384):
+    """BASELINE config #5 (blip_calibrate.py:78-98): InstructBLIP-Vicuna-7B shape - EVA-ViT-g (39 x 1408) + Q-Former (12 x 768) + the
+    Vicuna-7B LM of `eng` - POPE-like: 384 questions (6 per 224 px image) in batches of 128, VCD branch from add_diffusion_noise(image, 500),
+    alpha 0.5 (the driver never forwards cd_alpha), beta 0.1, top-p 1, top-k 50 (HF's default), max_length 20, noise(999) / zeros priors."""
+    import torch as _t
+    _t.cuda.reset_peak_memory_stats(dev)
+    import torch
+    from llava_align_amd.blip_driver import run_blip_pope
+    from llava_align_amd.blip_frontend import BlipConfig, BlipWeights, InstructBlipFrontEnd
+    front = InstructBlipFrontEnd(BlipWeights.random(BlipConfig(), dev, seed=1))
+    images = {f"im{i}.jpg": torch.randn(3, 224, 224, generator=torch.Generator().manual_seed(i)).to(dev) for i in range(n_q // 6)}
+    qs = [{"question_id": i, "image": f"im{i // 6}.jpg", "text": f"Is there a thing number {i} in the image?", "label": ("yes", "no")[i % 2]} for i in range(n_q)]
+    tok_llm = lambda p: [1] + [(sum(map(ord, w)) * 31 + 7) % 31990 + 3 for w in p.split()]
+    tok_qf = lambda p: [101] + [(sum(map(ord, w)) * 17) % 30000 + 200 for w in p.split()][:30] + [102]
+    kw = dict(batch_questions=128, use_cd=True, noise_step=500, cd_beta=0.1, max_length=20, seed=1)
+    run_blip_pope(eng, front, qs[:128], tok_llm, tok_qf, _decode_words, lambda n: images[n], **kw)
+    eng.call_log = []
+    res, dt = _timed(lambda: run_blip_pope(eng, front, qs, tok_llm, tok_qf, _decode_words, lambda n: images[n], **kw), dev)
+    out = {"workload": f"InstructBLIP-Vicuna-7B shape (EVA-ViT-g 39 x 1408, Q-Former 12 x 768, Vicuna-7B; synthetic weights), {n_q} POPE-like questions (6 per 224 px image), "
+                       "VCD branch = add_diffusion_noise(image, 500), alpha 0.5, beta 0.1, top-p 1, top-k 50, max_length 20, + noise(999) / zeros prior passes "
+                       "(blip_driver.run_blip_pope: 4 EVA-ViT + Q-Former passes per batch)",
+           "items": n_q, "seconds": round(dt, 3), "items_per_s": round(n_q / dt, 1), **_split_calls(eng, eng.call_log),
+           "front_end_and_host_s": None, "step_roofline": step_roofline(eng, eng.call_log), "n_answers": len(res["answers"]),
+           "hbm_peak_GB": round(torch.cuda.max_memory_allocated(dev) / 1e9, 1)}
+    out["front_end_and_host_s"] = round(dt - out["prefill_s"] - out["decode_s"], 3)
+    eng.call_log = None
+    del front
+    _release(eng)
+    return out
+
+
+def bench_config2_full(eng, dev, n_items=3000, batch=768):
+    """BASELINE config #2 as the reference's driver runs it (llava_calibrate.py:130-219): 3,000 POPE-like items (500 images x 6) through
+    pope_driver.run_pope - main pass (use_dd_unk, alpha 1, beta 0.1, T 0.2, max_new_tokens 64, answers stopped by EOS after 1 - 2 tokens),
+    the none / unk prior passes, label dicts, the JSONL answers file and the plain + calibrated scorers.  The EOS ids are the second tokens
+    the same seeded list emits in an untimed pass (which is also the warm-up)."""
+    import torch as _t
+    _t.cuda.reset_peak_memory_stats(dev)
+    import torch
+    from llava_align_amd.pope_driver import run_pope
+    ids, imgs = pope_prompts(n_items // 6, seed=2024)
+    on_dev = {}
+    images = {f"im{i}.jpg": on_dev.setdefault(i, imgs[6 * i].to(dev).to(torch.bfloat16)) for i in range(n_items // 6)}
+    by_text = {f"q{i}": ids[i].tolist() for i in range(n_items)}
+    qs = [{"question_id": i, "image": f"im{i // 6}.jpg", "text": f"q{i}", "label": ("yes", "no")[i % 2]} for i in range(n_items)]
+    enc = lambda text, with_image: by_text[text] if with_image else [t for t in by_text[text] if t != -200]
+    kw = dict(batch_questions=batch, unk_token_id=0, pad_token_id=0, use_dd_unk=True, cd_alpha=1.0, cd_beta=0.1, temperature=0.2, seed=1, stop_str=None)
+    probe = run_pope(eng, qs, enc, lambda t: " ".join(map(str, t)), lambda n: images[n], max_new_tokens=2, eos_token_id=None, **kw)
+    eos = sorted({int(a["text"].split()[1]) for a in probe["answers"]})
+    path = os.path.join(ROOT, "gpurun_out", "bench_pope_answers.jsonl") if os.path.isdir(os.path.join(ROOT, "gpurun_out")) else "/tmp/bench_pope_answers.jsonl"
+    eng.call_log = []
+    res, dt = _timed(lambda: run_pope(eng, qs, enc, _decode_words, lambda n: images[n], answers_path=path, max_new_tokens=64, eos_token_id=eos,
+                                      sync_every=2, **kw), dev)
+    n_tok = sum(len(a["text"].split()) for a in res["answers"])
+    sc = res["scores"]
+    out = {"workload": f"LLaVA-1.5-7B shapes, {n_items} POPE-like items = {n_items // 6} images x 6 in batches of {batch} through pope_driver.run_pope: main pass (use_dd_unk, alpha 1, "
+                       f"beta 0.1, T 0.2, max_new_tokens 64, {len(eos)} EOS ids -> answers of 1 - 2 tokens) + none / unk prior passes + label dicts + JSONL + scorers",
+           "items": n_items, "seconds": round(dt, 3), "items_per_s": round(n_items / dt, 1), "answer_tokens_per_s": round(n_tok / dt, 1),
+           "mean_answer_tokens": round(n_tok / n_items, 2), **_split_calls(eng, eng.call_log), "host_s": None,
+           "answers_file_bytes": os.path.getsize(path), "scorers_ran": sorted(k for k, v in sc.items() if v is not None),
+           "nan_rows": {k: v.get("nan_rows") for k, v in sc.items() if isinstance(v, dict) and "nan_rows" in v}}
+    out["host_s"] = round(dt - out["prefill_s"] - out["decode_s"], 3)
+    eng.call_log = None
+    _release(eng)
+    return out
+
+
+def bench_batch_invariant(eng, dev, ids, kw, baseline_s):
+    """The headline step under ops.GEMM_BATCH_INVARIANT (data-parallel GEMM schedule only, fixed dispatch thresholds: a row's logits no
+    longer depend on who else is in the batch - what the sharded drivers select so that 1-GPU and N-GPU cd_greedy runs agree)."""
+    from llava_align_amd import ops
+    old = ops.GEMM_BATCH_INVARIANT
+    ops.GEMM_BATCH_INVARIANT = True
+    try:
+        _release(eng)
+        eng.generate(ids, **kw)
+        _, dt = _timed(lambda: eng.generate(ids, **kw), dev)
+    finally:
+        ops.GEMM_BATCH_INVARIANT = old
+        _release(eng)
+    Q, n_new = len(ids), kw["max_new_tokens"]
+    return {"tokens_per_s_per_gpu": round(Q * n_new / dt, 1), "seconds_per_step": round(dt, 3), "cost_vs_tuned_schedules": round(dt / baseline_s, 4),
+            "note": "same workload as the headline, ops.GEMM_BATCH_INVARIANT = True; one timed step after one warm-up"}
+
+
 # ------------------------------------------------------------------ strong scaling: one question list split over the ranks
 def run_strong(a, eng, dev, rank, world):
     """`--strong N`: what the eval drivers do on a node (MME/run_llava.py:32-40): ONE seeded POPE-like list of N questions,
@@ -634,6 +871,10 @@ def main():
             line["speedup_vs_eager_gpu_single_question"] = round(line["single_question"]["tokens_per_s"] / line["eager_gpu"]["value"], 1)
             line["cpu_baseline"] = bench_cpu(eng)
             line["llava_bench_eos"] = bench_llava_bench_eos(eng, dev)
+            # every BASELINE config on the driver-timed line; the 7B engine serves #2-full, #5 and the batch-invariant step
+            line["batch_invariant"] = bench_batch_invariant(eng, dev, ids, kw, dt / a.steps)
+            line["config2_full"] = bench_config2_full(eng, dev)
+            line["config5"] = bench_config5(eng, dev)
             # the same workload in the reference's own dtype (fp16: builder.py:40; config #2 - the headline - says bf16): the bf16 engine
             # and its KV pools go first (two engines do not fit 288 GB at 768 questions)
             del eng, out, oe, o2
@@ -641,6 +882,10 @@ def main():
             gc.collect()
             torch.cuda.empty_cache()
             line["fp16"] = bench_fp16(a, dev, ids, host_imgs, n_new)
+            gc.collect()
+            torch.cuda.empty_cache()
+            line["config3"] = bench_config3(dev)
+            line["config4"] = bench_config4(dev)
         else:
             line["cpu_baseline"] = None
         line["collective_backend"] = (os.environ.get("VDD_DIST_BACKEND", "nccl") if use_dist else None)

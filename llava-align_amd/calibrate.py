@@ -97,23 +97,29 @@ def pope_scores(gt: Sequence[dict], gen: Sequence[dict]) -> dict:
 def pope_scores_calibrated(gt: Sequence[dict], gen: Sequence[dict], name: str = "naive", mode: str = "diagonal_W") -> dict:
     """'individual' calibration per question: p from gen['naive'], prior from gen[name] ('none', 'unk', or
     'none_unk' = their sum); arg-max of the calibrated 2-vector is the answer (0 = yes)."""
-    tp = tn = fp = fn = unknown = yes = total = 0
+    tp = tn = fp = fn = unknown = yes = total = nan_rows = 0
     confidence = 0.0
     for g, a in zip(gt, gen):
         assert g["question_id"] == a["question_id"]
         label = LABEL_TO_INT[g["label"]]
         p = np.array(get_prob_from_logits(a["naive"]), dtype=np.float64)
-        p = p / np.sum(p)
+        with np.errstate(invalid="ignore", divide="ignore"):
+            p = p / np.sum(p)
         W, b = np.identity(2), np.zeros([2, 1])
         if name != "naive":
             if name == "none_unk":
                 cf = np.array(get_prob_from_logits(a["unk"])) + np.array(get_prob_from_logits(a["none"]))
             else:
                 cf = np.array(get_prob_from_logits(a[name]), dtype=np.float64)
-            cf = cf / np.sum(cf)
+            with np.errstate(invalid="ignore", divide="ignore"):
+                cf = cf / np.sum(cf)
             W, b = calibrate_weight([x + 1e-4 for x in cf], mode)
-        q = np.matmul(W, np.expand_dims(p, axis=-1)) + b
-        q /= np.sum(q)
+        with np.errstate(invalid="ignore", divide="ignore"):
+            q = np.matmul(W, np.expand_dims(p, axis=-1)) + b
+            q /= np.sum(q)
+        # neither label among the top-10 of the answer (or of the prior): 0 / 0 -> NaN, whose arg-max is class 0 = "yes" in the reference
+        # (eval_pope_calibrate.py:65-74 has no guard).  Scored the same way here, but counted: `nan_rows` of the result.
+        nan_rows += int(not np.all(np.isfinite(q)))
         ans = int(np.argmax(q))
         confidence += float(np.max(q))
         if label == 0:
@@ -129,6 +135,7 @@ def pope_scores_calibrated(gt: Sequence[dict], gen: Sequence[dict], name: str = 
         total += 1
     out = _prf(tp, tn, fp, fn, yes, unknown, total)
     out["confidence"] = confidence / total
+    out["nan_rows"] = nan_rows
     return out
 
 

@@ -866,6 +866,9 @@ class VddLlavaEngine:
         self._kvs: Dict[bool, KVCache] = {}
         self._feat_cache: Dict[int, torch.Tensor] = {}
         self._graphs: dict = {}
+        # a list: every generate() appends its `stats`, with three HIP events (call start, first token sampled, last step issued) under
+        # "events" - how bench.py splits a driver's wall time into prefill and decode steps without adding a sync (`call_timing`)
+        self.call_log: Optional[list] = None
 
     # -- plumbing ---------------------------------------------------------------------------
     def kv(self, n_pre, t_pre, n_own, t_own, frag_only=False):
@@ -963,6 +966,14 @@ class VddLlavaEngine:
     def clear_image_cache(self):
         self._feat_cache.clear()
 
+    @staticmethod
+    def call_timing(stats: dict) -> dict:
+        """Prefill (vision tower + prompt passes + first token) and decode-loop time of one logged call, from the events of `call_log`
+        (synchronises on the last one).  decode_ms covers steps - 1 decode steps (the first token comes out of the prefill)."""
+        e0, e1, e2 = stats["events"]
+        e2.synchronize()
+        return {"prefill_ms": e0.elapsed_time(e1), "decode_ms": e1.elapsed_time(e2), "decode_steps": max(int(stats.get("steps_run", 1)) - 1, 0)}
+
     # -- generate -------------------------------------------------------------------------------
     def generate(self, *args, **kwargs) -> "GenerateOutput":
         """See `_generate`.  Runs it with the cyclic garbage collector paused: the prefill issues ~2,000 launches from
@@ -1014,6 +1025,10 @@ class VddLlavaEngine:
         sampling, `put(next token)` after every step (vcd_sample.py:264-265: one device -> host copy per step) and `end()` at the
         end (:299-300).  One question per call, as HF's own streamers require."""
         dev, lm = self.device, self.cfg.lm
+        events = None
+        if self.call_log is not None and dev.type == "cuda":
+            events = [torch.cuda.Event(enable_timing=True) for _ in range(3)]
+            events[0].record(torch.cuda.current_stream(dev))
         am = other.get("attention_mask")
         if am is not None and not bool(torch.as_tensor(am).ne(0).all()):
             raise ValueError("attention_mask with zeros: a left-padded [Q, L] id tensor would be decoded with its pad tokens as prompt - "
@@ -1145,6 +1160,10 @@ class VddLlavaEngine:
             raise ValueError(f"prompt ({plan['max_len']} positions) + max_new_tokens ({max_new_tokens}) exceed the rotary table "
                              f"(max_pos = {self.cfg.lm.max_pos}): lower max_new_tokens or build the engine with a larger LMConfig.max_pos")
         stats = {"n_rows": nb * Q, "prefill_tokens": plan["prefill_tokens"], "unshared_prefill_tokens": plan["unshared_tokens"]}
+        # the K / V a decode step reads at step 0 (+ one token per row and step after it): per row (SURVEY 8d's sum over rows) and with every
+        # shared prefix counted once (the bytes that have to cross the chip at least once per step)
+        stats.update(decode_rows=len(dec_rows), ctx_tokens_rows=sum(r[1] for r in dec_rows),
+                     ctx_tokens_distinct=sum(r[1] - r[3] for r in dec_rows) + sum({r[2]: r[3] for r in dec_rows if r[3] > 0}.values()))
 
         want_maps = bool(output_attentions) and Q == 1 and lm.head_dim == 128 and lm.n_layers > 0
         passes, frag_plen = [], None
@@ -1225,6 +1244,8 @@ class VddLlavaEngine:
         run.load(pos=[seg[i]["pos0"] + seg[i]["T"] for i in sel], cpos=[seg[i]["T"] for i in sel], slot=[seg[i]["slot"] for i in sel],
                  rows=dec_rows)
         n_new = 1
+        if events is not None:
+            events[1].record(torch.cuda.current_stream(dev))
         # retirement state: `alive` = the original question index of every question still in the runner; `master` collects the tokens
         alive = list(range(Q))
         master = None
@@ -1296,6 +1317,10 @@ class VddLlavaEngine:
                     break
                 if done_bad[0]:                                                               # :291, amortised over sync_every steps
                     break
+        if events is not None:
+            events[2].record(torch.cuda.current_stream(dev))
+            stats["events"], stats["steps_run"] = events, n_new
+            self.call_log.append(stats)
         if bool((run.status | run.status0).ne(0).any().item()):
             raise RuntimeError("probability tensor contains either `inf`, `nan` or element < 0")   # torch.multinomial, :202
         if streamer is not None:
