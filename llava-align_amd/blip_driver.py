@@ -45,7 +45,8 @@ def run_blip_pope(engine: VddLlavaEngine, front: InstructBlipFrontEnd, questions
                   cd_alpha: Optional[float] = None, top_p: float = 1.0, top_k: Optional[int] = 50, temperature: float = 1.0,
                   repetition_penalty: float = 1.0,
                   max_length: int = 256, min_length: int = 1, eos_token_id=2, pad_token_id: Optional[int] = 2,
-                  model_id: str = "instruct_blip", rank: Optional[int] = None, world: Optional[int] = None, **generate_kw) -> dict:
+                  model_id: str = "instruct_blip", rank: Optional[int] = None, world: Optional[int] = None,
+                  batch_invariant: Optional[bool] = None, **generate_kw) -> dict:
     """questions: POPE json lines (question_id, image, text[, label]).  Defaults are the reference driver's: top_p 1, temperature 1,
     top_k 50 (LAVIS never passes top_k, so HF's GenerationConfig default warps every sampled step: blip2_vicuna_instruct.py:390-410),
     repetition_penalty 1, max_length 256, min_length 1, cd_alpha left at the sampler's default (None -> 0.5), noise_step 500.
@@ -53,8 +54,10 @@ def run_blip_pope(engine: VddLlavaEngine, front: InstructBlipFrontEnd, questions
     its chunk of whole images (shard.ShardPlan; BASELINE config #5 runs on 4 GPUs), ONE collective gathers the results, rank 0 writes
     the file, every rank returns the full result.  Returns {"answers": [...], "scores": {...}}; the JSONL has the reference's
     fields (question_id, prompt, text, model_id, image, naive, noise, zeros, metadata; blip_calibrate.py:100-109)."""
+    import contextlib
+    from . import ops
     from .pope_driver import ResultRows, cut_at_eos
-    from .shard import ShardPlan
+    from .shard import ShardPlan, resolve_batch_invariant
     order = sorted(range(len(questions)), key=lambda i: (questions[i]["image"], i))
     plan = ShardPlan([questions[i]["image"] for i in order], rank, world)
     mine = [order[p_] for p_ in plan.mine]
@@ -67,38 +70,40 @@ def run_blip_pope(engine: VddLlavaEngine, front: InstructBlipFrontEnd, questions
                    min_length=min_length, eos_token_id=eos_token_id, pad_token_id=pad_token_id, n_top=10, cd_beta=cd_beta,
                    cd_alpha=cd_alpha, **generate_kw)
     rows = ResultRows(engine.device, max_length, pad_token_id if pad_token_id is not None else 0, n_sets=3)
-    for b0 in range(0, len(mine), batch_questions):
-        idx = mine[b0:b0 + batch_questions]
-        qs = [questions[i] for i in idx]
-        prompts = [q["text"] + QUESTION_SUFFIX for q in qs]
-        llm_ids = [tokenize_llm(p) for p in prompts]
-        qf_ids = [tokenize_qformer(p) for p in prompts]
-        cache: Dict[str, torch.Tensor] = {}
-        for q in qs:
-            if q["image"] not in cache:
-                cache[q["image"]] = load_image(q["image"]).to(engine.device)
-        # EVA-ViT once per DISTINCT clean image and once for the `zeros` image; the noised copies are drawn per question (fresh noise inside
-        # the reference's loop, blip_calibrate.py:80-82, :96) and so are their ViT passes; the Q-Former reads the instruction: per question
-        names = list(cache)
-        where = [names.index(q["image"]) for q in qs]
-        uniq = torch.stack([cache[n] for n in names])
-        ie_u = front.image_embeds(uniq)
-        ie_main = ie_u[where]
-        imgs = uniq[where]
-        emb = front.assemble(front.embeds_to_llm(ie_main, qf_ids), llm_ids, embed)
-        emb_cd = None
-        if use_cd:
-            imgs_cd = torch.stack([add_diffusion_noise(im, noise_step) for im in imgs])
-            emb_cd = front.assemble(front.embeds_to_llm(front.image_embeds(imgs_cd), qf_ids), llm_ids, embed)
-        main = engine.generate(None, inputs_embeds=emb, images_cd=emb_cd, max_length=max_length, **base_kw)
-        noise999 = torch.stack([add_diffusion_noise(im, 999) for im in imgs])
-        emb_n = front.assemble(front.embeds_to_llm(front.image_embeds(noise999), qf_ids), llm_ids, embed)
-        ie_zero = front.image_embeds(torch.zeros_like(uniq[:1])).expand(len(qs), -1, -1).contiguous()
-        emb_z = front.assemble(front.embeds_to_llm(ie_zero, qf_ids), llm_ids, embed)
-        prior_kw = {k: v for k, v in base_kw.items() if k not in ("cd_beta", "cd_alpha")}
-        noise = engine.generate(None, inputs_embeds=emb_n, max_length=1, **prior_kw)
-        zeros = engine.generate(None, inputs_embeds=emb_z, max_length=1, **prior_kw)
-        rows.add(idx, map_pad_to_eos(main.tokens), [(o.top_tok, o.top_prob) for o in (main, noise, zeros)])
+    invariant = resolve_batch_invariant(batch_invariant, plan.world, generate_kw)    # (the LM side; the EVA-ViT / Q-Former front-end is per image / per question)
+    with (ops.batch_invariant() if invariant else contextlib.nullcontext()):
+        for b0 in range(0, len(mine), batch_questions):
+            idx = mine[b0:b0 + batch_questions]
+            qs = [questions[i] for i in idx]
+            prompts = [q["text"] + QUESTION_SUFFIX for q in qs]
+            llm_ids = [tokenize_llm(p) for p in prompts]
+            qf_ids = [tokenize_qformer(p) for p in prompts]
+            cache: Dict[str, torch.Tensor] = {}
+            for q in qs:
+                if q["image"] not in cache:
+                    cache[q["image"]] = load_image(q["image"]).to(engine.device)
+            # EVA-ViT once per DISTINCT clean image and once for the `zeros` image; the noised copies are drawn per question (fresh noise inside
+            # the reference's loop, blip_calibrate.py:80-82, :96) and so are their ViT passes; the Q-Former reads the instruction: per question
+            names = list(cache)
+            where = [names.index(q["image"]) for q in qs]
+            uniq = torch.stack([cache[n] for n in names])
+            ie_u = front.image_embeds(uniq)
+            ie_main = ie_u[where]
+            imgs = uniq[where]
+            emb = front.assemble(front.embeds_to_llm(ie_main, qf_ids), llm_ids, embed)
+            emb_cd = None
+            if use_cd:
+                imgs_cd = torch.stack([add_diffusion_noise(im, noise_step) for im in imgs])
+                emb_cd = front.assemble(front.embeds_to_llm(front.image_embeds(imgs_cd), qf_ids), llm_ids, embed)
+            main = engine.generate(None, inputs_embeds=emb, images_cd=emb_cd, max_length=max_length, **base_kw)
+            noise999 = torch.stack([add_diffusion_noise(im, 999) for im in imgs])
+            emb_n = front.assemble(front.embeds_to_llm(front.image_embeds(noise999), qf_ids), llm_ids, embed)
+            ie_zero = front.image_embeds(torch.zeros_like(uniq[:1])).expand(len(qs), -1, -1).contiguous()
+            emb_z = front.assemble(front.embeds_to_llm(ie_zero, qf_ids), llm_ids, embed)
+            prior_kw = {k: v for k, v in base_kw.items() if k not in ("cd_beta", "cd_alpha")}
+            noise = engine.generate(None, inputs_embeds=emb_n, max_length=1, **prior_kw)
+            zeros = engine.generate(None, inputs_embeds=emb_z, max_length=1, **prior_kw)
+            rows.add(idx, map_pad_to_eos(main.tokens), [(o.top_tok, o.top_prob) for o in (main, noise, zeros)])
     got = rows.gather(plan, len(questions))                    # ONE collective; every rank holds every question's results behind it
     dicts = [[C.label_dict_from_top(t, p_, decode_token) for t, p_ in got["tops"][s_]] for s_ in range(3)]
     ordered = [{"question_id": q["question_id"], "prompt": q["text"] + QUESTION_SUFFIX, "text": decode(cut_at_eos(got["tokens"][i], eos_set)).strip(),
@@ -119,4 +124,4 @@ def run_blip_pope(engine: VddLlavaEngine, front: InstructBlipFrontEnd, questions
                 scores[name] = fn(gt, ordered, *args)
             except ZeroDivisionError:
                 scores[name] = None
-    return {"answers": ordered, "scores": scores}
+    return {"answers": ordered, "scores": scores, "batch_invariant": invariant}

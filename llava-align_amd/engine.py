@@ -1144,15 +1144,18 @@ class VddLlavaEngine:
         keep = [i for i, (name, _, _) in enumerate(branches) if not (use_cd and name == "cd")]
         sel = [b_ * Q + q for b_ in keep for q in range(Q)]
         dec_rows = [[seg[i]["slot"], seg[i]["pos0"] + seg[i]["T"] + 1, seg[i]["pslot"], seg[i]["plen"]] for i in sel]
-        grp, _members = group_rows_by_prefix(dec_rows) if self.group_attention else ([], [])
+        grp, _members = group_rows_by_prefix(dec_rows) if (self.group_attention and not ops.GEMM_BATCH_INVARIANT) else ([], [])
         if grp and (not grouping_pays(grp, dec_rows) or (len(dec_rows) <= ops.FUSED_ATTN_MAX_M and lm.head_dim == 128)):
             grp = []      # (up to 16 rows the one-launch RoPE + KV write + attention kernel beats the three launches of the grouped
                           #  path although it reads a shared prefix once per row: tools/small_batch_attn_probe.py, +4 ... 9 %)
         # retirement / growth of the own pools needs an EOS to retire on, per-question state that lives only in the runner's row order
         # (no processor stage, no per-step scores rows, no streamer) and the ungrouped attention (slots are renumbered)
         suffix_max = max(s_["T"] for s_ in plan["suffix"])
+        # ... and, for deterministic decodes (cd_greedy / top_k = 1), only in batch-invariant mode: with the tuned forms a survivor's low-order bits
+        # change as the batch shrinks through the kernel regimes, where the reference keeps the full batch until every row has emitted EOS
+        deterministic = bool(cd_greedy or top_k == 1)
         retire = bool(self.retire and eos_token_id is not None and not output_scores and streamer is None and not proc and not grp
-                      and max_new_tokens > self.kv_chunk)
+                      and max_new_tokens > self.kv_chunk and (ops.GEMM_BATCH_INVARIANT or not deterministic))
         own_cap = min(max_new_tokens, self.kv_chunk) if retire else max_new_tokens
         kv = self.kv(len(plan["prefix"]), max([s_.get("full_T", s_["T"]) for s_ in plan["prefix"]] + [0]), len(plan["suffix"]),
                      suffix_max + own_cap, frag_only=bool(grp))
@@ -1186,7 +1189,7 @@ class VddLlavaEngine:
         segs = plan["suffix"]
         x, pos, cpos, slot, seqs, max_tq = self._pack(segs)
         # short suffixes behind shared prefixes: four sequences of one prefix per attention workgroup (ops.flash_packs)
-        packs_h = ops.flash_packs([[0, 0, 0, 0, s["pslot"], s["plen"]] for s in segs]) if (max_tq <= 32 and lm.head_dim == 128) else None
+        packs_h = ops.flash_packs([[0, 0, 0, 0, s["pslot"], s["plen"]] for s in segs]) if (max_tq <= 32 and lm.head_dim == 128 and (not ops.GEMM_BATCH_INVARIANT or ops.FLASH_PACKS_IN_INVARIANT_MODE)) else None
         last, last_seqs, packs = h2d_int32(dev, [s["q_row0"] + s["T"] - 1 for s in segs],
                                            [[i, 1, s["pos0"] + s["T"] - 1, s["slot"], s["pslot"], s["plen"]] for i, s in enumerate(segs)],
                                            packs_h if packs_h is not None else [[0, -1, -1, -1]])
@@ -1222,7 +1225,7 @@ class VddLlavaEngine:
         ctr0 = sd << 24
         eos_t = torch.tensor(eos_token_id, dtype=torch.long, device=dev) if eos_token_id is not None else None
         cfgkey = (Q, nb, max_new_tokens, alpha, beta, warp.t, warp.k, warp.p, use_cd, use_dd, use_dd_unk, cd_greedy,
-                  tuple(eos_token_id) if eos_token_id is not None else None, pad_token_id, output_scores)
+                  tuple(eos_token_id) if eos_token_id is not None else None, pad_token_id, output_scores, ops.GEMM_BATCH_INVARIANT)
         cpi = ops.prefix_chunks_per_item(grp, lm.n_heads)
         n_groups, n_items = len(grp), len(ops.prefix_work_items(grp, cpi))
         cfgkey = cfgkey + (n_groups, n_items, cpi, proc_key)
@@ -1287,7 +1290,7 @@ class VddLlavaEngine:
                         break
                     live_q = [j for j, u in enumerate(unf) if u]
                     own_len = suffix_max + n_new                                         # own rows of the longest live slot (an upper bound)
-                    grow = own_len + sync_every + 1 > kv.t_own and n_new < max_new_tokens
+                    grow = own_len + sync_every + 1 > kv.t_own and n_new < max_new_tokens and kv.t_own < suffix_max + max_new_tokens
                     shrink = len(live_q) <= self.retire_fraction * len(unf) and run.nb * len(live_q) >= self.retire_min_rows
                     if not shrink:
                         live_q = list(range(len(unf)))                                  # growth only: everybody stays
@@ -1305,6 +1308,8 @@ class VddLlavaEngine:
                         old_slots = new_run.adopt(run, q_idx, n_new)
                         kv.repack_own(old_slots, own_len, suffix_max + cap)
                         new_run.workspace = ops.attention_workspace(run.nb * Qn, lm.n_heads, lm.head_dim, kv.t_pre + (kv.t_own + 63) // 64 * 64, dev)
+                        for k_ in [k_ for k_ in self._graphs if len(k_) > len(cfgkey) and k_[len(cfgkey)] == "retired"]:
+                            self._graphs.pop(k_)                          # the runner of the previous retirement event: nothing replays it again
                         self._graphs[cfgkey + ("retired", Qn, kv.t_own, stats["retire_events"])] = new_run
                         alive = [alive[j] for j in live_q]
                         run = new_run
@@ -1330,6 +1335,8 @@ class VddLlavaEngine:
             gen = master[:, :n_new].clone()
             if run.Q != Q:                                     # the pools (and the last runner) are those of the survivors only
                 self._graphs = {k_: r_ for k_, r_ in self._graphs.items() if r_.kv is not kv}
+            for k_ in [k_ for k_ in self._graphs if len(k_) > len(cfgkey) and k_[len(cfgkey)] == "retired"]:
+                self._graphs.pop(k_)                           # a grown-only runner: its pools are sized for this call's tail, not the next call's start
         else:
             gen = run.gen[:, :n_new].clone()
         if eos_t is not None:
@@ -1412,7 +1419,7 @@ class VddLlavaEngine:
     two_level_prefix = True      # [system prompt] prefilled once, the image prefixes behind it (False: every [sys + image] prefix in full)
 
     @staticmethod
-    def _split_system_prompt(plan, min_tokens: int = 8):
+    def _split_system_prompt(plan, min_tokens: int = 8, min_saved: int = 128):
         """Two-level prefixes: the [system prompt + 576 patch embeddings] prefixes of a call all start with the same tokens (the
         conversation template, 35 ids for LLaVA-1.5): that part is prefilled ONCE into a slot of its own, and each image prefix only
         runs its patch rows, attending [parent slot | own rows] and keeping the rows in front for a copy of the parent's K / V - the slot
@@ -1424,7 +1431,9 @@ class VddLlavaEngine:
                 groups.setdefault(tuple(s_["tokens"]), []).append(s_)
         # one parent per call keeps the level-1 pass uniform (one row offset); take the prompt shared by the most images
         best = max(groups.items(), key=lambda kv_: len(kv_[1]), default=None)
-        if best is None or len(best[1]) < 2 or len(best[0]) < min_tokens:
+        # (one question with a VCD branch has two image prefixes: a third pass per layer to save 35 tokens is a loss - the split has to
+        #  save at least `min_saved` prefill tokens, i.e. five images behind LLaVA-1.5's 35-token system prompt)
+        if best is None or len(best[1]) < 2 or len(best[0]) < min_tokens or len(best[0]) * (len(best[1]) - 1) < min_saved:
             return
         toks, members = list(best[0]), best[1]
         parent = dict(slot=len(plan["prefix"]), tokens=toks, img=None, T=len(toks), pos0=0, pslot=0, plen=0)

@@ -98,7 +98,7 @@ def run_mme(engine: VddLlavaEngine, questions: Sequence[dict], build_inputs: Cal
             max_new_tokens: int = 20, min_new_tokens: Optional[int] = None, noise_step: Optional[int] = None,
             gt: Optional[Dict[tuple, str]] = None, results_root: Optional[str] = None, experiment: str = "exp",
             subsets: Optional[Sequence[str]] = MME_SUBSETS, chunk: Optional[tuple] = None, rank: Optional[int] = None,
-            world: Optional[int] = None, **generate_kw) -> dict:
+            world: Optional[int] = None, batch_invariant: Optional[bool] = None, **generate_kw) -> dict:
     """questions: the llava_mme.jsonl lines (question_id 'category/image.ext', image, text, category); subsets filters them as the
     reference does; chunk=(n, k) takes the reference's k-th of n contiguous ceil-chunks (get_chunk, run_llava.py:32-40).
     generate_kw: cd_alpha, cd_beta, use_dd, use_dd_unk, temperature, top_p, top_k, seed - the reference's generate kwargs; the Qwen
@@ -107,9 +107,11 @@ def run_mme(engine: VddLlavaEngine, questions: Sequence[dict], build_inputs: Cal
     rank / world (default: the initialised torch.distributed group): the data-parallel form of the reference's --num-chunks /
     --chunk-idx processes (run_llava.py:261-262) - every rank calls this with the same list, decodes its chunk of whole images
     (shard.ShardPlan), ONE collective gathers the per-question results, rank 0 writes the answers / result files; every rank returns
-    the full result.
+    the full result.  batch_invariant: as in pope_driver.run_pope (default: on for cd_greedy / top_k = 1 / do_sample = False decodes).
     Returns {"answers": [...], "results": {name: dir}, "scores": {name: mme_scores}}."""
-    from .shard import get_chunk
+    import contextlib
+    from . import ops
+    from .shard import get_chunk, resolve_batch_invariant
     qs_all = [q for q in questions if subsets is None or q.get("category") in subsets]
     if chunk is not None:
         qs_all = [qs_all[i] for i in get_chunk(len(qs_all), chunk[0], chunk[1], group=1)]
@@ -124,33 +126,35 @@ def run_mme(engine: VddLlavaEngine, questions: Sequence[dict], build_inputs: Cal
         generate_kw = dict(generate_kw, seed=int(generate_kw["seed"]) + plan.rank)
     rows = ResultRows(engine.device, max_new_tokens, pad_token_id if pad_token_id is not None else 0, n_sets=3)
     plain_kw = {k: v for k, v in generate_kw.items() if k in ("temperature", "top_p", "top_k", "seed", "cd_alpha", "cd_beta")}
-    for b0 in range(0, len(mine), batch_questions):
-        idx = mine[b0:b0 + batch_questions]
-        lines = [qs_all[i] for i in idx]
-        img_cache: Dict[str, dict] = {}
+    invariant = resolve_batch_invariant(batch_invariant, plan.world, generate_kw)
+    with (ops.batch_invariant() if invariant else contextlib.nullcontext()):
+        for b0 in range(0, len(mine), batch_questions):
+            idx = mine[b0:b0 + batch_questions]
+            lines = [qs_all[i] for i in idx]
+            img_cache: Dict[str, dict] = {}
 
-        def main_inputs(line):
-            # one tensor object per distinct image, so that the engine shares its features and prompt-prefix KV
-            b = build_inputs(line, "main")
-            if b.get("image") is not None:
-                b["image"] = img_cache.setdefault(line["image"], b)["image"]
-            return b
-        mains = [main_inputs(l) for l in lines]
-        kw = dict(generate_kw)
-        if noise_step is not None and "image" in mains[0]:
-            from .vcd_add_noise import add_diffusion_noise
-            kw["images_cd"] = [add_diffusion_noise(img_cache[l["image"]]["image"].to(engine.device), noise_step) for l in lines]   # run_llava.py:187-190
-        main = _generate(engine, mains, max_new_tokens=max_new_tokens, n_top=10, eos_token_id=eos_token_id, pad_token_id=pad_token_id,
-                         min_new_tokens=min_new_tokens, **kw)
-        # content-free priors: plain sampling, only the step-0 distribution is used; min_new_tokens = 1 keeps EOS out of it as in
-        # the reference's calibration calls (run_qwen.py:111-131)
-        prior_kw = dict(max_new_tokens=1, n_top=10, **plain_kw)
-        if min_new_tokens:
-            prior_kw.update(min_new_tokens=min_new_tokens, eos_token_id=eos_token_id, pad_token_id=pad_token_id)
-        none = _generate(engine, [build_inputs(l, "none") for l in lines], **prior_kw)
-        unk = _generate(engine, [build_inputs(l, "unk") for l in lines], **prior_kw)
-        rows.add(idx, main.tokens, [(o.top_tok, o.top_prob) for o in (main, none, unk)])
-        engine.clear_image_cache()
+            def main_inputs(line):
+                # one tensor object per distinct image, so that the engine shares its features and prompt-prefix KV
+                b = build_inputs(line, "main")
+                if b.get("image") is not None:
+                    b["image"] = img_cache.setdefault(line["image"], b)["image"]
+                return b
+            mains = [main_inputs(l) for l in lines]
+            kw = dict(generate_kw)
+            if noise_step is not None and "image" in mains[0]:
+                from .vcd_add_noise import add_diffusion_noise
+                kw["images_cd"] = [add_diffusion_noise(img_cache[l["image"]]["image"].to(engine.device), noise_step) for l in lines]   # run_llava.py:187-190
+            main = _generate(engine, mains, max_new_tokens=max_new_tokens, n_top=10, eos_token_id=eos_token_id, pad_token_id=pad_token_id,
+                             min_new_tokens=min_new_tokens, **kw)
+            # content-free priors: plain sampling, only the step-0 distribution is used; min_new_tokens = 1 keeps EOS out of it as in
+            # the reference's calibration calls (run_qwen.py:111-131)
+            prior_kw = dict(max_new_tokens=1, n_top=10, **plain_kw)
+            if min_new_tokens:
+                prior_kw.update(min_new_tokens=min_new_tokens, eos_token_id=eos_token_id, pad_token_id=pad_token_id)
+            none = _generate(engine, [build_inputs(l, "none") for l in lines], **prior_kw)
+            unk = _generate(engine, [build_inputs(l, "unk") for l in lines], **prior_kw)
+            rows.add(idx, main.tokens, [(o.top_tok, o.top_prob) for o in (main, none, unk)])
+            engine.clear_image_cache()
     got = rows.gather(plan, len(qs_all))                       # ONE collective; every rank holds every question's results behind it
     dicts = [[C.label_dict_from_top(t, p_, decode_token) for t, p_ in got["tops"][s_]] for s_ in range(3)]
     answers = []
@@ -169,7 +173,7 @@ def run_mme(engine: VddLlavaEngine, questions: Sequence[dict], build_inputs: Cal
         with open(answers_path, "w") as f:
             for a in answers:
                 f.write(json.dumps(a) + "\n")
-    out = {"answers": answers, "results": {}, "scores": {}}
+    out = {"answers": answers, "results": {}, "scores": {}, "batch_invariant": invariant}
     if gt is not None:
         conv = C.mme_convert(answers, gt)
         out["converted"] = conv

@@ -3,6 +3,7 @@ provides device memory and the stream; every op here is a hand-written HIP kerne
 raises if the library is missing (no eager fallback)."""
 from __future__ import annotations
 
+import contextlib
 import ctypes as C
 from typing import Optional
 
@@ -232,8 +233,8 @@ NORM_FUSED_GAP = (9, 12)  # ... except here: from 9 rows the normalise-once kern
 
 
 def norm_fused_pays(M: int, d: int) -> bool:
-    """Does a decode step of M rows take the norm-fused five-launch layer?"""
-    if M > norm_fused_rows(d) or NORM_FUSED_GAP[0] <= M <= NORM_FUSED_GAP[1]:
+    """Does a decode step of M rows take the norm-fused five-launch layer?  (Never in batch-invariant mode: one projection form.)"""
+    if GEMM_BATCH_INVARIANT or M > norm_fused_rows(d) or NORM_FUSED_GAP[0] <= M <= NORM_FUSED_GAP[1]:
         return False
     return M <= UNEVEN_FUSED_MAX_M or not uneven_column_blocks(d)
 
@@ -287,9 +288,9 @@ def skinny_rows(N, K):
     X fragment, eight waves splitting K, two register stages (skinny_wide_kernel) - the GEMM's time is flat in M below one macro tile
     (qkv 31, o 27, gate/up 43, down 38 us: a 64 x 256 tile grid that covers a fraction of the CUs plus a serial stream-K fix-up), the
     16-column kernel re-read X four times per weight byte at 64 rows (tools/skinny_crossover_probe.py).  Needs K % 256 == 0 (every
-    LLaVA / Qwen width).  Under GEMM_BATCH_INVARIANT the switch stays at SKINNY_MAX_M rows."""
+    LLaVA / Qwen width).  Under GEMM_BATCH_INVARIANT there is no switch: every projection is the MFMA GEMM at every row count."""
     if GEMM_BATCH_INVARIANT:
-        return SKINNY_MAX_M
+        return 0
     if N > 8192:
         if (N, K) in SKINNY_ROWS_MEASURED:
             return SKINNY_ROWS_MEASURED[(N, K)]
@@ -317,11 +318,35 @@ EPI_NONE, EPI_BIAS, EPI_BIAS_QUICK_GELU, EPI_BIAS_GELU, EPI_SWIGLU, EPI_BIAS_RES
 GEMM_TUNE_MAX_M = 4096          # shapes up to here (the decode batch, single images) pick their tile shape / schedule by a
                                 # one-off timing run; above, 256 x 256 tiles + the hybrid schedule (tools/gemm_sched.py)
 GEMM_CANDIDATES = [(c, s_) for c in (1, 2, 3, 4, 5, 6, 7, 8, 9, 10, 11) for s_ in (0, 1, 2)]     # (macro tile id, schedule) -> config = c + 16 * s
-GEMM_BATCH_INVARIANT = False    # True: data-parallel schedule only.  Every output element is then accumulated over K in one fixed
-                                # order whatever the macro tile, i.e. a row's result does not depend on which other rows are in the
-                                # batch (stream-K cuts K where the batch shape puts the cut); costs the load balance at decode size
+GEMM_BATCH_INVARIANT = False    # True = batch-invariant mode: a row's results no longer depend on which other rows share its batch, because
+                                # every op then has ONE form with one summation order per output element -
+                                #   * projections: the MFMA GEMM's data-parallel schedule at EVERY row count (each element accumulated over K in one fixed
+                                #     order whatever the macro tile; stream-K cuts K where the batch shape puts the cut, the weight-streaming kernels split
+                                #     K over waves): skinny_rows() = 0, no norm-fused layer, no split-K slabs;
+                                #   * decode attention: rope_kv_write + the per-row split-KV kernel (fixed 64-key chunks merged in key order) for every batch -
+                                #     no one-launch kernel for few rows, no grouped prefix pass (its chunking follows the batch): fused_attention_rows() = 0,
+                                #     engine: no grouping;
+                                #   * prefill: one sequence per attention workgroup (no packs of four short suffixes).
+                                # What it buys: 1-GPU and N-GPU runs of a deterministic decode (cd_greedy / top_k = 1) agree token for token,
+                                # so do a batch and any sub-batch, and row retirement is exact.  What it costs: `batch_invariant` on the bench line.
+                                # The sharded drivers select it for such runs (pope_driver.resolve_batch_invariant); `with ops.batch_invariant():` scopes it.
 _gemm_ws = {}
 _gemm_choice = {}
+
+
+FLASH_PACKS_IN_INVARIANT_MODE = False   # (tools/invariance_probe.py decides: are packs of four suffixes bit-identical to one per workgroup?)
+
+
+@contextlib.contextmanager
+def batch_invariant(on: bool = True):
+    """Scope of the batch-invariant mode (GEMM_BATCH_INVARIANT above).  Captured decode steps are keyed by the mode, so entering or
+    leaving it never replays a graph of the other form."""
+    global GEMM_BATCH_INVARIANT
+    old, GEMM_BATCH_INVARIANT = GEMM_BATCH_INVARIANT, bool(on)
+    try:
+        yield
+    finally:
+        GEMM_BATCH_INVARIANT = old
 
 
 def _gemm_workspace(device, M, N):
@@ -643,9 +668,9 @@ FUSED_ATTN_UNGROUPED_MAX_M = 32
 
 
 def fused_attention_rows() -> int:
-    """Rows up to which an UNGROUPED decode step takes the one-launch RoPE + KV write + attention kernel.  Under GEMM_BATCH_INVARIANT the
-    wider band is off: a batch that shrinks through it (row retirement) would change the order its keys are summed in."""
-    return FUSED_ATTN_MAX_M if GEMM_BATCH_INVARIANT else max(FUSED_ATTN_MAX_M, FUSED_ATTN_UNGROUPED_MAX_M)
+    """Rows up to which an UNGROUPED decode step takes the one-launch RoPE + KV write + attention kernel.  Under GEMM_BATCH_INVARIANT: none
+    (the split-KV kernel sums a row's keys in one order at every batch size; a batch that shrinks into the one-launch band would change it)."""
+    return 0 if GEMM_BATCH_INVARIANT else max(FUSED_ATTN_MAX_M, FUSED_ATTN_UNGROUPED_MAX_M)
 
 
 FUSED_ATTN_SPLIT = True   # cut the keys of a (row, head) over 2 / 4 workgroups while H x M of them would leave most CUs idle

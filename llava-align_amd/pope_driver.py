@@ -88,7 +88,7 @@ def run_pope(engine: VddLlavaEngine, questions: Sequence[dict], encode: Callable
              decode: Callable[[List[int]], str], load_image: Callable[[str], torch.Tensor], answers_path: Optional[str] = None,
              model_id: str = "llava-align_amd", batch_questions: int = 384, unk_token_id: int = 0, eos_token_id=None,
              pad_token_id: Optional[int] = None, stop_str: Optional[str] = "</s>", max_new_tokens: int = 64, noise_step: Optional[int] = None,
-             rank: Optional[int] = None, world: Optional[int] = None, **generate_kw) -> dict:
+             rank: Optional[int] = None, world: Optional[int] = None, batch_invariant: Optional[bool] = None, **generate_kw) -> dict:
     """questions: dicts with question_id, image, text, label (the POPE json lines).  generate_kw: cd_alpha, cd_beta, use_dd,
     use_dd_unk, temperature, top_p, top_k, seed ... exactly the reference's model.generate kwargs (llava_calibrate.py:161-177);
     noise_step adds the VCD branch (images_cd = add_diffusion_noise(image, noise_step), :152-155).
@@ -97,9 +97,14 @@ def run_pope(engine: VddLlavaEngine, questions: Sequence[dict], encode: Callable
     with `rank` / `world` (default: the initialised torch.distributed group, else one rank) every rank calls this with the SAME
     question list, decodes its contiguous chunk of whole images (shard.ShardPlan), the per-question results are gathered in ONE
     collective, and rank 0 writes the answers file; every rank returns the full result.  An explicit `seed` is offset by the rank
-    (sampled runs then differ from a 1-rank run; cd_greedy / top_k = 1 runs are shard-invariant).
+    (sampled runs then differ from a 1-rank run).  Deterministic decodes (cd_greedy / top_k = 1 / do_sample = False) run in
+    batch-invariant mode unless `batch_invariant=False` (shard.resolve_batch_invariant, ops.GEMM_BATCH_INVARIANT): their answers are
+    then token for token the same on 1 and on N ranks and for every batch_questions; with the tuned kernel forms (the default for
+    sampled runs) a row's low-order bits depend on who shares its batch.
     Returns {"answers": [...], "scores": {"string_match": ..., "naive": ..., "none": ..., "unk": ..., "none_unk": ...}}."""
-    from .shard import ShardPlan
+    import contextlib
+    from . import ops
+    from .shard import ShardPlan, resolve_batch_invariant
     order = sorted(range(len(questions)), key=lambda i: (questions[i]["image"], i))      # one image's questions adjacent
     plan = ShardPlan([questions[i]["image"] for i in order], rank, world)
     mine = [order[p_] for p_ in plan.mine]
@@ -108,33 +113,35 @@ def run_pope(engine: VddLlavaEngine, questions: Sequence[dict], encode: Callable
         generate_kw = dict(generate_kw, seed=int(generate_kw["seed"]) + plan.rank)
     rows = ResultRows(engine.device, max_new_tokens, pad_token_id if pad_token_id is not None else 0, n_sets=3)
     img_cache: Dict[str, torch.Tensor] = {}
-    for b0 in range(0, len(mine), batch_questions):
-        idx = mine[b0:b0 + batch_questions]
-        qs = [questions[i] for i in idx]
-        for q in qs:
-            if q["image"] not in img_cache:
-                img_cache[q["image"]] = load_image(q["image"]).to(engine.device)
-        imgs = [img_cache[q["image"]] for q in qs]
-        ids_main = [torch.tensor(encode(q["text"], True)) for q in qs]
-        ids_none = [torch.tensor(encode(q["text"], False)) for q in qs]
-        ids_unk = [torch.tensor([unk_token_id if t == IMAGE_TOKEN_INDEX else t for t in r.tolist()]) for r in ids_main]    # :59-60
-        kw = dict(generate_kw)
-        if noise_step is not None:
-            from .vcd_add_noise import add_diffusion_noise
-            # fresh noise per QUESTION, as the reference draws it inside its per-question loop (llava_calibrate.py:152-155)
-            kw["images_cd"] = [add_diffusion_noise(img_cache[q["image"]], noise_step) for q in qs]
-        main = engine.generate(ids_main, images=imgs, max_new_tokens=max_new_tokens, n_top=10, eos_token_id=eos_token_id,
-                               pad_token_id=pad_token_id, **kw)
-        # content-free priors: plain sampling (no image -> no contrast branch), step-0 distribution only
-        plain_kw = {k: v for k, v in generate_kw.items() if k in ("temperature", "top_p", "top_k", "seed", "cd_alpha", "cd_beta")}
-        # (one call for both priors: 2 x len(qs) text-only prompts that share the conversation template's system prompt as a prefix slot)
-        prior = engine.generate(ids_none + ids_unk, images=None, max_new_tokens=1, n_top=10, **plain_kw)
-        n = len(qs)
-        rows.add(idx, main.tokens, [(main.top_tok, main.top_prob), (prior.top_tok[:n], prior.top_prob[:n]), (prior.top_tok[n:], prior.top_prob[n:])])
-        ahead = {questions[i]["image"] for i in mine[b0 + batch_questions:b0 + 2 * batch_questions]}
-        for k in [k for k in img_cache if k not in ahead]:
-            img_cache.pop(k)                                   # images are revisited only within a sorted neighbourhood
-        engine.clear_image_cache()
+    invariant = resolve_batch_invariant(batch_invariant, plan.world, generate_kw)
+    with (ops.batch_invariant() if invariant else contextlib.nullcontext()):
+        for b0 in range(0, len(mine), batch_questions):
+            idx = mine[b0:b0 + batch_questions]
+            qs = [questions[i] for i in idx]
+            for q in qs:
+                if q["image"] not in img_cache:
+                    img_cache[q["image"]] = load_image(q["image"]).to(engine.device)
+            imgs = [img_cache[q["image"]] for q in qs]
+            ids_main = [torch.tensor(encode(q["text"], True)) for q in qs]
+            ids_none = [torch.tensor(encode(q["text"], False)) for q in qs]
+            ids_unk = [torch.tensor([unk_token_id if t == IMAGE_TOKEN_INDEX else t for t in r.tolist()]) for r in ids_main]    # :59-60
+            kw = dict(generate_kw)
+            if noise_step is not None:
+                from .vcd_add_noise import add_diffusion_noise
+                # fresh noise per QUESTION, as the reference draws it inside its per-question loop (llava_calibrate.py:152-155)
+                kw["images_cd"] = [add_diffusion_noise(img_cache[q["image"]], noise_step) for q in qs]
+            main = engine.generate(ids_main, images=imgs, max_new_tokens=max_new_tokens, n_top=10, eos_token_id=eos_token_id,
+                                   pad_token_id=pad_token_id, **kw)
+            # content-free priors: plain sampling (no image -> no contrast branch), step-0 distribution only
+            plain_kw = {k: v for k, v in generate_kw.items() if k in ("temperature", "top_p", "top_k", "seed", "cd_alpha", "cd_beta")}
+            # (one call for both priors: 2 x len(qs) text-only prompts that share the conversation template's system prompt as a prefix slot)
+            prior = engine.generate(ids_none + ids_unk, images=None, max_new_tokens=1, n_top=10, **plain_kw)
+            n = len(qs)
+            rows.add(idx, main.tokens, [(main.top_tok, main.top_prob), (prior.top_tok[:n], prior.top_prob[:n]), (prior.top_tok[n:], prior.top_prob[n:])])
+            ahead = {questions[i]["image"] for i in mine[b0 + batch_questions:b0 + 2 * batch_questions]}
+            for k in [k for k in img_cache if k not in ahead]:
+                img_cache.pop(k)                                   # images are revisited only within a sorted neighbourhood
+            engine.clear_image_cache()
     got = rows.gather(plan, len(questions))                    # ONE collective; every rank holds every question's results behind it
     eos_set = set([eos_token_id] if isinstance(eos_token_id, int) else (eos_token_id or []))
     dicts = [[C.label_dict_from_top(t, p_, decode_token) for t, p_ in got["tops"][s_]] for s_ in range(3)]
@@ -156,7 +163,7 @@ def run_pope(engine: VddLlavaEngine, questions: Sequence[dict], encode: Callable
         scores["string_match"] = _try(C.pope_scores, gt, ordered)
         for name in ("naive", "none", "unk", "none_unk"):
             scores[name] = _try(C.pope_scores_calibrated, gt, ordered, name)
-    return {"answers": ordered, "scores": scores, "rank": plan.rank, "world": plan.world}
+    return {"answers": ordered, "scores": scores, "rank": plan.rank, "world": plan.world, "batch_invariant": invariant}
 
 
 def _try(f, *a):

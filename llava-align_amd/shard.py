@@ -131,3 +131,13 @@ def init_from_env(device_index: int | None = None):
         kw = {"device_id": device} if backend == "nccl" else {}
         dist.init_process_group(backend, rank=rank, world_size=world, **kw)
     return rank, world, device
+
+
+def resolve_batch_invariant(batch_invariant, world: int, generate_kw: dict) -> bool:
+    """Do the drivers decode in batch-invariant mode (ops.GEMM_BATCH_INVARIANT: one arithmetic form per op, a row's results independent of
+    its batch)?  An explicit True / False wins.  Default: yes for DETERMINISTIC decodes - cd_greedy, top_k = 1, do_sample = False - whose
+    answers are then the same token for token on 1 and on N ranks and for any batch size (SURVEY 8e: "top-k=1 runs are shard-invariant");
+    no for sampled runs, whose per-rank seeds make the shards differ from a 1-rank run anyway (`world` is accepted for that statement only)."""
+    if batch_invariant is not None:
+        return bool(batch_invariant)
+    return bool(generate_kw.get("cd_greedy") or generate_kw.get("top_k") == 1 or generate_kw.get("do_sample") is False)

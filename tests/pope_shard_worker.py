@@ -36,14 +36,13 @@ def load_image(name):
 
 
 def main(out_path):
-    from llava_align_amd import ops
     from llava_align_amd.engine import LlavaWeights, VddLlavaEngine, preset
     from llava_align_amd.pope_driver import run_pope
     from llava_align_amd.shard import init_from_env
     rank, world, dev = init_from_env()
-    # one fixed GEMM schedule: a row's logits then do not depend on which other questions share its batch (the chunk of a rank is a
-    # different batch than the whole list) nor on a timing-based tuner pick - so 2 ranks and 1 rank must agree token for token
-    ops.GEMM_AUTOTUNE, ops.GEMM_BATCH_INVARIANT = False, True
+    # nothing set by hand: cd_greedy makes run_pope decode in batch-invariant mode (shard.resolve_batch_invariant), in which a row's logits
+    # do not depend on which other questions share its batch (the chunk of a rank is a different batch than the whole list) nor on a
+    # timing-based tuner pick - so 2 ranks and 1 rank must agree token for token
     cfg = preset("tiny")
     eng = VddLlavaEngine(cfg, weights=LlavaWeights.random(cfg, dev, seed=3, std=0.06, dtype=torch.float16), device=dev, use_graph=True)
     res = run_pope(eng, questions(), encode, decode, load_image, answers_path=out_path + ".jsonl", batch_questions=8, max_new_tokens=6,

@@ -108,7 +108,7 @@ def test_two_level_prefixes_prefill_the_system_prompt_once():
     ids = [sys_tok + [IMG] + [7, 8, 9], sys_tok + [IMG] + [7, 8, 9, 10], sys_tok + [IMG] + [5]]
     plan = PlanOnly()._plan(branches_for(ids, [img_a, img_a, img_b], use_none=True), 576, True)
     before = plan["prefill_tokens"]
-    VddLlavaEngine._split_system_prompt(plan)
+    VddLlavaEngine._split_system_prompt(plan, min_saved=0)
     pre = plan["prefix"]
     assert [p["slot"] for p in pre] == [0, 1, 2, 3, 4] and pre[4]["tokens"] == sys_tok and pre[4]["img"] is None and pre[4]["T"] == 35
     for p in pre[:2]:                                                   # the two image prefixes: patch rows only, behind the parent
@@ -121,3 +121,10 @@ def test_two_level_prefixes_prefill_the_system_prompt_once():
     n = len(plan1["prefix"])
     VddLlavaEngine._split_system_prompt(plan1)
     assert len(plan1["prefix"]) == n and "cpos0" not in plan1["prefix"][0]
+    # ... and so do two images by default (one question + its VCD branch: a third prefill pass per layer to save 35 tokens is a loss;
+    # the split has to save >= 128 prefill tokens = five images behind a 35-token template)
+    for n_img, split in ((2, False), (4, False), (5, True)):
+        imgs_ = [torch.zeros(576, 8) for _ in range(n_img)]
+        plan_n = PlanOnly()._plan(branches_for([ids[0]] * n_img, imgs_), 576, True)
+        VddLlavaEngine._split_system_prompt(plan_n)
+        assert any("cpos0" in p_ for p_ in plan_n["prefix"]) == split, n_img

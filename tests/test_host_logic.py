@@ -173,17 +173,27 @@ def test_which_decode_steps_take_the_five_launch_layer():
 
 
 def test_one_launch_attention_band_and_its_batch_invariant_form():
-    """Ungrouped decode steps take the one-launch RoPE + KV write + attention kernel up to 32 rows (round 5: tools/few_row_curve.py); with
-    GEMM_BATCH_INVARIANT the band stays at the 16 rows of the few-row layer, so a batch that shrinks through 17 - 32 rows (row retirement)
-    keeps summing its keys in one order."""
+    """Ungrouped decode steps take the one-launch RoPE + KV write + attention kernel up to 32 rows (round 5: tools/few_row_curve.py).  In
+    batch-invariant mode every op has ONE form (round 6): no one-launch attention, no weight-streaming projections, no norm-fused layer,
+    no split-K slabs - whatever the row count - and `with ops.batch_invariant()` scopes the mode."""
     from llava_align_amd import ops
     assert ops.FUSED_ATTN_MAX_M == 16 and ops.FUSED_ATTN_UNGROUPED_MAX_M == 32 and ops.fused_attention_rows() == 32
-    old = ops.GEMM_BATCH_INVARIANT
-    try:
-        ops.GEMM_BATCH_INVARIANT = True
-        assert ops.fused_attention_rows() == 16
-    finally:
-        ops.GEMM_BATCH_INVARIANT = old
+    assert not ops.GEMM_BATCH_INVARIANT
+    with ops.batch_invariant():
+        assert ops.GEMM_BATCH_INVARIANT and ops.fused_attention_rows() == 0
+        assert ops.skinny_rows(4096, 4096) == ops.skinny_rows(32000, 4096) == ops.skinny_rows(27648, 5120) == 0
+        assert not any(ops.norm_fused_pays(m, 4096) for m in range(1, 20))
+        with ops.batch_invariant(False):
+            assert ops.fused_attention_rows() == 32
+        assert ops.GEMM_BATCH_INVARIANT
+    assert not ops.GEMM_BATCH_INVARIANT and ops.skinny_rows(4096, 4096) == 64
+
+
+def test_drivers_select_batch_invariance_for_deterministic_decodes():
+    from llava_align_amd.shard import resolve_batch_invariant as r
+    assert r(None, 1, dict(cd_greedy=True)) and r(None, 8, dict(top_k=1)) and r(None, 1, dict(do_sample=False))
+    assert not r(None, 8, dict(temperature=0.2, seed=1)) and not r(None, 1, dict(top_k=50)) and not r(None, 1, {})
+    assert r(True, 1, {}) and not r(False, 8, dict(cd_greedy=True))
 
 
 def test_in_tree_gemm_defaults_are_bound_to_the_kernel_source():
