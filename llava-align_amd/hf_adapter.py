@@ -172,14 +172,27 @@ def _resolve_generate_kwargs(gc, kw):
     return args, return_dict, want_attn
 
 
+def _set_guard(model) -> None:
+    """Remember where the model's lm_head lives (and its in-place version) at attach time.  The engine may hold a COPY of it (a tied or
+    non-contiguous lm_head goes through .contiguous()), so comparing against the engine's tensor would raise on every call; what has to be
+    noticed is the MODEL's parameter being re-allocated (model.to() / .half() / resize_token_embeddings) or overwritten in place."""
+    w = model.lm_head.weight
+    model._vdd_guard = (w.data_ptr(), w._version, tuple(w.shape), w.dtype)
+
+
+def _check_guard(model, message: str) -> None:
+    w = model.lm_head.weight
+    if getattr(model, "_vdd_guard", None) != (w.data_ptr(), w._version, tuple(w.shape), w.dtype):
+        raise RuntimeError(message)
+
+
 def _native_generate(model, inputs=None, generation_config=None, **kw):
     """`GenerationMixin.generate`'s argument handling for the keywords the reference's drivers use, in front of
     `VddLlavaEngine.generate`.  Explicit keywords (None included: llava_calibrate.py:170-171 pass top_p=None, top_k=None) override
     `model.generation_config`, as `generation_config.update(**kwargs)` does in HF."""
     eng: VddLlavaEngine = model._vdd_engine
-    if model.lm_head.weight.data_ptr() != eng.w.t["lm_head"].data_ptr():
-        raise RuntimeError("the model's parameters moved since attach_engine(model) (model.to() / .half() / resize_token_embeddings re-allocate "
-                           "them): the engine would decode with the old weights - call attach_engine(model) again")
+    _check_guard(model, "the model's parameters moved since attach_engine(model) (model.to() / .half() / resize_token_embeddings re-allocate "
+                        "them): the engine would decode with the old weights - call attach_engine(model) again")
     gc = generation_config if generation_config is not None else model.generation_config
     input_ids = inputs if inputs is not None else kw.pop("input_ids", None)
     if input_ids is None and kw.get("inputs_embeds") is None:
@@ -210,6 +223,7 @@ def attach_engine(model, share_storage: bool = True, use_graph: bool = True, max
     w = weights_from_hf(model, cfg, share_storage=share_storage)
     eng = VddLlavaEngine(cfg, weights=w, device=w.device, use_graph=use_graph, max_questions=max_questions)
     model._vdd_engine = eng
+    _set_guard(model)
     model.generate = types.MethodType(_native_generate, model)
     return eng
 
@@ -301,8 +315,7 @@ def _native_lm_generate(lm, inputs=None, generation_config=None, **kw):
     `generate(input_ids / inputs_embeds, stop_words_ids, min_new_tokens, ...)` (modeling_qwen.py:1044-1087) on the native engine.
     HF returns only the NEW tokens for an embeddings prompt; so does this."""
     eng: VddLlavaEngine = lm._vdd_engine
-    if lm.lm_head.weight.data_ptr() != eng.w.t["lm_head"].data_ptr():
-        raise RuntimeError("the language model's parameters moved since the engine was attached: attach again")
+    _check_guard(lm, "the language model's parameters moved since the engine was attached: attach again")
     gc = generation_config if generation_config is not None else lm.generation_config
     input_ids = inputs if inputs is not None else kw.pop("input_ids", None)
     embeds, mask = kw.pop("inputs_embeds", None), kw.pop("attention_mask", None)
@@ -342,6 +355,7 @@ def attach_lm_engine(lm, use_graph: bool = True, max_questions: int = 64) -> Vdd
     cfg = lm_config_from_hf(lm)
     eng = VddLlavaEngine(cfg, weights=lm_weights_from_hf(lm, cfg), device=lm.lm_head.weight.device, use_graph=use_graph, max_questions=max_questions)
     lm._vdd_engine = eng
+    _set_guard(lm)
     lm.generate = types.MethodType(_native_lm_generate, lm)
     return eng
 
@@ -486,8 +500,13 @@ def _native_qwen_generate(model, inputs=None, generation_config=None, **kw):
         kw["images_cd"] = torch.stack(cd if keep is None else [e[keep[i]] for i, e in enumerate(cd)])
     return_dict = kw.get("return_dict_in_generate", getattr(generation_config or model.generation_config, "return_dict_in_generate", False))
     out = _native_lm_generate(model, None, generation_config, **dict(kw, return_dict_in_generate=True))
-    seqs = torch.nn.utils.rnn.pad_sequence([torch.cat([r, t]) for r, t in zip(rows, out["tokens"])], batch_first=True,
-                                           padding_value=0)               # HF echoes the prompt ids in front (ids were given)
+    gc = generation_config if generation_config is not None else model.generation_config
+    pad = kw.get("pad_token_id", getattr(gc, "pad_token_id", None))
+    pad = pad if pad is not None else kw.get("eos_token_id", getattr(gc, "eos_token_id", None))      # Qwen: pad = eos = eod (run_qwen.py:196-197)
+    pad = (pad[0] if isinstance(pad, (list, tuple)) else pad) if pad is not None else 0
+    toks = out["tokens"]
+    seqs = torch.nn.utils.rnn.pad_sequence([torch.cat([r.to(toks.device), t]) for r, t in zip(rows, toks)], batch_first=True,
+                                           padding_value=int(pad))        # HF echoes the prompt ids in front (ids were given; CPU ids too)
     out["sequences"] = seqs
     return out if return_dict else seqs
 
@@ -499,6 +518,7 @@ def attach_qwen_engine(model, use_graph: bool = True, max_questions: int = 64) -
     eng = VddLlavaEngine(cfg, weights=lm_weights_from_hf(model, cfg), device=model.lm_head.weight.device, use_graph=use_graph,
                          max_questions=max_questions)
     model._vdd_engine = eng
+    _set_guard(model)
     model.generate = types.MethodType(_native_qwen_generate, model)
     return eng
 
@@ -509,6 +529,7 @@ def detach_engine(model) -> None:
     model.__dict__.pop("generate", None)
     model.__dict__.pop("_vdd_engine", None)
     model.__dict__.pop("_vdd_front", None)
+    model.__dict__.pop("_vdd_guard", None)
     for p in model.__dict__.pop("_vdd_shared", []):
         p.data = p.data.clone(memory_format=torch.contiguous_format)
 

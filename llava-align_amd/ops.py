@@ -326,7 +326,8 @@ GEMM_BATCH_INVARIANT = False    # True = batch-invariant mode: a row's results n
                                 #   * decode attention: rope_kv_write + the per-row split-KV kernel (fixed 64-key chunks merged in key order) for every batch -
                                 #     no one-launch kernel for few rows, no grouped prefix pass (its chunking follows the batch): fused_attention_rows() = 0,
                                 #     engine: no grouping;
-                                #   * prefill: one sequence per attention workgroup (no packs of four short suffixes).
+                                #   * prefill: unchanged - its planning choices (prefix sharing, two-level prefixes, packs of four short suffixes) move
+                                #     WHERE a key is read from, not the order keys are summed in (64-key tiles at global key indices): measured bit-identical.
                                 # What it buys: 1-GPU and N-GPU runs of a deterministic decode (cd_greedy / top_k = 1) agree token for token,
                                 # so do a batch and any sub-batch, and row retirement is exact.  What it costs: `batch_invariant` on the bench line.
                                 # The sharded drivers select it for such runs (pope_driver.resolve_batch_invariant); `with ops.batch_invariant():` scopes it.
@@ -334,7 +335,9 @@ _gemm_ws = {}
 _gemm_choice = {}
 
 
-FLASH_PACKS_IN_INVARIANT_MODE = False   # (tools/invariance_probe.py decides: are packs of four suffixes bit-identical to one per workgroup?)
+FLASH_PACKS_IN_INVARIANT_MODE = True    # packs of four short suffixes per attention workgroup walk each sequence's key tiles at the same global key
+                                        # indices as one sequence per workgroup: bit-identical (tools/invariance_probe.py, profiles/r06_invariance_probe.jsonl,
+                                        # tests/test_batch_invariant_gpu.py) - so they stay on in the mode, like two-level prefixes and prefix sharing
 
 
 @contextlib.contextmanager

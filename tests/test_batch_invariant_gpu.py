@@ -92,3 +92,37 @@ def test_run_pope_selects_the_mode_for_deterministic_decodes_only():
     s = run_pope(eng, qs, enc, dec, lambda n: images[n], batch_questions=18, seed=3, **kw)
     assert not s["batch_invariant"]
     assert run_pope(eng, qs, enc, dec, lambda n: images[n], batch_questions=18, seed=3, batch_invariant=True, **kw)["batch_invariant"]
+
+
+def test_prefill_planning_choices_do_not_change_a_bit_in_the_mode():
+    """What lets the mode keep the prefill's batch-dependent PLANNING (tools/invariance_probe.py): packs of four short suffixes per attention
+    workgroup, two-level prefixes (system prompt prefilled once when >= 5 images share it), prompt-prefix sharing itself and the common-prefix
+    slot of text-only prompts only change where a key is read from - every sequence's keys are still summed in 64-key tiles at the same global
+    key indices.  Score rows of every step, bit for bit."""
+    from llava_align_amd import ops
+    eng = _engine(W7B, n_layers=3, vit_layers=2)
+    ids, imgs = _prompts(6, 4, 32000, seed=71)
+    kw = dict(images=imgs, cd_alpha=1.0, cd_beta=0.1, cd_greedy=True, output_scores=True, max_new_tokens=5, use_dd=True, use_dd_unk=True, temperature=1.0, top_p=0.9)
+
+    def run(**over):
+        eng._kvs.clear(); eng._graphs.clear(); eng._kv = None
+        return eng.generate(ids, **dict(kw, **over))
+
+    def same(a, b):
+        return torch.equal(a.tokens, b.tokens) and all(torch.equal(x.view(torch.int16), y.view(torch.int16)) for x, y in zip(a.scores, b.scores))
+    with ops.batch_invariant():
+        base = run()
+        assert base.stats["prefill_tokens"] < base.stats["unshared_prefill_tokens"]
+        old = ops.FLASH_PACKS_IN_INVARIANT_MODE
+        try:
+            ops.FLASH_PACKS_IN_INVARIANT_MODE = not old
+            assert same(base, run())
+        finally:
+            ops.FLASH_PACKS_IN_INVARIANT_MODE = old
+        try:
+            eng.two_level_prefix = False
+            one_level = run()
+            assert one_level.stats["prefill_tokens"] > base.stats["prefill_tokens"] and same(base, one_level)
+        finally:
+            eng.two_level_prefix = True
+        assert same(base, run(share_prefix=False))

@@ -60,6 +60,7 @@ class _StubEngine:
 def test_generate_keywords_are_resolved_like_hf(model):
     stub = _StubEngine(model)
     model._vdd_engine = stub
+    A._set_guard(model)
     ids = torch.tensor([[1, 9, -200, 4]])
     gc = model.generation_config
     gc.temperature, gc.top_p, gc.top_k, gc.do_sample = 0.9, 0.6, 50, False
@@ -93,3 +94,30 @@ def test_generate_keywords_are_resolved_like_hf(model):
             A._native_generate(model, ids, max_new_tokens=1)
     finally:
         del model._vdd_engine
+
+
+def test_stale_weights_guard_follows_the_models_own_parameter():
+    """the guard compares the MODEL's lm_head with what it was at attach time (address, in-place version, shape, dtype) - not
+    with the engine's tensor, which is a copy when lm_head is tied to the embedding or not contiguous (every generate() used to raise)."""
+    import torch
+    from llava_align_amd import hf_adapter as A
+
+    class M(torch.nn.Module):
+        def __init__(self):
+            super().__init__()
+            self.embed = torch.nn.Embedding(16, 8)
+            self.lm_head = torch.nn.Linear(8, 16, bias=False)
+            self.lm_head.weight = self.embed.weight                      # tied
+    m = M()
+    A._set_guard(m)
+    engine_copy = m.lm_head.weight.detach().clone()                      # what a .contiguous() of a tied / strided head gives the engine
+    assert engine_copy.data_ptr() != m.lm_head.weight.data_ptr()
+    A._check_guard(m, "moved")                                           # unchanged model: fine, although the engine holds a copy
+    with torch.no_grad():
+        m.lm_head.weight.add_(1.0)                                       # a LoRA merge / in-place update
+    with pytest.raises(RuntimeError, match="moved"):
+        A._check_guard(m, "moved")
+    A._set_guard(m)
+    m.half()                                                             # re-allocation
+    with pytest.raises(RuntimeError, match="moved"):
+        A._check_guard(m, "moved")
