@@ -89,11 +89,16 @@ def test_generate_keywords_are_resolved_like_hf(model):
         with pytest.raises(ValueError, match=r"\[batch, length\]"):
             A._native_generate(model, [ids[0]], max_new_tokens=1)
         # parameters re-allocated behind the engine's back (model.to() / .half()): refuse instead of decoding with the old weights
-        stub.w.t["lm_head"] = model.lm_head.weight.clone()
-        with pytest.raises(RuntimeError, match="attach_engine"):
-            A._native_generate(model, ids, max_new_tokens=1)
+        old_w = model.lm_head.weight
+        model.lm_head.weight = torch.nn.Parameter(old_w.detach().clone())
+        try:
+            with pytest.raises(RuntimeError, match="attach_engine"):
+                A._native_generate(model, ids, max_new_tokens=1)
+        finally:
+            model.lm_head.weight = old_w
     finally:
         del model._vdd_engine
+        model.__dict__.pop("_vdd_guard", None)
 
 
 def test_stale_weights_guard_follows_the_models_own_parameter():
