@@ -125,3 +125,89 @@ def run_blip_pope(engine: VddLlavaEngine, front: InstructBlipFrontEnd, questions
             except ZeroDivisionError:
                 scores[name] = None
     return {"answers": ordered, "scores": scores, "batch_invariant": invariant}
+
+
+LAVIS_MEAN, LAVIS_STD = (0.48145466, 0.4578275, 0.40821073), (0.26862954, 0.26130258, 0.27577711)
+
+
+def blip_image_eval(path: str, size: int = 224) -> torch.Tensor:
+    """vis_processors['eval'] of load_model_and_preprocess('blip2_vicuna_instruct') (lavis/processors/blip_processors.py BlipImageEvalProcessor):
+    Resize((size, size), bicubic) -> ToTensor -> Normalize(mean, std) of an RGB image file -> [3, size, size] fp32."""
+    import numpy as np
+    from PIL import Image
+    im = Image.open(path).convert("RGB").resize((size, size), Image.BICUBIC)
+    x = torch.from_numpy(np.asarray(im, dtype=np.float32) / 255.0).permute(2, 0, 1)
+    return (x - torch.tensor(LAVIS_MEAN)[:, None, None]) / torch.tensor(LAVIS_STD)[:, None, None]
+
+
+def main(argv=None):
+    """python -m llava_align_amd.blip_driver --blip-checkpoint instruct_blip_vicuna7b.pth --llm-path vicuna-7b-v1.1 --bert-tokenizer bert-base-uncased
+    --image-folder IMGS --question-file coco_pope_adversarial.json --answers-file OUT.jsonl [--use_cd --noise_step 500 --cd_beta 0.1 --top_p 1
+    --seed 42 --num-chunks n --chunk-idx k]: the arguments of experiments/eval/calibrate/blip_calibrate.py:113-135 over the native front-end +
+    engine.  The model the reference gets from `load_model_and_preprocess(name="blip2_vicuna_instruct", model_type="vicuna7b")` (:66) is given
+    as its parts: the InstructBLIP state dict (visual_encoder.*, ln_vision.*, Qformer.*, query_tokens, llm_proj.* - LAVIS' released .pth, or
+    safetensors), the Vicuna directory (HF weights + tokenizer) and the BERT tokenizer the Q-Former reads the instruction with.
+    --cd_alpha is accepted and NOT forwarded, as in the reference (the sampler's 0.5 applies); --temperature / --top_k / --conv-mode
+    are parsed and unused there too.  Under torchrun: one rank per GPU (BASELINE config #5 runs on 4), whole images per rank, one gather."""
+    import argparse
+    import os
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--blip-checkpoint", required=True)
+    ap.add_argument("--llm-path", required=True)
+    ap.add_argument("--bert-tokenizer", required=True)
+    ap.add_argument("--model-base", default=None)
+    ap.add_argument("--image-folder", default="")
+    ap.add_argument("--question-file", required=True)
+    ap.add_argument("--answers-file", required=True)
+    ap.add_argument("--conv-mode", default="llava_v1")
+    ap.add_argument("--num-chunks", type=int, default=1)
+    ap.add_argument("--chunk-idx", type=int, default=0)
+    ap.add_argument("--temperature", type=float, default=1.0)
+    ap.add_argument("--top_p", type=float, default=1.0)
+    ap.add_argument("--top_k", type=int, default=None)
+    ap.add_argument("--noise_step", type=int, default=500)
+    ap.add_argument("--use_cd", action="store_true")
+    ap.add_argument("--cd_alpha", type=float, default=1.0)
+    ap.add_argument("--cd_beta", type=float, default=0.1)
+    ap.add_argument("--seed", type=int, default=42)
+    ap.add_argument("--batch", type=int, default=128)
+    ap.add_argument("--max_txt_len", type=int, default=128)
+    ap.add_argument("--dtype", choices=("float16", "bfloat16"), default="float16")
+    a = ap.parse_args(argv)
+    from . import checkpoint as K
+    from .blip_frontend import BlipWeights
+    from .engine import LlavaWeights
+    from .hf_adapter import blip_config_from_model
+    from .shard import get_chunk, init_from_env
+    rank, world, device = init_from_env()
+    dtype = getattr(torch, a.dtype)
+    sd = K.load_state_dict(a.blip_checkpoint)
+    bcfg = blip_config_from_model(None, sd)
+    front = InstructBlipFrontEnd(BlipWeights.from_state_dict(bcfg, sd, device, dtype=dtype))
+    cfg = K.config_from_dir(a.llm_path, fallback="llava-1.5-7b")           # the LM side only: the preset's CLIP tower is unused on this path
+    llm_sd = K.load_state_dict(a.llm_path)
+    eng = VddLlavaEngine(cfg, weights=LlavaWeights.lm_from_state_dict(cfg, llm_sd, device, dtype=dtype), device=device)
+    llm_tok = K.load_tokenizer(a.llm_path)
+    from transformers import AutoTokenizer
+    bert = AutoTokenizer.from_pretrained(a.bert_tokenizer)
+    questions = [json.loads(q) for q in open(os.path.expanduser(a.question_file))]
+    if a.num_chunks > 1:
+        questions = [questions[i] for i in get_chunk(len(questions), a.num_chunks, a.chunk_idx, group=1)]
+    os.makedirs(os.path.dirname(os.path.abspath(os.path.expanduser(a.answers_file))), exist_ok=True)
+    size = bcfg.vit.image
+    res = run_blip_pope(eng, front, questions, lambda p: llm_tok(p).input_ids,
+                        lambda p: bert(p, truncation=True, max_length=a.max_txt_len).input_ids,
+                        lambda ids: llm_tok.decode(ids, skip_special_tokens=True), lambda name: blip_image_eval(os.path.join(a.image_folder, name), size),
+                        answers_path=os.path.expanduser(a.answers_file), batch_questions=a.batch, use_cd=a.use_cd, noise_step=a.noise_step, cd_beta=a.cd_beta,
+                        top_p=a.top_p, rank=rank, world=world, seed=a.seed)
+    if rank == 0:
+        nan = {k: v["nan_rows"] for k, v in res["scores"].items() if isinstance(v, dict) and v.get("nan_rows")}
+        print(json.dumps({"scores": res["scores"], "n_answers": len(res["answers"]), "rows_whose_calibrated_vector_is_nan": nan}, indent=1))
+    if world > 1:
+        import torch.distributed as dist
+        dist.barrier()
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

@@ -156,15 +156,11 @@ class LlavaWeights:
         return w
 
     @staticmethod
-    def from_state_dict(cfg: LlavaConfig, sd: Dict[str, torch.Tensor], device, vision_sd: Optional[Dict[str, torch.Tensor]] = None,
-                        dtype=torch.bfloat16) -> "LlavaWeights":
-        """Maps an original-LLaVA-1.5 checkpoint (experiments/llava/model/builder.py:102-141 loads exactly these names):
-        `model.embed_tokens`, `model.layers.N.{self_attn.{q,k,v,o}_proj, mlp.{gate,up,down}_proj, input_layernorm,
-        post_attention_layernorm}`, `model.norm`, `lm_head`, `model.mm_projector.{0,2}`; the CLIP tower either inside the
-        checkpoint (`model.vision_tower.vision_tower.vision_model...`) or as a separate HF CLIP state dict (`vision_sd`,
-        keys `vision_model...`).  q/k/v and gate/up are concatenated for the fused projections."""
+    def lm_from_state_dict(cfg: LlavaConfig, sd: Dict[str, torch.Tensor], device, dtype=torch.bfloat16) -> "LlavaWeights":
+        """The language model alone (HF Llama names; a `LlamaForCausalLM` directory such as InstructBLIP's Vicuna, blip_driver.main):
+        no projector, no vision tower - such an engine takes inputs_embeds or text ids."""
         w = LlavaWeights(cfg, device, dtype)
-        lm, v = cfg.lm, cfg.vision
+        lm = cfg.lm
 
         def get(d, k):
             return d[k].detach().to(device=device, dtype=dtype).contiguous()
@@ -178,7 +174,23 @@ class LlavaWeights:
             w.t[p + "wo"] = get(sd, q + "self_attn.o_proj.weight")
             w.t[p + "wgu"] = torch.cat([get(sd, q + "mlp.gate_proj.weight"), get(sd, q + "mlp.up_proj.weight")], 0).contiguous()
             w.t[p + "wd"] = get(sd, q + "mlp.down_proj.weight")
-        w.t["norm"], w.t["lm_head"] = get(sd, "model.norm.weight"), get(sd, "lm_head.weight")
+        w.t["norm"] = get(sd, "model.norm.weight")
+        w.t["lm_head"] = get(sd, "lm_head.weight") if "lm_head.weight" in sd else w.t["embed"]       # tie_word_embeddings
+        return w
+
+    @staticmethod
+    def from_state_dict(cfg: LlavaConfig, sd: Dict[str, torch.Tensor], device, vision_sd: Optional[Dict[str, torch.Tensor]] = None,
+                        dtype=torch.bfloat16) -> "LlavaWeights":
+        """Maps an original-LLaVA-1.5 checkpoint (experiments/llava/model/builder.py:102-141 loads exactly these names):
+        `model.embed_tokens`, `model.layers.N.{self_attn.{q,k,v,o}_proj, mlp.{gate,up,down}_proj, input_layernorm,
+        post_attention_layernorm}`, `model.norm`, `lm_head`, `model.mm_projector.{0,2}`; the CLIP tower either inside the
+        checkpoint (`model.vision_tower.vision_tower.vision_model...`) or as a separate HF CLIP state dict (`vision_sd`,
+        keys `vision_model...`).  q/k/v and gate/up are concatenated for the fused projections."""
+        w = LlavaWeights.lm_from_state_dict(cfg, sd, device, dtype)
+        v = cfg.vision
+
+        def get(d, k):
+            return d[k].detach().to(device=device, dtype=dtype).contiguous()
         w.t["mm.w1"], w.t["mm.b1"] = get(sd, "model.mm_projector.0.weight"), get(sd, "model.mm_projector.0.bias")
         w.t["mm.w2"], w.t["mm.b2"] = get(sd, "model.mm_projector.2.weight"), get(sd, "model.mm_projector.2.bias")
         vs = vision_sd if vision_sd is not None else sd

@@ -185,3 +185,119 @@ def run_mme(engine: VddLlavaEngine, questions: Sequence[dict], build_inputs: Cal
                 except (FileNotFoundError, AssertionError):        # a chunk / subset without all 8 task files or with odd line counts
                     out["scores"][name] = None
     return out
+
+
+def _sweep_settings(args) -> list:
+    """The runs of one invocation of the reference's scripts (run_llava.py:281-318, run_qwen.py:268-304): 'default' first (run_llava: at
+    temperature 1.0; run_qwen: at --temperature), then - only with --use_dd / --use_dd_unk - temperature 0.05 ... 1.0, top_p 0 ... 1.0 and
+    top_k in 1 ... 500, each into `answers-file` with 'setting' replaced.  -> [(tag, temperature, top_p, top_k)]."""
+    import numpy as np
+    base_t = 1.0 if args.arch == "llava" else args.temperature
+    runs = [("default", base_t, args.top_p, args.top_k)]
+    if args.no_sweep or not (args.use_dd or args.use_dd_unk):
+        return runs
+    runs += [(f"temp_{t}", float(t), args.top_p, args.top_k) for t in np.round(np.arange(0.05, 1.05, 0.05), 2)]
+    runs += [(f"top_p_{p_}", args.temperature, float(p_), args.top_k) for p_ in np.round(np.arange(0, 1.05, 0.05), 2)]
+    runs += [(f"top_k_{k}", args.temperature, args.top_p, k) for k in (1, 2, 5, 10, 20, 50, 100, 200, 500)]
+    return runs
+
+
+def main(argv=None):
+    """python -m llava_align_amd.mme_driver --arch llava|qwen --model-path DIR --image-folder MME_Benchmark --question-file llava_mme.jsonl
+    --answers-file OUT-setting.jsonl [--use_dd --use_dd_unk --use_cd --noise_step 500 --cd_alpha 1 --cd_beta 0.1 --temperature T --top_p P
+    --top_k K --max_new_tokens N --num-chunks n --chunk-idx k --gt-root MME_Benchmark --no-sweep]: the arguments of the reference's
+    experiments/eval/MME/run_llava.py:253-318 and run_qwen.py:240-304 (and their sweep over temperature / top_p / top_k when a VDD flag
+    is on) over the native engine; with --gt-root also the calibrate converter + MME scorer that the reference runs as separate scripts.
+    --arch llava: a LLaVA-1.5 checkpoint directory (checkpoint.load_llava).  --arch qwen: a Qwen-VL directory loaded through transformers
+    (trust_remote_code, the caller's environment must provide what modeling_qwen.py imports) - its ViT + resampler fill the image slots,
+    the language model runs natively (hf_adapter.lm_weights_from_hf).  Under torchrun: one rank per GPU, whole images per rank, one gather."""
+    import argparse
+    import json
+    import os
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--arch", choices=("llava", "qwen"), default="llava")
+    ap.add_argument("--model-path", required=True)
+    ap.add_argument("--model-base", default=None)
+    ap.add_argument("--image-folder", required=True)
+    ap.add_argument("--question-file", required=True)
+    ap.add_argument("--answers-file", required=True, help="'setting' in the name is replaced per run (default / temp_T / top_p_P / top_k_K)")
+    ap.add_argument("--conv-mode", default="vicuna_v1")
+    ap.add_argument("--num-chunks", type=int, default=1)
+    ap.add_argument("--chunk-idx", type=int, default=0)
+    ap.add_argument("--temperature", type=float, default=None, help="default 0.2 (llava) / 1.0 (qwen), as the reference's scripts")
+    ap.add_argument("--top_p", type=float, default=None)
+    ap.add_argument("--top_k", type=int, default=None)
+    ap.add_argument("--num_beams", type=int, default=1)
+    ap.add_argument("--max_new_tokens", type=int, default=None, help="default: 128 (llava, run_llava.py:267) / 20 (qwen: the generate call's own value, run_qwen.py:195)")
+    ap.add_argument("--noise_step", type=int, default=500)
+    ap.add_argument("--use_cd", action="store_true")
+    ap.add_argument("--use_dd", action="store_true")
+    ap.add_argument("--use_dd_unk", action="store_true")
+    ap.add_argument("--cd_alpha", type=float, default=1.0)
+    ap.add_argument("--cd_beta", type=float, default=0.1)
+    ap.add_argument("--no-sweep", action="store_true", help="only the 'default' run")
+    ap.add_argument("--gt-root", default=None, help="MME benchmark tree: also convert (naive / none / unk / none_unk) and score")
+    ap.add_argument("--batch", type=int, default=256)
+    ap.add_argument("--seed", type=int, default=None)
+    ap.add_argument("--preset", default="llava-1.5-7b")
+    ap.add_argument("--vision-tower", default=None)
+    ap.add_argument("--dtype", choices=("float16", "bfloat16"), default="float16")
+    a = ap.parse_args(argv)
+    if a.num_beams != 1:
+        raise SystemExit("num_beams > 1: the reference patches sample() only (vcd_sample.py:325-326)")
+    if a.temperature is None:
+        a.temperature = 0.2 if a.arch == "llava" else 1.0
+    from . import checkpoint as K
+    from .shard import init_from_env
+    rank, world, device = init_from_env()
+    dtype = getattr(torch, a.dtype)
+    questions = [json.loads(q) for q in open(os.path.expanduser(a.question_file))]
+    gen_kw = dict(use_dd=a.use_dd, use_dd_unk=a.use_dd_unk, cd_alpha=a.cd_alpha, cd_beta=a.cd_beta)
+    if a.arch == "llava":
+        eng, tok, proc = K.load_llava(a.model_path, device, dtype=dtype, vision_tower=a.vision_tower, fallback_preset=a.preset)
+        build = llava_mme_inputs(lambda prompt: K.tokenizer_image_token(tok, prompt), lambda name: K.clip_preprocess(proc, os.path.join(a.image_folder, name)),
+                                 unk_token_id=tok.unk_token_id if tok.unk_token_id is not None else 0)
+        decode = lambda ids: tok.decode(ids, skip_special_tokens=True)
+        run_kw = dict(eos_token_id=tok.eos_token_id, pad_token_id=tok.pad_token_id or 0, stop_str="</s>", max_new_tokens=a.max_new_tokens or 128,
+                      noise_step=a.noise_step if a.use_cd else None)
+    else:
+        from transformers import AutoModelForCausalLM, AutoTokenizer
+        from .hf_adapter import lm_config_from_hf, lm_weights_from_hf, qwen_spliced_embeddings
+        tok = AutoTokenizer.from_pretrained(a.model_path, trust_remote_code=True)
+        model = AutoModelForCausalLM.from_pretrained(a.model_path, trust_remote_code=True, torch_dtype=dtype).to(device).eval()
+        cfg = lm_config_from_hf(model)
+        eng = VddLlavaEngine(cfg, weights=lm_weights_from_hf(model, cfg), device=device)
+        start = int(model.config.visual["image_start_id"])
+
+        def embed_prompt(text, path):                     # run_qwen.py:176-186: tokenizer([prompt], padding='longest') -> ids; the ViT reads the path
+            ids = torch.tensor([tok(text).input_ids], device=device)
+            e = qwen_spliced_embeddings(model, ids, None)[0]
+            if path is None:
+                return e
+            n = int((ids[0] == start + 1).nonzero()[0]) + 1          # '<img>' ... '</img>': the rows both questions about the image share
+            return e, n
+        build = qwen_mme_inputs(embed_prompt, lambda f: os.path.join(a.image_folder, f))
+        decode = lambda ids: tok.decode(ids, skip_special_tokens=True)
+        run_kw = dict(eos_token_id=tok.eod_id, pad_token_id=tok.eod_id, max_new_tokens=a.max_new_tokens or 20, min_new_tokens=1)      # run_qwen.py:194-197
+    gt = calibrate_gt = None
+    if a.gt_root:
+        gt = C.mme_load_gt(a.gt_root)
+    out_scores = {}
+    for tag, temp, top_p, top_k in _sweep_settings(a):
+        path = os.path.expanduser(a.answers_file).replace("setting", tag)
+        extra = dict(seed=a.seed) if a.seed is not None else {}
+        res = run_mme(eng, questions, build, decode, answers_path=path, model_id=os.path.basename(a.model_path.rstrip("/")), batch_questions=a.batch,
+                      gt=gt, results_root=os.path.join(os.path.dirname(os.path.abspath(path)), "eval_tool_answers") if gt else None,
+                      experiment=os.path.splitext(os.path.basename(path))[0], chunk=(a.num_chunks, a.chunk_idx) if a.num_chunks > 1 else None,
+                      rank=rank, world=world, temperature=temp, top_p=top_p, top_k=top_k, **gen_kw, **run_kw, **extra)
+        out_scores[tag] = {k: (v and {"Perception": v["Perception"]["total"], "Cognition": v["Cognition"]["total"]}) for k, v in res["scores"].items()}
+        if rank == 0:
+            print(json.dumps({"run": tag, "answers_file": path, "n_answers": len(res["answers"]), "scores": out_scores[tag]}), flush=True)
+    if world > 1:
+        import torch.distributed as dist
+        dist.barrier()
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

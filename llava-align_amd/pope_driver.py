@@ -188,7 +188,11 @@ def main(argv=None):
     ap.add_argument("--question-file", required=True)
     ap.add_argument("--image-folder", required=True)
     ap.add_argument("--answers-file", required=True)
-    ap.add_argument("--preset", default="llava-1.5-7b")
+    ap.add_argument("--preset", default="llava-1.5-7b", help="shapes for whatever the checkpoint's config.json does not say (its CLIP tower is named on the hub)")
+    ap.add_argument("--vision-tower", default=None, help="local directory of the CLIP tower `mm_vision_tower` names (weights + preprocessor_config.json)")
+    ap.add_argument("--max_new_tokens", type=int, default=64)
+    ap.add_argument("--seed", type=int, default=None)
+    ap.add_argument("--cd_greedy", action="store_true", help="arg-max of the contrasted distribution (deterministic: 1-rank and N-rank runs agree token for token)")
     ap.add_argument("--temperature", type=float, default=1.0)
     ap.add_argument("--top_p", type=float, default=None)
     ap.add_argument("--top_k", type=int, default=None)
@@ -200,38 +204,26 @@ def main(argv=None):
     ap.add_argument("--batch", type=int, default=384)
     ap.add_argument("--dtype", choices=("float16", "bfloat16"), default="float16", help="model dtype (the reference loads fp16, builder.py:40)")
     a = ap.parse_args(argv)
+    from .checkpoint import clip_preprocess, load_llava, tokenizer_image_token
     from .shard import init_from_env
     rank, world, device = init_from_env()
-    from PIL import Image
-    from safetensors.torch import load_file
-    from transformers import AutoTokenizer, CLIPImageProcessor
-    from .engine import LlavaWeights, preset
-    tok = AutoTokenizer.from_pretrained(a.model_path, use_fast=False)
-    sd = {}
-    for f in sorted(os.listdir(a.model_path)):
-        if f.endswith(".safetensors"):
-            sd.update(load_file(os.path.join(a.model_path, f)))
-    cfg = preset(a.preset)
-    eng = VddLlavaEngine(cfg, weights=LlavaWeights.from_state_dict(cfg, sd, device, dtype=getattr(torch, a.dtype)), device=device)
-    proc = CLIPImageProcessor.from_pretrained(a.model_path)
-
-    def encode(text, with_image):              # tokenizer_image_token (experiments/llava/mm_utils.py): split at <image>, join with -200
-        chunks = [tok(c).input_ids for c in llava_v1_prompt(text, with_image).split("<image>")]
-        ids = list(chunks[0])
-        for c in chunks[1:]:
-            ids += [IMAGE_TOKEN_INDEX] + c[1:]  # drop the BOS of later chunks
-        return ids
+    eng, tok, proc = load_llava(a.model_path, device, dtype=getattr(torch, a.dtype), vision_tower=a.vision_tower, fallback_preset=a.preset)
+    encode = lambda text, with_image: tokenizer_image_token(tok, llava_v1_prompt(text, with_image))
 
     questions = [json.loads(q) for q in open(os.path.expanduser(a.question_file))]
     os.makedirs(os.path.dirname(os.path.abspath(a.answers_file)), exist_ok=True)
+    extra = {k: v for k, v in (("seed", a.seed), ("cd_greedy", a.cd_greedy or None)) if v is not None}
     res = run_pope(eng, questions, encode, lambda ids: tok.decode(ids, skip_special_tokens=True),
-                   lambda name: proc.preprocess(Image.open(os.path.join(a.image_folder, name)).convert("RGB"), return_tensors="pt")["pixel_values"][0],
+                   lambda name: clip_preprocess(proc, os.path.join(a.image_folder, name)),
                    answers_path=a.answers_file, model_id=os.path.basename(a.model_path.rstrip("/")), batch_questions=a.batch,
-                   unk_token_id=tok.unk_token_id, eos_token_id=tok.eos_token_id, pad_token_id=tok.pad_token_id or 0,
-                   noise_step=a.noise_step, use_dd=a.use_dd, use_dd_unk=a.use_dd_unk, cd_alpha=a.cd_alpha, cd_beta=a.cd_beta,
-                   temperature=a.temperature, top_p=a.top_p, top_k=a.top_k, rank=rank, world=world)
+                   unk_token_id=tok.unk_token_id if tok.unk_token_id is not None else 0, eos_token_id=tok.eos_token_id,
+                   pad_token_id=tok.pad_token_id or 0, max_new_tokens=a.max_new_tokens, noise_step=a.noise_step, use_dd=a.use_dd,
+                   use_dd_unk=a.use_dd_unk, cd_alpha=a.cd_alpha, cd_beta=a.cd_beta, temperature=a.temperature, top_p=a.top_p, top_k=a.top_k,
+                   rank=rank, world=world, **extra)
     if rank == 0:
-        print(json.dumps(res["scores"], indent=1))
+        nan = {k: v["nan_rows"] for k, v in res["scores"].items() if isinstance(v, dict) and v.get("nan_rows")}
+        print(json.dumps({"scores": res["scores"], "batch_invariant": res["batch_invariant"], "world": world,
+                          "rows_whose_calibrated_vector_is_nan": nan}, indent=1))
     if world > 1:
         import torch.distributed as dist
         dist.barrier()

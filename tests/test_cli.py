@@ -1,0 +1,116 @@
+"""Command-line entry points of the drivers (the reference runs experiments/eval/calibrate/llava_calibrate.py:222-246,
+MME/run_llava.py:253-318, run_qwen.py:240-304 and blip_calibrate.py:113-135 from bash): the checkpoint-directory loader on CPU, and - on the
+GPU box - `python -m llava_align_amd.pope_driver` / `mme_driver` end to end from a generated checkpoint directory, alone and under torchrun
+with two ranks (gloo, both on the one GPU)."""
+import json
+import os
+import shutil
+import subprocess
+import sys
+
+import pytest
+import torch
+
+from tiny_checkpoint import write_checkpoint
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def test_checkpoint_directory_is_read_like_the_reference_reads_it(tmp_path):
+    from llava_align_amd import checkpoint as K
+    from llava_align_amd.engine import preset
+    info = write_checkpoint(str(tmp_path))
+    cfg = K.config_from_dir(info["ckpt"])
+    t = preset("tiny")
+    assert cfg.lm == t.lm and cfg.vision == t.vision                            # every shape comes from config.json, none from a preset
+    sd = K.load_state_dict(info["ckpt"])
+    assert "model.layers.1.mlp.down_proj.weight" in sd and sd["lm_head.weight"].dtype == torch.float16
+    tok = K.load_tokenizer(info["ckpt"])
+    ids = K.tokenizer_image_token(tok, "w1 w2 <image> yes no")
+    assert ids == [1, 6, 7, -200, 3, 4] and tok.unk_token_id == 0 and tok.eos_token_id == 2      # ONE BOS, -200 where <image> stood
+    assert K.tokenizer_image_token(tok, "w1 w2") == [1, 6, 7]
+    from transformers import CLIPImageProcessor
+    x = K.clip_preprocess(CLIPImageProcessor.from_pretrained(info["ckpt"]), os.path.join(info["images"], "im3.png"))
+    assert tuple(x.shape) == (3, 56, 56) and x.dtype == torch.float32
+    # a release that names its tower on the hub and carries no vision_config: the shapes come from --preset, or the call says what is missing
+    c2 = dict(info["config"]); c2.pop("vision_config")
+    os.makedirs(tmp_path / "hub", exist_ok=True)
+    json.dump(c2, open(tmp_path / "hub" / "config.json", "w"))
+    assert K.config_from_dir(str(tmp_path / "hub"), fallback="tiny").vision == t.vision
+    with pytest.raises(FileNotFoundError, match="vision-tower"):
+        K.config_from_dir(str(tmp_path / "hub"))
+
+
+def test_mme_cli_sweep_is_the_reference_scripts_sweep():
+    import argparse
+    from llava_align_amd.mme_driver import _sweep_settings
+    a = argparse.Namespace(arch="llava", temperature=0.2, top_p=None, top_k=None, use_dd=False, use_dd_unk=False, no_sweep=False)
+    assert _sweep_settings(a) == [("default", 1.0, None, None)]                  # run_llava.py:281-283: temperature 1.0, then exit() without a VDD flag
+    a.use_dd_unk = True
+    runs = _sweep_settings(a)
+    assert len(runs) == 1 + 20 + 21 + 9 and runs[1] == ("temp_0.05", 0.05, None, None) and runs[20][0] == "temp_1.0"
+    assert runs[21] == ("top_p_0.0", 0.2, 0.0, None) and runs[41] == ("top_p_1.0", 0.2, 1.0, None) and runs[-1] == ("top_k_500", 0.2, None, 500)
+    a.arch, a.temperature = "qwen", 1.0
+    assert _sweep_settings(a)[0] == ("default", 1.0, None, None)
+    a.no_sweep = True
+    assert len(_sweep_settings(a)) == 1
+
+
+def _env():
+    env = dict(os.environ, VDD_FORCE_DEVICE="0", VDD_DIST_BACKEND="gloo", PYTHONPATH=ROOT + os.pathsep + os.environ.get("PYTHONPATH", ""))
+    for k in ("RANK", "WORLD_SIZE", "LOCAL_RANK", "MASTER_ADDR", "MASTER_PORT"):
+        env.pop(k, None)
+    return env
+
+
+@pytest.mark.gpu
+def test_pope_driver_from_a_checkpoint_directory_alone_and_under_torchrun(tmp_path):
+    info = write_checkpoint(str(tmp_path))
+    common = ["--model-path", info["ckpt"], "--question-file", info["questions"], "--image-folder", info["images"], "--use_dd_unk", "--cd_alpha", "1",
+              "--cd_beta", "0.1", "--temperature", "0.5", "--cd_greedy", "--max_new_tokens", "6", "--batch", "6"]
+    one = str(tmp_path / "out" / "one.jsonl")
+    p1 = subprocess.run([sys.executable, "-m", "llava_align_amd.pope_driver", *common, "--answers-file", one], capture_output=True, text=True, env=_env(),
+                        timeout=900, cwd=ROOT)
+    assert p1.returncode == 0, p1.stderr[-3000:]
+    rep = json.loads(p1.stdout[p1.stdout.index("{"):])
+    assert rep["batch_invariant"] is True and rep["world"] == 1 and set(rep["scores"]) == {"string_match", "naive", "none", "unk", "none_unk"}
+    two = str(tmp_path / "out" / "two.jsonl")
+    p2 = subprocess.run([sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr", "127.0.0.1", "--master-port",
+                         "29561", "-m", "llava_align_amd.pope_driver", *common, "--answers-file", two], capture_output=True, text=True, env=_env(),
+                        timeout=900, cwd=ROOT)
+    assert p2.returncode == 0, p2.stderr[-3000:]
+    a, b = [json.loads(l) for l in open(one)], [json.loads(l) for l in open(two)]
+    assert [x["question_id"] for x in a] == list(range(100, 100 + info["n_questions"]))                 # the file's order, written once by rank 0
+    assert tuple(a[0].keys()) == ("question_id", "prompt", "text", "model_id", "image", "logits_score", "naive", "unk", "none", "metadata")
+    assert a[0]["model_id"] == "tiny-llava" and all(len(x["text"].split()) >= 1 for x in a)
+    assert a == b                                                                                       # 2 ranks == 1 rank, every field
+    assert json.loads(p2.stdout[p2.stdout.index("{"):])["world"] == 2
+
+
+@pytest.mark.gpu
+def test_mme_driver_from_a_checkpoint_directory(tmp_path):
+    info = write_checkpoint(str(tmp_path))
+    cats = ("existence", "count")
+    gt_root = tmp_path / "MME"
+    qfile = tmp_path / "llava_mme.jsonl"
+    with open(qfile, "w") as f:
+        for i in range(4):
+            cat = cats[i % 2]
+            os.makedirs(gt_root / cat, exist_ok=True)
+            shutil.copy(os.path.join(info["images"], f"im{i}.png"), gt_root / cat / f"{i:03d}.png")
+            lines = []
+            for k in range(2):
+                q = f"w{i} w{k} ? Please answer yes or no."
+                f.write(json.dumps({"question_id": f"{cat}/{i:03d}.png", "image": f"{cat}/{i:03d}.png", "text": q, "category": cat}) + "\n")
+                lines.append(f"{q}\t{('Yes', 'No')[(i + k) % 2]}")
+            open(gt_root / cat / f"{i:03d}.txt", "w").write("\n".join(lines) + "\n")
+    out = str(tmp_path / "answers" / "tiny-setting.jsonl")
+    p = subprocess.run([sys.executable, "-m", "llava_align_amd.mme_driver", "--arch", "llava", "--model-path", info["ckpt"], "--question-file", str(qfile),
+                        "--image-folder", str(gt_root), "--answers-file", out, "--use_dd_unk", "--max_new_tokens", "4", "--no-sweep", "--gt-root", str(gt_root),
+                        "--seed", "1"], capture_output=True, text=True, env=_env(), timeout=900, cwd=ROOT)
+    assert p.returncode == 0, p.stderr[-3000:]
+    rep = json.loads(p.stdout.strip().splitlines()[-1])
+    assert rep["run"] == "default" and rep["n_answers"] == 8 and rep["answers_file"].endswith("tiny-default.jsonl")
+    recs = [json.loads(l) for l in open(rep["answers_file"])]
+    assert len(recs) == 8 and set(recs[0]) >= {"question_id", "prompt", "text", "naive", "none", "unk", "answer_id", "model_id"}
+    assert os.path.isdir(os.path.join(os.path.dirname(out), "eval_tool_answers"))                      # the converter wrote the scorer's input tree
