@@ -675,6 +675,10 @@ class _DecodeRunner:
         self.graph = None
         self._tried = False
         self.grouping = None
+        # admission mode (VddLlavaEngine.generate_list): question slots are refilled while the others keep decoding, so every slot has its
+        # own first step - gen column of slot q at global step s = s - s0[q]; finished slots stay in the batch, frozen (see body)
+        self.max_new = max_new
+        self.s0 = torch.zeros(Q, dtype=torch.long, device=dev) if tail.get("admit") else None
         # logits-processor stage (vcd_sample.py:197): per-row EOS floor, stop-word flags, repetition-penalty history
         pr = tail.get("proc") or {}
         self.proc = pr
@@ -778,7 +782,32 @@ class _DecodeRunner:
         self.gen[:, :n_new] = old.gen[q_idx, :n_new]
         self.step_idx.copy_(old.step_idx); self.ctr.copy_(old.ctr)
         self.status.copy_(old.status[q_idx]); self.status0.copy_(old.status0[q_idx])
+        # the processor stage's per-question state (EOS floor, stop-word prompt tails, repetition-penalty history) moves with its question
+        if self.eos_min is not None:
+            self.eos_min.copy_(old.eos_min[q_idx])
+        if self.prompt_tail is not None:
+            self.prompt_tail.copy_(old.prompt_tail[q_idx])
+        if self.prompt_ids is not None:
+            self.prompt_ids.copy_(old.prompt_ids[q_idx])
+            self.prompt_cols = old.prompt_cols
         return old.slot[rows_idx].long()                           # the old slots of the kept rows, in the new slot order
+
+    def admit(self, q_idx: torch.Tensor, tok, unfinished, status0, pos, cpos, rows, pad: int):
+        """Admission mode: the question slots q_idx (int64 device tensor) start NEW questions whose first token `tok` was just sampled from
+        their prefill; pos / cpos / rows: the decode state of their nb x len(q_idx) rows, branch-major.  Contents of the static buffers
+        change, their addresses do not: the captured step keeps replaying."""
+        Q, nb, k = self.Q, self.nb, int(q_idx.numel())
+        r_idx = torch.cat([q_idx + b * Q for b in range(nb)])
+        p_, c_, w_ = h2d_int32(self.pos.device, pos, cpos, rows)
+        self.pos.index_copy_(0, r_idx, p_); self.cpos.index_copy_(0, r_idx, c_); self.rows.index_copy_(0, r_idx, w_)
+        self.tok.index_copy_(0, q_idx, tok)
+        self.unfinished.index_copy_(0, q_idx, unfinished)
+        self.status.index_fill_(0, q_idx, 0)
+        self.status0.index_copy_(0, q_idx, status0)
+        fresh = torch.full((k, self.gen.shape[1]), pad, dtype=torch.long, device=self.gen.device)
+        fresh[:, 0] = tok
+        self.gen.index_copy_(0, q_idx, fresh)
+        self.s0.index_copy_(0, q_idx, (self.step_idx - 1).expand(k))        # the next step writes column 1 of these slots
 
     def body(self, kv):
         t, Q, nb = self.tail, self.Q, self.nb
@@ -798,10 +827,22 @@ class _DecodeRunner:
         else:
             self.sample_tail(v, c, d, self.scores_buf, False, status_out=self._st, step_ptr=self.step_idx)
         self.status |= self._st
-        self.gen.index_copy_(1, self.step_idx, self.tok[:, None])
-        self.pos += 1
-        self.cpos += 1
-        self.rows[:, 1] += 1
+        if self.s0 is None:
+            self.gen.index_copy_(1, self.step_idx, self.tok[:, None])
+            self.pos += 1
+            self.cpos += 1
+            self.rows[:, 1] += 1
+        else:
+            # per-slot column; a slot whose answer reached max_new tokens is finished like one that emitted EOS; finished slots (pad tokens
+            # from the kernel) write the slack column and do not move: they rewrite ONE KV position and attend a fixed context until a
+            # waiting question takes the slot
+            col = (self.step_idx - self.s0).clamp_(max=self.max_new)
+            self.gen.scatter_(1, col[:, None], self.tok[:, None])
+            self.unfinished.mul_((col + 1 < self.max_new).long())
+            alive = self.unfinished.to(torch.int32).repeat(nb)
+            self.pos += alive
+            self.cpos += alive
+            self.rows[:, 1] += alive
         self.step_idx += 1
         self.ctr += 1
 
@@ -1161,13 +1202,15 @@ class VddLlavaEngine:
             grp = []      # (up to 16 rows the one-launch RoPE + KV write + attention kernel beats the three launches of the grouped
                           #  path although it reads a shared prefix once per row: tools/small_batch_attn_probe.py, +4 ... 9 %)
         # retirement / growth of the own pools needs an EOS to retire on, per-question state that lives only in the runner's row order
-        # (no processor stage, no per-step scores rows, no streamer) and the ungrouped attention (slots are renumbered)
+        # (no per-step scores rows, no streamer) and the ungrouped attention (slots are renumbered)
         suffix_max = max(s_["T"] for s_ in plan["suffix"])
         # ... and, for deterministic decodes (cd_greedy / top_k = 1), only in batch-invariant mode: with the tuned forms a survivor's low-order bits
         # change as the batch shrinks through the kernel regimes, where the reference keeps the full batch until every row has emitted EOS
         deterministic = bool(cd_greedy or top_k == 1)
-        retire = bool(self.retire and eos_token_id is not None and not output_scores and streamer is None and not proc and not grp
-                      and max_new_tokens > self.kv_chunk and (ops.GEMM_BATCH_INVARIANT or not deterministic))
+        # (round 6: the in-kernel processors - EOS floor of min_new_tokens / min_length, stop words, repetition penalty - are per-question state
+        #  that `adopt` carries along; only HF-style Python callables, which see the whole left-padded batch, still pin the batch)
+        retire = bool(self.retire and eos_token_id is not None and not output_scores and streamer is None and not (proc and proc.get("python"))
+                      and not grp and max_new_tokens > self.kv_chunk and (ops.GEMM_BATCH_INVARIANT or not deterministic))
         own_cap = min(max_new_tokens, self.kv_chunk) if retire else max_new_tokens
         kv = self.kv(len(plan["prefix"]), max([s_.get("full_T", s_["T"]) for s_ in plan["prefix"]] + [0]), len(plan["suffix"]),
                      suffix_max + own_cap, frag_only=bool(grp))
@@ -1368,6 +1411,209 @@ class VddLlavaEngine:
         stats["n_groups"] = n_groups          # > 0: the decode steps ran the grouped (shared-prefix) attention
         return GenerateOutput(seqs_out, gen, scores, top_prob, top_tok, stats,
                               attentions=StepAttentions(attn_maps, lm.n_layers, int(gen.shape[1])) if attn_maps is not None else None)
+
+    # -- a question LIST with a bounded number in flight: waiting questions take the slots of finished ones -----------------------------
+    @torch.no_grad()
+    def generate_list(self, input_ids: Sequence[torch.Tensor], images: Sequence[torch.Tensor], in_flight: int = 90,
+                      cd_alpha: Optional[float] = None, cd_beta: Optional[float] = None, use_dd: bool = False, use_dd_unk: bool = False,
+                      temperature: Optional[float] = None, top_p: Optional[float] = None, top_k: Optional[int] = None,
+                      max_new_tokens: int = 64, eos_token_id=None, pad_token_id: Optional[int] = None, cd_greedy: bool = False,
+                      n_top: int = 0, seed: Optional[int] = None, sync_every: int = 8, admit_min: Optional[int] = None) -> GenerateOutput:
+        """The reference walks an arbitrarily long question list one generate() call at a time (llava_sampling.py:78-116: LLaVA-Bench, answers
+        of 20 - 1,000 tokens; llava_calibrate.py:130).  generate() decodes ONE batch to its end - the last rows of a batch of open-ended
+        answers run almost alone.  This call takes the whole list and keeps `in_flight` questions decoding: when questions have emitted EOS
+        (or reached max_new_tokens), the next waiting questions are prefilled INTO THEIR SLOTS - own-KV slots, prefix slots and the rows of
+        the captured decode step are reused in place, nothing is re-captured or repacked - and join the running batch with a step index of
+        their own.  Same kwargs and semantics per question as generate() (LLaVA prompts: ids with one -200 slot + one image each; the
+        image-free branches use_dd / use_dd_unk); the VCD branch, processors, output_scores and streamers stay with generate().
+        Memory: nb x in_flight own slots of (longest suffix + max_new_tokens) tokens are held for the whole call.
+        admit_min: waiting questions are admitted once that many slots are free (default in_flight / 8; prefilling a handful of questions
+        costs a pass over the weights like a decode step of the whole batch).  Returns a GenerateOutput over ALL questions, input order;
+        stats: admissions, decode steps, mean live rows per step.  In batch-invariant mode with cd_greedy every answer equals the one
+        generate() gives the question in any batch."""
+        dev, lm = self.device, self.cfg.lm
+        if eos_token_id is None:
+            raise ValueError("generate_list needs eos_token_id: without an EOS every answer has max_new_tokens tokens and generate() in batches does the same work")
+        if pad_token_id is None:
+            raise ValueError("If `eos_token_id` is defined, make sure that `pad_token_id` is defined.")   # vcd_sample.py:258-259
+        if lm.head_dim != 128:
+            raise ValueError("generate_list: head_dim 128 models")
+        eos_token_id = [eos_token_id] if isinstance(eos_token_id, int) else list(eos_token_id)
+        ids_all = [r.reshape(-1).tolist() for r in input_ids]
+        N = len(ids_all)
+        if N == 0 or len(images) != N:
+            raise ValueError("generate_list: one image per question")
+        s_img = []
+        for q_, r in enumerate(ids_all):
+            if r.count(IMAGE_TOKEN_INDEX) != 1 or r[-1] == IMAGE_TOKEN_INDEX:
+                raise ValueError(f"prompt {q_}: exactly one image placeholder (-200), not at the end")
+            bad = [t_ for t_ in r if t_ != IMAGE_TOKEN_INDEX and not (0 <= t_ < lm.vocab)]
+            if bad:
+                raise ValueError(f"prompt {q_}: token id {bad[0]} outside [0, {lm.vocab})")
+            s_img.append(r.index(IMAGE_TOKEN_INDEX))
+        names = ["main"] + (["unk"] if use_dd_unk else (["none"] if use_dd else [])) + (["none"] if (use_dd and use_dd_unk) else [])
+        nb, contrast = len(names), len(names) > 1
+        alpha = cd_alpha if cd_alpha is not None else 0.5
+        beta = cd_beta if cd_beta is not None else 0.1
+        warp = WarpSpec(temperature=temperature, top_k=top_k, top_p=top_p)
+        n_img_tok = self.cfg.vision.n_patches
+        Qc = max(1, min(int(in_flight), N))
+        admit_min = max(1, Qc // 8) if admit_min is None else max(1, int(admit_min))
+        suffix_cap = max(len(r) - si - 1 for r, si in zip(ids_all, s_img))
+        t_pre = max(si + n_img_tok for si in s_img)
+        if t_pre + suffix_cap + max_new_tokens > lm.max_pos:
+            raise ValueError(f"prompt + max_new_tokens exceed the rotary table (max_pos = {lm.max_pos})")
+        shared_keys = {(nm, tuple(r[:si])) for r, si in zip(ids_all, s_img) for nm in names[1:]}
+        n_pre = Qc + len(shared_keys) + 1
+        kv = self.kv(n_pre, t_pre, nb * Qc, suffix_cap + max_new_tokens, frag_only=False)
+        eos_t = torch.tensor(eos_token_id, dtype=torch.long, device=dev)
+        from .sampling import fresh_offset
+        sd = (fresh_offset() if seed is None else int(seed)) & 0x3FFFFFFFFF
+        cfgkey = ("list", Qc, nb, max_new_tokens, alpha, beta, warp.t, warp.k, warp.p, use_dd, use_dd_unk, cd_greedy, tuple(eos_token_id), pad_token_id,
+                  ops.GEMM_BATCH_INVARIANT)
+        tail = dict(alpha=alpha, beta=beta, warp=warp, contrast=contrast, is_vcd=False, both=(use_dd and use_dd_unk), greedy=cd_greedy, eos_t=eos_t,
+                    pad=pad_token_id, output_scores=False, n_groups=0, n_items=0, cpi=1, proc={}, admit=True)
+        run = self._runner(cfgkey, Qc, nb, max_new_tokens, tail, kv)
+        run.reset(sd << 24)
+        run.unfinished.zero_()                                   # every slot starts free
+        run.slot.copy_(torch.arange(nb * Qc, dtype=torch.int32, device=dev))
+        # a free slot decodes a harmless row until a question takes it: one own token at position 0 of its (zeroed) slot
+        run.pos.zero_(); run.cpos.zero_(); run.s0.zero_(); run.gen.fill_(pad_token_id)
+        run.rows.copy_(torch.tensor([[r_, 1, 0, 0] for r_ in range(nb * Qc)], dtype=torch.int32).to(dev))
+        for i in range(lm.n_layers):
+            kv.ko[i][:, :, :1].zero_(); kv.vo[i][:, :, :1].zero_()
+        master = torch.full((N, max_new_tokens), pad_token_id, dtype=torch.long, device=dev)
+        top_prob = torch.zeros(N, n_top, dtype=torch.float32, device=dev) if n_top else None
+        top_tok = torch.zeros(N, n_top, dtype=torch.long, device=dev) if n_top else None
+        free_pre = list(range(n_pre - 1, -1, -1))
+        table: Dict[tuple, dict] = {}                            # prefix key -> {slot, ref, T, feat (kept alive: its address is part of nobody's key)}
+        slot_q = [-1] * Qc                                       # question in each slot
+        slot_keys: List[list] = [[] for _ in range(Qc)]
+        feat_of: Dict[int, torch.Tensor] = {}
+        waiting = list(range(N))
+        stats = {"n_rows": nb * Qc, "questions": N, "in_flight": Qc, "admissions": 0, "prefill_tokens": 0, "steps": 0, "graph": False}
+        live_row_steps = 0
+
+        def retire(slots):
+            """finished slots: their tokens go to `master`, their prefixes lose a reference"""
+            if not slots:
+                return
+            idx = torch.tensor(slots, dtype=torch.long, device=dev)
+            master.index_copy_(0, torch.tensor([slot_q[q] for q in slots], dtype=torch.long, device=dev), run.gen[idx, :max_new_tokens])
+            for q in slots:
+                for key in slot_keys[q]:
+                    e = table[key]
+                    e["ref"] -= 1
+                    if e["ref"] == 0:
+                        free_pre.append(e["slot"])
+                        del table[key]
+                im = id(images[slot_q[q]])
+                slot_q[q], slot_keys[q] = -1, []
+                if not any(k_[0] == "img" and k_[2] == im for k_ in table):
+                    feat_of.pop(im, None)
+
+        def admit(slots):
+            """the next len(slots) waiting questions: vision tower for images not seen yet, prefill of new prefixes + all suffixes, first token"""
+            qs = [waiting.pop(0) for _ in slots]
+            todo = [i for i in qs if id(images[i]) not in feat_of]
+            todo = list({id(images[i]): i for i in todo}.values())
+            if todo:
+                for i, f in zip(todo, self.image_features([images[i] for i in todo])):
+                    feat_of[id(images[i])] = f
+            new_pre, suffix, dec = [], [], []
+            for b, nm in enumerate(names):
+                for q, i in zip(slots, qs):
+                    r, si = ids_all[i], s_img[i]
+                    if nm == "main":
+                        key, toks, img, T = ("img", tuple(r[:si]), id(images[i])), r[:si], feat_of[id(images[i])], si + n_img_tok
+                    elif nm == "unk":
+                        key, toks, img, T = ("unk", tuple(r[:si])), r[:si] + [0], None, si + 1       # the <unk> token stays in the prefix (quirk #3)
+                    else:
+                        key, toks, img, T = ("none", tuple(r[:si])), r[:si], None, si
+                    e = table.get(key)
+                    if e is None:
+                        e = table[key] = dict(slot=free_pre.pop(), ref=0, T=T)
+                        new_pre.append(dict(slot=e["slot"], tokens=toks, img=img, T=T, pos0=0, pslot=0, plen=0))
+                    e["ref"] += 1
+                    slot_keys[q].append(key)
+                    suf = r[si + 1:]
+                    row = b * Qc + q
+                    suffix.append(dict(slot=row, tokens=suf, img=None, T=len(suf), pos0=T, pslot=e["slot"], plen=T))
+                    dec.append((T + len(suf), len(suf), [row, T + len(suf) + 1, e["slot"], T]))
+            for q, i in zip(slots, qs):
+                slot_q[q] = i
+            passes = []
+            if new_pre:
+                x, pos, cpos, slot, seqs, max_tq = self._pack(new_pre)
+                passes.append(dict(x=x, pos=pos, cpos=cpos, slot=slot, seqs=seqs, n_seq=len(new_pre), max_tq=max_tq, to_prefix_pool=True, keep_q=False))
+            x, pos, cpos, slot, seqs, max_tq = self._pack(suffix)
+            packs_h = ops.flash_packs([[0, 0, 0, 0, s_["pslot"], s_["plen"]] for s_ in suffix]) if (max_tq <= 32 and (not ops.GEMM_BATCH_INVARIANT or ops.FLASH_PACKS_IN_INVARIANT_MODE)) else None
+            last, last_seqs, packs = h2d_int32(dev, [s_["q_row0"] + s_["T"] - 1 for s_ in suffix],
+                                               [[j, 1, s_["pos0"] + s_["T"] - 1, s_["slot"], s_["pslot"], s_["plen"]] for j, s_ in enumerate(suffix)],
+                                               packs_h if packs_h is not None else [[0, -1, -1, -1]])
+            passes.append(dict(x=x, pos=pos, cpos=cpos, slot=slot, seqs=seqs, n_seq=len(suffix), max_tq=max_tq, to_prefix_pool=False, last_rows=last.long(),
+                               last_seqs=last_seqs, packs=packs if packs_h is not None else None, keep_q=False))
+            resid, delta = self.lm.prefill(passes, kv)[-1]
+            logits0 = self.lm.logits(resid, delta)                                  # [nb * k, V], branch-major
+            k = len(slots)
+            v0 = logits0[:k]
+            c0 = logits0[k:2 * k] if contrast else None
+            d0 = logits0[2 * k:3 * k] if nb == 3 else None
+            unf = torch.ones(k, dtype=torch.long, device=dev)
+            # the wave draws from its own Philox stream (seed = admission number): row j of a wave and row j of the running batch never
+            # see the same (counter, row) pair
+            r0 = contrast_sample(v0, c0, d0, alpha=alpha, beta=beta, warp=warp, pick_argmax=cd_greedy, seed=stats["admissions"] + 1, offset=0,
+                                 offset_ptr=run.ctr, n_top=n_top, eos_ids=eos_t, pad_id=pad_token_id, unfinished=unf)
+            q_idx = torch.tensor(slots, dtype=torch.long, device=dev)
+            run.admit(q_idx, r0.tokens, unf, r0.status, [d_[0] for d_ in dec], [d_[1] for d_ in dec], [d_[2] for d_ in dec], pad_token_id)
+            if n_top:
+                o_idx = torch.tensor(qs, dtype=torch.long, device=dev)
+                top_prob.index_copy_(0, o_idx, r0.top_prob); top_tok.index_copy_(0, o_idx, r0.top_tok)
+            stats["admissions"] += 1
+            stats["prefill_tokens"] += sum(p_["T"] for p_ in new_pre) + sum(s_["T"] for s_ in suffix)
+
+        admit(list(range(Qc)))
+        steps, marks = 0, []
+        while True:
+            run.step(kv)
+            steps += 1
+            if steps % self.LAUNCH_WINDOW == 0:
+                ev = torch.cuda.Event()
+                ev.record(torch.cuda.current_stream(dev))
+                marks.append(ev)
+                if len(marks) > 1:
+                    marks.pop(0).synchronize()
+            if steps % sync_every and not (steps in (1, 3) and sync_every > 2):
+                continue
+            state = torch.cat([run.unfinished, (run.status | run.status0).ne(0).any().long()[None]]).tolist()    # ONE sync
+            unf_h, bad = state[:-1], state[-1]
+            live_row_steps += nb * sum(unf_h) * min(sync_every, steps)
+            if bad:
+                break
+            done = [q for q in range(Qc) if not unf_h[q] and slot_q[q] >= 0]
+            if not waiting:
+                if not any(unf_h):
+                    break
+                continue
+            free = [q for q in range(Qc) if not unf_h[q]]
+            if len(free) >= min(admit_min, len(waiting)) or not any(unf_h):
+                retire(done)
+                admit(free[:len(waiting)])
+        if bool((run.status | run.status0).ne(0).any().item()):
+            raise RuntimeError("probability tensor contains either `inf`, `nan` or element < 0")   # torch.multinomial, vcd_sample.py:202
+        retire([q for q in range(Qc) if slot_q[q] >= 0])
+        is_eos = (master[:, :, None] == eos_t[None, None, :]).any(-1)
+        n_tok = torch.where(is_eos.any(1), is_eos.float().argmax(1) + 1, torch.full((N,), max_new_tokens, device=dev))
+        gen = master[:, : int(n_tok.max().item())].clone()
+        lens = [len(r) for r in ids_all]
+        (flat,) = h2d_int32(dev, [t_ for r in ids_all for t_ in r])
+        flat, offs = flat.long(), [0]
+        for n_ in lens:
+            offs.append(offs[-1] + n_)
+        seqs_out = [torch.cat([flat[offs[q]:offs[q + 1]], gen[q]]) for q in range(N)]
+        stats.update(steps=steps, graph=run.graph is not None, answer_tokens=int(n_tok.sum().item()),
+                     mean_live_rows=round(live_row_steps / max(steps, 1), 1), n_groups=0)
+        return GenerateOutput(seqs_out, gen, None, top_prob, top_tok, stats)
 
     def _processor_config(self, prompt_lens, ids_list, eos_token_id, min_new_tokens, min_length, stop_words_ids, repetition_penalty,
                           logits_processor, max_new_tokens):

@@ -1,0 +1,100 @@
+"""VddLlavaEngine.generate_list: a question LIST with a bounded number of questions in flight - waiting questions are prefilled into the
+slots of finished ones while the rest keeps decoding (the reference walks its list one B = 1 generate() call at a time,
+llava_sampling.py:78-116 / llava_calibrate.py:130, so a question's answer never depends on the others: the checker below)."""
+import numpy as np
+import pytest
+import torch
+
+from test_engine_shapes_gpu import _engine, _prompts
+
+pytestmark = pytest.mark.gpu
+DEV = "cuda:0"
+W7B = dict(d=4096, n_heads=32, n_kv_heads=32, head_dim=128, ffn=11008, vocab=32000)
+
+
+def _eos_set(n, seed, vocab=32000):
+    return sorted(set(np.random.default_rng(seed).integers(3, vocab, size=n).tolist()))
+
+
+def _answer_lengths(tokens, eos):
+    eos_t = torch.tensor(eos, device=tokens.device)
+    is_eos = (tokens[:, :, None] == eos_t).any(-1)
+    return torch.where(is_eos.any(1), is_eos.float().argmax(1) + 1, torch.full((tokens.shape[0],), tokens.shape[1], device=tokens.device))
+
+
+@pytest.mark.parametrize("mode", [dict(use_dd_unk=True, temperature=0.5), dict(use_dd=True, use_dd_unk=True, temperature=1.0, top_p=0.9)], ids=["dd_unk", "both_top_p"])
+def test_list_answers_equal_the_batch_answers_in_batch_invariant_mode(mode):
+    """40 questions, 12 in flight, answers of 1 ... 48 tokens (a random EOS set): every answer, its padding and its step-0 top-10 are those
+    of ONE generate() call over all 40 questions - token for token under cd_greedy in batch-invariant mode - although every question
+    decoded next to different neighbours, in a reused slot, from a step index of its own."""
+    from llava_align_amd import ops
+    eng = _engine(W7B, n_layers=3, vit_layers=2)
+    ids, imgs = _prompts(40, 1, 32000, seed=91)
+    eos = _eos_set(900, 5)                                   # ~3 % of the vocabulary: geometric answer lengths, mean ~ 30 tokens, capped at 48
+    kw = dict(cd_alpha=1.0, cd_beta=0.1, cd_greedy=True, max_new_tokens=48, eos_token_id=eos, pad_token_id=0, n_top=10, **mode)
+    with ops.batch_invariant():
+        eng.retire = False
+        ref = eng.generate(ids, images=imgs, sync_every=4, **kw)
+        out = eng.generate_list(ids, imgs, in_flight=12, sync_every=4, admit_min=2, **kw)
+    la, lb = _answer_lengths(ref.tokens, eos), _answer_lengths(out.tokens, eos)
+    assert torch.equal(la, lb) and int(la.min()) < 10 and int(la.max()) > 30                    # the answers really have different lengths
+    T = min(ref.tokens.shape[1], out.tokens.shape[1])
+    assert torch.equal(ref.tokens[:, :T], out.tokens[:, :T])
+    for q in range(40):                                                                        # padded like the reference pads (vcd_sample.py:260)
+        assert bool((out.tokens[q, int(lb[q]):] == 0).all())
+    assert torch.equal(ref.top_tok, out.top_tok) and torch.equal(ref.top_prob, out.top_prob)
+    st = out.stats
+    assert st["admissions"] >= 4 and st["in_flight"] == 12 and st["questions"] == 40 and st["graph"] and st["answer_tokens"] == int(lb.sum())
+    assert [s.shape[0] for s in out.sequences] == [len(i) + out.tokens.shape[1] for i in ids]
+
+
+def test_sampled_list_run_is_reproducible_and_well_formed():
+    eng = _engine(W7B, n_layers=2, vit_layers=2)
+    ids, imgs = _prompts(5, 6, 32000, seed=17)               # 30 questions, 6 per image: image prefixes shared across slots and waves
+    eos = _eos_set(1500, 3)
+    kw = dict(in_flight=8, use_dd_unk=True, cd_alpha=1.0, cd_beta=0.1, temperature=0.7, max_new_tokens=24, eos_token_id=eos, pad_token_id=0, seed=11,
+              sync_every=2)
+    a = eng.generate_list(ids, imgs, **kw)
+    b = eng.generate_list(ids, imgs, **kw)
+    assert torch.equal(a.tokens, b.tokens)                                                      # same seed, same schedule of admissions
+    c = eng.generate_list(ids, imgs, **dict(kw, seed=12))
+    assert not torch.equal(a.tokens[:, : min(a.tokens.shape[1], c.tokens.shape[1])], c.tokens[:, : min(a.tokens.shape[1], c.tokens.shape[1])])
+    L = _answer_lengths(a.tokens, eos)
+    eos_t = torch.tensor(eos, device=DEV)
+    for q in range(30):
+        n = int(L[q])
+        assert n == a.tokens.shape[1] or n == 24 or bool((a.tokens[q, n - 1] == eos_t).any())   # ends with EOS unless it ran to the cap
+        assert bool((a.tokens[q, n:] == 0).all())
+    assert a.stats["admissions"] >= 3 and 0 < a.stats["mean_live_rows"] <= 16
+
+
+def test_list_refuses_what_it_does_not_do():
+    eng = _engine(W7B, n_layers=1, vit_layers=1)
+    ids, imgs = _prompts(2, 1, 32000, seed=1)
+    with pytest.raises(ValueError, match="eos_token_id"):
+        eng.generate_list(ids, imgs, max_new_tokens=4)
+    with pytest.raises(ValueError, match="pad_token_id"):
+        eng.generate_list(ids, imgs, max_new_tokens=4, eos_token_id=2)
+    with pytest.raises(ValueError, match="one image placeholder"):
+        eng.generate_list([torch.tensor([1, 5, 6])], imgs[:1], max_new_tokens=4, eos_token_id=2, pad_token_id=0)
+
+
+def test_retirement_carries_the_in_kernel_processors():
+    """Round 6: a call with min_new_tokens / repetition_penalty (the Qwen MME and InstructBLIP call shapes, run_qwen.py:194,
+    blip2_vicuna_instruct.py:400) retires finished rows too - the EOS floor and the penalty history are per-question state that moves with
+    its question.  Token for token equal to the static run in batch-invariant mode."""
+    from llava_align_amd import ops
+    eng = _engine(W7B, n_layers=2, vit_layers=2)
+    ids, imgs = _prompts(24, 1, 32000, seed=41)
+    eos = _eos_set(600, 7)
+    kw = dict(images=imgs, use_dd_unk=True, cd_alpha=1.0, cd_beta=0.1, temperature=1.0, top_p=0.9, cd_greedy=True, max_new_tokens=160, eos_token_id=eos,
+              pad_token_id=0, min_new_tokens=6, repetition_penalty=1.2, sync_every=8)
+    with ops.batch_invariant():
+        eng.retire, eng.kv_chunk = False, 32
+        a = eng.generate(ids, **kw)
+        eng._kvs.clear(); eng._graphs.clear()
+        eng.retire = True
+        b = eng.generate(ids, **kw)
+    assert "retire_events" not in a.stats and b.stats["retire_events"] >= 2 and b.stats["rows_at_end"] < 48
+    assert int(_answer_lengths(a.tokens, eos).min()) >= 6                                       # the EOS floor held
+    assert a.tokens.shape == b.tokens.shape and torch.equal(a.tokens, b.tokens)

@@ -85,6 +85,7 @@ __global__ void __launch_bounds__(256) stream_launch(const char* w, size_t bytes
 }
 
 int main(int argc, char** argv) {
+    const int chain = argc > 2 ? atoi(argv[2]) : 5;       // 5: the one-question layer (five launches); 9: the 17 - 256-row layer (norm, qkv, rope, attention, o, norm, gate/up, down + one more small launch)
     const int variant = argc > 1 ? atoi(argv[1]) : 0;     // bit 0: no prefetch before the wait; bit 1: wait for the FIRST arrival only; bit 2: long poll sleep; bit 3: two-level poll (8 leaders + relay words); bit 4: hierarchical arrival (8 group counters)
     const size_t pool = (size_t)4 << 30;
     char* buf; hipMalloc(&buf, pool); hipMemset(buf, 1, pool);
@@ -92,8 +93,12 @@ int main(int argc, char** argv) {
     int *flags, *timeouts, *relay; hipMalloc(&flags, 4096 * 4); hipMalloc(&timeouts, 4); hipMalloc(&relay, 4096 * 1024 * 4);
     hipStream_t s[2]; hipStreamCreateWithFlags(&s[0], hipStreamNonBlocking); hipStreamCreateWithFlags(&s[1], hipStreamNonBlocking);
     // a 7B decoder layer's five launches: qkv 100 MB, (attention: 21 MB of K/V), o 33.5, gate/up 180, down 90
-    const size_t sizes[5] = {(size_t)100 << 20, (size_t)21 << 20, (size_t)33 << 20, (size_t)180 << 20, (size_t)90 << 20};
-    const int grid = 512, layers = 32, n = 5 * layers;
+    // (chain 9: the elementwise launches of the nine-launch layer move a few MB each: here 32 MB = one 64-KiB batch per workgroup, ~5 us - their cost IS the boundary)
+    const size_t sizes5[5] = {(size_t)100 << 20, (size_t)21 << 20, (size_t)33 << 20, (size_t)180 << 20, (size_t)90 << 20};
+    const size_t sizes9[9] = {(size_t)32 << 20, (size_t)100 << 20, (size_t)32 << 20, (size_t)64 << 20, (size_t)33 << 20, (size_t)32 << 20, (size_t)180 << 20, (size_t)32 << 20, (size_t)90 << 20};
+    const size_t* sizes = chain == 9 ? sizes9 : sizes5;
+    const int NL = chain == 9 ? 9 : 5;
+    const int grid = 512, layers = 32, n = NL * layers;
     // both forms are captured into a hipGraph (the engine replays its decode step as a graph: no host launch cost in the comparison);
     // the two-stream form forks s[1] off s[0] at the start of the capture and joins it at the end - between launches the flags are
     // the only dependency across the streams
@@ -104,7 +109,7 @@ int main(int argc, char** argv) {
         if (mode >= 1) { hipEventRecord(fork, s[0]); hipStreamWaitEvent(s[1], fork, 0); }
         size_t off = 0;
         for (int i = 0; i < n; ++i) {
-            size_t bytes = sizes[i % 5] / (grid * NB * 4096) * (grid * NB * 4096);
+            size_t bytes = sizes[i % NL] / (grid * NB * 4096) * (grid * NB * 4096);
             if (off + bytes > pool) off = 0;
             const int* wf = (mode == 1 && i > 0) ? flags + (i - 1) : nullptr;      // mode 2: two streams, NO dependency at all (what the two queues alone cost)
             hipLaunchKernelGGL(stream_launch, dim3(grid), dim3(256), 0, mode >= 1 ? s[i & 1] : s[0], buf + off, bytes, wf, (variant & 2) ? 1 : grid, flags + i, sink, timeouts, variant, relay + (size_t)(i > 0 ? i - 1 : 0) * 1024, 1, relay + (size_t)i * 1024);
@@ -126,12 +131,12 @@ int main(int argc, char** argv) {
         int to = 0; hipMemcpy(&to, timeouts, 4, hipMemcpyDeviceToHost);
         return std::make_pair(std::chrono::duration<double, std::micro>(t1 - t0).count() / layers, to);
     };
-    size_t layer_bytes = 0; for (size_t b : sizes) layer_bytes += b / (grid * NB * 4096) * (grid * NB * 4096);
+    size_t layer_bytes = 0; for (int i = 0; i < NL; ++i) layer_bytes += sizes[i] / (grid * NB * 4096) * (grid * NB * 4096);
     for (int rep = 0; rep < 3; ++rep) {
         auto a = run(0); auto b = run(1); auto c = run(2);
-        printf("{\"layer_MB\": %.1f, \"serial_us_per_layer\": %.1f, \"serial_TBps\": %.2f, \"two_stream_flag_us_per_layer\": %.1f, \"two_stream_TBps\": %.2f, \"flag_timeouts\": %d, "
+        printf("{\"launches_per_layer\": %d, \"variant\": %d, \"layer_MB\": %.1f, \"serial_us_per_layer\": %.1f, \"serial_TBps\": %.2f, \"two_stream_flag_us_per_layer\": %.1f, \"two_stream_TBps\": %.2f, \"flag_timeouts\": %d, "
                "\"two_stream_independent_us_per_layer\": %.1f}\n",
-               layer_bytes / 1e6, a.first, layer_bytes / a.first / 1e6, b.first, layer_bytes / b.first / 1e6, b.second, c.first);
+               NL, variant, layer_bytes / 1e6, a.first, layer_bytes / a.first / 1e6, b.first, layer_bytes / b.first / 1e6, b.second, c.first);
     }
     return 0;
 }
