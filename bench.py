@@ -307,6 +307,35 @@ def bench_llava_bench_eos(eng, dev, n_q=90, max_new=512, n_eos=250):
     eng._kvs.clear(); eng._graphs.clear(); eng._kv = None
     torch.cuda.empty_cache()
     out["speedup"] = round(out["retire"]["tokens_per_s"] / out["static"]["tokens_per_s"], 2)
+    # A LIST four times as long (llava_sampling.py:78 walks all of LLaVA-Bench): batch after batch through generate() with retirement, against
+    # generate_list() with the same 90 questions in flight - waiting questions take the slots of finished ones
+    ids4, imgs4 = pope_prompts(4 * n_q, per_img=1, seed=778)
+    imgs4 = [im.to(dev).to(eng.dtype) for im in imgs4]
+
+    def answer_tokens(tokens):
+        hit = (tokens[:, :, None] == eos_t).any(-1)
+        return float(torch.where(hit.any(1), hit.float().argmax(1) + 1, torch.full((tokens.shape[0],), tokens.shape[1], device=dev)).sum())
+
+    def batches():
+        return [eng.generate(ids4[b:b + n_q], **dict(kw, images=imgs4[b:b + n_q])) for b in range(0, 4 * n_q, n_q)]
+    kwl = {k: v for k, v in kw.items() if k != "images"}
+    batches()
+    outs, dt_b = _timed(batches, dev)
+    n_b = sum(answer_tokens(o.tokens) for o in outs)
+    eng._kvs.clear(); eng._graphs.clear(); eng._kv = None
+    torch.cuda.empty_cache()
+    torch.cuda.reset_peak_memory_stats(dev)
+    eng.generate_list(ids4, imgs4, in_flight=n_q, **kwl)
+    ol, dt_l = _timed(lambda: eng.generate_list(ids4, imgs4, in_flight=n_q, **kwl), dev)
+    out["list_of_360"] = {"batch_after_batch": {"tokens_per_s": round(n_b / dt_b, 1), "seconds": round(dt_b, 2), "answer_tokens": int(n_b)},
+                          "generate_list": {"tokens_per_s": round(answer_tokens(ol.tokens) / dt_l, 1), "seconds": round(dt_l, 2), "answer_tokens": int(answer_tokens(ol.tokens)),
+                                            "admissions": ol.stats["admissions"], "decode_steps": ol.stats["steps"], "mean_live_rows": ol.stats["mean_live_rows"],
+                                            "hbm_peak_GB": round(torch.cuda.max_memory_allocated(dev) / 1e9, 1)},
+                          "workload": f"{4 * n_q} questions of the same shape; both keep {n_q} questions = {3 * n_q} rows in flight (sampled runs: the two draw different "
+                                      "random streams, their length samples differ slightly)"}
+    out["list_of_360"]["speedup"] = round(out["list_of_360"]["generate_list"]["tokens_per_s"] / out["list_of_360"]["batch_after_batch"]["tokens_per_s"], 2)
+    eng._kvs.clear(); eng._graphs.clear(); eng._kv = None
+    torch.cuda.empty_cache()
     out["workload"] = (f"{n_q} questions x 3 branches (use_dd + use_dd_unk) = {3 * n_q} rows, one image each, top-p 0.9, T = 1, max_new_tokens {max_new}, "
                        f"{len(eos)} random EOS ids (sampled runs: the two legs draw different random streams, so their length samples differ slightly)")
     return out

@@ -809,6 +809,16 @@ class _DecodeRunner:
         self.gen.index_copy_(0, q_idx, fresh)
         self.s0.index_copy_(0, q_idx, (self.step_idx - 1).expand(k))        # the next step writes column 1 of these slots
 
+    def adopt_slots(self, old: "_DecodeRunner", q_idx: torch.Tensor):
+        """Admission mode, tail of a list: continue `old`'s decoding with its question slots q_idx only.  Own-KV slots are addressed per row
+        (`slot`), so nothing moves in the pools - the smaller step just lists the surviving rows."""
+        Qo, nb = old.Q, self.nb
+        rows_idx = torch.cat([q_idx + b * Qo for b in range(nb)])
+        self.pos.copy_(old.pos[rows_idx]); self.cpos.copy_(old.cpos[rows_idx]); self.slot.copy_(old.slot[rows_idx]); self.rows.copy_(old.rows[rows_idx])
+        self.tok.copy_(old.tok[q_idx]); self.unfinished.copy_(old.unfinished[q_idx]); self.gen.copy_(old.gen[q_idx]); self.s0.copy_(old.s0[q_idx])
+        self.step_idx.copy_(old.step_idx); self.ctr.copy_(old.ctr)
+        self.status.copy_(old.status[q_idx]); self.status0.copy_(old.status0[q_idx])
+
     def body(self, kv):
         t, Q, nb = self.tail, self.Q, self.nb
         self.tokens_rows.view(nb, Q).copy_(self.tok[None].expand(nb, Q))        # same new token for every branch of a question
@@ -1572,7 +1582,20 @@ class VddLlavaEngine:
             stats["admissions"] += 1
             stats["prefill_tokens"] += sum(p_["T"] for p_ in new_pre) + sum(s_["T"] for s_ in suffix)
 
-        admit(list(range(Qc)))
+        import time as _time
+        ev_pairs, host_admit = [], 0.0
+
+        def timed_admit(slots):
+            nonlocal host_admit
+            e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+            e0.record(torch.cuda.current_stream(dev))
+            t0 = _time.perf_counter()
+            admit(slots)
+            host_admit += _time.perf_counter() - t0
+            e1.record(torch.cuda.current_stream(dev))
+            ev_pairs.append((e0, e1))
+
+        timed_admit(list(range(Qc)))
         steps, marks = 0, []
         while True:
             run.step(kv)
@@ -1590,18 +1613,30 @@ class VddLlavaEngine:
             live_row_steps += nb * sum(unf_h) * min(sync_every, steps)
             if bad:
                 break
-            done = [q for q in range(Qc) if not unf_h[q] and slot_q[q] >= 0]
+            Qr = run.Q
+            done = [q for q in range(Qr) if not unf_h[q] and slot_q[q] >= 0]
             if not waiting:
                 if not any(unf_h):
                     break
+                live = [q for q in range(Qr) if unf_h[q]]
+                if len(live) <= self.retire_fraction * Qr and Qr > 8:
+                    # the tail of the list: nobody is waiting for the finished slots - a smaller step over the survivors (their KV stays where
+                    # it is; one capture per halving)
+                    retire(done)
+                    small = self._runner(cfgkey + ("tail", len(live)), len(live), nb, max_new_tokens, tail, kv)
+                    small.adopt_slots(run, torch.tensor(live, dtype=torch.long, device=dev))
+                    slot_q, slot_keys = [slot_q[q] for q in live], [slot_keys[q] for q in live]
+                    run = small
+                    stats["tail_shrinks"] = stats.get("tail_shrinks", 0) + 1
                 continue
-            free = [q for q in range(Qc) if not unf_h[q]]
+            free = [q for q in range(Qr) if not unf_h[q]]
             if len(free) >= min(admit_min, len(waiting)) or not any(unf_h):
                 retire(done)
-                admit(free[:len(waiting)])
+                timed_admit(free[:len(waiting)])
         if bool((run.status | run.status0).ne(0).any().item()):
             raise RuntimeError("probability tensor contains either `inf`, `nan` or element < 0")   # torch.multinomial, vcd_sample.py:202
-        retire([q for q in range(Qc) if slot_q[q] >= 0])
+        retire([q for q in range(run.Q) if slot_q[q] >= 0])
+        stats.update(admit_gpu_s=round(sum(a_.elapsed_time(b_) for a_, b_ in ev_pairs) / 1e3, 3), admit_host_s=round(host_admit, 3))
         is_eos = (master[:, :, None] == eos_t[None, None, :]).any(-1)
         n_tok = torch.where(is_eos.any(1), is_eos.float().argmax(1) + 1, torch.full((N,), max_new_tokens, device=dev))
         gen = master[:, : int(n_tok.max().item())].clone()

@@ -45,6 +45,7 @@ def test_list_answers_equal_the_batch_answers_in_batch_invariant_mode(mode):
     assert torch.equal(ref.top_tok, out.top_tok) and torch.equal(ref.top_prob, out.top_prob)
     st = out.stats
     assert st["admissions"] >= 4 and st["in_flight"] == 12 and st["questions"] == 40 and st["graph"] and st["answer_tokens"] == int(lb.sum())
+    assert st.get("tail_shrinks", 0) >= 1                                                      # the end of the list ran on a smaller step
     assert [s.shape[0] for s in out.sequences] == [len(i) + out.tokens.shape[1] for i in ids]
 
 
@@ -85,16 +86,17 @@ def test_retirement_carries_the_in_kernel_processors():
     its question.  Token for token equal to the static run in batch-invariant mode."""
     from llava_align_amd import ops
     eng = _engine(W7B, n_layers=2, vit_layers=2)
-    ids, imgs = _prompts(24, 1, 32000, seed=41)
+    ids, _ = _prompts(24, 1, 32000, seed=41)
+    ids = [torch.tensor([t for t in r.tolist() if t != -200]) for r in ids]       # slot-free prompts: what the reference combines the penalty with (LAVIS, Qwen)
     eos = _eos_set(600, 7)
-    kw = dict(images=imgs, use_dd_unk=True, cd_alpha=1.0, cd_beta=0.1, temperature=1.0, top_p=0.9, cd_greedy=True, max_new_tokens=160, eos_token_id=eos,
-              pad_token_id=0, min_new_tokens=6, repetition_penalty=1.2, sync_every=8)
+    kw = dict(temperature=1.0, top_p=0.9, cd_greedy=True, max_new_tokens=160, eos_token_id=eos, pad_token_id=0, min_new_tokens=6, repetition_penalty=1.2,
+              sync_every=8)
     with ops.batch_invariant():
         eng.retire, eng.kv_chunk = False, 32
         a = eng.generate(ids, **kw)
         eng._kvs.clear(); eng._graphs.clear()
         eng.retire = True
         b = eng.generate(ids, **kw)
-    assert "retire_events" not in a.stats and b.stats["retire_events"] >= 2 and b.stats["rows_at_end"] < 48
+    assert "retire_events" not in a.stats and b.stats["retire_events"] >= 2 and b.stats["rows_at_end"] < 24
     assert int(_answer_lengths(a.tokens, eos).min()) >= 6                                       # the EOS floor held
     assert a.tokens.shape == b.tokens.shape and torch.equal(a.tokens, b.tokens)
