@@ -21,8 +21,13 @@ Extra objects on the line:
   roofline_extra  the regimes where nothing is masked (beta = 1e-6) and V = 151,936
   pope_eos      the same batch stopped by EOS after 1-2 tokens per question (POPE answers), EOS logic of the kernel in the loop
   decode_step   measured ms per decode step of the engine vs the weight-streaming floor
-  cpu_baseline  the reference path on the host CPU: config #1 end to end on the toy LM (value), the sampling tail
-                with a stubbed forward (ms/step, comparable with BASELINE.md §2), and a bounded LLaVA-7B sample
+  cpu_baseline  the reference path on the host CPU: value = the headline's own model (LLaVA-1.5-7B shapes, one question, B = 1, 2 new
+                tokens, all 32 layers measured); `config1` = BASELINE config #1 end to end on the toy LM; `sampling_tail` = the per-step tail with a
+                stubbed forward (ms/step, comparable with BASELINE.md §2)
+  config2_full / config3 / config4 / config5   the other BASELINE configs through the drivers (pope_driver / mme_driver / blip_driver) and config #3's
+                13B shapes on this GPU and at its rank-of-8 share, each with a decode-step HBM roofline (`step_roofline`) from HIP events
+  batch_invariant   the headline step in batch-invariant mode (what the drivers select for deterministic decodes)
+  llava_bench_eos   config #3's call shape with EOS: static / retirement, and a 360-question list through generate_list against batch-after-batch
   eager_gpu     the reference path on this GPU: the oracle restatement of the patched sample() over HF's OWN eager stack - the installed
                 transformers' LlamaForCausalLM + CLIPVisionModel composed like LlavaLlamaForCausalLM (tests/hf_llava.py), 7B widths, 32 + 24
                 layers, fp16 (builder.py:40), eager attention with output_attentions=True (llava_calibrate.py:175) - B=1, one forward
@@ -319,13 +324,13 @@ def bench_llava_bench_eos(eng, dev, n_q=90, max_new=512, n_eos=250):
     def batches():
         return [eng.generate(ids4[b:b + n_q], **dict(kw, images=imgs4[b:b + n_q])) for b in range(0, 4 * n_q, n_q)]
     kwl = {k: v for k, v in kw.items() if k != "images"}
-    batches()
+    eng.generate(ids4[:n_q], **dict(kw, images=imgs4[:n_q], max_new_tokens=160))      # warm-up: graph capture paths of this shape (the tuner's picks are already there)
     outs, dt_b = _timed(batches, dev)
     n_b = sum(answer_tokens(o.tokens) for o in outs)
     eng._kvs.clear(); eng._graphs.clear(); eng._kv = None
     torch.cuda.empty_cache()
     torch.cuda.reset_peak_memory_stats(dev)
-    eng.generate_list(ids4, imgs4, in_flight=n_q, **kwl)
+    eng.generate_list(ids4[:n_q + 40], imgs4[:n_q + 40], in_flight=n_q, **kwl)     # warm-up on a short list: captures, tuner picks of the admission waves
     ol, dt_l = _timed(lambda: eng.generate_list(ids4, imgs4, in_flight=n_q, **kwl), dev)
     out["list_of_360"] = {"batch_after_batch": {"tokens_per_s": round(n_b / dt_b, 1), "seconds": round(dt_b, 2), "answer_tokens": int(n_b)},
                           "generate_list": {"tokens_per_s": round(answer_tokens(ol.tokens) / dt_l, 1), "seconds": round(dt_l, 2), "answer_tokens": int(answer_tokens(ol.tokens)),
@@ -346,7 +351,8 @@ def bench_cpu(eng):
     (b) BASELINE config #1 end to end - 32 POPE-like questions, B=1, use_dd, top-k 1, 8 new tokens, toy LM with V = 32000 - through
         the oracle restatement of the reference loop (value);
     (a) the sampling tail with a stubbed forward at V = 32000 (use_dd_unk, T = 0.2), ms per step, comparable with BASELINE.md §2;
-    plus a bounded LLaVA-1.5-7B sample (1 question, 2 new tokens, 2 of 32 decoder layers timed and scaled - labelled as such)."""
+    and `value`: the headline's own model on the host - LLaVA-1.5-7B shapes, 1 question, 2 new tokens, all 32 layers measured when a
+    2-layer estimate says that fits ~75 s (else the estimate, labelled)."""
     import copy
     import numpy as np
     import torch
@@ -395,21 +401,32 @@ def bench_cpu(eng):
     w0 = LlavaWeights(cfg0, "cpu")
     w0.t = {k: t for k, t in w.t.items() if not (k.startswith("l") and k[1].isdigit())}
     t_fixed = reference_path(w0, "cpu", pids[0], pimgs[0], n7)
-    t_full = t_fixed + max(0.0, (t_small - t_fixed) / layers) * full
-    return {"value": round(cfg1, 2), "unit": "tokens/s", "cores": threads, "host_cpus": os.cpu_count(), "kind": "port",
-            "comparable_with_headline": False,
-            "note": "value = BASELINE config #1 (the reference's CPU-runnable plumbing case: toy LM, d = 64) - a DIFFERENT model from the "
-                    "LLaVA-7B GPU headline, so value / cpu_baseline.value is not a speed-up; the same-model CPU figure is "
-                    "llava7b_bounded.tokens_per_s (2 of 32 layers timed, extrapolated)",
-            "sample": f"BASELINE config #1, fully measured: {n_q} POPE-like questions (35 sys + image slot + 24 text tokens), B=1, use_dd, "
-                      f"top-k 1, {n_new} new tokens each, toy KV-cache LM (V=32000, d=64) on torch-CPU through the oracle restatement of "
-                      f"the reference loop: {tot:.1f}s",
+    t_est = t_fixed + max(0.0, (t_small - t_fixed) / layers) * full
+    # the SAME model as the headline, measured in full when the estimate says it fits the bench's CPU budget (it does on the GPU box's
+    # host: ~30 s): all 32 decoder layers, ViT, projector, lm_head - one POPE-like question, use_dd_unk, 2 new tokens, B = 1
+    measured = t_est <= 75.0
+    if measured:
+        wf = LlavaWeights(eng.cfg, "cpu")
+        wf.t = {k: t.cpu() for k, t in eng.w.t.items()}
+        t_full = reference_path(wf, "cpu", pids[0], pimgs[0], n7)
+        del wf
+    else:
+        t_full = t_est
+    how = (f"measured in full: all {full} decoder layers + ViT + projector + lm_head, {t_full:.1f}s (the {layers}-layer estimate said {t_est:.1f}s)" if measured else
+           f"{layers} of {full} decoder layers timed ({t_small:.1f}s; depth-independent part {t_fixed:.1f}s), scaled to {full} layers -> {t_full:.1f}s (too slow to measure in full here)")
+    return {"value": round(n7 / t_full, 4), "unit": "tokens/s", "cores": threads, "host_cpus": os.cpu_count(), "kind": "port",
+            "comparable_with_headline": bool(measured), "extrapolated": not measured,
+            "note": "value = the headline's own model and decoding mode on the host CPU (the oracle restatement of the reference's patched sample() over "
+                    "this repo's plain-torch LLaVA, B = 1 as the reference decodes); the GPU figure beside it is `single_question` (same regime) - the "
+                    "768-question headline batches what the reference cannot",
+            "sample": f"LLaVA-1.5-7B shapes, 1 POPE-like question (35 sys + 576 image + ~24 text tokens), use_dd_unk, alpha 1, beta 0.1, T 0.2, {n7} new tokens, "
+                      f"bf16 torch-CPU, {threads} threads: {how}",
+            "config1": {"tokens_per_s": round(cfg1, 2),
+                        "sample": f"BASELINE config #1, fully measured: {n_q} POPE-like questions (35 sys + image slot + 24 text tokens), B=1, use_dd, "
+                                  f"top-k 1, {n_new} new tokens each, toy KV-cache LM (V=32000, d=64) on torch-CPU through the oracle restatement of "
+                                  f"the reference loop: {tot:.1f}s (a DIFFERENT model from the headline: plumbing only)"},
             "sampling_tail": {"ms_per_step": round(tail_ms, 3), "V": 32000, "mode": "use_dd_unk, T=0.2, bf16 logits, forward stubbed (replayed rows)",
-                              "steps": steps, "compare": "BASELINE.md §2: 1.4-2.4 ms/step on 8 vCPU"},
-            "llava7b_bounded": {"tokens_per_s": round(n7 / t_full, 4), "extrapolated": True,
-                                "sample": f"1 POPE-like question, {n7} new tokens, use_dd_unk, bf16 torch-CPU: ViT + projector + lm_head in full, "
-                                          f"{layers} of {full} decoder layers timed ({t_small:.1f}s; depth-independent part {t_fixed:.1f}s), scaled to "
-                                          f"{full} layers -> {t_full:.1f}s"}}
+                              "steps": steps, "compare": "BASELINE.md §2: 1.4-2.4 ms/step on 8 vCPU"}}
 
 
 def bench_fp16(a, dev, ids, host_imgs, n_new):
