@@ -517,6 +517,36 @@ class LanguageModel:
         return self._head(a)
 
     fuse_norms = True         # few rows in flight: the RMSNorm launches ride inside the projections around them
+    def _layer_form_thunks(self, M: int):
+        """What ops.norm_fused_pays times when it has no measurement for (M rows, this width) yet: one decoder layer's projections + norms in
+        the norm-fused five-launch form and in the seven-launch form (attention left out: the same one-launch kernel in both), each on the
+        weights of layer i % n_rot so that every timed launch streams its weights from HBM as the decode step does."""
+        c, t, dev, dt = self.cfg, self.w.t, self.w.device, self.w.dtype
+        if M > ops.norm_fused_rows(c.d) or c.n_layers < 1:
+            return None
+        n_rot = min(c.n_layers, 4)
+        g = torch.Generator(device=dev).manual_seed(0)
+        rnd_ = lambda *shape: (torch.randn(*shape, device=dev, generator=g) * 0.5).to(dt)
+        resid, att, delta0 = rnd_(M, c.d), rnd_(M, c.n_heads * c.head_dim), rnd_(M, c.d)
+        bias = lambda p: t[p + "bqkv_lm"] if c.qkv_bias else None
+
+        def fused(i):
+            p = f"l{i}."
+            r1, ss = ops.linear_resid_ss(att, t[p + "wo"], resid)
+            ops.linear_normed(r1, ss, t[p + "ln1"], c.eps, t[p + "wqkv"], bias=bias(p))
+            act = ops.swiglu_linear_normed(r1, ss, t[p + "ln2"], c.eps, t[p + "wgu"])
+            ops.linear_resid_ss(act, t[p + "wd"], r1)
+
+        def plain(i):
+            p = f"l{i}."
+            tmp = torch.empty_like(resid)
+            a = ops.rmsnorm(resid, t[p + "ln1"], c.eps, delta=delta0, resid_out=tmp)
+            ops.linear(a, t[p + "wqkv"], bias=bias(p))
+            o = ops.linear_to_norm(att, t[p + "wo"])
+            a = ops.rmsnorm(tmp, t[p + "ln2"], c.eps, delta=o, resid_out=tmp)
+            ops.linear_to_norm(ops.swiglu_linear(a, t[p + "wgu"]), t[p + "wd"])
+        return dict(fused=fused, plain=plain, device=dev, n_rot=n_rot)
+
     @torch.no_grad()
     def _decode_step_few_rows(self, resid, pos, cpos, slot, attn_rows, kv):
         """One question (2-3 branch rows) up to 16 rows: 5 launches per layer instead of 7.  The attention-output and MLP-down
@@ -554,8 +584,8 @@ class LanguageModel:
             # only the grouped pass, which reads the per-layer fragment images, may decode from it
             raise ValueError("decode_step: a frag_only KVCache decodes through the grouped attention only (pass `grouping`)")
         resid = ops.embed(tokens, t["embed"])
-        if (self.fuse_norms and grouping is None and tokens.shape[0] <= ops.FUSED_ATTN_MAX_M and ops.norm_fused_pays(tokens.shape[0], c.d) and D == 128
-                and c.ffn % 128 == 0 and c.n_layers > 0):
+        if (self.fuse_norms and grouping is None and tokens.shape[0] <= ops.FUSED_ATTN_MAX_M and D == 128 and c.ffn % 128 == 0 and c.n_layers > 0
+                and ops.norm_fused_pays(tokens.shape[0], c.d, self.w.dtype, lambda: self._layer_form_thunks(tokens.shape[0]))):
             return self._decode_step_few_rows(resid, pos, cpos, slot, attn_rows, kv)
         delta = None
         for i in range(c.n_layers):

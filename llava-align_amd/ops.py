@@ -187,56 +187,57 @@ def slab_splits(M, N, K, n_cu=256):
 
 def linear_to_norm(x, w):
     """Projection whose only consumer is the next RMSNorm's residual add (attention output / MLP down projection): returns either
-    the [M, N] product or, between skinny_rows() and SLAB_NORM_MAX_M rows, fp32 split-K slabs [S, M, N] that rmsnorm(delta=...) adds,
-    rounds and then adds to the residual stream - the same roundings as a rounded product followed by the add.  N = d gives the MFMA
-    GEMM 16 - 32 output tiles at these row counts: as a finished product each is cut over 8 - 16 workgroups and put together by ONE
-    that reads the others' partial tiles in turn; as slabs nobody waits (projection + norm, tools/skinny_crossover_probe.py: down
-    43.8 -> 38.6 us at 64 rows, 42.2 -> 37.6 at 96; o 29.1 -> 24.3 at 96 - both forms are launch- and latency-bound, ~20 us for the
-    33 MB of the o-projection).  Up to skinny_rows() rows: the weight-streaming kernel (eight waves per 16-column block split K)."""
+    the [M, N] product (weight-streaming kernel or MFMA GEMM) or fp32 split-K slabs [S, M, N] that rmsnorm(delta=...) adds, rounds and
+    then adds to the residual stream - the same roundings as a rounded product followed by the add.  Which of the three is MEASURED once
+    per (rows, N, K, dtype) on the real operands, consumer norm included (`_pick_form`); what decides (tools/skinny_crossover_probe.py,
+    DESIGN_APPENDIX): N = d gives the GEMM 16 - 32 output tiles at a few dozen rows - as a finished product each is cut over 8 - 16
+    workgroups and put together by ONE that reads the others' partial tiles in turn, as slabs nobody waits; the weight-streaming kernel
+    re-reads X per column block and, when N / 16 column blocks do not divide over the CUs (d = 5120: 320 blocks on 256), runs a second
+    round for a quarter of the chip."""
     M, K = x.shape
     N = w.shape[0]
-    if ((skinny_rows(N, K) < M or (M > UNEVEN_FUSED_MAX_M and uneven_column_blocks(N))) and M <= SLAB_NORM_MAX_M and N <= 8192 and K % 256 == 0
-            and not GEMM_BATCH_INVARIANT):
-        s = slab_splits(M, N, K)
-        if s:
-            return gemm_slabs(x, w, s)
-    return linear(x, w)
+    cands = {}
+    if _skinny_serves(M, K):
+        cands["skinny"] = lambda wi: skinny_gemm(x, wi)
+    if K % 128 == 0 and N % 4 == 0:
+        cands["gemm"] = lambda wi: gemm(x, wi)
+    s_ = slab_splits(M, N, K) if (M <= 256 and N <= 8192 and K % 256 == 0) else 0
+    if s_:
+        cands["slabs"] = lambda wi: gemm_slabs(x, wi, s_)
+    form = _pick_form("to_norm", M, N, K, x, w, cands, consumer="norm")
+    if form == "slabs":
+        return gemm_slabs(x, w, s_)
+    return skinny_gemm(x, w) if form == "skinny" else gemm(x, w)
 
 
-UNEVEN_BLOCKS_TO_SLABS = True
-UNEVEN_FUSED_MAX_M = 7      # rows up to which a model with uneven column blocks keeps the norm-fused five-launch layer (engine.LanguageModel.decode_step):
-                            # 13B decode step, five-launch / seven-launch + slabs: 6.01 / 6.55 ms at 2 rows, 6.45 / 6.90 at 4, 6.79 / 6.98 at 6, 7.58 / 7.31 at 8
-_n_cu = {}
+NORM_FUSED_MAX_M = 16   # rows up to which the normalise-once projections EXIST (their LDS image of the normalised rows; see norm_fused_rows)
 
 
-def uneven_column_blocks(N) -> bool:
-    """The weight-streaming kernels cut a d-wide output into N / 16 column blocks, one or a few per CU.  N = 4096 is 256 blocks on the
-    MI355X's 256 CUs; N = 5120 (LLaVA-1.5-13B) is 320 - a second round for a quarter of the chip with eight-wave blocks, or four-wave
-    blocks whose waves each walk a quarter of K in one dependent chain (down projection, K = 13,824: 38 - 77 us at 3 - 32 rows).  The
-    split-K slabs of the MFMA GEMM (12 parts x 20 tiles = 240 workgroups) stream the same weights in 27 - 29 us, the attention output
-    in 13.5 - 15 against 16.6 - 30.7 (profiles/r05_13b_d_wide_projections.jsonl).  Decode step of the 13B model, 3 branches per question:
-    15 rows 9.14 -> 8.42 ms, 24 rows 10.68 -> 9.41, 33 rows 9.73 -> 9.34; up to SKINNY_MAX_M rows the norm-fused five-launch layer stays
-    ahead (3 rows 6.2 vs 6.6 ms)."""
-    if not UNEVEN_BLOCKS_TO_SLABS:
+FORCE_FORM = {}             # tests / probes: kind ("linear", "to_norm", "swiglu") -> "skinny" | "gemm" | "slabs" wins whenever it is eligible
+FORCE_LAYER_FORM = None     # tests / probes: "fused" | "plain" for every row count the fused layer serves
+
+
+def norm_fused_pays(M: int, d: int, dtype=torch.bfloat16, time_forms=None) -> bool:
+    """Does a decode step of M rows take the norm-fused five-launch layer (RMSNorms inside the projections around them) or the
+    seven-launch layer (stand-alone norms, the projections in whatever form `_pick_form` measured)?  Measured once per (rows, d, dtype):
+    `time_forms()` -> {"fused": fn(i), "plain": fn(i), "device", "n_rot"}, each fn running one decoder layer's projections + norms on the
+    weights of layer i % n_rot (the engine passes them; without them - or under capture, or with the tuner off - the shape-generic
+    fallback: up to 8 rows).  What the measurement finds on the MI355X (tools/fused_band_probe.py, profiles/r05_*): 7B widths fused
+    everywhere up to 16 rows except 9 - 12 (the normalise-once kernels change their block plan at 9 rows); d = 5120 only up to 7 rows
+    (above, its d-wide projections are faster as split-K slabs, which need the stand-alone norms).  Never in batch-invariant mode."""
+    if GEMM_BATCH_INVARIANT or M > norm_fused_rows(d):
         return False
-    dev = torch.cuda.current_device() if torch.cuda.is_available() else -1
-    if dev not in _n_cu:
-        _n_cu[dev] = torch.cuda.get_device_properties(dev).multi_processor_count if dev >= 0 else 256      # (no device: the MI355X's CU count)
-    blocks = (N + 15) // 16
-    return blocks > _n_cu[dev] and blocks % _n_cu[dev] != 0
-
-
-NORM_FUSED_MAX_M = 16   # rows up to which the decoder layer's RMSNorms ride inside the projections around them
-NORM_FUSED_GAP = (9, 12)  # ... except here: from 9 rows the normalise-once kernels run ONE eight-wave block per CU with a 16-row prologue (two four-wave
-                          # blocks up to 8 rows), and until ~12 rows the seven-launch layer is ahead - 7B decode step 4.26 / 4.09 ms at 10 rows,
-                          # 4.51 / 4.47 at 12, 4.65 / 4.66 at 14, 4.80 / 4.91 at 16 (five / seven launches per layer)
-
-
-def norm_fused_pays(M: int, d: int) -> bool:
-    """Does a decode step of M rows take the norm-fused five-launch layer?  (Never in batch-invariant mode: one projection form.)"""
-    if GEMM_BATCH_INVARIANT or M > norm_fused_rows(d) or NORM_FUSED_GAP[0] <= M <= NORM_FUSED_GAP[1]:
-        return False
-    return M <= UNEVEN_FUSED_MAX_M or not uneven_column_blocks(d)
+    if FORCE_LAYER_FORM is not None:
+        return FORCE_LAYER_FORM == "fused"
+    key = ("layer", M, d, 0, _MODEL_DT[dtype])
+    got = _form_choice.get(key)
+    if got is None and time_forms is not None and GEMM_AUTOTUNE and not torch.cuda.is_current_stream_capturing():
+        tf = time_forms()                                  # built only when a measurement is really due
+        if tf:
+            got = _pick_timed(key, {k: tf[k] for k in ("fused", "plain")}, tf["device"], n_rot=tf["n_rot"])
+    if got is None:
+        return M <= FALLBACK_FUSED_ROWS
+    return got == "fused"
 
 
 def norm_fused_rows(d: int) -> int:
@@ -279,39 +280,118 @@ def swiglu_linear_normed(h, ss, ln_w, eps, w_gate_up, out=None):
     return out
 
 
-SKINNY_MAX_M = 8      # up to here every projection is a weight-streaming kernel
+# ---- which FORM a projection takes is measured, not tabulated (round 6).  Until round 5 the crossovers between the weight-streaming kernels, the
+# MFMA GEMM and its split-K slabs were literals measured on three model shapes (SKINNY_ROWS_MEASURED, SKINNY_DEEP_K_MAX_M, SKINNY_WIDE_MAX_M,
+# NORM_FUSED_GAP, UNEVEN_FUSED_MAX_M): any other width silently got LLaVA-1.5-7B's.  Now every (kind, rows, N, K, dtype) is timed once on
+# the real operands - like the GEMM's tile / schedule - persisted in the same cache file, and the in-tree gfx950 defaults
+# (form_choices_mi355x.json, generated by tools/form_sweep.py for the 7B / 13B / Qwen-VL shapes) are such measurements.
+FALLBACK_SKINNY_ROWS = 16   # no measurement available (graph capture in progress, GEMM_AUTOTUNE off): weight-streaming up to one MFMA row tile,
+FALLBACK_FUSED_ROWS = 8     # the GEMM above; norm-fused layer up to 8 rows - shape-generic, deliberately not a tuned number
+_form_choice = {}           # (kind, rows or 64-row bucket, N, K, dtype) -> "skinny" | "gemm" | "slabs";  ("layer", rows, d, 0, dtype) -> "fused" | "plain"
+
+
+def _skinny_serves(M, K) -> bool:
+    """Can the weight-streaming kernels take M rows of a K-deep product?  Up to 16 rows: 16-column blocks, K % 128; 17 - 64 rows: 32-column
+    blocks whose two MFMA column tiles share every X fragment, K % 256."""
+    return (M <= 16 and K % 128 == 0) or (M <= 64 and K % 256 == 0)
 
 
 def skinny_rows(N, K):
-    """Up to how many rows the weight-streaming kernels take an [N, K] projection before the row-batched MFMA GEMM does.  Up to 16 rows:
-    16-column blocks (one X fragment per W fragment).  17 - 64 rows (round 4): 32-column blocks whose two MFMA column tiles share every
-    X fragment, eight waves splitting K, two register stages (skinny_wide_kernel) - the GEMM's time is flat in M below one macro tile
-    (qkv 31, o 27, gate/up 43, down 38 us: a 64 x 256 tile grid that covers a fraction of the CUs plus a serial stream-K fix-up), the
-    16-column kernel re-read X four times per weight byte at 64 rows (tools/skinny_crossover_probe.py).  Needs K % 256 == 0 (every
-    LLaVA / Qwen width).  Under GEMM_BATCH_INVARIANT there is no switch: every projection is the MFMA GEMM at every row count."""
+    """Rows up to which an [N, K] projection takes the weight-streaming kernels according to what has been measured so far (0 in
+    batch-invariant mode: one form).  Introspection for tools and tests; the dispatch itself asks `_pick_form` per row count."""
     if GEMM_BATCH_INVARIANT:
         return 0
-    if N > 8192:
-        if (N, K) in SKINNY_ROWS_MEASURED:
-            return SKINNY_ROWS_MEASURED[(N, K)]
-        return SKINNY_WIDE_MAX_M if K % 256 == 0 else 16
-    return 64 if K <= 5120 else SKINNY_DEEP_K_MAX_M
+    dt = _lib.VDD_BF16
+    m = 0
+    for M in range(1, 65):
+        c = _form_choice.get(_form_key("linear", M, N, K, dt))
+        if c is None:
+            c = "skinny" if (M <= FALLBACK_SKINNY_ROWS and _skinny_serves(M, K)) else "gemm"
+        if c != "skinny":
+            break
+        m = M
+    return m
 
 
-SKINNY_DEEP_K_MAX_M = 26   # d-wide projections with K > 5120 (MLP down): projection + the norm that follows, weight-streaming kernel vs split-K slabs of the
-                           # GEMM: 31.6 / 34.3 us at 17 rows, 34.9 / 34.8 at 24, 38.8 / 35.2 at 32 (7B widths, two-stage kernel); decode step at 26 / 28 / 32
-                           # rows with the switch at 32: 5.24 / 5.36 / 5.47 ms, at 24: 5.27 / 5.26 / 5.31 (round 4: 32)
-
-# Wide outputs whose crossover is NOT where LLaVA-1.5-7B's is (tools/proj_form_probe.py, profiles/r05_proj_form_probe.jsonl: weight-streaming
-# kernel / MFMA GEMM in us).  The GEMM's time is flat in M and, once the weights are a few hundred MB, it streams them at 5.4 TB/s; the
-# weight-streaming kernels start at 5.8 TB/s and lose a few percent per row to their X fragments - so the bigger the matrix, the earlier
-# the GEMM wins: 13B gate/up (283 MB) 49.8 / 51.3 at 4 rows, 60.6 / 51.5 at 8, 73.2 / 52.1 at 24; 13B lm_head 70.7 / 59.2 at 8 rows;
-# 13B qkv 37.0 / 39.3 at 10 rows, 43.0 / 39.0 at 16; Qwen-VL's lm_head (V = 151,936, 1.24 GB) 222 / 226 at 8 rows, 276 / 228 at 16.
-SKINNY_ROWS_MEASURED = {(27648, 5120): 5, (32000, 5120): 3, (15360, 5120): 10, (151936, 4096): 8}
+def _form_key(kind, M, N, K, dt):
+    return (kind, M if M <= 64 else -(-M // 64) * 64, N, K, dt)
 
 
-SKINNY_WIDE_MAX_M = 24   # rows up to which wide outputs (qkv, gate/up, lm_head) take the 32-column weight-streaming kernel: 26.8 - 29.3 us
-                         # against the GEMM's 30.5 (qkv), 39.7 - 43.7 against 43 (gate/up) at 17 - 24 rows; beyond, its X re-reads cost more
+def _time_thunks(thunks, n_rot, iters=8, reps=2):
+    """name -> fn(i): fastest name.  Every launch gets another rotation index i (the callers rotate through copies of the weights, so
+    that none is still in the 256-MiB Infinity Cache when its turn comes again - in the decode step weights always come from HBM)."""
+    best, best_t = None, float("inf")
+    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    turn = 0
+    for name, fn in thunks.items():
+        fn(turn % n_rot); turn += 1                       # warm-up: nested tuning (the GEMM's tile, inner forms) happens here, untimed
+        fn(turn % n_rot); turn += 1
+        t = float("inf")
+        for _ in range(reps):
+            e0.record()
+            for _ in range(iters):
+                fn(turn % n_rot); turn += 1
+            e1.record()
+            e1.synchronize()
+            t = min(t, e0.elapsed_time(e1))
+        if t < best_t:
+            best, best_t = name, t
+    return best
+
+
+def _pick_timed(key, thunks, device, n_rot):
+    """The measured choice for `key`, from the process table, the persisted tables, or a timing run now (None: cannot measure here)."""
+    got = _form_choice.get(key)
+    if got is not None:
+        return got if got in thunks else None
+    if not GEMM_AUTOTUNE:
+        return None
+    _load_persisted(device)
+    got = _form_choice.get(key)
+    if got is not None and got in thunks:
+        return got
+    if torch.cuda.is_current_stream_capturing():
+        return None                                        # (not cached: the next eager call measures)
+    with _CacheLock():                                     # one rank of a node measures, the others read its pick
+        _read_cache_section()
+        got = _form_choice.get(key)
+        if got is None or got not in thunks:
+            got = _form_choice[key] = _time_thunks(thunks, n_rot)
+            _store_persisted(("form",) + tuple(key), got)
+    return got
+
+
+def _pick_form(kind, M, N, K, x, w, cands, consumer=None):
+    """Which of `cands` (name -> fn(weight)) runs this [M, K] x [N, K]^T product.  One eligible form: that one.  Batch-invariant mode: the
+    GEMM.  Else the measured one; a product whose consumer is the next RMSNorm is timed WITH that norm (slabs make the norm add S fp32
+    partials: cheaper projection, dearer norm)."""
+    if GEMM_BATCH_INVARIANT and "gemm" in cands:
+        return "gemm"
+    if len(cands) == 1:
+        return next(iter(cands))
+    if FORCE_FORM.get(kind) in cands:
+        return FORCE_FORM[kind]
+    dt = _MODEL_DT[x.dtype]
+    key = _form_key(kind, M, N, K, dt)
+    got = _form_choice.get(key)
+    if got is not None and got in cands:
+        return got
+    fallback = "skinny" if ("skinny" in cands and M <= FALLBACK_SKINNY_ROWS) else ("gemm" if "gemm" in cands else next(iter(cands)))
+    if not GEMM_AUTOTUNE or torch.cuda.is_current_stream_capturing():
+        return fallback
+    n_copies = int(min(24, max(2, -(-640 * 2 ** 20 // (w.numel() * 2)))))
+    try:
+        copies = [w] + [w.clone() for _ in range(n_copies - 1)]
+    except torch.OutOfMemoryError:
+        copies = [w]
+    if consumer == "norm":
+        res, lnw = torch.zeros(M, N, dtype=x.dtype, device=x.device), torch.ones(N, dtype=x.dtype, device=x.device)
+        thunks = {n_: (lambda i, f=f: rmsnorm(res, lnw, 1e-5, delta=f(copies[i]))) for n_, f in cands.items()}
+    else:
+        thunks = {n_: (lambda i, f=f: f(copies[i])) for n_, f in cands.items()}
+    got = _pick_timed(key, thunks, x.device, len(copies))
+    return got if got is not None else fallback
+
 
 # ---- row-batched MFMA GEMM (csrc/vdd_gemm.hip): every projection above SKINNY_MAX_M rows
 EPI_NONE, EPI_BIAS, EPI_BIAS_QUICK_GELU, EPI_BIAS_GELU, EPI_SWIGLU, EPI_BIAS_RESID = range(6)
@@ -430,14 +510,29 @@ def _gemm_key(M, N, K, epi, dt=_lib.VDD_BF16):
 
 
 def gemm_choices_export() -> dict:
-    """The tuner's choices so far as a JSON-able dict (key "bucket,N,K,epi,batch_invariant,dtype" -> config)."""
-    return {",".join(map(str, k)): v for k, v in _gemm_choice.items()}
+    """The tuner's choices so far as a JSON-able dict: "bucket,N,K,epi,batch_invariant,dtype" -> GEMM config, and
+    "form,kind,rows,N,K,dtype" -> the measured projection / layer form."""
+    out = {",".join(map(str, k)): v for k, v in _gemm_choice.items()}
+    out.update({"form," + ",".join(map(str, k)): v for k, v in _form_choice.items()})
+    return out
 
 
-def gemm_choices_import(d: dict):
+def form_choices_export() -> dict:
+    return {"form," + ",".join(map(str, k)): v for k, v in _form_choice.items()}
+
+
+def gemm_choices_import(d: dict, keep_existing: bool = False):
     for k, v in d.items():
+        if k.startswith("form,"):
+            _f, kind, M, N, K, dt = k.split(",")
+            key = (kind, int(M), int(N), int(K), int(dt))
+            if not (keep_existing and key in _form_choice):
+                _form_choice[key] = str(v)
+            continue
         b, N, K, epi, inv, *dt = k.split(",")
-        _gemm_choice[(int(b), int(N), int(K), int(epi), inv == "True", int(dt[0]) if dt else _lib.VDD_BF16)] = int(v)
+        key = (int(b), int(N), int(K), int(epi), inv == "True", int(dt[0]) if dt else _lib.VDD_BF16)
+        if not (keep_existing and key in _gemm_choice):
+            _gemm_choice[key] = int(v)
 
 
 # ---- persistence of the tuner's choices: run-to-run identical logits.  The winner among (tile, schedule) candidates is picked by
@@ -482,6 +577,21 @@ def gemm_source_fingerprint() -> str:
     return h.hexdigest()[:16]
 
 
+def kernel_source_fingerprint() -> str:
+    """What the in-tree FORM defaults are bound to: the sources of every kernel the forms choose between (the GEMM and the weight-streaming /
+    norm kernels)."""
+    import hashlib
+    import os
+    h = hashlib.sha256()
+    for f in ("vdd_gemm.hip", "vdd_llm_kernels.hip", "vdd_elem.h"):
+        path = os.path.join(os.path.dirname(os.path.abspath(__file__)), "csrc", f)
+        if not os.path.exists(path):
+            return ""
+        with open(path, "rb") as fh:
+            h.update(fh.read())
+    return h.hexdigest()[:16]
+
+
 def _read_cache_section():
     """The cache file's choices for this device and library build (re-read on every call: another rank may have tuned meanwhile)."""
     import json
@@ -515,6 +625,13 @@ def _load_persisted(device):
                 kk = k.split(",")
                 key = (int(kk[0]), int(kk[1]), int(kk[2]), int(kk[3]), kk[4] == "True", int(kk[5]))
                 _gemm_choice.setdefault(key, int(v))
+    fdefault = os.path.join(os.path.dirname(os.path.abspath(__file__)), "form_choices_mi355x.json")
+    if arch.startswith("gfx950") and os.path.exists(fdefault) and os.environ.get("VDD_GEMM_DEFAULTS", "").lower() not in ("off", "0", "none"):
+        with open(fdefault) as f:
+            doc = json.load(f)
+        bound, here = doc.get("kernel_source_sha", ""), kernel_source_fingerprint()
+        if not bound or not here or bound == here or os.environ.get("VDD_GEMM_DEFAULTS", "").lower() == "force":
+            gemm_choices_import(doc.get("choices", {}), keep_existing=True)
     _read_cache_section()
 
 
@@ -559,7 +676,7 @@ def _store_persisted(key, cfg):
         if os.path.exists(path):
             with open(path) as f:
                 data = json.load(f)
-        data.setdefault(_persist["section"], {})[",".join(map(str, key))] = int(cfg)
+        data.setdefault(_persist["section"], {})[",".join(map(str, key))] = cfg if isinstance(cfg, str) else int(cfg)
         tmp = f"{path}.{os.getpid()}.tmp"
         with open(tmp, "w") as f:
             json.dump(data, f, indent=0, sort_keys=True)
@@ -610,26 +727,44 @@ def _gemm_tune(x, w, out, bias, resid, M, N, K, epi, ws, iters=8):
 
 
 def linear(x, w, out=None, bias=None):
-    """Row-batched projection: weight-streaming GEMV kernel up to skinny_rows(N, K) rows, the MFMA GEMM above."""
-    if x.shape[0] <= skinny_rows(w.shape[0], x.shape[1]) and x.shape[1] % 128 == 0:
+    """Row-batched projection: a weight-streaming kernel or the MFMA GEMM, whichever was measured faster for this (rows, N, K, dtype)."""
+    M, K = x.shape
+    N = w.shape[0]
+    cands = {}
+    if _skinny_serves(M, K):
+        cands["skinny"] = lambda wi: skinny_gemm(x, wi)
+    if K % 128 == 0 and N % 4 == 0:
+        cands["gemm"] = lambda wi: gemm(x, wi)
+    if not cands:
+        raise ValueError(f"linear: no kernel serves M={M} N={N} K={K} (K % 128 == 0 and N % 4 == 0 for the GEMM)")
+    if _pick_form("linear", M, N, K, x, w, cands) == "skinny":
         y = skinny_gemm(x, w, out=out)
         return bias_act(y, bias, out=y) if bias is not None else y
     return gemm(x, w, bias=bias, epi=EPI_BIAS if bias is not None else EPI_NONE, out=out)
 
 
-def swiglu_linear(x, w_gate_up, out=None):
-    """silu(x Wg^T) * (x Wu^T) with w_gate_up = [Wg; Wu]: one launch either way - the fused weight-streaming kernel for a
-    handful of rows, the MFMA GEMM with the SwiGLU epilogue above (no [M, 2F] round trip, no silu_mul launch)."""
+def _skinny_swiglu(x, w_gate_up, out=None):
     M, K = x.shape
     F = w_gate_up.shape[0] // 2
-    if M <= min(16 if K % 256 else 64, skinny_rows(2 * F, K)) and K % 128 == 0:   # <= 16 rows: 8 features per block; 17 - 64: 16 (gate + up tiles)
-        dt = _dt(x, w_gate_up)
-        out = torch.empty(M, F, dtype=x.dtype, device=x.device) if out is None else out
-        _lib.check(_lib_ready().vdd_skinny_swiglu(x.data_ptr(), w_gate_up.data_ptr(), out.data_ptr(), M, F, K, x.stride(0), dt, _st(x)))
-        return out
-    if F % 128 == 0:
-        return gemm(x, w_gate_up, epi=EPI_SWIGLU, out=out)
-    return silu_mul(gemm(x, w_gate_up), out=out)
+    dt = _dt(x, w_gate_up)
+    out = torch.empty(M, F, dtype=x.dtype, device=x.device) if out is None else out
+    _lib.check(_lib_ready().vdd_skinny_swiglu(x.data_ptr(), w_gate_up.data_ptr(), out.data_ptr(), M, F, K, x.stride(0), dt, _st(x)))
+    return out
+
+
+def swiglu_linear(x, w_gate_up, out=None):
+    """silu(x Wg^T) * (x Wu^T) with w_gate_up = [Wg; Wu]: one launch either way - the fused weight-streaming kernel (<= 16 rows: 8 features per
+    block; 17 - 64: 16, gate + up tiles) or the MFMA GEMM with the SwiGLU epilogue (no [M, 2F] round trip, no silu_mul launch); measured."""
+    M, K = x.shape
+    F = w_gate_up.shape[0] // 2
+    gemm_form = (lambda wi, o=None: gemm(x, wi, epi=EPI_SWIGLU, out=o)) if F % 128 == 0 else (lambda wi, o=None: silu_mul(gemm(x, wi), out=o))
+    cands = {"gemm": gemm_form} if K % 128 == 0 else {}
+    if _skinny_serves(M, K):
+        cands["skinny"] = lambda wi, o=None: _skinny_swiglu(x, wi, o)
+    if not cands:
+        raise ValueError(f"swiglu_linear: no kernel serves M={M} F={F} K={K}")
+    form = _pick_form("swiglu", M, 2 * F, K, x, w_gate_up, {k: (lambda wi, f=f: f(wi)) for k, f in cands.items()})
+    return cands[form](w_gate_up, out)
 
 
 _attn_ws = {}

@@ -500,14 +500,16 @@ def test_norm_fused_few_row_step_equals_the_unfused_step(eng, n_img, per_img):
     kw = dict(images=imgs, use_dd_unk=True, cd_alpha=1.0, cd_beta=0.1, temperature=0.5, max_new_tokens=8, cd_greedy=True, output_scores=True)
     assert eng.lm.fuse_norms
     from llava_align_amd import ops
-    gap = ops.NORM_FUSED_GAP
     try:
-        ops.NORM_FUSED_GAP = (0, -1)       # the five-launch layer at EVERY row count up to 16 (the engine leaves 9 - 12 rows to the seven-launch one: it is faster there)
+        ops.FORCE_LAYER_FORM = "fused"     # the five-launch layer at EVERY row count up to 16 (left alone the engine takes whichever form it measured faster)
+        eng._graphs.clear()
         a = eng.generate(ids, **kw)
-        eng.lm.fuse_norms = False
+        ops.FORCE_LAYER_FORM = "plain"
+        eng._graphs.clear()
         b = eng.generate(ids, **kw)
     finally:
-        eng.lm.fuse_norms, ops.NORM_FUSED_GAP = True, gap
+        ops.FORCE_LAYER_FORM = None
+        eng._graphs.clear()
     for sa, sb in zip(a.scores, b.scores):
         fin = torch.isfinite(sa) & torch.isfinite(sb)
         assert (torch.isfinite(sa) ^ torch.isfinite(sb)).sum() <= 2 * len(ids) and (sa[fin].float() - sb[fin].float()).abs().max().item() <= 0.25

@@ -160,16 +160,31 @@ def test_norm_fused_row_limit_follows_the_lds_budget():
     assert [ops.norm_fused_rows(d) for d in (4096, 5120, 8192, 2048, 16384, 4000)] == [16, 14, 8, 16, 0, 0]
 
 
-def test_which_decode_steps_take_the_five_launch_layer():
-    """ops.norm_fused_pays (measured bands): 7B widths take the norm-fused layer up to 16 rows except 9 - 12 (the
-    normalise-once kernels change their block plan at 9 rows); d = 5120 (LLaVA-1.5-13B: 320 column blocks of 16 on 256 CUs) only up to 7
-    rows - above, its d-wide projections go to the GEMM's split-K slabs, which need the stand-alone norms."""
+def test_projection_and_layer_forms_are_measured_choices_with_generic_fallbacks(monkeypatch):
+    """Round 6: which FORM a projection / a few-row layer takes is a measured, persisted choice (ops._pick_form, ops.norm_fused_pays), not a
+    table of crossovers measured on three model shapes.  Host logic only: recorded choices win, eligibility limits hold, and without a
+    measurement (no GPU here: nothing can be timed) the shape-generic fallbacks apply."""
     from llava_align_amd import ops
-    assert not ops.uneven_column_blocks(4096) and ops.uneven_column_blocks(5120) and not ops.uneven_column_blocks(8192)
-    assert [m for m in range(1, 20) if ops.norm_fused_pays(m, 4096)] == [1, 2, 3, 4, 5, 6, 7, 8, 13, 14, 15, 16]
-    assert [m for m in range(1, 20) if ops.norm_fused_pays(m, 5120)] == [1, 2, 3, 4, 5, 6, 7]
-    assert not ops.norm_fused_pays(2, 4000)                      # widths the normalise-once kernels do not cover
-    assert ops.skinny_rows(27648, 5120) == 5 and ops.skinny_rows(22016, 4096) == ops.SKINNY_WIDE_MAX_M      # 13B gate/up crosses over early
+    monkeypatch.setattr(ops, "_form_choice", {})
+    assert ops._skinny_serves(16, 4096) and ops._skinny_serves(64, 4096) and not ops._skinny_serves(65, 4096)
+    assert ops._skinny_serves(16, 4224) and not ops._skinny_serves(17, 4224)                      # 17 - 64 rows need K % 256
+    assert ops._form_key("linear", 40, 12288, 4096, 2) == ("linear", 40, 12288, 4096, 2)          # exact rows up to 64 ...
+    assert ops._form_key("to_norm", 100, 4096, 11008, 2)[1] == 128                                # ... 64-row buckets above
+    # fallbacks: weight-streaming up to 16 rows, the norm-fused layer up to 8 (and never where its kernels do not exist)
+    assert ops.skinny_rows(12288, 4096) == ops.FALLBACK_SKINNY_ROWS == 16
+    assert [m for m in range(1, 20) if ops.norm_fused_pays(m, 4096)] == list(range(1, ops.FALLBACK_FUSED_ROWS + 1))
+    assert not ops.norm_fused_pays(2, 4000) and not ops.norm_fused_pays(15, 5120)                 # no such kernel / beyond its LDS image (14 rows at d = 5120)
+    # recorded measurements win
+    ops.gemm_choices_import({"form,layer,10,4096,0,2": "plain", "form,layer,13,4096,0,2": "fused", "form,linear,3,32000,5120,2": "gemm",
+                             "form,linear,1,32000,5120,2": "skinny", "form,linear,2,32000,5120,2": "skinny"})
+    assert not ops.norm_fused_pays(10, 4096) and ops.norm_fused_pays(13, 4096) and ops.norm_fused_pays(13, 4096, __import__("torch").bfloat16)
+    assert ops.skinny_rows(32000, 5120) == 2                                                       # (LLaVA-1.5-13B's lm_head leaves the weight-streaming kernel early)
+    assert ops.form_choices_export()["form,layer,10,4096,0,2"] == "plain"
+    # overrides for tests / probes
+    monkeypatch.setattr(ops, "FORCE_LAYER_FORM", "fused")
+    assert ops.norm_fused_pays(10, 4096) and not ops.norm_fused_pays(17, 4096)
+    with ops.batch_invariant():
+        assert not ops.norm_fused_pays(2, 4096) and ops.skinny_rows(32000, 5120) == 0
 
 
 def test_one_launch_attention_band_and_its_batch_invariant_form():
@@ -186,7 +201,7 @@ def test_one_launch_attention_band_and_its_batch_invariant_form():
         with ops.batch_invariant(False):
             assert ops.fused_attention_rows() == 32
         assert ops.GEMM_BATCH_INVARIANT
-    assert not ops.GEMM_BATCH_INVARIANT and ops.skinny_rows(4096, 4096) == 64
+    assert not ops.GEMM_BATCH_INVARIANT and ops.skinny_rows(4096, 4096) > 0
 
 
 def test_drivers_select_batch_invariance_for_deterministic_decodes():

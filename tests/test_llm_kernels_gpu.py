@@ -570,13 +570,26 @@ def test_gemm_split_k_slabs_feed_the_rmsnorm(M, N, K):
     y2 = O.rmsnorm(res, lnw, 1e-5, delta=O.gemm(x, w), resid_out=r2)
     assert (r1.float() - r2.float()).abs().max().item() <= 2 ** -7 * r2.float().abs().max().item()
     assert (y1.float() - y2.float()).abs().max().item() <= 2 ** -6 * y2.float().abs().max().item()
-    out = O.linear_to_norm(x, w)                                     # the engine's entry: slabs in the 33 - 128-row band, a product elsewhere
-    slabs_band = O.skinny_rows(N, K) < M or (M > O.SKINNY_MAX_M and O.uneven_column_blocks(N))     # (N = 5120: 320 column blocks on 256 CUs)
-    assert (out.dim() == 3) == (slabs_band and M <= O.SLAB_NORM_MAX_M and O.slab_splits(M, N, K) > 0)
-    if N == 5120 and K >= 5120:
-        assert (out.dim() == 3) == (M > O.UNEVEN_FUSED_MAX_M)      # LLaVA-1.5-13B's d-wide projections: the five-launch layer up to 7 rows, slabs above
-    if (M, N, K) == (12, 4096, 11008):
-        assert out.dim() == 2                          # 7B widths keep the weight-streaming kernel at 12 rows
+    # the engine's entry picks ONE of the eligible forms by measurement (ops._pick_form); whichever it is, the norm behind it gives the same
+    # residual stream and output to rounding, and the pick is recorded
+    out = O.linear_to_norm(x, w)
+    r3 = torch.empty_like(res)
+    y3 = O.rmsnorm(res, lnw, 1e-5, delta=out, resid_out=r3)
+    assert (r3.float() - r2.float()).abs().max().item() <= 2 ** -7 * r2.float().abs().max().item()
+    assert (y3.float() - y2.float()).abs().max().item() <= 2 ** -6 * y2.float().abs().max().item()
+    eligible = {"gemm"} | ({"skinny"} if O._skinny_serves(M, K) else set()) | ({"slabs"} if (M <= 256 and N <= 8192 and K % 256 == 0 and O.slab_splits(M, N, K)) else set())
+    if len(eligible) > 1:
+        pick = O._form_choice[O._form_key("to_norm", M, N, K, O._MODEL_DT[DT])]
+        assert pick in eligible and (out.dim() == 3) == (pick == "slabs")
+    for form in sorted(eligible):                                    # every eligible form on request (tests / probes: ops.FORCE_FORM)
+        O.FORCE_FORM["to_norm"] = form
+        try:
+            o_ = O.linear_to_norm(x, w)
+        finally:
+            O.FORCE_FORM.pop("to_norm")
+        assert (o_.dim() == 3) == (form == "slabs")
+        yf = O.rmsnorm(res, lnw, 1e-5, delta=o_, resid_out=torch.empty_like(res))
+        assert (yf.float() - y2.float()).abs().max().item() <= 2 ** -6 * y2.float().abs().max().item(), form
 
 
 def test_attention_probs_materialises_the_causal_map():
