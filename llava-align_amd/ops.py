@@ -637,29 +637,39 @@ def _load_persisted(device):
 
 class _CacheLock:
     """Exclusive advisory lock beside the cache file: the ranks of one node tune a missing shape ONE AT A TIME - the second one finds
-    the first one's pick in the file instead of timing its own (and possibly landing on another, equally fast, summation order)."""
+    the first one's pick in the file instead of timing its own (and possibly landing on another, equally fast, summation order).
+    Re-entrant within the process: measuring a projection FORM runs the GEMM, whose own tile tuner takes the lock again (flock on a second
+    descriptor of the same file would wait for the first one forever)."""
+    _depth = 0
+    _file = None
 
     def __enter__(self):
         import os
-        self.f = None
-        path = _persist["path"]
-        if path:
-            try:
-                import fcntl
-                os.makedirs(os.path.dirname(path), exist_ok=True)
-                self.f = open(path + ".lock", "w")
-                fcntl.flock(self.f, fcntl.LOCK_EX)
-            except (OSError, ImportError):
-                self.f = None
+        cls = _CacheLock
+        if cls._depth == 0:
+            cls._file = None
+            path = _persist["path"]
+            if path:
+                try:
+                    import fcntl
+                    os.makedirs(os.path.dirname(path), exist_ok=True)
+                    cls._file = open(path + ".lock", "w")
+                    fcntl.flock(cls._file, fcntl.LOCK_EX)
+                except (OSError, ImportError):
+                    cls._file = None
+        cls._depth += 1
         return self
 
     def __exit__(self, *exc):
-        if self.f is not None:
+        cls = _CacheLock
+        cls._depth -= 1
+        if cls._depth == 0 and cls._file is not None:
             try:
                 import fcntl
-                fcntl.flock(self.f, fcntl.LOCK_UN)
+                fcntl.flock(cls._file, fcntl.LOCK_UN)
             finally:
-                self.f.close()
+                cls._file.close()
+                cls._file = None
         return False
 
 

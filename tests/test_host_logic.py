@@ -243,3 +243,24 @@ def test_tuner_cache_merges_under_the_lock(tmp_path, monkeypatch):
     finally:
         ops._gemm_choice.clear()
         ops._gemm_choice.update(saved)
+
+
+def test_cache_lock_is_reentrant_within_a_process(tmp_path, monkeypatch):
+    """Measuring a projection FORM holds the cache lock and runs the GEMM, whose tile tuner takes it again: a second flock on another
+    descriptor of the same file would wait forever (it did, on the GPU box, for 20 minutes)."""
+    from llava_align_amd import ops
+    monkeypatch.setitem(ops._persist, "path", str(tmp_path / "choices.json"))
+    monkeypatch.setitem(ops._persist, "section", "dev|lib")
+    with ops._CacheLock():
+        with ops._CacheLock():
+            ops._store_persisted(("form", "linear", 3, 32000, 5120, 2), "gemm")
+            ops._store_persisted((1, 4096, 4096, 0, False, 2), 17)
+        assert ops._CacheLock._depth == 1 and ops._CacheLock._file is not None
+    assert ops._CacheLock._depth == 0 and ops._CacheLock._file is None
+    import json
+    sec = json.load(open(tmp_path / "choices.json"))["dev|lib"]
+    assert sec == {"form,linear,3,32000,5120,2": "gemm", "1,4096,4096,0,False,2": 17}
+    monkeypatch.setattr(ops, "_form_choice", {})
+    monkeypatch.setattr(ops, "_gemm_choice", {})
+    ops._read_cache_section()
+    assert ops._form_choice == {("linear", 3, 32000, 5120, 2): "gemm"} and ops._gemm_choice == {(1, 4096, 4096, 0, False, 2): 17}
