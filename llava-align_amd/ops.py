@@ -220,9 +220,10 @@ FORCE_LAYER_FORM = None     # tests / probes: "fused" | "plain" for every row co
 def norm_fused_pays(M: int, d: int, dtype=torch.bfloat16, time_forms=None) -> bool:
     """Does a decode step of M rows take the norm-fused five-launch layer (RMSNorms inside the projections around them) or the
     seven-launch layer (stand-alone norms, the projections in whatever form `_pick_form` measured)?  Measured once per (rows, d, dtype):
-    `time_forms()` -> {"fused": fn(i), "plain": fn(i), "device", "n_rot"}, each fn running one decoder layer's projections + norms on the
-    weights of layer i % n_rot (the engine passes them; without them - or under capture, or with the tuner off - the shape-generic
-    fallback: up to 8 rows).  What the measurement finds on the MI355X (tools/fused_band_probe.py, profiles/r05_*): 7B widths fused
+    `time_forms()` -> {"fused": fn(i), "plain": fn(i), "device", "n_rot", "iters"}: the engine passes the WHOLE decode step in either form
+    (timed on one layer's projections alone the pick was wrong where it is closest: LLaVA-1.5-13B at 2 - 3 rows, where the launches' gaps
+    decide - profiles/r06_layer_form_probe.jsonl); without them - or under capture, or with the tuner off - the shape-generic fallback:
+    up to 8 rows.  What the measurement finds on the MI355X (tools/fused_band_probe.py, profiles/r05_*): 7B widths fused
     everywhere up to 16 rows except 9 - 12 (the normalise-once kernels change their block plan at 9 rows); d = 5120 only up to 7 rows
     (above, its d-wide projections are faster as split-K slabs, which need the stand-alone norms).  Never in batch-invariant mode."""
     if GEMM_BATCH_INVARIANT or M > norm_fused_rows(d):
@@ -234,7 +235,7 @@ def norm_fused_pays(M: int, d: int, dtype=torch.bfloat16, time_forms=None) -> bo
     if got is None and time_forms is not None and GEMM_AUTOTUNE and not torch.cuda.is_current_stream_capturing():
         tf = time_forms()                                  # built only when a measurement is really due
         if tf:
-            got = _pick_timed(key, {k: tf[k] for k in ("fused", "plain")}, tf["device"], n_rot=tf["n_rot"])
+            got = _pick_timed(key, {k: tf[k] for k in ("fused", "plain")}, tf["device"], n_rot=tf["n_rot"], iters=tf.get("iters", 8))
     if got is None:
         return M <= FALLBACK_FUSED_ROWS
     return got == "fused"
@@ -339,7 +340,7 @@ def _time_thunks(thunks, n_rot, iters=8, reps=2):
     return best
 
 
-def _pick_timed(key, thunks, device, n_rot):
+def _pick_timed(key, thunks, device, n_rot, iters=8):
     """The measured choice for `key`, from the process table, the persisted tables, or a timing run now (None: cannot measure here)."""
     got = _form_choice.get(key)
     if got is not None:
@@ -356,7 +357,7 @@ def _pick_timed(key, thunks, device, n_rot):
         _read_cache_section()
         got = _form_choice.get(key)
         if got is None or got not in thunks:
-            got = _form_choice[key] = _time_thunks(thunks, n_rot)
+            got = _form_choice[key] = _time_thunks(thunks, n_rot, iters=iters)
             _store_persisted(("form",) + tuple(key), got)
     return got
 
