@@ -768,8 +768,11 @@ def swiglu_linear(x, w_gate_up, out=None):
     block; 17 - 64: 16, gate + up tiles) or the MFMA GEMM with the SwiGLU epilogue (no [M, 2F] round trip, no silu_mul launch); measured."""
     M, K = x.shape
     F = w_gate_up.shape[0] // 2
-    gemm_form = (lambda wi, o=None: gemm(x, wi, epi=EPI_SWIGLU, out=o)) if F % 128 == 0 else (lambda wi, o=None: silu_mul(gemm(x, wi), out=o))
-    cands = {"gemm": gemm_form} if K % 128 == 0 else {}
+    cands = {}
+    if K % 128 == 0 and F % 128 == 0:
+        cands["gemm"] = lambda wi, o=None: gemm(x, wi, epi=EPI_SWIGLU, out=o)
+    elif K % 128 == 0 and F % 8 == 0:                       # (odd feature counts: the plain GEMM + vdd_silu_mul, whose lanes take 8 features)
+        cands["gemm"] = lambda wi, o=None: silu_mul(gemm(x, wi), out=o)
     if _skinny_serves(M, K):
         cands["skinny"] = lambda wi, o=None: _skinny_swiglu(x, wi, o)
     if not cands:
