@@ -155,3 +155,35 @@ def test_few_row_layer_at_7b_widths_equals_the_unfused_layer(n_q):
         assert (torch.isfinite(sa) ^ torch.isfinite(sb)).sum() <= 2 * n_q, step
         assert (sa[fin].float() - sb[fin].float()).abs().max().item() <= 0.25, step
     assert (a.tokens == b.tokens).float().mean().item() >= 0.75
+
+
+def test_unseen_shape_gets_measured_forms_a_monotone_step_curve_and_the_reference_tokens():
+    """A shape nobody tuned a constant for: d = 8192, 64 heads with 8 KV heads (GQA), ffn 28672 - Llama-70B-like widths, 2
+    layers.  Every projection / layer form is measured at first use (ops._pick_form) instead of inheriting LLaVA-1.5-7B's crossovers: the
+    decode step must then never get markedly SLOWER by dropping rows (what a wrong crossover looks like: 9.0 -> 10.5 ms from 15 to 24
+    rows at 13B widths in round 4), and the tokens are the fp32 reference's."""
+    from llava_align_amd import ops
+    eng = _engine(dict(d=8192, n_heads=64, n_kv_heads=8, head_dim=128, ffn=28672, vocab=32000), n_layers=2, vit_layers=2)
+    ids, imgs = _prompts(64, 1, 32000, seed=23)
+    curve = []
+    for nq in (1, 2, 4, 8, 16, 32, 64):                                   # x 2 branches = 2 ... 128 rows, one image per question (ungrouped)
+        kw = dict(images=imgs[:nq], use_dd_unk=True, cd_alpha=1.0, cd_beta=0.1, temperature=0.5, max_new_tokens=24, seed=1)
+        best = 1e9
+        for rep in range(4):
+            eng.call_log = []
+            eng.generate(ids[:nq], **kw)
+            t = eng.call_timing(eng.call_log[-1])
+            if rep:
+                best = min(best, t["decode_ms"] / t["decode_steps"])
+        curve.append((2 * nq, best))
+    eng.call_log = None
+    for (r0, t0), (r1, t1) in zip(curve, curve[1:]):
+        assert t1 >= 0.93 * t0, curve                                     # monotone up to timing noise
+    assert curve[-1][1] <= 4.0 * curve[0][1], curve                        # and flat-ish: 64 x the rows cost a few x the time (weights dominate)
+    dt = ops._MODEL_DT[eng.dtype]
+    picked = {k: v for k, v in ops._form_choice.items() if k[2] in (8192, 10240, 57344, 32000) or (k[0] == "layer" and k[2] == 8192)}
+    assert any(k[0] == "to_norm" and k[2] == 8192 and k[3] == 28672 for k in picked) and any(k[0] == "swiglu" for k in picked), sorted(picked)
+    assert any(k[0] == "layer" and k[2] == 8192 for k in picked)           # the few-row layer form of THIS width was measured too
+    ref = RefLlava(eng.w, device=DEV)
+    out, checked = _compare(eng, ref, ids[:6], imgs[:6], dict(use_dd_unk=True), dict(temperature=0.5), n_new=4, questions=range(6), tol=0.5)
+    assert out.stats["n_rows"] == 12 and checked >= 6
