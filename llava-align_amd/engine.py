@@ -868,6 +868,11 @@ class _DecodeRunner:
             self.pos += alive
             self.cpos += alive
             self.rows[:, 1] += alive
+            # ... and stop attending their context: a finished row reads ONE key until its slot is taken (a third of the K / V bytes of a
+            # step were those of finished rows near the end of a list)
+            dead = alive == 0
+            self.rows[:, 1].masked_fill_(dead, 1)
+            self.rows[:, 3].masked_fill_(dead, 0)
         self.step_idx += 1
         self.ctr += 1
 
@@ -1452,7 +1457,7 @@ class VddLlavaEngine:
         their own.  Same kwargs and semantics per question as generate() (LLaVA prompts: ids with one -200 slot + one image each; the
         image-free branches use_dd / use_dd_unk); the VCD branch, processors, output_scores and streamers stay with generate().
         Memory: nb x in_flight own slots of (longest suffix + max_new_tokens) tokens are held for the whole call.
-        admit_min: waiting questions are admitted once that many slots are free (default in_flight / 8; prefilling a handful of questions
+        admit_min: waiting questions are admitted once that many slots are free (default in_flight / 16; prefilling a handful of questions
         costs a pass over the weights like a decode step of the whole batch).  Returns a GenerateOutput over ALL questions, input order;
         stats: admissions, decode steps, mean live rows per step.  In batch-invariant mode with cd_greedy every answer equals the one
         generate() gives the question in any batch."""
@@ -1483,7 +1488,7 @@ class VddLlavaEngine:
         warp = WarpSpec(temperature=temperature, top_k=top_k, top_p=top_p)
         n_img_tok = self.cfg.vision.n_patches
         Qc = max(1, min(int(in_flight), N))
-        admit_min = max(1, Qc // 8) if admit_min is None else max(1, int(admit_min))
+        admit_min = max(1, Qc // 16) if admit_min is None else max(1, int(admit_min))
         suffix_cap = max(len(r) - si - 1 for r, si in zip(ids_all, s_img))
         t_pre = max(si + n_img_tok for si in s_img)
         if t_pre + suffix_cap + max_new_tokens > lm.max_pos:

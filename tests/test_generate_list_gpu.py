@@ -49,11 +49,12 @@ def test_list_answers_equal_the_batch_answers_in_batch_invariant_mode(mode):
     assert [s.shape[0] for s in out.sequences] == [len(i) + out.tokens.shape[1] for i in ids]
 
 
-def test_sampled_list_run_is_reproducible_and_well_formed():
+@pytest.mark.parametrize("in_flight", [8, 3])                # 16 rows / 6 rows: the few-row layer forms decode the list too
+def test_sampled_list_run_is_reproducible_and_well_formed(in_flight):
     eng = _engine(W7B, n_layers=2, vit_layers=2)
     ids, imgs = _prompts(5, 6, 32000, seed=17)               # 30 questions, 6 per image: image prefixes shared across slots and waves
     eos = _eos_set(1500, 3)
-    kw = dict(in_flight=8, use_dd_unk=True, cd_alpha=1.0, cd_beta=0.1, temperature=0.7, max_new_tokens=24, eos_token_id=eos, pad_token_id=0, seed=11,
+    kw = dict(in_flight=in_flight, use_dd_unk=True, cd_alpha=1.0, cd_beta=0.1, temperature=0.7, max_new_tokens=24, eos_token_id=eos, pad_token_id=0, seed=11,
               sync_every=2)
     a = eng.generate_list(ids, imgs, **kw)
     b = eng.generate_list(ids, imgs, **kw)
@@ -66,7 +67,7 @@ def test_sampled_list_run_is_reproducible_and_well_formed():
         n = int(L[q])
         assert n == a.tokens.shape[1] or n == 24 or bool((a.tokens[q, n - 1] == eos_t).any())   # ends with EOS unless it ran to the cap
         assert bool((a.tokens[q, n:] == 0).all())
-    assert a.stats["admissions"] >= 3 and 0 < a.stats["mean_live_rows"] <= 16
+    assert a.stats["admissions"] >= 3 and 0 < a.stats["mean_live_rows"] <= 2 * in_flight
 
 
 def test_list_refuses_what_it_does_not_do():
