@@ -857,6 +857,13 @@ class _DecodeRunner:
             self.pos += 1
             self.cpos += 1
             self.rows[:, 1] += 1
+            if t["eos_t"] is not None and self.grouping is None and self.scores_buf is None:
+                # a question that has emitted EOS only produces pad tokens from here on (vcd_sample.py:260) and nobody reads its scores: its
+                # rows stop attending their context - ONE key - until the batch ends or they are retired (K / V bytes of a step follow the
+                # LIVE rows; the grouped pass keeps its group tables, and per-step score rows stay the reference's)
+                dead = (self.unfinished == 0).repeat(nb)
+                self.rows[:, 1].masked_fill_(dead, 1)
+                self.rows[:, 3].masked_fill_(dead, 0)
         else:
             # per-slot column; a slot whose answer reached max_new tokens is finished like one that emitted EOS; finished slots (pad tokens
             # from the kernel) write the slack column and do not move: they rewrite ONE KV position and attend a fixed context until a
