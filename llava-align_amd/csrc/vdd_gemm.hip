@@ -84,6 +84,14 @@ struct GemmArgs {
 constexpr int LDS_BYTES = 160 * 1024;
 constexpr int gemm_staging_bytes(int BN, int WM, int WN) { return ((BN / WN) % 64 == 0) ? WM * WN * 4096 : 0; }
 constexpr int gemm_stages(int BM, int BN, int WM, int WN) {
+    // 64 x 128: up to 64 rows of activations without padding the row tile to 128 - 24 KiB per K-tile buffer, six of them: four K-tiles (64 KiB of W
+    // per CU) in flight behind the two being worked on
+    // (32 x 128, up to 32 rows: 20 KiB per buffer, eight of them = 96 KiB of W in flight; never more buffers than the 6-bit vmcnt can count)
+    if (BM <= 64 && BN == 128) {
+        const int n = (LDS_BYTES - gemm_staging_bytes(BN, WM, WN)) / ((BM + BN) * 128), cap = 63 / ((BM + BN) / 8 / (WM * WN)) + 1;
+        const int m = n > 8 ? 8 : n;
+        return m > cap ? cap : m;
+    }
     if (BM == 64) return 3;
     if (BN == 128 && BM <= 192) { const int n = (LDS_BYTES - gemm_staging_bytes(BN, WM, WN)) / ((BM + BN) * 128); return n > 5 ? 5 : n; }
     return 2;
@@ -759,6 +767,11 @@ VDD_HIDDEN int VDD_IMPL(vdd_gemm)(const void* X, const void* W, void* Y, const v
         case 9: return launch_cfg<128, 128, 2, 4>(a, epilogue, sched, workspace, workspace_bytes, st);      // 8 waves of 64 x 32
         case 10: return launch_cfg<128, 128, 2, 2>(a, epilogue, sched, workspace, workspace_bytes, st);     // 4 waves of 64 x 64
         case 11: return launch_cfg<192, 128, 2, 2>(a, epilogue, sched, workspace, workspace_bytes, st);     // 4 waves of 96 x 64
+        // up to 64 rows (round 6): the row tile is the batch, six K-tile buffers; 12 pairs gate / up inside a wave
+        case 12: return launch_cfg<64, 128, 2, 2>(a, epilogue, sched, workspace, workspace_bytes, st);      // 4 waves of 32 x 64
+        case 13: return launch_cfg<64, 128, 2, 4>(a, epilogue, sched, workspace, workspace_bytes, st);      // 8 waves of 32 x 32
+        case 14: return launch_cfg<32, 128, 1, 4>(a, epilogue, sched, workspace, workspace_bytes, st);      // up to 32 rows: 4 waves of 32 x 32, eight buffers
+        case 15: return launch_cfg<32, 128, 1, 2>(a, epilogue, sched, workspace, workspace_bytes, st);      // 2 waves of 32 x 64 (gate / up pairs)
         // (launch_cfg<256, 256, 2, 2> - four waves of 128 x 128, one per SIMD with 512 registers, the vendor kernel's shape - instantiates as it
         //  is and was measured: 1.10 PF/s on random data, 1.27 on zero operands against 1.27 / 1.6 for the 8-wave tile: a lone wave per SIMD
         //  stalls its own MFMAs behind every LDS-DMA issue and fragment read.  profiles/r04_gemm_data_dependence.jsonl)

@@ -398,7 +398,9 @@ def _pick_form(kind, M, N, K, x, w, cands, consumer=None):
 EPI_NONE, EPI_BIAS, EPI_BIAS_QUICK_GELU, EPI_BIAS_GELU, EPI_SWIGLU, EPI_BIAS_RESID = range(6)
 GEMM_TUNE_MAX_M = 4096          # shapes up to here (the decode batch, single images) pick their tile shape / schedule by a
                                 # one-off timing run; above, 256 x 256 tiles + the hybrid schedule (tools/gemm_sched.py)
-GEMM_CANDIDATES = [(c, s_) for c in (1, 2, 3, 4, 5, 6, 7, 8, 9, 10, 11) for s_ in (0, 1, 2)]     # (macro tile id, schedule) -> config = c + 16 * s
+GEMM_CANDIDATES = [(c, s_) for c in (1, 2, 3, 4, 5, 6, 7, 8, 9, 10, 11, 12, 13, 14, 15) for s_ in (0, 1, 2)]     # (macro tile id, schedule) -> config = c + 16 * s
+import os as _os
+_GEMM_EXCLUDE = {int(c) for c in _os.environ.get("VDD_GEMM_EXCLUDE", "").split(",") if c.strip()}      # probes: tile ids the tuner must not pick
 GEMM_BATCH_INVARIANT = False    # True = batch-invariant mode: a row's results no longer depend on which other rows share its batch, because
                                 # every op then has ONE form with one summation order per output element -
                                 #   * projections: the MFMA GEMM's data-parallel schedule at EVERY row count (each element accumulated over K in one fixed
@@ -506,8 +508,9 @@ GEMM_AUTOTUNE = True            # False: 256 x 256 tiles + the hybrid schedule f
 def _gemm_key(M, N, K, epi, dt=_lib.VDD_BF16):
     """Tuning granularity: shapes up to GEMM_TUNE_MAX_M rows are bucketed by their number of 64-row units (the decode batch and
     the per-image ViT calls repeat a handful of sizes; a prefill length that differs by a few tokens must not re-run 24 candidates
-    and clone 640 MiB of weights); everything above shares one entry."""
-    return (-(-M // 64) if M <= GEMM_TUNE_MAX_M else 0, N, K, epi, GEMM_BATCH_INVARIANT, dt)
+    and clone 640 MiB of weights); everything above shares one entry.  Up to 32 rows: a bucket of its own (-1) - the 32 x 128 tiles
+    (round 6) only serve those."""
+    return (-1 if M <= 32 else (-(-M // 64) if M <= GEMM_TUNE_MAX_M else 0), N, K, epi, GEMM_BATCH_INVARIANT, dt)
 
 
 def gemm_choices_export() -> dict:
@@ -716,7 +719,10 @@ def _gemm_tune(x, w, out, bias, resid, M, N, K, epi, ws, iters=8):
     short = M <= 128
     chunks, reps = (int(min(6, max(1, 2.5e-3 / max(flops / 1.0e15, 30e-6) / iters))), 2) if short else (1, 1)
     for c, sch in GEMM_CANDIDATES:
-        if (epi == EPI_SWIGLU and c in (5, 6, 7, 9)) or (GEMM_BATCH_INVARIANT and sch != 1) or (c in (8, 9, 10, 11) and M > 256):
+        if ((epi == EPI_SWIGLU and c in (5, 6, 7, 9, 13, 14)) or (GEMM_BATCH_INVARIANT and sch != 1) or (c in (8, 9, 10, 11) and M > 256) or (c in (12, 13) and M > 64)
+                or (c in (14, 15) and M > 32)):
+            continue
+        if c in _GEMM_EXCLUDE:
             continue
         cfg = c + 16 * sch
         _gemm_call(x, copies[turn % len(copies)], out, bias, resid, M, N, K, epi, cfg, ws); turn += 1
