@@ -220,7 +220,9 @@ int vdd_skinny_swiglu_normed(const void* H, const float* ss, int nss, const void
  *   buffer per stream: launches on one stream may share it, launches that can run concurrently must not.
  * config: low 4 bits = macro tile (0 = 256x256; 1..8 = 256x256, 128x256, 256x128, 192x256, 256x192, 192x192, 192x128 (these
  *         three: no SwiGLU), 64x256 (a few dozen rows: the launch is a W stream); 9..11 = 128x128 (no SwiGLU), 128x128 and 192x128 on four
- *         waves: W streams for 65 - 256 rows with 3 - 5 K-tile buffers in flight); bits 4-5 = schedule (0 hybrid: whole-tile rounds + stream-K remainder, 1 data-parallel only,
+ *         waves: W streams for 65 - 256 rows with 3 - 5 K-tile buffers in flight; 12..15 = 64x128 on 4 / 8 waves, 32x128 on 4 / 2 waves (13, 14:
+ *         no SwiGLU): up to 64 / 32 rows, six / eight buffers); bits 6-7 = the tile id's high bits (id 16 = 96x128 on 4 waves, no SwiGLU:
+ *         batches that are a multiple of 96 rows rather than of 128); bits 4-5 = schedule (0 hybrid: whole-tile rounds + stream-K remainder, 1 data-parallel only,
  *         2 stream-K only).  Every choice writes the same result up to the fp32 summation order of a K-split tile.
  *         Schedule 3 = split-K SLABS (epilogue NONE only): bits 8-15 = S (1 .. K / 128); Y is then an fp32 buffer [S][M][N] (ldy = N,
  *         16-byte aligned) receiving the S partial products of every output tile - one (tile, K part) per workgroup, no fix-up, no

@@ -751,7 +751,7 @@ VDD_HIDDEN int VDD_IMPL(vdd_gemm)(const void* X, const void* W, void* Y, const v
         a.slabs = (float*)Y;
         if (a.slab_S < 1 || epilogue != EPI_NONE || ldy != N || ((uintptr_t)Y & 15)) return VDD_ERR_INVALID_ARG;
     }
-    config &= 15;
+    config = (config & 15) | (((config >> 6) & 3) << 4);      // macro tile id: bits 0-3 + bits 6-7 (ids 16 ..: round 6)
     if (config == 0) config = 1;
     switch (config) {
         case 1: return launch_cfg<256, 256, 2, 4>(a, epilogue, sched, workspace, workspace_bytes, st);
@@ -772,6 +772,11 @@ VDD_HIDDEN int VDD_IMPL(vdd_gemm)(const void* X, const void* W, void* Y, const v
         case 13: return launch_cfg<64, 128, 2, 4>(a, epilogue, sched, workspace, workspace_bytes, st);      // 8 waves of 32 x 32
         case 14: return launch_cfg<32, 128, 1, 4>(a, epilogue, sched, workspace, workspace_bytes, st);      // up to 32 rows: 4 waves of 32 x 32, eight buffers
         case 15: return launch_cfg<32, 128, 1, 2>(a, epilogue, sched, workspace, workspace_bytes, st);      // 2 waves of 32 x 64 (gate / up pairs)
+        // a 96-row tile: a batch of 270 rows (90 questions x 3 branches, BASELINE config #3) is three of them (288 rows) where 128- / 192-row tiles compute
+        // 384.  Measured (tools/gemm_96_tile_ab.py): the tuner takes it for the d x d attention-output projection at 90 - 360 rows (13B step at 270 rows
+        // 22.8 -> 22.0 ms) and for nothing else - the wide projections keep their 192-row tiles, whose padding costs less than streaming W a third
+        // time; the 2-wave and 96 x 256 variants of it were never picked and are not built
+        case 16: return launch_cfg<96, 128, 1, 4>(a, epilogue, sched, workspace, workspace_bytes, st);      // 4 waves of 96 x 32, five buffers
         // (launch_cfg<256, 256, 2, 2> - four waves of 128 x 128, one per SIMD with 512 registers, the vendor kernel's shape - instantiates as it
         //  is and was measured: 1.10 PF/s on random data, 1.27 on zero operands against 1.27 / 1.6 for the 8-wave tile: a lone wave per SIMD
         //  stalls its own MFMAs behind every LDS-DMA issue and fragment read.  profiles/r04_gemm_data_dependence.jsonl)

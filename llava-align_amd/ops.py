@@ -398,7 +398,13 @@ def _pick_form(kind, M, N, K, x, w, cands, consumer=None):
 EPI_NONE, EPI_BIAS, EPI_BIAS_QUICK_GELU, EPI_BIAS_GELU, EPI_SWIGLU, EPI_BIAS_RESID = range(6)
 GEMM_TUNE_MAX_M = 4096          # shapes up to here (the decode batch, single images) pick their tile shape / schedule by a
                                 # one-off timing run; above, 256 x 256 tiles + the hybrid schedule (tools/gemm_sched.py)
-GEMM_CANDIDATES = [(c, s_) for c in (1, 2, 3, 4, 5, 6, 7, 8, 9, 10, 11, 12, 13, 14, 15) for s_ in (0, 1, 2)]     # (macro tile id, schedule) -> config = c + 16 * s
+GEMM_CANDIDATES = [(c, s_) for c in (1, 2, 3, 4, 5, 6, 7, 8, 9, 10, 11, 12, 13, 14, 15, 16) for s_ in (0, 1, 2)]     # (macro tile id, schedule)
+
+
+def gemm_config(tile: int, sched: int = 0) -> int:
+    """The `config` word of vdd_gemm: tile id in bits 0-3 and 6-7, schedule in bits 4-5 (tile ids up to 15 are `tile + 16 * sched` as ever)."""
+    return (tile & 15) | ((sched & 3) << 4) | ((tile >> 4) << 6)
+
 import os as _os
 _GEMM_EXCLUDE = {int(c) for c in _os.environ.get("VDD_GEMM_EXCLUDE", "").split(",") if c.strip()}      # probes: tile ids the tuner must not pick
 GEMM_BATCH_INVARIANT = False    # True = batch-invariant mode: a row's results no longer depend on which other rows share its batch, because
@@ -486,7 +492,7 @@ def gemm(x, w, bias=None, resid=None, epi=EPI_NONE, out=None, config=None):
             _load_persisted(x.device)
             config = _gemm_choice.get(key)
         if config is None:
-            config = 1 + 16 if GEMM_BATCH_INVARIANT else 1
+            config = gemm_config(1, 1) if GEMM_BATCH_INVARIANT else 1
             if M <= GEMM_TUNE_MAX_M and GEMM_AUTOTUNE:
                 if not torch.cuda.is_current_stream_capturing():
                     with _CacheLock():                             # one rank of a node tunes, the others read its pick
@@ -719,12 +725,12 @@ def _gemm_tune(x, w, out, bias, resid, M, N, K, epi, ws, iters=8):
     short = M <= 128
     chunks, reps = (int(min(6, max(1, 2.5e-3 / max(flops / 1.0e15, 30e-6) / iters))), 2) if short else (1, 1)
     for c, sch in GEMM_CANDIDATES:
-        if ((epi == EPI_SWIGLU and c in (5, 6, 7, 9, 13, 14)) or (GEMM_BATCH_INVARIANT and sch != 1) or (c in (8, 9, 10, 11) and M > 256) or (c in (12, 13) and M > 64)
-                or (c in (14, 15) and M > 32)):
+        if ((epi == EPI_SWIGLU and c in (5, 6, 7, 9, 13, 14, 16)) or (GEMM_BATCH_INVARIANT and sch != 1) or (c in (8, 9, 10, 11) and M > 256) or (c in (12, 13) and M > 64)
+                or (c in (14, 15) and M > 32) or (c == 16 and M > 576)):
             continue
         if c in _GEMM_EXCLUDE:
             continue
-        cfg = c + 16 * sch
+        cfg = gemm_config(c, sch)
         _gemm_call(x, copies[turn % len(copies)], out, bias, resid, M, N, K, epi, cfg, ws); turn += 1
         t = float("inf")
         for _rep in range(reps):

@@ -56,7 +56,7 @@ def test_every_gemm_candidate_stays_inside_its_buffers(case):
     scale = want.abs().max().item()
     n = 0
     for c, sch in E.GEMM_CANDIDATES:
-        if (epi == E.EPI_SWIGLU and c in (5, 6, 7, 9, 13, 14)) or (c == 8 and M > 256):        # (9 - 15: the tuner tries them up to 256 / 64 / 32 rows; they are valid at any M)
+        if (epi == E.EPI_SWIGLU and c in (5, 6, 7, 9, 13, 14, 16)) or (c == 8 and M > 256):        # (9 - 15: the tuner tries them up to 256 / 64 / 32 rows; they are valid at any M)
             continue
         wsbuf = torch.full((need + 2 * GUARD,), 0x5A, dtype=torch.uint8, device=DEV)
         ws = wsbuf[GUARD:GUARD + need]
@@ -64,7 +64,7 @@ def test_every_gemm_candidate_stays_inside_its_buffers(case):
         obuf = torch.full((M * No + 2 * GUARD,), -7.0, dtype=DT, device=DEV)
         out = obuf[GUARD:GUARD + M * No].view(M, No)
         for _ in range(2):
-            E._gemm_call(x, w, out, bias, resid, M, No, K, epi, c + 16 * sch, ws)
+            E._gemm_call(x, w, out, bias, resid, M, No, K, epi, E.gemm_config(c, sch), ws)
         torch.cuda.synchronize()
         assert (wsbuf[:GUARD] == 0x5A).all() and (wsbuf[GUARD + need:] == 0x5A).all(), (c, sch, "workspace guard")
         assert (obuf[:GUARD] == -7.0).all() and (obuf[GUARD + M * No:] == -7.0).all(), (c, sch, "output guard")

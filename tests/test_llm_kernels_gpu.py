@@ -425,7 +425,7 @@ def test_gemm_matches_fp32_reference(M, N, K):
     ref = _gemm_ref(x, w, O.EPI_NONE, None, None)
     tol = 2 ** -7 * ref.abs().max().item() + 1e-3
     for cfg, sched in O.GEMM_CANDIDATES:
-        y = O.gemm(x, w, config=cfg + 16 * sched)
+        y = O.gemm(x, w, config=O.gemm_config(cfg, sched))
         assert (y.float() - ref).abs().max().item() <= tol, (cfg, sched)
     y = O.gemm(x, w)                                                       # tuned choice
     assert (y.float() - ref).abs().max().item() <= tol
@@ -444,10 +444,10 @@ def test_gemm_epilogues(M, N, K):
         w = bf(2 * N if epi == O.EPI_SWIGLU else N, K, scale=0.03, seed=55)
         ref = _gemm_ref(x, w, epi, bias, resid)
         tol = 2 ** -6 * ref.abs().max().item() + 2e-3
-        for cfg in (1, 2, 3, 4, 5, 6, 7, 8, 9, 10, 11, 12, 13, 14, 15):
-            if epi == O.EPI_SWIGLU and cfg in (5, 6, 7, 9, 13, 14): # 192-column tiles do not tile F % 128 features; one 32-column block per wave has no gate / up pair
+        for cfg in range(1, 17):
+            if epi == O.EPI_SWIGLU and cfg in (5, 6, 7, 9, 13, 14, 16): # 192-column tiles do not tile F % 128 features; one 32-column block per wave has no gate / up pair
                 continue
-            y = O.gemm(x, w, bias=bias, resid=resid, epi=epi, config=cfg)
+            y = O.gemm(x, w, bias=bias, resid=resid, epi=epi, config=O.gemm_config(cfg))
             assert y.shape == (M, N) and (y.float() - ref).abs().max().item() <= tol, (epi, cfg)
 
 
@@ -477,7 +477,7 @@ def test_gemm_small_launch_slabs_do_not_poison_a_large_launch_counters():
     ref = _gemm_ref(xb, w, O.EPI_NONE, None, None)
     tol = 2 ** -7 * ref.abs().max().item() + 1e-3
     for cfg, sched in ((2, 0), (2, 2), (7, 0), (1, 2), (3, 0)):                          # up to 313 x 32 = 10,016 tiles
-        y = O.gemm(xb, w, config=cfg + 16 * sched)
+        y = O.gemm(xb, w, config=O.gemm_config(cfg, sched))
         assert (y.float() - ref).abs().max().item() <= tol, (cfg, sched)
     import ctypes
     from llava_align_amd import _lib
