@@ -264,3 +264,24 @@ def test_cache_lock_is_reentrant_within_a_process(tmp_path, monkeypatch):
     monkeypatch.setattr(ops, "_gemm_choice", {})
     ops._read_cache_section()
     assert ops._form_choice == {("linear", 3, 32000, 5120, 2): "gemm"} and ops._gemm_choice == {(1, 4096, 4096, 0, False, 2): 17}
+
+
+def test_gemm_config_word_and_form_defaults():
+    """vdd_gemm's `config`: tile id in bits 0-3 and 6-7 (ids 16.. since round 6), schedule in bits 4-5 - ids up to 15 stay `tile + 16 * sched`;
+    the tuner has a bucket of its own for <= 32 rows (the 32 x 128 tiles serve only those); the in-tree FORM defaults are bound to the kernel sources."""
+    import json
+    import os
+    from llava_align_amd import ops
+    assert [ops.gemm_config(c, s) for c, s in ((1, 0), (9, 2), (15, 1))] == [1, 9 + 32, 15 + 16]
+    assert ops.gemm_config(16, 0) == 64 and ops.gemm_config(16, 2) == 64 + 32 and ops.gemm_config(17, 1) == 1 + 16 + 64
+    dec = lambda v: ((v & 15) | (((v >> 6) & 3) << 4), (v >> 4) & 3)
+    assert all(dec(ops.gemm_config(c, s)) == (c, s) for c in range(1, 20) for s in range(3))
+    assert ops._gemm_key(2, 4096, 4096, 0)[0] == ops._gemm_key(32, 4096, 4096, 0)[0] == -1
+    assert ops._gemm_key(33, 4096, 4096, 0)[0] == ops._gemm_key(64, 4096, 4096, 0)[0] == 1 and ops._gemm_key(65, 4096, 4096, 0)[0] == 2
+    pkg = os.path.dirname(os.path.abspath(ops.__file__))
+    doc = json.load(open(os.path.join(pkg, "form_choices_mi355x.json")))
+    assert doc["kernel_source_sha"] == ops.kernel_source_fingerprint() != "" and len(doc["choices"]) > 1000
+    assert all(k.startswith("form,") and v in ("skinny", "gemm", "slabs", "fused", "plain") for k, v in doc["choices"].items())
+    g = json.load(open(os.path.join(pkg, "gemm_choices_mi355x.json")))["choices"]
+    small = [dec(v)[0] for k, v in g.items() if k.split(",")[0] in ("-1", "1") and k.split(",")[1:3] in (["12288", "4096"], ["4096", "4096"], ["4096", "11008"])]
+    assert small and all(t in (12, 13, 14, 15) for t in small)                 # the few-dozen-row tiles of round 6 carry the 7B projections up to 64 rows
