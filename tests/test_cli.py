@@ -114,3 +114,43 @@ def test_mme_driver_from_a_checkpoint_directory(tmp_path):
     recs = [json.loads(l) for l in open(rep["answers_file"])]
     assert len(recs) == 8 and set(recs[0]) >= {"question_id", "prompt", "text", "naive", "none", "unk", "answer_id", "model_id"}
     assert os.path.isdir(os.path.join(os.path.dirname(out), "eval_tool_answers"))                      # the converter wrote the scorer's input tree
+
+
+@pytest.mark.gpu
+def test_blip_driver_from_its_parts(tmp_path):
+    """`python -m llava_align_amd.blip_driver` (blip_calibrate.py:113-135's arguments): the InstructBLIP state dict under LAVIS's names as one
+    safetensors file, the Vicuna directory (here the LM of the generated LLaVA checkpoint + its tokenizer), a generated BERT-style tokenizer
+    ([CLS] 101 ... [SEP] 102) for the Q-Former; test-sized towers with the real structure (88-wide ViT heads, cross-attention every 2nd layer)."""
+    from safetensors.torch import save_file
+    from tokenizers import Tokenizer, models, pre_tokenizers, processors
+    from transformers import PreTrainedTokenizerFast
+    from blip_weights import blip_state_dict
+    from llava_align_amd.blip_frontend import tiny_blip_config
+    info = write_checkpoint(str(tmp_path))
+    bcfg = tiny_blip_config()
+    save_file({k: v.to(torch.float16).contiguous() for k, v in blip_state_dict(bcfg, seed=11).items()}, str(tmp_path / "instruct_blip_tiny.safetensors"))
+    words = [f"[unused{i}]" for i in range(bcfg.qf.vocab)]
+    words[0], words[100], words[101], words[102] = "[PAD]", "[UNK]", "[CLS]", "[SEP]"
+    for i, w in enumerate(("is", "there", "a", "thing", "in", "the", "image", "?", "please", "answer", "this", "question", "with", "one", "word.")):
+        words[200 + i] = w
+    t = Tokenizer(models.WordLevel({w: i for i, w in enumerate(words)}, unk_token="[UNK]"))
+    t.pre_tokenizer = pre_tokenizers.WhitespaceSplit()
+    t.post_processor = processors.TemplateProcessing(single="[CLS] $A [SEP]", special_tokens=[("[CLS]", 101), ("[SEP]", 102)])
+    bert_dir = tmp_path / "bert-tiny"
+    PreTrainedTokenizerFast(tokenizer_object=t, unk_token="[UNK]", pad_token="[PAD]", cls_token="[CLS]", sep_token="[SEP]").save_pretrained(str(bert_dir))
+    qfile = tmp_path / "pope.json"
+    with open(qfile, "w") as f:
+        for q in range(10):
+            f.write(json.dumps({"question_id": q, "image": f"im{q % 5}.png", "text": f"is there a w{q} in the image ?", "label": ("yes", "no")[q % 2]}) + "\n")
+    out = str(tmp_path / "out" / "blip.jsonl")
+    p = subprocess.run([sys.executable, "-m", "llava_align_amd.blip_driver", "--blip-checkpoint", str(tmp_path / "instruct_blip_tiny.safetensors"), "--llm-path",
+                        info["ckpt"], "--bert-tokenizer", str(bert_dir), "--image-folder", info["images"], "--question-file", str(qfile), "--answers-file", out,
+                        "--use_cd", "--noise_step", "500", "--cd_beta", "0.1", "--seed", "7", "--batch", "4"], capture_output=True, text=True, env=_env(),
+                       timeout=900, cwd=ROOT)
+    assert p.returncode == 0, p.stderr[-3000:]
+    rep = json.loads(p.stdout[p.stdout.index("{"):])
+    assert rep["n_answers"] == 10 and set(rep["scores"]) == {"string_match", "naive", "noise", "zeros"}
+    recs = [json.loads(l) for l in open(out)]
+    assert [r["question_id"] for r in recs] == list(range(10))
+    assert tuple(recs[0].keys()) == ("question_id", "prompt", "text", "model_id", "image", "naive", "noise", "zeros", "metadata")     # blip_calibrate.py:100-109
+    assert recs[0]["prompt"].endswith(" Please answer this question with one word.") and recs[0]["model_id"] == "instruct_blip"
