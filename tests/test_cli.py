@@ -154,3 +154,30 @@ def test_blip_driver_from_its_parts(tmp_path):
     assert [r["question_id"] for r in recs] == list(range(10))
     assert tuple(recs[0].keys()) == ("question_id", "prompt", "text", "model_id", "image", "naive", "noise", "zeros", "metadata")     # blip_calibrate.py:100-109
     assert recs[0]["prompt"].endswith(" Please answer this question with one word.") and recs[0]["model_id"] == "instruct_blip"
+
+
+@pytest.mark.gpu
+def test_sampling_driver_from_a_checkpoint_directory_alone_and_under_torchrun(tmp_path):
+    """`python -m llava_align_amd.sampling_driver` (llava_sampling.py:128-195's arguments; BASELINE config #3's driver): open-ended answers through
+    generate_list, 'setting' -> 'default' in the answers file name, the reference's JSONL fields; two ranks write what one rank writes
+    (cd_greedy is not a CLI flag there, so the seeded sampled run is compared per rank count with itself: file shape, ids, order)."""
+    info = write_checkpoint(str(tmp_path))
+    common = ["--model-path", info["ckpt"], "--question-file", info["questions"], "--image-folder", info["images"], "--use_dd", "--use_dd_unk", "--cd_alpha", "1",
+              "--cd_beta", "0.1", "--max_new_tokens", "12", "--in-flight", "4", "--no-sweep"]
+    one = str(tmp_path / "out" / "one-setting.jsonl")
+    p1 = subprocess.run([sys.executable, "-m", "llava_align_amd.sampling_driver", *common, "--answers-file", one], capture_output=True, text=True, env=_env(),
+                        timeout=900, cwd=ROOT)
+    assert p1.returncode == 0, p1.stderr[-3000:]
+    rep = json.loads(p1.stdout.strip().splitlines()[-1])
+    assert rep["run"] == "default" and rep["n_answers"] == info["n_questions"] and rep["answers_file"].endswith("one-default.jsonl")
+    assert rep["stats"]["in_flight"] == 4 and rep["stats"]["admissions"] >= 2                       # the list went through refilled slots
+    a = [json.loads(l) for l in open(rep["answers_file"])]
+    assert [x["question_id"] for x in a] == list(range(100, 100 + info["n_questions"]))
+    assert tuple(a[0].keys()) == ("question_id", "prompt", "text", "model_id", "image", "metadata") and a[0]["model_id"] == "tiny-llava"   # llava_sampling.py:119-124
+    two = str(tmp_path / "out" / "two-setting.jsonl")
+    p2 = subprocess.run([sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr", "127.0.0.1", "--master-port",
+                         "29563", "-m", "llava_align_amd.sampling_driver", *common, "--answers-file", two], capture_output=True, text=True, env=_env(),
+                        timeout=900, cwd=ROOT)
+    assert p2.returncode == 0, p2.stderr[-3000:]
+    b = [json.loads(l) for l in open(two.replace("setting", "default"))]
+    assert [x["question_id"] for x in b] == [x["question_id"] for x in a] and all(set(x) == set(a[0]) for x in b)

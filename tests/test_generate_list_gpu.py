@@ -101,3 +101,35 @@ def test_retirement_carries_the_in_kernel_processors():
     assert "retire_events" not in a.stats and b.stats["retire_events"] >= 2 and b.stats["rows_at_end"] < 24
     assert int(_answer_lengths(a.tokens, eos).min()) >= 6                                       # the EOS floor held
     assert a.tokens.shape == b.tokens.shape and torch.equal(a.tokens, b.tokens)
+
+
+def test_run_sampling_is_shard_and_in_flight_invariant_for_deterministic_decodes():
+    """sampling_driver.run_sampling (the batched form of llava_sampling.py:57-126) with cd_greedy: the driver selects batch-invariant mode, so the
+    answers do not depend on how many questions are in flight - and equal ONE generate() call over the list."""
+    from llava_align_amd import ops
+    from llava_align_amd.sampling_driver import run_sampling
+    eng = _engine(W7B, n_layers=2, vit_layers=2)
+    ids, imgs = _prompts(14, 1, 32000, seed=33)
+    images = {f"im{i}.jpg": imgs[i] for i in range(14)}
+    by_text = {f"q{i}": ids[i].tolist() for i in range(14)}
+    qs = [{"question_id": 50 + i, "image": f"im{i}.jpg", "text": f"q{i}"} for i in range(14)]
+    enc = lambda prompt: by_text[prompt[prompt.index("<image>\n") + 8: prompt.rindex(" ASSISTANT:")]]
+    dec = lambda t: " ".join(map(str, t))
+    eos = _eos_set(1200, 9)
+    kw = dict(max_new_tokens=20, eos_token_id=eos, pad_token_id=0, stop_str=None, use_dd=True, use_dd_unk=True, cd_alpha=1.0, cd_beta=0.1, temperature=1.0,
+              top_p=0.9, cd_greedy=True)
+    a = run_sampling(eng, qs, enc, dec, lambda n: images[n], in_flight=4, **kw)
+    b = run_sampling(eng, qs, enc, dec, lambda n: images[n], in_flight=14, **kw)
+    assert a["batch_invariant"] and [x["text"] for x in a["answers"]] == [x["text"] for x in b["answers"]]
+    assert a["stats"]["admissions"] >= 3 and b["stats"]["admissions"] == 1
+    with ops.batch_invariant():
+        eng.retire = False
+        ref = eng.generate(ids, images=imgs, **{k: v for k, v in kw.items() if k != "stop_str"})
+    eos_s = set(eos)
+    for i, x in enumerate(a["answers"]):
+        want = []
+        for t in ref.tokens[i].tolist():
+            want.append(t)
+            if t in eos_s:
+                break
+        assert x["text"] == " ".join(map(str, want)), i
