@@ -406,6 +406,7 @@ def gemm_config(tile: int, sched: int = 0) -> int:
     return (tile & 15) | ((sched & 3) << 4) | ((tile >> 4) << 6)
 
 import os as _os
+_SMALL_TILE_ROWS = [int(v) for v in _os.environ.get("VDD_GEMM_SMALL_TILE_ROWS", "64,32").split(",")]     # probes: rows up to which the 64- / 32-row tiles are candidates
 _GEMM_EXCLUDE = {int(c) for c in _os.environ.get("VDD_GEMM_EXCLUDE", "").split(",") if c.strip()}      # probes: tile ids the tuner must not pick
 GEMM_BATCH_INVARIANT = False    # True = batch-invariant mode: a row's results no longer depend on which other rows share its batch, because
                                 # every op then has ONE form with one summation order per output element -
@@ -725,8 +726,8 @@ def _gemm_tune(x, w, out, bias, resid, M, N, K, epi, ws, iters=8):
     short = M <= 128
     chunks, reps = (int(min(6, max(1, 2.5e-3 / max(flops / 1.0e15, 30e-6) / iters))), 2) if short else (1, 1)
     for c, sch in GEMM_CANDIDATES:
-        if ((epi == EPI_SWIGLU and c in (5, 6, 7, 9, 13, 14, 16)) or (GEMM_BATCH_INVARIANT and sch != 1) or (c in (8, 9, 10, 11) and M > 256) or (c in (12, 13) and M > 64)
-                or (c in (14, 15) and M > 32) or (c == 16 and M > 576)):
+        if ((epi == EPI_SWIGLU and c in (5, 6, 7, 9, 13, 14, 16)) or (GEMM_BATCH_INVARIANT and sch != 1) or (c in (8, 9, 10, 11) and M > 256) or (c in (12, 13) and M > _SMALL_TILE_ROWS[0])
+                or (c in (14, 15) and M > _SMALL_TILE_ROWS[1]) or (c == 16 and M > 576)):
             continue
         if c in _GEMM_EXCLUDE:
             continue

@@ -9,7 +9,7 @@ if len(sys.argv) > 1 and sys.argv[1] == "--worker":
     from llava_align_amd.engine import VddLlavaEngine
     from bench import pope_prompts
     eng = VddLlavaEngine("llava-1.5-7b", device="cuda:0", use_graph=True)
-    for nq in (1, 2, 4, 6, 9, 12, 16, 24, 32, 48, 64):
+    for nq in ((17, 20, 24, 33, 40, 48, 64) if os.environ.get("VDD_GEMM_SMALL_TILE_ROWS", "64,32") != "64,32" or "again" in sys.argv[2] or sys.argv[2].startswith("tiles_to") else (1, 2, 4, 6, 9, 12, 16, 24, 32, 48, 64)):
         ids, imgs = pope_prompts((nq + 5) // 6, per_img=6, seed=5)
         ids, imgs = ids[:nq], imgs[:nq]
         kw = dict(images=imgs, use_dd_unk=True, cd_alpha=1.0, cd_beta=0.1, temperature=0.2, seed=3, max_new_tokens=48)
@@ -23,6 +23,9 @@ if len(sys.argv) > 1 and sys.argv[1] == "--worker":
         picks = {k: v & 15 for k, v in ops.gemm_choices_export().items() if not k.startswith("form") and k.split(",")[0] in ("-1", "1", "2")}
         print(json.dumps({"variant": sys.argv[2], "rows": 2 * nq, "ms_per_step": round(best, 3), "tile_of_small_buckets": picks}), flush=True)
 else:
-    for variant, excl in (("all_tiles", ""), ("no_32x128", "14,15"), ("no_small_tiles", "12,13,14,15")):
-        env = dict(os.environ, VDD_GEMM_DEFAULTS="off", VDD_GEMM_CHOICES="off", VDD_GEMM_EXCLUDE=excl)
+    variants = (("all_tiles", "", "64,32"), ("no_32x128", "14,15", "64,32"), ("no_small_tiles", "12,13,14,15", "64,32"))
+    if "--wide" in sys.argv:      # may the 64- / 32-row tiles also serve 65 - 128 / 33 - 64 rows (two row tiles per column panel)?
+        variants = (("tiles_to_64_32_rows", "", "64,32"), ("tiles_to_128_64_rows", "", "128,64"), ("tiles_to_64_32_rows_again", "", "64,32"))
+    for variant, excl, lim in variants:
+        env = dict(os.environ, VDD_GEMM_DEFAULTS="off", VDD_GEMM_CHOICES="off", VDD_GEMM_EXCLUDE=excl, VDD_GEMM_SMALL_TILE_ROWS=lim)
         subprocess.run([sys.executable, os.path.abspath(__file__), "--worker", variant], env=env, check=False)
