@@ -101,7 +101,23 @@ __global__ void __launch_bounds__(256) rmsnorm_kernel(const uint16_t* __restrict
             }
             if (slabs != nullptr) {      // delta = bf16(sum of the split-K fp32 partial slabs of the producing GEMM)
                 float dsum[8] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
-                for (int sl = 0; sl < n_slabs; ++sl) {
+                // the slabs are added in slab order (the bits of round 4), but their loads go out FOUR slabs at a time: one slab per iteration
+                // was one memory round trip per slab (S = 8 - 27: most of this launch's time at a few dozen rows)
+                int sl = 0;
+                for (; sl + 4 <= n_slabs; sl += 4) {
+                    float4 q0[4], q1[4];
+#pragma unroll
+                    for (int u = 0; u < 4; ++u) {
+                        q0[u] = *reinterpret_cast<const float4*>(slabs + (size_t)(sl + u) * slab_stride + off + e);
+                        q1[u] = *reinterpret_cast<const float4*>(slabs + (size_t)(sl + u) * slab_stride + off + e + 4);
+                    }
+#pragma unroll
+                    for (int u = 0; u < 4; ++u) {
+                        dsum[0] += q0[u].x; dsum[1] += q0[u].y; dsum[2] += q0[u].z; dsum[3] += q0[u].w;
+                        dsum[4] += q1[u].x; dsum[5] += q1[u].y; dsum[6] += q1[u].z; dsum[7] += q1[u].w;
+                    }
+                }
+                for (; sl < n_slabs; ++sl) {
                     const float4 p0 = *reinterpret_cast<const float4*>(slabs + (size_t)sl * slab_stride + off + e);
                     const float4 p1 = *reinterpret_cast<const float4*>(slabs + (size_t)sl * slab_stride + off + e + 4);
                     dsum[0] += p0.x; dsum[1] += p0.y; dsum[2] += p0.z; dsum[3] += p0.w;
