@@ -94,9 +94,20 @@ def pope_scores(gt: Sequence[dict], gen: Sequence[dict]) -> dict:
     return _prf(tp, tn, fp, fn, yes, unknown, len(gt))
 
 
+CALIBRATE_SOURCES = {"none_noise": ("noise", "none"), "none_unk": ("unk", "none"), "none_unk_noise": ("noise", "none", "unk"),
+                     "all": ("noise", "none", "zero", "unk")}          # eval_pope_calibrate.py:119-130: priors that are summed
+
+
+def calibrate_sources(name: str) -> tuple:
+    """The answer-file keys a calibration setting reads: 'naive' needs no prior, a plain name reads itself, the combined settings read the
+    priors they sum."""
+    return ("naive",) if name == "naive" else ("naive",) + CALIBRATE_SOURCES.get(name, (name,))
+
+
 def pope_scores_calibrated(gt: Sequence[dict], gen: Sequence[dict], name: str = "naive", mode: str = "diagonal_W") -> dict:
-    """'individual' calibration per question: p from gen['naive'], prior from gen[name] ('none', 'unk', or
-    'none_unk' = their sum); arg-max of the calibrated 2-vector is the answer (0 = yes)."""
+    """'individual' calibration per question (eval_pope_calibrate.py:115-139): p from gen['naive'], prior from gen[name] ('none', 'unk',
+    'noise', 'zero' / 'zeros', ...) or the sum of several ('none_unk', 'none_noise', 'none_unk_noise', 'all': CALIBRATE_SOURCES); arg-max of
+    the calibrated 2-vector is the answer (0 = yes)."""
     tp = tn = fp = fn = unknown = yes = total = nan_rows = 0
     confidence = 0.0
     for g, a in zip(gt, gen):
@@ -107,8 +118,10 @@ def pope_scores_calibrated(gt: Sequence[dict], gen: Sequence[dict], name: str = 
             p = p / np.sum(p)
         W, b = np.identity(2), np.zeros([2, 1])
         if name != "naive":
-            if name == "none_unk":
-                cf = np.array(get_prob_from_logits(a["unk"])) + np.array(get_prob_from_logits(a["none"]))
+            if name in CALIBRATE_SOURCES:
+                cf = np.array(get_prob_from_logits(a[CALIBRATE_SOURCES[name][0]]))
+                for src in CALIBRATE_SOURCES[name][1:]:
+                    cf = cf + np.array(get_prob_from_logits(a[src]))
             else:
                 cf = np.array(get_prob_from_logits(a[name]), dtype=np.float64)
             with np.errstate(invalid="ignore", divide="ignore"):
@@ -146,9 +159,12 @@ class AnswerWriter:
     def __init__(self, path: str):
         self.f = open(path, "w")
 
-    def write(self, question_id, prompt, text, model_id, image, logits_score, naive, unk=None, none=None, metadata=None):
+    def write(self, question_id, prompt, text, model_id, image, logits_score, naive, unk=None, none=None, metadata=None, extra=None):
+        """extra: further label dicts (image priors 'noise' / 'zeros' / 'ones', test_samples_llava.py:148-158), written before metadata."""
         rec = {"question_id": question_id, "prompt": prompt, "text": text, "model_id": model_id, "image": image,
-               "logits_score": logits_score, "naive": naive, "unk": unk, "none": none, "metadata": metadata or {}}
+               "logits_score": logits_score, "naive": naive, "unk": unk, "none": none}
+        rec.update(extra or {})
+        rec["metadata"] = metadata or {}
         self.f.write(json.dumps(rec) + "\n")
         self.f.flush()
 

@@ -110,6 +110,54 @@ def load_llava(model_path: str, device, dtype=torch.float16, vision_tower: Optio
     return eng, load_tokenizer(model_path), CLIPImageProcessor.from_pretrained(proc_dir)
 
 
+def qwen_embed_prompt(model, tokenize, device, keep_images: int = 16):
+    """The Qwen front-end the drivers call (mme_driver.qwen_mme_inputs, qwen_driver.run_qwen_pope): `embed_prompt(text, image)` -> [T, d] for
+    prompts without an <img> span (image = None), else ([T, d], n_shared) with n_shared = the rows up to and including </img>.  image: a path
+    string (the tower reads the file the prompt spells out, modeling_qwen.py:567-568) or a [3, S, S] tensor (`images=`, :565-566); the tower's
+    rows for the last `keep_images` distinct tensor OBJECTS are kept, so the six POPE questions about one image cost one ViT pass (the
+    reference: one per generate() call).  tokenize(text) -> ids."""
+    from .hf_adapter import qwen_spliced_embeddings
+    start = int(model.config.visual["image_start_id"])
+    kept: Dict[int, tuple] = {}                                   # id(tensor) -> (tensor, rows): holding the tensor keeps its id unique
+
+    @torch.no_grad()
+    def embed_prompt(text, image):
+        ids = torch.tensor([tokenize(text)], device=device)
+        feats = None
+        if torch.is_tensor(image):
+            hit = kept.get(id(image))
+            if hit is None:
+                if len(kept) >= keep_images:
+                    kept.pop(next(iter(kept)))
+                hit = kept[id(image)] = (image, model.transformer.visual(image[None].to(device)))
+            feats = hit[1]
+        e = qwen_spliced_embeddings(model, ids, None, feats=feats)[0]
+        if image is None:
+            return e
+        return e, int((ids[0] == start + 1).nonzero()[0]) + 1
+    return embed_prompt
+
+
+def load_qwen(model_path: str, device, dtype=torch.bfloat16, use_graph: bool = True):
+    """-> (engine, tokenizer, HF model, embed_prompt) of a Qwen-VL directory, as the reference's drivers load it
+    (`AutoTokenizer / QWenLMHeadModel.from_pretrained(model_path, trust_remote_code=True)`, MME/run_qwen.py:146-157, qwen_calibrate.py:75-86:
+    the caller's environment must provide what modeling_qwen.py imports).  The language model runs natively (hf_adapter.lm_weights_from_hf);
+    the ViT + resampler stay the model's own `transformer.visual` behind
+    `embed_prompt(text, image) -> [T, d]` or `([T, d], n_shared)`: image = None for prompts without an <img> span, a path string (the tower
+    reads the file the prompt spells out, modeling_qwen.py:567-568) or a [3, S, S] tensor (`images=`, :565-566); n_shared = the rows up to and
+    including </img>, which every prompt about the same image starts with."""
+    from transformers import AutoModelForCausalLM, AutoTokenizer
+    from .hf_adapter import lm_config_from_hf, lm_weights_from_hf, qwen_spliced_embeddings
+    tok = AutoTokenizer.from_pretrained(model_path, trust_remote_code=True)
+    tok.padding_side = "left"
+    tok.pad_token_id = tok.eod_id
+    model = AutoModelForCausalLM.from_pretrained(model_path, trust_remote_code=True, torch_dtype=dtype).to(device).eval()
+    cfg = lm_config_from_hf(model)
+    eng = VddLlavaEngine(cfg, weights=lm_weights_from_hf(model, cfg), device=device, use_graph=use_graph)
+    embed_prompt = qwen_embed_prompt(model, lambda text: tok(text).input_ids, device)
+    return eng, tok, model, embed_prompt
+
+
 def tokenizer_image_token(tok, prompt: str, image_token_index: int = -200):
     """experiments/llava/mm_utils.py tokenizer_image_token: split at '<image>', tokenise the chunks, join with -200, one BOS in front."""
     chunks = [tok(c).input_ids for c in prompt.split("<image>")]

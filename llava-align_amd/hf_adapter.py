@@ -449,11 +449,11 @@ def attach_blip_engine(model, use_graph: bool = True, max_questions: int = 64):
 
 
 # ------------------------------------------------------------------ Qwen-VL (experiments/Qwen_VL/modeling_qwen.py)
-def qwen_spliced_embeddings(model, input_ids: torch.Tensor, images: Optional[torch.Tensor]):
+def qwen_spliced_embeddings(model, input_ids: torch.Tensor, images: Optional[torch.Tensor], feats: Optional[torch.Tensor] = None):
     """What `QWenModel.forward` feeds its decoder for a prompt with image spans (modeling_qwen.py:545-575, 631-640, 688-693): token
     embeddings with the positions between every <img> (config.visual['image_start_id']) and </img> (+1) replaced by the rows the
     CALLER'S ViT + resampler (`model.transformer.visual`: out of scope here) returns for the image - from the
-    `images` tensor when given (:565-566), else from the path spelled out in the ids (`visual.encode`, :567-568).  -> list of [T, d]."""
+    `images` tensor when given (:565-566), else from the path spelled out in the ids (`visual.encode`, :567-568); `feats`: rows the caller already has from that tower (one [rows, d] per span).  -> list of [T, d]."""
     tr = model.transformer
     hidden = tr.wte(input_ids)
     start = int(model.config.visual["image_start_id"])
@@ -464,7 +464,9 @@ def qwen_spliced_embeddings(model, input_ids: torch.Tensor, images: Optional[tor
     if not bool((bos[0] == eos[0]).all()):
         raise ValueError("unbalanced <img> ... </img> spans")
     pos = torch.stack((bos[0], bos[1], eos[1]), dim=1).tolist()
-    if images is not None:
+    if feats is not None:
+        pass
+    elif images is not None:
         feats = tr.visual(images)
     else:
         paths = []

@@ -261,21 +261,7 @@ def main(argv=None):
         run_kw = dict(eos_token_id=tok.eos_token_id, pad_token_id=tok.pad_token_id or 0, stop_str="</s>", max_new_tokens=a.max_new_tokens or 128,
                       noise_step=a.noise_step if a.use_cd else None)
     else:
-        from transformers import AutoModelForCausalLM, AutoTokenizer
-        from .hf_adapter import lm_config_from_hf, lm_weights_from_hf, qwen_spliced_embeddings
-        tok = AutoTokenizer.from_pretrained(a.model_path, trust_remote_code=True)
-        model = AutoModelForCausalLM.from_pretrained(a.model_path, trust_remote_code=True, torch_dtype=dtype).to(device).eval()
-        cfg = lm_config_from_hf(model)
-        eng = VddLlavaEngine(cfg, weights=lm_weights_from_hf(model, cfg), device=device)
-        start = int(model.config.visual["image_start_id"])
-
-        def embed_prompt(text, path):                     # run_qwen.py:176-186: tokenizer([prompt], padding='longest') -> ids; the ViT reads the path
-            ids = torch.tensor([tok(text).input_ids], device=device)
-            e = qwen_spliced_embeddings(model, ids, None)[0]
-            if path is None:
-                return e
-            n = int((ids[0] == start + 1).nonzero()[0]) + 1          # '<img>' ... '</img>': the rows both questions about the image share
-            return e, n
+        eng, tok, _model, embed_prompt = K.load_qwen(a.model_path, device, dtype=dtype)      # run_qwen.py:176-186: the ViT reads the path in the prompt
         build = qwen_mme_inputs(embed_prompt, lambda f: os.path.join(a.image_folder, f))
         decode = lambda ids: tok.decode(ids, skip_special_tokens=True)
         run_kw = dict(eos_token_id=tok.eod_id, pad_token_id=tok.eod_id, max_new_tokens=a.max_new_tokens or 20, min_new_tokens=1)      # run_qwen.py:194-197

@@ -88,7 +88,8 @@ def run_pope(engine: VddLlavaEngine, questions: Sequence[dict], encode: Callable
              decode: Callable[[List[int]], str], load_image: Callable[[str], torch.Tensor], answers_path: Optional[str] = None,
              model_id: str = "llava-align_amd", batch_questions: int = 384, unk_token_id: int = 0, eos_token_id=None,
              pad_token_id: Optional[int] = None, stop_str: Optional[str] = "</s>", max_new_tokens: int = 64, noise_step: Optional[int] = None,
-             rank: Optional[int] = None, world: Optional[int] = None, batch_invariant: Optional[bool] = None, **generate_kw) -> dict:
+             rank: Optional[int] = None, world: Optional[int] = None, batch_invariant: Optional[bool] = None,
+             image_priors: Sequence[str] = (), **generate_kw) -> dict:
     """questions: dicts with question_id, image, text, label (the POPE json lines).  generate_kw: cd_alpha, cd_beta, use_dd,
     use_dd_unk, temperature, top_p, top_k, seed ... exactly the reference's model.generate kwargs (llava_calibrate.py:161-177);
     noise_step adds the VCD branch (images_cd = add_diffusion_noise(image, noise_step), :152-155).
@@ -101,8 +102,14 @@ def run_pope(engine: VddLlavaEngine, questions: Sequence[dict], encode: Callable
     batch-invariant mode unless `batch_invariant=False` (shard.resolve_batch_invariant, ops.GEMM_BATCH_INVARIANT): their answers are
     then token for token the same on 1 and on N ranks and for every batch_questions; with the tuned kernel forms (the default for
     sampled runs) a row's low-order bits depend on who shares its batch.
+    image_priors: further content-free passes that keep the image prompt and swap the IMAGE - 'noise' = add_diffusion_noise(image, 999),
+    'zeros', 'ones' (llava_calibrate.py:188-190 prepares them, experiments/eval/calibrate/test_samples_llava.py:134-145 runs them: plain
+    sampling, step-0 label dict) - written under those keys and scored like the text priors.
     Returns {"answers": [...], "scores": {"string_match": ..., "naive": ..., "none": ..., "unk": ..., "none_unk": ...}}."""
     import contextlib
+    image_priors = tuple(image_priors)
+    if any(n_ not in ("noise", "zeros", "ones") for n_ in image_priors):
+        raise ValueError("image_priors must be among 'noise', 'zeros', 'ones'")
     from . import ops
     from .shard import ShardPlan, resolve_batch_invariant
     order = sorted(range(len(questions)), key=lambda i: (questions[i]["image"], i))      # one image's questions adjacent
@@ -111,7 +118,7 @@ def run_pope(engine: VddLlavaEngine, questions: Sequence[dict], encode: Callable
     decode_token = lambda t: decode([t])
     if generate_kw.get("seed") is not None:
         generate_kw = dict(generate_kw, seed=int(generate_kw["seed"]) + plan.rank)
-    rows = ResultRows(engine.device, max_new_tokens, pad_token_id if pad_token_id is not None else 0, n_sets=3)
+    rows = ResultRows(engine.device, max_new_tokens, pad_token_id if pad_token_id is not None else 0, n_sets=3 + len(image_priors))
     img_cache: Dict[str, torch.Tensor] = {}
     invariant = resolve_batch_invariant(batch_invariant, plan.world, generate_kw)
     with (ops.batch_invariant() if invariant else contextlib.nullcontext()):
@@ -137,14 +144,24 @@ def run_pope(engine: VddLlavaEngine, questions: Sequence[dict], encode: Callable
             # (one call for both priors: 2 x len(qs) text-only prompts that share the conversation template's system prompt as a prefix slot)
             prior = engine.generate(ids_none + ids_unk, images=None, max_new_tokens=1, n_top=10, **plain_kw)
             n = len(qs)
-            rows.add(idx, main.tokens, [(main.top_tok, main.top_prob), (prior.top_tok[:n], prior.top_prob[:n]), (prior.top_tok[n:], prior.top_prob[n:])])
+            tops = [(main.top_tok, main.top_prob), (prior.top_tok[:n], prior.top_prob[:n]), (prior.top_tok[n:], prior.top_prob[n:])]
+            for name in image_priors:
+                if name == "noise":                                  # fresh noise per question, as the reference draws it inside its loop
+                    from .vcd_add_noise import add_diffusion_noise
+                    swapped = [add_diffusion_noise(im, 999) for im in imgs]
+                else:                                                # ONE tensor object: every question shares its features and prompt prefix
+                    const = (torch.zeros_like if name == "zeros" else torch.ones_like)(imgs[0])
+                    swapped = [const] * n
+                o = engine.generate(ids_main, images=swapped, max_new_tokens=1, n_top=10, **plain_kw)
+                tops.append((o.top_tok, o.top_prob))
+            rows.add(idx, main.tokens, tops)
             ahead = {questions[i]["image"] for i in mine[b0 + batch_questions:b0 + 2 * batch_questions]}
             for k in [k for k in img_cache if k not in ahead]:
                 img_cache.pop(k)                                   # images are revisited only within a sorted neighbourhood
             engine.clear_image_cache()
     got = rows.gather(plan, len(questions))                    # ONE collective; every rank holds every question's results behind it
     eos_set = set([eos_token_id] if isinstance(eos_token_id, int) else (eos_token_id or []))
-    dicts = [[C.label_dict_from_top(t, p_, decode_token) for t, p_ in got["tops"][s_]] for s_ in range(3)]
+    dicts = [[C.label_dict_from_top(t, p_, decode_token) for t, p_ in got["tops"][s_]] for s_ in range(3 + len(image_priors))]
     ordered = []
     for i, q in enumerate(questions):
         text = decode(cut_at_eos(got["tokens"][i], eos_set)).strip()
@@ -152,16 +169,17 @@ def run_pope(engine: VddLlavaEngine, questions: Sequence[dict], encode: Callable
             text = text[:-len(stop_str)]
         ordered.append({"question_id": q["question_id"], "prompt": q["text"], "text": text.strip(), "model_id": model_id,
                         "image": q["image"], "logits_score": C.get_prob_from_logits(dicts[0][i]), "naive": dicts[0][i],
-                        "unk": dicts[2][i], "none": dicts[1][i], "metadata": {}})
+                        "unk": dicts[2][i], "none": dicts[1][i], **{n_: dicts[3 + k][i] for k, n_ in enumerate(image_priors)}, "metadata": {}})
     if answers_path is not None and plan.rank == 0:
         with C.AnswerWriter(answers_path) as w:
             for a in ordered:
-                w.write(a["question_id"], a["prompt"], a["text"], a["model_id"], a["image"], a["logits_score"], a["naive"], a["unk"], a["none"])
+                w.write(a["question_id"], a["prompt"], a["text"], a["model_id"], a["image"], a["logits_score"], a["naive"], a["unk"], a["none"],
+                        extra={n_: a[n_] for n_ in image_priors})
     scores = {}
     if all("label" in q for q in questions):
         gt = [{"question_id": q["question_id"], "label": q["label"]} for q in questions]
         scores["string_match"] = _try(C.pope_scores, gt, ordered)
-        for name in ("naive", "none", "unk", "none_unk"):
+        for name in ("naive", "none", "unk", "none_unk") + image_priors:
             scores[name] = _try(C.pope_scores_calibrated, gt, ordered, name)
     return {"answers": ordered, "scores": scores, "rank": plan.rank, "world": plan.world, "batch_invariant": invariant}
 
@@ -202,6 +220,8 @@ def main(argv=None):
     ap.add_argument("--cd_alpha", type=float, default=1.0)
     ap.add_argument("--cd_beta", type=float, default=0.1)
     ap.add_argument("--batch", type=int, default=384)
+    ap.add_argument("--image-priors", nargs="*", default=[], choices=("noise", "zeros", "ones"),
+                    help="further content-free passes with the image swapped (test_samples_llava.py:134-145)")
     ap.add_argument("--dtype", choices=("float16", "bfloat16"), default="float16", help="model dtype (the reference loads fp16, builder.py:40)")
     a = ap.parse_args(argv)
     from .checkpoint import clip_preprocess, load_llava, tokenizer_image_token
@@ -219,7 +239,7 @@ def main(argv=None):
                    unk_token_id=tok.unk_token_id if tok.unk_token_id is not None else 0, eos_token_id=tok.eos_token_id,
                    pad_token_id=tok.pad_token_id or 0, max_new_tokens=a.max_new_tokens, noise_step=a.noise_step, use_dd=a.use_dd,
                    use_dd_unk=a.use_dd_unk, cd_alpha=a.cd_alpha, cd_beta=a.cd_beta, temperature=a.temperature, top_p=a.top_p, top_k=a.top_k,
-                   rank=rank, world=world, **extra)
+                   rank=rank, world=world, image_priors=tuple(a.image_priors), **extra)
     if rank == 0:
         nan = {k: v["nan_rows"] for k, v in res["scores"].items() if isinstance(v, dict) and v.get("nan_rows")}
         print(json.dumps({"scores": res["scores"], "batch_invariant": res["batch_invariant"], "world": world,

@@ -349,6 +349,52 @@ def gen_scorers():
     print("scorers:", out["eval_pope"], list(out["eval_pope_calibrate"]))
 
 
+def gen_scorers_all():
+    """eval_pope_calibrate.py over answer files that carry all five label dicts (naive, noise, none, zero, unk: what qwen_calibrate.py
+    writes) with the setting list of its line 82 - the one the script keeps as a comment, ['naive', 'noise', 'none', 'zero', 'unk',
+    'none_noise', 'none_unk', 'none_unk_noise', 'all'] - in place of line 83's four.  The script is read, that ONE line is swapped in
+    memory, and the result runs from a scratch directory (PYTHONPATH = the reference's experiments/ for its utils.metrics import)."""
+    import re
+    import subprocess
+    import tempfile
+    from ref_shim import REF_ROOT
+    rng = np.random.default_rng(29)
+    n = 80
+    gt, gen = [], []
+    for i in range(n):
+        lab = "yes" if rng.random() < 0.5 else "no"
+        def td():
+            py = float(rng.random()); pn = float(rng.random())
+            d = {"Yes" if rng.random() < 0.5 else "yes": py, "no": pn, "maybe": 0.01}
+            if rng.random() < 0.15:
+                d.pop("no")
+            return d
+        gt.append({"question_id": i, "label": lab, "text": "q", "image": "x.jpg"})
+        gen.append({"question_id": i, "text": "yes", "naive": td(), "noise": td(), "none": td(), "zero": td(), "unk": td()})
+    out = {"gt": gt, "gen": gen}
+    src = open(os.path.join(REF_ROOT, "experiments/eval/eval_pope_calibrate.py")).read()
+    four = "    for name in ['naive', 'none', 'unk', 'none_unk']:"
+    assert src.count(four) == 1
+    names = ["naive", "noise", "none", "zero", "unk", "none_noise", "none_unk", "none_unk_noise", "all"]
+    src = src.replace(four, "    for name in %r:" % names)
+    with tempfile.TemporaryDirectory() as d:
+        open(os.path.join(d, "scorer_all_settings.py"), "w").write(src)
+        for split in ("random", "popular", "adversarial"):
+            os.makedirs(os.path.join(d, "experiments/data/POPE/gqa"), exist_ok=True)
+            os.makedirs(os.path.join(d, "experiments/output/llava-13B"), exist_ok=True)
+            open(os.path.join(d, f"experiments/data/POPE/gqa/gqa_pope_{split}.json"), "w").write("\n".join(json.dumps(x) for x in gt))
+            open(os.path.join(d, f"experiments/output/llava-13B/llava_gqa_pope_{split}_seed55_both.jsonl"), "w").write("\n".join(json.dumps(x) for x in gen))
+        r = subprocess.run([sys.executable, os.path.join(d, "scorer_all_settings.py")], cwd=d, capture_output=True, text=True, check=True,
+                           env={**os.environ, "PYTHONDONTWRITEBYTECODE": "1", "PYTHONPATH": os.path.join(REF_ROOT, "experiments")})
+        blocks = re.findall(r"Evaluate the performance in (\w+) setting\nF1: ([0-9.]+) Accuracy: ([0-9.]+) Precision: ([0-9.]+) \t Recall: ([0-9.]+) \t yes: ([0-9.]+) unknow: ([0-9.]+) number questions (\d+) confidence ([0-9.eE+-]+)", r.stdout)
+        out["eval_pope_calibrate"] = {b[0]: {"f1": float(b[1]), "accuracy": float(b[2]), "precision": float(b[3]), "recall": float(b[4]),
+                                             "yes": float(b[5]), "n": int(b[7]), "confidence": float(b[8])} for b in blocks[:len(names)]}
+        assert list(out["eval_pope_calibrate"]) == names
+    with open(os.path.join(HERE, "scorers_all.json"), "w") as f:
+        json.dump(out, f)
+    print("scorers_all:", {k: v["accuracy"] for k, v in out["eval_pope_calibrate"].items()})
+
+
 def gen_mme_convert():
     """Runs the reference's MME converter SCRIPT (experiments/eval/MME/convert_answer_to_mme_calibrate.py) unmodified on a synthetic
     benchmark tree + answers file and records what it writes.  The script hard-codes an absolute ground-truth path
@@ -500,6 +546,7 @@ if __name__ == "__main__":
     gen_noise()
     gen_calibration()
     gen_scorers()
+    gen_scorers_all()
     gen_processors()
     gen_mme_convert()
     gen_kernel_vectors_gpu_scalar()

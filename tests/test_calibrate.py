@@ -58,6 +58,20 @@ def test_pope_scorers_match_reference_scripts():
         assert got["confidence"] == pytest.approx(want["confidence"], rel=1e-12)
 
 
+def test_every_calibration_setting_of_the_reference_script():
+    """The script's full setting list (its line 82: the priors qwen_calibrate.py writes - noise, none, zero, unk - and their sums)."""
+    g = load_json("scorers_all.json")
+    assert list(g["eval_pope_calibrate"]) == ["naive", "noise", "none", "zero", "unk", "none_noise", "none_unk", "none_unk_noise", "all"]
+    for name, want in g["eval_pope_calibrate"].items():
+        got = C.pope_scores_calibrated(g["gt"], g["gen"], name)
+        assert got["n"] == want["n"]
+        for k in ("f1", "accuracy", "precision", "recall", "yes"):
+            assert float(f"{got[k] * 100:.4}") == want[k], (name, k)
+        assert got["confidence"] == pytest.approx(want["confidence"], rel=1e-12)
+    assert C.calibrate_sources("naive") == ("naive",) and C.calibrate_sources("zero") == ("naive", "zero")
+    assert C.calibrate_sources("all") == ("naive", "noise", "none", "zero", "unk")
+
+
 def test_answer_writer_schema(tmp_path):
     p = tmp_path / "a.jsonl"
     with C.AnswerWriter(str(p)) as w:

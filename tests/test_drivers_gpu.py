@@ -135,6 +135,72 @@ def test_run_mme_qwen_call_shape_dual_pass_and_calibrate():
     assert (s_dd[keep] - s_pl[keep]).abs().max() <= 0.3               # (1+a) v - a c with c ~ v  ->  v
 
 
+def test_run_qwen_pope_five_passes_against_direct_calls(tmp_path):
+    """qwen_calibrate.py:90-168 on a QWenLMHeadModel-shaped object (its `transformer.visual` fills the <img> span): main pass with
+    use_dd_unk + four content-free priors; the answers file's fields; the deterministic priors (none / unk / zero) recomputed one question
+    at a time; image spans shared between the questions about one image; the answers-only call shape of qwenvl_sampling.py."""
+    import hf_doubles
+    from llava_align_amd import calibrate as C
+    from llava_align_amd.checkpoint import qwen_embed_prompt
+    from llava_align_amd.engine import VddLlavaEngine
+    from llava_align_amd.hf_adapter import lm_config_from_hf, lm_weights_from_hf
+    from llava_align_amd.qwen_driver import CALIBRATE_NAMES, SAMPLING_PROMPT, run_qwen_pope
+    model = hf_doubles.build_qwen(DEV, torch.bfloat16)
+    cfg = lm_config_from_hf(model)
+    eng = VddLlavaEngine(cfg, weights=lm_weights_from_hf(model, cfg), device=DEV)
+    V, eod, st = model.config.vocab_size, model.generation_config.eos_token_id, model.config.visual["image_start_id"]
+    visual_calls = []
+    model.transformer.visual.register_forward_hook(lambda m, a, o: visual_calls.append(a[0].shape[0]))
+
+    def tokenize(text):                                   # '<img>path</img>' -> <img> + img_rows slots + </img>, as the Qwen tokenizer expands it
+        out = []
+        for i, part in enumerate(text.replace("</img>", "<img>").split("<img>")):
+            out += [st] + [st + 2] * model.img_rows + [st + 1] if i % 2 else hf_doubles.word_ids(part, V - 40)
+        return out
+    embed = qwen_embed_prompt(model, tokenize, DEV)
+    images = {f"im{i}.jpg": torch.randn(3, 16, 16, generator=torch.Generator().manual_seed(40 + i)) for i in range(3)}
+    qs = [{"question_id": i, "image": f"im{i // 3}.jpg", "text": f"Is there a thing{i} in the image?", "label": ("yes", "no")[i % 2]} for i in range(9)]
+    torch.manual_seed(3)
+    kw = dict(eos_token_id=eod, pad_token_id=eod, max_new_tokens=4, temperature=0.5, cd_alpha=1.0, cd_beta=0.1)
+    res = run_qwen_pope(eng, qs, embed, decode, lambda n: images[n], image_path=lambda f: "/imgs/" + f, answers_path=str(tmp_path / "q" / "qwen.jsonl"),
+                        batch_questions=6, use_dd_unk=True, cd_greedy=True, **kw)
+    lines = [json.loads(l) for l in open(tmp_path / "q" / "qwen.jsonl")]
+    assert [l["question_id"] for l in lines] == list(range(9))
+    assert list(lines[0]) == ["question_id", "prompt", "text", "naive", "noise", "none", "zero", "unk", "model_id", "image", "metadata"]     # :155-166
+    assert lines[4]["prompt"] == "<img>/imgs/im1.jpg</img>Is there a thing4 in the image? Answer:" and lines[0]["model_id"] == "qwen-vl"
+    assert set(res["scores"]) == {"string_match"} | set(CALIBRATE_NAMES) and res["batch_invariant"]
+    # the tower ran once per clean image, once per question for the fresh noise of the `noise` prior, once per batch for the zero image
+    assert sorted(visual_calls) == [1] * (3 + 9 + 2)
+
+    def step0(text, image):
+        e = embed(text, image)
+        o = eng.generate(None, inputs_embeds=[e[0] if isinstance(e, tuple) else e], max_new_tokens=1, min_new_tokens=1, n_top=10, eos_token_id=eod,
+                         pad_token_id=eod, temperature=0.5)
+        return C.label_dict_from_top(o.top_tok[0].tolist(), o.top_prob[0].tolist(), decode_token)
+    zero = torch.zeros(3, 16, 16)
+    for q, a in zip(qs, lines):
+        want = {"none": step0("{} Answer:".format(q["text"]), None), "unk": step0("None {} Answer:".format(q["text"]), None),
+                "zero": step0(a["prompt"], zero)}
+        for name, w in want.items():
+            pg, pw = np.array(C.get_prob_from_logits(a[name])), np.array(C.get_prob_from_logits(w))
+            assert np.abs(pg - pw).max() <= 0.02 + 0.05 * pw.max(), (q["question_id"], name, pg, pw)
+        assert a["noise"] != a["zero"] and len(a["naive"]) >= 1
+    # main pass == the engine called directly on the same embeddings (cd_greedy: deterministic), incl. the EOS floor of min_new_tokens = 1
+    emb = [embed(l["prompt"], images[q["image"]])[0] for q, l in zip(qs, lines)]
+    from llava_align_amd import ops
+    with ops.batch_invariant():
+        direct = eng.generate(None, inputs_embeds=emb, use_dd_unk=True, cd_greedy=True, min_new_tokens=1, **kw)
+    from llava_align_amd.pope_driver import cut_at_eos
+    assert [l["text"] for l in lines] == [decode(cut_at_eos(t, {eod})).strip() for t in direct.tokens.tolist()]
+    # VCD: images_cd = the tower's rows for a noised copy, per question; answers-only shape (no priors, no label dicts in the file)
+    n0 = len(visual_calls)
+    s = run_qwen_pope(eng, qs[:3], embed, decode, lambda n: images[n], answers_path=str(tmp_path / "q" / "s.jsonl"), priors=(), prompt_format=SAMPLING_PROMPT,
+                      use_cd=True, noise_step=500, seed=5, **kw)
+    assert len(visual_calls) - n0 == 1 + 3 and s["scores"].keys() == {"string_match"} and not s["batch_invariant"]
+    first = json.loads(open(tmp_path / "q" / "s.jsonl").readline())
+    assert list(first) == ["question_id", "prompt", "text", "model_id", "image", "metadata"] and first["prompt"].startswith("Question: <img>im0.jpg</img> Is")
+
+
 def test_run_blip_pope_vcd_against_direct_front_end_and_engine_calls(tmp_path):
     from llava_align_amd import calibrate as C
     from llava_align_amd.blip_driver import QUESTION_SUFFIX, map_pad_to_eos, run_blip_pope

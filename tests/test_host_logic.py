@@ -153,6 +153,57 @@ def test_driver_prompt_builders_follow_the_reference_format_strings():
     assert map_pad_to_eos(torch.tensor([[5, 0, 0], [0, 7, 2]])).tolist() == [[5, 2, 2], [2, 7, 2]]
 
 
+def test_qwen_pope_driver_passes_prompts_and_kwargs_like_the_reference(monkeypatch):
+    """qwen_driver.run_qwen_pope against a recording engine (host logic only): the five passes' prompt strings (qwen_calibrate.py:36-41, :97),
+    which image each pass hands the front-end, the generate kwargs of the main pass vs the plain prior passes (:43-65, :113-136), image-span
+    sharing keys, the file's fields."""
+    import json
+    import types
+    import torch
+    from llava_align_amd import vcd_add_noise
+    from llava_align_amd.qwen_driver import PRIORS, run_qwen_pope
+    calls, fronts = [], []
+    monkeypatch.setattr(vcd_add_noise, "add_diffusion_noise", lambda im, t: im + torch.randn_like(im) * (1 + t))     # (the product's is a GPU kernel)
+
+    class Engine:
+        device = torch.device("cpu")
+
+        def clear_image_cache(self):
+            pass
+
+        def generate(self, ids, inputs_embeds=None, **kw):
+            calls.append(dict(kw, n=len(inputs_embeds)))
+            n, T = len(inputs_embeds), kw["max_new_tokens"]
+            return types.SimpleNamespace(tokens=torch.full((n, T), 5), top_tok=torch.arange(10).repeat(n, 1), top_prob=torch.full((n, 10), 0.1))
+
+    def embed_prompt(text, image):
+        fronts.append((text, None if image is None else ("zero" if not bool(image.any()) else round(float(image.std()), 1))))
+        e = torch.zeros(6, 4)
+        return e if image is None else (e, 4)
+    imgs = {"a.jpg": torch.ones(3, 4, 4) * torch.arange(4.0), "b.jpg": torch.ones(3, 4, 4) * torch.arange(4.0) * 3}
+    qs = [{"question_id": i, "image": "ab"[i // 2] + ".jpg", "text": f"Is it {i}?", "label": "yes"} for i in range(4)]
+    torch.manual_seed(0)
+    out = run_qwen_pope(Engine(), qs, embed_prompt, lambda ids: " ".join(map(str, ids)), lambda n: imgs[n], image_path=lambda f: "/d/" + f,
+                        use_cd=True, noise_step=500, use_dd=True, cd_alpha=1.0, cd_beta=0.1, temperature=0.2, top_k=None, seed=7)
+    assert [c["n"] for c in calls] == [4] * 5 and len(fronts) == 4 * 6
+    main, none, unk, noise, zero = calls
+    assert main["max_new_tokens"] == 20 and main["min_new_tokens"] == 1 and main["eos_token_id"] == main["pad_token_id"] == 151643
+    assert main["use_dd"] and len(main["images_cd"]) == 4 and main["n_top"] == 10 and main["seed"] == 7
+    assert [k[0] for k, _ in main["embeds_prefix"]] == ["clean"] * 4 and main["embeds_prefix"][0] == main["embeds_prefix"][1] != main["embeds_prefix"][2]
+    for c in (none, unk, noise, zero):                           # plain sampling: no VDD / VCD kwargs, one token, EOS floor as in the main call
+        assert "use_dd" not in c and "images_cd" not in c and c["max_new_tokens"] == 1 and c["min_new_tokens"] == 1 and c["temperature"] == 0.2
+    assert "embeds_prefix" not in none and "embeds_prefix" not in noise and len({k for k, _ in zero["embeds_prefix"]}) == 1
+    cd, mn, nn_, un, ns, zr = (fronts[i * 4:(i + 1) * 4] for i in range(6))
+    assert mn[1] == ("<img>/d/a.jpg</img>Is it 1? Answer:", 1.1) and mn[2][1] == 3.4
+    assert nn_[3] == ("Is it 3? Answer:", None) and un[0] == ("None Is it 0? Answer:", None)
+    assert [t for t, _ in ns] == [t for t, _ in mn] == [t for t, _ in zr] == [t for t, _ in cd] and all(v == "zero" for _, v in zr)
+    assert all(v not in (1.1, 3.4, "zero") for _, v in ns + cd)                            # noised copies, drawn per question
+    assert PRIORS == ("none", "unk", "noise", "zero")
+    a = out["answers"][2]
+    assert list(a) == ["question_id", "prompt", "text", "naive", "noise", "none", "zero", "unk", "model_id", "image", "metadata"]
+    assert a["prompt"] == "<img>/d/b.jpg</img>Is it 2? Answer:" and a["text"] == " ".join(["5"] * 20) and out["world"] == 1
+
+
 def test_norm_fused_row_limit_follows_the_lds_budget():
     """ops.norm_fused_rows: rows whose normalised copy (2 d bytes each) fits the 142 KiB the normalise-once projections may use; widths the
     kernel's chunk map does not cover (d % 256, d > 8192) take the unfused layer."""

@@ -72,3 +72,37 @@ def test_run_pope_matches_the_per_question_reference_procedure(tmp_path):
             checked += 1
         assert a["logits_score"] == C.get_prob_from_logits(a["naive"])
     assert checked >= 3
+
+
+def test_image_priors_swap_the_image_and_keep_the_prompt(tmp_path):
+    """test_samples_llava.py:134-158 / llava_calibrate.py:188-190: content-free passes with the image prompt and a noised / zero / all-ones
+    image, plain sampling, step-0 label dict - 'zeros' and 'ones' against the oracle loop over the fp32 reference model."""
+    from llava_align_amd import calibrate as C
+    from llava_align_amd.engine import LlavaWeights, VddLlavaEngine, preset
+    from llava_align_amd.pope_driver import run_pope
+    cfg = preset("tiny")
+    eng = VddLlavaEngine(cfg, weights=LlavaWeights.random(cfg, DEV, seed=3, std=0.06), device=DEV, use_graph=False)
+    ref = RefLlava(eng.w, device=DEV)
+    images = {f"img{i}.jpg": torch.randn(3, 56, 56, generator=torch.Generator().manual_seed(40 + i)) for i in range(2)}
+    questions = [{"question_id": i, "image": f"img{i % 2}.jpg", "text": f"q{i}", "label": ("yes", "no")[i % 2]} for i in range(6)]
+    path = tmp_path / "answers.jsonl"
+    torch.manual_seed(5)
+    res = run_pope(eng, questions, encode, decode, lambda name: images[name], answers_path=str(path), batch_questions=4, unk_token_id=0,
+                   max_new_tokens=3, use_dd_unk=True, cd_alpha=1.0, cd_beta=0.1, temperature=0.5, cd_greedy=True,
+                   image_priors=("noise", "zeros", "ones"))
+    lines = [json.loads(l) for l in open(path)]
+    assert list(lines[0]) == list(C.AnswerWriter.FIELDS[:-1]) + ["noise", "zeros", "ones", "metadata"]
+    assert set(res["scores"]) == {"string_match", "naive", "none", "unk", "none_unk", "noise", "zeros", "ones"}
+    for q, a in zip(questions, lines):
+        ids = encode(q["text"], True)
+        for name, img in (("zeros", torch.zeros(3, 56, 56)), ("ones", torch.ones(3, 56, 56))):
+            r = O.reference_loop(ref, torch.tensor([ids]), warp=O.WarpConfig(temperature=0.5), max_length=len(ids) + 1, pad_token_id=None,
+                                 eos_token_id=None, pick=O.pick_argmax, images=img[None], attention_mask=torch.ones(1, len(ids), dtype=torch.long),
+                                 use_cache=True, cd_alpha=1.0, cd_beta=0.1)
+            tp, tt = torch.topk(torch.softmax(r.scores[0][0].float(), -1), 10)
+            want = C.label_dict_from_top(tt.tolist(), tp.tolist(), decode_token)
+            pg, pw = np.array(C.get_prob_from_logits(a[name])), np.array(C.get_prob_from_logits(want))
+            assert np.abs(pg - pw).max() <= 0.05 + 0.15 * pw.max(), (q["question_id"], name, pg, pw)
+        assert a["noise"] != a["zeros"] and a["zeros"] != a["naive"]
+    with pytest.raises(ValueError, match="image_priors"):
+        run_pope(eng, questions, encode, decode, lambda name: images[name], image_priors=("white",))
