@@ -131,6 +131,11 @@ def main(argv=None):
     ap.add_argument("--max_new_tokens", type=int, default=1024)
     ap.add_argument("--in-flight", type=int, default=90)
     ap.add_argument("--no-sweep", action="store_true")
+    ap.add_argument("--naive", action="store_true", help="experiments/eval/llava_naive.py:39-98: ONE run at --temperature / --top_p / --top_k (greedy at "
+                    "temperature 0), always with the one-word suffix, into --answers-file as given")
+    ap.add_argument("--temperature", type=float, default=1.0)
+    ap.add_argument("--top_p", type=float, default=None)
+    ap.add_argument("--top_k", type=int, default=None)
     ap.add_argument("--preset", default="llava-1.5-7b")
     ap.add_argument("--vision-tower", default=None)
     ap.add_argument("--dtype", choices=("float16", "bfloat16"), default="float16")
@@ -143,20 +148,24 @@ def main(argv=None):
     if a.num_chunks > 1:
         questions = [questions[i] for i in get_chunk(len(questions), a.num_chunks, a.chunk_idx, group=1)]
     runs = [("default", 1.0, None, None)]
-    if not (a.no_sweep or a.use_cd):                                    # llava_sampling.py:162-195
+    if a.naive:
+        runs = [(None, a.temperature, a.top_p, a.top_k)]
+    elif not (a.no_sweep or a.use_cd):                                    # llava_sampling.py:162-195
         runs += [(f"temp_{t}", float(t), None, None) for t in np.round(np.arange(0.05, 1.05, 0.05), 2)]
         runs += [(f"top_p_{p_}", 1.0, float(p_), None) for p_ in np.arange(0, 1.05, 0.05)]
         runs += [(f"top_k_{k}", 1.0, None, k) for k in (1, 2, 5, 10, 20, 50, 100, 200, 500)]
     for tag, temp, top_p, top_k in runs:
-        path = os.path.expanduser(a.answers_file).replace("setting", tag)
+        path = os.path.expanduser(a.answers_file)
+        path = path.replace("setting", tag) if tag else path
+        greedy = dict(do_sample=False) if (a.naive and temp <= 0) else {}
         res = run_sampling(eng, questions, lambda p: K.tokenizer_image_token(tok, p), lambda ids: tok.decode(ids, skip_special_tokens=True),
                            lambda name: K.clip_preprocess(proc, os.path.join(a.image_folder, name)), answers_path=path,
-                           model_id=os.path.basename(a.model_path.rstrip("/")), pope_suffix="POPE" in a.question_file, in_flight=a.in_flight,
+                           model_id=os.path.basename(a.model_path.rstrip("/")), pope_suffix=a.naive or "POPE" in a.question_file, in_flight=a.in_flight,
                            max_new_tokens=a.max_new_tokens, eos_token_id=tok.eos_token_id, pad_token_id=tok.pad_token_id or 0,
                            noise_step=a.noise_step if a.use_cd else None, rank=rank, world=world, use_dd=a.use_dd, use_dd_unk=a.use_dd_unk,
-                           cd_alpha=a.cd_alpha, cd_beta=a.cd_beta, temperature=temp, top_p=top_p, top_k=top_k, seed=a.seed)
+                           cd_alpha=a.cd_alpha, cd_beta=a.cd_beta, temperature=temp if temp > 0 else 1.0, top_p=top_p, top_k=top_k, seed=a.seed, **greedy)
         if rank == 0:
-            print(json.dumps({"run": tag, "answers_file": path, "n_answers": len(res["answers"]), "stats": {k: v for k, v in res["stats"].items() if not hasattr(v, "__len__") or isinstance(v, str)}}), flush=True)
+            print(json.dumps({"run": tag or "naive", "answers_file": path, "n_answers": len(res["answers"]), "stats": {k: v for k, v in res["stats"].items() if not hasattr(v, "__len__") or isinstance(v, str)}}), flush=True)
     if world > 1:
         import torch.distributed as dist
         dist.barrier()

@@ -181,3 +181,11 @@ def test_sampling_driver_from_a_checkpoint_directory_alone_and_under_torchrun(tm
     assert p2.returncode == 0, p2.stderr[-3000:]
     b = [json.loads(l) for l in open(two.replace("setting", "default"))]
     assert [x["question_id"] for x in b] == [x["question_id"] for x in a] and all(set(x) == set(a[0]) for x in b)
+    # llava_naive.py's call shape: ONE run, the file name as given, greedy at --temperature 0 (plain arg-max: greedy_search is not patched)
+    naive = [str(tmp_path / "out" / f"naive{i}.jsonl") for i in range(2)]
+    runs = [subprocess.run([sys.executable, "-m", "llava_align_amd.sampling_driver", *common[:6], "--max_new_tokens", "6", "--naive", "--temperature", "0",
+                            "--answers-file", f], capture_output=True, text=True, env=_env(), timeout=900, cwd=ROOT) for f in naive]
+    assert all(r.returncode == 0 for r in runs), runs[0].stderr[-3000:]
+    assert json.loads(runs[0].stdout.strip().splitlines()[-1])["run"] == "naive"
+    c, c2 = ([json.loads(l) for l in open(f)] for f in naive)
+    assert len(c) == info["n_questions"] and tuple(c[0].keys()) == tuple(a[0].keys()) and [x["text"] for x in c] == [x["text"] for x in c2]
