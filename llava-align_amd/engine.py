@@ -1501,6 +1501,9 @@ class VddLlavaEngine:
         if t_pre + suffix_cap + max_new_tokens > lm.max_pos:
             raise ValueError(f"prompt + max_new_tokens exceed the rotary table (max_pos = {lm.max_pos})")
         shared_keys = {(nm, tuple(r[:si])) for r, si in zip(ids_all, s_img) for nm in names[1:]}
+        asked = Qc
+        Qc = self._fit_in_flight(Qc, lambda q_: (q_ + len(shared_keys) + 1, t_pre, nb * q_, suffix_cap + max_new_tokens))
+        admit_min = min(admit_min, max(1, Qc // 2))
         n_pre = Qc + len(shared_keys) + 1
         kv = self.kv(n_pre, t_pre, nb * Qc, suffix_cap + max_new_tokens, frag_only=False)
         eos_t = torch.tensor(eos_token_id, dtype=torch.long, device=dev)
@@ -1528,7 +1531,7 @@ class VddLlavaEngine:
         slot_keys: List[list] = [[] for _ in range(Qc)]
         feat_of: Dict[int, torch.Tensor] = {}
         waiting = list(range(N))
-        stats = {"n_rows": nb * Qc, "questions": N, "in_flight": Qc, "admissions": 0, "prefill_tokens": 0, "steps": 0, "graph": False}
+        stats = {"n_rows": nb * Qc, "questions": N, "in_flight": Qc, "in_flight_asked": asked, "admissions": 0, "prefill_tokens": 0, "steps": 0, "graph": False}
         live_row_steps = 0
 
         def retire(slots):
@@ -1676,6 +1679,31 @@ class VddLlavaEngine:
         stats.update(steps=steps, graph=run.graph is not None, answer_tokens=int(n_tok.sum().item()),
                      mean_live_rows=round(live_row_steps / max(steps, 1), 1), n_groups=0)
         return GenerateOutput(seqs_out, gen, None, top_prob, top_tok, stats)
+
+    KV_MEMORY_FRACTION = 0.92     # of what is free (+ what the pools being replaced give back): the rest is prefill activations, logits, graphs
+
+    def _fit_in_flight(self, Qc: int, dims) -> int:
+        """generate_list holds its own-KV slots at full length (suffix + max_new_tokens) for the whole call: 90 questions x 3 branches x 1,024
+        new tokens of a 13B model are 228 GB.  The number in flight is lowered (by eighths, not below 8) until the pools `dims(Qc)` =
+        (n_pre, t_pre, n_own, t_own) fit the device; the caller sees the value used in stats['in_flight']."""
+        if self.device.type != "cuda":
+            return Qc
+        cur = self._kvs.get(False)
+        free, _total = torch.cuda.mem_get_info(self.device)
+        avail = free + torch.cuda.memory_reserved(self.device) - torch.cuda.memory_allocated(self.device) + (cur.nbytes() if cur is not None else 0)
+
+        def need(q_):
+            n_pre, t_pre, n_own, t_own = dims(q_)
+            t_pre, t_own = (max(t_pre, 64) + 63) // 64 * 64, (max(t_own, 64) + 15) // 16 * 16
+            if cur is not None:
+                n_pre, t_pre, n_own, t_own = max(n_pre, cur.n_pre), max(t_pre, cur.t_pre), max(n_own, cur.n_own), max(t_own, cur.t_own)
+            return KVCache.bytes_needed(self.cfg.lm, n_pre, t_pre, n_own, t_own, self.dtype, False)
+        def fits_current(q_):
+            n_pre, t_pre, n_own, t_own = dims(q_)
+            return cur is not None and cur.fits(n_pre, (max(t_pre, 64) + 63) // 64 * 64, n_own, (max(t_own, 64) + 15) // 16 * 16, False)
+        while Qc > 8 and not fits_current(Qc) and need(Qc) > self.KV_MEMORY_FRACTION * avail:
+            Qc = max(8, Qc * 7 // 8)
+        return Qc
 
     def _processor_config(self, prompt_lens, ids_list, eos_token_id, min_new_tokens, min_length, stop_words_ids, repetition_penalty,
                           logits_processor, max_new_tokens):

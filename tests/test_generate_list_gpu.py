@@ -133,3 +133,26 @@ def test_run_sampling_is_shard_and_in_flight_invariant_for_deterministic_decodes
             if t in eos_s:
                 break
         assert x["text"] == " ".join(map(str, want)), i
+
+
+def test_in_flight_is_lowered_to_what_the_device_holds(monkeypatch):
+    """The own-KV slots of a list run are held at full length: with little memory free the call lowers the number in flight (by eighths, not
+    below 8) instead of failing in the allocator, says so in its stats, and still answers every question (here: equal to the batch run)."""
+    from llava_align_amd import ops
+    from llava_align_amd.engine import KVCache
+    eng = _engine(W7B, n_layers=2, vit_layers=2)
+    ids, imgs = _prompts(36, 1, 32000, seed=23)
+    eos = _eos_set(1500, 7)
+    kw = dict(use_dd_unk=True, cd_alpha=1.0, cd_beta=0.1, cd_greedy=True, temperature=0.5, max_new_tokens=32, eos_token_id=eos, pad_token_id=0)
+    with ops.batch_invariant():
+        ref = eng.generate(ids, images=imgs, **kw)
+        eng._kvs.clear(); eng._graphs.clear(); eng._kv = None
+        lm = eng.cfg.lm
+        # room for the pools of ~16 questions in flight: 32 asked -> 28 -> 24 -> 21 -> 18 -> 15
+        room = KVCache.bytes_needed(lm, 16 + 2, 640, 2 * 16, 64 + 32, eng.dtype, False) / eng.KV_MEMORY_FRACTION
+        real = torch.cuda.mem_get_info
+        monkeypatch.setattr(torch.cuda, "mem_get_info", lambda d=None: (int(room) - (torch.cuda.memory_reserved(d) - torch.cuda.memory_allocated(d)), real(d)[1]))
+        out = eng.generate_list(ids, imgs, in_flight=32, **kw)
+    assert out.stats["in_flight_asked"] == 32 and 8 <= out.stats["in_flight"] <= 16 and out.stats["n_rows"] == 2 * out.stats["in_flight"]
+    T = min(ref.tokens.shape[1], out.tokens.shape[1])
+    assert torch.equal(ref.tokens[:, :T], out.tokens[:, :T])
