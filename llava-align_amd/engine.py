@@ -1452,7 +1452,7 @@ class VddLlavaEngine:
     # -- a question LIST with a bounded number in flight: waiting questions take the slots of finished ones -----------------------------
     @torch.no_grad()
     def generate_list(self, input_ids: Sequence[torch.Tensor], images: Sequence[torch.Tensor], in_flight: int = 90,
-                      cd_alpha: Optional[float] = None, cd_beta: Optional[float] = None, use_dd: bool = False, use_dd_unk: bool = False,
+                      images_cd: Optional[Sequence[torch.Tensor]] = None, cd_alpha: Optional[float] = None, cd_beta: Optional[float] = None, use_dd: bool = False, use_dd_unk: bool = False,
                       temperature: Optional[float] = None, top_p: Optional[float] = None, top_k: Optional[int] = None,
                       max_new_tokens: int = 64, eos_token_id=None, pad_token_id: Optional[int] = None, cd_greedy: bool = False,
                       n_top: int = 0, seed: Optional[int] = None, sync_every: int = 8, admit_min: Optional[int] = None) -> GenerateOutput:
@@ -1462,7 +1462,9 @@ class VddLlavaEngine:
         (or reached max_new_tokens), the next waiting questions are prefilled INTO THEIR SLOTS - own-KV slots, prefix slots and the rows of
         the captured decode step are reused in place, nothing is re-captured or repacked - and join the running batch with a step index of
         their own.  Same kwargs and semantics per question as generate() (LLaVA prompts: ids with one -200 slot + one image each; the
-        image-free branches use_dd / use_dd_unk); the VCD branch, processors, output_scores and streamers stay with generate().
+        image-free branches use_dd / use_dd_unk; images_cd = one noised image per question: the VCD branch, which - like the reference's,
+        whose cd pass runs on the main cache from step 1 on (quirk #1) - contrasts step 0 only, so it is prefilled at admission into
+        scratch prefix slots and never decodes); prompts given as embeddings, processors, output_scores and streamers stay with generate().
         Memory: nb x in_flight own slots of (longest suffix + max_new_tokens) tokens are held for the whole call.
         admit_min: waiting questions are admitted once that many slots are free (default in_flight / 16; prefilling a handful of questions
         costs a pass over the weights like a decode step of the whole batch).  Returns a GenerateOutput over ALL questions, input order;
@@ -1488,8 +1490,14 @@ class VddLlavaEngine:
             if bad:
                 raise ValueError(f"prompt {q_}: token id {bad[0]} outside [0, {lm.vocab})")
             s_img.append(r.index(IMAGE_TOKEN_INDEX))
-        names = ["main"] + (["unk"] if use_dd_unk else (["none"] if use_dd else [])) + (["none"] if (use_dd and use_dd_unk) else [])
-        nb, contrast = len(names), len(names) > 1
+        vcd = images_cd is not None
+        if vcd and len(images_cd) != N:
+            raise ValueError("generate_list: one images_cd entry per question")
+        if vcd:                                                  # vcd_sample.py:148-150: the cd branch takes the place of the first image-free branch
+            names = ["main"] + (["none"] if (use_dd and use_dd_unk) else [])
+        else:
+            names = ["main"] + (["unk"] if use_dd_unk else (["none"] if use_dd else [])) + (["none"] if (use_dd and use_dd_unk) else [])
+        nb, contrast = len(names), vcd or len(names) > 1
         alpha = cd_alpha if cd_alpha is not None else 0.5
         beta = cd_beta if cd_beta is not None else 0.1
         warp = WarpSpec(temperature=temperature, top_k=top_k, top_p=top_p)
@@ -1502,16 +1510,19 @@ class VddLlavaEngine:
             raise ValueError(f"prompt + max_new_tokens exceed the rotary table (max_pos = {lm.max_pos})")
         shared_keys = {(nm, tuple(r[:si])) for r, si in zip(ids_all, s_img) for nm in names[1:]}
         asked = Qc
-        Qc = self._fit_in_flight(Qc, lambda q_: (q_ + len(shared_keys) + 1, t_pre, nb * q_, suffix_cap + max_new_tokens))
+        # VCD: every admitted question's cd prompt (tokens | noised patches | suffix) is prefilled as ONE sequence into a scratch prefix slot
+        t_pool = t_pre + (suffix_cap if vcd else 0)
+        pre_slots = lambda q_: (2 if vcd else 1) * q_ + len(shared_keys) + 1
+        Qc = self._fit_in_flight(Qc, lambda q_: (pre_slots(q_), t_pool, nb * q_, suffix_cap + max_new_tokens))
         admit_min = min(admit_min, max(1, Qc // 2))
-        n_pre = Qc + len(shared_keys) + 1
-        kv = self.kv(n_pre, t_pre, nb * Qc, suffix_cap + max_new_tokens, frag_only=False)
+        n_pre = pre_slots(Qc)
+        kv = self.kv(n_pre, t_pool, nb * Qc, suffix_cap + max_new_tokens, frag_only=False)
         eos_t = torch.tensor(eos_token_id, dtype=torch.long, device=dev)
         from .sampling import fresh_offset
         sd = (fresh_offset() if seed is None else int(seed)) & 0x3FFFFFFFFF
-        cfgkey = ("list", Qc, nb, max_new_tokens, alpha, beta, warp.t, warp.k, warp.p, use_dd, use_dd_unk, cd_greedy, tuple(eos_token_id), pad_token_id,
+        cfgkey = ("list", Qc, nb, max_new_tokens, alpha, beta, warp.t, warp.k, warp.p, use_dd, use_dd_unk, vcd, cd_greedy, tuple(eos_token_id), pad_token_id,
                   ops.GEMM_BATCH_INVARIANT)
-        tail = dict(alpha=alpha, beta=beta, warp=warp, contrast=contrast, is_vcd=False, both=(use_dd and use_dd_unk), greedy=cd_greedy, eos_t=eos_t,
+        tail = dict(alpha=alpha, beta=beta, warp=warp, contrast=contrast, is_vcd=vcd, both=(use_dd and use_dd_unk), greedy=cd_greedy, eos_t=eos_t,
                     pad=pad_token_id, output_scores=False, n_groups=0, n_items=0, cpi=1, proc={}, admit=True)
         run = self._runner(cfgkey, Qc, nb, max_new_tokens, tail, kv)
         run.reset(sd << 24)
@@ -1586,6 +1597,19 @@ class VddLlavaEngine:
             if new_pre:
                 x, pos, cpos, slot, seqs, max_tq = self._pack(new_pre)
                 passes.append(dict(x=x, pos=pos, cpos=cpos, slot=slot, seqs=seqs, n_seq=len(new_pre), max_tq=max_tq, to_prefix_pool=True, keep_q=False))
+            scratch = []
+            if vcd:
+                # fresh noise per question (llava_sampling.py:88-91): no feature cache, but whole tower chunks
+                f_cd = []
+                for i0 in range(0, len(qs), self.VIT_CHUNK):
+                    f_cd += list(self.vit(torch.stack([images_cd[i].reshape(images_cd[i].shape[-3:]).to(dev) for i in qs[i0:i0 + self.VIT_CHUNK]])))
+                scratch = [free_pre.pop() for _ in qs]
+                cd_seq = [dict(slot=sl, tokens=ids_all[i][:s_img[i]], img=f, suf=ids_all[i][s_img[i] + 1:], T=len(ids_all[i]) - 1 + n_img_tok, pos0=0,
+                               pslot=0, plen=0) for sl, i, f in zip(scratch, qs, f_cd)]
+                x, pos, cpos, slot, seqs, max_tq = self._pack(cd_seq)
+                last, last_seqs = h2d_int32(dev, [s_["q_row0"] + s_["T"] - 1 for s_ in cd_seq], [[j, 1, s_["T"] - 1, s_["slot"], 0, 0] for j, s_ in enumerate(cd_seq)])
+                passes.append(dict(x=x, pos=pos, cpos=cpos, slot=slot, seqs=seqs, n_seq=len(cd_seq), max_tq=max_tq, to_prefix_pool=True, last_rows=last.long(),
+                                   last_seqs=last_seqs, keep_q=False))
             x, pos, cpos, slot, seqs, max_tq = self._pack(suffix)
             packs_h = ops.flash_packs([[0, 0, 0, 0, s_["pslot"], s_["plen"]] for s_ in suffix]) if (max_tq <= 32 and (not ops.GEMM_BATCH_INVARIANT or ops.FLASH_PACKS_IN_INVARIANT_MODE)) else None
             last, last_seqs, packs = h2d_int32(dev, [s_["q_row0"] + s_["T"] - 1 for s_ in suffix],
@@ -1593,12 +1617,19 @@ class VddLlavaEngine:
                                                packs_h if packs_h is not None else [[0, -1, -1, -1]])
             passes.append(dict(x=x, pos=pos, cpos=cpos, slot=slot, seqs=seqs, n_seq=len(suffix), max_tq=max_tq, to_prefix_pool=False, last_rows=last.long(),
                                last_seqs=last_seqs, packs=packs if packs_h is not None else None, keep_q=False))
-            resid, delta = self.lm.prefill(passes, kv)[-1]
+            outs = self.lm.prefill(passes, kv)
+            resid, delta = outs[-1]
             logits0 = self.lm.logits(resid, delta)                                  # [nb * k, V], branch-major
             k = len(slots)
             v0 = logits0[:k]
-            c0 = logits0[k:2 * k] if contrast else None
-            d0 = logits0[2 * k:3 * k] if nb == 3 else None
+            if vcd:
+                c0 = self.lm.logits(*outs[-2])                                      # the cd prompts' last positions; their K/V are not needed again
+                d0 = logits0[k:2 * k] if nb == 2 else None
+                free_pre.extend(scratch)
+                stats["prefill_tokens"] += sum(s_["T"] for s_ in cd_seq)
+            else:
+                c0 = logits0[k:2 * k] if contrast else None
+                d0 = logits0[2 * k:3 * k] if nb == 3 else None
             unf = torch.ones(k, dtype=torch.long, device=dev)
             # the wave draws from its own Philox stream (seed = admission number): row j of a wave and row j of the running batch never
             # see the same (counter, row) pair

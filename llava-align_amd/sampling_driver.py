@@ -4,8 +4,8 @@ replacement of the reference's per-question loop experiments/eval/sampling/llava
 Per question the reference runs ONE `model.generate(input_ids, images=..., images_cd=..., cd_alpha, cd_beta, use_dd, use_dd_unk,
 do_sample, temperature, top_p, top_k, max_new_tokens=1024)` at B = 1 (:96-109) and writes `{question_id, prompt, text, model_id, image,
 metadata}` (:119-124).  Here the whole list goes to the engine: `generate_list` keeps `in_flight` questions decoding and refills the
-slots of finished ones (answers are 20 - 1,000 tokens: a fixed batch would decode to its slowest member); with the VCD branch
-(`noise_step`: images_cd = add_diffusion_noise(image, noise_step), :88-91) the list is decoded batch after batch through `generate`.
+slots of finished ones (answers are 20 - 1,000 tokens: a fixed batch would decode to its slowest member), also with the VCD branch
+(`noise_step`: images_cd = add_diffusion_noise(image, noise_step), :88-91).
 The prompt is the conv template's with '<image>\\n' in front of the question, + ' Please answer this question with one word.' when the
 question file is a POPE file (:71-76).  Tokenisation stays outside: `encode(prompt) -> ids` with -200 at '<image>', `decode(ids)`.
 """
@@ -60,19 +60,18 @@ def run_sampling(engine: VddLlavaEngine, questions: Sequence[dict], encode: Call
     with (ops.batch_invariant() if invariant else contextlib.nullcontext()):
         if not mine:
             toks = torch.zeros(0, 1, dtype=torch.long, device=dev)
-        elif noise_step is None and generate_kw.get("do_sample", True) is not False:
+        elif generate_kw.get("do_sample", True) is not False:
             kw = {k: v for k, v in generate_kw.items() if k != "do_sample"}
+            if noise_step is not None:
+                from .vcd_add_noise import add_diffusion_noise
+                kw["images_cd"] = [add_diffusion_noise(im, noise_step) for im in imgs]                 # fresh noise per question (:88-91)
             out = engine.generate_list(ids, imgs, in_flight=in_flight, max_new_tokens=max_new_tokens, eos_token_id=eos_token_id, pad_token_id=pad_token_id, **kw)
             toks, stats = out.tokens, out.stats
-        else:
-            from .vcd_add_noise import add_diffusion_noise
+        else:                       # do_sample=False: greedy_search is not patched - plain arg-max decoding, batch after batch
             parts = []
             for b0 in range(0, len(mine), in_flight):
                 sl = slice(b0, b0 + in_flight)
-                kw = dict(generate_kw)
-                if noise_step is not None:
-                    kw["images_cd"] = [add_diffusion_noise(im, noise_step) for im in imgs[sl]]      # fresh noise per question (:88-91)
-                o = engine.generate(ids[sl], images=imgs[sl], max_new_tokens=max_new_tokens, eos_token_id=eos_token_id, pad_token_id=pad_token_id, **kw)
+                o = engine.generate(ids[sl], images=imgs[sl], max_new_tokens=max_new_tokens, eos_token_id=eos_token_id, pad_token_id=pad_token_id, **generate_kw)
                 parts.append(o.tokens)
                 stats = o.stats
             T = max(p_.shape[1] for p_ in parts)

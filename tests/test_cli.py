@@ -189,3 +189,11 @@ def test_sampling_driver_from_a_checkpoint_directory_alone_and_under_torchrun(tm
     assert json.loads(runs[0].stdout.strip().splitlines()[-1])["run"] == "naive"
     c, c2 = ([json.loads(l) for l in open(f)] for f in naive)
     assert len(c) == info["n_questions"] and tuple(c[0].keys()) == tuple(a[0].keys()) and [x["text"] for x in c] == [x["text"] for x in c2]
+    # --use_cd: the VCD branch (images_cd = add_diffusion_noise(image, noise_step)) through generate_list; only the 'default' run (llava_sampling.py:162-163)
+    vcd = str(tmp_path / "out" / "vcd-setting.jsonl")
+    p3 = subprocess.run([sys.executable, "-m", "llava_align_amd.sampling_driver", *common[:6], "--use_cd", "--noise_step", "500", "--max_new_tokens", "8",
+                         "--in-flight", "4", "--answers-file", vcd], capture_output=True, text=True, env=_env(), timeout=900, cwd=ROOT)
+    assert p3.returncode == 0, p3.stderr[-3000:]
+    reps = [json.loads(l) for l in p3.stdout.strip().splitlines() if l.startswith("{")]
+    assert [r["run"] for r in reps] == ["default"] and reps[0]["stats"]["n_rows"] == 4 and reps[0]["stats"]["admissions"] >= 2
+    assert len(open(vcd.replace("setting", "default")).readlines()) == info["n_questions"]

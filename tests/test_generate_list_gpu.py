@@ -156,3 +156,31 @@ def test_in_flight_is_lowered_to_what_the_device_holds(monkeypatch):
     assert out.stats["in_flight_asked"] == 32 and 8 <= out.stats["in_flight"] <= 16 and out.stats["n_rows"] == 2 * out.stats["in_flight"]
     T = min(ref.tokens.shape[1], out.tokens.shape[1])
     assert torch.equal(ref.tokens[:, :T], out.tokens[:, :T])
+
+
+@pytest.mark.parametrize("both", [False, True], ids=["vcd", "vcd_plus_both_dd"])
+def test_vcd_list_answers_equal_the_batch_answers(both):
+    """images_cd through generate_list: the cd prompt of every admitted question (tokens | noised patches | suffix) is prefilled as one
+    sequence into a scratch prefix slot, contrasts step 0, and never decodes (from step 1 on the reference's cd pass reads the main cache:
+    c == v, quirk #1).  Token for token and top-10 for top-10 the answers of ONE generate(images_cd=...) call in batch-invariant mode."""
+    from llava_align_amd import ops
+    eng = _engine(W7B, n_layers=3, vit_layers=2)
+    ids, imgs = _prompts(26, 1, 32000, seed=47)
+    g = torch.Generator().manual_seed(9)
+    imgs_cd = [im + 0.8 * torch.randn(im.shape, generator=g).to(im.device, im.dtype) for im in imgs]
+    eos = _eos_set(900, 5)
+    kw = dict(cd_alpha=1.0, cd_beta=0.1, cd_greedy=True, temperature=0.7, max_new_tokens=40, eos_token_id=eos, pad_token_id=0, n_top=10,
+              use_dd=both, use_dd_unk=both)
+    with ops.batch_invariant():
+        eng.retire = False
+        ref = eng.generate(ids, images=imgs, images_cd=imgs_cd, sync_every=4, **kw)
+        plain = eng.generate(ids, images=imgs, sync_every=4, **kw)
+        out = eng.generate_list(ids, imgs, images_cd=imgs_cd, in_flight=8, sync_every=4, admit_min=2, **kw)
+    la, lb = _answer_lengths(ref.tokens, eos), _answer_lengths(out.tokens, eos)
+    assert torch.equal(la, lb) and int(la.max()) > 20
+    T = min(ref.tokens.shape[1], out.tokens.shape[1])
+    assert torch.equal(ref.tokens[:, :T], out.tokens[:, :T])
+    assert torch.equal(ref.top_tok, out.top_tok) and torch.equal(ref.top_prob, out.top_prob)
+    assert not torch.equal(ref.top_prob, plain.top_prob)                                       # the noised branch really contrasts step 0
+    st = out.stats
+    assert st["n_rows"] == (2 if both else 1) * 8 and st["admissions"] >= 3 and st["graph"]
