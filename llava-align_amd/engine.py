@@ -1451,8 +1451,9 @@ class VddLlavaEngine:
 
     # -- a question LIST with a bounded number in flight: waiting questions take the slots of finished ones -----------------------------
     @torch.no_grad()
-    def generate_list(self, input_ids: Sequence[torch.Tensor], images: Sequence[torch.Tensor], in_flight: int = 90,
-                      images_cd: Optional[Sequence[torch.Tensor]] = None, cd_alpha: Optional[float] = None, cd_beta: Optional[float] = None, use_dd: bool = False, use_dd_unk: bool = False,
+    def generate_list(self, input_ids: Optional[Sequence[torch.Tensor]], images: Optional[Sequence[torch.Tensor]] = None, in_flight: int = 90,
+                      images_cd: Optional[Sequence[torch.Tensor]] = None, inputs_embeds: Optional[Sequence[torch.Tensor]] = None,
+                      embeds_prefix: Optional[Sequence[Optional[tuple]]] = None, cd_alpha: Optional[float] = None, cd_beta: Optional[float] = None, use_dd: bool = False, use_dd_unk: bool = False,
                       temperature: Optional[float] = None, top_p: Optional[float] = None, top_k: Optional[int] = None,
                       max_new_tokens: int = 64, eos_token_id=None, pad_token_id: Optional[int] = None, cd_greedy: bool = False,
                       n_top: int = 0, seed: Optional[int] = None, sync_every: int = 8, admit_min: Optional[int] = None) -> GenerateOutput:
@@ -1464,7 +1465,9 @@ class VddLlavaEngine:
         their own.  Same kwargs and semantics per question as generate() (LLaVA prompts: ids with one -200 slot + one image each; the
         image-free branches use_dd / use_dd_unk; images_cd = one noised image per question: the VCD branch, which - like the reference's,
         whose cd pass runs on the main cache from step 1 on (quirk #1) - contrasts step 0 only, so it is prefilled at admission into
-        scratch prefix slots and never decodes); prompts given as embeddings, processors, output_scores and streamers stay with generate().
+        scratch prefix slots and never decodes).  Prompts given as embeddings (`input_ids=None, inputs_embeds=[...]`: the Qwen-VL / InstructBLIP
+        call shape, with `embeds_prefix` and embedding-valued `images_cd` as in generate(); the image-free branches of such prompts re-run the
+        SAME inputs) are admitted the same way.  Processors, output_scores and streamers stay with generate().
         Memory: nb x in_flight own slots of (longest suffix + max_new_tokens) tokens are held for the whole call.
         admit_min: waiting questions are admitted once that many slots are free (default in_flight / 16; prefilling a handful of questions
         costs a pass over the weights like a decode step of the whole batch).  Returns a GenerateOutput over ALL questions, input order;
@@ -1478,12 +1481,22 @@ class VddLlavaEngine:
         if lm.head_dim != 128:
             raise ValueError("generate_list: head_dim 128 models")
         eos_token_id = [eos_token_id] if isinstance(eos_token_id, int) else list(eos_token_id)
-        ids_all = [r.reshape(-1).tolist() for r in input_ids]
-        N = len(ids_all)
-        if N == 0 or len(images) != N:
-            raise ValueError("generate_list: one image per question")
-        s_img = []
-        for q_, r in enumerate(ids_all):
+        emb_mode = inputs_embeds is not None
+        if emb_mode:
+            if input_ids is not None or images is not None:
+                raise ValueError("generate_list: inputs_embeds replace input_ids / images")
+            emb_all = [e.reshape(-1, lm.d).to(dev, self.dtype) for e in inputs_embeds]
+            N = len(emb_all)
+            if N == 0 or (embeds_prefix is not None and len(embeds_prefix) != N):
+                raise ValueError("generate_list: one (key, n_rows) per prompt in embeds_prefix")
+            ids_all, s_img = [[] for _ in range(N)], [0] * N
+        else:
+            ids_all = [r.reshape(-1).tolist() for r in input_ids]
+            N = len(ids_all)
+            if N == 0 or images is None or len(images) != N:
+                raise ValueError("generate_list: one image per question")
+            s_img = []
+        for q_, r in enumerate(ids_all if not emb_mode else []):
             if r.count(IMAGE_TOKEN_INDEX) != 1 or r[-1] == IMAGE_TOKEN_INDEX:
                 raise ValueError(f"prompt {q_}: exactly one image placeholder (-200), not at the end")
             bad = [t_ for t_ in r if t_ != IMAGE_TOKEN_INDEX and not (0 <= t_ < lm.vocab)]
@@ -1504,14 +1517,37 @@ class VddLlavaEngine:
         n_img_tok = self.cfg.vision.n_patches
         Qc = max(1, min(int(in_flight), N))
         admit_min = max(1, Qc // 16) if admit_min is None else max(1, int(admit_min))
-        suffix_cap = max(len(r) - si - 1 for r, si in zip(ids_all, s_img))
-        t_pre = max(si + n_img_tok for si in s_img)
-        if t_pre + suffix_cap + max_new_tokens > lm.max_pos:
+        if emb_mode:
+            # a prompt = [shared rows | own rows]: the rows the caller declares common to every prompt with one key (embeds_prefix: '<img>' + the
+            # image slots), else - with image-free branches, which re-run the main branch's inputs - everything but the last position, shared by
+            # the branches of the question (engine._plan's rule for one generate() call)
+            emb_pre = []
+            for i, e in enumerate(emb_all):
+                T_ = int(e.shape[0])
+                ep = embeds_prefix[i] if embeds_prefix is not None else None
+                if ep is not None and 0 < int(ep[1]) < T_:
+                    emb_pre.append((("emb", ep[0], int(ep[1])), int(ep[1])))
+                elif nb > 1 and T_ > 1:
+                    emb_pre.append((("q", i), T_ - 1))
+                else:
+                    emb_pre.append((None, 0))
+            suffix_cap = max(int(e.shape[0]) - p_[1] for e, p_ in zip(emb_all, emb_pre))
+            t_pre = max([p_[1] for p_ in emb_pre] + [1])
+            longest = max(int(e.shape[0]) for e in emb_all)
+            shared_keys = set()
+            if vcd:
+                emb_cd_all = [e.reshape(-1, lm.d).to(dev, self.dtype) for e in images_cd]
+                longest = max([longest] + [int(e.shape[0]) for e in emb_cd_all])
+        else:
+            suffix_cap = max(len(r) - si - 1 for r, si in zip(ids_all, s_img))
+            t_pre = max(si + n_img_tok for si in s_img)
+            longest = t_pre + suffix_cap
+            shared_keys = {(nm, tuple(r[:si])) for r, si in zip(ids_all, s_img) for nm in names[1:]}
+        if longest + max_new_tokens > lm.max_pos:
             raise ValueError(f"prompt + max_new_tokens exceed the rotary table (max_pos = {lm.max_pos})")
-        shared_keys = {(nm, tuple(r[:si])) for r, si in zip(ids_all, s_img) for nm in names[1:]}
         asked = Qc
         # VCD: every admitted question's cd prompt (tokens | noised patches | suffix) is prefilled as ONE sequence into a scratch prefix slot
-        t_pool = t_pre + (suffix_cap if vcd else 0)
+        t_pool = max(t_pre, longest) if vcd else t_pre
         pre_slots = lambda q_: (2 if vcd else 1) * q_ + len(shared_keys) + 1
         Qc = self._fit_in_flight(Qc, lambda q_: (pre_slots(q_), t_pool, nb * q_, suffix_cap + max_new_tokens))
         admit_min = min(admit_min, max(1, Qc // 2))
@@ -1558,21 +1594,35 @@ class VddLlavaEngine:
                     if e["ref"] == 0:
                         free_pre.append(e["slot"])
                         del table[key]
-                im = id(images[slot_q[q]])
+                im = None if emb_mode else id(images[slot_q[q]])
                 slot_q[q], slot_keys[q] = -1, []
-                if not any(k_[0] == "img" and k_[2] == im for k_ in table):
+                if im is not None and not any(k_[0] == "img" and k_[2] == im for k_ in table):
                     feat_of.pop(im, None)
 
         def admit(slots):
             """the next len(slots) waiting questions: vision tower for images not seen yet, prefill of new prefixes + all suffixes, first token"""
             qs = [waiting.pop(0) for _ in slots]
-            todo = [i for i in qs if id(images[i]) not in feat_of]
+            todo = [] if emb_mode else [i for i in qs if id(images[i]) not in feat_of]
             todo = list({id(images[i]): i for i in todo}.values())
             if todo:
                 for i, f in zip(todo, self.image_features([images[i] for i in todo])):
                     feat_of[id(images[i])] = f
             new_pre, suffix, dec = [], [], []
-            for b, nm in enumerate(names):
+            for b, nm in enumerate(names if emb_mode else []):
+                for q, i in zip(slots, qs):
+                    e_, (key, P) = emb_all[i], emb_pre[i]
+                    T_, row, pslot = int(e_.shape[0]), b * Qc + q, 0
+                    if key is not None:
+                        e = table.get(key)
+                        if e is None:
+                            e = table[key] = dict(slot=free_pre.pop(), ref=0, T=P)
+                            new_pre.append(dict(slot=e["slot"], tokens=[], img=e_[:P], T=P, pos0=0, pslot=0, plen=0))
+                        e["ref"] += 1
+                        slot_keys[q].append(key)
+                        pslot = e["slot"]
+                    suffix.append(dict(slot=row, tokens=None, pre=[], img=e_[P:], suf=[], T=T_ - P, pos0=P, pslot=pslot, plen=P))
+                    dec.append((T_, T_ - P, [row, T_ + 1, pslot, P]))
+            for b, nm in enumerate([] if emb_mode else names):
                 for q, i in zip(slots, qs):
                     r, si = ids_all[i], s_img[i]
                     if nm == "main":
@@ -1601,11 +1651,14 @@ class VddLlavaEngine:
             if vcd:
                 # fresh noise per question (llava_sampling.py:88-91): no feature cache, but whole tower chunks
                 f_cd = []
-                for i0 in range(0, len(qs), self.VIT_CHUNK):
+                for i0 in range(0, len(qs) if not emb_mode else 0, self.VIT_CHUNK):
                     f_cd += list(self.vit(torch.stack([images_cd[i].reshape(images_cd[i].shape[-3:]).to(dev) for i in qs[i0:i0 + self.VIT_CHUNK]])))
                 scratch = [free_pre.pop() for _ in qs]
-                cd_seq = [dict(slot=sl, tokens=ids_all[i][:s_img[i]], img=f, suf=ids_all[i][s_img[i] + 1:], T=len(ids_all[i]) - 1 + n_img_tok, pos0=0,
-                               pslot=0, plen=0) for sl, i, f in zip(scratch, qs, f_cd)]
+                if emb_mode:          # images_cd = the noisy-image EMBEDDINGS of the whole prompt (modeling_llama.py:778-782, modeling_qwen.py:1089-1118)
+                    cd_seq = [dict(slot=sl, tokens=[], img=emb_cd_all[i], T=int(emb_cd_all[i].shape[0]), pos0=0, pslot=0, plen=0) for sl, i in zip(scratch, qs)]
+                else:
+                    cd_seq = [dict(slot=sl, tokens=ids_all[i][:s_img[i]], img=f, suf=ids_all[i][s_img[i] + 1:], T=len(ids_all[i]) - 1 + n_img_tok, pos0=0,
+                                   pslot=0, plen=0) for sl, i, f in zip(scratch, qs, f_cd)]
                 x, pos, cpos, slot, seqs, max_tq = self._pack(cd_seq)
                 last, last_seqs = h2d_int32(dev, [s_["q_row0"] + s_["T"] - 1 for s_ in cd_seq], [[j, 1, s_["T"] - 1, s_["slot"], 0, 0] for j, s_ in enumerate(cd_seq)])
                 passes.append(dict(x=x, pos=pos, cpos=cpos, slot=slot, seqs=seqs, n_seq=len(cd_seq), max_tq=max_tq, to_prefix_pool=True, last_rows=last.long(),
@@ -1701,12 +1754,15 @@ class VddLlavaEngine:
         is_eos = (master[:, :, None] == eos_t[None, None, :]).any(-1)
         n_tok = torch.where(is_eos.any(1), is_eos.float().argmax(1) + 1, torch.full((N,), max_new_tokens, device=dev))
         gen = master[:, : int(n_tok.max().item())].clone()
-        lens = [len(r) for r in ids_all]
-        (flat,) = h2d_int32(dev, [t_ for r in ids_all for t_ in r])
-        flat, offs = flat.long(), [0]
-        for n_ in lens:
-            offs.append(offs[-1] + n_)
-        seqs_out = [torch.cat([flat[offs[q]:offs[q + 1]], gen[q]]) for q in range(N)]
+        if emb_mode:                                             # no prompt ids to put in front (HF returns the new tokens for inputs_embeds)
+            seqs_out = [gen[q] for q in range(N)]
+        else:
+            lens = [len(r) for r in ids_all]
+            (flat,) = h2d_int32(dev, [t_ for r in ids_all for t_ in r])
+            flat, offs = flat.long(), [0]
+            for n_ in lens:
+                offs.append(offs[-1] + n_)
+            seqs_out = [torch.cat([flat[offs[q]:offs[q + 1]], gen[q]]) for q in range(N)]
         stats.update(steps=steps, graph=run.graph is not None, answer_tokens=int(n_tok.sum().item()),
                      mean_live_rows=round(live_row_steps / max(steps, 1), 1), n_groups=0)
         return GenerateOutput(seqs_out, gen, None, top_prob, top_tok, stats)

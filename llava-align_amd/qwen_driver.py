@@ -83,8 +83,29 @@ def run_qwen_pope(engine: VddLlavaEngine, questions: Sequence[dict], embed_promp
     prior_kw = dict(max_new_tokens=1, n_top=10, min_new_tokens=min_new_tokens, eos_token_id=eos_token_id, pad_token_id=pad_token_id, **plain_kw)
     invariant = resolve_batch_invariant(batch_invariant, plan.world, generate_kw)
     prompts = {}
+    # answers only, no EOS floor (qwenvl_sampling.py:89-103: open-ended answers, max_new_tokens 1024): the whole shard as ONE list, batch_questions
+    # in flight, waiting questions admitted into the slots of finished ones (engine.generate_list)
+    list_kw = ("temperature", "top_p", "top_k", "use_dd", "use_dd_unk", "cd_alpha", "cd_beta", "seed", "cd_greedy", "sync_every", "admit_min")
+    as_list = (not priors and not min_new_tokens and eos_token_id is not None and pad_token_id is not None and bool(mine)
+               and engine.cfg.lm.head_dim == 128 and all(k in list_kw for k in generate_kw))
     with (ops.batch_invariant() if invariant else contextlib.nullcontext()):
-        for b0 in range(0, len(mine), batch_questions):
+        if as_list:
+            cache: Dict[str, torch.Tensor] = {}
+            for i in mine:
+                if questions[i]["image"] not in cache:
+                    cache[questions[i]["image"]] = load_image(questions[i]["image"]).to(engine.device)
+            imgs = [cache[questions[i]["image"]] for i in mine]
+            texts = [prompt_format.format(image_path(questions[i]["image"]), questions[i]["text"]) for i in mine]
+            prompts.update(zip(mine, texts))
+            emb, pre = _embeds(embed_prompt, texts, imgs, [("clean", questions[i]["image"]) for i in mine])
+            kw = dict(generate_kw)
+            if use_cd:
+                kw["images_cd"] = _embeds(embed_prompt, texts, [add_diffusion_noise(im, noise_step) for im in imgs], [None] * len(mine))[0]
+            out = engine.generate_list(None, inputs_embeds=emb, embeds_prefix=pre, in_flight=batch_questions, max_new_tokens=max_new_tokens, n_top=10,
+                                       eos_token_id=eos_token_id, pad_token_id=pad_token_id, **kw)
+            rows.add(mine, out.tokens, [(out.top_tok, out.top_prob)])
+            list_stats = out.stats
+        for b0 in range(0, 0 if as_list else len(mine), batch_questions):
             idx = mine[b0:b0 + batch_questions]
             qs = [questions[i] for i in idx]
             cache: Dict[str, torch.Tensor] = {}
@@ -151,7 +172,8 @@ def run_qwen_pope(engine: VddLlavaEngine, questions: Sequence[dict], embed_promp
                 scores[name] = C.pope_scores(gt, answers) if name == "string_match" else C.pope_scores_calibrated(gt, answers, name)
             except ZeroDivisionError:
                 scores[name] = None
-    return {"answers": answers, "scores": scores, "rank": plan.rank, "world": plan.world, "batch_invariant": invariant}
+    return {"answers": answers, "scores": scores, "rank": plan.rank, "world": plan.world, "batch_invariant": invariant,
+            "stats": list_stats if as_list else {}}
 
 
 def main(argv=None):

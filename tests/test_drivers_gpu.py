@@ -199,6 +199,15 @@ def test_run_qwen_pope_five_passes_against_direct_calls(tmp_path):
     assert len(visual_calls) - n0 == 1 + 3 and s["scores"].keys() == {"string_match"} and not s["batch_invariant"]
     first = json.loads(open(tmp_path / "q" / "s.jsonl").readline())
     assert list(first) == ["question_id", "prompt", "text", "model_id", "image", "metadata"] and first["prompt"].startswith("Question: <img>im0.jpg</img> Is")
+    # open-ended shape (no EOS floor): the shard goes through generate_list, 4 in flight - same answers as one generate() call over all nine
+    eos = sorted(set(np.random.default_rng(2).integers(3, V - 40, size=60).tolist()))
+    lkw = dict(kw, eos_token_id=eos, pad_token_id=eod, max_new_tokens=24, min_new_tokens=None, cd_greedy=True, use_dd_unk=True)
+    lst = run_qwen_pope(eng, qs, embed, decode, lambda n: images[n], priors=(), prompt_format=SAMPLING_PROMPT, batch_questions=4, **lkw)
+    assert lst["stats"]["in_flight"] == 4 and lst["stats"]["admissions"] >= 2 and lst["batch_invariant"]
+    emb = [embed(a["prompt"], images[q["image"]])[0] for q, a in zip(qs, lst["answers"])]
+    with ops.batch_invariant():
+        direct = eng.generate(None, inputs_embeds=emb, **{k: v for k, v in lkw.items() if k != "min_new_tokens"})
+    assert [a["text"] for a in lst["answers"]] == [decode(cut_at_eos(t, set(eos))).strip() for t in direct.tokens.tolist()]
 
 
 def test_run_blip_pope_vcd_against_direct_front_end_and_engine_calls(tmp_path):

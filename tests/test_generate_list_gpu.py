@@ -184,3 +184,36 @@ def test_vcd_list_answers_equal_the_batch_answers(both):
     assert not torch.equal(ref.top_prob, plain.top_prob)                                       # the noised branch really contrasts step 0
     st = out.stats
     assert st["n_rows"] == (2 if both else 1) * 8 and st["admissions"] >= 3 and st["graph"]
+
+
+@pytest.mark.parametrize("mode", ["plain", "dd_unk", "vcd"])
+def test_embedding_prompts_through_the_list(mode):
+    """The Qwen-VL / InstructBLIP call shape: prompts as [T, d] embeddings, `embeds_prefix` = rows two questions about one image share, the
+    image-free branch re-running the same inputs, `images_cd` = the noisy-image embeddings of the whole prompt.  Answers and
+    step-0 top-10 equal ONE generate(inputs_embeds=...) call in batch-invariant mode."""
+    from llava_align_amd import ops
+    eng = _engine(W7B, n_layers=3, vit_layers=2)
+    g = torch.Generator(device=DEV).manual_seed(3)
+    mk = lambda n: (torch.randn(n, 4096, device=DEV, generator=g) * 0.05).to(torch.bfloat16)
+    shared = [mk(40) for _ in range(9)]                                       # '<img>' + image slots: one per image, two questions each
+    emb = [torch.cat([shared[i // 2], mk(7 + i % 5)]) for i in range(18)]
+    pre = [(f"im{i // 2}", 40) for i in range(18)]
+    emb_cd = [torch.cat([mk(40), e[40:]]) for e in emb]
+    eos = _eos_set(900, 5)
+    kw = dict(cd_alpha=1.0, cd_beta=0.1, cd_greedy=True, temperature=0.7, max_new_tokens=36, eos_token_id=eos, pad_token_id=0, n_top=10, use_dd_unk=mode == "dd_unk")
+    extra = dict(images_cd=emb_cd) if mode == "vcd" else {}
+    with ops.batch_invariant():
+        eng.retire = False
+        ref = eng.generate(None, inputs_embeds=emb, embeds_prefix=pre, sync_every=4, **kw, **extra)
+        out = eng.generate_list(None, inputs_embeds=emb, embeds_prefix=pre, in_flight=6, sync_every=4, admit_min=2, **kw, **extra)
+        bare = eng.generate_list(None, inputs_embeds=emb, in_flight=6, sync_every=4, admit_min=2, **kw, **extra)     # no declared sharing: same answers
+    la, lb = _answer_lengths(ref.tokens, eos), _answer_lengths(out.tokens, eos)
+    assert torch.equal(la, lb) and int(la.max()) > 15
+    T = min(ref.tokens.shape[1], out.tokens.shape[1], bare.tokens.shape[1])
+    assert torch.equal(ref.tokens[:, :T], out.tokens[:, :T]) and torch.equal(ref.tokens[:, :T], bare.tokens[:, :T])
+    assert torch.equal(ref.top_tok, out.top_tok) and torch.equal(ref.top_prob, out.top_prob)
+    assert out.stats["n_rows"] == (2 if mode == "dd_unk" else 1) * 6 and out.stats["admissions"] >= 3
+    assert out.stats["prefill_tokens"] < bare.stats["prefill_tokens"] or mode == "dd_unk"          # the declared image rows were prefilled once per image
+    assert [s_.shape[0] for s_ in out.sequences] == [out.tokens.shape[1]] * 18
+    with pytest.raises(ValueError, match="replace input_ids"):
+        eng.generate_list([torch.tensor([1, -200, 5])], None, inputs_embeds=emb[:1], eos_token_id=eos, pad_token_id=0)
