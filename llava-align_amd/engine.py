@@ -31,6 +31,7 @@ import math
 from dataclasses import dataclass, field
 from typing import Dict, List, Optional, Sequence
 
+import numpy as np
 import torch
 
 from . import ops
@@ -419,6 +420,35 @@ def h2d_int32(device, *arrays):
         out.append(dev_buf[o:o + n].view(*shape) if n else dev_buf[o:o])
         o += n
     return out
+
+
+def h2d_long(device, values) -> torch.Tensor:
+    """A host list of indices -> an int64 device tensor without blocking the host: `torch.tensor(list, device=...)` is a pageable copy that
+    WAITS for everything queued on the stream - inside generate() that was the vision tower (57 ms of a 768-question POPE call during which
+    the host planned nothing, and the GPU then idled until the prefill's first launch: tools/call_gaps.py)."""
+    return h2d_int32(device, values)[0].long()
+
+
+def prompt_plus_answer(device, ids_list, gen: torch.Tensor) -> List[torch.Tensor]:
+    """The `sequences` of a call: per question [prompt ids | generated row] (vcd_sample.py:263 appends to input_ids; prompts given as
+    embeddings have no ids: the new tokens alone, as HF returns them).  ONE upload + ONE gather into a flat buffer whose slices are the
+    rows - a torch.cat per question was 768 launches (9 ms of host time behind the last decode step of the bench batch: tools/call_gaps.py)."""
+    Q, T = int(gen.shape[0]), int(gen.shape[1])
+    lens = [len(r) for r in ids_list]
+    P = sum(lens)
+    if P == 0:
+        return [gen[q] for q in range(Q)]
+    idx = np.empty(P + Q * T, dtype=np.int32)
+    o = p0 = 0
+    ar_t = np.arange(T, dtype=np.int32)
+    for q, n in enumerate(lens):
+        idx[o:o + n] = np.arange(p0, p0 + n, dtype=np.int32)
+        idx[o + n:o + n + T] = ar_t + (P + q * T)
+        o += n + T
+        p0 += n
+    flat, idx_d = h2d_int32(device, np.fromiter((t for r in ids_list for t in r), dtype=np.int32, count=P), idx)
+    out = torch.cat([flat.long(), gen.reshape(-1)])[idx_d.long()]
+    return list(out.split([n + T for n in lens]))
 
 
 def grouping_pays(groups, rows, min_saved=0.25) -> bool:
@@ -1273,7 +1303,7 @@ class VddLlavaEngine:
                 pd = dict(x=x, pos=pos, cpos=cpos, slot=slot, seqs=seqs, n_seq=len(segs), max_tq=max_tq, to_prefix_pool=True, keep_q=want_maps)   # K/V only
                 if level:
                     n_sys = segs[0]["cpos0"]
-                    pd.update(own_row_offset=n_sys, parent_copy=(torch.tensor([s_["slot"] for s_ in segs], dtype=torch.long, device=dev),
+                    pd.update(own_row_offset=n_sys, parent_copy=(h2d_long(dev, [s_["slot"] for s_ in segs]),
                                                                    segs[0]["pslot"], n_sys))
                 passes.append(pd)
             if kv.frag_only:
@@ -1315,7 +1345,7 @@ class VddLlavaEngine:
         from .sampling import fresh_offset
         sd = (fresh_offset() if seed is None else int(seed)) & 0x3FFFFFFFFF
         ctr0 = sd << 24
-        eos_t = torch.tensor(eos_token_id, dtype=torch.long, device=dev) if eos_token_id is not None else None
+        eos_t = h2d_long(dev, eos_token_id) if eos_token_id is not None else None
         cfgkey = (Q, nb, max_new_tokens, alpha, beta, warp.t, warp.k, warp.p, use_cd, use_dd, use_dd_unk, cd_greedy,
                   tuple(eos_token_id) if eos_token_id is not None else None, pad_token_id, output_scores, ops.GEMM_BATCH_INVARIANT)
         cpi = ops.prefix_chunks_per_item(grp, lm.n_heads)
@@ -1436,13 +1466,7 @@ class VddLlavaEngine:
             if scores is not None:
                 scores = scores[:gen.shape[1]]
         # prompt ids back on the device in ONE copy (a torch.tensor(..., device=) per question is a synchronous pageable copy each)
-        lens = [len(r) for r in ids_list]
-        (flat,) = h2d_int32(dev, [t for r in ids_list for t in r]) if sum(lens) else (torch.zeros(0, dtype=torch.int32, device=dev),)
-        flat = flat.long()
-        offs = [0]
-        for n in lens:
-            offs.append(offs[-1] + n)
-        seqs_out = [torch.cat([flat[offs[q]:offs[q + 1]], gen[q]]) for q in range(Q)]
+        seqs_out = prompt_plus_answer(dev, ids_list, gen)
         stats["steps"] = int(gen.shape[1])
         stats["graph"] = run.graph is not None
         stats["n_groups"] = n_groups          # > 0: the decode steps ran the grouped (shared-prefix) attention
@@ -1553,7 +1577,7 @@ class VddLlavaEngine:
         admit_min = min(admit_min, max(1, Qc // 2))
         n_pre = pre_slots(Qc)
         kv = self.kv(n_pre, t_pool, nb * Qc, suffix_cap + max_new_tokens, frag_only=False)
-        eos_t = torch.tensor(eos_token_id, dtype=torch.long, device=dev)
+        eos_t = h2d_long(dev, eos_token_id)
         from .sampling import fresh_offset
         sd = (fresh_offset() if seed is None else int(seed)) & 0x3FFFFFFFFF
         cfgkey = ("list", Qc, nb, max_new_tokens, alpha, beta, warp.t, warp.k, warp.p, use_dd, use_dd_unk, vcd, cd_greedy, tuple(eos_token_id), pad_token_id,
@@ -1754,15 +1778,7 @@ class VddLlavaEngine:
         is_eos = (master[:, :, None] == eos_t[None, None, :]).any(-1)
         n_tok = torch.where(is_eos.any(1), is_eos.float().argmax(1) + 1, torch.full((N,), max_new_tokens, device=dev))
         gen = master[:, : int(n_tok.max().item())].clone()
-        if emb_mode:                                             # no prompt ids to put in front (HF returns the new tokens for inputs_embeds)
-            seqs_out = [gen[q] for q in range(N)]
-        else:
-            lens = [len(r) for r in ids_all]
-            (flat,) = h2d_int32(dev, [t_ for r in ids_all for t_ in r])
-            flat, offs = flat.long(), [0]
-            for n_ in lens:
-                offs.append(offs[-1] + n_)
-            seqs_out = [torch.cat([flat[offs[q]:offs[q + 1]], gen[q]]) for q in range(N)]
+        seqs_out = prompt_plus_answer(dev, ids_all, gen)        # (embedding prompts: ids_all is empty per question - the new tokens alone)
         stats.update(steps=steps, graph=run.graph is not None, answer_tokens=int(n_tok.sum().item()),
                      mean_live_rows=round(live_row_steps / max(steps, 1), 1), n_groups=0)
         return GenerateOutput(seqs_out, gen, None, top_prob, top_tok, stats)
