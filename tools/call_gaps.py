@@ -1,5 +1,5 @@
 """GPU-idle holes inside ONE generate() call of the POPE-proper batch (768 questions, 2 new tokens): run under rocprofv3 --kernel-trace, then
-`call_gaps.py analyse <kernel_trace.csv>` (NEW_TOKENS=64: the headline step).  The timed call sits between two marker launches (fills of a float64 tensor)."""
+`call_gaps.py analyse <kernel_trace.csv>` (NEW_TOKENS=64: the headline step; WHAT=config2_full | config5 | config4: the timed call of that bench.py leg).  The timed call sits between two marker launches (fills of a float64 tensor)."""
 import csv, json, os, sys, time
 if sys.argv[1:2] == ["analyse"]:
     rows = []
@@ -27,9 +27,29 @@ if sys.argv[1:2] == ["analyse"]:
     sys.exit(0)
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import torch
+import bench
 from bench import pope_prompts
 from llava_align_amd.engine import VddLlavaEngine
 dev = "cuda:0"
+what = os.environ.get("WHAT", "pope")
+m = torch.empty(54321, device=dev, dtype=torch.float64)
+if what != "pope":
+    # a driver leg of bench.py (config2_full / config5 / config4): the markers go around ITS timed call
+    def timed(fn, d):
+        torch.cuda.synchronize(d)
+        m.fill_(1.0); torch.cuda.synchronize(d)
+        t0 = time.perf_counter(); out = fn(); torch.cuda.synchronize(d)
+        dt = time.perf_counter() - t0
+        m.fill_(2.0); torch.cuda.synchronize(d)
+        return out, dt
+    bench._timed = timed
+    if what == "config4":
+        res = bench.bench_config4(torch.device(dev))
+    else:
+        eng = VddLlavaEngine("llava-1.5-7b", device=dev, seed=0, use_graph=True, lm_head_gain=4.0)
+        res = getattr(bench, "bench_" + what)(eng, torch.device(dev))
+    print(json.dumps({k: v for k, v in res.items() if k in ("seconds", "items_per_s", "prefill_s", "decode_s", "front_end_and_host_s")}))
+    sys.exit(0)
 eng = VddLlavaEngine("llava-1.5-7b", device=dev, seed=0, use_graph=True, lm_head_gain=4.0)
 ids, host_imgs = pope_prompts(128, seed=1234, vocab=eng.cfg.lm.vocab, image=eng.cfg.vision.image)
 on_dev = {}
@@ -38,7 +58,6 @@ kw = dict(images=imgs, use_dd_unk=True, cd_alpha=1.0, cd_beta=0.1, temperature=0
 for _ in range(2):
     eng.generate(ids, **kw)
 torch.cuda.synchronize()
-m = torch.empty(54321, device=dev, dtype=torch.float64)
 m.fill_(1.0); torch.cuda.synchronize()
 t0 = time.perf_counter()
 eng.generate(ids, **kw)
