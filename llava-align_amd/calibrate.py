@@ -260,15 +260,16 @@ def mme_convert(answers: Sequence[dict], gt: Dict[tuple, str], names: Sequence[s
             if name == "naive":
                 res.setdefault(category, []).append((file, a["prompt"], a["text"]))
                 continue
-            if calibrate_mode == "individual":
-                if name == "none_unk":
-                    s_ = np.array(prob["unk"][i]) + np.array(prob["none"][i])
-                    p_cf = s_ / np.sum(s_)
-                else:
-                    p_cf = prob[name][i]
-                W, b = calibrate_weight([x + 1e-4 for x in p_cf], mode)
-            q = np.matmul(W, np.expand_dims(prob["naive"][i], axis=-1)) + b
-            q /= np.sum(q)
+            with np.errstate(invalid="ignore", divide="ignore"):     # neither label among a top-10: 0 / 0 -> NaN -> arg-max 0, as the script computes it
+                if calibrate_mode == "individual":
+                    if name == "none_unk":
+                        s_ = np.array(prob["unk"][i]) + np.array(prob["none"][i])
+                        p_cf = s_ / np.sum(s_)
+                    else:
+                        p_cf = prob[name][i]
+                    W, b = calibrate_weight([x + 1e-4 for x in p_cf], mode)
+                q = np.matmul(W, np.expand_dims(prob["naive"][i], axis=-1)) + b
+                q /= np.sum(q)
             res.setdefault(category, []).append((file, a["prompt"], label[int(np.argmax(q))].capitalize()))
         out[name] = {}
         for category, tups in res.items():
