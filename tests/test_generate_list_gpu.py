@@ -217,3 +217,32 @@ def test_embedding_prompts_through_the_list(mode):
     assert [s_.shape[0] for s_ in out.sequences] == [out.tokens.shape[1]] * 18
     with pytest.raises(ValueError, match="replace input_ids"):
         eng.generate_list([torch.tensor([1, -200, 5])], None, inputs_embeds=emb[:1], eos_token_id=eos, pad_token_id=0)
+
+
+def test_short_lists_shared_images_and_one_question():
+    """Edges: fewer questions than slots, ONE question, six questions per image with the VCD branch (the clean prefix is shared across slots
+    and waves, every cd prompt has its own noise), a list shorter than one admission wave - each against generate() in batch-invariant mode."""
+    from llava_align_amd import ops
+    eng = _engine(W7B, n_layers=2, vit_layers=2)
+    ids, imgs = _prompts(3, 6, 32000, seed=29)                               # 18 questions, 6 per image
+    g = torch.Generator().manual_seed(4)
+    imgs_cd = [im + 0.5 * torch.randn(im.shape, generator=g).to(im.device, im.dtype) for im in imgs]
+    eos = _eos_set(1200, 8)
+    kw = dict(cd_alpha=1.0, cd_beta=0.1, cd_greedy=True, temperature=0.6, max_new_tokens=20, eos_token_id=eos, pad_token_id=0)
+    with ops.batch_invariant():
+        eng.retire = False
+        for sel, extra, fl in ((range(18), dict(images_cd=imgs_cd), 5), (range(3), dict(use_dd_unk=True), 8), ([7], dict(use_dd=True, use_dd_unk=True), 4),
+                               ([4], dict(images_cd=imgs_cd), 1)):
+            sel = list(sel)
+            ex = {k: ([v[i] for i in sel] if k == "images_cd" else v) for k, v in extra.items()}
+            ref = eng.generate([ids[i] for i in sel], images=[imgs[i] for i in sel], **kw, **ex)
+            out = eng.generate_list([ids[i] for i in sel], [imgs[i] for i in sel], in_flight=fl, sync_every=2, **kw, **ex)
+            T = min(ref.tokens.shape[1], out.tokens.shape[1])
+            assert torch.equal(ref.tokens[:, :T], out.tokens[:, :T]), (sel, list(extra))
+            assert out.stats["in_flight"] == min(fl, len(sel)) and out.stats["questions"] == len(sel)
+            for q, i in enumerate(sel):
+                assert torch.equal(out.sequences[q][: len(ids[i])].cpu(), ids[i]) and out.sequences[q].shape[0] == len(ids[i]) + out.tokens.shape[1]
+    with pytest.raises(ValueError, match="eos_token_id"):
+        eng.generate_list(ids[:2], imgs[:2], max_new_tokens=4)
+    with pytest.raises(ValueError, match="one images_cd entry per question"):
+        eng.generate_list(ids[:2], imgs[:2], images_cd=imgs_cd[:1], eos_token_id=eos, pad_token_id=0)
