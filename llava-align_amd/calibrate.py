@@ -104,50 +104,80 @@ def calibrate_sources(name: str) -> tuple:
     return ("naive",) if name == "naive" else ("naive",) + CALIBRATE_SOURCES.get(name, (name,))
 
 
+def _calibrated_row(p, cf, mode: str):
+    """One question, as the script computes it (eval_pope_calibrate.py:115-139): p, cf = the raw label probabilities of the answer and of the
+    prior (None: no prior).  -> q [2, 1], possibly NaN (neither label among a top-10: 0 / 0, no guard in the reference)."""
+    with np.errstate(invalid="ignore", divide="ignore"):
+        p = p / np.sum(p)
+        W, b = np.identity(2), np.zeros([2, 1])
+        if cf is not None:
+            cf = cf / np.sum(cf)
+            W, b = calibrate_weight([x + 1e-4 for x in cf], mode)
+        q = np.matmul(W, np.expand_dims(p, axis=-1)) + b
+        q /= np.sum(q)
+    return q
+
+
+def _calibrated_rows(P: np.ndarray, CF: Optional[np.ndarray], mode: str) -> np.ndarray:
+    """All questions at once, bit for bit the rows of `_calibrated_row` (tests/test_calibrate.py compares them): 3,000 questions x 4 settings
+    were 0.2 - 0.6 s of numpy calls on 2-vectors.  With W = inv(diag(c)) = diag(1 / c) exactly and b = 0, q = (p / c) renormalised; rows that
+    are not finite everywhere (and the identity_W mode) take the per-row path, whose NaN pattern decides their arg-max."""
+    n = P.shape[0]
+    with np.errstate(invalid="ignore", divide="ignore"):
+        p = P / (P[:, :1] + P[:, 1:])
+        if CF is None:
+            q = p.copy()
+        else:
+            c = CF / (CF[:, :1] + CF[:, 1:]) + 1e-4
+            q = (1.0 / c) * p
+        q = q / (q[:, :1] + q[:, 1:])
+    slow = ~np.isfinite(q).all(1) | ~np.isfinite(p).all(1)
+    if CF is not None:
+        slow |= ~np.isfinite(c).all(1)
+    if mode != "diagonal_W":
+        slow[:] = True
+    for i in np.nonzero(slow)[0]:
+        q[i] = _calibrated_row(P[i], None if CF is None else CF[i], mode).reshape(-1)
+    return q
+
+
 def pope_scores_calibrated(gt: Sequence[dict], gen: Sequence[dict], name: str = "naive", mode: str = "diagonal_W") -> dict:
     """'individual' calibration per question (eval_pope_calibrate.py:115-139): p from gen['naive'], prior from gen[name] ('none', 'unk',
     'noise', 'zero' / 'zeros', ...) or the sum of several ('none_unk', 'none_noise', 'none_unk_noise', 'all': CALIBRATE_SOURCES); arg-max of
     the calibrated 2-vector is the answer (0 = yes)."""
-    tp = tn = fp = fn = unknown = yes = total = nan_rows = 0
-    confidence = 0.0
     for g, a in zip(gt, gen):
         assert g["question_id"] == a["question_id"]
-        label = LABEL_TO_INT[g["label"]]
-        p = np.array(get_prob_from_logits(a["naive"]), dtype=np.float64)
-        with np.errstate(invalid="ignore", divide="ignore"):
-            p = p / np.sum(p)
-        W, b = np.identity(2), np.zeros([2, 1])
-        if name != "naive":
-            if name in CALIBRATE_SOURCES:
-                cf = np.array(get_prob_from_logits(a[CALIBRATE_SOURCES[name][0]]))
-                for src in CALIBRATE_SOURCES[name][1:]:
-                    cf = cf + np.array(get_prob_from_logits(a[src]))
-            else:
-                cf = np.array(get_prob_from_logits(a[name]), dtype=np.float64)
-            with np.errstate(invalid="ignore", divide="ignore"):
-                cf = cf / np.sum(cf)
-            W, b = calibrate_weight([x + 1e-4 for x in cf], mode)
-        with np.errstate(invalid="ignore", divide="ignore"):
-            q = np.matmul(W, np.expand_dims(p, axis=-1)) + b
-            q /= np.sum(q)
-        # neither label among the top-10 of the answer (or of the prior): 0 / 0 -> NaN, whose arg-max is class 0 = "yes" in the reference
-        # (eval_pope_calibrate.py:65-74 has no guard).  Scored the same way here, but counted: `nan_rows` of the result.
-        nan_rows += int(not np.all(np.isfinite(q)))
-        ans = int(np.argmax(q))
-        confidence += float(np.max(q))
+    n = len(gt)
+    labels = [LABEL_TO_INT[g["label"]] for g in gt]
+    P = np.array([get_prob_from_logits(a["naive"]) for a in gen], dtype=np.float64).reshape(n, 2)
+    CF = None
+    if name != "naive":
+        srcs = CALIBRATE_SOURCES.get(name, (name,))
+        CF = np.array([get_prob_from_logits(a[srcs[0]]) for a in gen], dtype=np.float64).reshape(n, 2)
+        for src in srcs[1:]:                                   # summed in the script's order
+            CF = CF + np.array([get_prob_from_logits(a[src]) for a in gen], dtype=np.float64).reshape(n, 2)
+    q = _calibrated_rows(P, CF, mode)
+    # neither label among the top-10 of the answer (or of the prior): 0 / 0 -> NaN, whose arg-max is class 0 = "yes" in the reference
+    # (eval_pope_calibrate.py:65-74 has no guard).  Scored the same way here, but counted: `nan_rows` of the result.
+    nan_rows = int((~np.isfinite(q).all(1)).sum())
+    ans = np.argmax(q, axis=1).tolist()                        # (the first NaN of a row, like np.argmax of the row alone)
+    confidence = 0.0
+    for v in np.max(q, axis=1).tolist():                       # accumulated in question order, as the script does
+        confidence += v
+    tp = tn = fp = fn = unknown = yes = 0
+    for label, a_ in zip(labels, ans):
         if label == 0:
-            if ans == 0:
+            if a_ == 0:
                 tp += 1; yes += 1
             else:
                 fn += 1
         else:
-            if ans == 1:
+            if a_ == 1:
                 tn += 1
             else:
                 yes += 1; fp += 1
-        total += 1
-    out = _prf(tp, tn, fp, fn, yes, unknown, total)
-    out["confidence"] = confidence / total
+    out = _prf(tp, tn, fp, fn, yes, unknown, n)
+    out["confidence"] = confidence / n
     out["nan_rows"] = nan_rows
     return out
 

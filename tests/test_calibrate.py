@@ -72,6 +72,31 @@ def test_every_calibration_setting_of_the_reference_script():
     assert C.calibrate_sources("all") == ("naive", "noise", "none", "zero", "unk")
 
 
+def test_vectorised_calibration_equals_the_per_question_arithmetic_bit_for_bit():
+    """calibrate._calibrated_rows (all questions at once) against calibrate._calibrated_row (the script's statements on one question): every
+    bit of q, NaN patterns included - rows without a label among the top-10 of the answer or of the prior, zero priors, tiny and huge
+    probabilities, both calibration modes."""
+    rng = np.random.default_rng(17)
+    n = 4000
+    P = rng.random((n, 2)) ** rng.integers(1, 8, size=(n, 1))
+    CF = rng.random((n, 2)) ** rng.integers(1, 8, size=(n, 1)) * rng.choice([1.0, 2.0, 4.0], size=(n, 1))     # sums of up to four priors
+    for rows, col in ((slice(0, 40), None), (slice(40, 80), 0), (slice(80, 120), 1)):
+        if col is None:
+            P[rows] = 0.0                                     # neither label in the answer's top-10
+        else:
+            P[rows, col] = 0.0
+    CF[100:160] = 0.0                                         # neither label in the prior's top-10
+    CF[160:200, 0] = 0.0
+    P[200:210] = 1e-300; CF[210:220] = 1e-300; P[220:230, 0] = 1e300
+    for mode in ("diagonal_W", "identity_W"):
+        for cf in (None, CF):
+            got = C._calibrated_rows(P, cf, mode)
+            want = np.stack([C._calibrated_row(P[i], None if cf is None else cf[i], mode).reshape(-1) for i in range(n)])
+            assert np.array_equal(got.view(np.int64), want.view(np.int64)), (mode, cf is None)
+            assert np.array_equal(np.argmax(got, 1), np.array([int(np.argmax(w)) for w in want]))
+    assert np.isnan(C._calibrated_rows(P, CF, "diagonal_W")).any(1).sum() >= 100
+
+
 def test_answer_writer_schema(tmp_path):
     p = tmp_path / "a.jsonl"
     with C.AnswerWriter(str(p)) as w:
