@@ -121,17 +121,33 @@ def run_pope(engine: VddLlavaEngine, questions: Sequence[dict], encode: Callable
     rows = ResultRows(engine.device, max_new_tokens, pad_token_id if pad_token_id is not None else 0, n_sets=3 + len(image_priors))
     img_cache: Dict[str, torch.Tensor] = {}
     invariant = resolve_batch_invariant(batch_invariant, plan.world, generate_kw)
-    with (ops.batch_invariant() if invariant else contextlib.nullcontext()):
-        for b0 in range(0, len(mine), batch_questions):
-            idx = mine[b0:b0 + batch_questions]
-            qs = [questions[i] for i in idx]
-            for q in qs:
-                if q["image"] not in img_cache:
-                    img_cache[q["image"]] = load_image(q["image"]).to(engine.device)
+    def host_inputs(b0):
+        """What a batch needs from the HOST - image files decoded / preprocessed (`load_image`), prompts tokenised (`encode`) - and nothing of the
+        device: prepared for batch k + 1 on a worker thread while the GPU runs batch k (the main thread sits in a stream wait then; with real
+        files the CLIP preprocessing of 128 images is of the order of the batch's GPU time)."""
+        idx = mine[b0:b0 + batch_questions]
+        qs = [questions[i] for i in idx]
+        host_imgs: Dict[str, torch.Tensor] = {}
+        for q in qs:
+            if q["image"] not in host_imgs and q["image"] not in img_cache:
+                host_imgs[q["image"]] = load_image(q["image"])
+        ids_main = [torch.tensor(encode(q["text"], True)) for q in qs]
+        ids_none = [torch.tensor(encode(q["text"], False)) for q in qs]
+        ids_unk = [torch.tensor([unk_token_id if t == IMAGE_TOKEN_INDEX else t for t in r.tolist()]) for r in ids_main]    # :59-60
+        return idx, qs, host_imgs, ids_main, ids_none, ids_unk
+
+    from concurrent.futures import ThreadPoolExecutor
+    starts = list(range(0, len(mine), batch_questions))
+    with (ops.batch_invariant() if invariant else contextlib.nullcontext()), ThreadPoolExecutor(max_workers=1) as pool:
+        ahead_inputs = pool.submit(host_inputs, starts[0]) if starts else None
+        for k, b0 in enumerate(starts):
+            idx, qs, host_imgs, ids_main, ids_none, ids_unk = ahead_inputs.result()
+            for name, im in host_imgs.items():
+                if name not in img_cache:
+                    img_cache[name] = im.to(engine.device)
+            if k + 1 < len(starts):
+                ahead_inputs = pool.submit(host_inputs, starts[k + 1])
             imgs = [img_cache[q["image"]] for q in qs]
-            ids_main = [torch.tensor(encode(q["text"], True)) for q in qs]
-            ids_none = [torch.tensor(encode(q["text"], False)) for q in qs]
-            ids_unk = [torch.tensor([unk_token_id if t == IMAGE_TOKEN_INDEX else t for t in r.tolist()]) for r in ids_main]    # :59-60
             kw = dict(generate_kw)
             if noise_step is not None:
                 from .vcd_add_noise import add_diffusion_noise
@@ -156,8 +172,8 @@ def run_pope(engine: VddLlavaEngine, questions: Sequence[dict], encode: Callable
                 tops.append((o.top_tok, o.top_prob))
             rows.add(idx, main.tokens, tops)
             ahead = {questions[i]["image"] for i in mine[b0 + batch_questions:b0 + 2 * batch_questions]}
-            for k in [k for k in img_cache if k not in ahead]:
-                img_cache.pop(k)                                   # images are revisited only within a sorted neighbourhood
+            for gone in [name for name in img_cache if name not in ahead]:
+                img_cache.pop(gone)                                # images are revisited only within a sorted neighbourhood (the worker's batch = `ahead`)
             engine.clear_image_cache()
     got = rows.gather(plan, len(questions))                    # ONE collective; every rank holds every question's results behind it
     eos_set = set([eos_token_id] if isinstance(eos_token_id, int) else (eos_token_id or []))

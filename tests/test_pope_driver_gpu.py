@@ -39,8 +39,15 @@ def test_run_pope_matches_the_per_question_reference_procedure(tmp_path):
     images = {f"img{i}.jpg": torch.randn(3, 56, 56, generator=torch.Generator().manual_seed(40 + i)) for i in range(3)}
     questions = [{"question_id": 100 + i, "image": f"img{i % 3}.jpg", "text": f"q{i}", "label": ("yes", "no")[i % 2]} for i in range(9)]
     path = tmp_path / "answers.jsonl"
-    res = run_pope(eng, questions, encode, decode, lambda name: images[name], answers_path=str(path), model_id="tiny", batch_questions=6,
+    import threading
+    loads = []
+
+    def load_image(name):                              # host work of batch k + 1 runs on a worker thread while the GPU decodes batch k
+        loads.append((name, threading.current_thread() is threading.main_thread()))
+        return images[name]
+    res = run_pope(eng, questions, encode, decode, load_image, answers_path=str(path), model_id="tiny", batch_questions=6,
                    unk_token_id=0, max_new_tokens=4, use_dd_unk=True, cd_alpha=1.0, cd_beta=0.1, temperature=0.5, cd_greedy=True)
+    assert sorted(n for n, _ in loads) == sorted(images) and not any(on_main for _, on_main in loads)      # each file once, none on the main thread
     lines = [json.loads(l) for l in open(path)]
     assert [l["question_id"] for l in lines] == [q["question_id"] for q in questions]
     assert all(tuple(l.keys()) == C.AnswerWriter.FIELDS for l in lines)
