@@ -644,7 +644,8 @@ def bench_config5(eng, dev, n_q=384):
 def bench_config2_full(eng, dev, n_items=3000, batch=768):
     """BASELINE config #2 as the reference's driver runs it (llava_calibrate.py:130-219): 3,000 POPE-like items (500 images x 6) through
     pope_driver.run_pope - main pass (use_dd_unk, alpha 1, beta 0.1, T 0.2, max_new_tokens 64, answers stopped by EOS after 1 - 2 tokens),
-    the none / unk prior passes, label dicts, the JSONL answers file and the plain + calibrated scorers.  The EOS ids are the second tokens
+    the none prior pass (the unk prior's label dict is read off the main pass's unk branch: the same ids), label dicts, the JSONL answers file and the plain +
+    calibrated scorers.  The EOS ids are the second tokens
     the same seeded list emits in an untimed pass (which is also the warm-up)."""
     import torch as _t
     _t.cuda.reset_peak_memory_stats(dev)
@@ -669,7 +670,7 @@ def bench_config2_full(eng, dev, n_items=3000, batch=768):
     n_tok = sum(len(a["text"].split()) for a in res["answers"])
     sc = res["scores"]
     out = {"workload": f"LLaVA-1.5-7B shapes, {n_items} POPE-like items = {n_items // 6} images x 6 in batches of {batch} through pope_driver.run_pope: main pass (use_dd_unk, alpha 1, "
-                       f"beta 0.1, T 0.2, max_new_tokens 64, {len(eos)} EOS ids -> answers of 1 - 2 tokens) + none / unk prior passes + label dicts + JSONL + scorers",
+                       f"beta 0.1, T 0.2, max_new_tokens 64, {len(eos)} EOS ids -> answers of 1 - 2 tokens) + none prior pass (unk prior = the main pass's unk branch) + label dicts + JSONL + scorers",
            "items": n_items, "seconds": round(dt, 3), "items_per_s": round(n_items / dt, 1), "answer_tokens_per_s": round(n_tok / dt, 1),
            "mean_answer_tokens": round(n_tok / n_items, 2), **_split_calls(eng, eng.call_log), "host_s": None,
            "answers_file_bytes": os.path.getsize(path), "scorers_ran": sorted(k for k, v in sc.items() if v is not None),

@@ -641,6 +641,7 @@ class GenerateOutput:
     top_tok: Optional[torch.Tensor] = None
     stats: dict = field(default_factory=dict)
     attentions: Optional["StepAttentions"] = None      # output_attentions=True with ONE question: what llava_calibrate.py:180 reads
+    branch_top: Optional[Dict[str, tuple]] = None      # branch_priors=True: {"unk" / "none": (top_tok, top_prob)} of that branch's OWN step-0 distribution
 
     def __getitem__(self, k):
         if k == "attentions" and self.attentions is not None:
@@ -1119,7 +1120,7 @@ class VddLlavaEngine:
                  min_length: Optional[int] = None, stop_words_ids=None, repetition_penalty: Optional[float] = None,
                  logits_processor=None, max_length: Optional[int] = None, num_beams: Optional[int] = None,
                  num_return_sequences: Optional[int] = None, embeds_prefix=None, streamer=None, output_attentions: bool = False,
-                 **other) -> GenerateOutput:
+                 branch_priors: bool = False, **other) -> GenerateOutput:
         """Same kwargs as the reference's model.generate(...) call (llava_calibrate.py:161-177); `input_ids` is a
         list of 1-D id tensors (one per question, each with one -200 image slot) or a [Q, L] tensor; `images` one
         image per question (repeat the SAME tensor for questions about the same image to share its features and
@@ -1365,6 +1366,16 @@ class VddLlavaEngine:
         if output_scores:
             scores.append(r0.scores)
         top_prob, top_tok = r0.top_prob, r0.top_tok
+        # branch_priors: the step-0 top-n of every image-free branch's OWN distribution under the call's warpers, no contrast - what a separate
+        # plain generate() over that branch's ids reports (the POPE driver's `unk` prior pass feeds exactly the ids of the `unk` branch,
+        # llava_calibrate.py:59-60 against vcd_sample.py:154-155: the same forward twice in the reference, once here)
+        branch_top = None
+        if branch_priors and n_top and inputs_embeds is None:
+            branch_top = {}
+            for bi, (bname, _, _) in enumerate(branches):
+                if bi and bname in ("unk", "none") and bname not in branch_top:
+                    rb = contrast_sample(logits0[bi * Q:(bi + 1) * Q], None, None, warp=warp, pick_argmax=True, seed=0, offset=0, n_top=n_top)
+                    branch_top[bname] = (rb.top_tok, rb.top_prob)
         # the VCD branch has no state of its own after step 0 (quirk #1): only the other branches keep decoding
         run.load(pos=[seg[i]["pos0"] + seg[i]["T"] for i in sel], cpos=[seg[i]["T"] for i in sel], slot=[seg[i]["slot"] for i in sel],
                  rows=dec_rows)
@@ -1471,7 +1482,7 @@ class VddLlavaEngine:
         stats["graph"] = run.graph is not None
         stats["n_groups"] = n_groups          # > 0: the decode steps ran the grouped (shared-prefix) attention
         return GenerateOutput(seqs_out, gen, scores, top_prob, top_tok, stats,
-                              attentions=StepAttentions(attn_maps, lm.n_layers, int(gen.shape[1])) if attn_maps is not None else None)
+                              attentions=StepAttentions(attn_maps, lm.n_layers, int(gen.shape[1])) if attn_maps is not None else None, branch_top=branch_top)
 
     # -- a question LIST with a bounded number in flight: waiting questions take the slots of finished ones -----------------------------
     @torch.no_grad()

@@ -89,7 +89,7 @@ def run_pope(engine: VddLlavaEngine, questions: Sequence[dict], encode: Callable
              model_id: str = "llava-align_amd", batch_questions: int = 384, unk_token_id: int = 0, eos_token_id=None,
              pad_token_id: Optional[int] = None, stop_str: Optional[str] = "</s>", max_new_tokens: int = 64, noise_step: Optional[int] = None,
              rank: Optional[int] = None, world: Optional[int] = None, batch_invariant: Optional[bool] = None,
-             image_priors: Sequence[str] = (), **generate_kw) -> dict:
+             image_priors: Sequence[str] = (), reuse_unk_branch: bool = True, **generate_kw) -> dict:
     """questions: dicts with question_id, image, text, label (the POPE json lines).  generate_kw: cd_alpha, cd_beta, use_dd,
     use_dd_unk, temperature, top_p, top_k, seed ... exactly the reference's model.generate kwargs (llava_calibrate.py:161-177);
     noise_step adds the VCD branch (images_cd = add_diffusion_noise(image, noise_step), :152-155).
@@ -105,6 +105,9 @@ def run_pope(engine: VddLlavaEngine, questions: Sequence[dict], encode: Callable
     image_priors: further content-free passes that keep the image prompt and swap the IMAGE - 'noise' = add_diffusion_noise(image, 999),
     'zeros', 'ones' (llava_calibrate.py:188-190 prepares them, experiments/eval/calibrate/test_samples_llava.py:134-145 runs them: plain
     sampling, step-0 label dict) - written under those keys and scored like the text priors.
+    reuse_unk_branch: with use_dd_unk the `unk` prior pass would feed the ids the main pass's `unk` branch already ran (image slot -> <unk>:
+    llava_calibrate.py:59-60 and vcd_sample.py:154-155 build the same row): its step-0 label dict is read off that branch
+    (generate(branch_priors=True)) and only the `none` prompts are prefilled again.  False: run it as a pass of its own, as the reference does.
     Returns {"answers": [...], "scores": {"string_match": ..., "naive": ..., "none": ..., "unk": ..., "none_unk": ...}}."""
     import contextlib
     image_priors = tuple(image_priors)
@@ -153,14 +156,22 @@ def run_pope(engine: VddLlavaEngine, questions: Sequence[dict], encode: Callable
                 from .vcd_add_noise import add_diffusion_noise
                 # fresh noise per QUESTION, as the reference draws it inside its per-question loop (llava_calibrate.py:152-155)
                 kw["images_cd"] = [add_diffusion_noise(img_cache[q["image"]], noise_step) for q in qs]
+            # the engine's `unk` branch replaces the slot by token 0 (the reference's literal, :154-155); it exists unless the VCD branch took its place
+            from_branch = bool(reuse_unk_branch and generate_kw.get("use_dd_unk") and unk_token_id == 0 and noise_step is None
+                               and generate_kw.get("do_sample", True) is not False)
             main = engine.generate(ids_main, images=imgs, max_new_tokens=max_new_tokens, n_top=10, eos_token_id=eos_token_id,
-                                   pad_token_id=pad_token_id, **kw)
+                                   pad_token_id=pad_token_id, branch_priors=from_branch, **kw)
             # content-free priors: plain sampling (no image -> no contrast branch), step-0 distribution only
             plain_kw = {k: v for k, v in generate_kw.items() if k in ("temperature", "top_p", "top_k", "seed", "cd_alpha", "cd_beta")}
-            # (one call for both priors: 2 x len(qs) text-only prompts that share the conversation template's system prompt as a prefix slot)
-            prior = engine.generate(ids_none + ids_unk, images=None, max_new_tokens=1, n_top=10, **plain_kw)
             n = len(qs)
-            tops = [(main.top_tok, main.top_prob), (prior.top_tok[:n], prior.top_prob[:n]), (prior.top_tok[n:], prior.top_prob[n:])]
+            if from_branch and main.branch_top and "unk" in main.branch_top:
+                prior = engine.generate(ids_none, images=None, max_new_tokens=1, n_top=10, **plain_kw)
+                unk_top = main.branch_top["unk"]
+            else:
+                # (one call for both priors: 2 x len(qs) text-only prompts that share the conversation template's system prompt as a prefix slot)
+                prior = engine.generate(ids_none + ids_unk, images=None, max_new_tokens=1, n_top=10, **plain_kw)
+                unk_top = (prior.top_tok[n:], prior.top_prob[n:])
+            tops = [(main.top_tok, main.top_prob), (prior.top_tok[:n], prior.top_prob[:n]), unk_top]
             for name in image_priors:
                 if name == "noise":                                  # fresh noise per question, as the reference draws it inside its loop
                     from .vcd_add_noise import add_diffusion_noise

@@ -113,3 +113,32 @@ def test_image_priors_swap_the_image_and_keep_the_prompt(tmp_path):
         assert a["noise"] != a["zeros"] and a["zeros"] != a["naive"]
     with pytest.raises(ValueError, match="image_priors"):
         run_pope(eng, questions, encode, decode, lambda name: images[name], image_priors=("white",))
+
+
+def test_unk_prior_is_read_off_the_unk_branch_of_the_main_pass():
+    """With use_dd_unk the `unk` prior prompt IS the main pass's `unk` branch (llava_calibrate.py:59-60 / vcd_sample.py:154-155 build the same
+    ids): run_pope reads its step-0 label dict off that branch instead of prefilling the prompt a second time.  In batch-invariant mode
+    (cd_greedy) a row's logits do not depend on its batch, so the dicts equal those of the separate pass bit for bit; without use_dd_unk,
+    with another <unk> id or with the VCD branch in the unk branch's place the separate pass runs."""
+    from llava_align_amd.engine import LlavaWeights, VddLlavaEngine, preset
+    from llava_align_amd.pope_driver import run_pope
+    cfg = preset("tiny")
+    eng = VddLlavaEngine(cfg, weights=LlavaWeights.random(cfg, DEV, seed=3, std=0.06), device=DEV, use_graph=False)
+    images = {f"img{i}.jpg": torch.randn(3, 56, 56, generator=torch.Generator().manual_seed(40 + i)) for i in range(3)}
+    questions = [{"question_id": i, "image": f"img{i % 3}.jpg", "text": f"q{i}", "label": ("yes", "no")[i % 2]} for i in range(9)]
+    calls = []
+    real = eng.generate
+    eng.generate = lambda *a, **k: calls.append((len(a[0]), k.get("branch_priors", False))) or real(*a, **k)
+    kw = dict(batch_questions=6, unk_token_id=0, max_new_tokens=3, cd_alpha=1.0, cd_beta=0.1, temperature=0.5, cd_greedy=True)
+    a = run_pope(eng, questions, encode, decode, lambda n: images[n], use_dd_unk=True, **kw)
+    assert calls == [(6, True), (6, False), (3, True), (3, False)]                    # main + the `none` prompts only
+    calls.clear()
+    b = run_pope(eng, questions, encode, decode, lambda n: images[n], use_dd_unk=True, reuse_unk_branch=False, **kw)
+    assert calls == [(6, False), (12, False), (3, False), (6, False)]                 # main + none and unk prompts
+    assert [x["unk"] for x in a["answers"]] == [x["unk"] for x in b["answers"]] and [x["none"] for x in a["answers"]] == [x["none"] for x in b["answers"]]
+    assert [x["text"] for x in a["answers"]] == [x["text"] for x in b["answers"]]
+    assert json.dumps(a["scores"], sort_keys=True) == json.dumps(b["scores"], sort_keys=True)       # (NaN confidences compare as text)
+    for extra in (dict(use_dd=True), dict(use_dd_unk=True, unk_token_id=5), dict(use_dd_unk=True, noise_step=500)):
+        calls.clear()
+        run_pope(eng, questions[:3], encode, decode, lambda n: images[n], **{**kw, **extra})
+        assert calls[1] == (6, False) and not calls[0][1], extra
