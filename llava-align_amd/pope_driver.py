@@ -123,6 +123,7 @@ def run_pope(engine: VddLlavaEngine, questions: Sequence[dict], encode: Callable
         generate_kw = dict(generate_kw, seed=int(generate_kw["seed"]) + plan.rank)
     rows = ResultRows(engine.device, max_new_tokens, pad_token_id if pad_token_id is not None else 0, n_sets=3 + len(image_priors))
     img_cache: Dict[str, torch.Tensor] = {}
+    prior_prompts = prior_distinct = 0
     invariant = resolve_batch_invariant(batch_invariant, plan.world, generate_kw)
     def host_inputs(b0):
         """What a batch needs from the HOST - image files decoded / preprocessed (`load_image`), prompts tokenised (`encode`) - and nothing of the
@@ -164,14 +165,24 @@ def run_pope(engine: VddLlavaEngine, questions: Sequence[dict], encode: Callable
             # content-free priors: plain sampling (no image -> no contrast branch), step-0 distribution only
             plain_kw = {k: v for k, v in generate_kw.items() if k in ("temperature", "top_p", "top_k", "seed", "cd_alpha", "cd_beta")}
             n = len(qs)
-            if from_branch and main.branch_top and "unk" in main.branch_top:
-                prior = engine.generate(ids_none, images=None, max_new_tokens=1, n_top=10, **plain_kw)
-                unk_top = main.branch_top["unk"]
-            else:
-                # (one call for both priors: 2 x len(qs) text-only prompts that share the conversation template's system prompt as a prefix slot)
-                prior = engine.generate(ids_none + ids_unk, images=None, max_new_tokens=1, n_top=10, **plain_kw)
-                unk_top = (prior.top_tok[n:], prior.top_prob[n:])
-            tops = [(main.top_tok, main.top_prob), (prior.top_tok[:n], prior.top_prob[:n]), unk_top]
+            reuse = from_branch and main.branch_top and "unk" in main.branch_top
+            # (one call for both priors: text-only prompts that share the conversation template's system prompt as a prefix slot.)  POPE asks the
+            # same few dozen questions ("Is there a <object> in the image?") about hundreds of images, and a text-only prompt's step-0 label dict
+            # is a function of its ids alone (the top-n of the warped distribution: nothing is drawn): every DISTINCT prompt is run once
+            want = ids_none if reuse else ids_none + ids_unk
+            first: Dict[tuple, int] = {}
+            where = [first.setdefault(tuple(r.tolist()), len(first)) for r in want]
+            uniq = [None] * len(first)
+            for r, j in zip(want, where):
+                if uniq[j] is None:
+                    uniq[j] = r
+            prior = engine.generate(uniq, images=None, max_new_tokens=1, n_top=10, **plain_kw)
+            back = torch.tensor(where, dtype=torch.long).to(prior.top_tok.device, non_blocking=True)
+            p_tok, p_prob = prior.top_tok[back], prior.top_prob[back]
+            unk_top = main.branch_top["unk"] if reuse else (p_tok[n:], p_prob[n:])
+            tops = [(main.top_tok, main.top_prob), (p_tok[:n], p_prob[:n]), unk_top]
+            prior_prompts = prior_prompts + len(want)
+            prior_distinct = prior_distinct + len(uniq)
             for name in image_priors:
                 if name == "noise":                                  # fresh noise per question, as the reference draws it inside its loop
                     from .vcd_add_noise import add_diffusion_noise
@@ -208,7 +219,8 @@ def run_pope(engine: VddLlavaEngine, questions: Sequence[dict], encode: Callable
         scores["string_match"] = _try(C.pope_scores, gt, ordered)
         for name in ("naive", "none", "unk", "none_unk") + image_priors:
             scores[name] = _try(C.pope_scores_calibrated, gt, ordered, name)
-    return {"answers": ordered, "scores": scores, "rank": plan.rank, "world": plan.world, "batch_invariant": invariant}
+    return {"answers": ordered, "scores": scores, "rank": plan.rank, "world": plan.world, "batch_invariant": invariant,
+            "prior_prompts": prior_prompts, "prior_prompts_run": prior_distinct}
 
 
 def _try(f, *a):

@@ -142,3 +142,27 @@ def test_unk_prior_is_read_off_the_unk_branch_of_the_main_pass():
         calls.clear()
         run_pope(eng, questions[:3], encode, decode, lambda n: images[n], **{**kw, **extra})
         assert calls[1] == (6, False) and not calls[0][1], extra
+
+
+def test_repeated_question_texts_run_their_prior_prompt_once():
+    """POPE asks the same questions about many images: a text-only prior prompt's step-0 label dict depends on its ids alone, so run_pope runs
+    every distinct prompt once and hands the result to all its questions - the dicts a per-question pass gives (batch-invariant mode: bit for bit)."""
+    from llava_align_amd import calibrate as C
+    from llava_align_amd import ops
+    from llava_align_amd.engine import LlavaWeights, VddLlavaEngine, preset
+    from llava_align_amd.pope_driver import run_pope
+    cfg = preset("tiny")
+    eng = VddLlavaEngine(cfg, weights=LlavaWeights.random(cfg, DEV, seed=3, std=0.06), device=DEV, use_graph=False)
+    images = {f"img{i}.jpg": torch.randn(3, 56, 56, generator=torch.Generator().manual_seed(40 + i)) for i in range(4)}
+    questions = [{"question_id": i, "image": f"img{i % 4}.jpg", "text": f"q{i % 3}", "label": ("yes", "no")[i % 2]} for i in range(12)]     # 3 distinct texts
+    kw = dict(unk_token_id=0, max_new_tokens=2, cd_alpha=1.0, cd_beta=0.1, temperature=0.5, cd_greedy=True)
+    a = run_pope(eng, questions, encode, decode, lambda n: images[n], batch_questions=12, use_dd_unk=True, **kw)
+    assert (a["prior_prompts"], a["prior_prompts_run"]) == (12, 3)
+    b = run_pope(eng, questions, encode, decode, lambda n: images[n], batch_questions=12, use_dd=True, **kw)                                  # none + unk prompts
+    assert (b["prior_prompts"], b["prior_prompts_run"]) == (24, 6)
+    with ops.batch_invariant():
+        o = eng.generate([torch.tensor(encode(q["text"], False)) for q in questions], images=None, max_new_tokens=1, n_top=10, temperature=0.5)
+    want = [C.label_dict_from_top(t, p_, decode_token) for t, p_ in zip(o.top_tok.tolist(), o.top_prob.tolist())]
+    assert [x["none"] for x in a["answers"]] == want == [x["none"] for x in b["answers"]]
+    assert [x["unk"] for x in a["answers"]] == [x["unk"] for x in b["answers"]]
+    assert len({json.dumps(x["none"], sort_keys=True) for x in a["answers"]}) == 3
