@@ -1794,6 +1794,8 @@ class VddLlavaEngine:
                      mean_live_rows=round(live_row_steps / max(steps, 1), 1), n_groups=0)
         return GenerateOutput(seqs_out, gen, None, top_prob, top_tok, stats)
 
+    share_repeated_rows = True        # _plan: image-free rows with identical ids share all but their last position
+    REPEATED_ROWS_MIN_SAVED = 256     # ... when that saves at least this many prefill tokens in a branch (every distinct row takes a prefix slot)
     KV_MEMORY_FRACTION = 0.92     # of what is free (+ what the pools being replaced give back): the rest is prefill activations, logits, graphs
 
     def _fit_in_flight(self, Qc: int, dims) -> int:
@@ -1959,6 +1961,17 @@ class VddLlavaEngine:
                     else:
                         suffix.append(dict(slot=len(suffix), tokens=None, pre=[], img=feats[qi], suf=[], T=T, pos0=0, pslot=0, plen=0))
                 continue
+            # image-free rows with the SAME ids (POPE asks "Is there a <object> in the image?" about hundreds of images: a 768-question batch holds
+            # a few dozen distinct `unk` / `none` rows): everything but the last position is one prefix slot per distinct row - prefilled once,
+            # attended by all its rows through the grouped pass; each row keeps its last token and what it generates in its own slot
+            repeated = set()
+            if share_prefix and self.share_repeated_rows and feats is None:
+                seen: Dict[tuple, int] = {}
+                for ids in rows:
+                    k_ = tuple(ids)
+                    seen[k_] = seen.get(k_, 0) + 1
+                if sum((c_ - 1) * (len(k_) - 1) for k_, c_ in seen.items() if c_ > 1) >= self.REPEATED_ROWS_MIN_SAVED:
+                    repeated = {k_ for k_, c_ in seen.items() if c_ > 1 and len(k_) > 1}
             for qi, ids in enumerate(rows):
                 src = main_rows[qi]
                 s_img = src.index(IMAGE_TOKEN_INDEX) if IMAGE_TOKEN_INDEX in src else None
@@ -1967,7 +1980,9 @@ class VddLlavaEngine:
                     pre_tok, suf_tok, plen = ids[:s_img], ids[s_img + 1:], s_img + n_img_tok
                     key = (tuple(pre_tok), img.data_ptr())
                 else:
-                    if s_img is None:
+                    if repeated and tuple(ids) in repeated:
+                        cut = len(ids) - 1
+                    elif s_img is None:
                         cut = self._common_split(rows) if share_prefix else 0
                     else:
                         cut = s_img + 1 if name == "unk" else s_img     # unk keeps the one <unk> token in the prefix (quirk #3)

@@ -126,3 +126,49 @@ def test_prefill_planning_choices_do_not_change_a_bit_in_the_mode():
         finally:
             eng.two_level_prefix = True
         assert same(base, run(share_prefix=False))
+
+
+def test_repeated_image_free_rows_share_their_prompt_without_changing_a_bit():
+    """POPE repeats a few dozen question texts over hundreds of images: the `unk` / `none` rows (and text-only prompts) with identical ids share
+    everything but their last position (engine._plan, share_repeated_rows).  Fewer prefill tokens, the same score rows at every step - the rows
+    diverge after step 0 (each follows its own question's sampled tokens) in their own slots."""
+    from llava_align_amd import ops
+    eng = _engine(W7B, n_layers=3, vit_layers=2)
+    ids, imgs = _prompts(8, 6, 32000, seed=71)                                   # 48 questions, 6 per image
+    texts = [ids[k][ids[k].tolist().index(-200) + 1:] for k in range(4)]         # four question texts asked about every image
+    ids = [torch.cat([r[: r.tolist().index(-200) + 1], texts[i % 4]]) for i, r in enumerate(ids)]
+    kw = dict(images=imgs, cd_alpha=1.0, cd_beta=0.1, cd_greedy=True, output_scores=True, max_new_tokens=6, temperature=1.0, top_p=0.9)
+
+    def run(**over):
+        eng._kvs.clear(); eng._graphs.clear(); eng._kv = None
+        return eng.generate(ids, **dict(kw, **over))
+    same = lambda a, b: torch.equal(a.tokens, b.tokens) and all(torch.equal(x.view(torch.int16), y.view(torch.int16)) for x, y in zip(a.scores, b.scores))
+    with ops.batch_invariant():
+        for mode in (dict(use_dd_unk=True), dict(use_dd=True, use_dd_unk=True)):
+            shared = run(**mode)
+            try:
+                eng.share_repeated_rows = False
+                plain = run(**mode)
+            finally:
+                eng.share_repeated_rows = True
+            n_free = 2 if len(mode) == 2 else 1
+            assert plain.stats["prefill_tokens"] - shared.stats["prefill_tokens"] >= n_free * 44 * 15 and same(shared, plain), mode
+            assert len({tuple(t) for t in shared.tokens.tolist()}) > 8           # the questions decode differently although their image-free rows started equal
+        # text-only prompts (the calibrate drivers' prior passes): 48 prompts, 4 distinct
+        text_only = [torch.tensor([t for t in r.tolist() if t != -200]) for r in ids]
+        a = eng.generate(text_only, images=None, max_new_tokens=3, temperature=0.5, cd_greedy=True, output_scores=True, n_top=10)
+        try:
+            eng.share_repeated_rows = False
+            eng._kvs.clear(); eng._graphs.clear(); eng._kv = None
+            b = eng.generate(text_only, images=None, max_new_tokens=3, temperature=0.5, cd_greedy=True, output_scores=True, n_top=10)
+        finally:
+            eng.share_repeated_rows = True
+        assert same(a, b) and torch.equal(a.top_prob, b.top_prob) and a.stats["prefill_tokens"] < b.stats["prefill_tokens"]
+    # the tuned forms take the same plan (grouped attention over the shared rows too); their low-order bits depend on the plan, the first tokens agree
+    t = run(use_dd_unk=True)
+    try:
+        eng.share_repeated_rows = False
+        u = run(use_dd_unk=True)
+    finally:
+        eng.share_repeated_rows = True
+    assert t.stats["n_groups"] > u.stats["n_groups"] >= 8 and (t.tokens[:, 0] == u.tokens[:, 0]).float().mean().item() >= 0.9
