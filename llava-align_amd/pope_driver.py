@@ -187,11 +187,19 @@ def run_pope(engine: VddLlavaEngine, questions: Sequence[dict], encode: Callable
                 if name == "noise":                                  # fresh noise per question, as the reference draws it inside its loop
                     from .vcd_add_noise import add_diffusion_noise
                     swapped = [add_diffusion_noise(im, 999) for im in imgs]
-                else:                                                # ONE tensor object: every question shares its features and prompt prefix
-                    const = (torch.zeros_like if name == "zeros" else torch.ones_like)(imgs[0])
-                    swapped = [const] * n
-                o = engine.generate(ids_main, images=swapped, max_new_tokens=1, n_top=10, **plain_kw)
-                tops.append((o.top_tok, o.top_prob))
+                    o = engine.generate(ids_main, images=swapped, max_new_tokens=1, n_top=10, **plain_kw)
+                    tops.append((o.top_tok, o.top_prob))
+                else:                                                # ONE tensor object: every question shares its features and prompt prefix,
+                    const = (torch.zeros_like if name == "zeros" else torch.ones_like)(imgs[0])          # and every distinct question text runs once
+                    first_i: Dict[tuple, int] = {}
+                    where_i = [first_i.setdefault(tuple(r.tolist()), len(first_i)) for r in ids_main]
+                    uniq_i = [None] * len(first_i)
+                    for r, j in zip(ids_main, where_i):
+                        if uniq_i[j] is None:
+                            uniq_i[j] = r
+                    o = engine.generate(uniq_i, images=[const] * len(uniq_i), max_new_tokens=1, n_top=10, **plain_kw)
+                    back_i = torch.tensor(where_i, dtype=torch.long).to(o.top_tok.device, non_blocking=True)
+                    tops.append((o.top_tok[back_i], o.top_prob[back_i]))
             rows.add(idx, main.tokens, tops)
             ahead = {questions[i]["image"] for i in mine[b0 + batch_questions:b0 + 2 * batch_questions]}
             for gone in [name for name in img_cache if name not in ahead]:
