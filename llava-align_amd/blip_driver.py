@@ -98,12 +98,17 @@ def run_blip_pope(engine: VddLlavaEngine, front: InstructBlipFrontEnd, questions
             main = engine.generate(None, inputs_embeds=emb, images_cd=emb_cd, max_length=max_length, **base_kw)
             noise999 = torch.stack([add_diffusion_noise(im, 999) for im in imgs])
             emb_n = front.assemble(front.embeds_to_llm(front.image_embeds(noise999), qf_ids), llm_ids, embed)
-            ie_zero = front.image_embeds(torch.zeros_like(uniq[:1])).expand(len(qs), -1, -1).contiguous()
-            emb_z = front.assemble(front.embeds_to_llm(ie_zero, qf_ids), llm_ids, embed)
+            # the zero image's prior depends on the question text alone (POPE repeats its texts over the images): Q-Former + LLM once per distinct prompt
+            first_z: Dict[str, int] = {}
+            where_z = [first_z.setdefault(p, len(first_z)) for p in prompts]
+            pick_z = [prompts.index(p) for p in first_z]
+            ie_zero = front.image_embeds(torch.zeros_like(uniq[:1])).expand(len(pick_z), -1, -1).contiguous()
+            emb_z = front.assemble(front.embeds_to_llm(ie_zero, [qf_ids[j] for j in pick_z]), [llm_ids[j] for j in pick_z], embed)
             prior_kw = {k: v for k, v in base_kw.items() if k not in ("cd_beta", "cd_alpha")}
             noise = engine.generate(None, inputs_embeds=emb_n, max_length=1, **prior_kw)
             zeros = engine.generate(None, inputs_embeds=emb_z, max_length=1, **prior_kw)
-            rows.add(idx, map_pad_to_eos(main.tokens), [(o.top_tok, o.top_prob) for o in (main, noise, zeros)])
+            back_z = torch.tensor(where_z, dtype=torch.long).to(zeros.top_tok.device, non_blocking=True)
+            rows.add(idx, map_pad_to_eos(main.tokens), [(main.top_tok, main.top_prob), (noise.top_tok, noise.top_prob), (zeros.top_tok[back_z], zeros.top_prob[back_z])])
     got = rows.gather(plan, len(questions))                    # ONE collective; every rank holds every question's results behind it
     dicts = [[C.label_dict_from_top(t, p_, decode_token) for t, p_ in got["tops"][s_]] for s_ in range(3)]
     ordered = [{"question_id": q["question_id"], "prompt": q["text"] + QUESTION_SUFFIX, "text": decode(cut_at_eos(got["tokens"][i], eos_set)).strip(),

@@ -129,11 +129,20 @@ def run_qwen_pope(engine: VddLlavaEngine, questions: Sequence[dict], embed_promp
             main = gen(texts, imgs, [("clean", q["image"]) for q in qs], max_new_tokens=max_new_tokens, min_new_tokens=min_new_tokens, n_top=10,
                        eos_token_id=eos_token_id, pad_token_id=pad_token_id, **kw)
             tops = [(main.top_tok, main.top_prob)]
+            def text_only(fmt):
+                """POPE repeats its question texts over the images, and a text-only prompt's step-0 label dict depends on the text alone: every
+                distinct prompt runs once"""
+                ts = [fmt.format(q["text"]) for q in qs]
+                first = {}
+                where = [first.setdefault(t, len(first)) for t in ts]
+                o_ = gen(list(first), [None] * len(first), [None] * len(first), **prior_kw)
+                back = torch.tensor(where, dtype=torch.long).to(o_.top_tok.device, non_blocking=True)
+                return type("Top", (), {"top_tok": o_.top_tok[back], "top_prob": o_.top_prob[back]})
             for name in priors:
                 if name == "none":
-                    o = gen(["{} Answer:".format(q["text"]) for q in qs], [None] * len(qs), [None] * len(qs), **prior_kw)
+                    o = text_only("{} Answer:")
                 elif name == "unk":
-                    o = gen(["{} {} Answer:".format("None", q["text"]) for q in qs], [None] * len(qs), [None] * len(qs), **prior_kw)
+                    o = text_only("None {} Answer:")
                 elif name == "noise":
                     o = gen(texts, [add_diffusion_noise(im, 999) for im in imgs], [None] * len(qs), **prior_kw)
                 else:             # one zero image per tensor shape: the span's rows replace the path bytes, so EVERY question shares them
