@@ -89,7 +89,7 @@ def run_pope(engine: VddLlavaEngine, questions: Sequence[dict], encode: Callable
              model_id: str = "llava-align_amd", batch_questions: int = 384, unk_token_id: int = 0, eos_token_id=None,
              pad_token_id: Optional[int] = None, stop_str: Optional[str] = "</s>", max_new_tokens: int = 64, noise_step: Optional[int] = None,
              rank: Optional[int] = None, world: Optional[int] = None, batch_invariant: Optional[bool] = None,
-             image_priors: Sequence[str] = (), reuse_unk_branch: bool = True, **generate_kw) -> dict:
+             image_priors: Sequence[str] = (), reuse_unk_branch: bool = True, image_workers: int = 8, **generate_kw) -> dict:
     """questions: dicts with question_id, image, text, label (the POPE json lines).  generate_kw: cd_alpha, cd_beta, use_dd,
     use_dd_unk, temperature, top_p, top_k, seed ... exactly the reference's model.generate kwargs (llava_calibrate.py:161-177);
     noise_step adds the VCD branch (images_cd = add_diffusion_noise(image, noise_step), :152-155).
@@ -105,6 +105,7 @@ def run_pope(engine: VddLlavaEngine, questions: Sequence[dict], encode: Callable
     image_priors: further content-free passes that keep the image prompt and swap the IMAGE - 'noise' = add_diffusion_noise(image, 999),
     'zeros', 'ones' (llava_calibrate.py:188-190 prepares them, experiments/eval/calibrate/test_samples_llava.py:134-145 runs them: plain
     sampling, step-0 label dict) - written under those keys and scored like the text priors.
+    image_workers: threads that run `load_image` for the NEXT batch's files while the GPU runs the current batch.
     reuse_unk_branch: with use_dd_unk the `unk` prior pass would feed the ids the main pass's `unk` branch already ran (image slot -> <unk>:
     llava_calibrate.py:59-60 and vcd_sample.py:154-155 build the same row): its step-0 label dict is read off that branch
     (generate(branch_priors=True)) and only the `none` prompts are prefilled again.  False: run it as a pass of its own, as the reference does.
@@ -131,10 +132,8 @@ def run_pope(engine: VddLlavaEngine, questions: Sequence[dict], encode: Callable
         files the CLIP preprocessing of 128 images is of the order of the batch's GPU time)."""
         idx = mine[b0:b0 + batch_questions]
         qs = [questions[i] for i in idx]
-        host_imgs: Dict[str, torch.Tensor] = {}
-        for q in qs:
-            if q["image"] not in host_imgs and q["image"] not in img_cache:
-                host_imgs[q["image"]] = load_image(q["image"])
+        names = list(dict.fromkeys(q["image"] for q in qs if q["image"] not in img_cache))
+        host_imgs: Dict[str, torch.Tensor] = dict(zip(names, loaders.map(load_image, names)))        # (PIL decoding / resizing releases the GIL)
         ids_main = [torch.tensor(encode(q["text"], True)) for q in qs]
         ids_none = [torch.tensor(encode(q["text"], False)) for q in qs]
         ids_unk = [torch.tensor([unk_token_id if t == IMAGE_TOKEN_INDEX else t for t in r.tolist()]) for r in ids_main]    # :59-60
@@ -142,7 +141,8 @@ def run_pope(engine: VddLlavaEngine, questions: Sequence[dict], encode: Callable
 
     from concurrent.futures import ThreadPoolExecutor
     starts = list(range(0, len(mine), batch_questions))
-    with (ops.batch_invariant() if invariant else contextlib.nullcontext()), ThreadPoolExecutor(max_workers=1) as pool:
+    with (ops.batch_invariant() if invariant else contextlib.nullcontext()), ThreadPoolExecutor(max_workers=1) as pool, \
+            ThreadPoolExecutor(max_workers=image_workers) as loaders:
         ahead_inputs = pool.submit(host_inputs, starts[0]) if starts else None
         for k, b0 in enumerate(starts):
             idx, qs, host_imgs, ids_main, ids_none, ids_unk = ahead_inputs.result()
