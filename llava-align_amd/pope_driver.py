@@ -165,7 +165,8 @@ def run_pope(engine: VddLlavaEngine, questions: Sequence[dict], encode: Callable
             # content-free priors: plain sampling (no image -> no contrast branch), step-0 distribution only
             plain_kw = {k: v for k, v in generate_kw.items() if k in ("temperature", "top_p", "top_k", "seed", "cd_alpha", "cd_beta")}
             n = len(qs)
-            reuse = from_branch and main.branch_top and "unk" in main.branch_top
+            branch_top = getattr(main, "branch_top", None) or {}
+            reuse = from_branch and "unk" in branch_top
             # (one call for both priors: text-only prompts that share the conversation template's system prompt as a prefix slot.)  POPE asks the
             # same few dozen questions ("Is there a <object> in the image?") about hundreds of images, and a text-only prompt's step-0 label dict
             # is a function of its ids alone (the top-n of the warped distribution: nothing is drawn): every DISTINCT prompt is run once
@@ -179,7 +180,7 @@ def run_pope(engine: VddLlavaEngine, questions: Sequence[dict], encode: Callable
             prior = engine.generate(uniq, images=None, max_new_tokens=1, n_top=10, **plain_kw)
             back = torch.tensor(where, dtype=torch.long).to(prior.top_tok.device, non_blocking=True)
             p_tok, p_prob = prior.top_tok[back], prior.top_prob[back]
-            unk_top = main.branch_top["unk"] if reuse else (p_tok[n:], p_prob[n:])
+            unk_top = branch_top["unk"] if reuse else (p_tok[n:], p_prob[n:])
             tops = [(main.top_tok, main.top_prob), (p_tok[:n], p_prob[:n]), unk_top]
             prior_prompts = prior_prompts + len(want)
             prior_distinct = prior_distinct + len(uniq)
