@@ -688,3 +688,39 @@ def test_vocabulary_that_is_not_a_multiple_of_eight(n_img, per_img):
             if outs[True].tokens[q, step].item() != r.sequences[0, ids[q].numel() + step].item():
                 break
     assert checked >= 2
+
+
+def test_reuse_prefill_decodes_again_from_the_kept_state():
+    """A sweep over sampling settings asks for the same prompts again (MME/run_llava.py:281-318 runs 51 settings over one question file): with
+    reuse_prefill the second call skips the vision tower and the prefill and decodes from the first call's pools and step-0 logits - tokens and
+    step-0 top-10 equal a fresh call's for the same seed, for another temperature too; any other call into the same pools drops the kept state."""
+    from test_engine_shapes_gpu import _engine, _prompts
+    eng = _engine(dict(d=4096, n_heads=32, n_kv_heads=32, head_dim=128, ffn=11008, vocab=32000), n_layers=2, vit_layers=2)
+    ids, imgs = _prompts(4, 6, 32000, seed=3)
+    other_ids, other_imgs = _prompts(2, 6, 32000, seed=4)
+    kw = dict(images=imgs, use_dd_unk=True, cd_alpha=1.0, cd_beta=0.1, max_new_tokens=8, n_top=10, seed=5)
+    towers = []
+    real = eng.image_features
+    eng.image_features = lambda *a, **k: towers.append(1) or real(*a, **k)
+    same = lambda a, b: torch.equal(a.tokens, b.tokens) and torch.equal(a.top_tok, b.top_tok) and torch.equal(a.top_prob, b.top_prob)
+    fresh = eng.generate(ids, temperature=0.7, **kw)
+    first = eng.generate(ids, temperature=0.7, reuse_prefill=True, **kw)
+    n0 = len(towers)
+    again = eng.generate(ids, temperature=0.7, reuse_prefill=True, **kw)
+    cold = eng.generate(ids, temperature=0.3, top_p=0.9, **kw)
+    warm = eng.generate(ids, temperature=0.7, reuse_prefill=True, **kw)                       # `cold` overwrote the pools: a miss that prefills again
+    n1 = len(towers)
+    swept = eng.generate(ids, temperature=0.3, top_p=0.9, reuse_prefill=True, **kw)
+    short = eng.generate(ids, temperature=0.3, top_p=0.9, reuse_prefill=True, **dict(kw, max_new_tokens=3))
+    assert not first.stats["prefill_reused"] and again.stats["prefill_reused"] and again.stats["prefill_tokens"] == 0 and n0 + 2 == n1 - 0
+    assert not warm.stats["prefill_reused"] and swept.stats["prefill_reused"] and short.stats["prefill_reused"] and len(towers) == n1
+    assert same(fresh, first) and same(fresh, again) and same(fresh, warm) and same(cold, swept)
+    assert torch.equal(short.tokens, cold.tokens[:, :3])
+    assert not eng.generate(ids, temperature=0.3, reuse_prefill=True, **dict(kw, max_new_tokens=12)).stats["prefill_reused"]      # more new tokens than kept room
+    eng.generate(other_ids, images=other_imgs, max_new_tokens=4, use_dd_unk=True)
+    assert not eng.generate(ids, temperature=0.3, reuse_prefill=True, **dict(kw, max_new_tokens=12)).stats["prefill_reused"]
+    text = [torch.tensor([t for t in r.tolist() if t != -200]) for r in ids]                   # text-only prompts (the prior passes of a sweep)
+    a = eng.generate(text, images=None, max_new_tokens=1, n_top=10, temperature=0.5, reuse_prefill=True)
+    b = eng.generate(text, images=None, max_new_tokens=1, n_top=10, temperature=0.9, reuse_prefill=True)
+    c = eng.generate(text, images=None, max_new_tokens=1, n_top=10, temperature=0.9)
+    assert b.stats["prefill_reused"] and torch.equal(b.top_prob, c.top_prob) and not torch.equal(a.top_prob, b.top_prob)
