@@ -98,7 +98,7 @@ def run_mme(engine: VddLlavaEngine, questions: Sequence[dict], build_inputs: Cal
             max_new_tokens: int = 20, min_new_tokens: Optional[int] = None, noise_step: Optional[int] = None,
             gt: Optional[Dict[tuple, str]] = None, results_root: Optional[str] = None, experiment: str = "exp",
             subsets: Optional[Sequence[str]] = MME_SUBSETS, chunk: Optional[tuple] = None, rank: Optional[int] = None,
-            world: Optional[int] = None, batch_invariant: Optional[bool] = None, **generate_kw) -> dict:
+            world: Optional[int] = None, batch_invariant: Optional[bool] = None, sweep: Optional[Sequence[dict]] = None, **generate_kw) -> dict:
     """questions: the llava_mme.jsonl lines (question_id 'category/image.ext', image, text, category); subsets filters them as the
     reference does; chunk=(n, k) takes the reference's k-th of n contiguous ceil-chunks (get_chunk, run_llava.py:32-40).
     generate_kw: cd_alpha, cd_beta, use_dd, use_dd_unk, temperature, top_p, top_k, seed - the reference's generate kwargs; the Qwen
@@ -108,6 +108,11 @@ def run_mme(engine: VddLlavaEngine, questions: Sequence[dict], build_inputs: Cal
     --chunk-idx processes (run_llava.py:261-262) - every rank calls this with the same list, decodes its chunk of whole images
     (shard.ShardPlan), ONE collective gathers the per-question results, rank 0 writes the answers / result files; every rank returns
     the full result.  batch_invariant: as in pope_driver.run_pope (default: on for cd_greedy / top_k = 1 / do_sample = False decodes).
+    sweep: the reference's scripts run the question file once per sampling setting (51 of them, run_llava.py:281-318).  A list of
+    {"tag", "temperature", "top_p", "top_k"[, "answers_path", "experiment"]} runs them ALL in one pass over the batches: the settings of a batch
+    share its vision-tower pass and its prefills (engine.generate(reuse_prefill=True): only the warpers differ, and they do not enter the
+    prefill), each decodes from that state with its own warpers.  Returns {"runs": {tag: the per-setting result}}; not with the VCD branch
+    (its noise is drawn per call), which decodes every setting from scratch.
     Returns {"answers": [...], "results": {name: dir}, "scores": {name: mme_scores}}."""
     import contextlib
     from . import ops
@@ -124,8 +129,13 @@ def run_mme(engine: VddLlavaEngine, questions: Sequence[dict], build_inputs: Cal
     eos_set = set([eos_token_id] if isinstance(eos_token_id, int) else (eos_token_id or []))
     if generate_kw.get("seed") is not None:
         generate_kw = dict(generate_kw, seed=int(generate_kw["seed"]) + plan.rank)
-    rows = ResultRows(engine.device, max_new_tokens, pad_token_id if pad_token_id is not None else 0, n_sets=3)
-    plain_kw = {k: v for k, v in generate_kw.items() if k in ("temperature", "top_p", "top_k", "seed", "cd_alpha", "cd_beta")}
+    settings = [dict(tag=None)] if sweep is None else [dict(s_) for s_ in sweep]
+    if not settings:
+        raise ValueError("sweep: at least one setting")
+    over = lambda s_: {k: s_[k] for k in ("temperature", "top_p", "top_k") if k in s_}
+    kws = [dict(generate_kw, **over(s_)) for s_ in settings]
+    keep = len(settings) > 1 and noise_step is None            # the settings of a batch decode from ONE prefill
+    all_rows = [ResultRows(engine.device, max_new_tokens, pad_token_id if pad_token_id is not None else 0, n_sets=3) for _ in settings]
     invariant = resolve_batch_invariant(batch_invariant, plan.world, generate_kw)
     with (ops.batch_invariant() if invariant else contextlib.nullcontext()):
         for b0 in range(0, len(mine), batch_questions):
@@ -140,51 +150,64 @@ def run_mme(engine: VddLlavaEngine, questions: Sequence[dict], build_inputs: Cal
                     b["image"] = img_cache.setdefault(line["image"], b)["image"]
                 return b
             mains = [main_inputs(l) for l in lines]
-            kw = dict(generate_kw)
-            if noise_step is not None and "image" in mains[0]:
-                from .vcd_add_noise import add_diffusion_noise
-                kw["images_cd"] = [add_diffusion_noise(img_cache[l["image"]]["image"].to(engine.device), noise_step) for l in lines]   # run_llava.py:187-190
-            main = _generate(engine, mains, max_new_tokens=max_new_tokens, n_top=10, eos_token_id=eos_token_id, pad_token_id=pad_token_id,
-                             min_new_tokens=min_new_tokens, **kw)
+            nones, unks = [build_inputs(l, "none") for l in lines], [build_inputs(l, "unk") for l in lines]
+            outs = [[None, None, None] for _ in settings]
+            # pass by pass, every setting behind the other: the kept prefill lives in the engine's pools, which the next pass type overwrites
+            for j, kw_s in enumerate(kws):
+                kw = dict(kw_s)
+                if noise_step is not None and "image" in mains[0]:
+                    from .vcd_add_noise import add_diffusion_noise
+                    kw["images_cd"] = [add_diffusion_noise(img_cache[l["image"]]["image"].to(engine.device), noise_step) for l in lines]   # run_llava.py:187-190
+                outs[j][0] = _generate(engine, mains, max_new_tokens=max_new_tokens, n_top=10, eos_token_id=eos_token_id, pad_token_id=pad_token_id,
+                                       min_new_tokens=min_new_tokens, reuse_prefill=keep, **kw)
             # content-free priors: plain sampling, only the step-0 distribution is used; min_new_tokens = 1 keeps EOS out of it as in
             # the reference's calibration calls (run_qwen.py:111-131)
-            prior_kw = dict(max_new_tokens=1, n_top=10, **plain_kw)
-            if min_new_tokens:
-                prior_kw.update(min_new_tokens=min_new_tokens, eos_token_id=eos_token_id, pad_token_id=pad_token_id)
-            none = _generate(engine, [build_inputs(l, "none") for l in lines], **prior_kw)
-            unk = _generate(engine, [build_inputs(l, "unk") for l in lines], **prior_kw)
-            rows.add(idx, main.tokens, [(o.top_tok, o.top_prob) for o in (main, none, unk)])
+            for which, inputs in ((1, nones), (2, unks)):
+                for j, kw_s in enumerate(kws):
+                    prior_kw = dict(max_new_tokens=1, n_top=10, **{k: v for k, v in kw_s.items() if k in ("temperature", "top_p", "top_k", "seed", "cd_alpha", "cd_beta")})
+                    if min_new_tokens:
+                        prior_kw.update(min_new_tokens=min_new_tokens, eos_token_id=eos_token_id, pad_token_id=pad_token_id)
+                    outs[j][which] = _generate(engine, inputs, reuse_prefill=keep, **prior_kw)
+            for j in range(len(settings)):
+                all_rows[j].add(idx, outs[j][0].tokens, [(o.top_tok, o.top_prob) for o in outs[j]])
             engine.clear_image_cache()
-    got = rows.gather(plan, len(qs_all))                       # ONE collective; every rank holds every question's results behind it
-    dicts = [[C.label_dict_from_top(t, p_, decode_token) for t, p_ in got["tops"][s_]] for s_ in range(3)]
-    answers = []
-    for i, line in enumerate(qs_all):
-        text = decode(cut_at_eos(got["tokens"][i], eos_set)).strip()
-        if stop_str and text.endswith(stop_str):
-            text = text[:-len(stop_str)]
-        answers.append({"question_id": line["question_id"], "prompt": line["text"], "text": text.strip(), "naive": dicts[0][i],
-                        "none": dicts[1][i], "unk": dicts[2][i], "answer_id": uuid.uuid4().hex[:22], "model_id": model_id, "metadata": {}})
-    if plan.rank != 0:
-        answers_path = results_root = None                     # rank 0 owns the files
-    if answers_path is not None:
-        import json
-        import os
-        os.makedirs(os.path.dirname(os.path.abspath(answers_path)), exist_ok=True)
-        with open(answers_path, "w") as f:
-            for a in answers:
-                f.write(json.dumps(a) + "\n")
-    out = {"answers": answers, "results": {}, "scores": {}, "batch_invariant": invariant}
-    if gt is not None:
-        conv = C.mme_convert(answers, gt)
-        out["converted"] = conv
-        if results_root is not None:
-            out["results"] = C.write_mme_results(conv, results_root, experiment)
-            for name, d in out["results"].items():
-                try:
-                    out["scores"][name] = C.mme_scores(d)
-                except (FileNotFoundError, AssertionError):        # a chunk / subset without all 8 task files or with odd line counts
-                    out["scores"][name] = None
-    return out
+
+    def finish(rows, answers_path, experiment):
+        got = rows.gather(plan, len(qs_all))                   # ONE collective per setting; every rank holds every question's results behind it
+        dicts = [[C.label_dict_from_top(t, p_, decode_token) for t, p_ in got["tops"][s_]] for s_ in range(3)]
+        answers = []
+        for i, line in enumerate(qs_all):
+            text = decode(cut_at_eos(got["tokens"][i], eos_set)).strip()
+            if stop_str and text.endswith(stop_str):
+                text = text[:-len(stop_str)]
+            answers.append({"question_id": line["question_id"], "prompt": line["text"], "text": text.strip(), "naive": dicts[0][i],
+                            "none": dicts[1][i], "unk": dicts[2][i], "answer_id": uuid.uuid4().hex[:22], "model_id": model_id, "metadata": {}})
+        root = results_root
+        if plan.rank != 0:
+            answers_path = root = None                         # rank 0 owns the files
+        if answers_path is not None:
+            import json
+            import os
+            os.makedirs(os.path.dirname(os.path.abspath(answers_path)), exist_ok=True)
+            with open(answers_path, "w") as f:
+                for a in answers:
+                    f.write(json.dumps(a) + "\n")
+        out = {"answers": answers, "results": {}, "scores": {}, "batch_invariant": invariant}
+        if gt is not None:
+            conv = C.mme_convert(answers, gt)
+            out["converted"] = conv
+            if root is not None:
+                out["results"] = C.write_mme_results(conv, root, experiment)
+                for name, d in out["results"].items():
+                    try:
+                        out["scores"][name] = C.mme_scores(d)
+                    except (FileNotFoundError, AssertionError):    # a chunk / subset without all 8 task files or with odd line counts
+                        out["scores"][name] = None
+        return out
+    if sweep is None:
+        return finish(all_rows[0], answers_path, experiment)
+    return {"runs": {s_["tag"]: finish(r_, s_.get("answers_path"), s_.get("experiment", f"{experiment}-{s_['tag']}")) for s_, r_ in zip(settings, all_rows)},
+            "batch_invariant": invariant}
 
 
 def _sweep_settings(args) -> list:
@@ -269,16 +292,20 @@ def main(argv=None):
     if a.gt_root:
         gt = C.mme_load_gt(a.gt_root)
     out_scores = {}
+    extra = dict(seed=a.seed) if a.seed is not None else {}
+    sweep = []
     for tag, temp, top_p, top_k in _sweep_settings(a):
         path = os.path.expanduser(a.answers_file).replace("setting", tag)
-        extra = dict(seed=a.seed) if a.seed is not None else {}
-        res = run_mme(eng, questions, build, decode, answers_path=path, model_id=os.path.basename(a.model_path.rstrip("/")), batch_questions=a.batch,
-                      gt=gt, results_root=os.path.join(os.path.dirname(os.path.abspath(path)), "eval_tool_answers") if gt else None,
-                      experiment=os.path.splitext(os.path.basename(path))[0], chunk=(a.num_chunks, a.chunk_idx) if a.num_chunks > 1 else None,
-                      rank=rank, world=world, temperature=temp, top_p=top_p, top_k=top_k, **gen_kw, **run_kw, **extra)
-        out_scores[tag] = {k: (v and {"Perception": v["Perception"]["total"], "Cognition": v["Cognition"]["total"]}) for k, v in res["scores"].items()}
+        sweep.append(dict(tag=tag, temperature=temp, top_p=top_p, top_k=top_k, answers_path=path, experiment=os.path.splitext(os.path.basename(path))[0]))
+    # ONE pass over the question file for all settings: a batch's vision-tower pass and prefills are shared by its settings (run_mme, `sweep`)
+    res = run_mme(eng, questions, build, decode, model_id=os.path.basename(a.model_path.rstrip("/")), batch_questions=a.batch, gt=gt,
+                  results_root=os.path.join(os.path.dirname(os.path.abspath(sweep[0]["answers_path"])), "eval_tool_answers") if gt else None,
+                  chunk=(a.num_chunks, a.chunk_idx) if a.num_chunks > 1 else None, rank=rank, world=world, sweep=sweep, **gen_kw, **run_kw, **extra)
+    for s_ in sweep:
+        r_ = res["runs"][s_["tag"]]
+        out_scores[s_["tag"]] = {k: (v and {"Perception": v["Perception"]["total"], "Cognition": v["Cognition"]["total"]}) for k, v in r_["scores"].items()}
         if rank == 0:
-            print(json.dumps({"run": tag, "answers_file": path, "n_answers": len(res["answers"]), "scores": out_scores[tag]}), flush=True)
+            print(json.dumps({"run": s_["tag"], "answers_file": s_["answers_path"], "n_answers": len(r_["answers"]), "scores": out_scores[s_["tag"]]}), flush=True)
     if world > 1:
         import torch.distributed as dist
         dist.barrier()

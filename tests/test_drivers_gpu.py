@@ -303,3 +303,43 @@ def test_run_pope_sharded_over_two_ranks_equals_one_rank(tmp_path):
         assert r["scores"] == r1["scores"]
     lines = [json.loads(l) for l in open(two + ".jsonl")]
     assert [l["question_id"] for l in lines] == list(range(1000, 1021)) and lines == [json.loads(l) for l in open(one + ".jsonl")]
+
+
+def test_run_mme_sweep_shares_one_prefill_per_batch_between_its_settings(eng, tmp_path):
+    """run_llava.py:281-318 walks the question file once per sampling setting; run_mme(sweep=[...]) walks it once: the settings of a batch decode
+    from one vision-tower pass and one prefill per pass type (engine.generate(reuse_prefill=True)).  Each setting's answers, label dicts and
+    converted files equal those of a run of its own."""
+    from llava_align_amd.mme_driver import llava_mme_inputs, run_mme
+    qs, gt = mme_questions()
+    images = {}
+
+    def load_image(name):
+        if name not in images:
+            images[name] = torch.randn(3, 56, 56, generator=torch.Generator().manual_seed(len(images)))
+        return images[name]
+    build = llava_mme_inputs(toy_encode, load_image, unk_token_id=0)
+    kw = dict(batch_questions=12, max_new_tokens=3, gt=gt, use_dd_unk=True, cd_alpha=1.0, cd_beta=0.1, cd_greedy=True)
+    settings = [dict(tag="default", temperature=1.0, top_p=None, top_k=None), dict(tag="temp_0.3", temperature=0.3, top_p=None, top_k=None),
+                dict(tag="top_p_0.6", temperature=1.0, top_p=0.6, top_k=None)]
+    for s_ in settings:
+        s_["answers_path"] = str(tmp_path / "sweep" / f"ans-{s_['tag']}.jsonl")
+    reused = []
+    real = eng.generate
+    eng.generate = lambda *a, **k: (lambda o: reused.append(bool(o.stats.get("prefill_reused"))) or o)(real(*a, **k))
+    try:
+        res = run_mme(eng, qs, build, decode, results_root=str(tmp_path / "res"), experiment="sw", sweep=settings, **kw)
+    finally:
+        eng.generate = real
+    n_batches = 3                                              # 32 questions, 12 per batch
+    assert len(reused) == n_batches * 3 * 3 and sum(reused) == n_batches * 3 * 2          # per batch and pass type: one prefill, two decodes from it
+    assert set(res["runs"]) == {"default", "temp_0.3", "top_p_0.6"}
+    for s_ in settings:
+        alone = run_mme(eng, qs, build, decode, temperature=s_["temperature"], top_p=s_["top_p"], top_k=s_["top_k"], **kw)
+        got = res["runs"][s_["tag"]]
+        strip = lambda a: {k: v for k, v in a.items() if k != "answer_id"}
+        assert [strip(a) for a in got["answers"]] == [strip(a) for a in alone["answers"]], s_["tag"]
+        assert got["converted"] == alone["converted"]
+        lines = [json.loads(l) for l in open(s_["answers_path"])]
+        assert [strip(l) for l in lines] == [strip(a) for a in got["answers"]]
+        assert sorted(os.listdir(got["results"]["naive"])) == sorted(c + ".txt" for c in CATS)
+    assert res["runs"]["default"]["answers"] != res["runs"]["temp_0.3"]["answers"]            # (the label dicts depend on the temperature)
