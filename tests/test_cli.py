@@ -114,6 +114,15 @@ def test_mme_driver_from_a_checkpoint_directory(tmp_path):
     recs = [json.loads(l) for l in open(rep["answers_file"])]
     assert len(recs) == 8 and set(recs[0]) >= {"question_id", "prompt", "text", "naive", "none", "unk", "answer_id", "model_id"}
     assert os.path.isdir(os.path.join(os.path.dirname(out), "eval_tool_answers"))                      # the converter wrote the scorer's input tree
+    # without --no-sweep: the reference scripts' 51 settings (run_llava.py:281-318) in ONE pass over the question file, one answers file per setting
+    out2 = str(tmp_path / "sweep" / "tiny-setting.jsonl")
+    p2 = subprocess.run([sys.executable, "-m", "llava_align_amd.mme_driver", "--arch", "llava", "--model-path", info["ckpt"], "--question-file", str(qfile),
+                         "--image-folder", str(gt_root), "--answers-file", out2, "--use_dd_unk", "--max_new_tokens", "3", "--seed", "1"],
+                        capture_output=True, text=True, env=_env(), timeout=900, cwd=ROOT)
+    assert p2.returncode == 0, p2.stderr[-3000:]
+    runs = [json.loads(l) for l in p2.stdout.strip().splitlines() if l.startswith("{")]
+    assert len(runs) == 51 and runs[0]["run"] == "default" and runs[1]["run"] == "temp_0.05" and runs[-1]["run"] == "top_k_500"
+    assert all(r["n_answers"] == 8 and os.path.exists(r["answers_file"]) for r in runs) and len({r["answers_file"] for r in runs}) == 51
 
 
 @pytest.mark.gpu
