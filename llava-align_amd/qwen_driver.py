@@ -53,7 +53,7 @@ def run_qwen_pope(engine: VddLlavaEngine, questions: Sequence[dict], embed_promp
                   answers_path: Optional[str] = None, model_id: str = "qwen-vl", batch_questions: int = 128, eos_token_id=151643,
                   pad_token_id: Optional[int] = 151643, max_new_tokens: int = 20, min_new_tokens: Optional[int] = 1, use_cd: bool = False,
                   noise_step: int = 500, priors: Sequence[str] = PRIORS, prompt_format: str = POPE_PROMPT, rank: Optional[int] = None,
-                  world: Optional[int] = None, batch_invariant: Optional[bool] = None, **generate_kw) -> dict:
+                  world: Optional[int] = None, batch_invariant: Optional[bool] = None, sweep: Optional[Sequence[dict]] = None, **generate_kw) -> dict:
     """questions: POPE json lines (question_id, image, text[, label]).  load_image(name) -> the [3, S, S] tensor the model's own
     `visual.image_transform` makes of the file (qwen_calibrate.py:100-101).  generate_kw: temperature, top_p, top_k, use_dd, use_dd_unk,
     cd_alpha, cd_beta, seed, cd_greedy ... - the reference's generate kwargs (:113-136; defaults there: temperature 0.2, cd_alpha 1,
@@ -62,7 +62,11 @@ def run_qwen_pope(engine: VddLlavaEngine, questions: Sequence[dict], embed_promp
     rank / world (default: the initialised torch.distributed group): every rank decodes its chunk of whole images (shard.ShardPlan), ONE
     collective gathers the results, rank 0 writes the file; every rank returns the full result.  batch_invariant: as in
     pope_driver.run_pope.  The JSONL carries the reference's fields (:155-166): question_id, prompt, text, naive, noise, none, zero, unk,
-    model_id, image, metadata.  Returns {"answers": [...], "scores": {...}}."""
+    model_id, image, metadata.  Returns {"answers": [...], "scores": {...}}.
+    sweep (answers-only runs, priors = (): qwenvl_sampling.py:147-185 walks the question file once per sampling setting): a list of
+    {"tag", "temperature", "top_p", "top_k"[, "answers_path"]} decodes every setting from ONE prefill per batch (engine.generate(reuse_prefill=True);
+    not with --use_cd, whose noise is drawn per call, and not for open-ended lists, which go through generate_list per setting).
+    Returns {"runs": {tag: result}}."""
     import contextlib
     from . import ops
     from .pope_driver import ResultRows, cut_at_eos
@@ -83,11 +87,18 @@ def run_qwen_pope(engine: VddLlavaEngine, questions: Sequence[dict], embed_promp
     prior_kw = dict(max_new_tokens=1, n_top=10, min_new_tokens=min_new_tokens, eos_token_id=eos_token_id, pad_token_id=pad_token_id, **plain_kw)
     invariant = resolve_batch_invariant(batch_invariant, plan.world, generate_kw)
     prompts = {}
+    if sweep is not None and priors:
+        raise ValueError("sweep: answers-only runs (priors=())")
+    settings = [dict(tag=None)] if sweep is None else [dict(s_) for s_ in sweep]
+    over = lambda s_: {k: s_[k] for k in ("temperature", "top_p", "top_k") if k in s_}
+    extra_rows = [ResultRows(engine.device, max_new_tokens, pad_token_id if pad_token_id is not None else 0, n_sets=1) for _ in settings[1:]]
     # answers only, no EOS floor (qwenvl_sampling.py:89-103: open-ended answers, max_new_tokens 1024): the whole shard as ONE list, batch_questions
     # in flight, waiting questions admitted into the slots of finished ones (engine.generate_list)
     list_kw = ("temperature", "top_p", "top_k", "use_dd", "use_dd_unk", "cd_alpha", "cd_beta", "seed", "cd_greedy", "sync_every", "admit_min")
     as_list = (not priors and not min_new_tokens and eos_token_id is not None and pad_token_id is not None and bool(mine)
                and engine.cfg.lm.head_dim == 128 and all(k in list_kw for k in generate_kw))
+    if sweep is not None and as_list:
+        raise ValueError("sweep: open-ended lists (no EOS floor) decode one setting per call")
     with (ops.batch_invariant() if invariant else contextlib.nullcontext()):
         if as_list:
             cache: Dict[str, torch.Tensor] = {}
@@ -117,8 +128,13 @@ def run_qwen_pope(engine: VddLlavaEngine, questions: Sequence[dict], embed_promp
             for i, t in zip(idx, texts):
                 prompts[i] = t
 
+            built = {}
+
             def gen(texts_, images_, keys_, **kw):
-                emb, pre = _embeds(embed_prompt, texts_, images_, keys_)
+                k_ = (id(texts_), id(images_))                  # the settings of a sweep pass the same lists: the same embedding tensors
+                if k_ not in built:
+                    built[k_] = (texts_, images_, _embeds(embed_prompt, texts_, images_, keys_))
+                emb, pre = built[k_][2]
                 if pre is not None:
                     kw["embeds_prefix"] = pre
                 return engine.generate(None, inputs_embeds=emb, **kw)
@@ -127,8 +143,12 @@ def run_qwen_pope(engine: VddLlavaEngine, questions: Sequence[dict], embed_promp
                 cd, _ = _embeds(embed_prompt, texts, [add_diffusion_noise(im, noise_step) for im in imgs], [None] * len(qs))
                 kw["images_cd"] = cd
             main = gen(texts, imgs, [("clean", q["image"]) for q in qs], max_new_tokens=max_new_tokens, min_new_tokens=min_new_tokens, n_top=10,
-                       eos_token_id=eos_token_id, pad_token_id=pad_token_id, **kw)
+                       eos_token_id=eos_token_id, pad_token_id=pad_token_id, reuse_prefill=len(settings) > 1 and not use_cd, **dict(kw, **over(settings[0])))
             tops = [(main.top_tok, main.top_prob)]
+            for s_, r_ in zip(settings[1:], extra_rows):       # the other settings of a sweep: the same prompts, decoded again from the kept prefill
+                o_ = gen(texts, imgs, [("clean", q["image"]) for q in qs], max_new_tokens=max_new_tokens, min_new_tokens=min_new_tokens, n_top=10,
+                         eos_token_id=eos_token_id, pad_token_id=pad_token_id, reuse_prefill=not use_cd, **dict(kw, **over(s_)))
+                r_.add(idx, o_.tokens, [(o_.top_tok, o_.top_prob)])
             def text_only(fmt):
                 """POPE repeats its question texts over the images, and a text-only prompt's step-0 label dict depends on the text alone: every
                 distinct prompt runs once"""
@@ -152,37 +172,41 @@ def run_qwen_pope(engine: VddLlavaEngine, questions: Sequence[dict], embed_promp
                 tops.append((o.top_tok, o.top_prob))
             rows.add(idx, main.tokens, tops)
             engine.clear_image_cache()
-    got = rows.gather(plan, len(questions))                    # ONE collective; every rank holds every question's results behind it
-    dicts = [[C.label_dict_from_top(t, p_, decode_token) for t, p_ in got["tops"][s_]] for s_ in range(1 + len(priors))]
-    answers = []
-    for i, q in enumerate(questions):
-        a = {"question_id": q["question_id"], "prompt": prompts.get(i, prompt_format.format(image_path(q["image"]), q["text"])),
-             "text": decode(cut_at_eos(got["tokens"][i], eos_set)).strip()}
-        if priors:
-            a["naive"] = dicts[0][i]
-            for name in ("noise", "none", "zero", "unk"):      # the file's key order (:160-164)
-                if name in priors:
-                    a[name] = dicts[1 + priors.index(name)][i]
-        a.update(model_id=model_id, image=q["image"], metadata={})
-        answers.append(a)
-    if answers_path is not None and plan.rank == 0:
-        import os
-        os.makedirs(os.path.dirname(os.path.abspath(answers_path)), exist_ok=True)
-        with open(answers_path, "w") as f:
-            for a in answers:
-                f.write(json.dumps(a) + "\n")
-    scores = {}
-    if all("label" in q for q in questions):
-        gt = [{"question_id": q["question_id"], "label": q["label"]} for q in questions]
-        for name in ("string_match",) + (CALIBRATE_NAMES if priors else ()):
-            if name != "string_match" and not set(C.calibrate_sources(name)) <= set(("naive",) + priors):
-                continue
-            try:
-                scores[name] = C.pope_scores(gt, answers) if name == "string_match" else C.pope_scores_calibrated(gt, answers, name)
-            except ZeroDivisionError:
-                scores[name] = None
-    return {"answers": answers, "scores": scores, "rank": plan.rank, "world": plan.world, "batch_invariant": invariant,
-            "stats": list_stats if as_list else {}}
+    def finish(rows, answers_path):
+        got = rows.gather(plan, len(questions))                    # ONE collective; every rank holds every question's results behind it
+        dicts = [[C.label_dict_from_top(t, p_, decode_token) for t, p_ in got["tops"][s_]] for s_ in range(1 + len(priors))]
+        answers = []
+        for i, q in enumerate(questions):
+            a = {"question_id": q["question_id"], "prompt": prompts.get(i, prompt_format.format(image_path(q["image"]), q["text"])),
+                 "text": decode(cut_at_eos(got["tokens"][i], eos_set)).strip()}
+            if priors:
+                a["naive"] = dicts[0][i]
+                for name in ("noise", "none", "zero", "unk"):      # the file's key order (:160-164)
+                    if name in priors:
+                        a[name] = dicts[1 + priors.index(name)][i]
+            a.update(model_id=model_id, image=q["image"], metadata={})
+            answers.append(a)
+        if answers_path is not None and plan.rank == 0:
+            import os
+            os.makedirs(os.path.dirname(os.path.abspath(answers_path)), exist_ok=True)
+            with open(answers_path, "w") as f:
+                for a in answers:
+                    f.write(json.dumps(a) + "\n")
+        scores = {}
+        if all("label" in q for q in questions):
+            gt = [{"question_id": q["question_id"], "label": q["label"]} for q in questions]
+            for name in ("string_match",) + (CALIBRATE_NAMES if priors else ()):
+                if name != "string_match" and not set(C.calibrate_sources(name)) <= set(("naive",) + priors):
+                    continue
+                try:
+                    scores[name] = C.pope_scores(gt, answers) if name == "string_match" else C.pope_scores_calibrated(gt, answers, name)
+                except ZeroDivisionError:
+                    scores[name] = None
+        return {"answers": answers, "scores": scores, "rank": plan.rank, "world": plan.world, "batch_invariant": invariant,
+                "stats": list_stats if as_list else {}}
+    if sweep is None:
+        return finish(rows, answers_path)
+    return {"runs": {s_["tag"]: finish(r_, s_.get("answers_path")) for s_, r_ in zip(settings, [rows] + extra_rows)}, "batch_invariant": invariant}
 
 
 def main(argv=None):
@@ -239,6 +263,20 @@ def main(argv=None):
             runs += [(f"top_p_{p_}", 1.0, float(p_), None) for p_ in np.round(np.arange(0, 1.05, 0.05), 2)]
             runs += [(f"top_k_{k}", 1.0, None, k) for k in (1, 2, 5, 10, 20, 50, 100, 200, 500)]
     pope = "POPE" in a.question_file
+    common = dict(image_path=lambda f: os.path.join(a.image_folder, f), model_id="qwen-vl" if "Chat" not in a.model_path else "qwen-vl-chat",
+                  batch_questions=a.batch, eos_token_id=tok.eod_id, pad_token_id=tok.eod_id, use_cd=a.use_cd, noise_step=a.noise_step, rank=rank, world=world,
+                  use_dd=a.use_dd, use_dd_unk=a.use_dd_unk, cd_alpha=a.cd_alpha, cd_beta=a.cd_beta, seed=a.seed)
+    if a.sampling and pope and len(runs) > 1:
+        # the POPE sampling sweep (answers of <= 20 tokens): every setting from ONE pass over the question file, a batch's prefill shared by its settings
+        sweep = [dict(tag=tag, temperature=temp, top_p=top_p, top_k=top_k, answers_path=os.path.expanduser(a.answers_file).replace("setting", tag))
+                 for tag, temp, top_p, top_k in runs]
+        res = run_qwen_pope(eng, questions, embed_prompt, lambda ids: tok.decode(ids, skip_special_tokens=True), load_image, priors=(), prompt_format=SAMPLING_PROMPT,
+                            max_new_tokens=20, min_new_tokens=1, sweep=sweep, **common)
+        if rank == 0:
+            for s_ in sweep:
+                print(json.dumps({"run": s_["tag"], "answers_file": s_["answers_path"], "n_answers": len(res["runs"][s_["tag"]]["answers"]),
+                                  "scores": res["runs"][s_["tag"]]["scores"]}), flush=True)
+        runs = []
     for tag, temp, top_p, top_k in runs:
         path = os.path.expanduser(a.answers_file)
         path = path.replace("setting", tag) if tag else path

@@ -199,6 +199,26 @@ def test_run_qwen_pope_five_passes_against_direct_calls(tmp_path):
     assert len(visual_calls) - n0 == 1 + 3 and s["scores"].keys() == {"string_match"} and not s["batch_invariant"]
     first = json.loads(open(tmp_path / "q" / "s.jsonl").readline())
     assert list(first) == ["question_id", "prompt", "text", "model_id", "image", "metadata"] and first["prompt"].startswith("Question: <img>im0.jpg</img> Is")
+    # a sampling sweep over the POPE file (qwenvl_sampling.py:147-185): three settings decode every batch from ONE prefill; each equals its own run
+    sw = [dict(tag="default", temperature=1.0, top_p=None, top_k=None, answers_path=str(tmp_path / "q" / "sw-default.jsonl")),
+          dict(tag="temp_0.3", temperature=0.3, top_p=None, top_k=None), dict(tag="top_k_2", temperature=1.0, top_p=None, top_k=2)]
+    skw = {k: v for k, v in kw.items() if k != "temperature"}
+    reused = []
+    real = eng.generate
+    eng.generate = lambda *a_, **k_: (lambda o_: reused.append(bool(o_.stats.get("prefill_reused"))) or o_)(real(*a_, **k_))
+    try:
+        swept = run_qwen_pope(eng, qs, embed, decode, lambda n: images[n], priors=(), prompt_format=SAMPLING_PROMPT, batch_questions=6, use_dd_unk=True,
+                              cd_greedy=True, sweep=sw, **skw)
+    finally:
+        eng.generate = real
+    assert reused == [False, True, True] * 2                   # two batches: one prefill, two decodes from it
+    for s_ in sw:
+        alone = run_qwen_pope(eng, qs, embed, decode, lambda n: images[n], priors=(), prompt_format=SAMPLING_PROMPT, batch_questions=6, use_dd_unk=True,
+                              cd_greedy=True, temperature=s_["temperature"], top_k=s_["top_k"], **skw)
+        assert [a_["text"] for a_ in swept["runs"][s_["tag"]]["answers"]] == [a_["text"] for a_ in alone["answers"]], s_["tag"]
+    assert len(open(sw[0]["answers_path"]).readlines()) == 9
+    with pytest.raises(ValueError, match="answers-only"):
+        run_qwen_pope(eng, qs, embed, decode, lambda n: images[n], sweep=sw, **skw)
     # open-ended shape (no EOS floor): the shard goes through generate_list, 4 in flight - same answers as one generate() call over all nine
     eos = sorted(set(np.random.default_rng(2).integers(3, V - 40, size=60).tolist()))
     lkw = dict(kw, eos_token_id=eos, pad_token_id=eod, max_new_tokens=24, min_new_tokens=None, cd_greedy=True, use_dd_unk=True)
